@@ -1,0 +1,148 @@
+"""Deterministic synthetic inputs for the volume-rendering hot path.
+
+Build-owned generator: no torch RNG, no files -- both the
+container and the GPU box regenerate bit-identical weights from a seed.
+
+* weights / biases: U(-1/sqrt(fan_in), 1/sqrt(fan_in)) -- the bounds of
+  ``nn.Linear``'s default init (the reference never overrides it:
+  /root/reference/models/nerf.py:30-34, models/nof.py:43-47).
+* "dense" regime: every trunk / final / extra / rgb weight is multiplied by
+  sqrt(6) (He-uniform: activations keep O(1) spatial variation through the eight
+  ReLU layers instead of collapsing to a bias-driven constant), ``sigma.weight``
+  by 8 and ``sigma.bias = 0`` so that sigma
+  crosses zero along every ray: alpha spans (0, 1), rays end up partially
+  opaque and the transmittance scan is actually exercised. (SURVEY.md §8d's
+  first proposal -- sigma.weight x50, bias 0.5 on default-init trunks -- gives
+  all-zero or all-one alpha depending on the seed, so it was refined here.)
+* rays: o ~ N(0, 0.1^2)^3, d = unit N(0,1)^3, near = 2, far = 6,
+  img_ind = -0.25, chained_img_ind = 0.5, background ~ U(0,1)^3.
+
+The stream is splitmix64 evaluated with numpy uint64 arithmetic, so it is
+exact integer math; uniforms are 24-bit dyadic rationals (exact in fp32).
+"""
+from __future__ import annotations
+
+import math
+from collections import OrderedDict
+
+import numpy as np
+
+_MASK = np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def _splitmix64(seed: int, n: int) -> np.ndarray:
+    """n successive outputs of splitmix64 started at ``seed`` (uint64 array)."""
+    with np.errstate(over="ignore"):
+        idx = np.arange(1, n + 1, dtype=np.uint64)
+        z = (np.uint64(seed & 0xFFFFFFFFFFFFFFFF) + idx * np.uint64(0x9E3779B97F4A7C15)) & _MASK
+        z = ((z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)) & _MASK
+        z = ((z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)) & _MASK
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def uniform01(seed: int, n: int) -> np.ndarray:
+    """float64 uniforms in [0, 1) with 24 random bits (exact in float32)."""
+    return (_splitmix64(seed, n) >> np.uint64(40)).astype(np.float64) * (1.0 / (1 << 24))
+
+
+def normal(seed: int, n: int) -> np.ndarray:
+    """float64 standard normals by Box-Muller over two uniform streams."""
+    m = (n + 1) // 2
+    u1 = (uniform01(seed, m) + 2.0 ** -25)  # keep log() finite
+    u2 = uniform01(seed ^ 0x5DEECE66D, m)
+    r = np.sqrt(-2.0 * np.log(u1))
+    out = np.empty(2 * m, dtype=np.float64)
+    out[0::2] = r * np.cos(2.0 * math.pi * u2)
+    out[1::2] = r * np.sin(2.0 * math.pi * u2)
+    return out[:n]
+
+
+def _stream_seed(seed: int, name: str) -> int:
+    h = 1469598103934665603
+    for ch in name.encode():
+        h = ((h ^ ch) * 1099511628211) & 0xFFFFFFFFFFFFFFFF
+    return (h ^ (seed * 0x9E3779B97F4A7C15)) & 0xFFFFFFFFFFFFFFFF
+
+
+def linear_init(seed: int, name: str, out_f: int, in_f: int):
+    """(weight (out,in), bias (out,)) float32, U(+-1/sqrt(in_f))."""
+    bound = 1.0 / math.sqrt(in_f)
+    w = (2.0 * uniform01(_stream_seed(seed, name + ".weight"), out_f * in_f) - 1.0) * bound
+    b = (2.0 * uniform01(_stream_seed(seed, name + ".bias"), out_f) - 1.0) * bound
+    return w.reshape(out_f, in_f).astype(np.float32), b.astype(np.float32)
+
+
+def nerf_state(seed=0, D=8, W=256, in_channels_xyz=63, skips=(4,), extra_feat_type="dir",
+               extra_feat_dim=27, regime="default", tag="nerf"):
+    """state_dict-shaped OrderedDict of numpy arrays with the reference's keys
+    (/root/reference/models/nerf.py:28-59; keys listed in SURVEY.md §8b)."""
+    sd = OrderedDict()
+    for i in range(D):
+        if i == 0:
+            fan = in_channels_xyz
+        elif i in skips:
+            fan = W + in_channels_xyz
+        else:
+            fan = W
+        w, b = linear_init(seed, f"{tag}.xyz_encoding_{i+1}", W, fan)
+        sd[f"xyz_encoding_{i+1}.0.weight"], sd[f"xyz_encoding_{i+1}.0.bias"] = w, b
+    w, b = linear_init(seed, f"{tag}.xyz_encoding_final", W, W)
+    sd["xyz_encoding_final.weight"], sd["xyz_encoding_final.bias"] = w, b
+    ext = extra_feat_dim if extra_feat_type != "none" else 0
+    w, b = linear_init(seed, f"{tag}.extra_encoding", W // 2, W + ext)
+    sd["extra_encoding.0.weight"], sd["extra_encoding.0.bias"] = w, b
+    w, b = linear_init(seed, f"{tag}.sigma", 1, W)
+    if regime == "dense":
+        gain = np.float32(math.sqrt(6.0))
+        for k in list(sd):
+            if k.endswith(".weight"):
+                sd[k] = (sd[k] * gain).astype(np.float32)
+        w = w * np.float32(8.0)
+        b = np.zeros_like(b)
+    elif regime != "default":
+        raise ValueError(regime)
+    sd["sigma.weight"], sd["sigma.bias"] = w, b
+    w, b = linear_init(seed, f"{tag}.rgb", 3, W // 2)
+    if regime == "dense":
+        w = (w * np.float32(math.sqrt(6.0))).astype(np.float32)
+    sd["rgb.0.weight"], sd["rgb.0.bias"] = w, b
+    return sd
+
+
+def nof_state(seed=0, D=4, W=128, in_channels_xyz=33, skips=(2,), extra_feat_dim=33,
+              use_quat=True, tag="nof", head_scale=1.0):
+    """Keys of /root/reference/models/nof.py:41-53. ``head_scale`` shrinks the
+    final layer so that a random-init flow stays near the identity (keeps the
+    chained points inside the sampled volume)."""
+    sd = OrderedDict()
+    cin = in_channels_xyz + extra_feat_dim
+    for i in range(D):
+        if i == 0:
+            fan = cin
+        elif i in skips:
+            fan = W + cin
+        else:
+            fan = W
+        w, b = linear_init(seed, f"{tag}.nof_encoding_{i+1}", W, fan)
+        sd[f"nof_encoding_{i+1}.0.weight"], sd[f"nof_encoding_{i+1}.0.bias"] = w, b
+    w, b = linear_init(seed, f"{tag}.nof_encoding_final", 9 if use_quat else 3, W)
+    sd["nof_encoding_final.weight"] = (w * np.float32(head_scale)).astype(np.float32)
+    sd["nof_encoding_final.bias"] = (b * np.float32(head_scale)).astype(np.float32)
+    return sd
+
+
+def rays(seed=0, n_rays=4096, chained=False, near=2.0, far=6.0, img_ind=-0.25,
+         chained_img_ind=0.5):
+    """(rays (N, 9|10), background (N,3)) float32 numpy; layout of
+    /root/reference/models/rendering.py:238-242."""
+    o = normal(_stream_seed(seed, "rays_o"), n_rays * 3).reshape(n_rays, 3) * 0.1
+    d = normal(_stream_seed(seed, "rays_d"), n_rays * 3).reshape(n_rays, 3)
+    d = d / np.linalg.norm(d, axis=1, keepdims=True)
+    cols = [o, d, np.full((n_rays, 1), near), np.full((n_rays, 1), far),
+            np.full((n_rays, 1), img_ind)]
+    if chained:
+        cols.append(np.full((n_rays, 1), chained_img_ind))
+    r = np.concatenate(cols, axis=1).astype(np.float32)
+    bg = uniform01(_stream_seed(seed, "background"), n_rays * 3).reshape(n_rays, 3).astype(np.float32)
+    return r, bg

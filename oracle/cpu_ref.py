@@ -1,0 +1,403 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU restatement of MoCo-Flow's volume-rendering path.
+
+A from-scratch PyTorch-CPU restatement (same op sequence, own code) of the rows
+of SURVEY.md §8(a):
+
+  E  Embedding        /root/reference/models/embedding.py:4-47
+  N  NeRF             /root/reference/models/nerf.py:5-102
+  F  NoF              /root/reference/models/nof.py:6-85   (quaternion head through
+                      oracle/kornia_restated.py -- PARITY UNPINNED for use_quat=True,
+                      see that file's header)
+  F' nof_inference    /root/reference/models/rendering.py:49-83
+  C  nerf_inference   /root/reference/models/rendering.py:86-192
+  S  sample_pdf       /root/reference/models/rendering.py:5-46
+  R  render_rays      /root/reference/models/rendering.py:195-375
+  +  trainer glue     /root/reference/trainer/trainer_moco_flow.py:146-187
+
+Pinning: tests/golden/*.npz were produced by importing the reference itself in
+the build container (tests/golden/gen_golden.py); tests/test_oracle_golden.py
+checks this file against every one of them (<= 1e-6 relative).
+
+It is the *checker* for the HIP path and the ``cpu_baseline`` ("port") leg of
+bench.py. It is never imported by ``moco_flow_amd``.
+
+The networks are plain containers of tensors (not nn.Module) keyed exactly like
+the reference's ``state_dict`` so that the same weights load into the oracle,
+the reference and the product.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from .kornia_restated import quaternion_log_to_exp, quaternion_to_rotation_matrix
+
+
+def _as_tensor_dict(state) -> Dict[str, torch.Tensor]:
+    out = {}
+    for k, v in state.items():
+        out[k] = v.detach().to(torch.float32).cpu() if isinstance(v, torch.Tensor) \
+            else torch.from_numpy(v).to(torch.float32)
+    return out
+
+
+# --------------------------------------------------------------------------- E
+class Embedding:
+    """embedding.py:4-47. ``out = [x, w0*sin(f0 x), w0*cos(f0 x), w1*sin(f1 x), ...]``."""
+
+    def __init__(self, in_channels: int, N_freqs: int, logscale: bool = True):
+        self.in_channels = in_channels
+        self.N_freqs = N_freqs
+        self.out_channels = in_channels * (2 * N_freqs + 1)
+        self.weights = [1] * N_freqs
+        if logscale:
+            self.freq_bands = 2 ** torch.linspace(0, N_freqs - 1, N_freqs)
+        else:
+            self.freq_bands = torch.linspace(1, 2 ** (N_freqs - 1), N_freqs)
+
+    def set_weights(self, weights):
+        if isinstance(weights, int):
+            self.weights = [weights] * self.N_freqs
+        else:
+            assert len(weights) == self.N_freqs
+            self.weights = weights
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        pieces = [x]
+        for w, f in zip(self.weights, self.freq_bands):
+            arg = f * x
+            pieces.append(w * torch.sin(arg))
+            pieces.append(w * torch.cos(arg))
+        return torch.cat(pieces, -1)
+
+
+# --------------------------------------------------------------------------- N
+class NeRF:
+    """nerf.py:5-102 as a tensor container."""
+
+    def __init__(self, D=8, W=256, in_channels_xyz=33, skips=(4,), extra_feat_type="none",
+                 extra_feat_dim=0, state=None):
+        assert extra_feat_type in ["none", "ind", "dir", "latent_code"], \
+            f"extra_feat_type {extra_feat_type} for NeRF model not supported!!!"
+        self.D, self.W = D, W
+        self.in_channels_xyz = in_channels_xyz
+        self.skips = list(skips)
+        self.extra_feat_type = extra_feat_type
+        self.extra_feat_dim = extra_feat_dim
+        self.p: Dict[str, torch.Tensor] = {}
+        if state is not None:
+            self.load_state_dict(state)
+
+    def load_state_dict(self, state):
+        self.p = _as_tensor_dict(state)
+
+    def state_dict(self):
+        return dict(self.p)
+
+    def __call__(self, inputs, sigma_only=False, img_ind=None):
+        p = self.p
+        if not sigma_only:
+            input_xyz, extra = torch.split(inputs, [self.in_channels_xyz, self.extra_feat_dim], dim=-1)
+        else:
+            input_xyz = inputs
+        h = input_xyz
+        for i in range(self.D):
+            if i in self.skips:
+                h = torch.cat([input_xyz, h], -1)
+            h = F.relu(F.linear(h, p[f"xyz_encoding_{i+1}.0.weight"], p[f"xyz_encoding_{i+1}.0.bias"]))
+        sigma = F.linear(h, p["sigma.weight"], p["sigma.bias"])
+        if sigma_only:
+            return sigma
+        feat = F.linear(h, p["xyz_encoding_final.weight"], p["xyz_encoding_final.bias"])
+        if self.extra_feat_type == "latent_code":
+            raise NotImplementedError("NeRF model does not support latent code yet!!!")
+        e = F.relu(F.linear(torch.cat([feat, extra], -1),
+                            p["extra_encoding.0.weight"], p["extra_encoding.0.bias"]))
+        rgb = torch.sigmoid(F.linear(e, p["rgb.0.weight"], p["rgb.0.bias"]))
+        return torch.cat([rgb, sigma], -1)
+
+
+# --------------------------------------------------------------------------- F
+class NoF:
+    """nof.py:6-85 as a tensor container."""
+
+    def __init__(self, D=8, W=256, in_channels_xyz=33, skips=(4,), extra_feat_type="ind",
+                 extra_feat_dim=0, use_quat=False, state=None):
+        assert extra_feat_type in ["ind", "latent_code"], \
+            f"extra_feat_type {extra_feat_type} for NoF model not supported!!!"
+        self.D, self.W = D, W
+        self.in_channels_xyz = in_channels_xyz
+        self.skips = list(skips)
+        self.extra_feat_type = extra_feat_type
+        self.extra_feat_dim = extra_feat_dim
+        self.use_quat = use_quat
+        self.p: Dict[str, torch.Tensor] = {}
+        if state is not None:
+            self.load_state_dict(state)
+
+    def load_state_dict(self, state):
+        self.p = _as_tensor_dict(state)
+
+    def state_dict(self):
+        return dict(self.p)
+
+    def __call__(self, inputs, xyz, img_ind=None):
+        if self.extra_feat_type == "latent_code":
+            raise NotImplementedError("NoF model does not support latent code yet!!!")
+        p = self.p
+        u = inputs
+        for i in range(self.D):
+            if i in self.skips:
+                u = torch.cat([inputs, u], -1)
+            u = F.relu(F.linear(u, p[f"nof_encoding_{i+1}.0.weight"], p[f"nof_encoding_{i+1}.0.bias"]))
+        head = F.linear(u, p["nof_encoding_final.weight"], p["nof_encoding_final.bias"])
+        if self.use_quat:
+            v, s, t = head[:, :3], head[:, 3:6], head[:, 6:9]
+            r = quaternion_to_rotation_matrix(quaternion_log_to_exp(v))
+            return torch.bmm((xyz - s).unsqueeze(1), r).squeeze(1) + s + t
+        return head + xyz
+
+
+# --------------------------------------------------------------------------- S
+def sample_pdf_full(bins, weights, N_importance, det=False, eps=1e-5, u=None):
+    """rendering.py:5-46, returning every intermediate needed for index parity.
+    ``u`` may be supplied (N, N_importance) to make the stochastic mode testable."""
+    N_rays, n_w = weights.shape
+    weights = weights + eps
+    pdf = weights / torch.sum(weights, -1, keepdim=True)
+    cdf = torch.cumsum(pdf, -1)
+    cdf = torch.cat([torch.zeros_like(cdf[:, :1]), cdf], -1)
+    if u is None:
+        if det:
+            u = torch.linspace(0, 1, N_importance, device=bins.device).expand(N_rays, N_importance)
+        else:
+            u = torch.rand(N_rays, N_importance, device=bins.device)
+    u = u.contiguous()
+    inds = torch.searchsorted(cdf, u, right=True)
+    below = torch.clamp_min(inds - 1, 0)
+    above = torch.clamp_max(inds, n_w)
+    pair = torch.stack([below, above], -1).view(N_rays, 2 * N_importance)
+    cdf_g = torch.gather(cdf, 1, pair).view(N_rays, N_importance, 2)
+    bins_g = torch.gather(bins, 1, pair).view(N_rays, N_importance, 2)
+    denom = cdf_g[..., 1] - cdf_g[..., 0]
+    denom[denom < eps] = 1
+    samples = bins_g[..., 0] + (u - cdf_g[..., 0]) / denom * (bins_g[..., 1] - bins_g[..., 0])
+    return dict(samples=samples, cdf=cdf, u=u, inds=inds, below=below, above=above)
+
+
+def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
+    return sample_pdf_full(bins, weights, N_importance, det=det, eps=eps)["samples"]
+
+
+# --------------------------------------------------------------------------- F'
+def _embed_padded(emb, x, width):
+    e = emb(x)
+    out = torch.zeros((x.shape[0], width))
+    out[:, :e.shape[1]] = e
+    return out
+
+
+def nof_inference(xyz_, ind_, nof_embeddings, nof_model):
+    """rendering.py:49-83."""
+    N, S = xyz_.shape[0], xyz_.shape[1]
+    flat = xyz_.reshape(-1, 3)
+    xyz_e = _embed_padded(nof_embeddings[0], flat, nof_model.in_channels_xyz)
+    ind_e = torch.repeat_interleave(nof_embeddings[1](ind_), repeats=S, dim=0)
+    inp = torch.cat([xyz_e, ind_e], -1)
+    img_ind = torch.repeat_interleave(ind_, repeats=S, dim=0).view(-1)
+    return nof_model(inp, flat, img_ind=img_ind).view(N, S, -1)
+
+
+# --------------------------------------------------------------------------- C
+def composite(sigmas, rgbs, z_vals, dir_, noise, activate_type="relu", background=None):
+    """rendering.py:157-192: sigma/rgb -> alpha, weights, rgb/depth. ``rgbs`` may be None."""
+    deltas = z_vals[:, 1:] - z_vals[:, :-1]
+    deltas = torch.cat([deltas, 1e10 * torch.ones_like(deltas[:, :1])], -1)
+    deltas = deltas * torch.norm(dir_.unsqueeze(1), dim=-1)
+    if activate_type == "relu":
+        alphas = 1 - torch.exp(-deltas * torch.relu(sigmas + noise))
+    elif activate_type == "softplus":
+        alphas = 1 - torch.exp(-deltas * F.softplus(sigmas + noise))
+    else:
+        raise ValueError("activation layer type: %s not support" % activate_type)
+    shifted = torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas + 1e-10], -1)
+    weights = alphas * torch.cumprod(shifted, -1)[:, :-1]
+    if rgbs is None:
+        return weights, alphas
+    wsum = weights.sum(1)
+    rgb = torch.sum(weights.unsqueeze(-1) * rgbs, -2)
+    depth = torch.sum(weights * z_vals, -1)
+    if background is not None:
+        rgb = rgb + background * (1 - wsum.unsqueeze(-1))
+    return rgb, depth, weights, alphas
+
+
+def nerf_inference(xyz_, ind_, dir_, z_vals, noise_std, nerf_embeddings, nerf_model,
+                   background=None, weights_only=False, activate_type="relu", noise=None):
+    """rendering.py:86-192. ``noise`` (N,S) overrides the internal randn draw."""
+    N, S = xyz_.shape[0], xyz_.shape[1]
+    dir_ = dir_.view(-1, 3)
+    flat = xyz_.reshape(-1, 3)
+    inp = _embed_padded(nerf_embeddings[0], flat, nerf_model.in_channels_xyz)
+    if not weights_only:
+        if nerf_model.extra_feat_type == "ind":
+            e = torch.repeat_interleave(nerf_embeddings[1](ind_), repeats=S, dim=0)
+            pad = torch.zeros((e.shape[0], nerf_model.extra_feat_dim))
+            pad[:, :e.shape[1]] = e
+            inp = torch.cat([inp, pad], 1)
+        elif nerf_model.extra_feat_type == "dir":
+            e = torch.repeat_interleave(nerf_embeddings[2](dir_), repeats=S, dim=0)
+            pad = torch.zeros((e.shape[0], nerf_model.extra_feat_dim))
+            pad[:, :e.shape[1]] = e
+            inp = torch.cat([inp, pad], 1)
+    img_ind = torch.repeat_interleave(ind_, repeats=S, dim=0).view(-1)
+    out = nerf_model(inp, sigma_only=weights_only, img_ind=img_ind)
+    if weights_only:
+        sigmas, rgbs = out.view(N, S), None
+    else:
+        out = out.view(N, S, 4)
+        rgbs, sigmas = out[..., :3], out[..., 3]
+    if noise is None:
+        noise = torch.randn(sigmas.shape) * noise_std   # always drawn (rendering.py:166)
+    return composite(sigmas, rgbs, z_vals, dir_, noise, activate_type,
+                     None if weights_only else background)
+
+
+# --------------------------------------------------------------------------- R
+def render_rays(rays, background, nerf_embeddings, nerf_models, nof_embeddings=None,
+                nof_models=None, chain_local=False, chain_global=False, N_samples=64,
+                N_importance=0, use_disp=False, perturb=0, noise_std=1,
+                nerf_activate_type="relu", test_time=False, _capture: Optional[dict] = None):
+    """rendering.py:195-375. ``_capture`` (test hook) receives z_vals / weights / alphas."""
+    N = rays.shape[0]
+    rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
+    near, far = rays[:, 6:7], rays[:, 7:8]
+    img_ind = rays[:, 8:9]
+    use_nof = nof_models is not None
+    if use_nof and chain_global:
+        chained_ind = rays[:, 9:10]
+
+    t = torch.linspace(0, 1, N_samples)
+    if not use_disp:
+        z_vals = near * (1 - t) + far * t
+    else:
+        z_vals = 1 / (1 / near * (1 - t) + 1 / far * t)
+    z_vals = z_vals.expand(N, N_samples)
+    if perturb > 0:
+        mid = 0.5 * (z_vals[:, :-1] + z_vals[:, 1:])
+        upper = torch.cat([mid, z_vals[:, -1:]], -1)
+        lower = torch.cat([z_vals[:, :1], mid], -1)
+        z_vals = lower + (upper - lower) * (perturb * torch.rand(z_vals.shape))
+
+    def chains(xyz):
+        """bw / fw NoF evaluations of one pass (rendering.py:270-286, 335-346)."""
+        bw = nof_models[0]
+        canon = nof_inference(xyz, img_ind, nof_embeddings, bw)
+        recon = chained_recon = None
+        if chain_local and not test_time:
+            fw = nof_models[1]
+            recon = nof_inference(canon, img_ind, nof_embeddings, fw)
+        if chain_global and not test_time:
+            fw = nof_models[1] if chain_local else _unbound_fw()
+            chained = nof_inference(canon, chained_ind, nof_embeddings, fw)
+            chained_canon = nof_inference(chained, chained_ind, nof_embeddings, bw)
+            chained_recon = nof_inference(chained_canon, img_ind, nof_embeddings, fw)
+        return canon, recon, chained_recon
+
+    def consensus(result, tag, xyz, recon, chained_recon, alphas):
+        mask = alphas.ge(0.01)
+        if not torch.any(mask):
+            mask = torch.ones_like(mask).bool()
+        if chain_local:
+            result[f"nof_local_disp_{tag}"] = torch.mean(torch.abs(xyz - recon)[mask], dim=1)
+        if chain_global:
+            result[f"nof_global_disp_{tag}"] = torch.mean(torch.abs(xyz - chained_recon)[mask], dim=1)
+
+    xyz_c = rays_o.unsqueeze(1) + rays_d.unsqueeze(1) * z_vals.unsqueeze(2)
+    if use_nof:
+        nerf_in, recon_c, chained_recon_c = chains(xyz_c)
+    else:
+        nerf_in = xyz_c
+
+    if N_importance > 0 and test_time:
+        w_c, a_c = nerf_inference(nerf_in, img_ind, rays_d, z_vals, noise_std, nerf_embeddings,
+                                  nerf_models[0], background=background, weights_only=True,
+                                  activate_type=nerf_activate_type)
+        result = {"opacity_coarse": w_c.sum(1)}
+    else:
+        rgb_c, depth_c, w_c, a_c = nerf_inference(nerf_in, img_ind, rays_d, z_vals, noise_std,
+                                                  nerf_embeddings, nerf_models[0],
+                                                  background=background, weights_only=False,
+                                                  activate_type=nerf_activate_type)
+        result = {"rgb_coarse": rgb_c, "depth_coarse": depth_c, "opacity_coarse": w_c.sum(1)}
+    if _capture is not None:
+        _capture.update(z_coarse=z_vals, weights_coarse=w_c, alphas_coarse=a_c)
+
+    if use_nof and not test_time:
+        consensus(result, "coarse", xyz_c, recon_c, chained_recon_c, a_c)
+
+    if N_importance > 0:
+        mid = 0.5 * (z_vals[:, :-1] + z_vals[:, 1:])
+        z_new = sample_pdf(mid, w_c[:, 1:-1], N_importance, det=(perturb == 0)).detach()
+        z_vals, _ = torch.sort(torch.cat([z_vals, z_new], -1), -1)
+        xyz_f = rays_o.unsqueeze(1) + rays_d.unsqueeze(1) * z_vals.unsqueeze(2)
+        if use_nof:
+            nerf_in, recon_f, chained_recon_f = chains(xyz_f)
+        else:
+            nerf_in = xyz_f
+        rgb_f, depth_f, w_f, a_f = nerf_inference(nerf_in, img_ind, rays_d, z_vals, noise_std,
+                                                  nerf_embeddings, nerf_models[1],
+                                                  background=background, weights_only=False,
+                                                  activate_type=nerf_activate_type)
+        result["rgb_fine"] = rgb_f
+        result["depth_fine"] = depth_f
+        result["opacity_fine"] = w_f.sum(1)
+        if _capture is not None:
+            _capture.update(z_fine=z_vals, weights_fine=w_f, alphas_fine=a_f)
+        if use_nof and not test_time:
+            consensus(result, "fine", xyz_f, recon_f, chained_recon_f, a_f)
+    return result
+
+
+def _unbound_fw():
+    # rendering.py:276-280: fw_nof is bound only under chain_local; chain_global alone
+    # hits an unbound local in the reference [SURVEY.md §8a row R].
+    raise UnboundLocalError("local variable 'fw_nof' referenced before assignment")
+
+
+# ------------------------------------------------------------- trainer-side glue
+def forward_nerf_alpha(xyz, deltas, nerf_embedding_xyz, nerf_model):
+    """trainer_moco_flow.py:146-157 (``forwarf_nerf``): softplus-activated alpha of points."""
+    inp = _embed_padded(nerf_embedding_xyz, xyz, nerf_model.in_channels_xyz)
+    sigmas = nerf_model(inp, sigma_only=True)
+    return 1 - torch.exp(-deltas * F.softplus(sigmas))
+
+
+def forward_nof_points(xyz, ind, num_frames, nof_embedding_xyz, nof_embedding_ind, nof_model):
+    """trainer_moco_flow.py:159-187 (``forward_nof``): ind is a frame index tensor (1,)."""
+    inp = _embed_padded(nof_embedding_xyz, xyz, nof_model.in_channels_xyz)
+    if nof_model.extra_feat_type == "ind":
+        ind_f = ind.unsqueeze(0).repeat((xyz.shape[0], 1)).float() * 2 / num_frames - 1.0
+        e = nof_embedding_ind(ind_f)
+        pad = torch.zeros((xyz.shape[0], nof_model.extra_feat_dim))
+        pad[:, :e.shape[1]] = e
+        inp = torch.cat([inp, pad], -1)
+    return nof_model(inp, xyz, ind)
+
+
+def psnr(a, b):
+    """models/metrics.py:4-13."""
+    return -10 * torch.log10(torch.mean((a - b) ** 2))
+
+
+# ------------------------------------------------------------------ conveniences
+def build_nerf(state, D=8, W=256, in_channels_xyz=63, skips=(4,), extra_feat_type="dir",
+               extra_feat_dim=27):
+    return NeRF(D, W, in_channels_xyz, skips, extra_feat_type, extra_feat_dim, state=state)
+
+
+def build_nof(state, D=4, W=128, in_channels_xyz=33, skips=(2,), extra_feat_dim=33, use_quat=True):
+    return NoF(D, W, in_channels_xyz, skips, "ind", extra_feat_dim, use_quat, state=state)

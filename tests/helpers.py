@@ -1,0 +1,76 @@
+"""Shared builders: turn a golden render case into (rays, bg, embeddings, models, kwargs)
+for either backend -- ``oracle.cpu_ref`` (CPU checker) or ``moco_flow_amd`` (HIP product)."""
+import os
+
+import numpy as np
+import torch
+
+from cases import RENDER_CASES  # tests/golden/cases.py
+from moco_flow_amd import synth
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load_golden(name):
+    return dict(np.load(os.path.join(GOLDEN, name + ".npz")))
+
+
+def relerr(a, b):
+    """max|a-b| / max|b|  (SURVEY.md §8d 'max-rel')."""
+    a = torch.as_tensor(a, dtype=torch.float64).cpu()
+    b = torch.as_tensor(b, dtype=torch.float64).cpu()
+    assert a.shape == b.shape, (a.shape, b.shape)
+    if b.numel() == 0:
+        return 0.0
+    return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
+
+
+def build_case(backend, case, seed, device="cpu"):
+    """backend: a module exposing Embedding / NeRF / NoF classes with the reference's
+    constructor signatures and ``load_state_dict``."""
+    c = case if isinstance(case, dict) else RENDER_CASES[case]
+    nof = c.get("nof", "none")
+    extra = c["extra"]
+    extra_dim = {"dir": 27, "ind": 5, "none": 0}[extra]
+
+    def emb(cin, nf, weights=None):
+        e = backend.Embedding(cin, nf, True)
+        if weights is not None:
+            e.weights = list(weights)
+        return e
+
+    def nerf(tag):
+        m = backend.NeRF(8, 256, 63, [4], extra, extra_dim)
+        sd = synth.nerf_state(seed, extra_feat_type=extra, extra_feat_dim=extra_dim,
+                              regime=c["regime"], tag=tag)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        return m.to(device) if hasattr(m, "to") else m
+
+    def nof_model(tag):
+        m = backend.NoF(4, 128, 33, [2], "ind", 33, c.get("quat", True))
+        sd = synth.nof_state(seed, use_quat=c.get("quat", True), tag=tag, head_scale=0.25)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        return m.to(device) if hasattr(m, "to") else m
+
+    nerf_embs = [emb(3, c.get("xyz_freqs", 10), c.get("xyz_w")),
+                 emb(1, 2) if extra == "ind" else None,
+                 emb(3, 4) if extra == "dir" else None]
+    nerfs = [nerf("coarse")] + ([nerf("fine")] if c["M"] > 0 else [])
+    nof_embs = nof_models = None
+    if nof != "none":
+        nof_embs = [emb(3, 5), emb(1, 16)]
+        nof_models = [nof_model("bw")] + ([nof_model("fw")] if nof in ("local", "global") else [])
+    kw = dict(nof_embeddings=nof_embs, nof_models=nof_models,
+              chain_local=nof in ("local", "global"), chain_global=nof == "global",
+              N_samples=c["S"], N_importance=c["M"], use_disp=c.get("disp", False), perturb=0,
+              noise_std=0, nerf_activate_type=c.get("act", "relu"), test_time=c.get("test", False))
+    return nerf_embs, nerfs, kw
+
+
+def case_inputs(c, seed, n=None, device="cpu"):
+    nof = c.get("nof", "none")
+    n = c["n"] if n is None else n
+    rays, bg = synth.rays(seed, n, chained=(nof == "global"))
+    rays = torch.from_numpy(rays).to(device)
+    bg = torch.from_numpy(bg).to(device) if c.get("bg", True) else None
+    return rays, bg

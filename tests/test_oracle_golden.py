@@ -1,0 +1,110 @@
+"""Pin the oracle (oracle/cpu_ref.py) against every golden vector produced by the
+reference itself (tests/golden/gen_golden.py). CPU only; tolerance 1e-6 relative
+(same library, same op order)."""
+import numpy as np
+import pytest
+import torch
+
+from cases import RENDER_CASES
+from helpers import build_case, load_golden, relerr
+from oracle import cpu_ref as R
+
+TOL = 1e-6
+
+
+@pytest.mark.parametrize("name", sorted(RENDER_CASES))
+def test_render_rays_matches_reference(name):
+    c = RENDER_CASES[name]
+    g = load_golden(name)
+    seed = int(g["meta_seed"])
+    embs, nerfs, kw = build_case(R, c, seed)
+    rays = torch.from_numpy(g["in_rays"])
+    bg = torch.from_numpy(g["in_background"]) if c.get("bg", True) else None
+    cap = {}
+    with torch.no_grad():
+        res = R.render_rays(rays, bg, embs, nerfs, _capture=cap, **kw)
+    want = {k[4:]: v for k, v in g.items() if k.startswith("out_")}
+    assert sorted(res) == sorted(want)
+    for k, v in want.items():
+        assert tuple(res[k].shape) == v.shape, k
+        assert res[k].dtype == torch.float32
+        assert relerr(res[k], v) <= TOL, (k, relerr(res[k], v))
+    for tag in ("coarse", "fine"):
+        if f"mid_z_{tag}" in g:
+            assert relerr(cap[f"z_{tag}"], g[f"mid_z_{tag}"]) <= TOL
+            assert relerr(cap[f"weights_{tag}"], g[f"mid_weights_{tag}"]) <= TOL
+            assert relerr(cap[f"alphas_{tag}"], g[f"mid_alphas_{tag}"]) <= TOL
+
+
+def test_embedding_vectors():
+    g = load_golden("u_embedding")
+    x3, x1 = torch.from_numpy(g["in_x3"]), torch.from_numpy(g["in_x1"])
+    for nf in (0, 2, 4, 5, 10, 16):
+        assert torch.equal(R.Embedding(3, nf)(x3), torch.from_numpy(g[f"out_x3_f{nf}"]))
+        assert torch.equal(R.Embedding(1, nf)(x1), torch.from_numpy(g[f"out_x1_f{nf}"]))
+        assert R.Embedding(3, nf).out_channels == 3 * (2 * nf + 1)
+    e = R.Embedding(3, 10)
+    e.set_weights(0)
+    assert torch.equal(e(x3), torch.from_numpy(g["out_x3_f10_w0"]))
+    e.weights = list(g["in_ramp"])
+    assert torch.equal(e(x3), torch.from_numpy(g["out_x3_f10_ramp"]))
+    assert torch.equal(R.Embedding(3, 6, logscale=False)(x3), torch.from_numpy(g["out_x3_f6_linear"]))
+    with pytest.raises(AssertionError):
+        e.set_weights([1, 2])
+
+
+def test_network_vectors():
+    from moco_flow_amd import synth
+    g = load_golden("u_networks")
+    for extra, dim in (("dir", 27), ("ind", 5), ("none", 0)):
+        sd = synth.nerf_state(11, extra_feat_type=extra, extra_feat_dim=dim, regime="dense", tag="unit")
+        m = R.NeRF(8, 256, 63, [4], extra, dim, state=sd)
+        inp = torch.from_numpy(g[f"in_nerf_{extra}"])
+        assert relerr(m(inp), g[f"out_nerf_{extra}_full"]) <= TOL
+        assert relerr(m(inp[:, :63].contiguous(), sigma_only=True), g[f"out_nerf_{extra}_sigma"]) <= TOL
+    for quat in (True, False):
+        m = R.NoF(4, 128, 33, [2], "ind", 33, quat, state=synth.nof_state(13, use_quat=quat, tag="unit"))
+        out = m(torch.from_numpy(g["in_nof_inputs"]), torch.from_numpy(g["in_nof_xyz"]))
+        assert relerr(out, g[f"out_nof_{'quat' if quat else 'flow'}"]) <= TOL
+
+
+def test_sample_pdf_vectors_bit_exact_indices():
+    g = load_golden("u_sample_pdf")
+    bins, w = torch.from_numpy(g["in_bins"]), torch.from_numpy(g["in_weights"])
+    full = R.sample_pdf_full(bins, w, 128, det=True)
+    assert torch.equal(full["inds"], torch.from_numpy(g["mid_inds_det"]))       # int64, bit-exact
+    assert torch.equal(full["cdf"], torch.from_numpy(g["mid_cdf"]))
+    assert relerr(full["samples"], g["out_samples_det"]) <= TOL
+    full = R.sample_pdf_full(bins, w, 128, det=False, u=torch.from_numpy(g["in_u_rand"]))
+    assert torch.equal(full["inds"], torch.from_numpy(g["mid_inds_rand"]))
+    assert relerr(full["samples"], g["out_samples_rand"]) <= TOL
+    assert w.sum() == torch.from_numpy(g["in_weights"]).sum()                   # input not mutated
+
+
+def test_trainer_glue_vectors():
+    from moco_flow_amd import synth
+    g = load_golden("u_trainer_glue")
+    xyz = torch.from_numpy(g["in_xyz"])
+    nerf = R.NeRF(8, 256, 63, [4], "ind", 5, state=synth.nerf_state(
+        32, extra_feat_type="ind", extra_feat_dim=5, regime="dense", tag="glue"))
+    a = R.forward_nerf_alpha(xyz, float(g["in_delta"]), R.Embedding(3, 10), nerf)
+    assert relerr(a, g["out_alphas"]) <= TOL
+    nof = R.NoF(4, 128, 33, [2], "ind", 33, True, state=synth.nof_state(33, use_quat=True, tag="glue"))
+    out = R.forward_nof_points(xyz, torch.from_numpy(g["in_ind"]), int(g["in_num_frames"]),
+                               R.Embedding(3, 5), R.Embedding(1, 16), nof)
+    assert relerr(out, g["out_nof_xyz"]) <= TOL
+
+
+def test_error_conventions():
+    with pytest.raises(AssertionError):
+        R.NeRF(extra_feat_type="bogus")
+    with pytest.raises(AssertionError):
+        R.NoF(extra_feat_type="dir")
+    with pytest.raises(ValueError):
+        R.composite(torch.zeros(1, 4), None, torch.arange(4.).view(1, 4), torch.ones(1, 3),
+                    torch.zeros(1, 4), activate_type="tanh")
+    with pytest.raises(NotImplementedError):
+        from moco_flow_amd import synth
+        sd = synth.nerf_state(1, D=2, W=32, in_channels_xyz=33, skips=(), extra_feat_type="latent_code",
+                              extra_feat_dim=4)
+        R.NeRF(2, 32, 33, [], "latent_code", 4, state=sd)(torch.zeros(2, 37))
