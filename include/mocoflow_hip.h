@@ -1,0 +1,187 @@
+/*
+ * mocoflow_hip.h -- C ABI of the MI355X (gfx950) volume-rendering path of MoCo-Flow.
+ *
+ * The reference (wyysf-98/MoCo_Flow) is pure Python/PyTorch and has NO native
+ * boundary of its own; this ABI is the build-defined drop-in surface described in
+ * SURVEY.md §8(b).  Every entry point below names the reference interface it
+ * replaces (file:line relative to the reference repository).
+ *
+ * Conventions
+ *   - extern "C", POD only: device pointers, 32/64-bit sizes, a hipStream_t passed
+ *     as void*.  No torch types, no exceptions, no allocation, no ownership
+ *     transfer: the caller allocates every output and workspace buffer.
+ *   - All pointers are DEVICE pointers (fp32 / int32 as documented) unless marked
+ *     "host".  Descriptor structs are read on the host during the call.
+ *   - Return value: 0 = ok; <0 = error (MF_E_*), text via mf_last_error()
+ *     (thread-local).  Work is enqueued on `stream`; nothing synchronises.
+ *   - The library is stateless; "packed weights" are plain caller-owned device
+ *     buffers produced by mf_*_pack from the PyTorch parameter tensors.
+ */
+#ifndef MOCOFLOW_HIP_H
+#define MOCOFLOW_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MF_ABI_VERSION 1
+
+enum {
+  MF_OK = 0,
+  MF_E_INVALID = -1,     /* bad argument / unsupported configuration */
+  MF_E_LAUNCH = -2,      /* HIP launch or runtime failure            */
+  MF_E_UNSUPPORTED = -3  /* valid for the reference, not built here  */
+};
+
+enum { MF_MAX_FREQS = 16, MF_MAX_LAYERS = 16 };
+
+/* ---- Embedding: models/embedding.py:4-47 ------------------------------------
+ * out = [x, w0*sin(f0 x), w0*cos(f0 x), w1*sin(f1 x), ...]; freq[] are the module's
+ * freq_bands (2^k or linear), weight[] its per-frequency weights (set_weights /
+ * trainer_moco_flow.py:289,301).  n_freqs == 0 is legal (identity). */
+typedef struct mf_embedding {
+  int32_t in_channels;             /* 3 (xyz, dir) or 1 (ind)             */
+  int32_t n_freqs;                 /* 0..MF_MAX_FREQS                     */
+  float freq[MF_MAX_FREQS];
+  float weight[MF_MAX_FREQS];
+} mf_embedding;
+
+/* ---- NeRF: models/nerf.py:5-102 ---------------------------------------------
+ * Parameter pointers follow the reference's state_dict:
+ *   trunk_w[i] / trunk_b[i]  = xyz_encoding_{i+1}.0.{weight,bias}
+ *   final_w / final_b        = xyz_encoding_final.{weight,bias}
+ *   extra_w / extra_b        = extra_encoding.0.{weight,bias}   (W/2, W+extra_feat_dim)
+ *   sigma_w / sigma_b        = sigma.{weight,bias}              (1, W)
+ *   rgb_w / rgb_b            = rgb.0.{weight,bias}              (3, W/2)
+ * All row-major (out, in) fp32 as nn.Linear stores them. */
+enum { MF_EXTRA_NONE = 0, MF_EXTRA_IND = 1, MF_EXTRA_DIR = 2 };
+
+typedef struct mf_nerf_desc {
+  int32_t D;                       /* trunk layers, 2..MF_MAX_LAYERS-1       */
+  int32_t W;                       /* hidden width: 256 (or 128)             */
+  int32_t in_channels_xyz;         /* 63 (= 3*(2*10+1)) or 33               */
+  uint32_t skip_mask;              /* bit i set <=> i in skips (nerf.py:84-86) */
+  int32_t extra_feat_type;         /* MF_EXTRA_*                             */
+  int32_t extra_feat_dim;          /* columns of extra_encoding beyond W     */
+  const float* trunk_w[MF_MAX_LAYERS];
+  const float* trunk_b[MF_MAX_LAYERS];
+  const float* final_w; const float* final_b;
+  const float* extra_w; const float* extra_b;
+  const float* sigma_w; const float* sigma_b;
+  const float* rgb_w;   const float* rgb_b;
+} mf_nerf_desc;
+
+/* ---- NoF: models/nof.py:6-85 --------------------------------------------------
+ *   trunk_w[i] / trunk_b[i] = nof_encoding_{i+1}.0.{weight,bias}
+ *   head_w / head_b         = nof_encoding_final.{weight,bias}  (9|3, W) */
+typedef struct mf_nof_desc {
+  int32_t D;                       /* trunk layers                           */
+  int32_t W;                       /* hidden width: 128                      */
+  int32_t in_channels_xyz;         /* 33                                     */
+  int32_t extra_feat_dim;          /* 33 (ind embedding width)               */
+  uint32_t skip_mask;
+  int32_t use_quat;                /* nof.py:75-82                           */
+  const float* trunk_w[MF_MAX_LAYERS];
+  const float* trunk_b[MF_MAX_LAYERS];
+  const float* head_w; const float* head_b;
+} mf_nof_desc;
+
+int32_t mf_version(void);
+const char* mf_last_error(void);
+
+/* Size in bytes of the packed-weights buffer for a network (0 on unsupported). */
+int64_t mf_nerf_packed_bytes(const mf_nerf_desc* d);
+int64_t mf_nof_packed_bytes(const mf_nof_desc* d);
+/* Re-order the nn.Linear tensors into the kernels' MFMA fragment stream.
+ * Must be re-run whenever the parameters change (optimizer.step). */
+int32_t mf_nerf_pack(const mf_nerf_desc* d, void* packed, void* stream);
+int32_t mf_nof_pack(const mf_nof_desc* d, void* packed, void* stream);
+
+/* Embedding.forward, models/embedding.py:30-47:  x (B, in_channels) -> out (B, C*(2F+1)). */
+int32_t mf_embedding_forward(const mf_embedding* e, const float* x, int64_t B, float* out, void* stream);
+
+/* NeRF.forward, models/nerf.py:61-102: inputs (B, in_channels_xyz [+ extra_feat_dim]) row
+ * stride `in_stride` floats -> out (B,4) = [rgb, sigma], or (B,1) sigma when sigma_only. */
+int32_t mf_nerf_forward(const mf_nerf_desc* d, const void* packed, const float* inputs,
+                        int64_t in_stride, int64_t B, int32_t sigma_only, float* out, void* stream);
+
+/* NoF.forward, models/nof.py:55-85: inputs (B, in_channels_xyz+extra_feat_dim), xyz (B,3) -> (B,3). */
+int32_t mf_nof_forward(const mf_nof_desc* d, const void* packed, const float* inputs,
+                       int64_t in_stride, const float* xyz, int64_t B, float* out, void* stream);
+
+/* ---- one rendering pass: nof_inference* + nerf_inference of models/rendering.py:49-192 as
+ * called from render_rays (rendering.py:262-314 coarse, 329-373 fine) -------------------- */
+enum {
+  MF_ACT_RELU = 0, MF_ACT_SOFTPLUS = 1        /* rendering.py:169-172 */
+};
+enum {
+  MF_F_SIGMA_ONLY   = 1 << 0,  /* weights_only=True: no rgb/depth (rendering.py:290-294)   */
+  MF_F_CHAIN_LOCAL  = 1 << 1,  /* fw(bw(x,i),i) consensus (rendering.py:275-277)            */
+  MF_F_CHAIN_GLOBAL = 1 << 2   /* fw_i(bw_j(fw_j(bw_i(x)))) (rendering.py:279-282)          */
+};
+
+typedef struct mf_render_args {
+  /* rays (N, ray_stride>=9|10): o(3) d(3) near far img_ind [chained_img_ind]
+   * (rendering.py:237-242) */
+  const float* rays; int64_t ray_stride; int64_t n_rays;
+  const float* background;          /* (N,3) or NULL (rendering.py:189-190)              */
+  int32_t n_samples;                /* S of this pass                                     */
+  /* depths: either z_vals (N,S) explicit (perturbed / fine pass), or z_steps (S,)
+   * = torch.linspace(0,1,S) with use_disp choosing rendering.py:247 vs :249 */
+  const float* z_vals; const float* z_steps; int32_t use_disp;
+  const float* noise;               /* (N,S) sigma noise already scaled by noise_std, or NULL */
+  int32_t activation;               /* MF_ACT_*                                           */
+  int32_t flags;                    /* MF_F_*                                             */
+  /* canonical NeRF */
+  const mf_nerf_desc* nerf; const void* nerf_packed;
+  mf_embedding emb_xyz;             /* nerf_embeddings[0]                                 */
+  mf_embedding emb_extra;           /* nerf_embeddings[1] (ind) or [2] (dir); ignored for none */
+  /* neural motion flow (NULL => plain NeRF) */
+  const mf_nof_desc* nof_bw; const void* nof_bw_packed;
+  const mf_nof_desc* nof_fw; const void* nof_fw_packed;
+  mf_embedding nof_emb_xyz, nof_emb_ind;
+  /* outputs (any may be NULL) */
+  float* rgb;                       /* (N,3) */
+  float* depth;                     /* (N,)  */
+  float* opacity;                   /* (N,)  weights.sum(1)                               */
+  float* weights;                   /* (N,S) */
+  float* alphas;                    /* (N,S) */
+  float* disp_local;                /* (N,S) mean_c |xyz - recon|         (rendering.py:310-311) */
+  float* disp_global;               /* (N,S) mean_c |xyz - chained_recon| (rendering.py:313-314) */
+} mf_render_args;
+
+int32_t mf_render_pass(const mf_render_args* a, void* stream);
+
+/* ---- hierarchical resampling: sample_pdf (rendering.py:5-46) [+ cat + sort, :321-326] ------
+ * General form.  Per ray: n_bins bin positions -- either explicit `bins` (N, n_bins), the
+ * reference's first argument, or the mid-points of z_coarse (N, n_bins+1) (rendering.py:321) --
+ * and n_bins-1 weights starting at weights + ray*w_stride.  u: uniform draws (N, M) with row
+ * stride u_stride, or ONE shared row with u_stride = 0 (the deterministic linspace(0,1,M)).
+ * cdf_in (N, n_bins), optional: use this cdf instead of normalising/summing the weights.
+ * Outputs (each optional): z_new_out (N,M) the drawn samples; inds_out (N,M) int32 the
+ * searchsorted(right=True) indices; z_sorted_out (N, n_bins+1+M) = sort(cat(z_coarse, samples))
+ * (needs z_coarse). */
+int32_t mf_sample_pdf(const float* bins, const float* z_coarse, const float* weights, int64_t w_stride,
+                      int64_t n_rays, int32_t n_bins, int32_t M, const float* u, int64_t u_stride,
+                      const float* cdf_in, float* z_new_out, int32_t* inds_out, float* z_sorted_out,
+                      void* stream);
+/* render_rays' use of it: z_coarse (N,S), weights (N,S) of the coarse pass (the kernel takes
+ * weights[:,1:-1]); u (N,M) draws; writes the sorted union z_out (N,S+M). */
+int32_t mf_sample_pdf_merge(const float* z_coarse, const float* weights, int64_t n_rays,
+                            int32_t S, int32_t M, const float* u, float* z_out,
+                            int32_t* inds_out, float* z_new_out, void* stream);
+
+/* ---- consensus compaction, rendering.py:306-314: mask = alphas >= 0.01 (all-true if none);
+ * out[k] = vals[p_k] for masked positions in row-major (ray, sample) order.
+ * count (device int64[1]) receives the number of outputs; scratch >= mf_compact_scratch_bytes. */
+int64_t mf_compact_scratch_bytes(int64_t n_rays);
+int32_t mf_compact_mask(const float* alphas, const float* vals_a, const float* vals_b,
+                        int64_t n_rays, int32_t S, float* out_a, float* out_b,
+                        int64_t* count, void* scratch, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MOCOFLOW_HIP_H */

@@ -1,0 +1,125 @@
+"""ctypes binding of the C-ABI library (include/mocoflow_hip.h).
+
+The product path has NO fallback: if ``libmocoflow_hip.so`` is missing or a call
+fails, a RuntimeError is raised (build with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C moco_flow_amd/csrc``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+MF_MAX_FREQS = 16
+MF_MAX_LAYERS = 16
+MF_EXTRA_NONE, MF_EXTRA_IND, MF_EXTRA_DIR = 0, 1, 2
+MF_ACT_RELU, MF_ACT_SOFTPLUS = 0, 1
+MF_F_SIGMA_ONLY, MF_F_CHAIN_LOCAL, MF_F_CHAIN_GLOBAL = 1, 2, 4
+
+LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmocoflow_hip.so")
+
+_fp = C.c_void_p   # device pointers travel as integers
+
+
+class mf_embedding(C.Structure):
+    _fields_ = [("in_channels", C.c_int32), ("n_freqs", C.c_int32),
+                ("freq", C.c_float * MF_MAX_FREQS), ("weight", C.c_float * MF_MAX_FREQS)]
+
+
+class mf_nerf_desc(C.Structure):
+    _fields_ = [("D", C.c_int32), ("W", C.c_int32), ("in_channels_xyz", C.c_int32),
+                ("skip_mask", C.c_uint32), ("extra_feat_type", C.c_int32), ("extra_feat_dim", C.c_int32),
+                ("trunk_w", _fp * MF_MAX_LAYERS), ("trunk_b", _fp * MF_MAX_LAYERS),
+                ("final_w", _fp), ("final_b", _fp), ("extra_w", _fp), ("extra_b", _fp),
+                ("sigma_w", _fp), ("sigma_b", _fp), ("rgb_w", _fp), ("rgb_b", _fp)]
+
+
+class mf_nof_desc(C.Structure):
+    _fields_ = [("D", C.c_int32), ("W", C.c_int32), ("in_channels_xyz", C.c_int32),
+                ("extra_feat_dim", C.c_int32), ("skip_mask", C.c_uint32), ("use_quat", C.c_int32),
+                ("trunk_w", _fp * MF_MAX_LAYERS), ("trunk_b", _fp * MF_MAX_LAYERS),
+                ("head_w", _fp), ("head_b", _fp)]
+
+
+class mf_render_args(C.Structure):
+    _fields_ = [("rays", _fp), ("ray_stride", C.c_int64), ("n_rays", C.c_int64),
+                ("background", _fp), ("n_samples", C.c_int32),
+                ("z_vals", _fp), ("z_steps", _fp), ("use_disp", C.c_int32),
+                ("noise", _fp), ("activation", C.c_int32), ("flags", C.c_int32),
+                ("nerf", C.POINTER(mf_nerf_desc)), ("nerf_packed", _fp),
+                ("emb_xyz", mf_embedding), ("emb_extra", mf_embedding),
+                ("nof_bw", C.POINTER(mf_nof_desc)), ("nof_bw_packed", _fp),
+                ("nof_fw", C.POINTER(mf_nof_desc)), ("nof_fw_packed", _fp),
+                ("nof_emb_xyz", mf_embedding), ("nof_emb_ind", mf_embedding),
+                ("rgb", _fp), ("depth", _fp), ("opacity", _fp), ("weights", _fp), ("alphas", _fp),
+                ("disp_local", _fp), ("disp_global", _fp)]
+
+
+# every symbol include/mocoflow_hip.h declares: (restype, argtypes)
+SYMBOLS = {
+    "mf_version": (C.c_int32, []),
+    "mf_last_error": (C.c_char_p, []),
+    "mf_nerf_packed_bytes": (C.c_int64, [C.POINTER(mf_nerf_desc)]),
+    "mf_nof_packed_bytes": (C.c_int64, [C.POINTER(mf_nof_desc)]),
+    "mf_nerf_pack": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, _fp]),
+    "mf_nof_pack": (C.c_int32, [C.POINTER(mf_nof_desc), _fp, _fp]),
+    "mf_embedding_forward": (C.c_int32, [C.POINTER(mf_embedding), _fp, C.c_int64, _fp, _fp]),
+    "mf_nerf_forward": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, _fp, C.c_int64, C.c_int64, C.c_int32, _fp, _fp]),
+    "mf_nof_forward": (C.c_int32, [C.POINTER(mf_nof_desc), _fp, _fp, C.c_int64, _fp, C.c_int64, _fp, _fp]),
+    "mf_render_pass": (C.c_int32, [C.POINTER(mf_render_args), _fp]),
+    "mf_sample_pdf_merge": (C.c_int32, [_fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
+    "mf_sample_pdf": (C.c_int32, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_int64,
+                                  _fp, _fp, _fp, _fp, _fp]),
+    "mf_compact_scratch_bytes": (C.c_int64, [C.c_int64]),
+    "mf_compact_mask": (C.c_int32, [_fp, _fp, _fp, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
+}
+
+_lock = threading.Lock()
+_lib = None
+
+
+def lib():
+    """The loaded C-ABI library; raises loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    with _lock:
+        if _lib is None:
+            if not os.path.exists(LIB_PATH):
+                raise RuntimeError(
+                    f"moco_flow_amd: HIP library not built ({LIB_PATH} missing). "
+                    "Run `make -C moco_flow_amd/csrc` (hipcc, gfx950). There is no CPU fallback.")
+            handle = C.CDLL(LIB_PATH)
+            for name, (res, args) in SYMBOLS.items():
+                fn = getattr(handle, name)   # AttributeError if the export is missing
+                fn.restype = res
+                fn.argtypes = args
+            if handle.mf_version() != 1:
+                raise RuntimeError("moco_flow_amd: ABI version mismatch")
+            _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = lib().mf_last_error().decode(errors="replace")
+        if rc == -3:
+            raise NotImplementedError(f"moco_flow_amd HIP path: {msg}")
+        raise RuntimeError(f"moco_flow_amd HIP call failed ({what}, rc={rc}): {msg}")
+
+
+def ptr(t):
+    """Device pointer of a tensor (or NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device) -> int:
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def require_gpu(t, what: str):
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"moco_flow_amd.{what}: tensor is on '{t.device}'. This package is the MI355X (HIP) path and has "
+            "no CPU implementation; move the module and its inputs to a 'cuda' device.")

@@ -1,0 +1,199 @@
+// mf_forward.hip -- module-level entry points (the trainers call the networks directly,
+// outside render_rays: trainer_moco_flow.py:146-187, 508-526; trainer_nerf.py:231,240):
+//   mf_embedding_forward : Embedding.forward   models/embedding.py:30-47
+//   mf_nerf_forward      : NeRF.forward        models/nerf.py:61-102
+//   mf_nof_forward       : NoF.forward         models/nof.py:55-85
+// The two network kernels run the same register-resident MFMA core as the fused render pass;
+// only the prologue (embedded inputs are read from memory instead of being computed) and the
+// epilogue (raw rgb/sigma rows are stored instead of being composited) differ.
+#include "mf_host.hpp"
+#include "mf_layout.hpp"
+#include "mf_nets.hpp"
+
+namespace mf {
+
+// ------------------------------------------------------------------ Embedding.forward
+struct EmbFwdParams {
+  mf_embedding e;
+  const float* x;
+  float* out;
+  long long B;
+};
+
+__global__ void embedding_forward_kernel(EmbFwdParams p) {
+  const int C = p.e.in_channels, F = p.e.n_freqs;
+  const int OC = C * (2 * F + 1);
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p.B * OC) return;
+  const long long b = idx / OC;
+  const int col = (int)(idx - b * OC);
+  float v;
+  if (col < C) {
+    v = p.x[b * C + col];
+  } else {
+    const int k = (col - C) / C;          // 0 .. 2F-1 : (freq, sin|cos)
+    const int c = (col - C) % C;
+    const int f = k >> 1;
+    const float arg = p.e.freq[f] * p.x[b * C + c];
+    v = p.e.weight[f] * ((k & 1) ? cosf(arg) : sinf(arg));
+  }
+  p.out[idx] = v;
+}
+
+// ------------------------------------------------------------------ NeRF.forward
+struct NerfFwdParams {
+  NetDev net;
+  const float* in;
+  long long in_stride, B;
+  int sigma_only, extra_kind, extra_cols, xyz_cols;
+  float* out;
+  uint32_t ring_off, buf_bytes;
+};
+
+__global__ __launch_bounds__(256, 1) void nerf_forward_kernel(NerfFwdParams p) {
+  const LaneId id;
+  NetDev net = p.net;
+  load_resident(net, id);
+  Stream st;
+  st.ring = p.ring_off;
+  st.buf_bytes = p.buf_bytes;
+  st.start(first_panel(net), first_groups(net), id);   // also drains the resident-block DMA
+  const long long ntiles = (p.B + kTile - 1) / kTile;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long b = tile * kTile + id.wave * 32 + id.j;
+    const bool valid = b < p.B;
+    const float* row = p.in + (valid ? b : p.B - 1) * p.in_stride;
+    float embx[kStepsNerfXyz], ext[kStepsExtraMax];
+#pragma unroll
+    for (int e = 0; e < kStepsNerfXyz; ++e) {
+      const int f0 = emb_feature(kEmbNerfXyz, 0, e, 0), f1 = emb_feature(kEmbNerfXyz, 1, e, 0);
+      const int f = id.h ? f1 : f0;
+      embx[e] = f >= 0 ? row[f] : 0.f;
+    }
+#pragma unroll
+    for (int e = 0; e < kStepsExtraMax; ++e) {
+      int f = -1;
+      if (p.extra_kind == kEmbDir) f = id.h ? emb_feature(kEmbDir, 1, e, 0) : emb_feature(kEmbDir, 0, e, 0);
+      else if (p.extra_kind == kEmbInd) f = id.h ? emb_feature(kEmbInd, 1, e, 0) : emb_feature(kEmbInd, 0, e, 0);
+      ext[e] = (!p.sigma_only && f >= 0 && f < p.extra_cols) ? row[p.xyz_cols + f] : 0.f;
+    }
+    float sigma, rgb[3] = {0.f, 0.f, 0.f};
+    nerf_eval<8>(net, embx, ext, p.sigma_only != 0, st, id, first_panel(net), first_groups(net), sigma, rgb);
+    if (valid && id.h == 0) {
+      if (p.sigma_only) p.out[b] = sigma;
+      else *reinterpret_cast<float4*>(p.out + b * 4) = make_float4(rgb[0], rgb[1], rgb[2], sigma);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ NoF.forward
+struct NofFwdParams {
+  NetDev net;
+  const float* in;
+  long long in_stride, B;
+  const float* xyz;
+  float* out;
+  uint32_t ring_off, buf_bytes;
+};
+
+__global__ __launch_bounds__(256, 1) void nof_forward_kernel(NofFwdParams p) {
+  const LaneId id;
+  NetDev net = p.net;
+  load_resident(net, id);
+  Stream st;
+  st.ring = p.ring_off;
+  st.buf_bytes = p.buf_bytes;
+  st.start(first_panel(net), first_groups(net), id);
+  const long long ntiles = (p.B + kTile - 1) / kTile;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long b = tile * kTile + id.wave * 32 + id.j;
+    const bool valid = b < p.B;
+    const long long bb = valid ? b : p.B - 1;
+    const float* row = p.in + bb * p.in_stride;
+    float emb[kStepsNofIn];
+#pragma unroll
+    for (int e = 0; e < kStepsNofIn; ++e) {
+      const int f = id.h ? emb_feature(kEmbNofIn, 1, e, 33) : emb_feature(kEmbNofIn, 0, e, 33);
+      emb[e] = f >= 0 ? row[f] : 0.f;
+    }
+    const float xyz[3] = {p.xyz[bb * 3 + 0], p.xyz[bb * 3 + 1], p.xyz[bb * 3 + 2]};
+    float o[3];
+    nof_eval(net, emb, xyz, st, id, first_panel(net), first_groups(net), o);
+    if (valid && id.h == 0) {
+      p.out[b * 3 + 0] = o[0];
+      p.out[b * 3 + 1] = o[1];
+      p.out[b * 3 + 2] = o[2];
+    }
+  }
+}
+
+int device_cus() {
+  static int cus = 0;
+  if (cus == 0) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  return cus;
+}
+
+}  // namespace mf
+
+using namespace mf;
+
+extern "C" int32_t mf_embedding_forward(const mf_embedding* e, const float* x, int64_t B, float* out, void* stream) {
+  if (!e || (B > 0 && (!x || !out))) return fail(MF_E_INVALID, "mf_embedding_forward: null argument");
+  if (e->in_channels < 1 || e->n_freqs < 0 || e->n_freqs > MF_MAX_FREQS)
+    return fail(MF_E_INVALID, "mf_embedding_forward: in_channels=%d n_freqs=%d out of range", e->in_channels, e->n_freqs);
+  if (B == 0) return MF_OK;
+  EmbFwdParams p{*e, x, out, B};
+  const long long total = B * e->in_channels * (2 * e->n_freqs + 1);
+  hipLaunchKernelGGL(embedding_forward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     static_cast<hipStream_t>(stream), p);
+  return check_launch("mf_embedding_forward");
+}
+
+extern "C" int32_t mf_nerf_forward(const mf_nerf_desc* d, const void* packed, const float* inputs, int64_t in_stride,
+                                   int64_t B, int32_t sigma_only, float* out, void* stream) {
+  if (!d || !packed || (B > 0 && (!inputs || !out))) return fail(MF_E_INVALID, "mf_nerf_forward: null argument");
+  NerfFwdParams p{};
+  if (!nerf_layout(*d, p.net.L)) return fail(MF_E_UNSUPPORTED, "mf_nerf_forward: unsupported NeRF configuration");
+  if (p.net.L.NT != 8) return fail(MF_E_UNSUPPORTED, "mf_nerf_forward: only W=256 is built");
+  if (B == 0) return MF_OK;
+  p.net.packed = static_cast<const char*>(packed);
+  p.net.res_lds = 0;
+  p.in = inputs; p.in_stride = in_stride; p.B = B; p.sigma_only = sigma_only; p.out = out;
+  p.extra_kind = d->extra_feat_type == MF_EXTRA_DIR ? kEmbDir : (d->extra_feat_type == MF_EXTRA_IND ? kEmbInd : kEmbNone);
+  p.extra_cols = d->extra_feat_type == MF_EXTRA_NONE ? 0 : d->extra_feat_dim;
+  p.xyz_cols = d->in_channels_xyz;
+  p.ring_off = (uint32_t)p.net.L.res_bytes;
+  p.buf_bytes = (uint32_t)p.net.L.max_groups * kGroupBytes;
+  const size_t lds = p.ring_off + 2 * (size_t)p.buf_bytes;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(MF_E_LAUNCH, "mf_nerf_forward: cannot reserve %zu bytes of LDS", lds);
+  const long long ntiles = (B + kTile - 1) / kTile;
+  const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
+  hipLaunchKernelGGL(nerf_forward_kernel, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  return check_launch("mf_nerf_forward");
+}
+
+extern "C" int32_t mf_nof_forward(const mf_nof_desc* d, const void* packed, const float* inputs, int64_t in_stride,
+                                  const float* xyz, int64_t B, float* out, void* stream) {
+  if (!d || !packed || (B > 0 && (!inputs || !xyz || !out))) return fail(MF_E_INVALID, "mf_nof_forward: null argument");
+  NofFwdParams p{};
+  if (!nof_layout(*d, p.net.L)) return fail(MF_E_UNSUPPORTED, "mf_nof_forward: unsupported NoF configuration");
+  if (B == 0) return MF_OK;
+  p.net.packed = static_cast<const char*>(packed);
+  p.net.res_lds = 0;
+  p.in = inputs; p.in_stride = in_stride; p.B = B; p.xyz = xyz; p.out = out;
+  p.ring_off = (uint32_t)p.net.L.res_bytes;
+  p.buf_bytes = (uint32_t)p.net.L.max_groups * kGroupBytes;
+  const size_t lds = p.ring_off + 2 * (size_t)p.buf_bytes;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(nof_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(MF_E_LAUNCH, "mf_nof_forward: cannot reserve %zu bytes of LDS", lds);
+  const long long ntiles = (B + kTile - 1) / kTile;
+  const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
+  hipLaunchKernelGGL(nof_forward_kernel, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  return check_launch("mf_nof_forward");
+}

@@ -1,0 +1,83 @@
+// mf_layout.hpp -- packed-buffer layouts derived from the C-ABI descriptors (host + device).
+#pragma once
+#include "../../include/mocoflow_hip.h"
+#include "mf_core.hpp"
+
+namespace mf {
+
+inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+
+// returns false (layout zeroed) for configurations the kernels do not implement
+inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L) {
+  L = NetLayout{};
+  if (d.W != 256 && d.W != 128) return false;
+  if (d.D < 2 || d.D + 1 > MF_MAX_LAYERS) return false;
+  if (d.in_channels_xyz != 63) return false;          // 3*(2*10+1); see DESIGN.md "envelope"
+  if (d.skip_mask & 1u) return false;                 // layer 0 already takes the input
+  if (d.skip_mask >> d.D) return false;
+  L.W = d.W;
+  L.NT = d.W / 32;
+  L.n_trunk = d.D + 1;                                // + xyz_encoding_final (no ReLU)
+  L.emb_steps = kStepsNerfXyz;
+  L.emb_mask = 1u | d.skip_mask;
+  L.relu_mask = (1u << d.D) - 1u;
+  switch (d.extra_feat_type) {
+    case MF_EXTRA_NONE: L.extra_steps = 0; break;
+    case MF_EXTRA_IND: L.extra_steps = kStepsInd; if (d.extra_feat_dim < 1) return false; break;
+    case MF_EXTRA_DIR: L.extra_steps = kStepsDir; if (d.extra_feat_dim < 3) return false; break;
+    default: return false;
+  }
+  int off = 0;
+  L.off_bias_trunk = off; off += L.n_trunk * L.W;
+  L.off_bias_extra = off; off += L.W / 2;
+  L.off_head_w = off; off += L.W;
+  L.off_head_b = off; off += 4;
+  L.off_rgb_w = off; off += 3 * (L.W / 2);
+  L.off_rgb_b = off; off += 4;
+  L.n_head = 1;
+  L.res_bytes = round_up((int64_t)off * 4, kGroupBytes);
+  int64_t groups = 0;
+  L.max_groups = 0;
+  for (int l = 0; l < L.n_trunk; ++l) {
+    const int g = trunk_groups(L, l);
+    groups += (int64_t)g * L.NT;
+    if (g > L.max_groups) L.max_groups = g;
+  }
+  const int ge = extra_groups(L);
+  groups += (int64_t)ge * (L.NT / 2);
+  if (ge > L.max_groups) L.max_groups = ge;
+  L.panel_bytes = groups * kGroupBytes;
+  return true;
+}
+
+inline bool nof_layout(const mf_nof_desc& d, NetLayout& L) {
+  L = NetLayout{};
+  if (d.W != 128) return false;
+  if (d.D < 2 || d.D > MF_MAX_LAYERS) return false;
+  if (d.in_channels_xyz != 33 || d.extra_feat_dim != 33) return false;   // 3*(2*5+1), 1*(2*16+1)
+  if ((d.skip_mask & 1u) || (d.skip_mask >> d.D)) return false;
+  L.W = d.W;
+  L.NT = d.W / 32;
+  L.n_trunk = d.D;
+  L.emb_steps = kStepsNofIn;
+  L.emb_mask = 1u | d.skip_mask;
+  L.relu_mask = (1u << d.D) - 1u;
+  L.extra_steps = -1;
+  L.n_head = d.use_quat ? 9 : 3;
+  int off = 0;
+  L.off_bias_trunk = off; off += L.n_trunk * L.W;
+  L.off_head_w = off; off += L.n_head * L.W;
+  L.off_head_b = off; off += 12;
+  L.res_bytes = round_up((int64_t)off * 4, kGroupBytes);
+  int64_t groups = 0;
+  L.max_groups = 0;
+  for (int l = 0; l < L.n_trunk; ++l) {
+    const int g = trunk_groups(L, l);
+    groups += (int64_t)g * L.NT;
+    if (g > L.max_groups) L.max_groups = g;
+  }
+  L.panel_bytes = groups * kGroupBytes;
+  return true;
+}
+
+}  // namespace mf

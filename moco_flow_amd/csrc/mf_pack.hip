@@ -1,0 +1,212 @@
+// mf_pack.hip -- re-order nn.Linear parameters into the MFMA fragment stream.
+//
+// Replaces nothing in the reference (it keeps (out,in) row-major tensors and calls addmm,
+// models/nerf.py:84-99, models/nof.py:70-75); this is the layout transform the fused kernels
+// need.  It is a pure permutation + zero padding: every packed float is either one source
+// weight or 0.  Group g of a panel holds, for lane (i = lane&31, h = lane>>5) and r = 0..3,
+// W[32t + i][col(step = 4g + r, h)]  -- see mf_core.hpp for the step -> column maps.
+#include "mf_host.hpp"
+#include "mf_layout.hpp"
+
+namespace mf {
+
+struct PackRegion {          // one trunk/extra layer's panels
+  const float* W;            // (n_out, n_in)
+  int n_in;
+  int tiles;                 // output tiles (n_out / 32)
+  int groups;                // groups per panel
+  int emb_steps;             // steps taken from the embedded-input block (0 if none)
+  int emb_first;             // 1: emb steps precede hidden steps (trunk); 0: follow them (extra)
+  int emb_kind;
+  int emb_col0;              // column of embedded feature 0 in W
+  int emb_cols;              // embedded columns present in W (features >= this are zero pad)
+  int hid_steps;             // NT*16 or 0
+  int hid_col0;              // column of hidden feature 0 in W
+  int xyz_cols;
+  long long dst_group0;      // first group index (in 1 KiB units) within the panel area
+};
+
+struct PackJob {
+  PackRegion reg[MF_MAX_LAYERS + 1];
+  int n_regions;
+  long long total_groups;
+  float* panels;             // packed + res_bytes
+};
+
+__global__ void pack_panels_kernel(PackJob job) {
+  const long long gidx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 slot
+  const long long grp = gidx >> 6;
+  if (grp >= job.total_groups) return;
+  const int lane = (int)(gidx & 63);
+  int ri = 0;
+  while (ri + 1 < job.n_regions && grp >= job.reg[ri + 1].dst_group0) ++ri;
+  const PackRegion& R = job.reg[ri];
+  const long long local = grp - R.dst_group0;
+  const int t = (int)(local / R.groups), g = (int)(local % R.groups);
+  const int i = lane & 31, h = lane >> 5;
+  const int n = 32 * t + i;
+  float4 v;
+  float* pv = &v.x;
+  for (int r = 0; r < 4; ++r) {
+    const int s = 4 * g + r;
+    int col = -1;
+    int se = R.emb_first ? s : s - R.hid_steps;
+    int sh = R.emb_first ? s - R.emb_steps : s;
+    if (se >= 0 && se < R.emb_steps) {
+      const int f = emb_feature(R.emb_kind, h, se, R.xyz_cols);
+      if (f >= 0 && f < R.emb_cols) col = R.emb_col0 + f;
+    } else if (sh >= 0 && sh < R.hid_steps) {
+      const int tin = sh >> 4, q = (sh >> 2) & 3, rr = sh & 3;
+      col = R.hid_col0 + 32 * tin + 8 * q + 4 * h + rr;
+    }
+    pv[r] = col >= 0 ? R.W[(long long)n * R.n_in + col] : 0.f;
+  }
+  reinterpret_cast<float4*>(job.panels)[gidx] = v;
+}
+
+struct ResCopy { const float* src; int dst_off; int n; };
+struct ResJob { ResCopy c[2 * MF_MAX_LAYERS + 8]; int n; float* res; int total; };
+
+__global__ void pack_resident_kernel(ResJob job) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= job.total) return;
+  float v = 0.f;
+  for (int k = 0; k < job.n; ++k) {
+    const int o = idx - job.c[k].dst_off;
+    if (o >= 0 && o < job.c[k].n) v = job.c[k].src[o];
+  }
+  job.res[idx] = v;
+}
+
+static int launch_pack(const PackJob& job, const ResJob& rj, hipStream_t st) {
+  const int rb = (rj.total + 255) / 256;
+  hipLaunchKernelGGL(pack_resident_kernel, dim3(rb), dim3(256), 0, st, rj);
+  const long long slots = job.total_groups * 64;
+  const int pb = (int)((slots + 255) / 256);
+  hipLaunchKernelGGL(pack_panels_kernel, dim3(pb), dim3(256), 0, st, job);
+  return check_launch("mf_pack");
+}
+
+}  // namespace mf
+
+using namespace mf;
+
+extern "C" int64_t mf_nerf_packed_bytes(const mf_nerf_desc* d) {
+  NetLayout L;
+  if (!d || !nerf_layout(*d, L)) { fail(MF_E_UNSUPPORTED, "mf_nerf_packed_bytes: unsupported NeRF configuration"); return 0; }
+  return L.res_bytes + L.panel_bytes;
+}
+
+extern "C" int64_t mf_nof_packed_bytes(const mf_nof_desc* d) {
+  NetLayout L;
+  if (!d || !nof_layout(*d, L)) { fail(MF_E_UNSUPPORTED, "mf_nof_packed_bytes: unsupported NoF configuration"); return 0; }
+  return L.res_bytes + L.panel_bytes;
+}
+
+extern "C" int32_t mf_nerf_pack(const mf_nerf_desc* d, void* packed, void* stream) {
+  NetLayout L;
+  if (!d || !packed) return fail(MF_E_INVALID, "mf_nerf_pack: null argument");
+  if (!nerf_layout(*d, L)) return fail(MF_E_UNSUPPORTED, "mf_nerf_pack: unsupported NeRF configuration "
+                                       "(W=%d D=%d in_channels_xyz=%d)", d->W, d->D, d->in_channels_xyz);
+  PackJob job{};
+  ResJob rj{};
+  long long g0 = 0;
+  int nr = 0;
+  for (int l = 0; l < L.n_trunk; ++l) {
+    PackRegion& R = job.reg[nr++];
+    const bool has_emb = (L.emb_mask >> l) & 1;
+    R.W = l < d->D ? d->trunk_w[l] : d->final_w;
+    if (!R.W) return fail(MF_E_INVALID, "mf_nerf_pack: missing weight pointer for layer %d", l);
+    R.n_in = (has_emb ? d->in_channels_xyz : 0) + (l > 0 ? L.W : 0);
+    R.tiles = L.NT;
+    R.groups = trunk_groups(L, l);
+    R.emb_steps = has_emb ? L.emb_steps : 0;
+    R.emb_first = 1;
+    R.emb_kind = kEmbNerfXyz;
+    R.emb_col0 = 0;
+    R.emb_cols = d->in_channels_xyz;
+    R.hid_steps = l > 0 ? L.NT * 16 : 0;
+    R.hid_col0 = has_emb ? d->in_channels_xyz : 0;
+    R.xyz_cols = d->in_channels_xyz;
+    R.dst_group0 = g0;
+    g0 += (long long)R.groups * R.tiles;
+    const float* b = l < d->D ? d->trunk_b[l] : d->final_b;
+    rj.c[rj.n++] = ResCopy{b, L.off_bias_trunk + l * L.W, L.W};
+  }
+  {
+    PackRegion& R = job.reg[nr++];
+    const int ext = d->extra_feat_type == MF_EXTRA_NONE ? 0 : d->extra_feat_dim;
+    R.W = d->extra_w;
+    if (!R.W) return fail(MF_E_INVALID, "mf_nerf_pack: missing extra_encoding weight");
+    R.n_in = L.W + ext;
+    R.tiles = L.NT / 2;
+    R.groups = extra_groups(L);
+    R.emb_steps = L.extra_steps;
+    R.emb_first = 0;
+    R.emb_kind = d->extra_feat_type == MF_EXTRA_DIR ? kEmbDir : (d->extra_feat_type == MF_EXTRA_IND ? kEmbInd : kEmbNone);
+    R.emb_col0 = L.W;
+    R.emb_cols = ext;
+    R.hid_steps = L.NT * 16;
+    R.hid_col0 = 0;
+    R.xyz_cols = 0;
+    R.dst_group0 = g0;
+    g0 += (long long)R.groups * R.tiles;
+    rj.c[rj.n++] = ResCopy{d->extra_b, L.off_bias_extra, L.W / 2};
+  }
+  rj.c[rj.n++] = ResCopy{d->sigma_w, L.off_head_w, L.W};
+  rj.c[rj.n++] = ResCopy{d->sigma_b, L.off_head_b, 1};
+  rj.c[rj.n++] = ResCopy{d->rgb_w, L.off_rgb_w, 3 * (L.W / 2)};
+  rj.c[rj.n++] = ResCopy{d->rgb_b, L.off_rgb_b, 3};
+  for (int k = 0; k < rj.n; ++k)
+    if (!rj.c[k].src) return fail(MF_E_INVALID, "mf_nerf_pack: missing bias/head pointer (%d)", k);
+  job.n_regions = nr;
+  job.total_groups = g0;
+  job.panels = reinterpret_cast<float*>(static_cast<char*>(packed) + L.res_bytes);
+  rj.res = static_cast<float*>(packed);
+  rj.total = (int)(L.res_bytes / 4);
+  if (g0 * kGroupBytes != L.panel_bytes) return fail(MF_E_INVALID, "mf_nerf_pack: layout mismatch");
+  return launch_pack(job, rj, static_cast<hipStream_t>(stream));
+}
+
+extern "C" int32_t mf_nof_pack(const mf_nof_desc* d, void* packed, void* stream) {
+  NetLayout L;
+  if (!d || !packed) return fail(MF_E_INVALID, "mf_nof_pack: null argument");
+  if (!nof_layout(*d, L)) return fail(MF_E_UNSUPPORTED, "mf_nof_pack: unsupported NoF configuration "
+                                      "(W=%d D=%d in_channels_xyz=%d extra_feat_dim=%d)", d->W, d->D,
+                                      d->in_channels_xyz, d->extra_feat_dim);
+  PackJob job{};
+  ResJob rj{};
+  long long g0 = 0;
+  int nr = 0;
+  const int cin = d->in_channels_xyz + d->extra_feat_dim;
+  for (int l = 0; l < L.n_trunk; ++l) {
+    PackRegion& R = job.reg[nr++];
+    const bool has_emb = (L.emb_mask >> l) & 1;
+    R.W = d->trunk_w[l];
+    if (!R.W || !d->trunk_b[l]) return fail(MF_E_INVALID, "mf_nof_pack: missing parameter pointer for layer %d", l);
+    R.n_in = (has_emb ? cin : 0) + (l > 0 ? L.W : 0);
+    R.tiles = L.NT;
+    R.groups = trunk_groups(L, l);
+    R.emb_steps = has_emb ? L.emb_steps : 0;
+    R.emb_first = 1;
+    R.emb_kind = kEmbNofIn;
+    R.emb_col0 = 0;
+    R.emb_cols = cin;
+    R.hid_steps = l > 0 ? L.NT * 16 : 0;
+    R.hid_col0 = has_emb ? cin : 0;
+    R.xyz_cols = d->in_channels_xyz;
+    R.dst_group0 = g0;
+    g0 += (long long)R.groups * R.tiles;
+    rj.c[rj.n++] = ResCopy{d->trunk_b[l], L.off_bias_trunk + l * L.W, L.W};
+  }
+  if (!d->head_w || !d->head_b) return fail(MF_E_INVALID, "mf_nof_pack: missing head parameters");
+  rj.c[rj.n++] = ResCopy{d->head_w, L.off_head_w, L.n_head * L.W};
+  rj.c[rj.n++] = ResCopy{d->head_b, L.off_head_b, L.n_head};
+  job.n_regions = nr;
+  job.total_groups = g0;
+  job.panels = reinterpret_cast<float*>(static_cast<char*>(packed) + L.res_bytes);
+  rj.res = static_cast<float*>(packed);
+  rj.total = (int)(L.res_bytes / 4);
+  if (g0 * kGroupBytes != L.panel_bytes) return fail(MF_E_INVALID, "mf_nof_pack: layout mismatch");
+  return launch_pack(job, rj, static_cast<hipStream_t>(stream));
+}

@@ -1,0 +1,340 @@
+// mf_render.hip -- one fused rendering pass of render_rays (models/rendering.py:195-375):
+//
+//   ray -> z (rendering.py:245-251) -> xyz (:262-263)
+//       -> [bw NoF -> canonical xyz, fw NoF chains for the consensus terms (:270-286, :49-83)]
+//       -> positional encoding (embedding.py:42-46) -> NeRF MLP (nerf.py:78-102)
+//       -> sigma -> alpha -> exclusive transmittance scan -> rgb / depth / opacity (:157-192)
+//
+// in ONE kernel launch.  Nothing between the input rays and the output pixels is written to
+// HBM except the optional (N,S) planes a caller asks for (weights/alphas feed sample_pdf and the
+// consensus mask; disp_* are the per-sample consensus distances).
+//
+// Work decomposition: a workgroup (4 waves, one per SIMD, up to 512 VGPRs each) takes a GROUP
+// of G whole rays (G*S samples, a multiple of 128 whenever S allows), walks it in tiles of 128
+// samples -- 32 per wave, one sample per lane&31, the two lane halves holding the two k-halves
+// of every MFMA step -- and keeps each sample's (r,g,b,sigma,z) in LDS until the group's rays
+// are composited by one wave per ray with a wavefront product-scan.  Workgroups are persistent
+// (grid = #CUs) so the weight stream never drains between tiles.
+#include "mf_host.hpp"
+#include "mf_layout.hpp"
+#include "mf_nets.hpp"
+
+namespace mf {
+
+struct RenderParams {
+  const float* rays; long long ray_stride; long long n_rays;
+  const float* bg;
+  int S;
+  const float* z_vals; const float* z_steps; int use_disp;
+  const float* noise;
+  int activation, flags;
+  NetDev nerf;
+  EmbParams exyz, eext;
+  int extra_type;
+  NetDev bw, fw;
+  EmbParams nxyz, nind;
+  float *rgb, *depth, *opacity, *weights, *alphas, *disp_local, *disp_global;
+  int G;
+  long long n_groups;
+  uint32_t ring_off, buf_bytes, sbuf_off, zbuf_off;
+};
+
+// inclusive product scan across the 64 lanes of a wave
+MF_D float wave_scan_mul(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(v, d, 64);
+    if (lane >= d) v *= o;
+  }
+  return v;
+}
+MF_D float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+template <bool MOCO>
+__global__ __launch_bounds__(256, 1) void render_kernel(RenderParams p) {
+  const LaneId id;
+  const NetDev nerf = p.nerf;
+  load_resident(nerf, id);
+  if (MOCO) {
+    load_resident(p.bw, id);
+    if (p.flags & (MF_F_CHAIN_LOCAL | MF_F_CHAIN_GLOBAL)) load_resident(p.fw, id);
+  }
+  Stream st;
+  st.ring = p.ring_off;
+  st.buf_bytes = p.buf_bytes;
+  const char* prog_first = MOCO ? first_panel(p.bw) : first_panel(nerf);
+  const int prog_first_groups = MOCO ? first_groups(p.bw) : first_groups(nerf);
+  st.start(prog_first, prog_first_groups, id);
+
+  const int S = p.S;
+  const bool sigma_only = p.flags & MF_F_SIGMA_ONLY;
+  float4* sbuf = reinterpret_cast<float4*>(smem + p.sbuf_off);
+  float* zbuf = reinterpret_cast<float*>(smem + p.zbuf_off);
+
+  for (long long group = blockIdx.x; group < p.n_groups; group += gridDim.x) {
+    const long long ray0 = group * p.G;
+    const int nr = (int)((p.n_rays - ray0) < p.G ? (p.n_rays - ray0) : p.G);
+    const int nsamp = nr * S;
+    const int ntiles = (nsamp + kTile - 1) / kTile;
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+      const int srel = tile * kTile + id.wave * 32 + id.j;
+      const bool valid = srel < nsamp;
+      const int sl = valid ? srel : nsamp - 1;
+      const int rr = sl / S;
+      const int si = sl - rr * S;
+      const long long ray = ray0 + rr;
+      const float* rp = p.rays + ray * p.ray_stride;
+      const float o[3] = {rp[0], rp[1], rp[2]};
+      const float d[3] = {rp[3], rp[4], rp[5]};
+      float z;
+      if (p.z_vals) {
+        z = p.z_vals[ray * S + si];
+      } else {
+        const float nearv = rp[6], farv = rp[7], t = p.z_steps[si];
+        if (!p.use_disp) z = nearv * (1.f - t) + farv * t;                    // rendering.py:247
+        else z = 1.f / (1.f / nearv * (1.f - t) + 1.f / farv * t);            // rendering.py:249
+      }
+      float x[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) x[c] = o[c] + d[c] * z;                      // rendering.py:262-263
+
+      float xin[3] = {x[0], x[1], x[2]};      // what the canonical NeRF sees
+      if (MOCO) {
+        // chain program (rendering.py:270-282): step 0 bw(x,i) -> canon; local: fw(canon,i) -> recon;
+        // global: fw(canon,j) -> a; bw(a,j) -> b; fw(b,i) -> chained recon.
+        const float ind_i = rp[8];
+        const float ind_j = (p.flags & MF_F_CHAIN_GLOBAL) ? rp[9] : 0.f;
+        const bool loc = p.flags & MF_F_CHAIN_LOCAL, glob = p.flags & MF_F_CHAIN_GLOBAL;
+        const int nsteps = 1 + (loc ? 1 : 0) + (glob ? 3 : 0);
+        float canon[3] = {0.f, 0.f, 0.f}, cur[3] = {x[0], x[1], x[2]};
+        float dl = 0.f, dg = 0.f;
+        for (int step = 0; step < nsteps; ++step) {
+          // role of this step: 0 = bw_i, 1 = local fw_i, 2 = fw_j, 3 = bw_j, 4 = final fw_i
+          // (chain_global implies chain_local -- checked on the host -- so role == step)
+          const int role = step;
+          const bool use_fw = (role == 1 || role == 2 || role == 4);
+          const NetDev net = use_fw ? p.fw : p.bw;
+          const float ind = (role == 2 || role == 3) ? ind_j : ind_i;
+          if (role == 1 || role == 2) { cur[0] = canon[0]; cur[1] = canon[1]; cur[2] = canon[2]; }
+          // what follows this evaluation in the panel program
+          const bool last = step == nsteps - 1;
+          const bool next_fw = (role + 1 == 1 || role + 1 == 2 || role + 1 == 4);
+          const char* follow = last ? first_panel(nerf) : (next_fw ? first_panel(p.fw) : first_panel(p.bw));
+          const int follow_groups = last ? first_groups(nerf) : (next_fw ? first_groups(p.fw) : first_groups(p.bw));
+          float emb[kStepsNofIn], out[3];
+          nof_embed(emb, cur, ind, p.nxyz, p.nind, id.h);
+          nof_eval(net, emb, cur, st, id, follow, follow_groups, out);
+          if (role == 0) { canon[0] = out[0]; canon[1] = out[1]; canon[2] = out[2]; }
+          if (role == 1) dl = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
+          if (role == 4) dg = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
+          cur[0] = out[0]; cur[1] = out[1]; cur[2] = out[2];
+        }
+        xin[0] = canon[0]; xin[1] = canon[1]; xin[2] = canon[2];
+        if (valid && id.h == 0) {
+          if (loc && p.disp_local) p.disp_local[ray * S + si] = dl;
+          if (glob && p.disp_global) p.disp_global[ray * S + si] = dg;
+        }
+      }
+
+      float embx[kStepsNerfXyz], ext[kStepsExtraMax];
+      emb_eval<3, 10>(embx, xin, p.exyz, id.h);
+#pragma unroll
+      for (int e = BlkXyz10::SLOTS; e < kStepsNerfXyz; ++e) embx[e] = 0.f;
+#pragma unroll
+      for (int e = 0; e < kStepsExtraMax; ++e) ext[e] = 0.f;
+      if (!sigma_only) {
+        if (p.extra_type == MF_EXTRA_DIR) {
+          emb_eval<3, 4>(ext, d, p.eext, id.h);                                // rendering.py:138-142
+        } else if (p.extra_type == MF_EXTRA_IND) {
+          const float iv[1] = {rp[8]};
+          emb_eval<1, 2>(ext, iv, p.eext, id.h);                               // rendering.py:133-137
+        }
+      }
+      float sigma, rgb[3] = {0.f, 0.f, 0.f};
+      nerf_eval<8>(nerf, embx, ext, sigma_only, st, id, prog_first, prog_first_groups, sigma, rgb);
+      if (valid && id.h == 0) {
+        sbuf[srel] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
+        zbuf[srel] = z;
+      }
+    }
+    __syncthreads();
+
+    // ---- composite (rendering.py:157-192): one wave per ray, lanes over samples
+    for (int rr = id.wave; rr < nr; rr += kWaves) {
+      const long long ray = ray0 + rr;
+      const float* rp = p.rays + ray * p.ray_stride;
+      const float dnorm = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);  // rendering.py:164
+      float carry = 1.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_w = 0.f;
+      for (int base = 0; base < S; base += 64) {
+        const int i = base + id.lane;
+        const bool v = i < S;
+        const int ii = v ? i : S - 1;
+        const float4 s4 = sbuf[rr * S + ii];
+        const float z = zbuf[rr * S + ii];
+        const float znext = zbuf[rr * S + (ii + 1 < S ? ii + 1 : ii)];
+        float delta = (ii == S - 1) ? 1e10f : znext - z;                       // :158-160
+        delta = delta * dnorm;
+        float sg = s4.w;
+        if (p.noise) sg = sg + p.noise[ray * S + ii];                          // :166 (pre-scaled)
+        float a;
+        if (p.activation == MF_ACT_RELU) a = fmaxf(sg, 0.f);
+        else a = sg > 20.f ? sg : log1pf(expf(sg));                            // nn.Softplus(beta=1, threshold=20)
+        float alpha = 1.f - expf(-delta * a);                                  // :170/172
+        if (!v) alpha = 0.f;
+        const float pt = v ? (1.f - alpha) + 1e-10f : 1.f;                     // :176-177
+        const float incl = wave_scan_mul(pt, id.lane);
+        float excl = __shfl_up(incl, 1, 64);
+        if (id.lane == 0) excl = 1.f;
+        const float w = alpha * (carry * excl);                                // :178-179
+        carry = carry * __shfl(incl, 63, 64);
+        if (v) {
+          if (p.weights) p.weights[ray * S + i] = w;
+          if (p.alphas) p.alphas[ray * S + i] = alpha;
+          acc_w += w;
+          acc_r += w * s4.x; acc_g += w * s4.y; acc_b += w * s4.z;
+          acc_d += w * z;
+        }
+      }
+      acc_w = wave_sum(acc_w);                                                 // :180
+      if (!sigma_only) {
+        acc_r = wave_sum(acc_r); acc_g = wave_sum(acc_g); acc_b = wave_sum(acc_b);   // :186
+        acc_d = wave_sum(acc_d);                                               // :187
+      }
+      if (id.lane == 0) {
+        if (p.opacity) p.opacity[ray] = acc_w;
+        if (!sigma_only) {
+          if (p.bg) {                                                          // :189-190
+            const float k = 1.f - acc_w;
+            acc_r = acc_r + p.bg[ray * 3 + 0] * k;
+            acc_g = acc_g + p.bg[ray * 3 + 1] * k;
+            acc_b = acc_b + p.bg[ray * 3 + 2] * k;
+          }
+          if (p.rgb) { p.rgb[ray * 3 + 0] = acc_r; p.rgb[ray * 3 + 1] = acc_g; p.rgb[ray * 3 + 2] = acc_b; }
+          if (p.depth) p.depth[ray] = acc_d;
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+static void to_params(const mf_embedding& e, EmbParams& o) {
+  for (int k = 0; k < 16; ++k) {
+    o.freq[k] = k < e.n_freqs ? e.freq[k] : 0.f;
+    o.weight[k] = k < e.n_freqs ? e.weight[k] : 0.f;
+  }
+}
+
+int device_cus();   // mf_forward.hip
+
+}  // namespace mf
+
+using namespace mf;
+
+extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
+  if (!a || !a->nerf || !a->nerf_packed) return fail(MF_E_INVALID, "mf_render_pass: null argument");
+  if (a->n_rays < 0 || a->n_samples < 1) return fail(MF_E_INVALID, "mf_render_pass: n_rays=%lld n_samples=%d",
+                                                    (long long)a->n_rays, a->n_samples);
+  if (a->n_rays == 0) return MF_OK;
+  if (!a->rays || a->ray_stride < 9) return fail(MF_E_INVALID, "mf_render_pass: rays missing or ray_stride < 9");
+  if (!a->z_vals && !a->z_steps) return fail(MF_E_INVALID, "mf_render_pass: need z_vals or z_steps");
+  if (a->activation != MF_ACT_RELU && a->activation != MF_ACT_SOFTPLUS)
+    return fail(MF_E_INVALID, "mf_render_pass: activation %d not supported", a->activation);
+  RenderParams p{};
+  if (!nerf_layout(*a->nerf, p.nerf.L)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported NeRF configuration");
+  if (p.nerf.L.NT != 8) return fail(MF_E_UNSUPPORTED, "mf_render_pass: only W=256 NeRF is built");
+  if (a->emb_xyz.in_channels != 3 || a->emb_xyz.n_freqs > 10)
+    return fail(MF_E_UNSUPPORTED, "mf_render_pass: xyz embedding must have 3 channels and <= 10 frequencies");
+  const bool sigma_only = a->flags & MF_F_SIGMA_ONLY;
+  if (!sigma_only && a->nerf->extra_feat_type == MF_EXTRA_DIR &&
+      (a->emb_extra.in_channels != 3 || a->emb_extra.n_freqs > 4 ||
+       3 * (2 * a->emb_extra.n_freqs + 1) > a->nerf->extra_feat_dim))
+    return fail(MF_E_UNSUPPORTED, "mf_render_pass: dir embedding must have 3 channels, <= 4 frequencies and fit extra_feat_dim");
+  if (!sigma_only && a->nerf->extra_feat_type == MF_EXTRA_IND &&
+      (a->emb_extra.in_channels != 1 || a->emb_extra.n_freqs > 2 ||
+       (2 * a->emb_extra.n_freqs + 1) > a->nerf->extra_feat_dim))
+    return fail(MF_E_UNSUPPORTED, "mf_render_pass: ind embedding must have 1 channel, <= 2 frequencies and fit extra_feat_dim");
+  const bool moco = a->nof_bw != nullptr;
+  const bool chains = a->flags & (MF_F_CHAIN_LOCAL | MF_F_CHAIN_GLOBAL);
+  if (!moco && chains) return fail(MF_E_INVALID, "mf_render_pass: chain flags need NoF models");
+  if ((a->flags & MF_F_CHAIN_GLOBAL) && !(a->flags & MF_F_CHAIN_LOCAL))
+    return fail(MF_E_INVALID, "mf_render_pass: chain_global without chain_local (the reference raises UnboundLocalError, rendering.py:276-280)");
+  if ((a->flags & MF_F_CHAIN_GLOBAL) && a->ray_stride < 10)
+    return fail(MF_E_INVALID, "mf_render_pass: chain_global needs the chained image index column (ray_stride >= 10)");
+
+  p.rays = a->rays; p.ray_stride = a->ray_stride; p.n_rays = a->n_rays; p.bg = a->background;
+  p.S = a->n_samples; p.z_vals = a->z_vals; p.z_steps = a->z_steps; p.use_disp = a->use_disp;
+  p.noise = a->noise; p.activation = a->activation; p.flags = a->flags;
+  p.nerf.packed = static_cast<const char*>(a->nerf_packed);
+  to_params(a->emb_xyz, p.exyz);
+  to_params(a->emb_extra, p.eext);
+  p.extra_type = a->nerf->extra_feat_type;
+  p.rgb = a->rgb; p.depth = a->depth; p.opacity = a->opacity; p.weights = a->weights; p.alphas = a->alphas;
+  p.disp_local = a->disp_local; p.disp_global = a->disp_global;
+
+  uint32_t lds = 0;
+  p.nerf.res_lds = lds; lds += (uint32_t)p.nerf.L.res_bytes;
+  int max_groups = p.nerf.L.max_groups;
+  if (moco) {
+    if (!a->nof_bw_packed) return fail(MF_E_INVALID, "mf_render_pass: nof_bw_packed missing");
+    if (!nof_layout(*a->nof_bw, p.bw.L)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported backward NoF configuration");
+    p.bw.packed = static_cast<const char*>(a->nof_bw_packed);
+    p.bw.res_lds = lds; lds += (uint32_t)p.bw.L.res_bytes;
+    if (p.bw.L.max_groups > max_groups) max_groups = p.bw.L.max_groups;
+    if (chains) {
+      if (!a->nof_fw || !a->nof_fw_packed) return fail(MF_E_INVALID, "mf_render_pass: chain flags need the forward NoF");
+      if (!nof_layout(*a->nof_fw, p.fw.L)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported forward NoF configuration");
+      p.fw.packed = static_cast<const char*>(a->nof_fw_packed);
+      p.fw.res_lds = lds; lds += (uint32_t)p.fw.L.res_bytes;
+      if (p.fw.L.max_groups > max_groups) max_groups = p.fw.L.max_groups;
+    }
+    if (a->nof_emb_xyz.in_channels != 3 || a->nof_emb_xyz.n_freqs > 5 || a->nof_emb_ind.in_channels != 1 ||
+        a->nof_emb_ind.n_freqs != 16)
+      return fail(MF_E_UNSUPPORTED, "mf_render_pass: NoF embeddings must be xyz(3, <=5 freqs) and ind(1, 16 freqs)");
+    to_params(a->nof_emb_xyz, p.nxyz);
+    to_params(a->nof_emb_ind, p.nind);
+  }
+  p.ring_off = lds;
+  p.buf_bytes = (uint32_t)max_groups * kGroupBytes;
+  lds += 2 * p.buf_bytes;
+
+  // rays per group: smallest G with G*S a multiple of the 128-sample tile, capped by the LDS left
+  const uint32_t lds_cap = 160 * 1024;
+  const int max_samples = (int)((lds_cap - lds) / 20);
+  const int S = a->n_samples;
+  if (S > max_samples) return fail(MF_E_UNSUPPORTED, "mf_render_pass: n_samples=%d exceeds the %d samples a workgroup can stage", S, max_samples);
+  int G = 1;
+  while ((G * S) % kTile != 0 && (G + 1) * S <= max_samples && G < 64) ++G;
+  if ((G * S) % kTile != 0) {           // no exact fit: take as many rays as reduce the padding waste
+    int best = 1; double best_eff = 0;
+    for (int g = 1; g * S <= max_samples && g <= 64; ++g) {
+      const int tiles = (g * S + kTile - 1) / kTile;
+      const double eff = (double)(g * S) / (tiles * kTile);
+      if (eff > best_eff + 1e-9) { best_eff = eff; best = g; }
+    }
+    G = best;
+  }
+  p.G = G;
+  p.n_groups = (a->n_rays + G - 1) / G;
+  p.sbuf_off = lds; lds += (uint32_t)(G * S) * 16;
+  p.zbuf_off = lds; lds += (uint32_t)(G * S) * 4;
+  lds = (lds + 15u) & ~15u;
+
+  const int grid = (int)(p.n_groups < device_cus() ? p.n_groups : device_cus());
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (moco) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(render_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);
+    hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(256), lds, st, p);
+  } else {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(render_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);
+    hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(256), lds, st, p);
+  }
+  return check_launch("mf_render_pass");
+}

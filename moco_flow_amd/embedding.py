@@ -1,0 +1,58 @@
+"""Drop-in for /root/reference/models/embedding.py (class Embedding, :4-47)."""
+import torch
+from torch import nn
+
+from . import _lib as L
+
+
+class Embedding(nn.Module):
+    """x -> (x, w0 sin(f0 x), w0 cos(f0 x), w1 sin(f1 x), ...).
+
+    Same constructor, attributes (N_freqs, in_channels, out_channels, freq_bands,
+    weights, funcs) and ``set_weights`` contract as the reference; no parameters or
+    buffers, hence no state_dict entries. ``forward`` runs mf_embedding_forward."""
+
+    def __init__(self, in_channels, N_freqs, logscale=True):
+        super().__init__()
+        self.N_freqs = N_freqs
+        self.in_channels = in_channels
+        self.funcs = [torch.sin, torch.cos]
+        self.out_channels = in_channels * (len(self.funcs) * N_freqs + 1)
+        self.weights = [1] * N_freqs
+        if logscale:
+            self.freq_bands = 2 ** torch.linspace(0, N_freqs - 1, N_freqs)
+        else:
+            self.freq_bands = torch.linspace(1, 2 ** (N_freqs - 1), N_freqs)
+
+    def set_weights(self, weights):
+        if isinstance(weights, int):
+            self.weights = [weights] * self.N_freqs
+        else:
+            assert len(weights) == self.N_freqs
+            self.weights = weights
+
+    def descriptor(self) -> "L.mf_embedding":
+        if self.N_freqs > L.MF_MAX_FREQS:
+            raise NotImplementedError(f"Embedding with N_freqs={self.N_freqs} > {L.MF_MAX_FREQS} is not built")
+        d = L.mf_embedding()
+        d.in_channels = self.in_channels
+        d.n_freqs = self.N_freqs
+        for k in range(self.N_freqs):
+            d.freq[k] = float(self.freq_bands[k])
+            d.weight[k] = float(self.weights[k])
+        return d
+
+    def forward(self, x):
+        L.require_gpu(x, "Embedding.forward")
+        if x.dim() != 2 or x.shape[1] != self.in_channels:
+            raise RuntimeError(f"Embedding expects (B, {self.in_channels}), got {tuple(x.shape)}")
+        if torch.is_grad_enabled() and x.requires_grad:
+            raise NotImplementedError("moco_flow_amd: backward through the HIP embedding is not built yet "
+                                      "(SURVEY.md §8f-1); call under torch.no_grad()")
+        xc = x.detach().contiguous().float()
+        out = torch.empty((x.shape[0], self.out_channels), device=x.device, dtype=torch.float32)
+        d = self.descriptor()
+        with torch.cuda.device(x.device):
+            L.check(L.lib().mf_embedding_forward(d, L.ptr(xc), x.shape[0], L.ptr(out),
+                                                 L.current_stream(x.device)), "mf_embedding_forward")
+        return out

@@ -1,0 +1,42 @@
+"""Packed-weights cache: nn.Linear tensors -> the kernels' MFMA fragment stream.
+
+The packed buffer is rebuilt whenever any parameter's storage pointer or version
+counter changes (optimizer.step, load_state_dict, .to(device))."""
+import torch
+
+from . import _lib as L
+
+
+def _grad_guard(module, what):
+    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
+        raise NotImplementedError(
+            f"moco_flow_amd.{what}: the backward pass of the fused HIP path is not built yet "
+            "(SURVEY.md §8f-1). Call under torch.no_grad() (or freeze the parameters).")
+
+
+class PackedWeights:
+    def __init__(self):
+        self.key = None
+        self.buf = None
+        self.desc = None
+        self.keep = None   # contiguous fp32 views the descriptor points into
+
+    def get(self, module, build_desc, bytes_fn, pack_fn, what):
+        params = list(module.parameters())
+        if not params:
+            raise RuntimeError(f"{what}: module has no parameters")
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError(f"moco_flow_amd.{what}: parameters are on '{dev}'. This is the MI355X (HIP) "
+                               "path; there is no CPU implementation. Call .to('cuda') first.")
+        key = tuple((p.data_ptr(), p._version, p.dtype) for p in params)
+        if key != self.key:
+            desc, keep = build_desc()
+            nbytes = bytes_fn(desc)
+            if nbytes <= 0:
+                L.check(-3, what)
+            buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+            with torch.cuda.device(dev):
+                L.check(pack_fn(desc, buf.data_ptr(), L.current_stream(dev)), what + " pack")
+            self.key, self.buf, self.desc, self.keep = key, buf, desc, keep
+        return self.desc, self.buf

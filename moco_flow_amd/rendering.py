@@ -1,0 +1,259 @@
+"""Drop-in for /root/reference/models/rendering.py: ``render_rays`` (:195-375) and
+``sample_pdf`` (:5-46) with the reference's signatures, running on the HIP path.
+
+Each pass (coarse, fine) is ONE fused kernel launch (mf_render_pass): ray -> depths ->
+points -> [NoF chains] -> encoding -> NeRF -> composite. The hierarchical resample is one
+launch (mf_sample_pdf_merge) and the consensus-mask compaction three tiny ones
+(mf_compact_mask). Random draws (perturb / noise / stochastic resampling) are made here
+with torch, in the reference's order, and handed to the kernels, which stay deterministic.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+from .packing import _grad_guard
+
+# Draw torch.randn(N,S) in every pass even when noise_std == 0, as the reference does
+# (rendering.py:166), so that the device RNG stream advances identically.
+STRICT_RNG = True
+
+
+def _emb_desc(e):
+    return e.descriptor() if e is not None else L.mf_embedding()
+
+
+def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation, nerf, nerf_embs,
+                 nof_models, nof_embs, chain_local, chain_global, sigma_only, want_planes):
+    """One mf_render_pass call. Returns dict of fresh tensors."""
+    dev = rays.device
+    N = rays.shape[0]
+    S = z_vals.shape[1] if z_vals is not None else z_steps.shape[0]
+    a = L.mf_render_args()
+    a.rays, a.ray_stride, a.n_rays = L.ptr(rays), rays.stride(0), N
+    a.background = L.ptr(background)
+    a.n_samples = S
+    a.z_vals, a.z_steps, a.use_disp = L.ptr(z_vals), L.ptr(z_steps), 1 if use_disp else 0
+    a.noise = L.ptr(noise)
+    a.activation = activation
+    flags = 0
+    if sigma_only:
+        flags |= L.MF_F_SIGMA_ONLY
+    if chain_local:
+        flags |= L.MF_F_CHAIN_LOCAL
+    if chain_global:
+        flags |= L.MF_F_CHAIN_GLOBAL
+    a.flags = flags
+    desc, buf = nerf.packed()
+    a.nerf, a.nerf_packed = C.pointer(desc), buf.data_ptr()
+    a.emb_xyz = _emb_desc(nerf_embs[0])
+    if nerf.extra_feat_type == "ind":
+        a.emb_extra = _emb_desc(nerf_embs[1])
+    elif nerf.extra_feat_type == "dir":
+        a.emb_extra = _emb_desc(nerf_embs[2])
+    keep = [desc, buf]
+    if nof_models is not None:
+        bd, bb = nof_models[0].packed()
+        a.nof_bw, a.nof_bw_packed = C.pointer(bd), bb.data_ptr()
+        keep += [bd, bb]
+        if chain_local or chain_global:
+            fd, fb = nof_models[1].packed()
+            a.nof_fw, a.nof_fw_packed = C.pointer(fd), fb.data_ptr()
+            keep += [fd, fb]
+        a.nof_emb_xyz, a.nof_emb_ind = _emb_desc(nof_embs[0]), _emb_desc(nof_embs[1])
+    out = {}
+
+    def alloc(name, shape, cond=True):
+        if cond:
+            out[name] = torch.empty(shape, device=dev, dtype=torch.float32)
+            return out[name].data_ptr()
+        return None
+
+    a.rgb = alloc("rgb", (N, 3), not sigma_only)
+    a.depth = alloc("depth", (N,), not sigma_only)
+    a.opacity = alloc("opacity", (N,))
+    a.weights = alloc("weights", (N, S), want_planes)
+    a.alphas = alloc("alphas", (N, S), want_planes)
+    a.disp_local = alloc("disp_local", (N, S), chain_local)
+    a.disp_global = alloc("disp_global", (N, S), chain_global)
+    with torch.cuda.device(dev):
+        L.check(L.lib().mf_render_pass(C.byref(a), L.current_stream(dev)), "mf_render_pass")
+    del keep
+    return out
+
+
+def _compact(alphas, vals_a, vals_b):
+    """rendering.py:306-314: (vals[mask] for mask = alphas >= 0.01, all-true if empty)."""
+    dev = alphas.device
+    N, S = alphas.shape
+    lib = L.lib()
+    scratch = torch.empty(int(lib.mf_compact_scratch_bytes(N)), dtype=torch.uint8, device=dev)
+    count = torch.zeros(1, dtype=torch.int64, device=dev)
+    oa = torch.empty(N * S, device=dev, dtype=torch.float32) if vals_a is not None else None
+    ob = torch.empty(N * S, device=dev, dtype=torch.float32) if vals_b is not None else None
+    with torch.cuda.device(dev):
+        L.check(lib.mf_compact_mask(L.ptr(alphas), L.ptr(vals_a), L.ptr(vals_b), N, S, L.ptr(oa), L.ptr(ob),
+                                    count.data_ptr(), scratch.data_ptr(), L.current_stream(dev)), "mf_compact_mask")
+    n = int(count.item())   # data-dependent length, as in the reference's boolean indexing
+    return (oa[:n] if oa is not None else None), (ob[:n] if ob is not None else None)
+
+
+def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
+    """Reference signature (rendering.py:5-46): bins (N, nb), weights (N, nb-1) -> (N, N_importance).
+    (render_rays itself uses the fused form, ``resample_merge``.)"""
+    L.require_gpu(bins, "sample_pdf")
+    if eps != 1e-5:
+        raise NotImplementedError("sample_pdf: only eps=1e-5 (the reference's only call value) is built")
+    dev = bins.device
+    N, nb = bins.shape
+    if weights.shape != (N, nb - 1):
+        raise RuntimeError(f"sample_pdf: weights must be (N, {nb - 1}), got {tuple(weights.shape)}")
+    M = N_importance
+    if det:
+        u, u_stride = torch.linspace(0, 1, M, device=dev), 0
+    else:
+        u, u_stride = torch.rand(N, M, device=dev), M
+    b = bins.detach().contiguous().float()
+    w = weights.detach().contiguous().float()
+    out = torch.empty((N, M), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        L.check(L.lib().mf_sample_pdf(L.ptr(b), None, L.ptr(w), nb - 1, N, nb, M, L.ptr(u), u_stride, None,
+                                      L.ptr(out), None, None, L.current_stream(dev)), "mf_sample_pdf")
+    return out
+
+
+def resample_merge(z_vals, weights, N_importance, det=True, u=None, return_aux=False, cdf=None):
+    """sample_pdf(z_mid, weights[:,1:-1]) + cat + sort of render_rays (rendering.py:321-326)
+    as one HIP launch. z_vals, weights: (N,S). Returns the sorted (N, S+M) depths."""
+    L.require_gpu(z_vals, "resample_merge")
+    dev = z_vals.device
+    N, S = z_vals.shape
+    M = N_importance
+    if u is None:
+        if det:
+            u = torch.linspace(0, 1, M, device=dev)
+            u_stride = 0
+        else:
+            u = torch.rand(N, M, device=dev)
+            u_stride = M
+    else:
+        u = u.contiguous().float()
+        u_stride = M if u.dim() == 2 else 0
+    if cdf is not None:
+        cdf = cdf.detach().contiguous().float()
+    z = z_vals.detach().contiguous().float()
+    w = weights.detach().contiguous().float()
+    z_out = torch.empty((N, S + M), device=dev, dtype=torch.float32)
+    inds = torch.empty((N, M), device=dev, dtype=torch.int32) if return_aux else None
+    z_new = torch.empty((N, M), device=dev, dtype=torch.float32) if return_aux else None
+    with torch.cuda.device(dev):
+        L.check(L.lib().mf_sample_pdf(None, L.ptr(z), w.data_ptr() + 4, S, N, S - 1, M, L.ptr(u), u_stride,
+                                      L.ptr(cdf), L.ptr(z_new), L.ptr(inds), L.ptr(z_out),
+                                      L.current_stream(dev)), "mf_sample_pdf")
+    if return_aux:
+        return z_out, inds, z_new
+    return z_out
+
+
+def render_rays(rays,
+                background,
+                nerf_embeddings,
+                nerf_models,
+                nof_embeddings=None,
+                nof_models=None,
+                chain_local=False,
+                chain_global=False,
+                N_samples=64,
+                N_importance=0,
+                use_disp=False,
+                perturb=0,
+                noise_std=1,
+                nerf_activate_type='relu',
+                test_time=False,
+                ):
+    """Same contract as the reference's render_rays (rendering.py:195-375): rays (N, 9|10),
+    background (N,3)|None -> dict with rgb/depth/opacity_{coarse,fine} and, in training with NoF,
+    nof_{local,global}_disp_{coarse,fine}."""
+    L.require_gpu(rays, "render_rays")
+    if nerf_activate_type == 'relu':
+        act = L.MF_ACT_RELU
+    elif nerf_activate_type == 'softplus':
+        act = L.MF_ACT_SOFTPLUS
+    else:
+        raise ValueError('activation layer type: %s not support' % nerf_activate_type)   # rendering.py:174
+    use_nof = nof_models is not None
+    if use_nof and chain_global and not chain_local and not test_time:
+        # rendering.py:276-280: fw_nof is only bound under chain_local
+        raise UnboundLocalError("local variable 'fw_nof' referenced before assignment")
+    for m in list(nerf_models) + (list(nof_models) if use_nof else []):
+        _grad_guard(m, "render_rays")
+    dev = rays.device
+    rays = rays.detach().float()
+    if rays.dim() != 2 or rays.shape[1] < (10 if (use_nof and chain_global) else 9):
+        raise RuntimeError(f"render_rays: rays must be (N, 9|10), got {tuple(rays.shape)}")
+    if rays.stride(1) != 1:
+        rays = rays.contiguous()
+    if background is not None:
+        background = background.detach().float().contiguous()
+    N = rays.shape[0]
+    S = N_samples
+    loc = bool(use_nof and chain_local and not test_time)
+    glob = bool(use_nof and chain_global and not test_time)
+    need_fine = N_importance > 0
+
+    z_steps = torch.linspace(0, 1, S, device=dev)                     # rendering.py:245
+    z_vals = None
+    if perturb > 0 or need_fine:
+        near, far = rays[:, 6:7], rays[:, 7:8]
+        if not use_disp:
+            z_vals = near * (1 - z_steps) + far * z_steps
+        else:
+            z_vals = 1 / (1 / near * (1 - z_steps) + 1 / far * z_steps)
+        z_vals = z_vals.expand(N, S)
+        if perturb > 0:                                                # rendering.py:253-260
+            z_mid = 0.5 * (z_vals[:, :-1] + z_vals[:, 1:])
+            upper = torch.cat([z_mid, z_vals[:, -1:]], -1)
+            lower = torch.cat([z_vals[:, :1], z_mid], -1)
+            z_vals = lower + (upper - lower) * (perturb * torch.rand(z_vals.shape, device=dev))
+        z_vals = z_vals.contiguous()
+
+    def draw_noise(shape):
+        if noise_std != 0:
+            return (torch.randn(shape, device=dev) * noise_std).contiguous()
+        if STRICT_RNG and shape[0] > 0:
+            torch.randn(shape, device=dev)
+        return None
+
+    coarse_sigma_only = bool(need_fine and test_time)                  # rendering.py:290-294
+    want_planes = need_fine or loc or glob
+    c = _render_pass(rays, background, z_vals, None if z_vals is not None else z_steps, use_disp,
+                     draw_noise((N, S)), act, nerf_models[0], nerf_embeddings,
+                     nof_models if use_nof else None, nof_embeddings, loc, glob, coarse_sigma_only, want_planes)
+    if coarse_sigma_only:
+        result = {'opacity_coarse': c["opacity"]}
+    else:
+        result = {'rgb_coarse': c["rgb"], 'depth_coarse': c["depth"], 'opacity_coarse': c["opacity"]}
+    if loc or glob:
+        la, ga = _compact(c["alphas"], c.get("disp_local"), c.get("disp_global"))
+        if loc:
+            result['nof_local_disp_coarse'] = la
+        if glob:
+            result['nof_global_disp_coarse'] = ga
+
+    if need_fine:
+        z_all = resample_merge(z_vals, c["weights"], N_importance, det=(perturb == 0))
+        f = _render_pass(rays, background, z_all, None, use_disp, draw_noise((N, S + N_importance)), act,
+                         nerf_models[1], nerf_embeddings, nof_models if use_nof else None, nof_embeddings,
+                         loc, glob, False, loc or glob)
+        result['rgb_fine'] = f["rgb"]
+        result['depth_fine'] = f["depth"]
+        result['opacity_fine'] = f["opacity"]
+        if loc or glob:
+            la, ga = _compact(f["alphas"], f.get("disp_local"), f.get("disp_global"))
+            if loc:
+                result['nof_local_disp_fine'] = la
+            if glob:
+                result['nof_global_disp_fine'] = ga
+    return result
