@@ -43,10 +43,12 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(PdfParams p) {
     for (int i = lane; i < nb; i += 64) cdf[i] = p.cdf_in[ray * nb + i];
   } else {
     const float* wr = p.w + ray * p.w_stride;                                                // weights[:, 1:-1]
-    float part = 0.f;
-    for (int i = lane; i < nw; i += 64) { const float v = wr[i] + 1e-5f; pdf[i] = v; part += v; }   // :20
-    float tot = part;
-    for (int d = 32; d >= 1; d >>= 1) tot += __shfl_xor(tot, d, 64);                         // :21 torch.sum
+    for (int i = lane; i < nw; i += 64) pdf[i] = wr[i] + 1e-5f;                              // :20
+    __builtin_amdgcn_wave_barrier();
+    // :21 torch.sum -- its association order is backend/ISA specific even inside the reference;
+    // here: plain left-to-right fp32 (every lane recomputes it, LDS broadcast reads)
+    float tot = 0.f;
+    for (int i = 0; i < nw; ++i) tot += pdf[i];
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < nw; i += 64) pdf[i] = pdf[i] / tot;
     __builtin_amdgcn_wave_barrier();

@@ -172,10 +172,12 @@ def render_rays(rays,
                 noise_std=1,
                 nerf_activate_type='relu',
                 test_time=False,
+                _capture=None,
                 ):
     """Same contract as the reference's render_rays (rendering.py:195-375): rays (N, 9|10),
     background (N,3)|None -> dict with rgb/depth/opacity_{coarse,fine} and, in training with NoF,
-    nof_{local,global}_disp_{coarse,fine}."""
+    nof_{local,global}_disp_{coarse,fine}. ``_capture`` (dict, test hook) receives the per-pass
+    (N,S) planes the kernels produced (z, weights, alphas) without changing the result."""
     L.require_gpu(rays, "render_rays")
     if nerf_activate_type == 'relu':
         act = L.MF_ACT_RELU
@@ -227,7 +229,7 @@ def render_rays(rays,
         return None
 
     coarse_sigma_only = bool(need_fine and test_time)                  # rendering.py:290-294
-    want_planes = need_fine or loc or glob
+    want_planes = need_fine or loc or glob or _capture is not None
     c = _render_pass(rays, background, z_vals, None if z_vals is not None else z_steps, use_disp,
                      draw_noise((N, S)), act, nerf_models[0], nerf_embeddings,
                      nof_models if use_nof else None, nof_embeddings, loc, glob, coarse_sigma_only, want_planes)
@@ -242,11 +244,15 @@ def render_rays(rays,
         if glob:
             result['nof_global_disp_coarse'] = ga
 
+    if _capture is not None:
+        _capture.update(z_coarse=z_vals, weights_coarse=c.get("weights"), alphas_coarse=c.get("alphas"))
     if need_fine:
         z_all = resample_merge(z_vals, c["weights"], N_importance, det=(perturb == 0))
         f = _render_pass(rays, background, z_all, None, use_disp, draw_noise((N, S + N_importance)), act,
                          nerf_models[1], nerf_embeddings, nof_models if use_nof else None, nof_embeddings,
-                         loc, glob, False, loc or glob)
+                         loc, glob, False, loc or glob or _capture is not None)
+        if _capture is not None:
+            _capture.update(z_fine=z_all, weights_fine=f.get("weights"), alphas_fine=f.get("alphas"))
         result['rgb_fine'] = f["rgb"]
         result['depth_fine'] = f["depth"]
         result['opacity_fine'] = f["opacity"]

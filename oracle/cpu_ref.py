@@ -270,8 +270,11 @@ def nerf_inference(xyz_, ind_, dir_, z_vals, noise_std, nerf_embeddings, nerf_mo
 def render_rays(rays, background, nerf_embeddings, nerf_models, nof_embeddings=None,
                 nof_models=None, chain_local=False, chain_global=False, N_samples=64,
                 N_importance=0, use_disp=False, perturb=0, noise_std=1,
-                nerf_activate_type="relu", test_time=False, _capture: Optional[dict] = None):
-    """rendering.py:195-375. ``_capture`` (test hook) receives z_vals / weights / alphas."""
+                nerf_activate_type="relu", test_time=False, _capture: Optional[dict] = None,
+                _z_fine_override=None):
+    """rendering.py:195-375. ``_capture`` (test hook) receives z_vals / weights / alphas;
+    ``_z_fine_override`` (test hook) replaces the sorted fine depths, so that the fine pass can be
+    checked independently of the u = 1.0 resampling hazard."""
     N = rays.shape[0]
     rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
     near, far = rays[:, 6:7], rays[:, 7:8]
@@ -343,6 +346,8 @@ def render_rays(rays, background, nerf_embeddings, nerf_models, nof_embeddings=N
         mid = 0.5 * (z_vals[:, :-1] + z_vals[:, 1:])
         z_new = sample_pdf(mid, w_c[:, 1:-1], N_importance, det=(perturb == 0)).detach()
         z_vals, _ = torch.sort(torch.cat([z_vals, z_new], -1), -1)
+        if _z_fine_override is not None:
+            z_vals = _z_fine_override
         xyz_f = rays_o.unsqueeze(1) + rays_d.unsqueeze(1) * z_vals.unsqueeze(2)
         if use_nof:
             nerf_in, recon_f, chained_recon_f = chains(xyz_f)
