@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile_gpu.sh output directory: per-kernel stats + PMC counters averaged
+per dispatch of the dominant kernel. Applies the gfx950 FETCH_SIZE x2 correction of
+MI355X_MICROARCH.md (HBM section) and reports both raw and corrected values."""
+import csv
+import glob
+import os
+import sys
+from collections import defaultdict
+
+out = sys.argv[1]
+
+
+def rows(pattern):
+    for f in glob.glob(os.path.join(out, pattern), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                yield r
+
+
+print("== kernel stats (rocprofv3 --kernel-trace --stats) ==")
+for f in glob.glob(os.path.join(out, "trace/**/*kernel_stats.csv"), recursive=True):
+    with open(f) as fh:
+        for i, line in enumerate(fh):
+            if i < 12:
+                print(line.rstrip())
+dur = defaultdict(list)
+for r in rows("trace/**/*kernel_trace.csv"):
+    dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+dom = None
+if dur:
+    dom = max(dur, key=lambda k: sum(dur[k]))
+    d = dur[dom]
+    print(f"\ndominant kernel: {dom[:90]}\n  dispatches {len(d)}  avg {sum(d)/len(d)/1e3:.1f} us  min {min(d)/1e3:.1f}  max {max(d)/1e3:.1f}")
+    r0 = next(r for r in rows("trace/**/*kernel_trace.csv") if r["Kernel_Name"] == dom)
+    print("  VGPR", r0.get("VGPR_Count"), "AccVGPR", r0.get("Accum_VGPR_Count"), "SGPR", r0.get("SGPR_Count"),
+          "LDS", r0.get("LDS_Block_Size"), "scratch", r0.get("Scratch_Size"), "grid", r0.get("Grid_Size"),
+          "wg", r0.get("Workgroup_Size"))
+print("\n== PMC (per dispatch of the dominant kernel, mean) ==")
+for sub in ("pmc_mfma", "pmc_fetch", "pmc_write", "pmc_wait"):
+    acc = defaultdict(list)
+    for r in rows(f"{sub}/**/*counter_collection.csv"):
+        if dom and r["Kernel_Name"] != dom:
+            continue
+        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        print(f"{sub:10s} {k:28s} mean {sum(v)/len(v):.6g}  (n={len(v)})")
+        if k == "FETCH_SIZE":
+            kb = sum(v) / len(v)
+            print(f"{'':10s} -> HBM read  raw {kb*1024/1e6:.3f} MB, gfx950-corrected (x2) {2*kb*1024/1e6:.3f} MB per launch")
+        if k == "WRITE_SIZE":
+            kb = sum(v) / len(v)
+            print(f"{'':10s} -> HBM write {kb*1024/1e6:.3f} MB per launch (uncalibrated)")
