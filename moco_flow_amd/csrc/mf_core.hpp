@@ -1,92 +1,99 @@
 // mf_core.hpp -- register-resident fused MLP core for gfx950 (MI355X, CDNA4).
 //
-// Design: the MLPs of models/nerf.py and models/nof.py are evaluated
-// TRANSPOSED, H_out^T = W * H_in^T, on v_mfma_f32_32x32x2_f32:
-//   A operand = a 32-row slice of the nn.Linear weight (rows = output features),
-//   B operand = activations (columns = 32 ray-samples, one per lane&31),
-//   C/D       = 32 output features x 32 samples, 16 fp32 per lane.
-// The C/D register layout of that instruction (row = (reg&3) + 8*(reg>>2) + 4*(lane>>5),
-// col = lane&31) is exactly a valid B-operand layout for 16 further k-steps if the k
-// order is permuted to  k(step=(q,r), half h) = r + 8q + 4h.  The weights are re-ordered
-// once on the host side into that order ("fragment stream", mf_pack.hip), so a layer's
-// output registers feed the next layer's MFMAs with no shuffle, no LDS round trip and no
-// HBM traffic: activations never leave the register file.  One wave owns 32 samples and
-// the full hidden vector (W/32 tiles x 16 regs); the four waves of a workgroup share the
-// weight stream, which is DMA'd global->LDS (global_load_lds_dwordx4) one "panel" (the
-// 32 output rows of one layer) ahead of the MFMAs, double buffered.
+// Design.  The MLPs of models/nerf.py and models/nof.py are evaluated
+// TRANSPOSED, H_out^T = W * H_in^T, on v_mfma_f32_16x16x4_f32 (exact fp32, 32-cycle issue):
+//   A operand = 16 rows of the nn.Linear weight (rows = output features),
+//   B operand = activations (columns = 16 ray-samples, one per lane&15),
+//   C/D       = 16 output features x 16 samples, 4 fp32 per lane.
+// The C/D register layout of that instruction (row = 4*(lane>>4) + reg, col = lane&15) is
+// exactly a valid B-operand layout for 4 further k-steps if the k order inside a 16-wide
+// k-tile is  k(step r, lane-group g) = 4g + r.  The weights are re-ordered once into that
+// order ("fragment stream", mf_pack.hip), so a layer's output registers feed the next layer's
+// MFMAs directly: no shuffle, no LDS round trip, no HBM traffic -- activations never leave
+// the register file.
+//
+// One wave owns 16 samples and the whole hidden vector (W/16 k-tiles x 4 regs = 64 VGPRs for
+// W = 256) and computes TWO 16-row output tiles at a time (two independent accumulator chains
+// that share every B operand).  A workgroup is 8 waves = 128 samples, two waves per SIMD at
+// <= 256 registers each: while one wave is in a prologue / epilogue / barrier, its SIMD
+// partner keeps the matrix pipe busy.  The 8 waves share the weight stream, which is DMA'd
+// global->LDS (global_load_lds_dwordx4) in "panels" (32 output rows of one layer), running
+// two panels ahead of the MFMAs in a 3-slot ring.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace mf {
 
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kGroupBytes = 1024;   // one fragment group: 64 lanes x float4 = 4 k-steps
-constexpr int kWaves = 4;           // waves per workgroup (one per SIMD)
-constexpr int kTile = 128;          // samples per workgroup tile (32 per wave)
+constexpr int kGroupBytes = 1024;   // one fragment group: 64 lanes x float4 = 16 rows x 16 k (4 MFMA steps)
+constexpr int kWaves = 8;           // waves per workgroup (two per SIMD)
+constexpr int kWaveSamples = 16;    // samples per wave
+constexpr int kTile = 128;          // samples per workgroup tile
+constexpr int kThreads = 512;
 
 #define MF_HD __host__ __device__ __forceinline__
 #define MF_D __device__ __forceinline__
 
+constexpr int round4(int x) { return (x + 3) & ~3; }
+
 // ------------------------------------------------------------------ embedding blocks
-// A frequency embedding (models/embedding.py:42-46) of C components with at most F
-// frequencies, split across the two 32-lane halves of a wave: half h owns the sin/cos
-// pairs p = 2*pi + h (p -> frequency p / C, component p % C) and the raw components
-// 2*ri + h.  SLOTS registers per lane; slot e of half h is reference column feature(h,e).
+// A frequency embedding (models/embedding.py:42-46) of C components with at most F frequencies,
+// split across the four 16-lane groups of a wave: group g owns the sin/cos pairs p = 4*pi + g
+// (p -> frequency p / C, component p % C); the raw components ride as pseudo-pairs after the
+// real ones (pseudo-pair q holds raw 2q, 2q+1).  SLOTS registers per lane; slot e of group g is
+// reference column feature(g, e) (or -1: zero).
 template <int C, int F>
 struct EmbBlock {
-  static constexpr int NPAIR = (C * F + 1) / 2;
-  static constexpr int NRAW = (C + 1) / 2;
-  static constexpr int SLOTS = 2 * NPAIR + NRAW;
-  MF_HD static int feature(int h, int e) {
-    if (e < 2 * NPAIR) {
-      const int p = 2 * (e >> 1) + h;
-      if (p >= C * F) return -1;
+  static constexpr int NPAIR = C * F;                       // real pairs
+  static constexpr int NALL = NPAIR + (C + 1) / 2;          // + raw pseudo-pairs
+  static constexpr int NPI = (NALL + 3) / 4;                // pair slots per lane group
+  static constexpr int SLOTS = 2 * NPI;
+  MF_HD static int feature(int g, int e) {
+    const int p = 4 * (e >> 1) + g, sc = e & 1;
+    if (p < NPAIR) {
       const int f = p / C, c = p % C;
-      return C + 2 * C * f + C * (e & 1) + c;
+      return C + 2 * C * f + C * sc + c;
     }
-    const int r = 2 * (e - 2 * NPAIR) + h;
-    return r < C ? r : -1;
+    const int raw = 2 * (p - NPAIR) + sc;
+    return raw < C ? raw : -1;
   }
 };
 
-constexpr int round4(int x) { return (x + 3) & ~3; }
-
-// Input-slot maps of the three places an embedding enters a network.  `steps` is the
-// number of MFMA k-steps (= registers per lane), a multiple of 4 (one fragment group).
+// Input-slot maps of the places an embedding enters a network.  `steps` = registers per lane
+// = MFMA k-steps, a multiple of 4 (one fragment group per output tile).
 enum EmbKind : int { kEmbNerfXyz = 0, kEmbNofIn = 1, kEmbDir = 2, kEmbInd = 3, kEmbNone = 4 };
 
-using BlkXyz10 = EmbBlock<3, 10>;   // NeRF xyz, in_channels_xyz = 63
-using BlkXyz5 = EmbBlock<3, 5>;     // NoF xyz, in_channels_xyz = 33
-using BlkInd16 = EmbBlock<1, 16>;   // NoF ind, extra_feat_dim = 33
-using BlkDir4 = EmbBlock<3, 4>;     // NeRF dir, 27
-using BlkInd2 = EmbBlock<1, 2>;     // NeRF ind, 5
+using BlkXyz10 = EmbBlock<3, 10>;   // NeRF xyz, in_channels_xyz = 63 -> 16 slots
+using BlkXyz5 = EmbBlock<3, 5>;     // NoF xyz, in_channels_xyz = 33  -> 10 slots
+using BlkInd16 = EmbBlock<1, 16>;   // NoF ind, extra_feat_dim = 33   -> 10 slots
+using BlkDir4 = EmbBlock<3, 4>;     // NeRF dir, 27                   -> 8 slots
+using BlkInd2 = EmbBlock<1, 2>;     // NeRF ind, 5                    -> 2 slots
 
-constexpr int kStepsNerfXyz = round4(BlkXyz10::SLOTS);                    // 32
-constexpr int kStepsNofIn = round4(BlkXyz5::SLOTS + BlkInd16::SLOTS);     // 36
-constexpr int kStepsDir = round4(BlkDir4::SLOTS);                         // 16
+constexpr int kStepsNerfXyz = round4(BlkXyz10::SLOTS);                    // 16
+constexpr int kStepsNofIn = round4(BlkXyz5::SLOTS + BlkInd16::SLOTS);     // 20
+constexpr int kStepsDir = round4(BlkDir4::SLOTS);                         // 8
 constexpr int kStepsInd = round4(BlkInd2::SLOTS);                         // 4
 constexpr int kStepsExtraMax = kStepsDir;
 
-// reference column (within the embedded input vector) of slot e of half h; -1 = zero pad.
+// reference column (within the embedded input vector) of slot e of lane group g; -1 = zero pad.
 // `xyz_cols` = the network's in_channels_xyz (NoF: the ind block starts there).
-MF_HD int emb_feature(int kind, int h, int e, int xyz_cols) {
+MF_HD int emb_feature(int kind, int g, int e, int xyz_cols) {
   switch (kind) {
     case kEmbNerfXyz:
-      return e < BlkXyz10::SLOTS ? BlkXyz10::feature(h, e) : -1;
+      return e < BlkXyz10::SLOTS ? BlkXyz10::feature(g, e) : -1;
     case kEmbNofIn:
-      if (e < BlkXyz5::SLOTS) return BlkXyz5::feature(h, e);
+      if (e < BlkXyz5::SLOTS) return BlkXyz5::feature(g, e);
       if (e < BlkXyz5::SLOTS + BlkInd16::SLOTS) {
-        const int f = BlkInd16::feature(h, e - BlkXyz5::SLOTS);
+        const int f = BlkInd16::feature(g, e - BlkXyz5::SLOTS);
         return f < 0 ? -1 : xyz_cols + f;
       }
       return -1;
     case kEmbDir:
-      return e < BlkDir4::SLOTS ? BlkDir4::feature(h, e) : -1;
+      return e < BlkDir4::SLOTS ? BlkDir4::feature(g, e) : -1;
     case kEmbInd:
-      return e < BlkInd2::SLOTS ? BlkInd2::feature(h, e) : -1;
+      return e < BlkInd2::SLOTS ? BlkInd2::feature(g, e) : -1;
     default:
       return -1;
   }
@@ -100,14 +107,16 @@ struct EmbParams {
 
 // ------------------------------------------------------------------ packed layouts
 // A packed network = [resident block (biases, VALU head weights), padded to 1 KiB]
-//                    [panels in program order], each panel = groups x 1 KiB.
+//                    [panels in program order].
+// A panel = 32 output rows of one layer = two 16-row tiles; its groups alternate between the
+// two tiles: [tile0 k-quad 0][tile1 k-quad 0][tile0 k-quad 1] ...  (k-quad = 4 k-steps = 16 k).
 struct NetLayout {
-  int W, NT;               // hidden width, W/32
+  int W, NK, NP;           // hidden width, k-tiles (W/16), panels per W-wide layer (W/32)
   int n_trunk;             // trunk layers streamed through the generic loop (NeRF: D+1 incl. final)
   int emb_steps;           // k-steps of the embedded-input block
   uint32_t emb_mask;       // trunk layers that consume the embedded input (layer 0 + skips)
   uint32_t relu_mask;      // trunk layers followed by ReLU
-  int extra_steps;         // NeRF extra_encoding: k-steps of the extra block (0, 4, 16); -1 = no extra layer
+  int extra_steps;         // NeRF extra_encoding: k-steps of the extra block (0, 4, 8); -1 = no extra layer
   int64_t res_bytes;       // resident block size (multiple of 1 KiB)
   int64_t panel_bytes;     // all panels
   int max_groups;          // largest panel, in groups
@@ -121,13 +130,14 @@ struct NetLayout {
   int n_head;              // NoF: 9 | 3
 };
 
-MF_HD int trunk_groups(const NetLayout& L, int layer) {
-  return (((L.emb_mask >> layer) & 1) ? L.emb_steps / 4 : 0) + (layer > 0 ? L.NT * 4 : 0);
+// k-quads (batches) and groups of a trunk-layer panel
+MF_HD int trunk_quads(const NetLayout& L, int layer) {
+  return (((L.emb_mask >> layer) & 1) ? L.emb_steps / 4 : 0) + (layer > 0 ? L.NK : 0);
 }
-MF_HD int extra_groups(const NetLayout& L) { return L.NT * 4 + L.extra_steps / 4; }
+MF_HD int trunk_groups(const NetLayout& L, int layer) { return 2 * trunk_quads(L, layer); }
+MF_HD int extra_groups(const NetLayout& L) { return 2 * (L.NK + L.extra_steps / 4); }
 
 // ------------------------------------------------------------------ device helpers
-
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
 MF_D void glds16(const char* g, uint32_t lds_off) {
@@ -136,104 +146,136 @@ MF_D void glds16(const char* g, uint32_t lds_off) {
 }
 MF_D void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
-MF_D float xhalf_sum(float v) {   // v(lane) + v(lane ^ 32)
-  return v + __shfl_xor(v, 32, 64);
+// sum over the four lane groups of a sample column (lanes j, j+16, j+32, j+48)
+MF_D float xgroup_sum(float v) {
+  v += __shfl_xor(v, 16, 64);
+  v += __shfl_xor(v, 32, 64);
+  return v;
 }
 
 struct LaneId {
-  int lane, wave, j, h;
+  int lane, wave, j, g;
   MF_D LaneId() {
     lane = threadIdx.x & 63;
     wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    j = lane & 31;
-    h = lane >> 5;
+    j = lane & 15;
+    g = lane >> 4;
   }
 };
 
-// Weight-panel stream: double-buffered LDS ring fed by LDS-DMA.
-// Invariant between out-tiles: the current panel is complete and visible in buffer `cur`,
-// no DMA in flight, every wave is past the barrier that ended the previous panel.
-struct Stream {
-  const char* gnext;      // global address of the next panel to fetch (wave-uniform)
-  uint32_t ring;          // LDS byte offset of ring buffer 0
-  uint32_t buf_bytes;     // bytes per ring buffer
-  uint32_t cur;           // 0 / 1
+template <class T>
+MF_D T sel4(int g, T a0, T a1, T a2, T a3) {
+  const T lo = (g & 1) ? a1 : a0;
+  const T hi = (g & 1) ? a3 : a2;
+  return (g & 2) ? hi : lo;
+}
 
-  MF_D uint32_t cur_off() const { return ring + cur * buf_bytes; }
-  // start fetching the next panel (`groups` KiB) into the other buffer
-  MF_D void prefetch(int groups, const LaneId& id) {
-    const uint32_t dst = ring + (cur ^ 1u) * buf_bytes;
+// Weight-panel stream: a 3-slot LDS ring fed by LDS-DMA (global_load_lds_dwordx4), running
+// TWO panels ahead of the MFMAs.  While panel c is being multiplied, panel c+1 is already
+// complete and visible (so its first fragments and bias can be pre-read during c's tail: no
+// exposed LDS latency at a panel boundary) and panel c+2 is in flight.  One workgroup barrier
+// per panel, placed behind the first MFMAs of the panel:
+//   RAW: every wave waited vmcnt(0) for its own pieces of c+1 before arriving;
+//   WAR: every wave has started c, hence finished reading c-1, whose slot c+2 overwrites.
+struct Stream {
+  const char* gnext;      // global address of the panel two ahead of the one being computed
+  uint32_t ring;          // LDS byte offset of slot 0
+  uint32_t buf_bytes;     // bytes per slot
+  uint32_t cur;           // slot (0..2) of the panel being computed
+
+  MF_D uint32_t slot_off(uint32_t k) const {
+    uint32_t s = cur + k;
+    s = s >= 3u ? s - 3u : s;
+    return ring + s * buf_bytes;
+  }
+  MF_D void dma_to(uint32_t dst, int groups, const LaneId& id) {
     const char* g = gnext + id.lane * 16;
     for (int grp = id.wave; grp < groups; grp += kWaves) glds16(g + grp * kGroupBytes, dst + grp * kGroupBytes);
     gnext += (size_t)groups * kGroupBytes;
   }
-  MF_D void flip() {
+  // barrier of the panel + launch of the DMA for the panel two ahead
+  MF_D void sync_and_dma(int groups, const char* jump, const LaneId& id) {
+    wait_vm0();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (jump) gnext = jump;
+    dma_to(slot_off(2), groups, id);
+  }
+  MF_D void advance() { cur = cur == 2u ? 0u : cur + 1u; }
+  // cold start: the program's first two panels (same layer, `groups` each) into slots 0 and 1
+  MF_D void start(const char* first, int groups, const LaneId& id) {
+    cur = 0;
+    gnext = first;
+    dma_to(ring, groups, id);
+    dma_to(ring + buf_bytes, groups, id);
     wait_vm0();
     __syncthreads();
-    cur ^= 1u;
-  }
-  // cold start: fetch the first panel of the program into buffer 0
-  MF_D void start(const char* first, int groups, const LaneId& id) {
-    cur = 1;
-    gnext = first;
-    prefetch(groups, id);
-    flip();
   }
 };
 
 MF_D f32x4 lds_f4(uint32_t byte_off) { return *(const f32x4*)(smem + byte_off); }
 MF_D float lds_f(uint32_t byte_off) { return *(const float*)(smem + byte_off); }
 
-#define MF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x2f32((a), (b), (c), 0, 0, 0)
+#define MF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// One output tile (32 features x 32 samples): acc += W_panel * [emb ; hidden].
+// What a panel needs before its first MFMA, pre-read during the previous panel's tail:
+// the first fragment group of each of its two tiles and their bias in C/D order
+// (reg r of lane group g <- bias[16*tile + 4g + r]).
+struct Carry {
+  f32x4 wE, wO, bE, bO;
+  MF_D void load(uint32_t panel_lane_off, uint32_t bias_byte_off, int g) {
+    wE = lds_f4(panel_lane_off);
+    wO = lds_f4(panel_lane_off + kGroupBytes);
+    bE = lds_f4(bias_byte_off + 16 * g);
+    bO = lds_f4(bias_byte_off + 64 + 16 * g);
+  }
+};
+
+// One panel = two 16-row output tiles (E: rows 0-15, O: rows 16-31) x 16 samples:
+//   out = max(bias + W_panel * [emb ; hidden], lo)      (lo = 0: ReLU, -inf: linear)
 // MODE: 1 = embedded input only, 2 = hidden only, 3 = both (skip layers, emb first).
-// Fragment groups are fetched two ahead of the MFMAs that use them: the ds_reads for
-// batch b+1 are issued right after the first MFMA of batch b (7 MFMAs = 448 cycles of
-// cover), so the lgkmcnt wait in front of batch b+1 is free.
-template <int MODE, int NT, int EMB>
-MF_D f32x16 out_tile(f32x16 acc, const f32x16 (&hid)[NT], const float (&emb)[EMB], uint32_t panel_lane_off) {
-  constexpr int GE = (MODE & 1) ? EMB / 4 : 0;
-  constexpr int GH = (MODE & 2) ? NT * 4 : 0;
-  constexpr int G = GE + GH;
-  auto bop = [&](int g, int r) -> float {
-    if (g < GE) return emb[4 * g + r];
-    const int gh = g - GE;
-    return hid[gh >> 2][4 * (gh & 3) + r];
-  };
-  f32x4 w0 = lds_f4(panel_lane_off);
-  f32x4 w1 = (G > 1) ? lds_f4(panel_lane_off + kGroupBytes) : w0;
+// Per k-quad: two ds_read_b128 (one group per tile) feed 8 MFMAs; the E and O chains alternate
+// and share every B operand, so no MFMA directly follows its own predecessor and the ds_reads
+// sit between independent MFMAs.  Groups are fetched one k-quad (8 MFMAs) ahead.  `hook` runs
+// behind the first MFMA pair of the panel (workgroup barrier + DMA of the panel two ahead);
+// the NEXT panel's Carry is read behind the first pair of the last k-quad.
+template <int MODE, int NK, int EMB, class Hook>
+MF_D void out_pair(Carry& carry, const f32x4 (&hid)[NK], const float (&emb)[EMB], uint32_t panel_lane_off,
+                   uint32_t next_panel_lane_off, uint32_t next_bias_off, int g, Hook&& hook, float lo, f32x4& outE,
+                   f32x4& outO) {
+  constexpr int QE = (MODE & 1) ? EMB / 4 : 0;
+  constexpr int QH = (MODE & 2) ? NK : 0;
+  constexpr int Q = QE + QH;
+  auto bop = [&](int q, int r) -> float { return q < QE ? emb[4 * q + r] : hid[q - QE][r]; };
+  f32x4 E = carry.bE, O = carry.bO;
+  f32x4 wE = carry.wE, wO = carry.wO;
 #pragma unroll
-  for (int g = 0; g < G; g += 2) {
-    f32x4 n0 = w0, n1 = w1;
-    acc = MF_MFMA(w0[0], bop(g, 0), acc);
+  for (int q = 0; q < Q; ++q) {
+    f32x4 nE = wE, nO = wO;
+    E = MF_MFMA(wE[0], bop(q, 0), E);
+    O = MF_MFMA(wO[0], bop(q, 0), O);
     __builtin_amdgcn_sched_barrier(0);
-    if (g + 2 < G) n0 = lds_f4(panel_lane_off + (g + 2) * kGroupBytes);
-    if (g + 3 < G) n1 = lds_f4(panel_lane_off + (g + 3) * kGroupBytes);
+    if (q + 1 < Q) {
+      nE = lds_f4(panel_lane_off + (2 * (q + 1)) * kGroupBytes);
+      nO = lds_f4(panel_lane_off + (2 * (q + 1) + 1) * kGroupBytes);
+    }
+    if (q == 0) hook();
+    if (q + 1 >= Q) carry.load(next_panel_lane_off, next_bias_off, g);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int r = 1; r < 4; ++r) acc = MF_MFMA(w0[r], bop(g, r), acc);
-    if (g + 1 < G) {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) acc = MF_MFMA(w1[r], bop(g + 1, r), acc);
+    for (int r = 1; r < 4; ++r) {
+      E = MF_MFMA(wE[r], bop(q, r), E);
+      O = MF_MFMA(wO[r], bop(q, r), O);
     }
     __builtin_amdgcn_sched_barrier(0);
-    w0 = n0;
-    w1 = n1;
+    wE = nE;
+    wO = nO;
   }
-  return acc;
-}
-
-// bias of output tile t in C/D register order: reg 4q+r <- bias[32t + 8q + 4h + r]
-MF_D f32x16 bias_tile(uint32_t bias_byte_off, int t, int h) {
-  f32x16 acc;
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const f32x4 b = lds_f4(bias_byte_off + (32 * t + 8 * q + 4 * h) * 4);
-#pragma unroll
-    for (int r = 0; r < 4; ++r) acc[4 * q + r] = b[r];
+  for (int i = 0; i < 4; ++i) {
+    outE[i] = fmaxf(E[i], lo);
+    outO[i] = fmaxf(O[i], lo);
   }
-  return acc;
 }
 
 // Uniform per-network state handed to the device code (kernarg -> SGPRs).
@@ -243,90 +285,96 @@ struct NetDev {
   uint32_t res_lds;        // LDS byte offset where its resident block lives
 };
 
-// One trunk layer: out = act(W_l [emb;hid] + b_l) for all NT output tiles.
-// `next_groups`/`jump`: size of the panel that follows this layer's last panel, and, if the
-// program leaves this network's contiguous panel order there, its address.
-template <int NT, int EMB>
-MF_D void trunk_layer(const NetDev& net, int layer, f32x16 (&act)[NT], const float (&emb)[EMB],
-                      Stream& st, const LaneId& id, int next_groups, const char* jump) {
+// The layer that follows in program order (possibly the first layer of another network).
+struct NextLayer {
+  int groups;              // panel size of that layer
+  const char* jump;        // its first panel's address if the program leaves the contiguous order, else null
+  uint32_t bias_off;       // LDS byte offset of its bias vector
+};
+
+// One trunk layer: act <- relu?(W_l [emb ; act] + b_l), NK/2 panels of two tiles.
+template <int NK, int EMB>
+MF_D void trunk_layer(const NetDev& net, int layer, f32x4 (&act)[NK], const float (&emb)[EMB], Stream& st,
+                      Carry& carry, const LaneId& id, const NextLayer& nxt) {
+  constexpr int NP = NK / 2;
   const int has_emb = (net.L.emb_mask >> layer) & 1;
   const int mode = (has_emb ? 1 : 0) | (layer > 0 ? 2 : 0);
   const int groups = trunk_groups(net.L, layer);
   const float lo = ((net.L.relu_mask >> layer) & 1) ? 0.f : -__builtin_inff();
   const uint32_t bias_off = net.res_lds + (net.L.off_bias_trunk + layer * net.L.W) * 4;
-  f32x16 out[NT];
+  f32x4 out[NK];
 #pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    if (t == NT - 1) {
-      if (jump) st.gnext = jump;
-      st.prefetch(next_groups, id);
-    } else {
-      st.prefetch(groups, id);
-    }
-    const uint32_t p = st.cur_off() + id.lane * 16;
-    f32x16 acc = bias_tile(bias_off, t, id.h);
-    if (mode == 2) acc = out_tile<2, NT, EMB>(acc, act, emb, p);
-    else if (mode == 3) acc = out_tile<3, NT, EMB>(acc, act, emb, p);
-    else acc = out_tile<1, NT, EMB>(acc, act, emb, p);
-#pragma unroll
-    for (int i = 0; i < 16; ++i) out[t][i] = fmaxf(acc[i], lo);
-    st.flip();
+  for (int t = 0; t < NP; ++t) {
+    const uint32_t p = st.slot_off(0) + id.lane * 16;
+    const uint32_t pn = st.slot_off(1) + id.lane * 16;
+    const uint32_t nb = (t + 1 < NP) ? bias_off + 32 * (t + 1) * 4 : nxt.bias_off;
+    // panel two ahead: same layer while t+2 < NP, else panel (t+2-NP) of the next layer
+    auto hook = [&]() { st.sync_and_dma(t + 2 < NP ? groups : nxt.groups, t == NP - 2 ? nxt.jump : nullptr, id); };
+    if (mode == 2) out_pair<2, NK, EMB>(carry, act, emb, p, pn, nb, id.g, hook, lo, out[2 * t], out[2 * t + 1]);
+    else if (mode == 3) out_pair<3, NK, EMB>(carry, act, emb, p, pn, nb, id.g, hook, lo, out[2 * t], out[2 * t + 1]);
+    else out_pair<1, NK, EMB>(carry, act, emb, p, pn, nb, id.g, hook, lo, out[2 * t], out[2 * t + 1]);
+    st.advance();
   }
 #pragma unroll
-  for (int t = 0; t < NT; ++t) act[t] = out[t];
+  for (int t = 0; t < NK; ++t) act[t] = out[t];
 }
 
-// VALU head: n_out dot products of the lane's half of the hidden vector with natural-order
-// weight rows in LDS (broadcast ds_read_b128), summed across the two halves.  Every lane of
-// a sample column ends up with the full sums.
-template <int NT, int NOUT>
-MF_D void valu_head(const f32x16 (&act)[NT], uint32_t w_byte_off, int row_floats, uint32_t b_byte_off,
-                    int h, float (&out)[NOUT]) {
+// VALU head: NOUT dot products of the lane's quarter of the hidden vector with natural-order
+// weight rows in LDS (broadcast ds_read_b128), summed across the four lane groups.  Every lane
+// of a sample column ends up with the full sums.
+template <int NK, int NOUT>
+MF_D void valu_head(const f32x4 (&act)[NK], uint32_t w_byte_off, int row_floats, uint32_t b_byte_off, int g,
+                    float (&out)[NOUT]) {
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) {
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
-    for (int t = 0; t < NT; ++t) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const f32x4 w = lds_f4(w_byte_off + (o * row_floats + 32 * t + 8 * q + 4 * h) * 4);
-        s0 = __builtin_fmaf(w[0], act[t][4 * q + 0], s0);
-        s1 = __builtin_fmaf(w[1], act[t][4 * q + 1], s1);
-        s0 = __builtin_fmaf(w[2], act[t][4 * q + 2], s0);
-        s1 = __builtin_fmaf(w[3], act[t][4 * q + 3], s1);
-      }
+    for (int t = 0; t < NK; ++t) {
+      const f32x4 w = lds_f4(w_byte_off + (o * row_floats + 16 * t + 4 * g) * 4);
+      s0 = __builtin_fmaf(w[0], act[t][0], s0);
+      s1 = __builtin_fmaf(w[1], act[t][1], s1);
+      s0 = __builtin_fmaf(w[2], act[t][2], s0);
+      s1 = __builtin_fmaf(w[3], act[t][3], s1);
     }
-    out[o] = xhalf_sum(s0 + s1) + lds_f(b_byte_off + o * 4);
+    out[o] = xgroup_sum(s0 + s1) + lds_f(b_byte_off + o * 4);
   }
 }
 
 // ------------------------------------------------------------------ embedding in registers
-// dst[0..SLOTS) of block (C,F) for this lane-half.  arg = freq*x is rounded to fp32 before
+// dst[0..SLOTS) of block (C,F) for this lane group.  arg = freq*x is rounded to fp32 before
 // sin/cos exactly as `func(freq*x)` in embedding.py:45; weight multiplies the result.
 template <int C, int F>
-MF_D void emb_eval(float* dst, const float (&v)[C], const EmbParams& ep, int h) {
+MF_D void emb_eval(float* dst, const float (&v)[C], const EmbParams& ep, int g) {
   using B = EmbBlock<C, F>;
 #pragma unroll
-  for (int pi = 0; pi < B::NPAIR; ++pi) {
-    const int p0 = 2 * pi, p1 = 2 * pi + 1;
-    const int f0 = p0 / C, c0 = p0 % C;
-    const bool ok1 = p1 < C * F;
-    const int f1 = ok1 ? p1 / C : f0, c1 = ok1 ? p1 % C : c0;
-    const float x = h ? v[c1] : v[c0];
-    const float fr = h ? ep.freq[f1] : ep.freq[f0];
-    const float w = h ? (ok1 ? ep.weight[f1] : 0.f) : ep.weight[f0];
-    float s = 0.f, c = 0.f;
-    // weights are wave-uniform (kernarg): skip the transcendental when both halves are muted
-    if (ep.weight[f0] != 0.f || (ok1 && ep.weight[f1] != 0.f)) sincosf(fr * x, &s, &c);
-    dst[2 * pi] = w * s;
-    dst[2 * pi + 1] = w * c;
-  }
+  for (int pi = 0; pi < B::NPI; ++pi) {
+    // the four lane groups' pairs p = 4*pi + {0,1,2,3}: real pair -> (freq, comp); else raw pseudo-pair
+    float xs[4], frs[4], ws[4], r0[4], r1[4];
+    bool rl[4];
+    bool any_live = false;
 #pragma unroll
-  for (int ri = 0; ri < B::NRAW; ++ri) {
-    const int r0 = 2 * ri, r1 = 2 * ri + 1;
-    dst[2 * B::NPAIR + ri] = h ? (r1 < C ? v[r1 < C ? r1 : 0] : 0.f) : v[r0];
+    for (int k = 0; k < 4; ++k) {
+      const int p = 4 * pi + k;
+      const bool real = p < B::NPAIR;
+      const int f = real ? p / C : 0, c = real ? p % C : 0;
+      rl[k] = real;
+      xs[k] = v[c];
+      frs[k] = ep.freq[f];
+      ws[k] = real ? ep.weight[f] : 0.f;
+      const int raw = real ? 0 : 2 * (p - B::NPAIR);
+      r0[k] = (!real && raw < C) ? v[raw < C ? raw : 0] : 0.f;
+      r1[k] = (!real && raw + 1 < C) ? v[raw + 1 < C ? raw + 1 : 0] : 0.f;
+      if (real) any_live |= ep.weight[f] != 0.f;       // wave-uniform (kernarg)
+    }
+    const float x = sel4(g, xs[0], xs[1], xs[2], xs[3]);
+    const float fr = sel4(g, frs[0], frs[1], frs[2], frs[3]);
+    const float w = sel4(g, ws[0], ws[1], ws[2], ws[3]);
+    const bool real = sel4(g, rl[0], rl[1], rl[2], rl[3]);
+    float s = 0.f, c = 0.f;
+    if (any_live) sincosf(fr * x, &s, &c);   // skipped when every frequency of this slot is muted
+    dst[2 * pi] = real ? w * s : sel4(g, r0[0], r0[1], r0[2], r0[3]);
+    dst[2 * pi + 1] = real ? w * c : sel4(g, r1[0], r1[1], r1[2], r1[3]);
   }
 }
-
 
 }  // namespace mf

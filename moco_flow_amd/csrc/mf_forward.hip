@@ -50,40 +50,46 @@ struct NerfFwdParams {
   uint32_t ring_off, buf_bytes;
 };
 
-__global__ __launch_bounds__(256, 1) void nerf_forward_kernel(NerfFwdParams p) {
+__global__ __launch_bounds__(kThreads, 2) void nerf_forward_kernel(NerfFwdParams p) {
   const LaneId id;
   NetDev net = p.net;
   load_resident(net, id);
   Stream st;
+  Carry carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
-  st.start(first_panel(net), first_groups(net), id);   // also drains the resident-block DMA
+  start_program(net, st, carry, id);                    // also drains the resident-block DMA
   const long long ntiles = (p.B + kTile - 1) / kTile;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long b = tile * kTile + id.wave * 32 + id.j;
+    const long long b = tile * kTile + id.wave * kWaveSamples + id.j;
     const bool valid = b < p.B;
     const float* row = p.in + (valid ? b : p.B - 1) * p.in_stride;
     float embx[kStepsNerfXyz], ext[kStepsExtraMax];
 #pragma unroll
     for (int e = 0; e < kStepsNerfXyz; ++e) {
-      const int f0 = emb_feature(kEmbNerfXyz, 0, e, 0), f1 = emb_feature(kEmbNerfXyz, 1, e, 0);
-      const int f = id.h ? f1 : f0;
+      const int f = sel4(id.g, emb_feature(kEmbNerfXyz, 0, e, 0), emb_feature(kEmbNerfXyz, 1, e, 0),
+                         emb_feature(kEmbNerfXyz, 2, e, 0), emb_feature(kEmbNerfXyz, 3, e, 0));
       embx[e] = f >= 0 ? row[f] : 0.f;
     }
 #pragma unroll
     for (int e = 0; e < kStepsExtraMax; ++e) {
       int f = -1;
-      if (p.extra_kind == kEmbDir) f = id.h ? emb_feature(kEmbDir, 1, e, 0) : emb_feature(kEmbDir, 0, e, 0);
-      else if (p.extra_kind == kEmbInd) f = id.h ? emb_feature(kEmbInd, 1, e, 0) : emb_feature(kEmbInd, 0, e, 0);
+      if (p.extra_kind == kEmbDir)
+        f = sel4(id.g, emb_feature(kEmbDir, 0, e, 0), emb_feature(kEmbDir, 1, e, 0), emb_feature(kEmbDir, 2, e, 0),
+                 emb_feature(kEmbDir, 3, e, 0));
+      else if (p.extra_kind == kEmbInd)
+        f = sel4(id.g, emb_feature(kEmbInd, 0, e, 0), emb_feature(kEmbInd, 1, e, 0), emb_feature(kEmbInd, 2, e, 0),
+                 emb_feature(kEmbInd, 3, e, 0));
       ext[e] = (!p.sigma_only && f >= 0 && f < p.extra_cols) ? row[p.xyz_cols + f] : 0.f;
     }
     float sigma, rgb[3] = {0.f, 0.f, 0.f};
-    nerf_eval<8>(net, embx, ext, p.sigma_only != 0, st, id, first_panel(net), first_groups(net), sigma, rgb);
-    if (valid && id.h == 0) {
+    nerf_eval<16>(net, embx, ext, p.sigma_only != 0, st, carry, id, follow_of(net), sigma, rgb);
+    if (valid && id.g == 0) {
       if (p.sigma_only) p.out[b] = sigma;
       else *reinterpret_cast<float4*>(p.out + b * 4) = make_float4(rgb[0], rgb[1], rgb[2], sigma);
     }
   }
+  wait_vm0();   // the stream runs two panels ahead: drain the LDS-DMA before the workgroup retires
 }
 
 // ------------------------------------------------------------------ NoF.forward
@@ -96,35 +102,38 @@ struct NofFwdParams {
   uint32_t ring_off, buf_bytes;
 };
 
-__global__ __launch_bounds__(256, 1) void nof_forward_kernel(NofFwdParams p) {
+__global__ __launch_bounds__(kThreads, 2) void nof_forward_kernel(NofFwdParams p) {
   const LaneId id;
   NetDev net = p.net;
   load_resident(net, id);
   Stream st;
+  Carry carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
-  st.start(first_panel(net), first_groups(net), id);
+  start_program(net, st, carry, id);
   const long long ntiles = (p.B + kTile - 1) / kTile;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long b = tile * kTile + id.wave * 32 + id.j;
+    const long long b = tile * kTile + id.wave * kWaveSamples + id.j;
     const bool valid = b < p.B;
     const long long bb = valid ? b : p.B - 1;
     const float* row = p.in + bb * p.in_stride;
     float emb[kStepsNofIn];
 #pragma unroll
     for (int e = 0; e < kStepsNofIn; ++e) {
-      const int f = id.h ? emb_feature(kEmbNofIn, 1, e, 33) : emb_feature(kEmbNofIn, 0, e, 33);
+      const int f = sel4(id.g, emb_feature(kEmbNofIn, 0, e, 33), emb_feature(kEmbNofIn, 1, e, 33),
+                         emb_feature(kEmbNofIn, 2, e, 33), emb_feature(kEmbNofIn, 3, e, 33));
       emb[e] = f >= 0 ? row[f] : 0.f;
     }
     const float xyz[3] = {p.xyz[bb * 3 + 0], p.xyz[bb * 3 + 1], p.xyz[bb * 3 + 2]};
     float o[3];
-    nof_eval(net, emb, xyz, st, id, first_panel(net), first_groups(net), o);
-    if (valid && id.h == 0) {
+    nof_eval(net, emb, xyz, st, carry, id, follow_of(net), o);
+    if (valid && id.g == 0) {
       p.out[b * 3 + 0] = o[0];
       p.out[b * 3 + 1] = o[1];
       p.out[b * 3 + 2] = o[2];
     }
   }
+  wait_vm0();
 }
 
 int device_cus() {
@@ -159,7 +168,7 @@ extern "C" int32_t mf_nerf_forward(const mf_nerf_desc* d, const void* packed, co
   if (!d || !packed || (B > 0 && (!inputs || !out))) return fail(MF_E_INVALID, "mf_nerf_forward: null argument");
   NerfFwdParams p{};
   if (!nerf_layout(*d, p.net.L)) return fail(MF_E_UNSUPPORTED, "mf_nerf_forward: unsupported NeRF configuration");
-  if (p.net.L.NT != 8) return fail(MF_E_UNSUPPORTED, "mf_nerf_forward: only W=256 is built");
+  if (p.net.L.NK != 16) return fail(MF_E_UNSUPPORTED, "mf_nerf_forward: only W=256 is built");
   if (B == 0) return MF_OK;
   p.net.packed = static_cast<const char*>(packed);
   p.net.res_lds = 0;
@@ -169,12 +178,12 @@ extern "C" int32_t mf_nerf_forward(const mf_nerf_desc* d, const void* packed, co
   p.xyz_cols = d->in_channels_xyz;
   p.ring_off = (uint32_t)p.net.L.res_bytes;
   p.buf_bytes = (uint32_t)p.net.L.max_groups * kGroupBytes;
-  const size_t lds = p.ring_off + 2 * (size_t)p.buf_bytes;
+  const size_t lds = p.ring_off + 3 * (size_t)p.buf_bytes;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(MF_E_LAUNCH, "mf_nerf_forward: cannot reserve %zu bytes of LDS", lds);
   const long long ntiles = (B + kTile - 1) / kTile;
   const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
-  hipLaunchKernelGGL(nerf_forward_kernel, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  hipLaunchKernelGGL(nerf_forward_kernel, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
   return check_launch("mf_nerf_forward");
 }
 
@@ -189,11 +198,11 @@ extern "C" int32_t mf_nof_forward(const mf_nof_desc* d, const void* packed, cons
   p.in = inputs; p.in_stride = in_stride; p.B = B; p.xyz = xyz; p.out = out;
   p.ring_off = (uint32_t)p.net.L.res_bytes;
   p.buf_bytes = (uint32_t)p.net.L.max_groups * kGroupBytes;
-  const size_t lds = p.ring_off + 2 * (size_t)p.buf_bytes;
+  const size_t lds = p.ring_off + 3 * (size_t)p.buf_bytes;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(nof_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(MF_E_LAUNCH, "mf_nof_forward: cannot reserve %zu bytes of LDS", lds);
   const long long ntiles = (B + kTile - 1) / kTile;
   const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
-  hipLaunchKernelGGL(nof_forward_kernel, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  hipLaunchKernelGGL(nof_forward_kernel, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
   return check_launch("mf_nof_forward");
 }

@@ -16,7 +16,8 @@ inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L) {
   if (d.skip_mask & 1u) return false;                 // layer 0 already takes the input
   if (d.skip_mask >> d.D) return false;
   L.W = d.W;
-  L.NT = d.W / 32;
+  L.NK = d.W / 16;
+  L.NP = d.W / 32;
   L.n_trunk = d.D + 1;                                // + xyz_encoding_final (no ReLU)
   L.emb_steps = kStepsNerfXyz;
   L.emb_mask = 1u | d.skip_mask;
@@ -40,11 +41,11 @@ inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L) {
   L.max_groups = 0;
   for (int l = 0; l < L.n_trunk; ++l) {
     const int g = trunk_groups(L, l);
-    groups += (int64_t)g * L.NT;
+    groups += (int64_t)g * L.NP;
     if (g > L.max_groups) L.max_groups = g;
   }
   const int ge = extra_groups(L);
-  groups += (int64_t)ge * (L.NT / 2);
+  groups += (int64_t)ge * (L.NP / 2);
   if (ge > L.max_groups) L.max_groups = ge;
   L.panel_bytes = groups * kGroupBytes;
   return true;
@@ -57,7 +58,8 @@ inline bool nof_layout(const mf_nof_desc& d, NetLayout& L) {
   if (d.in_channels_xyz != 33 || d.extra_feat_dim != 33) return false;   // 3*(2*5+1), 1*(2*16+1)
   if ((d.skip_mask & 1u) || (d.skip_mask >> d.D)) return false;
   L.W = d.W;
-  L.NT = d.W / 32;
+  L.NK = d.W / 16;
+  L.NP = d.W / 32;
   L.n_trunk = d.D;
   L.emb_steps = kStepsNofIn;
   L.emb_mask = 1u | d.skip_mask;
@@ -73,7 +75,7 @@ inline bool nof_layout(const mf_nof_desc& d, NetLayout& L) {
   L.max_groups = 0;
   for (int l = 0; l < L.n_trunk; ++l) {
     const int g = trunk_groups(L, l);
-    groups += (int64_t)g * L.NT;
+    groups += (int64_t)g * L.NP;
     if (g > L.max_groups) L.max_groups = g;
   }
   L.panel_bytes = groups * kGroupBytes;

@@ -6,9 +6,24 @@
 
 namespace mf {
 
-
 MF_D const char* first_panel(const NetDev& n) { return n.packed + n.L.res_bytes; }
 MF_D int first_groups(const NetDev& n) { return trunk_groups(n.L, 0); }
+
+// Where the program continues after a network: the first layer of the next network evaluated.
+MF_D NextLayer follow_of(const NetDev& n) {
+  NextLayer f;
+  f.groups = trunk_groups(n.L, 0);
+  f.jump = n.packed + n.L.res_bytes;
+  f.bias_off = n.res_lds + n.L.off_bias_trunk * 4;
+  return f;
+}
+MF_D NextLayer next_trunk(const NetDev& n, int layer) {   // trunk layer `layer` of the same network
+  NextLayer f;
+  f.groups = trunk_groups(n.L, layer);
+  f.jump = nullptr;
+  f.bias_off = n.res_lds + (n.L.off_bias_trunk + layer * n.L.W) * 4;
+  return f;
+}
 
 // Copy a network's resident block (biases + VALU head weights) global -> LDS.
 MF_D void load_resident(const NetDev& n, const LaneId& id) {
@@ -16,65 +31,80 @@ MF_D void load_resident(const NetDev& n, const LaneId& id) {
   for (int g = id.wave; g < groups; g += kWaves) glds16(n.packed + g * kGroupBytes + id.lane * 16, n.res_lds + g * kGroupBytes);
 }
 
+// Prime the stream and the carry at the first panel of network `n` (kernel start).
+MF_D void start_program(const NetDev& n, Stream& st, Carry& carry, const LaneId& id) {
+  st.start(first_panel(n), first_groups(n), id);
+  carry.load(st.slot_off(0) + id.lane * 16, n.res_lds + n.L.off_bias_trunk * 4, id.g);
+}
+
 // extra_encoding (nerf.py:98): (W/2) outputs from [final(W) ; extra block], ReLU.
-template <int NT>
-MF_D void extra_layer(const NetDev& net, const f32x16 (&act)[NT], const float (&ext)[kStepsExtraMax],
-                      f32x16 (&out)[NT / 2], Stream& st, const LaneId& id, int next_groups, const char* jump) {
+template <int NK>
+MF_D void extra_layer(const NetDev& net, const f32x4 (&act)[NK], const float (&ext)[kStepsExtraMax],
+                      f32x4 (&out)[NK / 2], Stream& st, Carry& carry, const LaneId& id, const NextLayer& nxt) {
+  constexpr int NPO = NK / 4;                      // panels of the (W/2)-wide layer
   const int groups = extra_groups(net.L);
-  const int ge = net.L.extra_steps / 4;
+  const int qe = net.L.extra_steps / 4;
   const uint32_t bias_off = net.res_lds + net.L.off_bias_extra * 4;
   const float dummy[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-  for (int t = 0; t < NT / 2; ++t) {
-    if (t == NT / 2 - 1) {
-      if (jump) st.gnext = jump;
-      st.prefetch(next_groups, id);
-    } else {
-      st.prefetch(groups, id);
-    }
-    const uint32_t p = st.cur_off() + id.lane * 16;
-    f32x16 acc = bias_tile(bias_off, t, id.h);
-    acc = out_tile<2, NT, 4>(acc, act, dummy, p);
+  for (int t = 0; t < NPO; ++t) {
+    const uint32_t p = st.slot_off(0) + id.lane * 16;
+    const uint32_t pn = st.slot_off(1) + id.lane * 16;
+    const uint32_t nb = (t + 1 < NPO) ? bias_off + 32 * (t + 1) * 4 : nxt.bias_off;
+    auto hook = [&]() { st.sync_and_dma(t + 2 < NPO ? groups : nxt.groups, t == NPO - 2 ? nxt.jump : nullptr, id); };
+    // hidden part through the common path (kept linear: lo = -inf), then the <= 2 extra k-quads
+    f32x4 E, O;
+    out_pair<2, NK, 4>(carry, act, dummy, p, pn, nb, id.g, hook, -__builtin_inff(), E, O);
 #pragma unroll
-    for (int g = 0; g < kStepsExtraMax / 4; ++g) {
-      if (g < ge) {
-        const f32x4 w = lds_f4(p + (NT * 4 + g) * kGroupBytes);
+    for (int q = 0; q < kStepsExtraMax / 4; ++q) {
+      if (q < qe) {
+        const f32x4 wE = lds_f4(p + (2 * (NK + q)) * kGroupBytes);
+        const f32x4 wO = lds_f4(p + (2 * (NK + q) + 1) * kGroupBytes);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) acc = MF_MFMA(w[r], ext[4 * g + r], acc);
+        for (int r = 0; r < 4; ++r) {
+          E = MF_MFMA(wE[r], ext[4 * q + r], E);
+          O = MF_MFMA(wO[r], ext[4 * q + r], O);
+        }
       }
     }
 #pragma unroll
-    for (int i = 0; i < 16; ++i) out[t][i] = fmaxf(acc[i], 0.f);
-    st.flip();
+    for (int i = 0; i < 4; ++i) {
+      out[2 * t][i] = fmaxf(E[i], 0.f);
+      out[2 * t + 1][i] = fmaxf(O[i], 0.f);
+    }
+    st.advance();
   }
 }
 
-// Canonical NeRF on this wave's 32 samples.  `follow`/`follow_groups`: the program's next
-// panel after this network (always given; the stream jumps there after the last panel used).
-template <int NT>
+// Canonical NeRF on this wave's 16 samples.  `follow`: the first layer of whatever the panel
+// program evaluates after this network (the stream jumps there behind the last panel used).
+template <int NK>
 MF_D void nerf_eval(const NetDev& net, const float (&embx)[kStepsNerfXyz], const float (&ext)[kStepsExtraMax],
-                    bool sigma_only, Stream& st, const LaneId& id, const char* follow, int follow_groups,
+                    bool sigma_only, Stream& st, Carry& carry, const LaneId& id, const NextLayer& follow,
                     float& sigma, float (&rgb)[3]) {
-  f32x16 act[NT];
+  f32x4 act[NK];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NK; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) act[t][i] = 0.f;
+    for (int i = 0; i < 4; ++i) act[t][i] = 0.f;
   const int D = net.L.n_trunk - 1;
   for (int l = 0; l < D; ++l) {
     const bool last = sigma_only && l == D - 1;
-    trunk_layer<NT, kStepsNerfXyz>(net, l, act, embx, st, id, last ? follow_groups : trunk_groups(net.L, l + 1),
-                                   last ? follow : nullptr);
+    trunk_layer<NK, kStepsNerfXyz>(net, l, act, embx, st, carry, id, last ? follow : next_trunk(net, l + 1));
   }
   float sg[1];
-  valu_head<NT, 1>(act, net.res_lds + net.L.off_head_w * 4, net.L.W, net.res_lds + net.L.off_head_b * 4, id.h, sg);
+  valu_head<NK, 1>(act, net.res_lds + net.L.off_head_w * 4, net.L.W, net.res_lds + net.L.off_head_b * 4, id.g, sg);
   sigma = sg[0];
   if (sigma_only) return;
-  trunk_layer<NT, kStepsNerfXyz>(net, D, act, embx, st, id, extra_groups(net.L), nullptr);   // xyz_encoding_final
-  f32x16 e[NT / 2];
-  extra_layer<NT>(net, act, ext, e, st, id, follow_groups, follow);
+  NextLayer ex;
+  ex.groups = extra_groups(net.L);
+  ex.jump = nullptr;
+  ex.bias_off = net.res_lds + net.L.off_bias_extra * 4;
+  trunk_layer<NK, kStepsNerfXyz>(net, D, act, embx, st, carry, id, ex);                  // xyz_encoding_final
+  f32x4 e[NK / 2];
+  extra_layer<NK>(net, act, ext, e, st, carry, id, follow);
   float o[3];
-  valu_head<NT / 2, 3>(e, net.res_lds + net.L.off_rgb_w * 4, net.L.W / 2, net.res_lds + net.L.off_rgb_b * 4, id.h, o);
+  valu_head<NK / 2, 3>(e, net.res_lds + net.L.off_rgb_w * 4, net.L.W / 2, net.res_lds + net.L.off_rgb_b * 4, id.g, o);
 #pragma unroll
   for (int c = 0; c < 3; ++c) rgb[c] = 1.f / (1.f + expf(-o[c]));   // nn.Sigmoid, nerf.py:57-59
 }
@@ -104,29 +134,28 @@ MF_D void quat_transform(const float (&T)[9], const float (&xyz)[3], float (&out
   out[2] = (px * R02 + py * R12 + pz * R22) + T[5] + T[8];
 }
 
-// Neural motion flow on this wave's 32 samples; emb = [xyz block ; ind block] (kStepsNofIn).
+// Neural motion flow on this wave's 16 samples; emb = [xyz block ; ind block] (kStepsNofIn).
 MF_D void nof_eval(const NetDev& net, const float (&emb)[kStepsNofIn], const float (&xyz)[3], Stream& st,
-                   const LaneId& id, const char* follow, int follow_groups, float (&out)[3]) {
-  constexpr int NT = 4;
-  f32x16 act[NT];
+                   Carry& carry, const LaneId& id, const NextLayer& follow, float (&out)[3]) {
+  constexpr int NK = 8;
+  f32x4 act[NK];
 #pragma unroll
-  for (int t = 0; t < NT; ++t)
+  for (int t = 0; t < NK; ++t)
 #pragma unroll
-    for (int i = 0; i < 16; ++i) act[t][i] = 0.f;
+    for (int i = 0; i < 4; ++i) act[t][i] = 0.f;
   const int D = net.L.n_trunk;
   for (int l = 0; l < D; ++l) {
     const bool last = l == D - 1;
-    trunk_layer<NT, kStepsNofIn>(net, l, act, emb, st, id, last ? follow_groups : trunk_groups(net.L, l + 1),
-                                 last ? follow : nullptr);
+    trunk_layer<NK, kStepsNofIn>(net, l, act, emb, st, carry, id, last ? follow : next_trunk(net, l + 1));
   }
   const uint32_t wo = net.res_lds + net.L.off_head_w * 4, bo = net.res_lds + net.L.off_head_b * 4;
   if (net.L.n_head == 9) {
     float T[9];
-    valu_head<NT, 9>(act, wo, net.L.W, bo, id.h, T);
+    valu_head<NK, 9>(act, wo, net.L.W, bo, id.g, T);
     quat_transform(T, xyz, out);
   } else {
     float T[3];
-    valu_head<NT, 3>(act, wo, net.L.W, bo, id.h, T);
+    valu_head<NK, 3>(act, wo, net.L.W, bo, id.g, T);
 #pragma unroll
     for (int c = 0; c < 3; ++c) out[c] = T[c] + xyz[c];
   }
@@ -134,13 +163,12 @@ MF_D void nof_eval(const NetDev& net, const float (&emb)[kStepsNofIn], const flo
 
 // NoF input block from a point and an image index (rendering.py:70-75)
 MF_D void nof_embed(float (&emb)[kStepsNofIn], const float (&xyz)[3], float ind, const EmbParams& exyz,
-                    const EmbParams& eind, int h) {
-  emb_eval<3, 5>(emb, xyz, exyz, h);
+                    const EmbParams& eind, int g) {
+  emb_eval<3, 5>(emb, xyz, exyz, g);
   const float iv[1] = {ind};
-  emb_eval<1, 16>(emb + BlkXyz5::SLOTS, iv, eind, h);
+  emb_eval<1, 16>(emb + BlkXyz5::SLOTS, iv, eind, g);
 #pragma unroll
   for (int e = BlkXyz5::SLOTS + BlkInd16::SLOTS; e < kStepsNofIn; ++e) emb[e] = 0.f;
 }
-
 
 }  // namespace mf

@@ -3,8 +3,9 @@
 // Replaces nothing in the reference (it keeps (out,in) row-major tensors and calls addmm,
 // models/nerf.py:84-99, models/nof.py:70-75); this is the layout transform the fused kernels
 // need.  It is a pure permutation + zero padding: every packed float is either one source
-// weight or 0.  Group g of a panel holds, for lane (i = lane&31, h = lane>>5) and r = 0..3,
-// W[32t + i][col(step = 4g + r, h)]  -- see mf_core.hpp for the step -> column maps.
+// weight or 0.  A panel is 32 output rows; its groups alternate between its two 16-row tiles.
+// Group (tile half, k-quad q) holds, for lane (i = lane&15, g = lane>>4) and r = 0..3,
+// W[32P + 16*half + i][col(step = 4q + r, g)]  -- see mf_core.hpp for the step -> column maps.
 #include "mf_host.hpp"
 #include "mf_layout.hpp"
 
@@ -13,14 +14,14 @@ namespace mf {
 struct PackRegion {          // one trunk/extra layer's panels
   const float* W;            // (n_out, n_in)
   int n_in;
-  int tiles;                 // output tiles (n_out / 32)
-  int groups;                // groups per panel
+  int tiles;                 // panels (n_out / 32)
+  int groups;                // groups per panel (2 per k-quad)
   int emb_steps;             // steps taken from the embedded-input block (0 if none)
   int emb_first;             // 1: emb steps precede hidden steps (trunk); 0: follow them (extra)
   int emb_kind;
   int emb_col0;              // column of embedded feature 0 in W
   int emb_cols;              // embedded columns present in W (features >= this are zero pad)
-  int hid_steps;             // NT*16 or 0
+  int hid_steps;             // 4*NK (= W/4) or 0
   int hid_col0;              // column of hidden feature 0 in W
   int xyz_cols;
   long long dst_group0;      // first group index (in 1 KiB units) within the panel area
@@ -42,22 +43,23 @@ __global__ void pack_panels_kernel(PackJob job) {
   while (ri + 1 < job.n_regions && grp >= job.reg[ri + 1].dst_group0) ++ri;
   const PackRegion& R = job.reg[ri];
   const long long local = grp - R.dst_group0;
-  const int t = (int)(local / R.groups), g = (int)(local % R.groups);
-  const int i = lane & 31, h = lane >> 5;
-  const int n = 32 * t + i;
+  const int P = (int)(local / R.groups), gi = (int)(local % R.groups);
+  const int q = gi >> 1, half = gi & 1;
+  const int i = lane & 15, g = lane >> 4;
+  const int n = 32 * P + 16 * half + i;
   float4 v;
   float* pv = &v.x;
   for (int r = 0; r < 4; ++r) {
-    const int s = 4 * g + r;
+    const int s = 4 * q + r;
     int col = -1;
-    int se = R.emb_first ? s : s - R.hid_steps;
-    int sh = R.emb_first ? s - R.emb_steps : s;
+    const int se = R.emb_first ? s : s - R.hid_steps;
+    const int sh = R.emb_first ? s - R.emb_steps : s;
     if (se >= 0 && se < R.emb_steps) {
-      const int f = emb_feature(R.emb_kind, h, se, R.xyz_cols);
+      const int f = emb_feature(R.emb_kind, g, se, R.xyz_cols);
       if (f >= 0 && f < R.emb_cols) col = R.emb_col0 + f;
     } else if (sh >= 0 && sh < R.hid_steps) {
-      const int tin = sh >> 4, q = (sh >> 2) & 3, rr = sh & 3;
-      col = R.hid_col0 + 32 * tin + 8 * q + 4 * h + rr;
+      const int kt = sh >> 2, rr = sh & 3;
+      col = R.hid_col0 + 16 * kt + 4 * g + rr;
     }
     pv[r] = col >= 0 ? R.W[(long long)n * R.n_in + col] : 0.f;
   }
@@ -118,14 +120,14 @@ extern "C" int32_t mf_nerf_pack(const mf_nerf_desc* d, void* packed, void* strea
     R.W = l < d->D ? d->trunk_w[l] : d->final_w;
     if (!R.W) return fail(MF_E_INVALID, "mf_nerf_pack: missing weight pointer for layer %d", l);
     R.n_in = (has_emb ? d->in_channels_xyz : 0) + (l > 0 ? L.W : 0);
-    R.tiles = L.NT;
+    R.tiles = L.NP;
     R.groups = trunk_groups(L, l);
     R.emb_steps = has_emb ? L.emb_steps : 0;
     R.emb_first = 1;
     R.emb_kind = kEmbNerfXyz;
     R.emb_col0 = 0;
     R.emb_cols = d->in_channels_xyz;
-    R.hid_steps = l > 0 ? L.NT * 16 : 0;
+    R.hid_steps = l > 0 ? L.NK * 4 : 0;
     R.hid_col0 = has_emb ? d->in_channels_xyz : 0;
     R.xyz_cols = d->in_channels_xyz;
     R.dst_group0 = g0;
@@ -139,14 +141,14 @@ extern "C" int32_t mf_nerf_pack(const mf_nerf_desc* d, void* packed, void* strea
     R.W = d->extra_w;
     if (!R.W) return fail(MF_E_INVALID, "mf_nerf_pack: missing extra_encoding weight");
     R.n_in = L.W + ext;
-    R.tiles = L.NT / 2;
+    R.tiles = L.NP / 2;
     R.groups = extra_groups(L);
     R.emb_steps = L.extra_steps;
     R.emb_first = 0;
     R.emb_kind = d->extra_feat_type == MF_EXTRA_DIR ? kEmbDir : (d->extra_feat_type == MF_EXTRA_IND ? kEmbInd : kEmbNone);
     R.emb_col0 = L.W;
     R.emb_cols = ext;
-    R.hid_steps = L.NT * 16;
+    R.hid_steps = L.NK * 4;
     R.hid_col0 = 0;
     R.xyz_cols = 0;
     R.dst_group0 = g0;
@@ -185,14 +187,14 @@ extern "C" int32_t mf_nof_pack(const mf_nof_desc* d, void* packed, void* stream)
     R.W = d->trunk_w[l];
     if (!R.W || !d->trunk_b[l]) return fail(MF_E_INVALID, "mf_nof_pack: missing parameter pointer for layer %d", l);
     R.n_in = (has_emb ? cin : 0) + (l > 0 ? L.W : 0);
-    R.tiles = L.NT;
+    R.tiles = L.NP;
     R.groups = trunk_groups(L, l);
     R.emb_steps = has_emb ? L.emb_steps : 0;
     R.emb_first = 1;
     R.emb_kind = kEmbNofIn;
     R.emb_col0 = 0;
     R.emb_cols = cin;
-    R.hid_steps = l > 0 ? L.NT * 16 : 0;
+    R.hid_steps = l > 0 ? L.NK * 4 : 0;
     R.hid_col0 = has_emb ? cin : 0;
     R.xyz_cols = d->in_channels_xyz;
     R.dst_group0 = g0;

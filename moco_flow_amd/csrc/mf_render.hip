@@ -9,12 +9,12 @@
 // HBM except the optional (N,S) planes a caller asks for (weights/alphas feed sample_pdf and the
 // consensus mask; disp_* are the per-sample consensus distances).
 //
-// Work decomposition: a workgroup (4 waves, one per SIMD, up to 512 VGPRs each) takes a GROUP
+// Work decomposition: a workgroup (8 waves, two per SIMD, <= 256 registers each) takes a GROUP
 // of G whole rays (G*S samples, a multiple of 128 whenever S allows), walks it in tiles of 128
-// samples -- 32 per wave, one sample per lane&31, the two lane halves holding the two k-halves
-// of every MFMA step -- and keeps each sample's (r,g,b,sigma,z) in LDS until the group's rays
-// are composited by one wave per ray with a wavefront product-scan.  Workgroups are persistent
-// (grid = #CUs) so the weight stream never drains between tiles.
+// samples -- 16 per wave, one sample per lane&15, the four 16-lane groups holding the four
+// k-quarters of every MFMA step -- and keeps each sample's (r,g,b,sigma,z) in LDS until the
+// group's rays are composited by one wave per ray with a wavefront product-scan.  Workgroups
+// are persistent (grid = #CUs) so the weight stream never drains between tiles.
 #include "mf_host.hpp"
 #include "mf_layout.hpp"
 #include "mf_nets.hpp"
@@ -55,7 +55,7 @@ MF_D float wave_sum(float v) {
 }
 
 template <bool MOCO>
-__global__ __launch_bounds__(256, 1) void render_kernel(RenderParams p) {
+__global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
   const LaneId id;
   const NetDev nerf = p.nerf;
   load_resident(nerf, id);
@@ -64,11 +64,13 @@ __global__ __launch_bounds__(256, 1) void render_kernel(RenderParams p) {
     if (p.flags & (MF_F_CHAIN_LOCAL | MF_F_CHAIN_GLOBAL)) load_resident(p.fw, id);
   }
   Stream st;
+  Carry carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
-  const char* prog_first = MOCO ? first_panel(p.bw) : first_panel(nerf);
-  const int prog_first_groups = MOCO ? first_groups(p.bw) : first_groups(nerf);
-  st.start(prog_first, prog_first_groups, id);
+  // the panel program of a tile: [bw NoF, fw NoF chains,] NeRF, then around again
+  const NextLayer prog_first = MOCO ? follow_of(p.bw) : follow_of(nerf);
+  if (MOCO) start_program(p.bw, st, carry, id);
+  else start_program(nerf, st, carry, id);
 
   const int S = p.S;
   const bool sigma_only = p.flags & MF_F_SIGMA_ONLY;
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(256, 1) void render_kernel(RenderParams p) {
     const int ntiles = (nsamp + kTile - 1) / kTile;
 
     for (int tile = 0; tile < ntiles; ++tile) {
-      const int srel = tile * kTile + id.wave * 32 + id.j;
+      const int srel = tile * kTile + id.wave * kWaveSamples + id.j;
       const bool valid = srel < nsamp;
       const int sl = valid ? srel : nsamp - 1;
       const int rr = sl / S;
@@ -124,40 +126,39 @@ __global__ __launch_bounds__(256, 1) void render_kernel(RenderParams p) {
           // what follows this evaluation in the panel program
           const bool last = step == nsteps - 1;
           const bool next_fw = (role + 1 == 1 || role + 1 == 2 || role + 1 == 4);
-          const char* follow = last ? first_panel(nerf) : (next_fw ? first_panel(p.fw) : first_panel(p.bw));
-          const int follow_groups = last ? first_groups(nerf) : (next_fw ? first_groups(p.fw) : first_groups(p.bw));
+          const NextLayer follow = last ? follow_of(nerf) : (next_fw ? follow_of(p.fw) : follow_of(p.bw));
           float emb[kStepsNofIn], out[3];
-          nof_embed(emb, cur, ind, p.nxyz, p.nind, id.h);
-          nof_eval(net, emb, cur, st, id, follow, follow_groups, out);
+          nof_embed(emb, cur, ind, p.nxyz, p.nind, id.g);
+          nof_eval(net, emb, cur, st, carry, id, follow, out);
           if (role == 0) { canon[0] = out[0]; canon[1] = out[1]; canon[2] = out[2]; }
           if (role == 1) dl = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
           if (role == 4) dg = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
           cur[0] = out[0]; cur[1] = out[1]; cur[2] = out[2];
         }
         xin[0] = canon[0]; xin[1] = canon[1]; xin[2] = canon[2];
-        if (valid && id.h == 0) {
+        if (valid && id.g == 0) {
           if (loc && p.disp_local) p.disp_local[ray * S + si] = dl;
           if (glob && p.disp_global) p.disp_global[ray * S + si] = dg;
         }
       }
 
       float embx[kStepsNerfXyz], ext[kStepsExtraMax];
-      emb_eval<3, 10>(embx, xin, p.exyz, id.h);
+      emb_eval<3, 10>(embx, xin, p.exyz, id.g);
 #pragma unroll
       for (int e = BlkXyz10::SLOTS; e < kStepsNerfXyz; ++e) embx[e] = 0.f;
 #pragma unroll
       for (int e = 0; e < kStepsExtraMax; ++e) ext[e] = 0.f;
       if (!sigma_only) {
         if (p.extra_type == MF_EXTRA_DIR) {
-          emb_eval<3, 4>(ext, d, p.eext, id.h);                                // rendering.py:138-142
+          emb_eval<3, 4>(ext, d, p.eext, id.g);                                // rendering.py:138-142
         } else if (p.extra_type == MF_EXTRA_IND) {
           const float iv[1] = {rp[8]};
-          emb_eval<1, 2>(ext, iv, p.eext, id.h);                               // rendering.py:133-137
+          emb_eval<1, 2>(ext, iv, p.eext, id.g);                               // rendering.py:133-137
         }
       }
       float sigma, rgb[3] = {0.f, 0.f, 0.f};
-      nerf_eval<8>(nerf, embx, ext, sigma_only, st, id, prog_first, prog_first_groups, sigma, rgb);
-      if (valid && id.h == 0) {
+      nerf_eval<16>(nerf, embx, ext, sigma_only, st, carry, id, prog_first, sigma, rgb);
+      if (valid && id.g == 0) {
         sbuf[srel] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
         zbuf[srel] = z;
       }
@@ -221,6 +222,7 @@ __global__ __launch_bounds__(256, 1) void render_kernel(RenderParams p) {
     }
     __syncthreads();
   }
+  wait_vm0();   // the stream runs two panels ahead: drain the LDS-DMA before the workgroup retires
 }
 
 static void to_params(const mf_embedding& e, EmbParams& o) {
@@ -247,7 +249,7 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
     return fail(MF_E_INVALID, "mf_render_pass: activation %d not supported", a->activation);
   RenderParams p{};
   if (!nerf_layout(*a->nerf, p.nerf.L)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported NeRF configuration");
-  if (p.nerf.L.NT != 8) return fail(MF_E_UNSUPPORTED, "mf_render_pass: only W=256 NeRF is built");
+  if (p.nerf.L.NK != 16) return fail(MF_E_UNSUPPORTED, "mf_render_pass: only W=256 NeRF is built");
   if (a->emb_xyz.in_channels != 3 || a->emb_xyz.n_freqs > 10)
     return fail(MF_E_UNSUPPORTED, "mf_render_pass: xyz embedding must have 3 channels and <= 10 frequencies");
   const bool sigma_only = a->flags & MF_F_SIGMA_ONLY;
@@ -301,7 +303,7 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
   }
   p.ring_off = lds;
   p.buf_bytes = (uint32_t)max_groups * kGroupBytes;
-  lds += 2 * p.buf_bytes;
+  lds += 3 * p.buf_bytes;
 
   // rays per group: smallest G with G*S a multiple of the 128-sample tile, capped by the LDS left
   const uint32_t lds_cap = 160 * 1024;
@@ -330,11 +332,11 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
   if (moco) {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(render_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);
-    hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(kThreads), lds, st, p);
   } else {
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(render_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);
-    hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(256), lds, st, p);
+    hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(kThreads), lds, st, p);
   }
   return check_launch("mf_render_pass");
 }
