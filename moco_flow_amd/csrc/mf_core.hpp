@@ -182,6 +182,7 @@ struct Stream {
   uint32_t ring;          // LDS byte offset of slot 0
   uint32_t buf_bytes;     // bytes per slot
   uint32_t cur;           // slot (0..2) of the panel being computed
+  int dbg;                // timing-ablation switches (MF_DEBUG_FLAGS; 0 in production)
 
   MF_D uint32_t slot_off(uint32_t k) const {
     uint32_t s = cur + k;
@@ -196,10 +197,11 @@ struct Stream {
   // barrier of the panel + launch of the DMA for the panel two ahead
   MF_D void sync_and_dma(int groups, const char* jump, const LaneId& id) {
     wait_vm0();
-    __builtin_amdgcn_s_barrier();
+    if (!(dbg & 1)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (jump) gnext = jump;
-    dma_to(slot_off(2), groups, id);
+    if (!(dbg & 2)) dma_to(slot_off(2), groups, id);
+    else gnext += (size_t)groups * kGroupBytes;
   }
   MF_D void advance() { cur = cur == 2u ? 0u : cur + 1u; }
   // cold start: the program's first two panels (same layer, `groups` each) into slots 0 and 1

@@ -58,6 +58,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_forward_kernel(NerfFwdParams
   Carry carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
+  st.dbg = 0;
   start_program(net, st, carry, id);                    // also drains the resident-block DMA
   const long long ntiles = (p.B + kTile - 1) / kTile;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -110,6 +111,7 @@ __global__ __launch_bounds__(kThreads, 2) void nof_forward_kernel(NofFwdParams p
   Carry carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
+  st.dbg = 0;
   start_program(net, st, carry, id);
   const long long ntiles = (p.B + kTile - 1) / kTile;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {

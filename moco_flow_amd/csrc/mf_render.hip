@@ -15,6 +15,8 @@
 // k-quarters of every MFMA step -- and keeps each sample's (r,g,b,sigma,z) in LDS until the
 // group's rays are composited by one wave per ray with a wavefront product-scan.  Workgroups
 // are persistent (grid = #CUs) so the weight stream never drains between tiles.
+#include <cstdlib>
+
 #include "mf_host.hpp"
 #include "mf_layout.hpp"
 #include "mf_nets.hpp"
@@ -37,6 +39,7 @@ struct RenderParams {
   int G;
   long long n_groups;
   uint32_t ring_off, buf_bytes, sbuf_off, zbuf_off;
+  int dbg;
 };
 
 // inclusive product scan across the 64 lanes of a wave
@@ -67,6 +70,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
   Carry carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
+  st.dbg = p.dbg;
   // the panel program of a tile: [bw NoF, fw NoF chains,] NeRF, then around again
   const NextLayer prog_first = MOCO ? follow_of(p.bw) : follow_of(nerf);
   if (MOCO) start_program(p.bw, st, carry, id);
@@ -143,7 +147,8 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
       }
 
       float embx[kStepsNerfXyz], ext[kStepsExtraMax];
-      emb_eval<3, 10>(embx, xin, p.exyz, id.g);
+      if (!(p.dbg & 4)) emb_eval<3, 10>(embx, xin, p.exyz, id.g);
+      else { for (int e = 0; e < kStepsNerfXyz; ++e) embx[e] = xin[e % 3]; }
 #pragma unroll
       for (int e = BlkXyz10::SLOTS; e < kStepsNerfXyz; ++e) embx[e] = 0.f;
 #pragma unroll
@@ -166,7 +171,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
     __syncthreads();
 
     // ---- composite (rendering.py:157-192): one wave per ray, lanes over samples
-    for (int rr = id.wave; rr < nr; rr += kWaves) {
+    for (int rr = id.wave; rr < ((p.dbg & 8) ? 0 : nr); rr += kWaves) {
       const long long ray = ray0 + rr;
       const float* rp = p.rays + ray * p.ray_stride;
       const float dnorm = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);  // rendering.py:164
@@ -278,6 +283,7 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
   p.extra_type = a->nerf->extra_feat_type;
   p.rgb = a->rgb; p.depth = a->depth; p.opacity = a->opacity; p.weights = a->weights; p.alphas = a->alphas;
   p.disp_local = a->disp_local; p.disp_global = a->disp_global;
+  { const char* e = getenv("MF_DEBUG_FLAGS"); p.dbg = e ? atoi(e) : 0; }   // timing ablations only
 
   uint32_t lds = 0;
   p.nerf.res_lds = lds; lds += (uint32_t)p.nerf.L.res_bytes;
