@@ -194,13 +194,23 @@ struct Stream {
     for (int grp = id.wave; grp < groups; grp += kWaves) glds16(g + grp * kGroupBytes, dst + grp * kGroupBytes);
     gnext += (size_t)groups * kGroupBytes;
   }
+  // steady state: only the "early" half of the workgroup (waves 4-7, one per SIMD) issues the
+  // DMA -- its SIMD partner is in the MFMA-dense middle of its panel at that moment
+  MF_D void dma_early_half(uint32_t dst, int groups, const LaneId& id) {
+    if (id.wave >= kWaves / 2) {
+      const char* g = gnext + id.lane * 16;
+      for (int grp = id.wave - kWaves / 2; grp < groups; grp += kWaves / 2)
+        glds16(g + grp * kGroupBytes, dst + grp * kGroupBytes);
+    }
+    gnext += (size_t)groups * kGroupBytes;
+  }
   // barrier of the panel + launch of the DMA for the panel two ahead
   MF_D void sync_and_dma(int groups, const char* jump, const LaneId& id) {
     wait_vm0();
     if (!(dbg & 1)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (jump) gnext = jump;
-    if (!(dbg & 2)) dma_to(slot_off(2), groups, id);
+    if (!(dbg & 2)) dma_early_half(slot_off(2), groups, id);
     else gnext += (size_t)groups * kGroupBytes;
   }
   MF_D void advance() { cur = cur == 2u ? 0u : cur + 1u; }
@@ -238,13 +248,17 @@ struct Carry {
 // MODE: 1 = embedded input only, 2 = hidden only, 3 = both (skip layers, emb first).
 // Per k-quad: two ds_read_b128 (one group per tile) feed 8 MFMAs; the E and O chains alternate
 // and share every B operand, so no MFMA directly follows its own predecessor and the ds_reads
-// sit between independent MFMAs.  Groups are fetched one k-quad (8 MFMAs) ahead.  `hook` runs
-// behind the first MFMA pair of the panel (workgroup barrier + DMA of the panel two ahead);
-// the NEXT panel's Carry is read behind the first pair of the last k-quad.
+// sit between independent MFMAs.  Groups are fetched one k-quad (8 MFMAs) ahead.  `hook` is the
+// panel's workgroup barrier (+ DMA of the panel two ahead).  It sits behind the FIRST k-quad's
+// leading MFMA pair for the early half of the workgroup (waves 4-7) and in the MIDDLE of the
+// panel for the late half (waves 0-3): since all eight waves meet at that barrier, the two waves
+// that share a SIMD run half a panel out of phase, so one of them is always in MFMA-dense code
+// while the other crosses a panel boundary (epilogue, branches, carry loads, DMA issue).
+// The NEXT panel's Carry is read behind the first pair of the last k-quad.
 template <int MODE, int NK, int EMB, class Hook>
 MF_D void out_pair(Carry& carry, const f32x4 (&hid)[NK], const float (&emb)[EMB], uint32_t panel_lane_off,
-                   uint32_t next_panel_lane_off, uint32_t next_bias_off, int g, Hook&& hook, float lo, f32x4& outE,
-                   f32x4& outO) {
+                   uint32_t next_panel_lane_off, uint32_t next_bias_off, int g, bool late, Hook&& hook, float lo,
+                   f32x4& outE, f32x4& outO) {
   constexpr int QE = (MODE & 1) ? EMB / 4 : 0;
   constexpr int QH = (MODE & 2) ? NK : 0;
   constexpr int Q = QE + QH;
@@ -261,7 +275,8 @@ MF_D void out_pair(Carry& carry, const f32x4 (&hid)[NK], const float (&emb)[EMB]
       nE = lds_f4(panel_lane_off + (2 * (q + 1)) * kGroupBytes);
       nO = lds_f4(panel_lane_off + (2 * (q + 1) + 1) * kGroupBytes);
     }
-    if (q == 0) hook();
+    if (q == 0 && !late) hook();
+    if (q == Q / 2 && late) hook();
     if (q + 1 >= Q) carry.load(next_panel_lane_off, next_bias_off, g);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -312,9 +327,10 @@ MF_D void trunk_layer(const NetDev& net, int layer, f32x4 (&act)[NK], const floa
     const uint32_t nb = (t + 1 < NP) ? bias_off + 32 * (t + 1) * 4 : nxt.bias_off;
     // panel two ahead: same layer while t+2 < NP, else panel (t+2-NP) of the next layer
     auto hook = [&]() { st.sync_and_dma(t + 2 < NP ? groups : nxt.groups, t == NP - 2 ? nxt.jump : nullptr, id); };
-    if (mode == 2) out_pair<2, NK, EMB>(carry, act, emb, p, pn, nb, id.g, hook, lo, out[2 * t], out[2 * t + 1]);
-    else if (mode == 3) out_pair<3, NK, EMB>(carry, act, emb, p, pn, nb, id.g, hook, lo, out[2 * t], out[2 * t + 1]);
-    else out_pair<1, NK, EMB>(carry, act, emb, p, pn, nb, id.g, hook, lo, out[2 * t], out[2 * t + 1]);
+    const bool late = id.wave < kWaves / 2;
+    if (mode == 2) out_pair<2, NK, EMB>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, out[2 * t], out[2 * t + 1]);
+    else if (mode == 3) out_pair<3, NK, EMB>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, out[2 * t], out[2 * t + 1]);
+    else out_pair<1, NK, EMB>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, out[2 * t], out[2 * t + 1]);
     st.advance();
   }
 #pragma unroll
