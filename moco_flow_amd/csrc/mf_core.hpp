@@ -194,8 +194,8 @@ struct Stream {
     for (int grp = id.wave; grp < groups; grp += kWaves) glds16(g + grp * kGroupBytes, dst + grp * kGroupBytes);
     gnext += (size_t)groups * kGroupBytes;
   }
-  // steady state: only the "early" half of the workgroup (waves 4-7, one per SIMD) issues the
-  // DMA -- its SIMD partner is in the MFMA-dense middle of its panel at that moment
+  // variant kept for A/B runs: only the "early" half of the workgroup (waves 4-7, one per SIMD)
+  // issues the DMA (measured 1 % slower than all eight waves issuing, profiles/r01 notes)
   MF_D void dma_early_half(uint32_t dst, int groups, const LaneId& id) {
     if (id.wave >= kWaves / 2) {
       const char* g = gnext + id.lane * 16;
@@ -206,11 +206,12 @@ struct Stream {
   }
   // barrier of the panel + launch of the DMA for the panel two ahead
   MF_D void sync_and_dma(int groups, const char* jump, const LaneId& id) {
-    wait_vm0();
+    if (!(dbg & 16)) wait_vm0();
     if (!(dbg & 1)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (jump) gnext = jump;
-    if (!(dbg & 2)) dma_early_half(slot_off(2), groups, id);
+    if (dbg & 32) dma_early_half(slot_off(2), groups, id);         // ablation: one issuing wave per SIMD
+    else if (!(dbg & 2)) dma_to(slot_off(2), groups, id);
     else gnext += (size_t)groups * kGroupBytes;
   }
   MF_D void advance() { cur = cur == 2u ? 0u : cur + 1u; }
@@ -327,7 +328,7 @@ MF_D void trunk_layer(const NetDev& net, int layer, f32x4 (&act)[NK], const floa
     const uint32_t nb = (t + 1 < NP) ? bias_off + 32 * (t + 1) * 4 : nxt.bias_off;
     // panel two ahead: same layer while t+2 < NP, else panel (t+2-NP) of the next layer
     auto hook = [&]() { st.sync_and_dma(t + 2 < NP ? groups : nxt.groups, t == NP - 2 ? nxt.jump : nullptr, id); };
-    const bool late = id.wave < kWaves / 2;
+    const bool late = id.wave < kWaves / 2 && !(st.dbg & 64);
     if (mode == 2) out_pair<2, NK, EMB>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, out[2 * t], out[2 * t + 1]);
     else if (mode == 3) out_pair<3, NK, EMB>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, out[2 * t], out[2 * t + 1]);
     else out_pair<1, NK, EMB>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, out[2 * t], out[2 * t + 1]);

@@ -54,7 +54,7 @@ MF_D void extra_layer(const NetDev& net, const f32x4 (&act)[NK], const float (&e
     auto hook = [&]() { st.sync_and_dma(t + 2 < NPO ? groups : nxt.groups, t == NPO - 2 ? nxt.jump : nullptr, id); };
     // hidden part through the common path (kept linear: lo = -inf), then the <= 2 extra k-quads
     f32x4 E, O;
-    out_pair<2, NK, 4>(carry, act, dummy, p, pn, nb, id.g, id.wave < kWaves / 2, hook, -__builtin_inff(), E, O);
+    out_pair<2, NK, 4>(carry, act, dummy, p, pn, nb, id.g, id.wave < kWaves / 2 && !(st.dbg & 64), hook, -__builtin_inff(), E, O);
 #pragma unroll
     for (int q = 0; q < kStepsExtraMax / 4; ++q) {
       if (q < qe) {

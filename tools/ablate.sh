@@ -1,6 +1,6 @@
 #!/bin/bash
 # timing ablations of the render kernel (results are WRONG with flags != 0; timing only)
-for f in 0 1 2 3 4 8 15; do
+for f in ${FLAGS:-0 1 2 3 4 8 15}; do
   echo -n "MF_DEBUG_FLAGS=$f: "
   MF_DEBUG_FLAGS=$f python bench.py --no-cpu-baseline --steps 30 --warmup 3 | python -c "import sys,json; d=json.loads(sys.stdin.readline()); print('ms', round(d['ms_per_step'],4), 'frac', round(d['roofline']['frac'],4))"
 done
