@@ -177,7 +177,10 @@ def main():
                    "rays_per_gpu": N_RAYS, "samples_per_ray": N_SAMPLES, "global_rays": N_RAYS * world,
                    "sharding": f"rays{world}" if world > 1 else "none"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_F32_TFLOPS, "traffic": None,
+                     "frac": achieved / PEAK_F32_TFLOPS,
+                     # HBM bytes per launch from the committed PMC passes of this same command
+                     # (profiles/r01c_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); C2 only
+                     "traffic": 25.3e6 if a.workload == "nerf" else None, "traffic_unit": "B/launch",
                      "kernel_ms": kernel_ms, "flops_per_launch": N_RAYS * N_SAMPLES * flops_per_sample},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
