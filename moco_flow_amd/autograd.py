@@ -1,0 +1,190 @@
+"""Backward pass of the drop-in modules -- INTERIM.
+
+Forward values always come from the fused HIP kernels. When gradients are requested, the
+backward of the custom autograd Functions below RE-COMPUTES the same pass with differentiable
+PyTorch-ROCm device ops (the reference's own op sequence: models/nerf.py:78-102,
+models/nof.py:69-82, models/embedding.py:42-46, models/rendering.py:49-192) on exactly the
+depths / noise / masks the kernels used, and back-propagates through that. This runs on the GPU
+(it is not a CPU path and shares no code with the test-side checker); it is reference-speed, not fused, and is
+what a fused HIP backward (dX chain with recomputed ReLU masks + dW GEMMs) will replace.
+Gradients flow to every network parameter that requires grad (frozen sub-modules are honoured,
+trainer_moco_flow.py:391-404) and not through the resampled depths (rendering.py:323).
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+
+# ------------------------------------------------------------------ differentiable restatement
+def embed(emb, x):
+    """embedding.py:42-46 with torch ops on x's device."""
+    out = [x]
+    for w, f in zip(emb.weights, emb.freq_bands):
+        f = float(f)
+        out += [w * torch.sin(f * x), w * torch.cos(f * x)]
+    return torch.cat(out, -1)
+
+
+def _pad_to(t, width):
+    if t.shape[1] == width:
+        return t
+    out = t.new_zeros((t.shape[0], width))
+    out[:, :t.shape[1]] = t
+    return out
+
+
+def nerf_forward(m, inputs, sigma_only=False):
+    """nerf.py:78-102 on the module's own parameters."""
+    if not sigma_only:
+        xyz, extra = torch.split(inputs, [m.in_channels_xyz, m.extra_feat_dim], dim=-1)
+    else:
+        xyz = inputs
+    h = xyz
+    for i in range(m.D):
+        if i in m.skips:
+            h = torch.cat([xyz, h], -1)
+        lin = getattr(m, f"xyz_encoding_{i+1}")[0]
+        h = F.relu(F.linear(h, lin.weight, lin.bias))
+    sigma = F.linear(h, m.sigma.weight, m.sigma.bias)
+    if sigma_only:
+        return sigma
+    feat = F.linear(h, m.xyz_encoding_final.weight, m.xyz_encoding_final.bias)
+    e = F.relu(F.linear(torch.cat([feat, extra], -1), m.extra_encoding[0].weight, m.extra_encoding[0].bias))
+    rgb = torch.sigmoid(F.linear(e, m.rgb[0].weight, m.rgb[0].bias))
+    return torch.cat([rgb, sigma], -1)
+
+
+def _quat_rotate(T, xyz):
+    """kornia 0.6.5 quaternion_log_to_exp + quaternion_to_rotation_matrix (restated),
+    then nof.py:80."""
+    v, s, t = T[:, :3], T[:, 3:6], T[:, 6:9]
+    n = torch.norm(v, p=2, dim=-1, keepdim=True).clamp(min=1e-8)
+    q = torch.cat([v * torch.sin(n) / n, torch.cos(n)], -1)
+    q = F.normalize(q, p=2.0, dim=-1, eps=1e-12)
+    x, y, z, w = torch.chunk(q, 4, dim=-1)
+    tx, ty, tz = 2.0 * x, 2.0 * y, 2.0 * z
+    twx, twy, twz = tx * w, ty * w, tz * w
+    txx, txy, txz = tx * x, ty * x, tz * x
+    tyy, tyz, tzz = ty * y, tz * y, tz * z
+    R = torch.stack((1.0 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.0 - (txx + tzz), tyz - twx,
+                     txz - twy, tyz + twx, 1.0 - (txx + tyy)), dim=-1).view(-1, 3, 3)
+    return torch.bmm((xyz - s).unsqueeze(1), R).squeeze(1) + s + t
+
+
+def nof_forward(m, inputs, xyz):
+    """nof.py:69-82."""
+    u = inputs
+    for i in range(m.D):
+        if i in m.skips:
+            u = torch.cat([inputs, u], -1)
+        lin = getattr(m, f"nof_encoding_{i+1}")[0]
+        u = F.relu(F.linear(u, lin.weight, lin.bias))
+    head = F.linear(u, m.nof_encoding_final.weight, m.nof_encoding_final.bias)
+    return _quat_rotate(head, xyz) if m.use_quat else head + xyz
+
+
+def _nof_points(xyz, ind, nof_embs, m):
+    """rendering.py:49-83 for (N,S,3) points and (N,1) indices."""
+    N, S = xyz.shape[0], xyz.shape[1]
+    flat = xyz.reshape(-1, 3)
+    xe = _pad_to(embed(nof_embs[0], flat), m.in_channels_xyz)
+    ie = torch.repeat_interleave(embed(nof_embs[1], ind), repeats=S, dim=0)
+    return nof_forward(m, torch.cat([xe, ie], -1), flat).view(N, S, 3)
+
+
+def render_pass(rays, background, z_vals, noise, activation, nerf, nerf_embs, nof_models, nof_embs,
+                chain_local, chain_global, sigma_only, masks: Optional[Dict[str, torch.Tensor]]):
+    """One pass of render_rays (rendering.py:262-314 / 329-373) as differentiable torch ops on given
+    depths. Returns the same dict the fused kernel fills (rgb, depth, opacity, weights, alphas and the
+    mask-compacted consensus vectors when ``masks`` carries the kernel's mask)."""
+    N, S = z_vals.shape
+    o, d = rays[:, 0:3], rays[:, 3:6]
+    ind = rays[:, 8:9]
+    xyz = o.unsqueeze(1) + d.unsqueeze(1) * z_vals.unsqueeze(2)
+    out = {}
+    pts = xyz
+    if nof_models is not None:
+        bw = nof_models[0]
+        canon = _nof_points(xyz, ind, nof_embs, bw)
+        if chain_local:
+            fw = nof_models[1]
+            recon = _nof_points(canon, ind, nof_embs, fw)
+            out["disp_local_full"] = torch.abs(xyz - recon)
+        if chain_global:
+            cind = rays[:, 9:10]
+            a = _nof_points(canon, cind, nof_embs, fw)
+            b = _nof_points(a, cind, nof_embs, bw)
+            out["disp_global_full"] = torch.abs(xyz - _nof_points(b, ind, nof_embs, fw))
+        pts = canon
+    flat = pts.reshape(-1, 3)
+    inp = _pad_to(embed(nerf_embs[0], flat), nerf.in_channels_xyz)
+    if not sigma_only:
+        if nerf.extra_feat_type == "ind":
+            e = torch.repeat_interleave(embed(nerf_embs[1], ind), repeats=S, dim=0)
+            inp = torch.cat([inp, _pad_to(e, nerf.extra_feat_dim)], 1)
+        elif nerf.extra_feat_type == "dir":
+            e = torch.repeat_interleave(embed(nerf_embs[2], d), repeats=S, dim=0)
+            inp = torch.cat([inp, _pad_to(e, nerf.extra_feat_dim)], 1)
+    net = nerf_forward(nerf, inp, sigma_only=sigma_only)
+    if sigma_only:
+        sigmas, rgbs = net.view(N, S), None
+    else:
+        net = net.view(N, S, 4)
+        rgbs, sigmas = net[..., :3], net[..., 3]
+    deltas = z_vals[:, 1:] - z_vals[:, :-1]
+    deltas = torch.cat([deltas, 1e10 * torch.ones_like(deltas[:, :1])], -1) * torch.norm(d.unsqueeze(1), dim=-1)
+    sg = sigmas if noise is None else sigmas + noise
+    act = torch.relu(sg) if activation == "relu" else F.softplus(sg)
+    alphas = 1 - torch.exp(-deltas * act)
+    shifted = torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas + 1e-10], -1)
+    weights = alphas * torch.cumprod(shifted, -1)[:, :-1]
+    out["opacity"] = weights.sum(1)
+    out["weights"], out["alphas"] = weights, alphas
+    if not sigma_only:
+        rgb = torch.sum(weights.unsqueeze(-1) * rgbs, -2)
+        if background is not None:
+            rgb = rgb + background * (1 - out["opacity"].unsqueeze(-1))
+        out["rgb"] = rgb
+        out["depth"] = torch.sum(weights * z_vals, -1)
+    return out
+
+
+# ------------------------------------------------------------------ autograd glue
+def needs_grad(modules) -> bool:
+    return torch.is_grad_enabled() and any(p.requires_grad for m in modules if m is not None for p in m.parameters())
+
+
+class RecomputeBackward(torch.autograd.Function):
+    """forward: hand back tensors already computed by the HIP kernels; backward: rebuild them with
+    ``recompute()`` (differentiable torch ops) and pull the incoming gradients through."""
+
+    @staticmethod
+    def forward(ctx, recompute, n_out, *tensors):
+        outs, params = tensors[:n_out], tensors[n_out:]
+        ctx.recompute = recompute
+        ctx.params = params
+        return tuple(o.detach() for o in outs)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        params = ctx.params
+        with torch.enable_grad():
+            outs = ctx.recompute()
+        pairs = [(o, g) for o, g in zip(outs, grads) if g is not None and o.requires_grad]
+        need = [i for i, p in enumerate(params) if p.requires_grad]
+        result: List[Optional[torch.Tensor]] = [None] * len(params)
+        if pairs and need:
+            got = torch.autograd.grad([o for o, _ in pairs], [params[i] for i in need],
+                                      [g.to(o.dtype) for o, g in pairs], allow_unused=True)
+            for i, g in zip(need, got):
+                result[i] = g
+        return (None, None) + tuple([None] * len(grads)) + tuple(result)
+
+
+def attach(outputs: List[torch.Tensor], params: List[torch.Tensor], recompute) -> List[torch.Tensor]:
+    """Make the HIP-computed ``outputs`` differentiable w.r.t. ``params`` through ``recompute``."""
+    res = RecomputeBackward.apply(recompute, len(outputs), *outputs, *params)
+    return list(res)

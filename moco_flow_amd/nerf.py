@@ -3,7 +3,7 @@ import torch
 from torch import nn
 
 from . import _lib as L
-from .packing import PackedWeights, _grad_guard
+from .packing import PackedWeights
 
 
 class NeRF(nn.Module):
@@ -79,7 +79,6 @@ class NeRF(nn.Module):
     def forward(self, inputs, sigma_only=False, img_ind=None):
         """inputs (B, in_channels_xyz [+ extra_feat_dim]) -> (B,4) rgb+sigma, or (B,1) sigma."""
         L.require_gpu(inputs, "NeRF.forward")
-        _grad_guard(self, "NeRF.forward")
         if sigma_only:
             width = self.in_channels_xyz
         else:
@@ -98,4 +97,8 @@ class NeRF(nn.Module):
             L.check(L.lib().mf_nerf_forward(desc, buf.data_ptr(), L.ptr(x), x.stride(0) if B else width, B,
                                             1 if sigma_only else 0, L.ptr(out), L.current_stream(x.device)),
                     "mf_nerf_forward")
+        from . import autograd as A
+        if A.needs_grad([self]) or (torch.is_grad_enabled() and inputs.requires_grad):
+            params = [p for p in self.parameters()] + ([inputs] if inputs.requires_grad else [])
+            out, = A.attach([out], params, lambda: [A.nerf_forward(self, inputs, sigma_only)])
         return out

@@ -3,7 +3,7 @@ import torch
 from torch import nn
 
 from . import _lib as L
-from .packing import PackedWeights, _grad_guard
+from .packing import PackedWeights
 
 
 class NoF(nn.Module):
@@ -71,7 +71,6 @@ class NoF(nn.Module):
         if self.extra_feat_type == "latent_code":
             raise NotImplementedError("NoF model does not support latent code yet!!!")
         L.require_gpu(inputs, "NoF.forward")
-        _grad_guard(self, "NoF.forward")
         width = self.in_channels_xyz + self.extra_feat_dim
         if inputs.dim() != 2 or inputs.shape[1] != width or xyz.shape != (inputs.shape[0], 3):
             raise RuntimeError(f"NoF expects inputs (B, {width}) and xyz (B, 3), got {tuple(inputs.shape)}, {tuple(xyz.shape)}")
@@ -85,4 +84,8 @@ class NoF(nn.Module):
         with torch.cuda.device(x.device):
             L.check(L.lib().mf_nof_forward(desc, buf.data_ptr(), L.ptr(x), x.stride(0) if B else width, L.ptr(p), B,
                                            L.ptr(out), L.current_stream(x.device)), "mf_nof_forward")
+        from . import autograd as A
+        wrt = [t for t in (inputs, xyz) if torch.is_grad_enabled() and t.requires_grad]
+        if A.needs_grad([self]) or wrt:
+            out, = A.attach([out], [p for p in self.parameters()] + wrt, lambda: [A.nof_forward(self, inputs, xyz)])
         return out

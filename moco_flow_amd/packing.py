@@ -7,13 +7,6 @@ import torch
 from . import _lib as L
 
 
-def _grad_guard(module, what):
-    if torch.is_grad_enabled() and any(p.requires_grad for p in module.parameters()):
-        raise NotImplementedError(
-            f"moco_flow_amd.{what}: the backward pass of the fused HIP path is not built yet "
-            "(SURVEY.md §8f-1). Call under torch.no_grad() (or freeze the parameters).")
-
-
 class PackedWeights:
     def __init__(self):
         self.key = None

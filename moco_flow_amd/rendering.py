@@ -14,7 +14,7 @@ import ctypes as C
 import torch
 
 from . import _lib as L
-from .packing import _grad_guard
+from . import autograd as A
 
 # Draw torch.randn(N,S) in every pass even when noise_std == 0, as the reference does
 # (rendering.py:166), so that the device RNG stream advances identically.
@@ -189,8 +189,8 @@ def render_rays(rays,
     if use_nof and chain_global and not chain_local and not test_time:
         # rendering.py:276-280: fw_nof is only bound under chain_local
         raise UnboundLocalError("local variable 'fw_nof' referenced before assignment")
-    for m in list(nerf_models) + (list(nof_models) if use_nof else []):
-        _grad_guard(m, "render_rays")
+    all_models = list(nerf_models) + (list(nof_models) if use_nof else [])
+    grad = A.needs_grad(all_models)       # backward = differentiable recompute (autograd.py, interim)
     dev = rays.device
     rays = rays.detach().float()
     if rays.dim() != 2 or rays.shape[1] < (10 if (use_nof and chain_global) else 9):
@@ -207,7 +207,7 @@ def render_rays(rays,
 
     z_steps = torch.linspace(0, 1, S, device=dev)                     # rendering.py:245
     z_vals = None
-    if perturb > 0 or need_fine:
+    if perturb > 0 or need_fine or grad:
         near, far = rays[:, 6:7], rays[:, 7:8]
         if not use_disp:
             z_vals = near * (1 - z_steps) + far * z_steps
@@ -229,9 +229,10 @@ def render_rays(rays,
         return None
 
     coarse_sigma_only = bool(need_fine and test_time)                  # rendering.py:290-294
-    want_planes = need_fine or loc or glob or _capture is not None
+    want_planes = need_fine or loc or glob or grad or _capture is not None
+    noise_c = draw_noise((N, S))
     c = _render_pass(rays, background, z_vals, None if z_vals is not None else z_steps, use_disp,
-                     draw_noise((N, S)), act, nerf_models[0], nerf_embeddings,
+                     noise_c, act, nerf_models[0], nerf_embeddings,
                      nof_models if use_nof else None, nof_embeddings, loc, glob, coarse_sigma_only, want_planes)
     if coarse_sigma_only:
         result = {'opacity_coarse': c["opacity"]}
@@ -248,9 +249,10 @@ def render_rays(rays,
         _capture.update(z_coarse=z_vals, weights_coarse=c.get("weights"), alphas_coarse=c.get("alphas"))
     if need_fine:
         z_all = resample_merge(z_vals, c["weights"], N_importance, det=(perturb == 0))
-        f = _render_pass(rays, background, z_all, None, use_disp, draw_noise((N, S + N_importance)), act,
+        noise_f = draw_noise((N, S + N_importance))
+        f = _render_pass(rays, background, z_all, None, use_disp, noise_f, act,
                          nerf_models[1], nerf_embeddings, nof_models if use_nof else None, nof_embeddings,
-                         loc, glob, False, loc or glob or _capture is not None)
+                         loc, glob, False, loc or glob or grad or _capture is not None)
         if _capture is not None:
             _capture.update(z_fine=z_all, weights_fine=f.get("weights"), alphas_fine=f.get("alphas"))
         result['rgb_fine'] = f["rgb"]
@@ -262,4 +264,48 @@ def render_rays(rays,
                 result['nof_local_disp_fine'] = la
             if glob:
                 result['nof_global_disp_fine'] = ga
+    if grad and N > 0:
+        result = _attach_backward(result, rays, background, all_models, nerf_embeddings, nerf_models,
+                                  nof_embeddings, nof_models if use_nof else None, loc, glob, nerf_activate_type,
+                                  coarse_sigma_only, z_vals, noise_c, c["alphas"],
+                                  (z_all, noise_f, f["alphas"]) if need_fine else None)
     return result
+
+
+def _mask_of(alphas):
+    mask = alphas.ge(0.01)                      # rendering.py:306-308
+    if not torch.any(mask):
+        mask = torch.ones_like(mask).bool()
+    return mask
+
+
+def _attach_backward(result, rays, background, all_models, nerf_embs, nerf_models, nof_embs, nof_models,
+                     loc, glob, activation, coarse_sigma_only, z_c, noise_c, alphas_c, fine):
+    """Make the HIP-computed result differentiable: the backward re-runs both passes with torch ops
+    (autograd.render_pass) on the same depths, noise and consensus masks."""
+    keys = list(result.keys())
+    mask_c = _mask_of(alphas_c) if (loc or glob) else None
+    mask_f = _mask_of(fine[2]) if (fine is not None and (loc or glob)) else None
+
+    def recompute():
+        outs = {}
+
+        def one(tag, nerf, z, noise, sigma_only, mask):
+            r = A.render_pass(rays, background, z, noise, activation, nerf, nerf_embs, nof_models, nof_embs,
+                              loc, glob, sigma_only, None)
+            if not sigma_only:
+                outs[f"rgb_{tag}"], outs[f"depth_{tag}"] = r["rgb"], r["depth"]
+            outs[f"opacity_{tag}"] = r["opacity"]
+            if loc:
+                outs[f"nof_local_disp_{tag}"] = torch.mean(r["disp_local_full"][mask], dim=1)
+            if glob:
+                outs[f"nof_global_disp_{tag}"] = torch.mean(r["disp_global_full"][mask], dim=1)
+
+        one("coarse", nerf_models[0], z_c, noise_c, coarse_sigma_only, mask_c)
+        if fine is not None:
+            one("fine", nerf_models[1], fine[0], fine[1], False, mask_f)
+        return [outs[k] for k in keys]
+
+    params = [p for m in all_models for p in m.parameters()]
+    attached = A.attach([result[k] for k in keys], params, recompute)
+    return {k: v for k, v in zip(keys, attached)}

@@ -117,7 +117,9 @@ def test_no_cpu_fallback_and_loud_errors():
     for f in os.listdir(pkg):
         if f.endswith(".py"):
             src += open(os.path.join(pkg, f)).read()
-    assert "oracle" not in src.replace("oracle/kornia_restated.py", "")
+    import re as _re
+    assert not _re.search(r"^\s*(from|import)\s+oracle", src, flags=_re.M)
+    assert "cpu_ref" not in src
 
 
 def test_shard_bounds_cover_and_order():
