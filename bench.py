@@ -32,7 +32,8 @@ sys.path.insert(0, ROOT)
 
 N_RAYS, N_SAMPLES = 4096, 64
 FLOPS_PER_SAMPLE = {"nerf_dir": 1186816, "nerf_ind": 1181184, "nof_quat": 134400}
-PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 256 CU @ 2.4 GHz
+PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32-input MFMA, 256 CU @ 2.4 GHz
+PEAK_BF16_TFLOPS = 2516.0        # dense bf16 MFMA (only the hidden GEMMs run there in --precision bf16)
 
 
 def build_models(dev, workload):
@@ -92,6 +93,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--workload", choices=["nerf", "moco"], default="nerf",
                     help="nerf = BASELINE config C2 (headline); moco = C3-shaped chain in fp32")
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
+                    help="f32 = exact-fp32 MFMA (headline, config C2); bf16 = bf16 hidden GEMMs (configs C3-C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     a = ap.parse_args()
 
@@ -113,6 +116,7 @@ def main():
     import moco_flow_amd as M
     from moco_flow_amd import rendering, synth
     rendering.STRICT_RNG = False        # noise_std = 0: do not launch the reference's dead randn
+    rendering.set_precision(a.precision)
     M._lib.lib()                        # fail loudly if the HIP library is missing
 
     models = build_models(dev, a.workload)
@@ -167,20 +171,22 @@ def main():
     else:
         flops_per_sample = FLOPS_PER_SAMPLE["nerf_ind"] + 2 * FLOPS_PER_SAMPLE["nof_quat"]
     achieved = N_RAYS * N_SAMPLES * flops_per_sample / (kernel_ms * 1e-3) / 1e12
+    peak = PEAK_F32_TFLOPS if a.precision == "f32" else PEAK_BF16_TFLOPS
     line = {
         "metric": "ray-samples/sec (4096 rays x 64 samples)", "value": value, "unit": "ray-samples/s",
         "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
         "config": {"workload": ("C2: canonical NeRF 8x256 (xyz F=10, dir F=4), fused HIP encode+MLP+composite, "
                                 "fp32 MFMA" if a.workload == "nerf" else
-                                "C3-shaped: bw NoF -> NeRF(ind) -> fw NoF local chain, fp32 MFMA"),
+                                "C3-shaped: bw NoF -> NeRF(ind) -> fw NoF local chain") + f" [{a.precision}]",
                    "rays_per_gpu": N_RAYS, "samples_per_ray": N_SAMPLES, "global_rays": N_RAYS * world,
                    "sharding": f"rays{world}" if world > 1 else "none"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / PEAK_F32_TFLOPS,
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
+                     "frac": achieved / peak,
                      # HBM bytes per launch from the committed PMC passes of this same command
                      # (profiles/r01c_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); C2 only
-                     "traffic": 25.3e6 if a.workload == "nerf" else None, "traffic_unit": "B/launch",
+                     "traffic": 25.3e6 if (a.workload == "nerf" and a.precision == "f32") else None,
+                     "traffic_unit": "B/launch",
                      "kernel_ms": kernel_ms, "flops_per_launch": N_RAYS * N_SAMPLES * flops_per_sample},
     }
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 1
+#define MF_ABI_VERSION 2
 
 enum {
   MF_OK = 0,
@@ -36,6 +36,12 @@ enum {
 };
 
 enum { MF_MAX_FREQS = 16, MF_MAX_LAYERS = 16 };
+
+/* Arithmetic of the W-wide ("hidden") GEMMs of the fused pass.  F32: exact-fp32 MFMA everywhere
+ * (the reference's arithmetic; BASELINE configs C1-C2).  BF16: hidden-layer weights and
+ * activations rounded to bf16 (RNE), fp32 accumulate (v_mfma_f32_16x16x32_bf16); the embedded-
+ * input k-ranges, biases, heads and the composite stay fp32 (BASELINE configs C3-C5). */
+enum { MF_PREC_F32 = 0, MF_PREC_BF16 = 1 };
 
 /* ---- Embedding: models/embedding.py:4-47 ------------------------------------
  * out = [x, w0*sin(f0 x), w0*cos(f0 x), w1*sin(f1 x), ...]; freq[] are the module's
@@ -98,6 +104,12 @@ int64_t mf_nof_packed_bytes(const mf_nof_desc* d);
  * Must be re-run whenever the parameters change (optimizer.step). */
 int32_t mf_nerf_pack(const mf_nerf_desc* d, void* packed, void* stream);
 int32_t mf_nof_pack(const mf_nof_desc* d, void* packed, void* stream);
+/* The same with an explicit MF_PREC_* (the plain forms are MF_PREC_F32).  A packed buffer can only
+ * be used by a render pass of the same precision. */
+int64_t mf_nerf_packed_bytes_p(const mf_nerf_desc* d, int32_t precision);
+int64_t mf_nof_packed_bytes_p(const mf_nof_desc* d, int32_t precision);
+int32_t mf_nerf_pack_p(const mf_nerf_desc* d, int32_t precision, void* packed, void* stream);
+int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* packed, void* stream);
 
 /* Embedding.forward, models/embedding.py:30-47:  x (B, in_channels) -> out (B, C*(2F+1)). */
 int32_t mf_embedding_forward(const mf_embedding* e, const float* x, int64_t B, float* out, void* stream);
@@ -150,6 +162,7 @@ typedef struct mf_render_args {
   float* alphas;                    /* (N,S) */
   float* disp_local;                /* (N,S) mean_c |xyz - recon|         (rendering.py:310-311) */
   float* disp_global;               /* (N,S) mean_c |xyz - chained_recon| (rendering.py:313-314) */
+  int32_t precision;                /* MF_PREC_*: must match how every *_packed buffer was packed      */
 } mf_render_args;
 
 int32_t mf_render_pass(const mf_render_args* a, void* stream);

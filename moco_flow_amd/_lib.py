@@ -15,6 +15,8 @@ MF_MAX_LAYERS = 16
 MF_EXTRA_NONE, MF_EXTRA_IND, MF_EXTRA_DIR = 0, 1, 2
 MF_ACT_RELU, MF_ACT_SOFTPLUS = 0, 1
 MF_F_SIGMA_ONLY, MF_F_CHAIN_LOCAL, MF_F_CHAIN_GLOBAL = 1, 2, 4
+MF_PREC_F32, MF_PREC_BF16 = 0, 1
+MF_ABI_VERSION = 2
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmocoflow_hip.so")
 
@@ -52,7 +54,7 @@ class mf_render_args(C.Structure):
                 ("nof_fw", C.POINTER(mf_nof_desc)), ("nof_fw_packed", _fp),
                 ("nof_emb_xyz", mf_embedding), ("nof_emb_ind", mf_embedding),
                 ("rgb", _fp), ("depth", _fp), ("opacity", _fp), ("weights", _fp), ("alphas", _fp),
-                ("disp_local", _fp), ("disp_global", _fp)]
+                ("disp_local", _fp), ("disp_global", _fp), ("precision", C.c_int32)]
 
 
 # every symbol include/mocoflow_hip.h declares: (restype, argtypes)
@@ -63,6 +65,10 @@ SYMBOLS = {
     "mf_nof_packed_bytes": (C.c_int64, [C.POINTER(mf_nof_desc)]),
     "mf_nerf_pack": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, _fp]),
     "mf_nof_pack": (C.c_int32, [C.POINTER(mf_nof_desc), _fp, _fp]),
+    "mf_nerf_packed_bytes_p": (C.c_int64, [C.POINTER(mf_nerf_desc), C.c_int32]),
+    "mf_nof_packed_bytes_p": (C.c_int64, [C.POINTER(mf_nof_desc), C.c_int32]),
+    "mf_nerf_pack_p": (C.c_int32, [C.POINTER(mf_nerf_desc), C.c_int32, _fp, _fp]),
+    "mf_nof_pack_p": (C.c_int32, [C.POINTER(mf_nof_desc), C.c_int32, _fp, _fp]),
     "mf_embedding_forward": (C.c_int32, [C.POINTER(mf_embedding), _fp, C.c_int64, _fp, _fp]),
     "mf_nerf_forward": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, _fp, C.c_int64, C.c_int64, C.c_int32, _fp, _fp]),
     "mf_nof_forward": (C.c_int32, [C.POINTER(mf_nof_desc), _fp, _fp, C.c_int64, _fp, C.c_int64, _fp, _fp]),
@@ -94,7 +100,7 @@ def lib():
                 fn = getattr(handle, name)   # AttributeError if the export is missing
                 fn.restype = res
                 fn.argtypes = args
-            if handle.mf_version() != 1:
+            if handle.mf_version() != MF_ABI_VERSION:
                 raise RuntimeError("moco_flow_amd: ABI version mismatch")
             _lib = handle
     return _lib

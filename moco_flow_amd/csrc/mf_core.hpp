@@ -26,6 +26,8 @@
 namespace mf {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int kGroupBytes = 1024;   // one fragment group: 64 lanes x float4 = 16 rows x 16 k (4 MFMA steps)
 constexpr int kWaves = 8;           // waves per workgroup (two per SIMD)
@@ -112,6 +114,7 @@ struct EmbParams {
 // two tiles: [tile0 k-quad 0][tile1 k-quad 0][tile0 k-quad 1] ...  (k-quad = 4 k-steps = 16 k).
 struct NetLayout {
   int W, NK, NP;           // hidden width, k-tiles (W/16), panels per W-wide layer (W/32)
+  int bf16;                // 1: hidden (W-wide) k-ranges are stored as bf16 and run on v_mfma_f32_16x16x32_bf16
   int n_trunk;             // trunk layers streamed through the generic loop (NeRF: D+1 incl. final)
   int emb_steps;           // k-steps of the embedded-input block
   uint32_t emb_mask;       // trunk layers that consume the embedded input (layer 0 + skips)
@@ -130,12 +133,14 @@ struct NetLayout {
   int n_head;              // NoF: 9 | 3
 };
 
-// k-quads (batches) and groups of a trunk-layer panel
-MF_HD int trunk_quads(const NetLayout& L, int layer) {
-  return (((L.emb_mask >> layer) & 1) ? L.emb_steps / 4 : 0) + (layer > 0 ? L.NK : 0);
+// batches of a panel: an embedded-input batch = one fp32 k-quad (16 k, 8 MFMAs); a hidden batch =
+// one fp32 k-quad (16 k) or, in bf16 mode, one 32-k step (2 MFMAs).  Two 1 KiB groups per batch.
+MF_HD int hidden_batches(const NetLayout& L) { return L.bf16 ? L.NP : L.NK; }
+MF_HD int trunk_batches(const NetLayout& L, int layer) {
+  return (((L.emb_mask >> layer) & 1) ? L.emb_steps / 4 : 0) + (layer > 0 ? hidden_batches(L) : 0);
 }
-MF_HD int trunk_groups(const NetLayout& L, int layer) { return 2 * trunk_quads(L, layer); }
-MF_HD int extra_groups(const NetLayout& L) { return 2 * (L.NK + L.extra_steps / 4); }
+MF_HD int trunk_groups(const NetLayout& L, int layer) { return 2 * trunk_batches(L, layer); }
+MF_HD int extra_groups(const NetLayout& L) { return 2 * (hidden_batches(L) + L.extra_steps / 4); }
 
 // ------------------------------------------------------------------ device helpers
 extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -231,63 +236,172 @@ MF_D float lds_f(uint32_t byte_off) { return *(const float*)(smem + byte_off); }
 
 #define MF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-// What a panel needs before its first MFMA, pre-read during the previous panel's tail:
-// the first fragment group of each of its two tiles and their bias in C/D order
+#define MF_MFMA_BF16(a, b, c) \
+  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+// Activation storage of one wave (16 samples).  fp32: one f32x4 per 16-feature k-tile.
+// bf16: one u32x4 (8 bf16) per 32-feature block, holding exactly a finished panel's two
+// accumulators [E0..E3 | O0..O3] = features 32P + {4g..4g+3} and 32P + 16 + {4g..4g+3}: the
+// B operand of the 32-k step P of the next layer (weights are packed in the same k order).
+template <bool BF16> struct ActT { using T = f32x4; };
+template <> struct ActT<true> { using T = u32x4; };
+template <bool BF16, int NK> struct ActLen { static constexpr int N = BF16 ? NK / 2 : NK; };
+// fragment prefetch distance in batches: a bf16 batch is only 2 MFMAs (32 cycles), so the LDS
+// latency needs 4 of them; an fp32 batch is 8 MFMAs (256 cycles).
+template <bool BF16> struct Pipe { static constexpr int PD = BF16 ? 4 : 1; };
+
+MF_D u32x4 pack8(const f32x4& e, const f32x4& o) {
+  bf16x8 v;
+  v[0] = (__bf16)e[0]; v[1] = (__bf16)e[1]; v[2] = (__bf16)e[2]; v[3] = (__bf16)e[3];
+  v[4] = (__bf16)o[0]; v[5] = (__bf16)o[1]; v[6] = (__bf16)o[2]; v[7] = (__bf16)o[3];
+  return __builtin_bit_cast(u32x4, v);
+}
+MF_D float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+MF_D float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// What a panel needs before its first MFMAs, pre-read during the previous panel's tail: the
+// fragment groups of its first PD batches (two tiles each) and the two tiles' bias in C/D order
 // (reg r of lane group g <- bias[16*tile + 4g + r]).
-struct Carry {
-  f32x4 wE, wO, bE, bO;
-  MF_D void load(uint32_t panel_lane_off, uint32_t bias_byte_off, int g) {
-    wE = lds_f4(panel_lane_off);
-    wO = lds_f4(panel_lane_off + kGroupBytes);
+template <int PD>
+struct CarryT {
+  f32x4 wE[PD], wO[PD], bE, bO;
+  MF_D void load_bias(uint32_t bias_byte_off, int g) {
     bE = lds_f4(bias_byte_off + 16 * g);
     bO = lds_f4(bias_byte_off + 64 + 16 * g);
+  }
+  MF_D void load(uint32_t panel_lane_off, uint32_t bias_byte_off, int g) {   // cold start
+#pragma unroll
+    for (int i = 0; i < PD; ++i) {
+      wE[i] = lds_f4(panel_lane_off + (2 * i) * kGroupBytes);
+      wO[i] = lds_f4(panel_lane_off + (2 * i + 1) * kGroupBytes);
+    }
+    load_bias(bias_byte_off, g);
   }
 };
 
 // One panel = two 16-row output tiles (E: rows 0-15, O: rows 16-31) x 16 samples:
-//   out = max(bias + W_panel * [emb ; hidden], lo)      (lo = 0: ReLU, -inf: linear)
+//   (E, O) = max(bias + W_panel * [emb ; hidden], lo)      (lo = 0: ReLU, -inf: linear)
 // MODE: 1 = embedded input only, 2 = hidden only, 3 = both (skip layers, emb first).
-// Per k-quad: two ds_read_b128 (one group per tile) feed 8 MFMAs; the E and O chains alternate
-// and share every B operand, so no MFMA directly follows its own predecessor and the ds_reads
-// sit between independent MFMAs.  Groups are fetched one k-quad (8 MFMAs) ahead.  `hook` is the
-// panel's workgroup barrier (+ DMA of the panel two ahead).  It sits behind the FIRST k-quad's
-// leading MFMA pair for the early half of the workgroup (waves 4-7) and in the MIDDLE of the
-// panel for the late half (waves 0-3): since all eight waves meet at that barrier, the two waves
-// that share a SIMD run half a panel out of phase, so one of them is always in MFMA-dense code
-// while the other crosses a panel boundary (epilogue, branches, carry loads, DMA issue).
-// The NEXT panel's Carry is read behind the first pair of the last k-quad.
-template <int MODE, int NK, int EMB, class Hook>
-MF_D void out_pair(Carry& carry, const f32x4 (&hid)[NK], const float (&emb)[EMB], uint32_t panel_lane_off,
-                   uint32_t next_panel_lane_off, uint32_t next_bias_off, int g, bool late, Hook&& hook, float lo,
-                   f32x4& outE, f32x4& outO) {
+// Per batch two ds_read_b128 (one group per tile) feed 8 fp32 MFMAs (or 2 bf16 MFMAs); the E
+// and O chains alternate and share every B operand, so no MFMA directly follows its own
+// predecessor and the ds_reads sit between independent MFMAs.  Groups are fetched PD batches
+// ahead through a register ring that runs on into the NEXT panel's slot, so a panel boundary
+// exposes no LDS latency.  `hook` is the panel's workgroup barrier (+ DMA of the panel two
+// ahead).  It sits behind the FIRST batch's leading MFMA pair for the early half of the
+// workgroup (waves 4-7) and in the MIDDLE of the panel for the late half (waves 0-3): since all
+// eight waves meet at that barrier, the two waves that share a SIMD run half a panel out of
+// phase, so one of them is always in MFMA-dense code while the other crosses a panel boundary
+// (epilogue, branches, DMA issue).
+template <int MODE, int NK, int EMB, bool BF16, class Hook>
+MF_D void out_pair(CarryT<Pipe<BF16>::PD>& carry, const typename ActT<BF16>::T (&hid)[ActLen<BF16, NK>::N],
+                   const float (&emb)[EMB], uint32_t panel_lane_off, uint32_t next_panel_lane_off,
+                   uint32_t next_bias_off, int g, bool late, Hook&& hook, float lo, f32x4& outE, f32x4& outO) {
+  if constexpr (!BF16) {
+    // fp32: one batch (8 MFMAs) of prefetch is enough; this hand-shaped form of the loop below (two
+    // named fragment registers instead of the ring) is what hipcc allocates best (12 % faster).
+    constexpr int QE = (MODE & 1) ? EMB / 4 : 0;
+    constexpr int QH = (MODE & 2) ? NK : 0;
+    constexpr int Q = QE + QH;
+    auto bop = [&](int q, int r) -> float {
+      if (q < QE) return emb[4 * q + r];
+      else return hid[q - QE][r];
+    };
+    f32x4 E = carry.bE, O = carry.bO;
+    f32x4 wE = carry.wE[0], wO = carry.wO[0];
+#pragma unroll
+    for (int q = 0; q < Q; ++q) {
+      f32x4 nE = wE, nO = wO;
+      E = MF_MFMA(wE[0], bop(q, 0), E);
+      O = MF_MFMA(wO[0], bop(q, 0), O);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + 1 < Q) {
+        nE = lds_f4(panel_lane_off + (2 * (q + 1)) * kGroupBytes);
+        nO = lds_f4(panel_lane_off + (2 * (q + 1) + 1) * kGroupBytes);
+      }
+      if (q == 0 && !late) hook();
+      if (q == Q / 2 && late) hook();
+      if (q + 1 >= Q) {
+        carry.wE[0] = lds_f4(next_panel_lane_off);
+        carry.wO[0] = lds_f4(next_panel_lane_off + kGroupBytes);
+        carry.load_bias(next_bias_off, g);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int r = 1; r < 4; ++r) {
+        E = MF_MFMA(wE[r], bop(q, r), E);
+        O = MF_MFMA(wO[r], bop(q, r), O);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      wE = nE;
+      wO = nO;
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      outE[i] = fmaxf(E[i], lo);
+      outO[i] = fmaxf(O[i], lo);
+    }
+    return;
+  }
+  constexpr int PD = Pipe<BF16>::PD;
   constexpr int QE = (MODE & 1) ? EMB / 4 : 0;
-  constexpr int QH = (MODE & 2) ? NK : 0;
+  constexpr int QH = (MODE & 2) ? ActLen<BF16, NK>::N : 0;
   constexpr int Q = QE + QH;
-  auto bop = [&](int q, int r) -> float { return q < QE ? emb[4 * q + r] : hid[q - QE][r]; };
+  static_assert(Q >= PD, "panel shorter than the fragment pipeline");
+  // the late half must not read the next panel (prefetch of batch b + PD >= Q) before its barrier
+  constexpr int LATEQ = (Q / 2 < Q - PD) ? Q / 2 : Q - PD;
   f32x4 E = carry.bE, O = carry.bO;
-  f32x4 wE = carry.wE, wO = carry.wO;
+  f32x4 rE[PD + 1], rO[PD + 1];
 #pragma unroll
-  for (int q = 0; q < Q; ++q) {
-    f32x4 nE = wE, nO = wO;
-    E = MF_MFMA(wE[0], bop(q, 0), E);
-    O = MF_MFMA(wO[0], bop(q, 0), O);
-    __builtin_amdgcn_sched_barrier(0);
-    if (q + 1 < Q) {
-      nE = lds_f4(panel_lane_off + (2 * (q + 1)) * kGroupBytes);
-      nO = lds_f4(panel_lane_off + (2 * (q + 1) + 1) * kGroupBytes);
-    }
-    if (q == 0 && !late) hook();
-    if (q == Q / 2 && late) hook();
-    if (q + 1 >= Q) carry.load(next_panel_lane_off, next_bias_off, g);
-    __builtin_amdgcn_sched_barrier(0);
+  for (int i = 0; i < PD; ++i) { rE[i] = carry.wE[i]; rO[i] = carry.wO[i]; }
 #pragma unroll
-    for (int r = 1; r < 4; ++r) {
-      E = MF_MFMA(wE[r], bop(q, r), E);
-      O = MF_MFMA(wO[r], bop(q, r), O);
+  for (int b = 0; b < Q; ++b) {
+    const int s = b % (PD + 1);
+    const bool f32_batch = !BF16 || b < QE;
+    if (f32_batch) {
+      float bv;
+      if (b < QE) bv = emb[4 * b];
+      else if constexpr (!BF16) bv = hid[b - QE][0];
+      E = MF_MFMA(rE[s][0], bv, E);
+      O = MF_MFMA(rO[s][0], bv, O);
+    } else {
+      if constexpr (BF16) {
+        E = MF_MFMA_BF16(rE[s], hid[b - QE], E);
+        O = MF_MFMA_BF16(rO[s], hid[b - QE], O);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
-    wE = nE;
-    wO = nO;
+    // fragment prefetch of batch b + PD: reads of the CURRENT panel go ahead of the barrier (the
+    // wave then sits in it with its loads in flight); reads of the NEXT panel must follow it
+    const int sp = (b + PD) % (PD + 1);
+    const int nbp = b + PD;
+    if (nbp < Q) {
+      rE[sp] = lds_f4(panel_lane_off + (2 * nbp) * kGroupBytes);
+      rO[sp] = lds_f4(panel_lane_off + (2 * nbp + 1) * kGroupBytes);
+    }
+    if (b == 0 && !late) hook();
+    if (b == LATEQ && late) hook();
+    if (nbp >= Q) {
+      rE[sp] = lds_f4(next_panel_lane_off + (2 * (nbp - Q)) * kGroupBytes);
+      rO[sp] = lds_f4(next_panel_lane_off + (2 * (nbp - Q) + 1) * kGroupBytes);
+    }
+    if (b == Q - 1) carry.load_bias(next_bias_off, g);
+    __builtin_amdgcn_sched_barrier(0);
+    if (f32_batch) {
+#pragma unroll
+      for (int r = 1; r < 4; ++r) {
+        float bv;
+        if (b < QE) bv = emb[4 * b + r];
+        else if constexpr (!BF16) bv = hid[b - QE][r];
+        E = MF_MFMA(rE[s][r], bv, E);
+        O = MF_MFMA(rO[s][r], bv, O);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int i = 0; i < PD; ++i) {
+    carry.wE[i] = rE[(Q + i) % (PD + 1)];
+    carry.wO[i] = rO[(Q + i) % (PD + 1)];
   }
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
@@ -311,16 +425,17 @@ struct NextLayer {
 };
 
 // One trunk layer: act <- relu?(W_l [emb ; act] + b_l), NK/2 panels of two tiles.
-template <int NK, int EMB>
-MF_D void trunk_layer(const NetDev& net, int layer, f32x4 (&act)[NK], const float (&emb)[EMB], Stream& st,
-                      Carry& carry, const LaneId& id, const NextLayer& nxt) {
+template <int NK, int EMB, bool BF16>
+MF_D void trunk_layer(const NetDev& net, int layer, typename ActT<BF16>::T (&act)[ActLen<BF16, NK>::N],
+                      const float (&emb)[EMB], Stream& st, CarryT<Pipe<BF16>::PD>& carry, const LaneId& id,
+                      const NextLayer& nxt) {
   constexpr int NP = NK / 2;
   const int has_emb = (net.L.emb_mask >> layer) & 1;
   const int mode = (has_emb ? 1 : 0) | (layer > 0 ? 2 : 0);
   const int groups = trunk_groups(net.L, layer);
   const float lo = ((net.L.relu_mask >> layer) & 1) ? 0.f : -__builtin_inff();
   const uint32_t bias_off = net.res_lds + (net.L.off_bias_trunk + layer * net.L.W) * 4;
-  f32x4 out[NK];
+  typename ActT<BF16>::T out[ActLen<BF16, NK>::N];
 #pragma unroll
   for (int t = 0; t < NP; ++t) {
     const uint32_t p = st.slot_off(0) + id.lane * 16;
@@ -329,13 +444,20 @@ MF_D void trunk_layer(const NetDev& net, int layer, f32x4 (&act)[NK], const floa
     // panel two ahead: same layer while t+2 < NP, else panel (t+2-NP) of the next layer
     auto hook = [&]() { st.sync_and_dma(t + 2 < NP ? groups : nxt.groups, t == NP - 2 ? nxt.jump : nullptr, id); };
     const bool late = id.wave < kWaves / 2 && !(st.dbg & 64);
-    if (mode == 2) out_pair<2, NK, EMB>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, out[2 * t], out[2 * t + 1]);
-    else if (mode == 3) out_pair<3, NK, EMB>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, out[2 * t], out[2 * t + 1]);
-    else out_pair<1, NK, EMB>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, out[2 * t], out[2 * t + 1]);
+    f32x4 E, O;
+    if (mode == 2) out_pair<2, NK, EMB, BF16>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, E, O);
+    else if (mode == 3) out_pair<3, NK, EMB, BF16>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, E, O);
+    else out_pair<1, NK, EMB, BF16>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, E, O);
+    if constexpr (BF16) {
+      out[t] = pack8(E, O);
+    } else {
+      out[2 * t] = E;
+      out[2 * t + 1] = O;
+    }
     st.advance();
   }
 #pragma unroll
-  for (int t = 0; t < NK; ++t) act[t] = out[t];
+  for (int t = 0; t < ActLen<BF16, NK>::N; ++t) act[t] = out[t];
 }
 
 // VALU head: NOUT dot products of the lane's quarter of the hidden vector with natural-order
@@ -354,6 +476,30 @@ MF_D void valu_head(const f32x4 (&act)[NK], uint32_t w_byte_off, int row_floats,
       s1 = __builtin_fmaf(w[1], act[t][1], s1);
       s0 = __builtin_fmaf(w[2], act[t][2], s0);
       s1 = __builtin_fmaf(w[3], act[t][3], s1);
+    }
+    out[o] = xgroup_sum(s0 + s1) + lds_f(b_byte_off + o * 4);
+  }
+}
+
+// Same head on bf16-packed activations (unpacked on the fly; weights and accumulation fp32).
+template <int NA, int NOUT>
+MF_D void valu_head(const u32x4 (&act)[NA], uint32_t w_byte_off, int row_floats, uint32_t b_byte_off, int g,
+                    float (&out)[NOUT]) {
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NA; ++t) {
+      const f32x4 wE = lds_f4(w_byte_off + (o * row_floats + 32 * t + 4 * g) * 4);
+      const f32x4 wO = lds_f4(w_byte_off + (o * row_floats + 32 * t + 16 + 4 * g) * 4);
+      s0 = __builtin_fmaf(wE[0], bf_lo(act[t][0]), s0);
+      s1 = __builtin_fmaf(wE[1], bf_hi(act[t][0]), s1);
+      s0 = __builtin_fmaf(wE[2], bf_lo(act[t][1]), s0);
+      s1 = __builtin_fmaf(wE[3], bf_hi(act[t][1]), s1);
+      s0 = __builtin_fmaf(wO[0], bf_lo(act[t][2]), s0);
+      s1 = __builtin_fmaf(wO[1], bf_hi(act[t][2]), s1);
+      s0 = __builtin_fmaf(wO[2], bf_lo(act[t][3]), s0);
+      s1 = __builtin_fmaf(wO[3], bf_hi(act[t][3]), s1);
     }
     out[o] = xgroup_sum(s0 + s1) + lds_f(b_byte_off + o * 4);
   }

@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_forward_kernel(NerfFwdParams
   NetDev net = p.net;
   load_resident(net, id);
   Stream st;
-  Carry carry;
+  CarryT<1> carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = 0;
@@ -84,7 +84,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_forward_kernel(NerfFwdParams
       ext[e] = (!p.sigma_only && f >= 0 && f < p.extra_cols) ? row[p.xyz_cols + f] : 0.f;
     }
     float sigma, rgb[3] = {0.f, 0.f, 0.f};
-    nerf_eval<16>(net, embx, ext, p.sigma_only != 0, st, carry, id, follow_of(net), sigma, rgb);
+    nerf_eval<16, false>(net, embx, ext, p.sigma_only != 0, st, carry, id, follow_of(net), sigma, rgb);
     if (valid && id.g == 0) {
       if (p.sigma_only) p.out[b] = sigma;
       else *reinterpret_cast<float4*>(p.out + b * 4) = make_float4(rgb[0], rgb[1], rgb[2], sigma);
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kThreads, 2) void nof_forward_kernel(NofFwdParams p
   NetDev net = p.net;
   load_resident(net, id);
   Stream st;
-  Carry carry;
+  CarryT<1> carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = 0;
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kThreads, 2) void nof_forward_kernel(NofFwdParams p
     }
     const float xyz[3] = {p.xyz[bb * 3 + 0], p.xyz[bb * 3 + 1], p.xyz[bb * 3 + 2]};
     float o[3];
-    nof_eval(net, emb, xyz, st, carry, id, follow_of(net), o);
+    nof_eval<false>(net, emb, xyz, st, carry, id, follow_of(net), o);
     if (valid && id.g == 0) {
       p.out[b * 3 + 0] = o[0];
       p.out[b * 3 + 1] = o[1];

@@ -8,8 +8,9 @@ namespace mf {
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // returns false (layout zeroed) for configurations the kernels do not implement
-inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L) {
+inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L, int bf16 = 0) {
   L = NetLayout{};
+  L.bf16 = bf16 ? 1 : 0;
   if (d.W != 256 && d.W != 128) return false;
   if (d.D < 2 || d.D + 1 > MF_MAX_LAYERS) return false;
   if (d.in_channels_xyz != 63) return false;          // 3*(2*10+1); see DESIGN.md "envelope"
@@ -51,8 +52,9 @@ inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L) {
   return true;
 }
 
-inline bool nof_layout(const mf_nof_desc& d, NetLayout& L) {
+inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0) {
   L = NetLayout{};
+  L.bf16 = bf16 ? 1 : 0;
   if (d.W != 128) return false;
   if (d.D < 2 || d.D > MF_MAX_LAYERS) return false;
   if (d.in_channels_xyz != 33 || d.extra_feat_dim != 33) return false;   // 3*(2*5+1), 1*(2*16+1)

@@ -32,16 +32,19 @@ MF_D void load_resident(const NetDev& n, const LaneId& id) {
 }
 
 // Prime the stream and the carry at the first panel of network `n` (kernel start).
-MF_D void start_program(const NetDev& n, Stream& st, Carry& carry, const LaneId& id) {
+template <int PD>
+MF_D void start_program(const NetDev& n, Stream& st, CarryT<PD>& carry, const LaneId& id) {
   st.start(first_panel(n), first_groups(n), id);
   carry.load(st.slot_off(0) + id.lane * 16, n.res_lds + n.L.off_bias_trunk * 4, id.g);
 }
 
 // extra_encoding (nerf.py:98): (W/2) outputs from [final(W) ; extra block], ReLU.
-template <int NK>
-MF_D void extra_layer(const NetDev& net, const f32x4 (&act)[NK], const float (&ext)[kStepsExtraMax],
-                      f32x4 (&out)[NK / 2], Stream& st, Carry& carry, const LaneId& id, const NextLayer& nxt) {
+template <int NK, bool BF16>
+MF_D void extra_layer(const NetDev& net, const typename ActT<BF16>::T (&act)[ActLen<BF16, NK>::N],
+                      const float (&ext)[kStepsExtraMax], typename ActT<BF16>::T (&out)[ActLen<BF16, NK / 2>::N],
+                      Stream& st, CarryT<Pipe<BF16>::PD>& carry, const LaneId& id, const NextLayer& nxt) {
   constexpr int NPO = NK / 4;                      // panels of the (W/2)-wide layer
+  constexpr int QH = ActLen<BF16, NK>::N;          // hidden batches in front of the extra block
   const int groups = extra_groups(net.L);
   const int qe = net.L.extra_steps / 4;
   const uint32_t bias_off = net.res_lds + net.L.off_bias_extra * 4;
@@ -52,14 +55,15 @@ MF_D void extra_layer(const NetDev& net, const f32x4 (&act)[NK], const float (&e
     const uint32_t pn = st.slot_off(1) + id.lane * 16;
     const uint32_t nb = (t + 1 < NPO) ? bias_off + 32 * (t + 1) * 4 : nxt.bias_off;
     auto hook = [&]() { st.sync_and_dma(t + 2 < NPO ? groups : nxt.groups, t == NPO - 2 ? nxt.jump : nullptr, id); };
-    // hidden part through the common path (kept linear: lo = -inf), then the <= 2 extra k-quads
+    // hidden part through the common path (kept linear: lo = -inf), then the <= 2 extra k-quads (fp32)
     f32x4 E, O;
-    out_pair<2, NK, 4>(carry, act, dummy, p, pn, nb, id.g, id.wave < kWaves / 2 && !(st.dbg & 64), hook, -__builtin_inff(), E, O);
+    out_pair<2, NK, 4, BF16>(carry, act, dummy, p, pn, nb, id.g, id.wave < kWaves / 2 && !(st.dbg & 64), hook,
+                             -__builtin_inff(), E, O);
 #pragma unroll
     for (int q = 0; q < kStepsExtraMax / 4; ++q) {
       if (q < qe) {
-        const f32x4 wE = lds_f4(p + (2 * (NK + q)) * kGroupBytes);
-        const f32x4 wO = lds_f4(p + (2 * (NK + q) + 1) * kGroupBytes);
+        const f32x4 wE = lds_f4(p + (2 * (QH + q)) * kGroupBytes);
+        const f32x4 wO = lds_f4(p + (2 * (QH + q) + 1) * kGroupBytes);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           E = MF_MFMA(wE[r], ext[4 * q + r], E);
@@ -69,8 +73,14 @@ MF_D void extra_layer(const NetDev& net, const f32x4 (&act)[NK], const float (&e
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      out[2 * t][i] = fmaxf(E[i], 0.f);
-      out[2 * t + 1][i] = fmaxf(O[i], 0.f);
+      E[i] = fmaxf(E[i], 0.f);
+      O[i] = fmaxf(O[i], 0.f);
+    }
+    if constexpr (BF16) {
+      out[t] = pack8(E, O);
+    } else {
+      out[2 * t] = E;
+      out[2 * t + 1] = O;
     }
     st.advance();
   }
@@ -78,33 +88,33 @@ MF_D void extra_layer(const NetDev& net, const f32x4 (&act)[NK], const float (&e
 
 // Canonical NeRF on this wave's 16 samples.  `follow`: the first layer of whatever the panel
 // program evaluates after this network (the stream jumps there behind the last panel used).
-template <int NK>
+template <int NK, bool BF16>
 MF_D void nerf_eval(const NetDev& net, const float (&embx)[kStepsNerfXyz], const float (&ext)[kStepsExtraMax],
-                    bool sigma_only, Stream& st, Carry& carry, const LaneId& id, const NextLayer& follow,
-                    float& sigma, float (&rgb)[3]) {
-  f32x4 act[NK];
+                    bool sigma_only, Stream& st, CarryT<Pipe<BF16>::PD>& carry, const LaneId& id,
+                    const NextLayer& follow, float& sigma, float (&rgb)[3]) {
+  typename ActT<BF16>::T act[ActLen<BF16, NK>::N];
 #pragma unroll
-  for (int t = 0; t < NK; ++t)
+  for (int t = 0; t < ActLen<BF16, NK>::N; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) act[t][i] = 0.f;
+    for (int i = 0; i < 4; ++i) act[t][i] = 0;
   const int D = net.L.n_trunk - 1;
   for (int l = 0; l < D; ++l) {
     const bool last = sigma_only && l == D - 1;
-    trunk_layer<NK, kStepsNerfXyz>(net, l, act, embx, st, carry, id, last ? follow : next_trunk(net, l + 1));
+    trunk_layer<NK, kStepsNerfXyz, BF16>(net, l, act, embx, st, carry, id, last ? follow : next_trunk(net, l + 1));
   }
   float sg[1];
-  valu_head<NK, 1>(act, net.res_lds + net.L.off_head_w * 4, net.L.W, net.res_lds + net.L.off_head_b * 4, id.g, sg);
+  valu_head(act, net.res_lds + net.L.off_head_w * 4, net.L.W, net.res_lds + net.L.off_head_b * 4, id.g, sg);
   sigma = sg[0];
   if (sigma_only) return;
   NextLayer ex;
   ex.groups = extra_groups(net.L);
   ex.jump = nullptr;
   ex.bias_off = net.res_lds + net.L.off_bias_extra * 4;
-  trunk_layer<NK, kStepsNerfXyz>(net, D, act, embx, st, carry, id, ex);                  // xyz_encoding_final
-  f32x4 e[NK / 2];
-  extra_layer<NK>(net, act, ext, e, st, carry, id, follow);
+  trunk_layer<NK, kStepsNerfXyz, BF16>(net, D, act, embx, st, carry, id, ex);            // xyz_encoding_final
+  typename ActT<BF16>::T e[ActLen<BF16, NK / 2>::N];
+  extra_layer<NK, BF16>(net, act, ext, e, st, carry, id, follow);
   float o[3];
-  valu_head<NK / 2, 3>(e, net.res_lds + net.L.off_rgb_w * 4, net.L.W / 2, net.res_lds + net.L.off_rgb_b * 4, id.g, o);
+  valu_head(e, net.res_lds + net.L.off_rgb_w * 4, net.L.W / 2, net.res_lds + net.L.off_rgb_b * 4, id.g, o);
 #pragma unroll
   for (int c = 0; c < 3; ++c) rgb[c] = 1.f / (1.f + expf(-o[c]));   // nn.Sigmoid, nerf.py:57-59
 }
@@ -135,27 +145,28 @@ MF_D void quat_transform(const float (&T)[9], const float (&xyz)[3], float (&out
 }
 
 // Neural motion flow on this wave's 16 samples; emb = [xyz block ; ind block] (kStepsNofIn).
+template <bool BF16>
 MF_D void nof_eval(const NetDev& net, const float (&emb)[kStepsNofIn], const float (&xyz)[3], Stream& st,
-                   Carry& carry, const LaneId& id, const NextLayer& follow, float (&out)[3]) {
+                   CarryT<Pipe<BF16>::PD>& carry, const LaneId& id, const NextLayer& follow, float (&out)[3]) {
   constexpr int NK = 8;
-  f32x4 act[NK];
+  typename ActT<BF16>::T act[ActLen<BF16, NK>::N];
 #pragma unroll
-  for (int t = 0; t < NK; ++t)
+  for (int t = 0; t < ActLen<BF16, NK>::N; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) act[t][i] = 0.f;
+    for (int i = 0; i < 4; ++i) act[t][i] = 0;
   const int D = net.L.n_trunk;
   for (int l = 0; l < D; ++l) {
     const bool last = l == D - 1;
-    trunk_layer<NK, kStepsNofIn>(net, l, act, emb, st, carry, id, last ? follow : next_trunk(net, l + 1));
+    trunk_layer<NK, kStepsNofIn, BF16>(net, l, act, emb, st, carry, id, last ? follow : next_trunk(net, l + 1));
   }
   const uint32_t wo = net.res_lds + net.L.off_head_w * 4, bo = net.res_lds + net.L.off_head_b * 4;
   if (net.L.n_head == 9) {
     float T[9];
-    valu_head<NK, 9>(act, wo, net.L.W, bo, id.g, T);
+    valu_head(act, wo, net.L.W, bo, id.g, T);
     quat_transform(T, xyz, out);
   } else {
     float T[3];
-    valu_head<NK, 3>(act, wo, net.L.W, bo, id.g, T);
+    valu_head(act, wo, net.L.W, bo, id.g, T);
 #pragma unroll
     for (int c = 0; c < 3; ++c) out[c] = T[c] + xyz[c];
   }

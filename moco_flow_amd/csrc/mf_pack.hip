@@ -21,7 +21,9 @@ struct PackRegion {          // one trunk/extra layer's panels
   int emb_kind;
   int emb_col0;              // column of embedded feature 0 in W
   int emb_cols;              // embedded columns present in W (features >= this are zero pad)
-  int hid_steps;             // 4*NK (= W/4) or 0
+  int hid_steps;             // fp32: hidden k-steps 4*NK (= W/4); bf16: unused (see hid_batches)
+  int hid_batches;           // hidden batches per tile row: NK (fp32 k-quads) or NP (bf16 32-k steps); 0 if none
+  int bf16;                  // hidden groups hold 8 bf16 per lane instead of 4 fp32
   int hid_col0;              // column of hidden feature 0 in W
   int xyz_cols;
   long long dst_group0;      // first group index (in 1 KiB units) within the panel area
@@ -44,24 +46,36 @@ __global__ void pack_panels_kernel(PackJob job) {
   const PackRegion& R = job.reg[ri];
   const long long local = grp - R.dst_group0;
   const int P = (int)(local / R.groups), gi = (int)(local % R.groups);
-  const int q = gi >> 1, half = gi & 1;
+  const int b = gi >> 1, half = gi & 1;                 // batch within the panel, tile half
   const int i = lane & 15, g = lane >> 4;
   const int n = 32 * P + 16 * half + i;
-  float4 v;
+  const int eb = R.emb_steps / 4;                       // embedded-input batches (fp32 k-quads)
+  const int be = R.emb_first ? b : b - R.hid_batches;   // index within the embedded block
+  const int bh = R.emb_first ? b - eb : b;              // index within the hidden block
+  const float* row = R.W + (long long)n * R.n_in;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   float* pv = &v.x;
-  for (int r = 0; r < 4; ++r) {
-    const int s = 4 * q + r;
-    int col = -1;
-    const int se = R.emb_first ? s : s - R.hid_steps;
-    const int sh = R.emb_first ? s - R.emb_steps : s;
-    if (se >= 0 && se < R.emb_steps) {
-      const int f = emb_feature(R.emb_kind, g, se, R.xyz_cols);
-      if (f >= 0 && f < R.emb_cols) col = R.emb_col0 + f;
-    } else if (sh >= 0 && sh < R.hid_steps) {
-      const int kt = sh >> 2, rr = sh & 3;
-      col = R.hid_col0 + 16 * kt + 4 * g + rr;
+  if (be >= 0 && be < eb) {
+    for (int r = 0; r < 4; ++r) {
+      const int f = emb_feature(R.emb_kind, g, 4 * be + r, R.xyz_cols);
+      pv[r] = (f >= 0 && f < R.emb_cols) ? row[R.emb_col0 + f] : 0.f;
     }
-    pv[r] = col >= 0 ? R.W[(long long)n * R.n_in + col] : 0.f;
+  } else if (bh >= 0 && bh < R.hid_batches) {
+    if (!R.bf16) {
+      for (int r = 0; r < 4; ++r) pv[r] = row[R.hid_col0 + 16 * bh + 4 * g + r];
+    } else {
+      // 32-k step bh: position p of lane group g <- k = 32*bh + (p < 4 ? 4g + p : 16 + 4g + p - 4),
+      // the order in which a finished panel's accumulators [E0..3 | O0..3] sit in registers
+      unsigned short h8[8];
+      for (int pp = 0; pp < 8; ++pp) {
+        const int k = 32 * bh + (pp < 4 ? 4 * g + pp : 16 + 4 * g + pp - 4);
+        const unsigned u = __float_as_uint(row[R.hid_col0 + k]);
+        const unsigned rnd = u + 0x7fffu + ((u >> 16) & 1u);           // round to nearest even
+        h8[pp] = (unsigned short)(((u & 0x7f800000u) == 0x7f800000u ? u : rnd) >> 16);
+      }
+      unsigned* pu = reinterpret_cast<unsigned*>(&v.x);
+      for (int w = 0; w < 4; ++w) pu[w] = (unsigned)h8[2 * w] | ((unsigned)h8[2 * w + 1] << 16);
+    }
   }
   reinterpret_cast<float4*>(job.panels)[gidx] = v;
 }
@@ -93,22 +107,23 @@ static int launch_pack(const PackJob& job, const ResJob& rj, hipStream_t st) {
 
 using namespace mf;
 
-extern "C" int64_t mf_nerf_packed_bytes(const mf_nerf_desc* d) {
+extern "C" int64_t mf_nerf_packed_bytes_p(const mf_nerf_desc* d, int32_t precision) {
   NetLayout L;
-  if (!d || !nerf_layout(*d, L)) { fail(MF_E_UNSUPPORTED, "mf_nerf_packed_bytes: unsupported NeRF configuration"); return 0; }
+  if (!d || (precision != MF_PREC_F32 && precision != MF_PREC_BF16) || !nerf_layout(*d, L, precision)) { fail(MF_E_UNSUPPORTED, "mf_nerf_packed_bytes: unsupported NeRF configuration"); return 0; }
   return L.res_bytes + L.panel_bytes;
 }
 
-extern "C" int64_t mf_nof_packed_bytes(const mf_nof_desc* d) {
+extern "C" int64_t mf_nof_packed_bytes_p(const mf_nof_desc* d, int32_t precision) {
   NetLayout L;
-  if (!d || !nof_layout(*d, L)) { fail(MF_E_UNSUPPORTED, "mf_nof_packed_bytes: unsupported NoF configuration"); return 0; }
+  if (!d || (precision != MF_PREC_F32 && precision != MF_PREC_BF16) || !nof_layout(*d, L, precision)) { fail(MF_E_UNSUPPORTED, "mf_nof_packed_bytes: unsupported NoF configuration"); return 0; }
   return L.res_bytes + L.panel_bytes;
 }
 
-extern "C" int32_t mf_nerf_pack(const mf_nerf_desc* d, void* packed, void* stream) {
+extern "C" int32_t mf_nerf_pack_p(const mf_nerf_desc* d, int32_t precision, void* packed, void* stream) {
   NetLayout L;
   if (!d || !packed) return fail(MF_E_INVALID, "mf_nerf_pack: null argument");
-  if (!nerf_layout(*d, L)) return fail(MF_E_UNSUPPORTED, "mf_nerf_pack: unsupported NeRF configuration "
+  if (precision != MF_PREC_F32 && precision != MF_PREC_BF16) return fail(MF_E_INVALID, "mf_nerf_pack: precision %d", precision);
+  if (!nerf_layout(*d, L, precision)) return fail(MF_E_UNSUPPORTED, "mf_nerf_pack: unsupported NeRF configuration "
                                        "(W=%d D=%d in_channels_xyz=%d)", d->W, d->D, d->in_channels_xyz);
   PackJob job{};
   ResJob rj{};
@@ -128,6 +143,8 @@ extern "C" int32_t mf_nerf_pack(const mf_nerf_desc* d, void* packed, void* strea
     R.emb_col0 = 0;
     R.emb_cols = d->in_channels_xyz;
     R.hid_steps = l > 0 ? L.NK * 4 : 0;
+    R.hid_batches = l > 0 ? hidden_batches(L) : 0;
+    R.bf16 = L.bf16;
     R.hid_col0 = has_emb ? d->in_channels_xyz : 0;
     R.xyz_cols = d->in_channels_xyz;
     R.dst_group0 = g0;
@@ -149,6 +166,8 @@ extern "C" int32_t mf_nerf_pack(const mf_nerf_desc* d, void* packed, void* strea
     R.emb_col0 = L.W;
     R.emb_cols = ext;
     R.hid_steps = L.NK * 4;
+    R.hid_batches = hidden_batches(L);
+    R.bf16 = L.bf16;
     R.hid_col0 = 0;
     R.xyz_cols = 0;
     R.dst_group0 = g0;
@@ -170,10 +189,11 @@ extern "C" int32_t mf_nerf_pack(const mf_nerf_desc* d, void* packed, void* strea
   return launch_pack(job, rj, static_cast<hipStream_t>(stream));
 }
 
-extern "C" int32_t mf_nof_pack(const mf_nof_desc* d, void* packed, void* stream) {
+extern "C" int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* packed, void* stream) {
   NetLayout L;
   if (!d || !packed) return fail(MF_E_INVALID, "mf_nof_pack: null argument");
-  if (!nof_layout(*d, L)) return fail(MF_E_UNSUPPORTED, "mf_nof_pack: unsupported NoF configuration "
+  if (precision != MF_PREC_F32 && precision != MF_PREC_BF16) return fail(MF_E_INVALID, "mf_nof_pack: precision %d", precision);
+  if (!nof_layout(*d, L, precision)) return fail(MF_E_UNSUPPORTED, "mf_nof_pack: unsupported NoF configuration "
                                       "(W=%d D=%d in_channels_xyz=%d extra_feat_dim=%d)", d->W, d->D,
                                       d->in_channels_xyz, d->extra_feat_dim);
   PackJob job{};
@@ -195,6 +215,8 @@ extern "C" int32_t mf_nof_pack(const mf_nof_desc* d, void* packed, void* stream)
     R.emb_col0 = 0;
     R.emb_cols = cin;
     R.hid_steps = l > 0 ? L.NK * 4 : 0;
+    R.hid_batches = l > 0 ? hidden_batches(L) : 0;
+    R.bf16 = L.bf16;
     R.hid_col0 = has_emb ? cin : 0;
     R.xyz_cols = d->in_channels_xyz;
     R.dst_group0 = g0;
@@ -212,3 +234,8 @@ extern "C" int32_t mf_nof_pack(const mf_nof_desc* d, void* packed, void* stream)
   if (g0 * kGroupBytes != L.panel_bytes) return fail(MF_E_INVALID, "mf_nof_pack: layout mismatch");
   return launch_pack(job, rj, static_cast<hipStream_t>(stream));
 }
+
+extern "C" int64_t mf_nerf_packed_bytes(const mf_nerf_desc* d) { return mf_nerf_packed_bytes_p(d, MF_PREC_F32); }
+extern "C" int64_t mf_nof_packed_bytes(const mf_nof_desc* d) { return mf_nof_packed_bytes_p(d, MF_PREC_F32); }
+extern "C" int32_t mf_nerf_pack(const mf_nerf_desc* d, void* packed, void* stream) { return mf_nerf_pack_p(d, MF_PREC_F32, packed, stream); }
+extern "C" int32_t mf_nof_pack(const mf_nof_desc* d, void* packed, void* stream) { return mf_nof_pack_p(d, MF_PREC_F32, packed, stream); }

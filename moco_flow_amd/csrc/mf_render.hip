@@ -57,7 +57,7 @@ MF_D float wave_sum(float v) {
   return v;
 }
 
-template <bool MOCO>
+template <bool MOCO, bool BF16>
 __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
   const LaneId id;
   const NetDev nerf = p.nerf;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
     if (p.flags & (MF_F_CHAIN_LOCAL | MF_F_CHAIN_GLOBAL)) load_resident(p.fw, id);
   }
   Stream st;
-  Carry carry;
+  CarryT<Pipe<BF16>::PD> carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = p.dbg;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
           const NextLayer follow = last ? follow_of(nerf) : (next_fw ? follow_of(p.fw) : follow_of(p.bw));
           float emb[kStepsNofIn], out[3];
           nof_embed(emb, cur, ind, p.nxyz, p.nind, id.g);
-          nof_eval(net, emb, cur, st, carry, id, follow, out);
+          nof_eval<BF16>(net, emb, cur, st, carry, id, follow, out);
           if (role == 0) { canon[0] = out[0]; canon[1] = out[1]; canon[2] = out[2]; }
           if (role == 1) dl = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
           if (role == 4) dg = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
@@ -162,7 +162,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
         }
       }
       float sigma, rgb[3] = {0.f, 0.f, 0.f};
-      nerf_eval<16>(nerf, embx, ext, sigma_only, st, carry, id, prog_first, sigma, rgb);
+      nerf_eval<16, BF16>(nerf, embx, ext, sigma_only, st, carry, id, prog_first, sigma, rgb);
       if (valid && id.g == 0) {
         sbuf[srel] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
         zbuf[srel] = z;
@@ -252,8 +252,11 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
   if (!a->z_vals && !a->z_steps) return fail(MF_E_INVALID, "mf_render_pass: need z_vals or z_steps");
   if (a->activation != MF_ACT_RELU && a->activation != MF_ACT_SOFTPLUS)
     return fail(MF_E_INVALID, "mf_render_pass: activation %d not supported", a->activation);
+  if (a->precision != MF_PREC_F32 && a->precision != MF_PREC_BF16)
+    return fail(MF_E_INVALID, "mf_render_pass: precision %d", a->precision);
+  const int bf16 = a->precision == MF_PREC_BF16;
   RenderParams p{};
-  if (!nerf_layout(*a->nerf, p.nerf.L)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported NeRF configuration");
+  if (!nerf_layout(*a->nerf, p.nerf.L, bf16)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported NeRF configuration");
   if (p.nerf.L.NK != 16) return fail(MF_E_UNSUPPORTED, "mf_render_pass: only W=256 NeRF is built");
   if (a->emb_xyz.in_channels != 3 || a->emb_xyz.n_freqs > 10)
     return fail(MF_E_UNSUPPORTED, "mf_render_pass: xyz embedding must have 3 channels and <= 10 frequencies");
@@ -290,13 +293,13 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
   int max_groups = p.nerf.L.max_groups;
   if (moco) {
     if (!a->nof_bw_packed) return fail(MF_E_INVALID, "mf_render_pass: nof_bw_packed missing");
-    if (!nof_layout(*a->nof_bw, p.bw.L)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported backward NoF configuration");
+    if (!nof_layout(*a->nof_bw, p.bw.L, bf16)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported backward NoF configuration");
     p.bw.packed = static_cast<const char*>(a->nof_bw_packed);
     p.bw.res_lds = lds; lds += (uint32_t)p.bw.L.res_bytes;
     if (p.bw.L.max_groups > max_groups) max_groups = p.bw.L.max_groups;
     if (chains) {
       if (!a->nof_fw || !a->nof_fw_packed) return fail(MF_E_INVALID, "mf_render_pass: chain flags need the forward NoF");
-      if (!nof_layout(*a->nof_fw, p.fw.L)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported forward NoF configuration");
+      if (!nof_layout(*a->nof_fw, p.fw.L, bf16)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported forward NoF configuration");
       p.fw.packed = static_cast<const char*>(a->nof_fw_packed);
       p.fw.res_lds = lds; lds += (uint32_t)p.fw.L.res_bytes;
       if (p.fw.L.max_groups > max_groups) max_groups = p.fw.L.max_groups;
@@ -335,14 +338,18 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
 
   const int grid = (int)(p.n_groups < device_cus() ? p.n_groups : device_cus());
   hipStream_t st = static_cast<hipStream_t>(stream);
+  const void* fn = moco ? (bf16 ? reinterpret_cast<const void*>(render_kernel<true, true>)
+                                : reinterpret_cast<const void*>(render_kernel<true, false>))
+                        : (bf16 ? reinterpret_cast<const void*>(render_kernel<false, true>)
+                                : reinterpret_cast<const void*>(render_kernel<false, false>));
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);
   if (moco) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(render_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);
-    hipLaunchKernelGGL(render_kernel<true>, dim3(grid), dim3(kThreads), lds, st, p);
+    if (bf16) hipLaunchKernelGGL((render_kernel<true, true>), dim3(grid), dim3(kThreads), lds, st, p);
+    else hipLaunchKernelGGL((render_kernel<true, false>), dim3(grid), dim3(kThreads), lds, st, p);
   } else {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(render_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-      return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);
-    hipLaunchKernelGGL(render_kernel<false>, dim3(grid), dim3(kThreads), lds, st, p);
+    if (bf16) hipLaunchKernelGGL((render_kernel<false, true>), dim3(grid), dim3(kThreads), lds, st, p);
+    else hipLaunchKernelGGL((render_kernel<false, false>), dim3(grid), dim3(kThreads), lds, st, p);
   }
   return check_launch("mf_render_pass");
 }

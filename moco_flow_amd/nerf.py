@@ -39,6 +39,7 @@ class NeRF(nn.Module):
         self.sigma = nn.Linear(W, 1)
         self.rgb = nn.Sequential(nn.Linear(W // 2, 3), nn.Sigmoid())
         self._packed = PackedWeights()
+        self._packed_bf16 = PackedWeights()
 
     # ---- HIP plumbing -----------------------------------------------------
     def _build_desc(self):
@@ -71,10 +72,11 @@ class NeRF(nn.Module):
         d.rgb_w, d.rgb_b = dp(self.rgb[0].weight), dp(self.rgb[0].bias)
         return d, keep
 
-    def packed(self):
-        """(descriptor, packed device buffer), re-packed when the parameters changed."""
+    def packed(self, precision=L.MF_PREC_F32):
+        """(descriptor, packed device buffer), re-packed when the parameters (or the precision) changed."""
         lib = L.lib()
-        return self._packed.get(self, self._build_desc, lib.mf_nerf_packed_bytes, lib.mf_nerf_pack, "NeRF")
+        cache = self._packed if precision == L.MF_PREC_F32 else self._packed_bf16
+        return cache.get(self, self._build_desc, lib.mf_nerf_packed_bytes_p, lib.mf_nerf_pack_p, "NeRF", precision)
 
     def forward(self, inputs, sigma_only=False, img_ind=None):
         """inputs (B, in_channels_xyz [+ extra_feat_dim]) -> (B,4) rgb+sigma, or (B,1) sigma."""

@@ -35,6 +35,7 @@ class NoF(nn.Module):
             setattr(self, f"nof_encoding_{i+1}", nn.Sequential(layer, nn.ReLU(True)))
         self.nof_encoding_final = nn.Linear(W, 9 if use_quat else 3)
         self._packed = PackedWeights()
+        self._packed_bf16 = PackedWeights()
 
     def _build_desc(self):
         if self.extra_feat_type == "latent_code":
@@ -62,9 +63,10 @@ class NoF(nn.Module):
         d.head_w, d.head_b = dp(self.nof_encoding_final.weight), dp(self.nof_encoding_final.bias)
         return d, keep
 
-    def packed(self):
+    def packed(self, precision=L.MF_PREC_F32):
         lib = L.lib()
-        return self._packed.get(self, self._build_desc, lib.mf_nof_packed_bytes, lib.mf_nof_pack, "NoF")
+        cache = self._packed if precision == L.MF_PREC_F32 else self._packed_bf16
+        return cache.get(self, self._build_desc, lib.mf_nof_packed_bytes_p, lib.mf_nof_pack_p, "NoF", precision)
 
     def forward(self, inputs, xyz, img_ind=None):
         """inputs (B, in_channels_xyz + extra_feat_dim), xyz (B,3) -> (B,3)."""

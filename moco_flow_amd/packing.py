@@ -14,7 +14,7 @@ class PackedWeights:
         self.desc = None
         self.keep = None   # contiguous fp32 views the descriptor points into
 
-    def get(self, module, build_desc, bytes_fn, pack_fn, what):
+    def get(self, module, build_desc, bytes_fn, pack_fn, what, precision=0):
         params = list(module.parameters())
         if not params:
             raise RuntimeError(f"{what}: module has no parameters")
@@ -22,14 +22,14 @@ class PackedWeights:
         if dev.type != "cuda":
             raise RuntimeError(f"moco_flow_amd.{what}: parameters are on '{dev}'. This is the MI355X (HIP) "
                                "path; there is no CPU implementation. Call .to('cuda') first.")
-        key = tuple((p.data_ptr(), p._version, p.dtype) for p in params)
+        key = (precision,) + tuple((p.data_ptr(), p._version, p.dtype) for p in params)
         if key != self.key:
             desc, keep = build_desc()
-            nbytes = bytes_fn(desc)
+            nbytes = bytes_fn(desc, precision)
             if nbytes <= 0:
                 L.check(-3, what)
             buf = torch.empty(nbytes, dtype=torch.uint8, device=dev)
             with torch.cuda.device(dev):
-                L.check(pack_fn(desc, buf.data_ptr(), L.current_stream(dev)), what + " pack")
+                L.check(pack_fn(desc, precision, buf.data_ptr(), L.current_stream(dev)), what + " pack")
             self.key, self.buf, self.desc, self.keep = key, buf, desc, keep
         return self.desc, self.buf

@@ -16,6 +16,20 @@ import torch
 from . import _lib as L
 from . import autograd as A
 
+# Arithmetic of the hidden (256-/128-wide) GEMMs of the fused pass: "f32" = exact-fp32 MFMA (the
+# reference's arithmetic, BASELINE configs C1-C2; default) or "bf16" = bf16 operands with fp32
+# accumulate (BASELINE configs C3-C5); embedded-input k-ranges, heads and composite stay fp32.
+# The reference's render_rays signature has no such knob, so it is a module setting.
+PRECISION = "f32"
+
+
+def set_precision(p: str):
+    global PRECISION
+    if p not in ("f32", "bf16"):
+        raise ValueError(f"precision must be 'f32' or 'bf16', got {p!r}")
+    PRECISION = p
+
+
 # Draw torch.randn(N,S) in every pass even when noise_std == 0, as the reference does
 # (rendering.py:166), so that the device RNG stream advances identically.
 STRICT_RNG = True
@@ -46,7 +60,9 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
     if chain_global:
         flags |= L.MF_F_CHAIN_GLOBAL
     a.flags = flags
-    desc, buf = nerf.packed()
+    prec = L.MF_PREC_BF16 if PRECISION == "bf16" else L.MF_PREC_F32
+    a.precision = prec
+    desc, buf = nerf.packed(prec)
     a.nerf, a.nerf_packed = C.pointer(desc), buf.data_ptr()
     a.emb_xyz = _emb_desc(nerf_embs[0])
     if nerf.extra_feat_type == "ind":
@@ -55,11 +71,11 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
         a.emb_extra = _emb_desc(nerf_embs[2])
     keep = [desc, buf]
     if nof_models is not None:
-        bd, bb = nof_models[0].packed()
+        bd, bb = nof_models[0].packed(prec)
         a.nof_bw, a.nof_bw_packed = C.pointer(bd), bb.data_ptr()
         keep += [bd, bb]
         if chain_local or chain_global:
-            fd, fb = nof_models[1].packed()
+            fd, fb = nof_models[1].packed(prec)
             a.nof_fw, a.nof_fw_packed = C.pointer(fd), fb.data_ptr()
             keep += [fd, fb]
         a.nof_emb_xyz, a.nof_emb_ind = _emb_desc(nof_embs[0]), _emb_desc(nof_embs[1])
