@@ -295,7 +295,8 @@ struct CarryT {
 template <int MODE, int NK, int EMB, bool BF16, class Hook>
 MF_D void out_pair(CarryT<Pipe<BF16>::PD>& carry, const typename ActT<BF16>::T (&hid)[ActLen<BF16, NK>::N],
                    const float (&emb)[EMB], uint32_t panel_lane_off, uint32_t next_panel_lane_off,
-                   uint32_t next_bias_off, int g, bool late, Hook&& hook, float lo, f32x4& outE, f32x4& outO) {
+                   uint32_t next_bias_off, int g, bool late, Hook&& hook, float lo, f32x4& outE, f32x4& outO,
+                   bool late_prio = false) {
   if constexpr (!BF16) {
     // fp32: one batch (8 MFMAs) of prefetch is enough; this hand-shaped form of the loop below (two
     // named fragment registers instead of the ring) is what hipcc allocates best (12 % faster).
@@ -308,6 +309,7 @@ MF_D void out_pair(CarryT<Pipe<BF16>::PD>& carry, const typename ActT<BF16>::T (
     };
     f32x4 E = carry.bE, O = carry.bO;
     f32x4 wE = carry.wE[0], wO = carry.wO[0];
+    if (late_prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
       f32x4 nE = wE, nO = wO;
@@ -335,6 +337,7 @@ MF_D void out_pair(CarryT<Pipe<BF16>::PD>& carry, const typename ActT<BF16>::T (
       wE = nE;
       wO = nO;
     }
+    if (late_prio) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       outE[i] = fmaxf(E[i], lo);
@@ -445,9 +448,10 @@ MF_D void trunk_layer(const NetDev& net, int layer, typename ActT<BF16>::T (&act
     auto hook = [&]() { st.sync_and_dma(t + 2 < NP ? groups : nxt.groups, t == NP - 2 ? nxt.jump : nullptr, id); };
     const bool late = id.wave < kWaves / 2 && !(st.dbg & 64);
     f32x4 E, O;
-    if (mode == 2) out_pair<2, NK, EMB, BF16>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, E, O);
-    else if (mode == 3) out_pair<3, NK, EMB, BF16>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, E, O);
-    else out_pair<1, NK, EMB, BF16>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, E, O);
+    const bool prio = (st.dbg & 256) != 0;
+    if (mode == 2) out_pair<2, NK, EMB, BF16>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, E, O, prio);
+    else if (mode == 3) out_pair<3, NK, EMB, BF16>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, E, O, prio);
+    else out_pair<1, NK, EMB, BF16>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, E, O, prio);
     if constexpr (BF16) {
       out[t] = pack8(E, O);
     } else {

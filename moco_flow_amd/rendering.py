@@ -189,11 +189,15 @@ def render_rays(rays,
                 nerf_activate_type='relu',
                 test_time=False,
                 _capture=None,
+                _rng=None,
                 ):
     """Same contract as the reference's render_rays (rendering.py:195-375): rays (N, 9|10),
     background (N,3)|None -> dict with rgb/depth/opacity_{coarse,fine} and, in training with NoF,
     nof_{local,global}_disp_{coarse,fine}. ``_capture`` (dict, test hook) receives the per-pass
-    (N,S) planes the kernels produced (z, weights, alphas) without changing the result."""
+    (N,S) planes the kernels produced (z, weights, alphas) without changing the result; ``_rng`` (dict,
+    test hook) supplies the random draws instead of torch.rand / randn: perturb_rand (N,S),
+    noise_coarse (N,S), noise_fine (N,S+M) (already scaled by noise_std), u (N,M)."""
+    _rng = _rng or {}
     L.require_gpu(rays, "render_rays")
     if nerf_activate_type == 'relu':
         act = L.MF_ACT_RELU
@@ -234,10 +238,13 @@ def render_rays(rays,
             z_mid = 0.5 * (z_vals[:, :-1] + z_vals[:, 1:])
             upper = torch.cat([z_mid, z_vals[:, -1:]], -1)
             lower = torch.cat([z_vals[:, :1], z_mid], -1)
-            z_vals = lower + (upper - lower) * (perturb * torch.rand(z_vals.shape, device=dev))
+            pr = _rng["perturb_rand"] if "perturb_rand" in _rng else torch.rand(z_vals.shape, device=dev)
+            z_vals = lower + (upper - lower) * (perturb * pr)
         z_vals = z_vals.contiguous()
 
-    def draw_noise(shape):
+    def draw_noise(shape, key=None):
+        if key in _rng:
+            return _rng[key].contiguous().float()
         if noise_std != 0:
             return (torch.randn(shape, device=dev) * noise_std).contiguous()
         if STRICT_RNG and shape[0] > 0:
@@ -246,7 +253,7 @@ def render_rays(rays,
 
     coarse_sigma_only = bool(need_fine and test_time)                  # rendering.py:290-294
     want_planes = need_fine or loc or glob or grad or _capture is not None
-    noise_c = draw_noise((N, S))
+    noise_c = draw_noise((N, S), "noise_coarse")
     c = _render_pass(rays, background, z_vals, None if z_vals is not None else z_steps, use_disp,
                      noise_c, act, nerf_models[0], nerf_embeddings,
                      nof_models if use_nof else None, nof_embeddings, loc, glob, coarse_sigma_only, want_planes)
@@ -264,8 +271,8 @@ def render_rays(rays,
     if _capture is not None:
         _capture.update(z_coarse=z_vals, weights_coarse=c.get("weights"), alphas_coarse=c.get("alphas"))
     if need_fine:
-        z_all = resample_merge(z_vals, c["weights"], N_importance, det=(perturb == 0))
-        noise_f = draw_noise((N, S + N_importance))
+        z_all = resample_merge(z_vals, c["weights"], N_importance, det=(perturb == 0), u=_rng.get("u"))
+        noise_f = draw_noise((N, S + N_importance), "noise_fine")
         f = _render_pass(rays, background, z_all, None, use_disp, noise_f, act,
                          nerf_models[1], nerf_embeddings, nof_models if use_nof else None, nof_embeddings,
                          loc, glob, False, loc or glob or grad or _capture is not None)

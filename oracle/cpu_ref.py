@@ -271,10 +271,13 @@ def render_rays(rays, background, nerf_embeddings, nerf_models, nof_embeddings=N
                 nof_models=None, chain_local=False, chain_global=False, N_samples=64,
                 N_importance=0, use_disp=False, perturb=0, noise_std=1,
                 nerf_activate_type="relu", test_time=False, _capture: Optional[dict] = None,
-                _z_fine_override=None):
+                _z_fine_override=None, _rng: Optional[dict] = None):
     """rendering.py:195-375. ``_capture`` (test hook) receives z_vals / weights / alphas;
     ``_z_fine_override`` (test hook) replaces the sorted fine depths, so that the fine pass can be
-    checked independently of the u = 1.0 resampling hazard."""
+    checked independently of the u = 1.0 resampling hazard; ``_rng`` (test hook)
+    supplies the random draws (perturb_rand (N,S), noise_coarse (N,S), noise_fine (N,S+M), u (N,M))
+    so that the stochastic branches (rendering.py:259, 166, 30) can be compared across devices."""
+    _rng = _rng or {}
     N = rays.shape[0]
     rays_o, rays_d = rays[:, 0:3], rays[:, 3:6]
     near, far = rays[:, 6:7], rays[:, 7:8]
@@ -293,7 +296,8 @@ def render_rays(rays, background, nerf_embeddings, nerf_models, nof_embeddings=N
         mid = 0.5 * (z_vals[:, :-1] + z_vals[:, 1:])
         upper = torch.cat([mid, z_vals[:, -1:]], -1)
         lower = torch.cat([z_vals[:, :1], mid], -1)
-        z_vals = lower + (upper - lower) * (perturb * torch.rand(z_vals.shape))
+        pr = _rng["perturb_rand"] if "perturb_rand" in _rng else torch.rand(z_vals.shape)
+        z_vals = lower + (upper - lower) * (perturb * pr)
 
     def chains(xyz):
         """bw / fw NoF evaluations of one pass (rendering.py:270-286, 335-346)."""
@@ -328,13 +332,14 @@ def render_rays(rays, background, nerf_embeddings, nerf_models, nof_embeddings=N
     if N_importance > 0 and test_time:
         w_c, a_c = nerf_inference(nerf_in, img_ind, rays_d, z_vals, noise_std, nerf_embeddings,
                                   nerf_models[0], background=background, weights_only=True,
-                                  activate_type=nerf_activate_type)
+                                  activate_type=nerf_activate_type, noise=_rng.get("noise_coarse"))
         result = {"opacity_coarse": w_c.sum(1)}
     else:
         rgb_c, depth_c, w_c, a_c = nerf_inference(nerf_in, img_ind, rays_d, z_vals, noise_std,
                                                   nerf_embeddings, nerf_models[0],
                                                   background=background, weights_only=False,
-                                                  activate_type=nerf_activate_type)
+                                                  activate_type=nerf_activate_type,
+                                                  noise=_rng.get("noise_coarse"))
         result = {"rgb_coarse": rgb_c, "depth_coarse": depth_c, "opacity_coarse": w_c.sum(1)}
     if _capture is not None:
         _capture.update(z_coarse=z_vals, weights_coarse=w_c, alphas_coarse=a_c)
@@ -344,7 +349,10 @@ def render_rays(rays, background, nerf_embeddings, nerf_models, nof_embeddings=N
 
     if N_importance > 0:
         mid = 0.5 * (z_vals[:, :-1] + z_vals[:, 1:])
-        z_new = sample_pdf(mid, w_c[:, 1:-1], N_importance, det=(perturb == 0)).detach()
+        if "u" in _rng:
+            z_new = sample_pdf_full(mid, w_c[:, 1:-1], N_importance, det=False, u=_rng["u"])["samples"].detach()
+        else:
+            z_new = sample_pdf(mid, w_c[:, 1:-1], N_importance, det=(perturb == 0)).detach()
         z_vals, _ = torch.sort(torch.cat([z_vals, z_new], -1), -1)
         if _z_fine_override is not None:
             z_vals = _z_fine_override
@@ -356,7 +364,7 @@ def render_rays(rays, background, nerf_embeddings, nerf_models, nof_embeddings=N
         rgb_f, depth_f, w_f, a_f = nerf_inference(nerf_in, img_ind, rays_d, z_vals, noise_std,
                                                   nerf_embeddings, nerf_models[1],
                                                   background=background, weights_only=False,
-                                                  activate_type=nerf_activate_type)
+                                                  activate_type=nerf_activate_type, noise=_rng.get("noise_fine"))
         result["rgb_fine"] = rgb_f
         result["depth_fine"] = depth_f
         result["opacity_fine"] = w_f.sum(1)

@@ -100,7 +100,7 @@ def _check_result(res, want, c, flipped=None, fine_tol=TOL):
             assert abs(n_g - n_w) <= max(2, int(0.002 * n_w)), (k, n_g, n_w)
             if n_g == n_w:
                 d = (got.cpu().double() - torch.from_numpy(v).double()).abs() / max(float(np.abs(v).max()), 1e-30)
-                n_out = int((d > TOL).sum())
+                n_out = int((d > (fine_tol if k.endswith("_fine") else TOL)).sum())
                 assert n_out <= (16 * n_flip if k.endswith("_fine") else 0), (k, n_out, float(d.max()))
             else:
                 assert abs(float(got.mean()) - float(v.mean())) <= 1e-3 * abs(float(v.mean()))
@@ -415,3 +415,36 @@ def test_bf16_hidden_gemms(M, R, name):
             assert psnr > 38.0, (k, psnr)
     for k in ("opacity_coarse", "depth_coarse"):
         assert relerr(res[k], g["out_" + k]) <= 6e-2, (k, relerr(res[k], g["out_" + k]))
+
+
+@pytest.mark.parametrize("name", ["r_nerf_dir_fine_train", "r_moco_global_fine"])
+def test_stochastic_branches_with_injected_draws(M, R, name):
+    """perturb > 0 (stratified jitter, rendering.py:253-260), noise_std > 0 (:166) and the stochastic
+    resample (u ~ rand, :30): the random tensors are drawn once here and injected into both the
+    oracle and the HIP path, which then must agree to 1e-4 -- with random u there is no u = 1.0 hazard,
+    so the fine pass is compared directly."""
+    c = dict(RENDER_CASES[name])
+    seed = int(load_golden(name)["meta_seed"])
+    n, S, Mi = 96, c["S"], c["M"]
+    rays, bg = case_inputs(c, seed, n=n)
+    gen = torch.Generator().manual_seed(5)
+    rng = dict(perturb_rand=torch.rand(n, S, generator=gen), noise_coarse=0.3 * torch.randn(n, S, generator=gen),
+               noise_fine=0.3 * torch.randn(n, S + Mi, generator=gen), u=torch.rand(n, Mi, generator=gen))
+    embs_o, nerfs_o, kw_o = build_case(R, c, seed)
+    embs, nerfs, kw = build_case(M, c, seed, device="cuda")
+    kw_o.update(perturb=1.0, noise_std=0.3)
+    kw.update(perturb=1.0, noise_std=0.3)
+    cap_o, cap = {}, {}
+    with torch.no_grad():
+        want = R.render_rays(rays, bg, embs_o, nerfs_o, _rng=rng, _capture=cap_o, **kw_o)
+        res = M.render_rays(rays.cuda(), bg.cuda(), embs, nerfs, _rng={k: v.cuda() for k, v in rng.items()},
+                            _capture=cap, **kw)
+    assert relerr(cap["z_coarse"], cap_o["z_coarse"]) <= 1e-6
+    # resample conditioning (a low-weight bin divides an O(ulp) cdf difference by ~1e-5): the drawn
+    # depths agree to ~1e-3 of the range; the fine pass itself is then pinned on identical depths
+    assert relerr(cap["z_fine"], cap_o["z_fine"]) <= 1e-3
+    _check_result(res, {k: v.numpy() for k, v in want.items()}, c, None, fine_tol=5e-3)
+    with torch.no_grad():
+        want2 = R.render_rays(rays, bg, embs_o, nerfs_o, _rng=rng, _z_fine_override=cap["z_fine"].cpu(), **kw_o)
+    _check_result({k: v for k, v in res.items() if "fine" in k},
+                  {k: v.numpy() for k, v in want2.items() if "fine" in k}, c, None)
