@@ -21,6 +21,9 @@
 // two panels ahead of the MFMAs in a 3-slot ring.
 #pragma once
 #include <hip/hip_runtime.h>
+#ifndef MF_F32_PD
+#define MF_F32_PD 1   // fp32 fragment prefetch distance in batches (1 or 2; 2 measured 1.3 % slower: more spills)
+#endif
 #include <stdint.h>
 
 namespace mf {
@@ -248,7 +251,7 @@ template <> struct ActT<true> { using T = u32x4; };
 template <bool BF16, int NK> struct ActLen { static constexpr int N = BF16 ? NK / 2 : NK; };
 // fragment prefetch distance in batches: a bf16 batch is only 2 MFMAs (32 cycles), so the LDS
 // latency needs 4 of them; an fp32 batch is 8 MFMAs (256 cycles).
-template <bool BF16> struct Pipe { static constexpr int PD = BF16 ? 4 : 1; };
+template <bool BF16> struct Pipe { static constexpr int PD = BF16 ? 4 : MF_F32_PD; };
 
 MF_D u32x4 pack8(const f32x4& e, const f32x4& o) {
   bf16x8 v;
@@ -307,8 +310,10 @@ MF_D void out_pair(CarryT<Pipe<BF16>::PD>& carry, const typename ActT<BF16>::T (
       if (q < QE) return emb[4 * q + r];
       else return hid[q - QE][r];
     };
+    constexpr int PDF = Pipe<false>::PD;                 // 1 or 2 batches of fragment prefetch
     f32x4 E = carry.bE, O = carry.bO;
     f32x4 wE = carry.wE[0], wO = carry.wO[0];
+    f32x4 xE = carry.wE[PDF - 1], xO = carry.wO[PDF - 1];   // second pipeline stage (PDF == 2)
     if (late_prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
     for (int q = 0; q < Q; ++q) {
@@ -316,17 +321,18 @@ MF_D void out_pair(CarryT<Pipe<BF16>::PD>& carry, const typename ActT<BF16>::T (
       E = MF_MFMA(wE[0], bop(q, 0), E);
       O = MF_MFMA(wO[0], bop(q, 0), O);
       __builtin_amdgcn_sched_barrier(0);
-      if (q + 1 < Q) {
-        nE = lds_f4(panel_lane_off + (2 * (q + 1)) * kGroupBytes);
-        nO = lds_f4(panel_lane_off + (2 * (q + 1) + 1) * kGroupBytes);
+      const int nq = q + PDF;
+      if (nq < Q) {
+        nE = lds_f4(panel_lane_off + (2 * nq) * kGroupBytes);
+        nO = lds_f4(panel_lane_off + (2 * nq + 1) * kGroupBytes);
       }
       if (q == 0 && !late) hook();
       if (q == Q / 2 && late) hook();
-      if (q + 1 >= Q) {
-        carry.wE[0] = lds_f4(next_panel_lane_off);
-        carry.wO[0] = lds_f4(next_panel_lane_off + kGroupBytes);
-        carry.load_bias(next_bias_off, g);
+      if (nq >= Q) {                                     // runs on into the next panel (after the barrier)
+        nE = lds_f4(next_panel_lane_off + (2 * (nq - Q)) * kGroupBytes);
+        nO = lds_f4(next_panel_lane_off + (2 * (nq - Q) + 1) * kGroupBytes);
       }
+      if (q + 1 >= Q) carry.load_bias(next_bias_off, g);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int r = 1; r < 4; ++r) {
@@ -334,9 +340,15 @@ MF_D void out_pair(CarryT<Pipe<BF16>::PD>& carry, const typename ActT<BF16>::T (
         O = MF_MFMA(wO[r], bop(q, r), O);
       }
       __builtin_amdgcn_sched_barrier(0);
-      wE = nE;
-      wO = nO;
+      if constexpr (PDF == 2) {
+        wE = xE; wO = xO;
+        xE = nE; xO = nO;
+      } else {
+        wE = nE; wO = nO;
+      }
     }
+    carry.wE[0] = wE; carry.wO[0] = wO;
+    if constexpr (PDF == 2) { carry.wE[1] = xE; carry.wO[1] = xO; }
     if (late_prio) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
     for (int i = 0; i < 4; ++i) {

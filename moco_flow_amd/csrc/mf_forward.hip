@@ -55,7 +55,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_forward_kernel(NerfFwdParams
   NetDev net = p.net;
   load_resident(net, id);
   Stream st;
-  CarryT<1> carry;
+  CarryT<Pipe<false>::PD> carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = 0;
@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kThreads, 2) void nof_forward_kernel(NofFwdParams p
   NetDev net = p.net;
   load_resident(net, id);
   Stream st;
-  CarryT<1> carry;
+  CarryT<Pipe<false>::PD> carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = 0;
