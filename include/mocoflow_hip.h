@@ -123,6 +123,17 @@ int32_t mf_nerf_forward(const mf_nerf_desc* d, const void* packed, const float* 
 int32_t mf_nof_forward(const mf_nof_desc* d, const void* packed, const float* inputs,
                        int64_t in_stride, const float* xyz, int64_t B, float* out, void* stream);
 
+/* Fused point query: xyz (B,3) -> [backward NoF at image index ind] -> positional encoding -> NeRF
+ * trunk -> raw sigma (B,), one launch.  Replaces the per-chunk module sequence forward_nof /
+ * nerf_embedding_xyz / zero-pad / NeRF(sigma_only=True) of trainer_moco_flow.py:146-187 and the
+ * lattice loop of visualize_mesh (trainer_moco_flow.py:500-526, trainer_nerf.py:215-245).
+ * nof == NULL: canonical-space query.  ind: per-point indices (B,) or NULL -> ind_scalar for all.
+ * canon (B,3), optional: the point after the backward flow. */
+int32_t mf_points_sigma(const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz,
+                        const mf_nof_desc* nof, const void* nof_packed, const mf_embedding* nof_emb_xyz,
+                        const mf_embedding* nof_emb_ind, const float* xyz, const float* ind,
+                        float ind_scalar, int64_t B, float* sigma, float* canon, void* stream);
+
 /* ---- one rendering pass: nof_inference* + nerf_inference of models/rendering.py:49-192 as
  * called from render_rays (rendering.py:262-314 coarse, 329-373 fine) -------------------- */
 enum {

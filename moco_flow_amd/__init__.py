@@ -11,10 +11,11 @@ from .embedding import Embedding
 from .losses import MSELoss
 from .nerf import NeRF
 from .nof import NoF
+from .points import query_sigma
 from .rendering import render_rays, resample_merge, sample_pdf, set_precision
 
 __all__ = ["Embedding", "NeRF", "NoF", "get_model", "get_loss", "render_rays", "sample_pdf",
-           "resample_merge", "set_precision", "MSELoss"]
+           "resample_merge", "set_precision", "query_sigma", "MSELoss"]
 
 
 def get_model(model_config):

@@ -138,6 +138,65 @@ __global__ __launch_bounds__(kThreads, 2) void nof_forward_kernel(NofFwdParams p
   wait_vm0();
 }
 
+// ------------------------------------------------------------------ fused point queries
+// sigma (and the canonical position) of free points: the whole of forward_nof + embed + pad +
+// NeRF(sigma_only) that trainer_moco_flow.py:146-187 / 500-526 (visualize_mesh lattice, SMPL-point
+// losses) spell with five module calls and three padded temporaries per 10 000-point chunk, as one
+// launch over all points: xyz -> [bw NoF(ind)] -> encode in registers -> NeRF trunk -> sigma.
+struct PointsParams {
+  NetDev nerf, nof;
+  EmbParams exyz, nxyz, nind;
+  const float* xyz;        // (B,3)
+  const float* ind;        // (B,) per-point image index, or null -> ind_scalar
+  float ind_scalar;
+  long long B;
+  float* sigma;            // (B,)  raw sigma (no activation)
+  float* canon;            // (B,3) or null: the point after the backward flow
+  uint32_t ring_off, buf_bytes;
+};
+
+template <bool NOF>
+__global__ __launch_bounds__(kThreads, 2) void points_kernel(PointsParams p) {
+  const LaneId id;
+  load_resident(p.nerf, id);
+  if (NOF) load_resident(p.nof, id);
+  Stream st;
+  CarryT<Pipe<false>::PD> carry;
+  st.ring = p.ring_off;
+  st.buf_bytes = p.buf_bytes;
+  st.dbg = 0;
+  const NextLayer prog_first = NOF ? follow_of(p.nof) : follow_of(p.nerf);
+  if (NOF) start_program(p.nof, st, carry, id);
+  else start_program(p.nerf, st, carry, id);
+  const long long ntiles = (p.B + kTile - 1) / kTile;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long b = tile * kTile + id.wave * kWaveSamples + id.j;
+    const bool valid = b < p.B;
+    const long long bb = valid ? b : p.B - 1;
+    float x[3] = {p.xyz[bb * 3 + 0], p.xyz[bb * 3 + 1], p.xyz[bb * 3 + 2]};
+    if (NOF) {
+      const float ind = p.ind ? p.ind[bb] : p.ind_scalar;
+      float emb[kStepsNofIn], out[3];
+      nof_embed(emb, x, ind, p.nxyz, p.nind, id.g);
+      nof_eval<false>(p.nof, emb, x, st, carry, id, follow_of(p.nerf), out);
+      x[0] = out[0]; x[1] = out[1]; x[2] = out[2];
+      if (valid && id.g == 0 && p.canon) {
+        p.canon[b * 3 + 0] = x[0]; p.canon[b * 3 + 1] = x[1]; p.canon[b * 3 + 2] = x[2];
+      }
+    }
+    float embx[kStepsNerfXyz], ext[kStepsExtraMax];
+    emb_eval<3, 10>(embx, x, p.exyz, id.g);
+#pragma unroll
+    for (int e = BlkXyz10::SLOTS; e < kStepsNerfXyz; ++e) embx[e] = 0.f;
+#pragma unroll
+    for (int e = 0; e < kStepsExtraMax; ++e) ext[e] = 0.f;
+    float sigma, rgb[3];
+    nerf_eval<16, false>(p.nerf, embx, ext, true, st, carry, id, prog_first, sigma, rgb);
+    if (valid && id.g == 0) p.sigma[b] = sigma;
+  }
+  wait_vm0();
+}
+
 int device_cus() {
   static int cus = 0;
   if (cus == 0) {
@@ -207,4 +266,54 @@ extern "C" int32_t mf_nof_forward(const mf_nof_desc* d, const void* packed, cons
   const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
   hipLaunchKernelGGL(nof_forward_kernel, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
   return check_launch("mf_nof_forward");
+}
+
+static void emb_to_params(const mf_embedding& e, EmbParams& o) {
+  for (int k = 0; k < 16; ++k) {
+    o.freq[k] = k < e.n_freqs ? e.freq[k] : 0.f;
+    o.weight[k] = k < e.n_freqs ? e.weight[k] : 0.f;
+  }
+}
+
+extern "C" int32_t mf_points_sigma(const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz,
+                                   const mf_nof_desc* nof, const void* nof_packed, const mf_embedding* nof_emb_xyz,
+                                   const mf_embedding* nof_emb_ind, const float* xyz, const float* ind,
+                                   float ind_scalar, int64_t B, float* sigma, float* canon, void* stream) {
+  if (!nerf || !nerf_packed || !emb_xyz || (B > 0 && (!xyz || !sigma)))
+    return fail(MF_E_INVALID, "mf_points_sigma: null argument");
+  PointsParams p{};
+  if (!nerf_layout(*nerf, p.nerf.L) || p.nerf.L.NK != 16)
+    return fail(MF_E_UNSUPPORTED, "mf_points_sigma: unsupported NeRF configuration");
+  if (emb_xyz->in_channels != 3 || emb_xyz->n_freqs > 10)
+    return fail(MF_E_UNSUPPORTED, "mf_points_sigma: xyz embedding must have 3 channels and <= 10 frequencies");
+  if (B == 0) return MF_OK;
+  uint32_t lds = 0;
+  p.nerf.packed = static_cast<const char*>(nerf_packed);
+  p.nerf.res_lds = lds; lds += (uint32_t)p.nerf.L.res_bytes;
+  int max_groups = p.nerf.L.max_groups;
+  emb_to_params(*emb_xyz, p.exyz);
+  if (nof) {
+    if (!nof_packed || !nof_emb_xyz || !nof_emb_ind) return fail(MF_E_INVALID, "mf_points_sigma: NoF arguments missing");
+    if (!nof_layout(*nof, p.nof.L)) return fail(MF_E_UNSUPPORTED, "mf_points_sigma: unsupported NoF configuration");
+    if (nof_emb_xyz->in_channels != 3 || nof_emb_xyz->n_freqs > 5 || nof_emb_ind->in_channels != 1 || nof_emb_ind->n_freqs != 16)
+      return fail(MF_E_UNSUPPORTED, "mf_points_sigma: NoF embeddings must be xyz(3, <=5 freqs) and ind(1, 16 freqs)");
+    p.nof.packed = static_cast<const char*>(nof_packed);
+    p.nof.res_lds = lds; lds += (uint32_t)p.nof.L.res_bytes;
+    if (p.nof.L.max_groups > max_groups) max_groups = p.nof.L.max_groups;
+    emb_to_params(*nof_emb_xyz, p.nxyz);
+    emb_to_params(*nof_emb_ind, p.nind);
+  }
+  p.xyz = xyz; p.ind = ind; p.ind_scalar = ind_scalar; p.B = B; p.sigma = sigma; p.canon = canon;
+  p.ring_off = lds;
+  p.buf_bytes = (uint32_t)max_groups * kGroupBytes;
+  lds += 3 * p.buf_bytes;
+  const void* fn = nof ? reinterpret_cast<const void*>(points_kernel<true>) : reinterpret_cast<const void*>(points_kernel<false>);
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(MF_E_LAUNCH, "mf_points_sigma: cannot reserve %u bytes of LDS", lds);
+  const long long ntiles = (B + kTile - 1) / kTile;
+  const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (nof) hipLaunchKernelGGL(points_kernel<true>, dim3(grid), dim3(kThreads), lds, st, p);
+  else hipLaunchKernelGGL(points_kernel<false>, dim3(grid), dim3(kThreads), lds, st, p);
+  return check_launch("mf_points_sigma");
 }

@@ -448,3 +448,35 @@ def test_stochastic_branches_with_injected_draws(M, R, name):
         want2 = R.render_rays(rays, bg, embs_o, nerfs_o, _rng=rng, _z_fine_override=cap["z_fine"].cpu(), **kw_o)
     _check_result({k: v for k, v in res.items() if "fine" in k},
                   {k: v.numpy() for k, v in want2.items() if "fine" in k}, c, None)
+
+
+def test_fused_point_query(M, R):
+    """mf_points_sigma == the trainer's five-call sequence (forward_nof -> embed -> pad -> NeRF sigma_only),
+    checked against the oracle's restatement of trainer_moco_flow.py:146-187."""
+    from moco_flow_amd import synth
+    torch.manual_seed(1)
+    B = 1000                                     # not a multiple of the 128-point tile
+    xyz = (torch.rand(B, 3) * 3 - 1.5)
+    sd_n = synth.nerf_state(41, extra_feat_type="ind", extra_feat_dim=5, regime="dense", tag="pts")
+    sd_f = synth.nof_state(42, use_quat=True, tag="pts", head_scale=0.25)
+    nerf = M.NeRF(8, 256, 63, [4], "ind", 5)
+    nerf.load_state_dict({k: torch.from_numpy(v) for k, v in sd_n.items()})
+    nof = M.NoF(4, 128, 33, [2], "ind", 33, True)
+    nof.load_state_dict({k: torch.from_numpy(v) for k, v in sd_f.items()})
+    nerf, nof = nerf.cuda(), nof.cuda()
+    ex, nx, ni = M.Embedding(3, 10), M.Embedding(3, 5), M.Embedding(1, 16)
+    frame, num_frames = torch.tensor([17]), 300
+    ind = float(frame.item()) * 2 / num_frames - 1.0
+    with torch.no_grad():
+        sig, canon = M.query_sigma(xyz.cuda(), nerf, ex, bw_nof=nof, nof_embeddings=[nx, ni], ind=ind,
+                                   return_canonical=True)
+        sig0 = M.query_sigma(xyz.cuda(), nerf, ex)
+        onerf = R.NeRF(8, 256, 63, [4], "ind", 5, state=sd_n)
+        onof = R.NoF(4, 128, 33, [2], "ind", 33, True, state=sd_f)
+        ocanon = R.forward_nof_points(xyz, frame, num_frames, R.Embedding(3, 5), R.Embedding(1, 16), onof)
+        osig = onerf(R.Embedding(3, 10)(ocanon), sigma_only=True)
+        osig0 = onerf(R.Embedding(3, 10)(xyz), sigma_only=True)
+    assert sig.shape == (B, 1) and canon.shape == (B, 3)
+    assert relerr(canon, ocanon) <= TOL
+    assert relerr(sig, osig) <= TOL
+    assert relerr(sig0, osig0) <= TOL
