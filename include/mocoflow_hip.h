@@ -205,6 +205,19 @@ int32_t mf_compact_mask(const float* alphas, const float* vals_a, const float* v
                         int64_t n_rays, int32_t S, float* out_a, float* out_b,
                         int64_t* count, void* scratch, void* stream);
 
+/* ---- producers either side of the path -----------------------------
+ * Camera.make_rays (utils/camera.py:134-148 with gen_ray_directions :29-50 and gen_rays :52-81):
+ * rays_out (H*W, 9) = [o(3), unit d(3), near, far, idx], pixel order row-major; the direction is
+ * ((i-cx)/focal, -(j-cy)/focal, -1) rotated by c2w[:, :3] (host pointer to the 3x4 row-major matrix, or
+ * NULL for camera coordinates).  near/far/idx are the scalars make_rays broadcasts. */
+int32_t mf_make_rays(int32_t H, int32_t W, float focal, float cx, float cy, const float* c2w_host,
+                     float nearv, float farv, float idx, float* rays_out, void* stream);
+/* knn_cuda.KNN(k=1, transpose_mode=True) of the vendored wheel (datasets/moco_flow_dataset.py:35,120):
+ * ref (V,3), query (Q,3) -> dist (Q,) Euclidean distance to, and ind (Q,) int64 0-based index of, the
+ * nearest reference point; first minimum on ties. */
+int32_t mf_knn1(const float* ref, int64_t V, const float* query, int64_t Q, float* dist, int64_t* ind,
+                void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,108 @@
+// mf_aux.hip -- the producers on either side of the hot path:
+//   mf_make_rays : Camera.make_rays / gen_ray_directions / gen_rays   utils/camera.py:29-81, 134-148
+//   mf_knn1      : knn_cuda.KNN(k=1)  (vendored wheel docker/KNN_CUDA-0.2: knn_cuda/csrc/cuda/knn.cu:29-183)
+#include "mf_host.hpp"
+
+namespace mf {
+
+struct RaysParams {
+  int H, W;
+  float fx, cx, cy;
+  float R[9], t[3];
+  int has_c2w;
+  float nearv, farv, idx;
+  float* out;
+};
+
+// one thread per pixel; row-major pixel order (row j, column i), 9 floats per ray
+__global__ void make_rays_kernel(RaysParams p) {
+  const long long n = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= (long long)p.H * p.W) return;
+  const int j = (int)(n / p.W), i = (int)(n - (long long)j * p.W);
+  // camera.py:47-48: ((i - cx)/f0, -(j - cy)/f0, -1); both axes use focal[0]
+  const float dx = ((float)i - p.cx) / p.fx;
+  const float dy = -(((float)j - p.cy) / p.fx);
+  const float dz = -1.f;
+  float wx, wy, wz, ox = 0.f, oy = 0.f, oz = 0.f;
+  if (p.has_c2w) {
+    // camera.py:73: directions @ c2w[:, :3].T  (dot over the camera axes, in order)
+    wx = dx * p.R[0] + dy * p.R[1] + dz * p.R[2];
+    wy = dx * p.R[3] + dy * p.R[4] + dz * p.R[5];
+    wz = dx * p.R[6] + dy * p.R[7] + dz * p.R[8];
+    ox = p.t[0]; oy = p.t[1]; oz = p.t[2];
+  } else {
+    wx = dx; wy = dy; wz = dz;
+  }
+  const float nrm = sqrtf(wx * wx + wy * wy + wz * wz);      // camera.py:68/74
+  float* o = p.out + n * 9;
+  o[0] = ox; o[1] = oy; o[2] = oz;
+  o[3] = wx / nrm; o[4] = wy / nrm; o[5] = wz / nrm;
+  o[6] = p.nearv; o[7] = p.farv; o[8] = p.idx;
+}
+
+struct KnnParams {
+  const float* ref; long long V;
+  const float* query; long long Q;
+  float* dist; long long* ind;
+};
+
+// k = 1 nearest reference point of each query: one thread per query, reference points staged
+// through LDS in tiles; first minimum wins on ties (the wheel's insertion sort uses strict '<').
+__global__ __launch_bounds__(256) void knn1_kernel(KnnParams p) {
+  __shared__ float tile[1024 * 3];
+  const long long q = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const bool valid = q < p.Q;
+  float qx = 0.f, qy = 0.f, qz = 0.f;
+  if (valid) { qx = p.query[q * 3]; qy = p.query[q * 3 + 1]; qz = p.query[q * 3 + 2]; }
+  float best = __builtin_inff();
+  long long besti = 0;
+  for (long long base = 0; base < p.V; base += 1024) {
+    const int n = (int)((p.V - base) < 1024 ? (p.V - base) : 1024);
+    __syncthreads();
+    for (int k = threadIdx.x; k < n * 3; k += blockDim.x) tile[k] = p.ref[base * 3 + k];
+    __syncthreads();
+    for (int v = 0; v < n; ++v) {
+      const float ax = tile[v * 3] - qx, ay = tile[v * 3 + 1] - qy, az = tile[v * 3 + 2] - qz;
+      const float d = __builtin_fmaf(az, az, __builtin_fmaf(ay, ay, ax * ax));   // knn.cu:75-79 (nvcc fmad)
+      if (d < best) { best = d; besti = base + v; }
+    }
+  }
+  if (valid) {
+    p.dist[q] = sqrtf(best);                                  // knn.cu:178-183
+    p.ind[q] = besti;                                         // 0-based (knn_cuda/__init__.py:45)
+  }
+}
+
+}  // namespace mf
+
+using namespace mf;
+
+extern "C" int32_t mf_make_rays(int32_t H, int32_t W, float focal, float cx, float cy, const float* c2w_host,
+                                float nearv, float farv, float idx, float* rays_out, void* stream) {
+  if (H < 0 || W < 0 || focal == 0.f) return fail(MF_E_INVALID, "mf_make_rays: H=%d W=%d focal=%g", H, W, focal);
+  if ((long long)H * W == 0) return MF_OK;
+  if (!rays_out) return fail(MF_E_INVALID, "mf_make_rays: null output");
+  RaysParams p{};
+  p.H = H; p.W = W; p.fx = focal; p.cx = cx; p.cy = cy;
+  p.has_c2w = c2w_host != nullptr;
+  if (c2w_host) {
+    for (int a = 0; a < 3; ++a) {
+      for (int b = 0; b < 3; ++b) p.R[a * 3 + b] = c2w_host[a * 4 + b];
+      p.t[a] = c2w_host[a * 4 + 3];
+    }
+  }
+  p.nearv = nearv; p.farv = farv; p.idx = idx; p.out = rays_out;
+  const long long n = (long long)H * W;
+  hipLaunchKernelGGL(make_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  return check_launch("mf_make_rays");
+}
+
+extern "C" int32_t mf_knn1(const float* ref, int64_t V, const float* query, int64_t Q, float* dist, int64_t* ind,
+                           void* stream) {
+  if (V < 1 || Q < 0) return fail(MF_E_INVALID, "mf_knn1: V=%lld Q=%lld", (long long)V, (long long)Q);
+  if (Q == 0) return MF_OK;
+  if (!ref || !query || !dist || !ind) return fail(MF_E_INVALID, "mf_knn1: null argument");
+  KnnParams p{ref, V, query, Q, dist, reinterpret_cast<long long*>(ind)};
+  hipLaunchKernelGGL(knn1_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  return check_launch("mf_knn1");
+}

@@ -30,6 +30,7 @@ from __future__ import annotations
 import math
 from typing import Dict, List, Optional, Sequence
 
+import numpy as np
 import torch
 import torch.nn.functional as F
 
@@ -414,3 +415,37 @@ def build_nerf(state, D=8, W=256, in_channels_xyz=63, skips=(4,), extra_feat_typ
 
 def build_nof(state, D=4, W=128, in_channels_xyz=33, skips=(2,), extra_feat_dim=33, use_quat=True):
     return NoF(D, W, in_channels_xyz, skips, "ind", extra_feat_dim, use_quat, state=state)
+
+
+# ------------------------------------------------------------- producers (§8f rows 3-4)
+def gen_ray_directions(H, W, focal, camera_c=(0, 0)):
+    """utils/camera.py:29-50."""
+    i, j = torch.meshgrid(torch.linspace(0, W - 1, W), torch.linspace(0, H - 1, H), indexing="ij")
+    i, j = i.t(), j.t()
+    focal = [focal[0], focal[0]] if len(focal) == 1 else list(focal)
+    return torch.stack([(i - camera_c[0]) / focal[0], -(j - camera_c[1]) / focal[0], -torch.ones_like(i)], -1)
+
+
+def make_rays(H, W, focal, center, c2w, near, far, idx):
+    """utils/camera.py:52-81 + 134-148: (H*W, 9) rays. c2w: (3|4, 4) numpy array or None."""
+    directions = gen_ray_directions(H, W, focal, center)
+    if c2w is None:
+        rays_d = directions / torch.norm(directions, dim=-1, keepdim=True)
+        rays_o = torch.zeros_like(directions)
+    else:
+        m = torch.from_numpy(np.asarray(c2w)[:3, :4]).float()
+        rays_d = directions @ m[:, :3].T
+        rays_d = rays_d / torch.norm(rays_d, dim=-1, keepdim=True)
+        rays_o = m[:, 3].expand(rays_d.shape)
+    rays_d, rays_o = rays_d.reshape(-1, 3), rays_o.reshape(-1, 3)
+    one = torch.ones_like(rays_o[:, :1])
+    return torch.cat([rays_o, rays_d, near * one, far * one, idx * one], dim=1)
+
+
+def knn1(ref, query):
+    """k = 1 brute force with the wheel's semantics (knn_cuda/csrc/cuda/knn.cu:29-183, __init__.py:42-46):
+    Euclidean distance and 0-based index of the nearest reference point, FIRST minimum on ties.
+    PARITY UNPINNED against the wheel itself (CUDA only, cannot run here); exact by construction."""
+    d2 = ((query[:, None, :].double() - ref[None, :, :].double()) ** 2).sum(-1)
+    ind = torch.argmin(d2, dim=1)              # first minimum
+    return torch.sqrt(d2.gather(1, ind[:, None])).float(), ind[:, None]

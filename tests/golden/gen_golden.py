@@ -261,6 +261,26 @@ def unit_trainer_glue():
          in_delta=np.float64(1.0 / 128), out_alphas=alphas, out_nof_xyz=out_xyz)
 
 
+def unit_camera():
+    """utils/camera.py imported as-is (cv2 is only used by get_valid_rays_mask; a stub module satisfies
+    the import). Camera.make_rays for two poses + camera-space rays."""
+    import types
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+    from utils.camera import Camera, gen_rays, convert_AABB_to_verts
+    H, W = 24, 40
+    K = np.array([[55.5, 0, 19.25], [0, 57.0, 12.5], [0, 0, 1]], dtype=np.float64)
+    cam = Camera((H, W), K)
+    th = 0.7
+    c2w = np.array([[np.cos(th), 0.1, np.sin(th), 0.3], [0.05, 0.99, -0.1, -0.2],
+                    [-np.sin(th), 0.08, np.cos(th), 2.5], [0, 0, 0, 1]], dtype=np.float64)
+    cam.c2w = c2w
+    verts = convert_AABB_to_verts(np.array([[-0.6, -0.9, -0.4], [0.5, 0.8, 0.45]]))
+    rays = cam.make_rays(verts, 0.375)
+    o_cam, d_cam = gen_rays(cam.directions, None)
+    save("u_camera", in_K=K, in_c2w=c2w, in_aabb_verts=verts, in_HW=np.array([H, W]), in_idx=np.float64(0.375),
+         out_rays=rays, out_dirs_cam=d_cam, out_directions=cam.directions)
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for name in sorted(RENDER_CASES):
@@ -271,3 +291,4 @@ if __name__ == "__main__":
         unit_networks()
         unit_sample_pdf()
         unit_trainer_glue()
+        unit_camera()

@@ -480,3 +480,47 @@ def test_fused_point_query(M, R):
     assert relerr(canon, ocanon) <= TOL
     assert relerr(sig, osig) <= TOL
     assert relerr(sig0, osig0) <= TOL
+
+
+def test_make_rays_vs_golden(M):
+    from moco_flow_amd import camera
+    g = load_golden("u_camera")
+    H, W = [int(v) for v in g["in_HW"]]
+    K, c2w = g["in_K"], g["in_c2w"]
+    near, far = camera.near_far_from_aabb(g["in_aabb_verts"], c2w)
+    rays = camera.make_rays(H, W, K[0][0], (K[0][2], K[1][2]), c2w, near, far, float(g["in_idx"]))
+    assert rays.shape == (H * W, 9) and rays.is_cuda
+    assert relerr(rays, g["out_rays"]) <= 1e-6
+    assert torch.equal(rays[:, 6:9].cpu(), torch.from_numpy(g["out_rays"])[:, 6:9])     # near / far / idx columns
+    cam = camera.make_rays(H, W, K[0][0], (K[0][2], K[1][2]), None, 0.0, 1.0, 0.0)
+    assert relerr(cam[:, 3:6], g["out_dirs_cam"]) <= 1e-6
+    assert float(cam[:, :3].abs().max()) == 0.0
+    # the generated rays feed the fused pass directly (no host round trip)
+    embs, nerfs, kw = build_case(M, RENDER_CASES["r_nerf_dir_dense"], 5, device="cuda")
+    with torch.no_grad():
+        out = M.render_rays(rays, None, embs, nerfs, **kw)
+    assert out["rgb_coarse"].shape == (H * W, 3)
+
+
+def test_knn1_vs_oracle(M, R):
+    from moco_flow_amd.knn import KNN
+    torch.manual_seed(3)
+    V, Q = 6890, 20000                      # SMPL vertex count, 2 x N_sampled of the joint stage
+    ref = torch.randn(V, 3) * 0.5
+    ref[100] = ref[37]                      # an exact duplicate: the first index must win
+    query = torch.cat([torch.rand(Q // 2, 3) * 3 - 1.5, ref[torch.randint(V, (Q // 2,))] + 0.05 * torch.randn(Q // 2, 3)])
+    query[5] = ref[100]
+    d, i = KNN(k=1, transpose_mode=True)(ref[None].cuda(), query[None].cuda())
+    assert d.shape == (1, Q, 1) and i.shape == (1, Q, 1) and i.dtype == torch.int64
+    od, oi = R.knn1(ref, query)
+    same = i[0].cpu() == oi
+    # fp32 distances may tie-break differently from the fp64 oracle on near-equidistant pairs only
+    assert float(same.float().mean()) > 0.9995
+    assert int(i[0, 5, 0]) == 37
+    bad = ~same.view(-1)
+    if bool(bad.any()):
+        alt = (query[bad] - ref[i[0].cpu().view(-1)[bad]]).norm(dim=1)
+        assert relerr(alt, od.view(-1)[bad]) <= 1e-5
+    assert relerr(d[0], od) <= 1e-5
+    with pytest.raises(NotImplementedError):
+        KNN(k=2, transpose_mode=True)

@@ -108,3 +108,25 @@ def test_error_conventions():
         sd = synth.nerf_state(1, D=2, W=32, in_channels_xyz=33, skips=(), extra_feat_type="latent_code",
                               extra_feat_dim=4)
         R.NeRF(2, 32, 33, [], "latent_code", 4, state=sd)(torch.zeros(2, 37))
+
+
+def test_camera_vectors():
+    g = load_golden("u_camera")
+    H, W = [int(v) for v in g["in_HW"]]
+    K, c2w = g["in_K"], g["in_c2w"]
+    d = np.sqrt(np.sum((g["in_aabb_verts"] - c2w[:3, 3]) ** 2, axis=-1))
+    rays = R.make_rays(H, W, [K[0][0], K[1][1]], [K[0][2], K[1][2]], c2w, min(d), max(d), float(g["in_idx"]))
+    assert rays.shape == (H * W, 9)
+    assert relerr(rays, g["out_rays"]) <= TOL
+    assert torch.equal(R.gen_ray_directions(H, W, [K[0][0], K[1][1]], [K[0][2], K[1][2]]),
+                       torch.from_numpy(g["out_directions"]))
+    cam = R.make_rays(H, W, [K[0][0]], [K[0][2], K[1][2]], None, 0.0, 1.0, 0.0)
+    assert relerr(cam[:, 3:6], g["out_dirs_cam"]) <= TOL
+
+
+def test_knn1_semantics():
+    ref = torch.tensor([[0., 0, 0], [1, 0, 0], [1, 0, 0], [0, 2, 0]])
+    q = torch.tensor([[0.9, 0, 0], [0, 0.9, 0], [0, 1.1, 0], [5, 5, 5]])
+    d, i = R.knn1(ref, q)
+    assert i.view(-1).tolist() == [1, 0, 3, 3]          # first minimum on the duplicated point
+    assert relerr(d.view(-1), torch.tensor([0.1, 0.9, 0.9, (25 + 9 + 25) ** 0.5])) <= 1e-6
