@@ -12,10 +12,10 @@ from .losses import MSELoss
 from .nerf import NeRF
 from .nof import NoF
 from .points import query_sigma
-from .rendering import render_rays, resample_merge, sample_pdf, set_precision
+from .rendering import render_rays, resample_merge, sample_pdf, set_precision, set_train_forward
 
 __all__ = ["Embedding", "NeRF", "NoF", "get_model", "get_loss", "render_rays", "sample_pdf",
-           "resample_merge", "set_precision", "query_sigma", "MSELoss"]
+           "resample_merge", "set_precision", "set_train_forward", "query_sigma", "MSELoss"]
 
 
 def get_model(model_config):

@@ -30,6 +30,22 @@ def set_precision(p: str):
     PRECISION = p
 
 
+# What runs when gradients are requested (training):
+#   "hip"   (default) forward values from the fused HIP kernels, backward = differentiable recompute
+#           (autograd.py). Every number a caller sees comes from the kernels; costs one extra forward.
+#   "torch" the differentiable PyTorch-ROCm device path is the forward too (no duplicate work):
+#           reference-speed training until the fused HIP backward lands. The
+#           resampling still runs in the HIP kernel. Inference (no_grad) is always the HIP path.
+TRAIN_FORWARD = "hip"
+
+
+def set_train_forward(mode: str):
+    global TRAIN_FORWARD
+    if mode not in ("hip", "torch"):
+        raise ValueError(f"train forward must be 'hip' or 'torch', got {mode!r}")
+    TRAIN_FORWARD = mode
+
+
 # Draw torch.randn(N,S) in every pass even when noise_std == 0, as the reference does
 # (rendering.py:166), so that the device RNG stream advances identically.
 STRICT_RNG = True
@@ -254,6 +270,11 @@ def render_rays(rays,
     coarse_sigma_only = bool(need_fine and test_time)                  # rendering.py:290-294
     want_planes = need_fine or loc or glob or grad or _capture is not None
     noise_c = draw_noise((N, S), "noise_coarse")
+    if grad and N > 0 and TRAIN_FORWARD == "torch":
+        return _torch_training_render(rays, background, nerf_embeddings, nerf_models, nof_embeddings,
+                                      nof_models if use_nof else None, loc, glob, nerf_activate_type,
+                                      coarse_sigma_only, z_vals, noise_c, N_importance, perturb == 0,
+                                      lambda: draw_noise((N, S + N_importance), "noise_fine"), _rng.get("u"))
     c = _render_pass(rays, background, z_vals, None if z_vals is not None else z_steps, use_disp,
                      noise_c, act, nerf_models[0], nerf_embeddings,
                      nof_models if use_nof else None, nof_embeddings, loc, glob, coarse_sigma_only, want_planes)
@@ -293,6 +314,36 @@ def render_rays(rays,
                                   coarse_sigma_only, z_vals, noise_c, c["alphas"],
                                   (z_all, noise_f, f["alphas"]) if need_fine else None)
     return result
+
+
+def _torch_training_render(rays, background, nerf_embs, nerf_models, nof_embs, nof_models, loc, glob, activation,
+                           coarse_sigma_only, z_c, noise_c, n_importance, det, draw_noise_f, u):
+    """TRAIN_FORWARD == "torch": both passes with differentiable device ops (autograd.render_pass);
+    only the (detached) hierarchical resample runs in the HIP kernel."""
+    result = {}
+
+    def one(tag, nerf, z, noise, sigma_only):
+        r = A.render_pass(rays, background, z, noise, activation, nerf, nerf_embs, nof_models, nof_embs,
+                          loc, glob, sigma_only, None)
+        if not sigma_only:
+            result[f"rgb_{tag}"], result[f"depth_{tag}"] = r["rgb"], r["depth"]
+        result[f"opacity_{tag}"] = r["opacity"]
+        if loc or glob:
+            mask = _mask_of(r["alphas"].detach())
+            if loc:
+                result[f"nof_local_disp_{tag}"] = torch.mean(r["disp_local_full"][mask], dim=1)
+            if glob:
+                result[f"nof_global_disp_{tag}"] = torch.mean(r["disp_global_full"][mask], dim=1)
+        return r
+
+    c = one("coarse", nerf_models[0], z_c, noise_c, coarse_sigma_only)
+    if n_importance > 0:
+        z_all = resample_merge(z_c, c["weights"].detach(), n_importance, det=det, u=u)
+        one("fine", nerf_models[1], z_all, draw_noise_f(), False)
+    # key order of the reference: coarse rgb/depth/opacity, coarse consensus, fine ..., fine consensus
+    order = ["rgb_coarse", "depth_coarse", "opacity_coarse", "nof_local_disp_coarse", "nof_global_disp_coarse",
+             "rgb_fine", "depth_fine", "opacity_fine", "nof_local_disp_fine", "nof_global_disp_fine"]
+    return {k: result[k] for k in order if k in result}
 
 
 def _mask_of(alphas):

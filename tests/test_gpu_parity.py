@@ -554,3 +554,36 @@ def test_training_loop_converges(M):
     with torch.no_grad():                       # the re-packed weights are what inference now uses
         res = M.render_rays(rays, bg, embs, nerfs, **kw)
     assert float(crit(res, target)) < losses[0]
+
+
+def test_train_forward_torch_mode_matches_hip_mode(M):
+    """TRAIN_FORWARD="torch" (reference-speed training path) returns the same values and gradients as the
+    default mode (HIP forward + recompute backward), with the same keys in the same order."""
+    from moco_flow_amd import rendering
+    c = dict(RENDER_CASES["r_moco_global_fine"])
+    seed = int(load_golden("r_moco_global_fine")["meta_seed"])
+    embs, nerfs, kw = build_case(M, c, seed, device="cuda")
+    rays, bg = case_inputs(c, seed, n=40)
+    rays, bg = rays.cuda(), bg.cuda()
+    nets = list(nerfs) + list(kw["nof_models"])
+
+    def run():
+        for m in nets:
+            m.zero_grad(set_to_none=True)
+        res = M.render_rays(rays, bg, embs, nerfs, **kw)
+        loss = sum(v.mean() for v in res.values())
+        loss.backward()
+        return res, [p.grad.clone() for m in nets for p in m.parameters()]
+
+    a, ga = run()
+    try:
+        rendering.set_train_forward("torch")
+        b, gb = run()
+    finally:
+        rendering.set_train_forward("hip")
+    assert list(a.keys()) == list(b.keys())
+    for k in a:
+        if a[k].shape == b[k].shape:
+            assert relerr(a[k], b[k]) <= (2e-3 if "fine" in k else TOL), k     # fine: resample conditioning
+    for x, y in zip(ga, gb):
+        assert relerr(x, y) <= 5e-3
