@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 2
+#define MF_ABI_VERSION 3
 
 enum {
   MF_OK = 0,
@@ -174,6 +174,14 @@ typedef struct mf_render_args {
   float* disp_local;                /* (N,S) mean_c |xyz - recon|         (rendering.py:310-311) */
   float* disp_global;               /* (N,S) mean_c |xyz - chained_recon| (rendering.py:313-314) */
   int32_t precision;                /* MF_PREC_*: must match how every *_packed buffer was packed      */
+  /* training forward (MF_PREC_F32 only; all optional): what the backward needs, written once by the
+   * fused kernel instead of being recomputed.  dump_acts (N*S, dump_stride): per sample the NeRF's
+   * post-activation layer outputs in natural feature order [h_0 | ... | h_{D-1} | xyz_encoding_final |
+   * extra_encoding] (dump_stride >= (D+1)*W + W/2 floats); dump_rgbsigma (N*S, 4): per-sample rgb (after
+   * the sigmoid) and raw sigma; dump_xyz (N*S, 3): the point fed to the NeRF (canonical under NoF). */
+  float* dump_acts; int64_t dump_stride;
+  float* dump_rgbsigma;
+  float* dump_xyz;
 } mf_render_args;
 
 int32_t mf_render_pass(const mf_render_args* a, void* stream);

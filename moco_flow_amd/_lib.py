@@ -16,7 +16,7 @@ MF_EXTRA_NONE, MF_EXTRA_IND, MF_EXTRA_DIR = 0, 1, 2
 MF_ACT_RELU, MF_ACT_SOFTPLUS = 0, 1
 MF_F_SIGMA_ONLY, MF_F_CHAIN_LOCAL, MF_F_CHAIN_GLOBAL = 1, 2, 4
 MF_PREC_F32, MF_PREC_BF16 = 0, 1
-MF_ABI_VERSION = 2
+MF_ABI_VERSION = 3
 
 LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmocoflow_hip.so")
 
@@ -54,7 +54,8 @@ class mf_render_args(C.Structure):
                 ("nof_fw", C.POINTER(mf_nof_desc)), ("nof_fw_packed", _fp),
                 ("nof_emb_xyz", mf_embedding), ("nof_emb_ind", mf_embedding),
                 ("rgb", _fp), ("depth", _fp), ("opacity", _fp), ("weights", _fp), ("alphas", _fp),
-                ("disp_local", _fp), ("disp_global", _fp), ("precision", C.c_int32)]
+                ("disp_local", _fp), ("disp_global", _fp), ("precision", C.c_int32),
+                ("dump_acts", _fp), ("dump_stride", C.c_int64), ("dump_rgbsigma", _fp), ("dump_xyz", _fp)]
 
 
 # every symbol include/mocoflow_hip.h declares: (restype, argtypes)

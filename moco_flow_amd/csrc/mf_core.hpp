@@ -440,10 +440,13 @@ struct NextLayer {
 };
 
 // One trunk layer: act <- relu?(W_l [emb ; act] + b_l), NK/2 panels of two tiles.
-template <int NK, int EMB, bool BF16>
+// `dump_row` (training forward only, DUMP instantiations): this lane's sample row of the activation
+// dump, already offset to this layer; the layer's post-activation outputs are stored there in
+// natural feature order (the dW GEMMs of the backward read them).  nullptr: nothing stored.
+template <int NK, int EMB, bool BF16, bool DUMP = false>
 MF_D void trunk_layer(const NetDev& net, int layer, typename ActT<BF16>::T (&act)[ActLen<BF16, NK>::N],
                       const float (&emb)[EMB], Stream& st, CarryT<Pipe<BF16>::PD>& carry, const LaneId& id,
-                      const NextLayer& nxt) {
+                      const NextLayer& nxt, float* dump_row = nullptr) {
   constexpr int NP = NK / 2;
   const int has_emb = (net.L.emb_mask >> layer) & 1;
   const int mode = (has_emb ? 1 : 0) | (layer > 0 ? 2 : 0);
@@ -469,6 +472,12 @@ MF_D void trunk_layer(const NetDev& net, int layer, typename ActT<BF16>::T (&act
     } else {
       out[2 * t] = E;
       out[2 * t + 1] = O;
+    }
+    if constexpr (DUMP) {
+      if (dump_row) {
+        *reinterpret_cast<f32x4*>(dump_row + 32 * t + 4 * id.g) = E;
+        *reinterpret_cast<f32x4*>(dump_row + 32 * t + 16 + 4 * id.g) = O;
+      }
     }
     st.advance();
   }

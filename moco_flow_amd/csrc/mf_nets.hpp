@@ -39,10 +39,11 @@ MF_D void start_program(const NetDev& n, Stream& st, CarryT<PD>& carry, const La
 }
 
 // extra_encoding (nerf.py:98): (W/2) outputs from [final(W) ; extra block], ReLU.
-template <int NK, bool BF16>
+template <int NK, bool BF16, bool DUMP = false>
 MF_D void extra_layer(const NetDev& net, const typename ActT<BF16>::T (&act)[ActLen<BF16, NK>::N],
                       const float (&ext)[kStepsExtraMax], typename ActT<BF16>::T (&out)[ActLen<BF16, NK / 2>::N],
-                      Stream& st, CarryT<Pipe<BF16>::PD>& carry, const LaneId& id, const NextLayer& nxt) {
+                      Stream& st, CarryT<Pipe<BF16>::PD>& carry, const LaneId& id, const NextLayer& nxt,
+                      float* dump_row = nullptr) {
   constexpr int NPO = NK / 4;                      // panels of the (W/2)-wide layer
   constexpr int QH = ActLen<BF16, NK>::N;          // hidden batches in front of the extra block
   const int groups = extra_groups(net.L);
@@ -82,16 +83,23 @@ MF_D void extra_layer(const NetDev& net, const typename ActT<BF16>::T (&act)[Act
       out[2 * t] = E;
       out[2 * t + 1] = O;
     }
+    if constexpr (DUMP) {
+      if (dump_row) {
+        *reinterpret_cast<f32x4*>(dump_row + 32 * t + 4 * id.g) = E;
+        *reinterpret_cast<f32x4*>(dump_row + 32 * t + 16 + 4 * id.g) = O;
+      }
+    }
     st.advance();
   }
 }
 
 // Canonical NeRF on this wave's 16 samples.  `follow`: the first layer of whatever the panel
 // program evaluates after this network (the stream jumps there behind the last panel used).
-template <int NK, bool BF16>
+// DUMP (training forward): `dump_row` = this lane's sample row [h_0 .. h_{D-1} | final | extra] (nullptr: skip).
+template <int NK, bool BF16, bool DUMP = false>
 MF_D void nerf_eval(const NetDev& net, const float (&embx)[kStepsNerfXyz], const float (&ext)[kStepsExtraMax],
                     bool sigma_only, Stream& st, CarryT<Pipe<BF16>::PD>& carry, const LaneId& id,
-                    const NextLayer& follow, float& sigma, float (&rgb)[3]) {
+                    const NextLayer& follow, float& sigma, float (&rgb)[3], float* dump_row = nullptr) {
   typename ActT<BF16>::T act[ActLen<BF16, NK>::N];
 #pragma unroll
   for (int t = 0; t < ActLen<BF16, NK>::N; ++t)
@@ -100,7 +108,8 @@ MF_D void nerf_eval(const NetDev& net, const float (&embx)[kStepsNerfXyz], const
   const int D = net.L.n_trunk - 1;
   for (int l = 0; l < D; ++l) {
     const bool last = sigma_only && l == D - 1;
-    trunk_layer<NK, kStepsNerfXyz, BF16>(net, l, act, embx, st, carry, id, last ? follow : next_trunk(net, l + 1));
+    trunk_layer<NK, kStepsNerfXyz, BF16, DUMP>(net, l, act, embx, st, carry, id, last ? follow : next_trunk(net, l + 1),
+                                               dump_row ? dump_row + l * net.L.W : nullptr);
   }
   float sg[1];
   valu_head(act, net.res_lds + net.L.off_head_w * 4, net.L.W, net.res_lds + net.L.off_head_b * 4, id.g, sg);
@@ -110,9 +119,10 @@ MF_D void nerf_eval(const NetDev& net, const float (&embx)[kStepsNerfXyz], const
   ex.groups = extra_groups(net.L);
   ex.jump = nullptr;
   ex.bias_off = net.res_lds + net.L.off_bias_extra * 4;
-  trunk_layer<NK, kStepsNerfXyz, BF16>(net, D, act, embx, st, carry, id, ex);            // xyz_encoding_final
+  trunk_layer<NK, kStepsNerfXyz, BF16, DUMP>(net, D, act, embx, st, carry, id, ex,          // xyz_encoding_final
+                                             dump_row ? dump_row + D * net.L.W : nullptr);
   typename ActT<BF16>::T e[ActLen<BF16, NK / 2>::N];
-  extra_layer<NK, BF16>(net, act, ext, e, st, carry, id, follow);
+  extra_layer<NK, BF16, DUMP>(net, act, ext, e, st, carry, id, follow, dump_row ? dump_row + (D + 1) * net.L.W : nullptr);
   float o[3];
   valu_head(e, net.res_lds + net.L.off_rgb_w * 4, net.L.W / 2, net.res_lds + net.L.off_rgb_b * 4, id.g, o);
 #pragma unroll

@@ -40,6 +40,7 @@ struct RenderParams {
   long long n_groups;
   uint32_t ring_off, buf_bytes, sbuf_off, zbuf_off;
   int dbg;
+  float* dump_acts; long long dump_stride; float* dump_rgbsigma; float* dump_xyz;   // training forward
 };
 
 // inclusive product scan across the 64 lanes of a wave
@@ -57,7 +58,7 @@ MF_D float wave_sum(float v) {
   return v;
 }
 
-template <bool MOCO, bool BF16>
+template <bool MOCO, bool BF16, bool DUMP>
 __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
   const LaneId id;
   const NetDev nerf = p.nerf;
@@ -162,10 +163,18 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
         }
       }
       float sigma, rgb[3] = {0.f, 0.f, 0.f};
-      nerf_eval<16, BF16>(nerf, embx, ext, sigma_only, st, carry, id, prog_first, sigma, rgb);
+      float* dump_row = nullptr;
+      if constexpr (DUMP) {
+        if (valid && p.dump_acts) dump_row = p.dump_acts + (ray * S + si) * p.dump_stride;
+      }
+      nerf_eval<16, BF16, DUMP>(nerf, embx, ext, sigma_only, st, carry, id, prog_first, sigma, rgb, dump_row);
       if (valid && id.g == 0) {
         sbuf[srel] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
         zbuf[srel] = z;
+        if constexpr (DUMP) {
+          if (p.dump_rgbsigma) *reinterpret_cast<float4*>(p.dump_rgbsigma + (ray * S + si) * 4) = make_float4(rgb[0], rgb[1], rgb[2], sigma);
+          if (p.dump_xyz) { float* q = p.dump_xyz + (ray * S + si) * 3; q[0] = xin[0]; q[1] = xin[1]; q[2] = xin[2]; }
+        }
       }
     }
     __syncthreads();
@@ -338,18 +347,17 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
 
   const int grid = (int)(p.n_groups < device_cus() ? p.n_groups : device_cus());
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const void* fn = moco ? (bf16 ? reinterpret_cast<const void*>(render_kernel<true, true>)
-                                : reinterpret_cast<const void*>(render_kernel<true, false>))
-                        : (bf16 ? reinterpret_cast<const void*>(render_kernel<false, true>)
-                                : reinterpret_cast<const void*>(render_kernel<false, false>));
-  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  const bool dump = a->dump_acts || a->dump_rgbsigma || a->dump_xyz;
+  if (dump && bf16) return fail(MF_E_UNSUPPORTED, "mf_render_pass: the activation dump (training forward) is fp32 only");
+  if (a->dump_acts && a->dump_stride < (int64_t)p.nerf.L.n_trunk * p.nerf.L.W + p.nerf.L.W / 2)
+    return fail(MF_E_INVALID, "mf_render_pass: dump_stride %lld too small", (long long)a->dump_stride);
+  p.dump_acts = a->dump_acts; p.dump_stride = a->dump_stride; p.dump_rgbsigma = a->dump_rgbsigma; p.dump_xyz = a->dump_xyz;
+  void (*kern)(RenderParams) =
+      dump ? (moco ? render_kernel<true, false, true> : render_kernel<false, false, true>)
+           : (moco ? (bf16 ? render_kernel<true, true, false> : render_kernel<true, false, false>)
+                   : (bf16 ? render_kernel<false, true, false> : render_kernel<false, false, false>));
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);
-  if (moco) {
-    if (bf16) hipLaunchKernelGGL((render_kernel<true, true>), dim3(grid), dim3(kThreads), lds, st, p);
-    else hipLaunchKernelGGL((render_kernel<true, false>), dim3(grid), dim3(kThreads), lds, st, p);
-  } else {
-    if (bf16) hipLaunchKernelGGL((render_kernel<false, true>), dim3(grid), dim3(kThreads), lds, st, p);
-    else hipLaunchKernelGGL((render_kernel<false, false>), dim3(grid), dim3(kThreads), lds, st, p);
-  }
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, p);
   return check_launch("mf_render_pass");
 }

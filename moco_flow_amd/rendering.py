@@ -56,7 +56,7 @@ def _emb_desc(e):
 
 
 def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation, nerf, nerf_embs,
-                 nof_models, nof_embs, chain_local, chain_global, sigma_only, want_planes):
+                 nof_models, nof_embs, chain_local, chain_global, sigma_only, want_planes, dump=False):
     """One mf_render_pass call. Returns dict of fresh tensors."""
     dev = rays.device
     N = rays.shape[0]
@@ -110,6 +110,12 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
     a.alphas = alloc("alphas", (N, S), want_planes)
     a.disp_local = alloc("disp_local", (N, S), chain_local)
     a.disp_global = alloc("disp_global", (N, S), chain_global)
+    if dump:                                     # training forward: what the explicit backward reads
+        stride = (nerf.D + 1) * nerf.W + nerf.W // 2
+        a.dump_acts = alloc("acts", (N * S, stride), not sigma_only)
+        a.dump_stride = stride
+        a.dump_rgbsigma = alloc("rgbsig", (N * S, 4))
+        a.dump_xyz = alloc("xyz_in", (N * S, 3))
     with torch.cuda.device(dev):
         L.check(L.lib().mf_render_pass(C.byref(a), L.current_stream(dev)), "mf_render_pass")
     del keep
@@ -277,7 +283,8 @@ def render_rays(rays,
                                       lambda: draw_noise((N, S + N_importance), "noise_fine"), _rng.get("u"))
     c = _render_pass(rays, background, z_vals, None if z_vals is not None else z_steps, use_disp,
                      noise_c, act, nerf_models[0], nerf_embeddings,
-                     nof_models if use_nof else None, nof_embeddings, loc, glob, coarse_sigma_only, want_planes)
+                     nof_models if use_nof else None, nof_embeddings, loc, glob, coarse_sigma_only, want_planes,
+                     dump=grad and PRECISION == "f32" and not coarse_sigma_only)
     if coarse_sigma_only:
         result = {'opacity_coarse': c["opacity"]}
     else:
@@ -296,7 +303,8 @@ def render_rays(rays,
         noise_f = draw_noise((N, S + N_importance), "noise_fine")
         f = _render_pass(rays, background, z_all, None, use_disp, noise_f, act,
                          nerf_models[1], nerf_embeddings, nof_models if use_nof else None, nof_embeddings,
-                         loc, glob, False, loc or glob or grad or _capture is not None)
+                         loc, glob, False, loc or glob or grad or _capture is not None,
+                         dump=grad and PRECISION == "f32")
         if _capture is not None:
             _capture.update(z_fine=z_all, weights_fine=f.get("weights"), alphas_fine=f.get("alphas"))
         result['rgb_fine'] = f["rgb"]
@@ -308,7 +316,11 @@ def render_rays(rays,
                 result['nof_local_disp_fine'] = la
             if glob:
                 result['nof_global_disp_fine'] = ga
-    if grad and N > 0:
+    if grad and N > 0 and "acts" in c and (not need_fine or "acts" in f):
+        result = _attach_explicit(result, rays, background, nerf_embeddings, nerf_models, nof_embeddings,
+                                  nof_models if use_nof else None, loc, glob, nerf_activate_type,
+                                  (c, z_vals, noise_c), (f, z_all, noise_f) if need_fine else None)
+    elif grad and N > 0:
         result = _attach_backward(result, rays, background, all_models, nerf_embeddings, nerf_models,
                                   nof_embeddings, nof_models if use_nof else None, loc, glob, nerf_activate_type,
                                   coarse_sigma_only, z_vals, noise_c, c["alphas"],
@@ -344,6 +356,59 @@ def _torch_training_render(rays, background, nerf_embs, nerf_models, nof_embs, n
     order = ["rgb_coarse", "depth_coarse", "opacity_coarse", "nof_local_disp_coarse", "nof_global_disp_coarse",
              "rgb_fine", "depth_fine", "opacity_fine", "nof_local_disp_fine", "nof_global_disp_fine"]
     return {k: result[k] for k in order if k in result}
+
+
+def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs, nof_models, loc, glob,
+                     activation, coarse, fine):
+    """Training graph on top of the fused forward (TRAIN_FORWARD == "hip", fp32): values are the HIP
+    kernels' outputs; gradients flow through
+      * autograd.NerfSamples -- explicit library-GEMM backward of the NeRF over the kernel's activation
+        dump (no recompute of the 12-layer MLP),
+      * a differentiable composite on the dumped per-sample (rgb, sigma) ((N,S) elementwise only),
+      * a differentiable recompute of the (9x smaller) NoF chains where they exist.
+    Each returned tensor is  hip_value + (torch_value - torch_value.detach())."""
+    rays_o, rays_d, ind = rays[:, 0:3], rays[:, 3:6], rays[:, 8:9]
+    out = {}
+
+    def one(tag, nerf, pack):
+        p, z, noise = pack
+        N, S = z.shape
+        xyz = rays_o.unsqueeze(1) + rays_d.unsqueeze(1) * z.unsqueeze(2)
+        mask = _mask_of(p["alphas"]) if (loc or glob) else None
+        xin = p["xyz_in"]
+        if nof_models is not None:
+            bw = nof_models[0]
+            canon = A._nof_points(xyz, ind, nof_embs, bw)
+            if loc:
+                fw = nof_models[1]
+                recon = A._nof_points(canon, ind, nof_embs, fw)
+                out[f"nof_local_disp_{tag}"] = torch.mean(torch.abs(xyz - recon)[mask], dim=1)
+            if glob:
+                cind = rays[:, 9:10]
+                a_ = A._nof_points(canon, cind, nof_embs, fw)
+                b_ = A._nof_points(a_, cind, nof_embs, bw)
+                out[f"nof_global_disp_{tag}"] = torch.mean(torch.abs(xyz - A._nof_points(b_, ind, nof_embs, fw))[mask], dim=1)
+            xin = canon.reshape(-1, 3)
+        with torch.no_grad():
+            emb_in = A._pad_to(A.embed(nerf_embs[0], p["xyz_in"]), nerf.in_channels_xyz)
+            extra_in = None
+            if nerf.extra_feat_type == "ind":
+                extra_in = A._pad_to(torch.repeat_interleave(A.embed(nerf_embs[1], ind), S, dim=0), nerf.extra_feat_dim)
+            elif nerf.extra_feat_type == "dir":
+                extra_in = A._pad_to(torch.repeat_interleave(A.embed(nerf_embs[2], rays_d), S, dim=0), nerf.extra_feat_dim)
+        rgbsig = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, nerf_embs[0], xin,
+                                     *nerf.parameters())
+        comp = A.composite_from_samples(rgbsig, z, rays_d, noise, activation, background, False)
+        out[f"rgb_{tag}"], out[f"depth_{tag}"], out[f"opacity_{tag}"] = comp["rgb"], comp["depth"], comp["opacity"]
+
+    one("coarse", nerf_models[0], coarse)
+    if fine is not None:
+        one("fine", nerf_models[1], fine)
+    final = {}
+    for k, v in result.items():
+        t = out[k]
+        final[k] = v.detach() + (t - t.detach())
+    return final
 
 
 def _mask_of(alphas):
