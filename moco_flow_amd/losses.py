@@ -1,15 +1,30 @@
-"""Result-dict losses of /root/reference/models/losses.py (:4-26): plain torch reductions
-over the (N,3) outputs of the fused pass -- 3 floats per ray, not a kernel."""
+"""Photometric loss over the result dict of ``render_rays`` (reference: models/losses.py:4-26).
+
+The value is mean((rgb_coarse - target)^2) plus, when a fine pass ran, the same term on
+``rgb_fine`` -- two reductions over 3 floats per ray, plain device ops and not a kernel of the hot
+path.  The sharded variant that keeps the global mean exact under ragged ray
+shards lives in ``dist.loss_partials`` / ``dist.reduce_loss``.
+"""
+from __future__ import annotations
+
+from typing import Mapping
+
+import torch
+import torch.nn.functional as F
 from torch import nn
+
+_PASSES = ("coarse", "fine")
 
 
 class MSELoss(nn.Module):
-    def __init__(self):
-        super().__init__()
-        self.loss = nn.MSELoss(reduction='mean')
+    """Sum over the rendered passes of the mean squared colour error."""
 
-    def forward(self, inputs, targets):
-        loss = self.loss(inputs['rgb_coarse'], targets)
-        if 'rgb_fine' in inputs:
-            loss = loss + self.loss(inputs['rgb_fine'], targets)
-        return loss
+    def forward(self, inputs: Mapping[str, torch.Tensor], targets: torch.Tensor) -> torch.Tensor:
+        terms = [F.mse_loss(inputs[f"rgb_{p}"], targets, reduction="mean")
+                 for p in _PASSES if f"rgb_{p}" in inputs]
+        if len(terms) == 0 or "rgb_coarse" not in inputs:
+            raise KeyError("rgb_coarse")
+        total = terms[0]
+        for t in terms[1:]:
+            total = total + t
+        return total
