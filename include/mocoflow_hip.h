@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 3
+#define MF_ABI_VERSION 4
 
 enum {
   MF_OK = 0,
@@ -122,6 +122,24 @@ int32_t mf_nerf_forward(const mf_nerf_desc* d, const void* packed, const float* 
 /* NoF.forward, models/nof.py:55-85: inputs (B, in_channels_xyz+extra_feat_dim), xyz (B,3) -> (B,3). */
 int32_t mf_nof_forward(const mf_nof_desc* d, const void* packed, const float* inputs,
                        int64_t in_stride, const float* xyz, int64_t B, float* out, void* stream);
+
+/* ---- backward of NeRF.forward over the training forward's dump (ABI v4) -------------------
+ * Replaces the autograd graph torch records for models/nerf.py:78-102 under loss.backward()
+ * (trainer/base.py:188-197).  The input-gradient chain (nine W-wide contractions per sample) runs
+ * on the same register-resident MFMA core as the forward, on the transposed weights:
+ *   mf_nerf_bwd_packed_bytes / mf_nerf_pack_bwd : transposed fragment stream of a NeRF (fp32, W=256);
+ *     re-run whenever the parameters change.
+ *   mf_nerf_backward : g_out (P,4) = dL/d[rgb (after the sigmoid), sigma], acts (P,stride) and
+ *     rgbsigma (P,4) = mf_render_args.dump_acts / dump_rgbsigma of the forward ->
+ *       gpre  (round_up(P,128), stride): pre-activation gradients in the dump's layout
+ *             [d z_0 .. d z_{D-1} | d xyz_encoding_final | d extra_encoding]  (rows >= P are scratch)
+ *       ghead (P,4): [d rgb pre-sigmoid (3), d sigma]
+ *     The weight gradients are then plain GEMMs on (acts, gpre):  dW_l = gpre_l^T in_l,  db_l = sum gpre_l. */
+int64_t mf_nerf_bwd_packed_bytes(const mf_nerf_desc* d);
+int32_t mf_nerf_pack_bwd(const mf_nerf_desc* d, void* packed, void* stream);
+int32_t mf_nerf_backward(const mf_nerf_desc* d, const void* packed_bwd, int64_t P, const float* g_out,
+                         const float* acts, int64_t stride, const float* rgbsigma, float* gpre,
+                         float* ghead, void* stream);
 
 /* Fused point query: xyz (B,3) -> [backward NoF at image index ind] -> positional encoding -> NeRF
  * trunk -> raw sigma (B,), one launch.  Replaces the per-chunk module sequence forward_nof /

@@ -217,13 +217,42 @@ def embed_backward(emb, x, g_emb):
     return g
 
 
+NERF_BACKWARD = "hip"     # "hip": fused dX chain (mf_nerf_backward) + library dW GEMMs; "gemm": library GEMMs only
+
+
+def set_nerf_backward(kind: str) -> None:
+    global NERF_BACKWARD
+    if kind not in ("hip", "gemm"):
+        raise ValueError(f"nerf backward: {kind} not valid (hip | gemm)")
+    NERF_BACKWARD = kind
+
+
+def nerf_backward_hip(m, g_out, acts, rgbsig):
+    """mf_nerf_backward: (gpre (P,stride) in the dump's layout, ghead (P,4)) from dL/d[rgb, sigma]."""
+    import ctypes as C
+    from . import _lib as L
+    P, stride = acts.shape
+    desc, buf = m.packed_bwd()
+    dev = acts.device
+    g_out = g_out.contiguous().float()
+    gpre = torch.empty(((P + 127) // 128 * 128, stride), device=dev, dtype=torch.float32)
+    ghead = torch.empty((P, 4), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        L.check(L.lib().mf_nerf_backward(C.byref(desc), buf.data_ptr(), P, g_out.data_ptr(), acts.data_ptr(), stride,
+                                         rgbsig.data_ptr(), gpre.data_ptr(), ghead.data_ptr(),
+                                         L.current_stream(dev)), "mf_nerf_backward")
+    return gpre[:P], ghead
+
+
 class NerfSamples(torch.autograd.Function):
     """Per-sample (rgb, sigma) of the canonical NeRF as an autograd node whose forward IS the fused HIP
-    kernel's output (``rgbsig``, dumped) and whose backward is an explicit chain of library GEMMs
-    (PyTorch-ROCm matmul = rocBLAS/hipBLASLt) over the kernel's activation dump -- no forward
-    recompute, no autograd graph over the 12-layer MLP:
-        per layer   dW = g_pre^T @ input,  db = sum g_pre,  g_in = g_pre @ W,  g_pre = g ⊙ (h > 0).
-    Inputs that may need grad: the points ``xin`` (under NoF) and every NeRF parameter."""
+    kernel's output (``rgbsig``, dumped).  Backward, per layer
+        g_pre = g (.) (h > 0),   g_in = g_pre @ W,   dW = g_pre^T @ input,   db = sum g_pre:
+    the g_pre / g_in chain of all layers is ONE fused HIP launch over the kernel's activation dump
+    (mf_nerf_backward: the forward's register-resident MFMA core on the transposed weights); the dW
+    are plain library GEMMs (PyTorch-ROCm matmul = rocBLAS/hipBLASLt) on (dump, g_pre).  No forward
+    recompute, no autograd graph over the 12-layer MLP.  Inputs that may need grad: the points
+    ``xin`` (under NoF) and every NeRF parameter."""
 
     @staticmethod
     def forward(ctx, m, acts, rgbsig, emb_in, extra_in, emb_xyz, xin, *params):
@@ -239,55 +268,80 @@ class NerfSamples(torch.autograd.Function):
         rgbsig, xin = ctx.saved_tensors
         D, W = m.D, m.W
         names = [n for n, _ in m.named_parameters()]
-        plist = [p for _, p in m.named_parameters()]
+        req = {n: p.requires_grad for n, p in m.named_parameters()}
         grads = {n: None for n in names}
-
-        def want(n):
-            return dict(zip(names, plist))[n].requires_grad
-
-        def lin_grads(prefix, g_pre, x_in):
-            if want(prefix + ".weight"):
-                grads[prefix + ".weight"] = g_pre.t() @ x_in
-            if want(prefix + ".bias"):
-                grads[prefix + ".bias"] = g_pre.sum(0)
+        cin = m.in_channels_xyz
+        need_in = ctx.xin_grad
 
         with torch.no_grad():
             h = lambda l: acts[:, l * W:(l + 1) * W]
             f = acts[:, D * W:(D + 1) * W]
             e2 = acts[:, (D + 1) * W:(D + 1) * W + W // 2]
-            rgb = rgbsig[:, :3]
-            g_pre_rgb = g_out[:, :3] * rgb * (1 - rgb)
-            g_sigma = g_out[:, 3:4].contiguous()
-            lin_grads("rgb.0", g_pre_rgb, e2)
-            g_e2 = (g_pre_rgb @ m.rgb[0].weight) * (e2 > 0)
-            in_extra = f if extra is None else torch.cat([f, extra], -1)
-            lin_grads("extra_encoding.0", g_e2, in_extra)
-            g_f = g_e2 @ m.extra_encoding[0].weight[:, :W]
-            lin_grads("xyz_encoding_final", g_f, h(D - 1))
-            lin_grads("sigma", g_sigma, h(D - 1))
-            g_h = g_f @ m.xyz_encoding_final.weight + g_sigma @ m.sigma.weight
-            need_in = ctx.xin_grad
-            g_emb = torch.zeros_like(emb) if need_in else None
-            cin = m.in_channels_xyz
-            for l in range(D - 1, -1, -1):
-                g_pre = g_h * (h(l) > 0)
-                lin = getattr(m, f"xyz_encoding_{l+1}")[0]
-                if l == 0:
-                    x_in = emb
-                elif l in m.skips:
-                    x_in = torch.cat([emb, h(l - 1)], -1)
-                else:
-                    x_in = h(l - 1)
-                lin_grads(f"xyz_encoding_{l+1}.0", g_pre, x_in)
-                if l == 0:
-                    if need_in:
-                        g_emb += g_pre @ lin.weight
-                elif l in m.skips:
-                    if need_in:
-                        g_emb += g_pre @ lin.weight[:, :cin]
-                    g_h = g_pre @ lin.weight[:, cin:]
-                else:
-                    g_h = g_pre @ lin.weight
+            if NERF_BACKWARD == "hip" and acts.shape[0] > 0:
+                gpre, ghead = nerf_backward_hip(m, g_out, acts, rgbsig)
+                bias_sums = gpre.sum(0) if any(req[n] for n in names if n.endswith(".bias")) else None
+                gslot = lambda l: gpre[:, l * W:(l + 1) * W]
+
+                def lin_grads(prefix, g_pre, parts, b0=None):
+                    if req[prefix + ".weight"]:
+                        gt = g_pre.t()
+                        blocks = [gt @ x for x in parts]
+                        grads[prefix + ".weight"] = blocks[0] if len(blocks) == 1 else torch.cat(blocks, 1)
+                    if req[prefix + ".bias"]:
+                        grads[prefix + ".bias"] = g_pre.sum(0) if b0 is None else bias_sums[b0:b0 + g_pre.shape[1]].clone()
+
+                g_e2 = gpre[:, (D + 1) * W:(D + 1) * W + W // 2]
+                g_f = gslot(D)
+                lin_grads("rgb.0", ghead[:, :3], [e2])
+                lin_grads("sigma", ghead[:, 3:4], [h(D - 1)])
+                lin_grads("extra_encoding.0", g_e2, [f] if extra is None else [f, extra], (D + 1) * W)
+                lin_grads("xyz_encoding_final", g_f, [h(D - 1)], D * W)
+                g_emb = None
+                for l in range(D):
+                    lin = getattr(m, f"xyz_encoding_{l+1}")[0]
+                    parts = [emb] if l == 0 else ([emb, h(l - 1)] if l in m.skips else [h(l - 1)])
+                    lin_grads(f"xyz_encoding_{l+1}.0", gslot(l), parts, l * W)
+                    if need_in and (l == 0 or l in m.skips):
+                        t = gslot(l) @ lin.weight[:, :cin]
+                        g_emb = t if g_emb is None else g_emb + t
+            else:
+                def lin_grads(prefix, g_pre, x_in):
+                    if req[prefix + ".weight"]:
+                        grads[prefix + ".weight"] = g_pre.t() @ x_in
+                    if req[prefix + ".bias"]:
+                        grads[prefix + ".bias"] = g_pre.sum(0)
+
+                rgb = rgbsig[:, :3]
+                g_pre_rgb = g_out[:, :3] * rgb * (1 - rgb)
+                g_sigma = g_out[:, 3:4].contiguous()
+                lin_grads("rgb.0", g_pre_rgb, e2)
+                g_e2 = (g_pre_rgb @ m.rgb[0].weight) * (e2 > 0)
+                in_extra = f if extra is None else torch.cat([f, extra], -1)
+                lin_grads("extra_encoding.0", g_e2, in_extra)
+                g_f = g_e2 @ m.extra_encoding[0].weight[:, :W]
+                lin_grads("xyz_encoding_final", g_f, h(D - 1))
+                lin_grads("sigma", g_sigma, h(D - 1))
+                g_h = g_f @ m.xyz_encoding_final.weight + g_sigma @ m.sigma.weight
+                g_emb = torch.zeros_like(emb) if need_in else None
+                for l in range(D - 1, -1, -1):
+                    g_pre = g_h * (h(l) > 0)
+                    lin = getattr(m, f"xyz_encoding_{l+1}")[0]
+                    if l == 0:
+                        x_in = emb
+                    elif l in m.skips:
+                        x_in = torch.cat([emb, h(l - 1)], -1)
+                    else:
+                        x_in = h(l - 1)
+                    lin_grads(f"xyz_encoding_{l+1}.0", g_pre, x_in)
+                    if l == 0:
+                        if need_in:
+                            g_emb += g_pre @ lin.weight
+                    elif l in m.skips:
+                        if need_in:
+                            g_emb += g_pre @ lin.weight[:, :cin]
+                        g_h = g_pre @ lin.weight[:, cin:]
+                    else:
+                        g_h = g_pre @ lin.weight
             g_xin = embed_backward(ctx.emb_xyz, xin, g_emb[:, :ctx.emb_xyz.out_channels]) if need_in else None
         return (None, None, None, None, None, None, g_xin) + tuple(grads[n] for n in names)
 

@@ -1,0 +1,297 @@
+// mf_backward.hip -- input-gradient chain of the canonical NeRF over the training forward's dump.
+//
+// What it replaces: the autograd backward of models/nerf.py:78-102 that torch records for
+// `loss.backward()` (trainer/base.py:188-197).  Per ray-sample, given dL/d[rgb, sigma]:
+//     d_o   = d_rgb * rgb * (1 - rgb)                         (nn.Sigmoid, nerf.py:57-59)
+//     d_e   = (W_rgb^T d_o)              * [e   > 0]          (extra_encoding ReLU, nerf.py:98)
+//     d_g   =  W_e[:, :W]^T d_e                               (xyz_encoding_final has no activation)
+//     d_z_{D-1} = (W_f^T d_g + w_sigma d_sigma) * [h_D > 0]
+//     d_z_{l-1} = (W_l[:, hidden]^T d_z_l)      * [h_l > 0]   l = D-1 .. 1
+// i.e. the same register-resident transposed MLP as the forward, run on W^T: the nine W-wide
+// contractions go to v_mfma_f32_16x16x4_f32 through the fragment stream (packed from the transposed
+// weights by mf_nerf_pack_bwd), the ReLU masks come from the forward's activation dump, and every
+// pre-activation gradient is stored in the dump's own layout [d_z_0 .. d_z_{D-1} | d_g | d_e] so that
+// the weight gradients are plain library GEMMs  dW_l = d_z_l^T h_l  on (dump, this buffer).
+// d_sigma enters the xyz_encoding_final^T layer as one extra k-step (a 4-step "embedded" block whose
+// only live slot carries d_sigma against the packed sigma.weight row).
+#include "mf_host.hpp"
+#include "mf_layout.hpp"
+#include "mf_nets.hpp"
+
+namespace mf {
+
+constexpr int kBwdSigSteps = 4;   // k-steps of the d_sigma block in front of the final^T layer
+
+// Backward "network" of a NeRF(D, W=256): layer 0 = extra_encoding^T (K = W/2), layer 1 =
+// xyz_encoding_final^T (+ the d_sigma block), layers 2..D = trunk layers D-1..1 transposed.
+inline bool nerf_bwd_layout(const mf_nerf_desc& d, NetLayout& L) {
+  NetLayout F;
+  if (!nerf_layout(d, F, 0) || F.W != 256) return false;
+  L = NetLayout{};
+  L.W = F.W; L.NK = F.NK; L.NP = F.NP;
+  L.n_trunk = d.D + 1;
+  L.emb_steps = kBwdSigSteps;
+  L.emb_mask = 2u;
+  L.relu_mask = 0;
+  L.extra_steps = -1;
+  int off = 0;
+  L.off_bias_trunk = off; off += L.W;            // one shared all-zero bias vector
+  L.off_rgb_w = off; off += 3 * (L.W / 2);       // rgb.0.weight, natural order (VALU prologue)
+  L.res_bytes = round_up((int64_t)off * 4, kGroupBytes);
+  L.max_groups = 2 * (L.NK + 1);
+  L.panel_bytes = (int64_t)(L.NK + 2 * (L.NK + 1) + 2 * L.NK * (d.D - 1)) * L.NP * kGroupBytes;
+  return true;
+}
+MF_HD int bwd_groups(const NetLayout& L, int layer) {
+  return layer == 0 ? L.NK : (layer == 1 ? 2 * (L.NK + 1) : 2 * L.NK);
+}
+
+int device_cus();   // mf_forward.hip
+
+// ------------------------------------------------------------------ packing (transposed fragment stream)
+struct BwdPackJob {
+  const float* W[MF_MAX_LAYERS + 1];   // forward weight feeding backward layer i
+  int ld[MF_MAX_LAYERS + 1];           // its row length (forward in-features)
+  int col0[MF_MAX_LAYERS + 1];         // first hidden column
+  int groups[MF_MAX_LAYERS + 1];
+  long long g0[MF_MAX_LAYERS + 2];
+  int n_layers, NP;
+  const float* sigma_w;
+  const float* rgb_w;
+  int res_floats, off_rgb_w, n_rgb_w;
+  float* res;
+  float* panels;
+  long long total_groups;
+};
+
+__global__ void pack_bwd_kernel(BwdPackJob job) {
+  const long long gidx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gidx < job.res_floats) {
+    const int o = (int)gidx - job.off_rgb_w;
+    job.res[gidx] = (o >= 0 && o < job.n_rgb_w) ? job.rgb_w[o] : 0.f;
+  }
+  const long long grp = gidx >> 6;
+  if (grp >= job.total_groups) return;
+  const int lane = (int)(gidx & 63);
+  int li = 0;
+  while (li + 1 < job.n_layers && grp >= job.g0[li + 1]) ++li;
+  const long long local = grp - job.g0[li];
+  const int P = (int)(local / job.groups[li]), gi = (int)(local % job.groups[li]);
+  const int b = gi >> 1, half = gi & 1;
+  const int i = lane & 15, g = lane >> 4;
+  const int n = 32 * P + 16 * half + i;            // output feature of the backward layer = forward input column
+  const int sig = li == 1 ? 1 : 0;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (sig && b == 0) {
+    if (g == 0) v.x = job.sigma_w[n];              // step 0 of lane group 0 carries d_sigma
+  } else {
+    const int bh = b - sig;
+    float* pv = &v.x;
+    for (int r = 0; r < 4; ++r) {
+      const int k = 16 * bh + 4 * g + r;           // forward output row
+      pv[r] = job.W[li][(long long)k * job.ld[li] + job.col0[li] + n];
+    }
+  }
+  reinterpret_cast<float4*>(job.panels)[gidx] = v;
+}
+
+// ------------------------------------------------------------------ the kernel
+struct BwdParams {
+  NetDev net;
+  int D;
+  long long P, stride;
+  const float* g_out;      // (P,4)  dL/d[rgb, sigma]
+  const float* acts;       // (P,stride) forward dump
+  const float* rgbsigma;   // (P,4)
+  float* gpre;             // (round_up(P,128), stride)
+  float* ghead;            // (P,4)  [d rgb pre-sigmoid, d sigma]
+  uint32_t ring_off, buf_bytes;
+  int dbg;
+};
+
+// One W-wide layer of the chain: out = W^T-panels * [sig ; in], times the ReLU mask of the forward
+// activation it is the gradient of; stored to this lane's row of the gradient buffer.
+template <int MODE, int NKI, bool MASK>
+MF_D void bwd_layer(const f32x4 (&in)[NKI], const float (&sig)[kBwdSigSteps], f32x4 (&out)[16], int groups,
+                    uint32_t zero_bias, Stream& st, CarryT<Pipe<false>::PD>& carry, const LaneId& id,
+                    const NextLayer& nxt, const float* mask_row, float* store_row) {
+  constexpr int NP = 8;
+#pragma unroll
+  for (int t = 0; t < NP; ++t) {
+    const uint32_t p = st.slot_off(0) + id.lane * 16;
+    const uint32_t pn = st.slot_off(1) + id.lane * 16;
+    f32x4 m0 = {1.f, 1.f, 1.f, 1.f}, m1 = {1.f, 1.f, 1.f, 1.f};
+    auto hook = [&]() {
+      st.sync_and_dma(t + 2 < NP ? groups : nxt.groups, t == NP - 2 ? nxt.jump : nullptr, id);
+      if constexpr (MASK) {     // behind the barrier: in flight for the rest of the panel
+        m0 = *reinterpret_cast<const f32x4*>(mask_row + 32 * t + 4 * id.g);
+        m1 = *reinterpret_cast<const f32x4*>(mask_row + 32 * t + 16 + 4 * id.g);
+      }
+    };
+    const bool late = id.wave < kWaves / 2;
+    f32x4 E, O;
+    out_pair<MODE, NKI, kBwdSigSteps, false>(carry, in, sig, p, pn, zero_bias, id.g, late, hook, -__builtin_inff(), E, O);
+    if constexpr (MASK) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        E[i] = m0[i] > 0.f ? E[i] : 0.f;
+        O[i] = m1[i] > 0.f ? O[i] : 0.f;
+      }
+    }
+    *reinterpret_cast<f32x4*>(store_row + 32 * t + 4 * id.g) = E;
+    *reinterpret_cast<f32x4*>(store_row + 32 * t + 16 + 4 * id.g) = O;
+    out[2 * t] = E;
+    out[2 * t + 1] = O;
+    st.advance();
+  }
+}
+
+__global__ __launch_bounds__(kThreads, 2) void nerf_backward_kernel(BwdParams p) {
+  const LaneId id;
+  const NetDev net = p.net;
+  load_resident(net, id);
+  Stream st;
+  CarryT<Pipe<false>::PD> carry;
+  st.ring = p.ring_off;
+  st.buf_bytes = p.buf_bytes;
+  st.dbg = p.dbg;
+  const uint32_t zero_bias = net.res_lds + net.L.off_bias_trunk * 4;
+  const char* first = net.packed + net.L.res_bytes;
+  st.start(first, bwd_groups(net.L, 0), id);
+  carry.load(st.slot_off(0) + id.lane * 16, zero_bias, id.g);
+  const int D = p.D, W = net.L.W;
+  const uint32_t rgbw = net.res_lds + net.L.off_rgb_w * 4;
+  auto next_of = [&](int layer) {                 // the layer after `layer` in program order
+    NextLayer f;
+    const int nl = layer + 1 <= D ? layer + 1 : 0;
+    f.groups = bwd_groups(net.L, nl);
+    f.jump = nl == 0 ? first : nullptr;
+    f.bias_off = zero_bias;
+    return f;
+  };
+  const long long ntiles = (p.P + kTile - 1) / kTile;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long s = tile * kTile + id.wave * kWaveSamples + id.j;
+    const bool valid = s < p.P;
+    const long long ss = valid ? s : p.P - 1;
+    const float4 go = *reinterpret_cast<const float4*>(p.g_out + ss * 4);
+    const float4 rs = *reinterpret_cast<const float4*>(p.rgbsigma + ss * 4);
+    const float d0 = go.x * rs.x * (1.f - rs.x), d1 = go.y * rs.y * (1.f - rs.y), d2 = go.z * rs.z * (1.f - rs.z);
+    if (valid && id.g == 0) *reinterpret_cast<float4*>(p.ghead + s * 4) = make_float4(d0, d1, d2, go.w);
+    const float* arow = p.acts + ss * p.stride;
+    float* grow = p.gpre + s * p.stride;           // rows up to round_up(P,128) exist
+    // d_e = (W_rgb^T d_o) * [e > 0], in the B-operand layout (k-tile t, lane group g: features 16t+4g+r)
+    f32x4 de[8];
+    {
+      const float* erow = arow + (long long)(D + 1) * W;
+      float* gerow = grow + (long long)(D + 1) * W;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const f32x4 w0 = lds_f4(rgbw + (0 * (W / 2) + 16 * t + 4 * id.g) * 4);
+        const f32x4 w1 = lds_f4(rgbw + (1 * (W / 2) + 16 * t + 4 * id.g) * 4);
+        const f32x4 w2 = lds_f4(rgbw + (2 * (W / 2) + 16 * t + 4 * id.g) * 4);
+        const f32x4 e4 = *reinterpret_cast<const f32x4*>(erow + 16 * t + 4 * id.g);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float v = __builtin_fmaf(w2[r], d2, __builtin_fmaf(w1[r], d1, w0[r] * d0));
+          de[t][r] = e4[r] > 0.f ? v : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(gerow + 16 * t + 4 * id.g) = de[t];
+      }
+    }
+    const float nosig[kBwdSigSteps] = {0.f, 0.f, 0.f, 0.f};
+    const float sig[kBwdSigSteps] = {id.g == 0 ? go.w : 0.f, 0.f, 0.f, 0.f};
+    f32x4 a[16], b[16];
+    // layer 0: d_g = W_e[:, :W]^T d_e          (no activation on xyz_encoding_final)
+    bwd_layer<2, 8, false>(de, nosig, a, bwd_groups(net.L, 0), zero_bias, st, carry, id, next_of(0), nullptr,
+                           grow + (long long)D * W);
+    // layer 1: d_z_{D-1} = (W_f^T d_g + w_sigma d_sigma) * [h_D > 0]
+    bwd_layer<3, 16, true>(a, sig, b, bwd_groups(net.L, 1), zero_bias, st, carry, id, next_of(1),
+                           arow + (long long)(D - 1) * W, grow + (long long)(D - 1) * W);
+    // layers 2..D: d_z_{l-1} = (W_l^T d_z_l) * [h_l > 0],  l = D-1 .. 1
+    for (int i = 2; i <= D; ++i) {
+      const int l = D + 1 - i;
+      bwd_layer<2, 16, true>(b, nosig, a, bwd_groups(net.L, i), zero_bias, st, carry, id, next_of(i),
+                             arow + (long long)(l - 1) * W, grow + (long long)(l - 1) * W);
+#pragma unroll
+      for (int t = 0; t < 16; ++t) b[t] = a[t];
+    }
+  }
+  wait_vm0();
+}
+
+}  // namespace mf
+
+using namespace mf;
+
+extern "C" int64_t mf_nerf_bwd_packed_bytes(const mf_nerf_desc* d) {
+  NetLayout L;
+  if (!d || !nerf_bwd_layout(*d, L)) { fail(MF_E_UNSUPPORTED, "mf_nerf_bwd_packed_bytes: unsupported NeRF configuration"); return 0; }
+  return L.res_bytes + L.panel_bytes;
+}
+
+extern "C" int32_t mf_nerf_pack_bwd(const mf_nerf_desc* d, void* packed, void* stream) {
+  NetLayout L;
+  if (!d || !packed) return fail(MF_E_INVALID, "mf_nerf_pack_bwd: null argument");
+  if (!nerf_bwd_layout(*d, L)) return fail(MF_E_UNSUPPORTED, "mf_nerf_pack_bwd: unsupported NeRF configuration (W=%d D=%d)", d->W, d->D);
+  BwdPackJob job{};
+  const int ext = d->extra_feat_type == MF_EXTRA_NONE ? 0 : d->extra_feat_dim;
+  job.n_layers = d->D + 1;
+  job.NP = L.NP;
+  long long g0 = 0;
+  for (int i = 0; i <= d->D; ++i) {
+    if (i == 0) { job.W[i] = d->extra_w; job.ld[i] = L.W + ext; job.col0[i] = 0; }
+    else if (i == 1) { job.W[i] = d->final_w; job.ld[i] = L.W; job.col0[i] = 0; }
+    else {
+      const int l = d->D + 1 - i;
+      const bool skip = (d->skip_mask >> l) & 1u;
+      job.W[i] = d->trunk_w[l];
+      job.ld[i] = L.W + (skip ? d->in_channels_xyz : 0);
+      job.col0[i] = skip ? d->in_channels_xyz : 0;
+    }
+    if (!job.W[i]) return fail(MF_E_INVALID, "mf_nerf_pack_bwd: missing weight pointer (backward layer %d)", i);
+    job.groups[i] = bwd_groups(L, i);
+    job.g0[i] = g0;
+    g0 += (long long)job.groups[i] * L.NP;
+  }
+  job.g0[d->D + 1] = g0;
+  if (!d->sigma_w || !d->rgb_w) return fail(MF_E_INVALID, "mf_nerf_pack_bwd: missing sigma / rgb weight");
+  job.sigma_w = d->sigma_w;
+  job.rgb_w = d->rgb_w;
+  job.res_floats = (int)(L.res_bytes / 4);
+  job.off_rgb_w = L.off_rgb_w;
+  job.n_rgb_w = 3 * (L.W / 2);
+  job.res = static_cast<float*>(packed);
+  job.panels = reinterpret_cast<float*>(static_cast<char*>(packed) + L.res_bytes);
+  job.total_groups = g0;
+  if (g0 * kGroupBytes != L.panel_bytes) return fail(MF_E_INVALID, "mf_nerf_pack_bwd: layout mismatch");
+  const long long slots = g0 * 64;
+  hipLaunchKernelGGL(pack_bwd_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), job);
+  return check_launch("mf_nerf_pack_bwd");
+}
+
+extern "C" int32_t mf_nerf_backward(const mf_nerf_desc* d, const void* packed_bwd, int64_t P, const float* g_out,
+                                    const float* acts, int64_t stride, const float* rgbsigma, float* gpre,
+                                    float* ghead, void* stream) {
+  if (!d || !packed_bwd || (P > 0 && (!g_out || !acts || !rgbsigma || !gpre || !ghead)))
+    return fail(MF_E_INVALID, "mf_nerf_backward: null argument");
+  BwdParams p{};
+  if (!nerf_bwd_layout(*d, p.net.L)) return fail(MF_E_UNSUPPORTED, "mf_nerf_backward: unsupported NeRF configuration");
+  if (stride < (int64_t)(d->D + 1) * d->W + d->W / 2 || (stride & 3))
+    return fail(MF_E_INVALID, "mf_nerf_backward: stride %lld too small or not a multiple of 4", (long long)stride);
+  if (P == 0) return MF_OK;
+  p.net.packed = static_cast<const char*>(packed_bwd);
+  p.net.res_lds = 0;
+  p.D = d->D; p.P = P; p.stride = stride;
+  p.g_out = g_out; p.acts = acts; p.rgbsigma = rgbsigma; p.gpre = gpre; p.ghead = ghead;
+  p.ring_off = (uint32_t)p.net.L.res_bytes;
+  p.buf_bytes = (uint32_t)p.net.L.max_groups * kGroupBytes;
+  p.dbg = 0;
+  const size_t lds = p.ring_off + 3 * (size_t)p.buf_bytes;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(MF_E_LAUNCH, "mf_nerf_backward: cannot reserve %zu bytes of LDS", lds);
+  const long long ntiles = (P + kTile - 1) / kTile;
+  const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
+  hipLaunchKernelGGL(nerf_backward_kernel, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+  return check_launch("mf_nerf_backward");
+}

@@ -40,6 +40,7 @@ class NeRF(nn.Module):
         self.rgb = nn.Sequential(nn.Linear(W // 2, 3), nn.Sigmoid())
         self._packed = PackedWeights()
         self._packed_bf16 = PackedWeights()
+        self._packed_bwd = PackedWeights()
 
     # ---- HIP plumbing -----------------------------------------------------
     def _build_desc(self):
@@ -77,6 +78,12 @@ class NeRF(nn.Module):
         lib = L.lib()
         cache = self._packed if precision == L.MF_PREC_F32 else self._packed_bf16
         return cache.get(self, self._build_desc, lib.mf_nerf_packed_bytes_p, lib.mf_nerf_pack_p, "NeRF", precision)
+
+    def packed_bwd(self):
+        """(descriptor, transposed fragment stream) for mf_nerf_backward; fp32 only."""
+        lib = L.lib()
+        return self._packed_bwd.get(self, self._build_desc, lambda d, _p: lib.mf_nerf_bwd_packed_bytes(d),
+                                    lambda d, _p, buf, st: lib.mf_nerf_pack_bwd(d, buf, st), "NeRF backward", "bwd")
 
     def forward(self, inputs, sigma_only=False, img_ind=None):
         """inputs (B, in_channels_xyz [+ extra_feat_dim]) -> (B,4) rgb+sigma, or (B,1) sigma."""

@@ -594,17 +594,20 @@ def test_train_forward_torch_mode_matches_hip_mode(M):
         assert relerr(x, y) <= 5e-2           # kink flips at points 1e-6 apart, see test_gradients_vs_oracle
 
 
-def test_explicit_nerf_backward_unit(M):
-    """autograd.NerfSamples (explicit library-GEMM backward over the kernel's activation dump) against
-    plain torch autograd of the same network on the SAME points: parameter and input-point gradients
-    to 1e-4, frozen sub-module honoured."""
+@pytest.mark.parametrize("kind,n_rays", [("hip", 40), ("hip", 37), ("hip", 1), ("gemm", 40)])
+def test_explicit_nerf_backward_unit(M, kind, n_rays):
+    """autograd.NerfSamples (fused HIP dX chain mf_nerf_backward + library dW GEMMs over the kernel's
+    activation dump; "gemm": library GEMMs only) against plain torch autograd of the same network on the
+    SAME points: parameter and input-point gradients to 1e-4, frozen sub-module honoured, ragged
+    sample counts (not a multiple of the 128-sample tile)."""
     from moco_flow_amd import autograd as A, rendering, synth
     import ctypes as C
     torch.manual_seed(0)
+    A.set_nerf_backward(kind)
     c = dict(RENDER_CASES["r_nerf_ind_dense"])
     embs, nerfs, kw = build_case(M, c, 21, device="cuda")
     nerf = nerfs[0]
-    rays, bg = case_inputs(c, 21, n=40)
+    rays, bg = case_inputs(c, 21, n=n_rays)
     rays, bg = rays.cuda(), bg.cuda()
     S = 64
     z = (rays[:, 6:7] * (1 - torch.linspace(0, 1, S, device="cuda")) + rays[:, 7:8] * torch.linspace(0, 1, S, device="cuda")).contiguous()
@@ -617,9 +620,12 @@ def test_explicit_nerf_backward_unit(M):
     extra_in = A._pad_to(torch.repeat_interleave(A.embed(embs[1], ind), S, dim=0), 5)
     for q in nerf.rgb.parameters():
         q.requires_grad_(False)
-    gout = torch.randn(40 * S, 4, device="cuda")
+    gout = torch.randn(n_rays * S, 4, device="cuda")
     out = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, embs[0], xin, *nerf.parameters())
-    out.backward(gout)
+    try:
+        out.backward(gout)
+    finally:
+        A.set_nerf_backward("hip")
     got = {n: (q.grad.clone() if q.grad is not None else None) for n, q in nerf.named_parameters()}
     got_x = xin.grad.clone()
     nerf.zero_grad(set_to_none=True)

@@ -38,6 +38,9 @@ def eager_fwd():
 print(f"N_rand={N} rays x ({S} + {S+Mi}) samples = {N*(2*S+Mi)/1e6:.2f} M samples/step")
 print(f"  HIP forward (no_grad)            : {timeit(fwd_only):8.2f} ms")
 print(f"  PyTorch-ROCm eager forward        : {timeit(eager_fwd):8.2f} ms")
-print(f"  HIP forward + interim backward    : {timeit(fwd_bwd):8.2f} ms")
+print(f"  HIP forward + HIP dX chain + dW GEMMs : {timeit(fwd_bwd):8.2f} ms")
+A.set_nerf_backward("gemm")
+print(f"  HIP forward + library-GEMM backward   : {timeit(fwd_bwd):8.2f} ms")
+A.set_nerf_backward("hip")
 rendering.set_train_forward("torch")
 print(f"  TRAIN_FORWARD=torch fwd+bwd       : {timeit(fwd_bwd):8.2f} ms")
