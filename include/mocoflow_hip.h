@@ -141,6 +141,24 @@ int32_t mf_nerf_backward(const mf_nerf_desc* d, const void* packed_bwd, int64_t 
                          const float* acts, int64_t stride, const float* rgbsigma, float* gpre,
                          float* ghead, void* stream);
 
+/* Weight / bias gradients of a set of linear layers over P samples, ONE persistent launch:
+ *     dW_i = G_i[:P]^T X_i[:P]   (n_out x n_in),      db_i = sum_s G_i[s]   (n_out)
+ * G_i / X_i: fp32 row-major device matrices (column slices of the mf_nerf_backward gradient buffer, of
+ * the forward's activation dump, or of the embedded inputs), 16-byte aligned, strides multiples of 4
+ * floats.  Supported blocks (n_out x n_in): 256x256, 256x64, 128x256, 128x32, and 4x640 (the two heads
+ * at once: G = ghead (P,4), X = dump columns [h_D | final | extra]).  dW is written as a dense
+ * (max(n_out,16), n_in) matrix, db (optional, may be NULL) as max(n_out,16) floats.  Deterministic
+ * (fixed-order partial sums through `scratch`, no atomics).  Replaces the dW/db halves of torch's
+ * addmm backward for models/nerf.py:78-102. */
+#define MF_WG_MAX_ITEMS 16
+typedef struct mf_wgrad_item {
+  const float* G; int64_t g_stride; int32_t n_out;
+  const float* X; int64_t x_stride; int32_t n_in;
+  float* dW; float* db;
+} mf_wgrad_item;
+int64_t mf_weight_grads_scratch_bytes(const mf_wgrad_item* items, int32_t n_items, int64_t P);
+int32_t mf_weight_grads(const mf_wgrad_item* items, int32_t n_items, int64_t P, void* scratch, void* stream);
+
 /* Fused point query: xyz (B,3) -> [backward NoF at image index ind] -> positional encoding -> NeRF
  * trunk -> raw sigma (B,), one launch.  Replaces the per-chunk module sequence forward_nof /
  * nerf_embedding_xyz / zero-pad / NeRF(sigma_only=True) of trainer_moco_flow.py:146-187 and the

@@ -43,6 +43,15 @@ class mf_nof_desc(C.Structure):
                 ("head_w", _fp), ("head_b", _fp)]
 
 
+class mf_wgrad_item(C.Structure):
+    _fields_ = [("G", _fp), ("g_stride", C.c_int64), ("n_out", C.c_int32),
+                ("X", _fp), ("x_stride", C.c_int64), ("n_in", C.c_int32),
+                ("dW", _fp), ("db", _fp)]
+
+
+MF_WG_MAX_ITEMS = 16
+
+
 class mf_render_args(C.Structure):
     _fields_ = [("rays", _fp), ("ray_stride", C.c_int64), ("n_rays", C.c_int64),
                 ("background", _fp), ("n_samples", C.c_int32),
@@ -75,6 +84,8 @@ SYMBOLS = {
     "mf_nof_forward": (C.c_int32, [C.POINTER(mf_nof_desc), _fp, _fp, C.c_int64, _fp, C.c_int64, _fp, _fp]),
     "mf_nerf_bwd_packed_bytes": (C.c_int64, [C.POINTER(mf_nerf_desc)]),
     "mf_nerf_pack_bwd": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, _fp]),
+    "mf_weight_grads_scratch_bytes": (C.c_int64, [C.POINTER(mf_wgrad_item), C.c_int32, C.c_int64]),
+    "mf_weight_grads": (C.c_int32, [C.POINTER(mf_wgrad_item), C.c_int32, C.c_int64, _fp, _fp]),
     "mf_nerf_backward": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, C.c_int64, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp]),
     "mf_render_pass": (C.c_int32, [C.POINTER(mf_render_args), _fp]),
     "mf_points_sigma": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, C.POINTER(mf_embedding), C.POINTER(mf_nof_desc), _fp,

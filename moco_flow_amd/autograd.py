@@ -244,6 +244,41 @@ def nerf_backward_hip(m, g_out, acts, rgbsig):
     return gpre[:P], ghead
 
 
+_WG_BLOCK = {(256, 256): (256, 256), (256, 64): (256, 64), (128, 256): (128, 256), (128, 32): (128, 32), (4, 640): (16, 640)}
+
+
+def weight_grads(jobs, P, dev):
+    """mf_weight_grads: jobs = [(G, X, n_out, n_in, want_bias)] with G / X fp32 device matrices (column
+    slices allowed) -> [(dW (rows, n_in), db (rows,) | None)] in ONE persistent HIP launch."""
+    import ctypes as C
+    from . import _lib as L
+    n = len(jobs)
+    if n == 0:
+        return []
+    if n > L.MF_WG_MAX_ITEMS:
+        raise RuntimeError(f"weight_grads: {n} items (max {L.MF_WG_MAX_ITEMS})")
+    items = (L.mf_wgrad_item * n)()
+    outs = []
+    for it, (G, X, n_out, n_in, bias) in zip(items, jobs):
+        rows, cols = _WG_BLOCK[(n_out, n_in)]
+        dW = torch.empty((rows, cols), device=dev, dtype=torch.float32)
+        db = torch.empty((rows,), device=dev, dtype=torch.float32) if bias else None
+        if G.stride(1) != 1 or X.stride(1) != 1:
+            raise RuntimeError("weight_grads: operands must be row-major")
+        it.G, it.g_stride, it.n_out = G.data_ptr(), G.stride(0), n_out
+        it.X, it.x_stride, it.n_in = X.data_ptr(), X.stride(0), n_in
+        it.dW, it.db = dW.data_ptr(), (db.data_ptr() if bias else None)
+        outs.append((dW, db))
+    lib = L.lib()
+    nbytes = lib.mf_weight_grads_scratch_bytes(items, n, P)
+    if nbytes < 0:
+        L.check(-3, "mf_weight_grads")
+    scratch = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        L.check(lib.mf_weight_grads(items, n, P, scratch.data_ptr(), L.current_stream(dev)), "mf_weight_grads")
+    return outs
+
+
 class NerfSamples(torch.autograd.Function):
     """Per-sample (rgb, sigma) of the canonical NeRF as an autograd node whose forward IS the fused HIP
     kernel's output (``rgbsig``, dumped).  Backward, per layer
@@ -277,33 +312,72 @@ class NerfSamples(torch.autograd.Function):
             h = lambda l: acts[:, l * W:(l + 1) * W]
             f = acts[:, D * W:(D + 1) * W]
             e2 = acts[:, (D + 1) * W:(D + 1) * W + W // 2]
-            if NERF_BACKWARD == "hip" and acts.shape[0] > 0:
+            fused = (NERF_BACKWARD == "hip" and acts.shape[0] > 0 and W == 256 and cin <= 64
+                     and m.extra_feat_dim <= 32 and D + len([s for s in m.skips if 0 < s < D]) + 4 <= 16)
+            if fused:
                 gpre, ghead = nerf_backward_hip(m, g_out, acts, rgbsig)
-                bias_sums = gpre.sum(0) if any(req[n] for n in names if n.endswith(".bias")) else None
+                P, dev = acts.shape[0], acts.device
                 gslot = lambda l: gpre[:, l * W:(l + 1) * W]
-
-                def lin_grads(prefix, g_pre, parts, b0=None):
-                    if req[prefix + ".weight"]:
-                        gt = g_pre.t()
-                        blocks = [gt @ x for x in parts]
-                        grads[prefix + ".weight"] = blocks[0] if len(blocks) == 1 else torch.cat(blocks, 1)
-                    if req[prefix + ".bias"]:
-                        grads[prefix + ".bias"] = g_pre.sum(0) if b0 is None else bias_sums[b0:b0 + g_pre.shape[1]].clone()
-
                 g_e2 = gpre[:, (D + 1) * W:(D + 1) * W + W // 2]
-                g_f = gslot(D)
-                lin_grads("rgb.0", ghead[:, :3], [e2])
-                lin_grads("sigma", ghead[:, 3:4], [h(D - 1)])
-                lin_grads("extra_encoding.0", g_e2, [f] if extra is None else [f, extra], (D + 1) * W)
-                lin_grads("xyz_encoding_final", g_f, [h(D - 1)], D * W)
-                g_emb = None
+                wants = lambda prefix: req[prefix + ".weight"] or req[prefix + ".bias"]
+                emb64 = F.pad(emb, (0, 64 - emb.shape[1])) if emb.shape[1] < 64 else emb
+                jobs, sinks = [], []
+
+                def put(prefix, blocks, bias_from=0):
+                    """blocks: [(job index, row slice, col slice)] concatenated along the columns"""
+                    sinks.append((prefix, blocks, bias_from))
+
                 for l in range(D):
-                    lin = getattr(m, f"xyz_encoding_{l+1}")[0]
-                    parts = [emb] if l == 0 else ([emb, h(l - 1)] if l in m.skips else [h(l - 1)])
-                    lin_grads(f"xyz_encoding_{l+1}.0", gslot(l), parts, l * W)
-                    if need_in and (l == 0 or l in m.skips):
-                        t = gslot(l) @ lin.weight[:, :cin]
-                        g_emb = t if g_emb is None else g_emb + t
+                    name = f"xyz_encoding_{l+1}.0"
+                    if not wants(name):
+                        continue
+                    blocks = []
+                    if l == 0 or l in m.skips:
+                        jobs.append((gslot(l), emb64, 256, 64, l == 0))
+                        blocks.append((len(jobs) - 1, slice(0, W), slice(0, cin)))
+                    if l > 0:
+                        jobs.append((gslot(l), h(l - 1), 256, 256, True))
+                        blocks.append((len(jobs) - 1, slice(0, W), slice(0, W)))
+                    put(name, blocks, blocks[-1][0])
+                if wants("xyz_encoding_final"):
+                    jobs.append((gslot(D), h(D - 1), 256, 256, True))
+                    put("xyz_encoding_final", [(len(jobs) - 1, slice(0, W), slice(0, W))], len(jobs) - 1)
+                if wants("extra_encoding.0"):
+                    jobs.append((g_e2, f, 128, 256, True))
+                    blocks = [(len(jobs) - 1, slice(0, W // 2), slice(0, W))]
+                    if extra is not None:
+                        ext32 = F.pad(extra, (0, 32 - extra.shape[1])) if extra.shape[1] < 32 else extra
+                        jobs.append((g_e2, ext32, 128, 32, False))
+                        blocks.append((len(jobs) - 1, slice(0, W // 2), slice(0, extra.shape[1])))
+                    put("extra_encoding.0", blocks, blocks[0][0])
+                head_job = None
+                if wants("sigma") or wants("rgb.0"):
+                    jobs.append((ghead, acts[:, (D - 1) * W:(D - 1) * W + 640], 4, 640, True))
+                    head_job = len(jobs) - 1
+                res = weight_grads(jobs, P, dev)
+                for prefix, blocks, bias_from in sinks:
+                    if req[prefix + ".weight"]:
+                        parts = [res[j][0][rs, cs] for j, rs, cs in blocks]
+                        grads[prefix + ".weight"] = parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, 1)
+                    if req[prefix + ".bias"]:
+                        grads[prefix + ".bias"] = res[bias_from][1][blocks[0][1]].clone()
+                if head_job is not None:
+                    hW, hb = res[head_job]
+                    if req["sigma.weight"]:
+                        grads["sigma.weight"] = hW[3:4, 0:W].contiguous()
+                    if req["sigma.bias"]:
+                        grads["sigma.bias"] = hb[3:4].clone()
+                    if req["rgb.0.weight"]:
+                        grads["rgb.0.weight"] = hW[0:3, 2 * W:2 * W + W // 2].contiguous()
+                    if req["rgb.0.bias"]:
+                        grads["rgb.0.bias"] = hb[0:3].clone()
+                g_emb = None
+                if need_in:
+                    for l in range(D):
+                        if l == 0 or l in m.skips:
+                            lin = getattr(m, f"xyz_encoding_{l+1}")[0]
+                            t = gslot(l) @ lin.weight[:, :cin]
+                            g_emb = t if g_emb is None else g_emb + t
             else:
                 def lin_grads(prefix, g_pre, x_in):
                     if req[prefix + ".weight"]:

@@ -1,0 +1,313 @@
+// mf_wgrad.hip -- weight / bias gradients of the NeRF layers:  dW_i = G_i^T X_i,  db_i = sum_s G_i[s]
+//
+// What it replaces: the dW / db halves of torch's addmm backward for the 12 nn.Linear of
+// models/nerf.py:78-102 under loss.backward() (trainer/base.py:188-197).  G_i are column slices of the
+// pre-activation gradient buffer written by mf_nerf_backward, X_i column slices of the forward's
+// activation dump (or the embedded inputs): both (P, .) row-major with P ~ 1e6 samples, outputs at most
+// 256 x 256.  Library GEMMs handle this shape (tiny M,N; K = P; strided operands) at 30-60 % of the
+// matrix peak and need ~25 launches; here ALL layers run in ONE persistent launch:
+//   * the contraction runs over SAMPLES: v_mfma_f32_16x16x4_f32 with A = G^T (16 out-features x 4
+//     samples) and B = X (4 samples x 16 in-features); a workgroup owns the whole (n_out x n_in) output
+//     of one item in registers (8 waves x up to 4x8 accumulator tiles) and streams 16-sample stages of
+//     (G, X) rows HBM -> LDS with LDS-DMA through a 3-slot ring (one barrier per stage);
+//   * the linearised (item, stage) space is cut into #CU equal-cost ranges, one per workgroup, so
+//     each workgroup flushes at most a few partial results; partials go to a scratch buffer and a
+//     second tiny kernel sums them in a fixed order (deterministic, no atomics);
+//   * db falls out of the G tile already in LDS (one column per thread).
+#include "mf_host.hpp"
+#include "mf_core.hpp"
+
+namespace mf {
+
+int device_cus();   // mf_forward.hip
+
+constexpr int kWgStage = 16;          // samples per stage
+constexpr int kWgMaxItems = MF_WG_MAX_ITEMS;
+
+// Output-block shapes (n_out x n_in), the 8 waves arranged (8 / WAVES_C) x WAVES_C, each wave WR x WC
+// 16x16 tiles.  GW = valid G columns per row (the rest of the 16-row minimum is zero).
+template <int NOUT_, int NIN_, int WR_, int WC_, int WAVES_C_, int GW_>
+struct WgShape {
+  static constexpr int NOUT = NOUT_, NIN = NIN_, WR = WR_, WC = WC_, WAVES_C = WAVES_C_, GW = GW_;
+  static constexpr int PG = NOUT + 4, PX = NIN + 4;                  // LDS pitches (floats): pitch % 8 == 4
+  static constexpr int SLOT_BYTES = kWgStage * (PG + PX) * 4;
+  static constexpr int OUT_FLOATS = NOUT * NIN + NOUT;               // partial: dW then db
+  static_assert((8 / WAVES_C) * WR * 16 == NOUT && WAVES_C * WC * 16 == NIN, "wave tiling must cover the block");
+};
+using ShapeA = WgShape<256, 256, 4, 8, 2, 256>;   // hidden x hidden
+using ShapeB = WgShape<256, 64, 2, 4, 1, 256>;    // hidden x embedded xyz (63 -> 64)
+using ShapeC = WgShape<128, 256, 4, 4, 4, 128>;   // extra_encoding x final
+using ShapeD = WgShape<128, 32, 1, 2, 1, 128>;    // extra_encoding x embedded dir / ind (<= 32)
+using ShapeE = WgShape<16, 640, 1, 5, 8, 4>;      // heads: [d rgb(3), d sigma] x [h_D | final | extra]
+
+// modelled cost of one stage, in CU cycles: max(MFMA time, HBM time at ~7 B/cycle/CU) + fixed part
+MF_HD int wg_stage_cost(int shape) {
+  switch (shape) {
+    case 0: return 8192 + 400;
+    case 1: return 2925 + 400;
+    case 2: return 4096 + 400;
+    case 3: return 1460 + 400;
+    default: return 5900 + 400;
+  }
+}
+MF_HD int wg_out_floats(int shape) {
+  switch (shape) {
+    case 0: return ShapeA::OUT_FLOATS;
+    case 1: return ShapeB::OUT_FLOATS;
+    case 2: return ShapeC::OUT_FLOATS;
+    case 3: return ShapeD::OUT_FLOATS;
+    default: return ShapeE::OUT_FLOATS;
+  }
+}
+
+struct WgItem {
+  const float* G; long long g_stride;
+  const float* X; long long x_stride;
+  int shape, want_bias;
+  long long cost0;        // start of this item in the linearised cost space
+  long long part_off;     // float offset of its first partial in the scratch buffer
+  int slot0, n_slots;     // first workgroup touching it, number of partials
+  float* dW; float* db;   // final (NOUT, NIN) / (NOUT)
+};
+
+struct WgParams {
+  WgItem it[kWgMaxItems];
+  int n_items, grid;
+  long long P, stages, total_cost;
+  float* scratch;
+};
+
+// stage range [b, e) of item `it` that workgroup w owns (same integer formula on host and device)
+MF_HD void wg_range(long long total, int grid, int w, long long cost0, int c, long long stages, long long& b, long long& e) {
+  const long long lo = total * w / grid, hi = total * (w + 1) / grid;
+  auto cut = [&](long long x) {
+    long long q = x <= cost0 ? 0 : (x - cost0 + c - 1) / c;
+    return q > stages ? stages : q;
+  };
+  b = cut(lo);
+  e = cut(hi);
+}
+
+MF_D void lds_zero(uint32_t byte_off) { *(float*)(smem + byte_off) = 0.f; }
+
+template <class S>
+MF_D void wg_load_stage(const WgItem& it, long long stage, long long P, uint32_t slot, const LaneId& id) {
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int rr = id.wave + 8 * k;
+    const long long s = stage * kWgStage + rr;
+    const uint32_t dg = slot + rr * S::PG * 4, dx = slot + kWgStage * S::PG * 4 + rr * S::PX * 4;
+    if (s < P) {
+      const char* gsrc = reinterpret_cast<const char*>(it.G + s * it.g_stride);
+      const char* xsrc = reinterpret_cast<const char*>(it.X + s * it.x_stride);
+      if (id.lane < S::GW / 4) glds16(gsrc + id.lane * 16, dg);
+#pragma unroll
+      for (int c0 = 0; c0 < S::NIN / 4; c0 += 64)
+        if (c0 + id.lane < S::NIN / 4) glds16(xsrc + (c0 + id.lane) * 16, dx + c0 * 16);
+    } else {      // past the last sample: the rows contribute nothing
+      for (int c = id.lane; c < S::GW; c += 64) lds_zero(dg + c * 4);
+      for (int c = id.lane; c < S::NIN; c += 64) lds_zero(dx + c * 4);
+    }
+  }
+}
+
+template <class S>
+MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, float* part, const LaneId& id) {
+  constexpr int WR = S::WR, WC = S::WC;
+  const int tid = threadIdx.x;
+  const int wr = id.wave / S::WAVES_C, wc = id.wave % S::WAVES_C;
+  const int row0 = wr * WR * 16, col0 = wc * WC * 16;
+  __syncthreads();                                   // previous segment's readers are done with the ring
+  if (S::GW < S::NOUT) {                             // narrow G: the unused columns of every slot stay zero
+    for (int i = tid; i < 3 * kWgStage * S::PG; i += kThreads) {
+      const int sl = i / (kWgStage * S::PG), o = i % (kWgStage * S::PG);
+      lds_zero(sl * S::SLOT_BYTES + o * 4);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  f32x4 acc[WR][WC];
+#pragma unroll
+  for (int a = 0; a < WR; ++a)
+#pragma unroll
+    for (int b = 0; b < WC; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float bsum = 0.f;
+  wg_load_stage<S>(it, sb, P, 0, id);
+  if (sb + 1 < se) wg_load_stage<S>(it, sb + 1, P, S::SLOT_BYTES, id);
+  uint32_t cur = 0;
+  // lane (i = lane & 15, kg = lane >> 4), MFMA step m: sample row 4*kg + m of the stage
+  const uint32_t aoff = ((4 * id.g) * S::PG + row0 + id.j) * 4;
+  const uint32_t boff = kWgStage * S::PG * 4 + ((4 * id.g) * S::PX + col0 + id.j) * 4;
+  for (long long st = sb; st < se; ++st) {
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+    if (st + 2 < se) wg_load_stage<S>(it, st + 2, P, (cur >= 1 ? cur - 1 : 2) * S::SLOT_BYTES, id);
+    const uint32_t base = cur * S::SLOT_BYTES;
+    if (it.want_bias && tid < S::NOUT) {
+#pragma unroll
+      for (int s = 0; s < kWgStage; ++s) bsum += lds_f(base + (s * S::PG + tid) * 4);
+    }
+    float a[2][WR], b[2][WC];
+#pragma unroll
+    for (int t = 0; t < WR; ++t) a[0][t] = lds_f(base + aoff + (16 * t) * 4);
+#pragma unroll
+    for (int t = 0; t < WC; ++t) b[0][t] = lds_f(base + boff + (16 * t) * 4);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int c = m & 1, n = c ^ 1;
+      if (m + 1 < 4) {
+#pragma unroll
+        for (int t = 0; t < WR; ++t) a[n][t] = lds_f(base + aoff + ((m + 1) * S::PG + 16 * t) * 4);
+#pragma unroll
+        for (int t = 0; t < WC; ++t) b[n][t] = lds_f(base + boff + ((m + 1) * S::PX + 16 * t) * 4);
+      }
+#pragma unroll
+      for (int ti = 0; ti < WR; ++ti)
+#pragma unroll
+        for (int tj = 0; tj < WC; ++tj) acc[ti][tj] = MF_MFMA(a[c][ti], b[c][tj], acc[ti][tj]);
+    }
+    cur = cur == 2 ? 0 : cur + 1;
+  }
+  // partial result: C/D layout row = 4*(lane>>4) + r, col = lane & 15
+#pragma unroll
+  for (int ti = 0; ti < WR; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < WC; ++tj)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        part[(long long)(row0 + 16 * ti + 4 * id.g + r) * S::NIN + col0 + 16 * tj + id.j] = acc[ti][tj][r];
+  if (tid < S::NOUT) part[(long long)S::NOUT * S::NIN + tid] = bsum;
+}
+
+__global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WgParams p) {
+  const LaneId id;
+  const int w = blockIdx.x;
+  for (int i = 0; i < p.n_items; ++i) {
+    const WgItem& it = p.it[i];
+    long long b, e;
+    wg_range(p.total_cost, p.grid, w, it.cost0, wg_stage_cost(it.shape), p.stages, b, e);
+    if (b >= e) continue;
+    float* part = p.scratch + it.part_off + (long long)(w - it.slot0) * wg_out_floats(it.shape);
+    switch (it.shape) {
+      case 0: wg_segment<ShapeA>(it, b, e, p.P, part, id); break;
+      case 1: wg_segment<ShapeB>(it, b, e, p.P, part, id); break;
+      case 2: wg_segment<ShapeC>(it, b, e, p.P, part, id); break;
+      case 3: wg_segment<ShapeD>(it, b, e, p.P, part, id); break;
+      default: wg_segment<ShapeE>(it, b, e, p.P, part, id); break;
+    }
+  }
+}
+
+// fixed-order sum of the partials of every item
+__global__ void wgrad_reduce_kernel(WgParams p) {
+  const int i = blockIdx.y;
+  if (i >= p.n_items) return;
+  const WgItem& it = p.it[i];
+  const int nf = wg_out_floats(it.shape);
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nf) return;
+  const float* src = p.scratch + it.part_off + e;
+  float s = 0.f;
+  for (int k = 0; k < it.n_slots; ++k) {
+    long long b, en;      // workgroups whose range of this item is empty (tiny P) wrote nothing
+    wg_range(p.total_cost, p.grid, it.slot0 + k, it.cost0, wg_stage_cost(it.shape), p.stages, b, en);
+    if (b < en) s += src[(long long)k * nf];
+  }
+  int nout, nin;
+  switch (it.shape) {
+    case 0: nout = ShapeA::NOUT; nin = ShapeA::NIN; break;
+    case 1: nout = ShapeB::NOUT; nin = ShapeB::NIN; break;
+    case 2: nout = ShapeC::NOUT; nin = ShapeC::NIN; break;
+    case 3: nout = ShapeD::NOUT; nin = ShapeD::NIN; break;
+    default: nout = ShapeE::NOUT; nin = ShapeE::NIN; break;
+  }
+  if (e < nout * nin) it.dW[e] = s;
+  else if (it.db) it.db[e - nout * nin] = s;
+}
+
+static int shape_of(const mf_wgrad_item& a) {
+  if (a.n_out == 256 && a.n_in == 256) return 0;
+  if (a.n_out == 256 && a.n_in == 64) return 1;
+  if (a.n_out == 128 && a.n_in == 256) return 2;
+  if (a.n_out == 128 && a.n_in == 32) return 3;
+  if (a.n_out == 4 && a.n_in == 640) return 4;
+  return -1;
+}
+
+static int wg_plan(const mf_wgrad_item* items, int n, long long P, WgParams& p, long long& scratch_floats) {
+  if (n < 0 || n > kWgMaxItems) return fail(MF_E_INVALID, "mf_weight_grads: %d items (max %d)", n, kWgMaxItems);
+  p = WgParams{};
+  p.n_items = n;
+  p.P = P;
+  p.stages = (P + kWgStage - 1) / kWgStage;
+  p.grid = device_cus();
+  long long cost = 0;
+  for (int i = 0; i < n; ++i) {
+    const mf_wgrad_item& a = items[i];
+    const int sh = shape_of(a);
+    if (sh < 0) return fail(MF_E_UNSUPPORTED, "mf_weight_grads: item %d has unsupported block %d x %d", i, a.n_out, a.n_in);
+    if (!a.G || !a.X || !a.dW) return fail(MF_E_INVALID, "mf_weight_grads: item %d has a null pointer", i);
+    if ((a.g_stride & 3) || (a.x_stride & 3) || (reinterpret_cast<uintptr_t>(a.G) & 15) || (reinterpret_cast<uintptr_t>(a.X) & 15))
+      return fail(MF_E_INVALID, "mf_weight_grads: item %d operands must be 16-byte aligned with strides that are multiples of 4 floats", i);
+    WgItem& it = p.it[i];
+    it.G = a.G; it.g_stride = a.g_stride; it.X = a.X; it.x_stride = a.x_stride;
+    it.shape = sh; it.want_bias = a.db ? 1 : 0; it.dW = a.dW; it.db = a.db;
+    it.cost0 = cost;
+    cost += p.stages * wg_stage_cost(sh);
+  }
+  p.total_cost = cost;
+  scratch_floats = 0;
+  for (int i = 0; i < n; ++i) {
+    WgItem& it = p.it[i];
+    int first = -1, last = -1;
+    for (int w = 0; w < p.grid; ++w) {
+      long long b, e;
+      wg_range(p.total_cost, p.grid, w, it.cost0, wg_stage_cost(it.shape), p.stages, b, e);
+      if (b < e) { if (first < 0) first = w; last = w; }
+    }
+    it.slot0 = first < 0 ? 0 : first;
+    it.n_slots = first < 0 ? 0 : last - first + 1;
+    it.part_off = scratch_floats;
+    scratch_floats += (long long)it.n_slots * wg_out_floats(it.shape);
+  }
+  return MF_OK;
+}
+
+}  // namespace mf
+
+using namespace mf;
+
+extern "C" int64_t mf_weight_grads_scratch_bytes(const mf_wgrad_item* items, int32_t n_items, int64_t P) {
+  WgParams p;
+  long long fl = 0;
+  if (!items || P < 0 || wg_plan(items, n_items, P, p, fl) != MF_OK) return -1;
+  return fl * 4 + 16;
+}
+
+extern "C" int32_t mf_weight_grads(const mf_wgrad_item* items, int32_t n_items, int64_t P, void* scratch, void* stream) {
+  if (!items || P < 0) return fail(MF_E_INVALID, "mf_weight_grads: null argument");
+  if (n_items == 0) return MF_OK;
+  WgParams p;
+  long long fl = 0;
+  const int rc = wg_plan(items, n_items, P, p, fl);
+  if (rc != MF_OK) return rc;
+  if (fl > 0 && !scratch) return fail(MF_E_INVALID, "mf_weight_grads: scratch buffer missing");
+  p.scratch = static_cast<float*>(scratch);
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  if (P > 0) {
+    int lds = ShapeA::SLOT_BYTES;
+    if (ShapeB::SLOT_BYTES > lds) lds = ShapeB::SLOT_BYTES;
+    if (ShapeC::SLOT_BYTES > lds) lds = ShapeC::SLOT_BYTES;
+    if (ShapeD::SLOT_BYTES > lds) lds = ShapeD::SLOT_BYTES;
+    if (ShapeE::SLOT_BYTES > lds) lds = ShapeE::SLOT_BYTES;
+    lds *= 3;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+      return fail(MF_E_LAUNCH, "mf_weight_grads: cannot reserve %d bytes of LDS", lds);
+    hipLaunchKernelGGL(wgrad_kernel, dim3(p.grid), dim3(kThreads), lds, st, p);
+  }
+  int maxf = 0;
+  for (int i = 0; i < n_items; ++i) if (wg_out_floats(p.it[i].shape) > maxf) maxf = wg_out_floats(p.it[i].shape);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((maxf + 255) / 256, n_items), dim3(256), 0, st, p);
+  return check_launch("mf_weight_grads");
+}
