@@ -17,6 +17,7 @@
 #include "mf_host.hpp"
 #include "mf_layout.hpp"
 #include "mf_nets.hpp"
+#include <cstdlib>
 
 namespace mf {
 
@@ -122,7 +123,7 @@ MF_D void bwd_layer(const f32x4 (&in)[NKI], const float (&sig)[kBwdSigSteps], f3
     const uint32_t pn = st.slot_off(1) + id.lane * 16;
     f32x4 m0 = {1.f, 1.f, 1.f, 1.f}, m1 = {1.f, 1.f, 1.f, 1.f};
     auto hook = [&]() {
-      st.sync_and_dma(t + 2 < NP ? groups : nxt.groups, t == NP - 2 ? nxt.jump : nullptr, id);
+      st.template sync_and_dma<true>(t + 2 < NP ? groups : nxt.groups, t == NP - 2 ? nxt.jump : nullptr, id);
       if constexpr (MASK) {     // behind the barrier: in flight for the rest of the panel
         m0 = *reinterpret_cast<const f32x4*>(mask_row + 32 * t + 4 * id.g);
         m1 = *reinterpret_cast<const f32x4*>(mask_row + 32 * t + 16 + 4 * id.g);
@@ -155,6 +156,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_backward_kernel(BwdParams p)
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = p.dbg;
+  st.keep2 = !(p.dbg & 4);        // every panel ends with two unconditional row stores
   const uint32_t zero_bias = net.res_lds + net.L.off_bias_trunk * 4;
   const char* first = net.packed + net.L.res_bytes;
   st.start(first, bwd_groups(net.L, 0), id);
@@ -287,6 +289,7 @@ extern "C" int32_t mf_nerf_backward(const mf_nerf_desc* d, const void* packed_bw
   p.ring_off = (uint32_t)p.net.L.res_bytes;
   p.buf_bytes = (uint32_t)p.net.L.max_groups * kGroupBytes;
   p.dbg = 0;
+  if (const char* e = getenv("MF_DEBUG_FLAGS")) p.dbg = atoi(e);   // timing ablations only
   const size_t lds = p.ring_off + 3 * (size_t)p.buf_bytes;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(MF_E_LAUNCH, "mf_nerf_backward: cannot reserve %zu bytes of LDS", lds);

@@ -191,6 +191,7 @@ struct Stream {
   uint32_t buf_bytes;     // bytes per slot
   uint32_t cur;           // slot (0..2) of the panel being computed
   int dbg;                // timing-ablation switches (MF_DEBUG_FLAGS; 0 in production)
+  bool keep2;             // KEEP2 instantiations only: this wave stores two dump rows per panel
 
   MF_D uint32_t slot_off(uint32_t k) const {
     uint32_t s = cur + k;
@@ -212,9 +213,15 @@ struct Stream {
     }
     gnext += (size_t)groups * kGroupBytes;
   }
-  // barrier of the panel + launch of the DMA for the panel two ahead
+  // barrier of the panel + launch of the DMA for the panel two ahead.
+  // KEEP2 (kernels that store two rows of a dump at the end of every panel: training forward,
+  // backward chain): the wave's two youngest vector-memory operations are those stores; the VM counter
+  // retires in issue order, so vmcnt(2) already guarantees the panel DMA issued before them has landed
+  // and the stores stay in flight across the barrier instead of being drained at it.
+  template <bool KEEP2 = false>
   MF_D void sync_and_dma(int groups, const char* jump, const LaneId& id) {
-    if (!(dbg & 16)) wait_vm0();
+    if (KEEP2 && keep2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+    else if (!(dbg & 16)) wait_vm0();
     if (!(dbg & 1)) __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (jump) gnext = jump;
@@ -460,7 +467,7 @@ MF_D void trunk_layer(const NetDev& net, int layer, typename ActT<BF16>::T (&act
     const uint32_t pn = st.slot_off(1) + id.lane * 16;
     const uint32_t nb = (t + 1 < NP) ? bias_off + 32 * (t + 1) * 4 : nxt.bias_off;
     // panel two ahead: same layer while t+2 < NP, else panel (t+2-NP) of the next layer
-    auto hook = [&]() { st.sync_and_dma(t + 2 < NP ? groups : nxt.groups, t == NP - 2 ? nxt.jump : nullptr, id); };
+    auto hook = [&]() { st.template sync_and_dma<DUMP>(t + 2 < NP ? groups : nxt.groups, t == NP - 2 ? nxt.jump : nullptr, id); };
     const bool late = id.wave < kWaves / 2 && !(st.dbg & 64);
     f32x4 E, O;
     const bool prio = (st.dbg & 256) != 0;
@@ -478,6 +485,7 @@ MF_D void trunk_layer(const NetDev& net, int layer, typename ActT<BF16>::T (&act
         *reinterpret_cast<f32x4*>(dump_row + 32 * t + 4 * id.g) = E;
         *reinterpret_cast<f32x4*>(dump_row + 32 * t + 16 + 4 * id.g) = O;
       }
+      st.keep2 = __ballot(dump_row != nullptr) != 0ull;   // the wave issued the two stores
     }
     st.advance();
   }

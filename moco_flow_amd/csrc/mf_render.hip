@@ -72,6 +72,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = p.dbg;
+  st.keep2 = false;
   // the panel program of a tile: [bw NoF, fw NoF chains,] NeRF, then around again
   const NextLayer prog_first = MOCO ? follow_of(p.bw) : follow_of(nerf);
   if (MOCO) start_program(p.bw, st, carry, id);
@@ -167,6 +168,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
       if constexpr (DUMP) {
         if (valid && p.dump_acts) dump_row = p.dump_acts + (ray * S + si) * p.dump_stride;
       }
+      st.keep2 = false;      // the first panel's barrier drains everything (see Stream::sync_and_dma)
       nerf_eval<16, BF16, DUMP>(nerf, embx, ext, sigma_only, st, carry, id, prog_first, sigma, rgb, dump_row);
       if (valid && id.g == 0) {
         sbuf[srel] = make_float4(rgb[0], rgb[1], rgb[2], sigma);

@@ -16,6 +16,7 @@
 //   * db falls out of the G tile already in LDS (one column per thread).
 #include "mf_host.hpp"
 #include "mf_core.hpp"
+#include <cstdlib>
 
 namespace mf {
 
@@ -75,6 +76,7 @@ struct WgParams {
   int n_items, grid;
   long long P, stages, total_cost;
   float* scratch;
+  int dbg;                // timing-ablation switches (MF_DEBUG_FLAGS; 0 in production): 1 = no half-stage stagger
 };
 
 // stage range [b, e) of item `it` that workgroup w owns (same integer formula on host and device)
@@ -90,29 +92,41 @@ MF_HD void wg_range(long long total, int grid, int w, long long cost0, int c, lo
 
 MF_D void lds_zero(uint32_t byte_off) { *(float*)(smem + byte_off) = 0.f; }
 
+// Running source of one segment: this wave's two rows (wave, wave + 8) of the next stage to fetch.
+// Held in registers -- re-reading the item from kernarg memory at every stage put four dependent
+// s_load round trips between the barrier and the first MFMAs (measured 12 % of a 256x256 stage).
+struct WgSource {
+  const char* g;            // G row `wave` of the next stage (+ lane * 16)
+  const char* x;            // X row `wave` of the next stage (+ lane * 16)
+  long long g_stage, x_stage, g_half, x_half;   // byte steps: one stage (16 rows), half a stage (8 rows)
+  long long row;            // sample index of that row
+};
+
 template <class S>
-MF_D void wg_load_stage(const WgItem& it, long long stage, long long P, uint32_t slot, const LaneId& id) {
+MF_D void wg_load_stage(WgSource& src, long long P, uint32_t slot, const LaneId& id) {
 #pragma unroll
   for (int k = 0; k < 2; ++k) {
     const int rr = id.wave + 8 * k;
-    const long long s = stage * kWgStage + rr;
     const uint32_t dg = slot + rr * S::PG * 4, dx = slot + kWgStage * S::PG * 4 + rr * S::PX * 4;
-    if (s < P) {
-      const char* gsrc = reinterpret_cast<const char*>(it.G + s * it.g_stride);
-      const char* xsrc = reinterpret_cast<const char*>(it.X + s * it.x_stride);
-      if (id.lane < S::GW / 4) glds16(gsrc + id.lane * 16, dg);
+    if (src.row + 8 * k < P) {
+      const char* gsrc = src.g + (k ? src.g_half : 0);
+      const char* xsrc = src.x + (k ? src.x_half : 0);
+      if (id.lane < S::GW / 4) glds16(gsrc, dg);
 #pragma unroll
       for (int c0 = 0; c0 < S::NIN / 4; c0 += 64)
-        if (c0 + id.lane < S::NIN / 4) glds16(xsrc + (c0 + id.lane) * 16, dx + c0 * 16);
+        if (c0 + id.lane < S::NIN / 4) glds16(xsrc + c0 * 16, dx + c0 * 16);
     } else {      // past the last sample: the rows contribute nothing
       for (int c = id.lane; c < S::GW; c += 64) lds_zero(dg + c * 4);
       for (int c = id.lane; c < S::NIN; c += 64) lds_zero(dx + c * 4);
     }
   }
+  src.g += src.g_stage;
+  src.x += src.x_stage;
+  src.row += kWgStage;
 }
 
 template <class S>
-MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, float* part, const LaneId& id) {
+MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, float* part, const LaneId& id, int dbg) {
   constexpr int WR = S::WR, WC = S::WC;
   const int tid = threadIdx.x;
   const int wr = id.wave / S::WAVES_C, wc = id.wave % S::WAVES_C;
@@ -132,19 +146,38 @@ MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, 
 #pragma unroll
     for (int b = 0; b < WC; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
   float bsum = 0.f;
-  wg_load_stage<S>(it, sb, P, 0, id);
-  if (sb + 1 < se) wg_load_stage<S>(it, sb + 1, P, S::SLOT_BYTES, id);
+  const bool want_bias = it.want_bias != 0 && tid < S::NOUT;
+  WgSource src;
+  {
+    const long long gs = it.g_stride * 4, xs = it.x_stride * 4;
+    src.row = sb * kWgStage + id.wave;
+    src.g = reinterpret_cast<const char*>(it.G) + src.row * gs + id.lane * 16;
+    src.x = reinterpret_cast<const char*>(it.X) + src.row * xs + id.lane * 16;
+    src.g_stage = gs * kWgStage; src.x_stage = xs * kWgStage;
+    src.g_half = gs * 8; src.x_half = xs * 8;
+  }
+  wg_load_stage<S>(src, P, 0, id);
+  if (sb + 1 < se) wg_load_stage<S>(src, P, S::SLOT_BYTES, id);
   uint32_t cur = 0;
   // lane (i = lane & 15, kg = lane >> 4), MFMA step m: sample row 4*kg + m of the stage
   const uint32_t aoff = ((4 * id.g) * S::PG + row0 + id.j) * 4;
   const uint32_t boff = kWgStage * S::PG * 4 + ((4 * id.g) * S::PX + col0 + id.j) * 4;
+  // One barrier per stage.  At barrier `st` the data of stage st+1 is already complete (every wave
+  // drained its share before arriving at barrier st-1 ... st), so the barrier may sit anywhere inside
+  // stage st: waves 4-7 take it at the start, waves 0-3 (their SIMD partners) in the middle, which
+  // keeps the two waves of a SIMD half a stage out of phase -- one is always in MFMA-dense code while
+  // the other crosses a stage boundary (barrier, DMA issue, first fragment reads).
+  const bool late = id.wave < kWaves / 2 && !(dbg & 1);
   for (long long st = sb; st < se; ++st) {
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (st + 2 < se) wg_load_stage<S>(it, st + 2, P, (cur >= 1 ? cur - 1 : 2) * S::SLOT_BYTES, id);
     const uint32_t base = cur * S::SLOT_BYTES;
-    if (it.want_bias && tid < S::NOUT) {
+    auto hook = [&]() {
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      if (st + 2 < se) wg_load_stage<S>(src, P, (cur >= 1 ? cur - 1 : 2) * S::SLOT_BYTES, id);
+    };
+    if (!late || st == sb) hook();      // (a segment's first stage has no earlier barrier to rely on)
+    if (want_bias) {
 #pragma unroll
       for (int s = 0; s < kWgStage; ++s) bsum += lds_f(base + (s * S::PG + tid) * 4);
     }
@@ -156,6 +189,7 @@ MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, 
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int c = m & 1, n = c ^ 1;
+      if (m == 2 && late && st != sb) hook();
       if (m + 1 < 4) {
 #pragma unroll
         for (int t = 0; t < WR; ++t) a[n][t] = lds_f(base + aoff + ((m + 1) * S::PG + 16 * t) * 4);
@@ -190,11 +224,11 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WgParams p) {
     if (b >= e) continue;
     float* part = p.scratch + it.part_off + (long long)(w - it.slot0) * wg_out_floats(it.shape);
     switch (it.shape) {
-      case 0: wg_segment<ShapeA>(it, b, e, p.P, part, id); break;
-      case 1: wg_segment<ShapeB>(it, b, e, p.P, part, id); break;
-      case 2: wg_segment<ShapeC>(it, b, e, p.P, part, id); break;
-      case 3: wg_segment<ShapeD>(it, b, e, p.P, part, id); break;
-      default: wg_segment<ShapeE>(it, b, e, p.P, part, id); break;
+      case 0: wg_segment<ShapeA>(it, b, e, p.P, part, id, p.dbg); break;
+      case 1: wg_segment<ShapeB>(it, b, e, p.P, part, id, p.dbg); break;
+      case 2: wg_segment<ShapeC>(it, b, e, p.P, part, id, p.dbg); break;
+      case 3: wg_segment<ShapeD>(it, b, e, p.P, part, id, p.dbg); break;
+      default: wg_segment<ShapeE>(it, b, e, p.P, part, id, p.dbg); break;
     }
   }
 }
@@ -294,6 +328,7 @@ extern "C" int32_t mf_weight_grads(const mf_wgrad_item* items, int32_t n_items, 
   if (rc != MF_OK) return rc;
   if (fl > 0 && !scratch) return fail(MF_E_INVALID, "mf_weight_grads: scratch buffer missing");
   p.scratch = static_cast<float*>(scratch);
+  if (const char* e = getenv("MF_DEBUG_FLAGS")) p.dbg = atoi(e);
   hipStream_t st = static_cast<hipStream_t>(stream);
   if (P > 0) {
     int lds = ShapeA::SLOT_BYTES;

@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Micro-benchmark of mf_weight_grads (and mf_nerf_backward) on the stage-1 fine-pass shape
+(5120 rays x 256 samples): per-shape item sets, to calibrate the scheduler's cost model and to track
+the kernels' MFMA efficiency.  Usage: bench_wgrad.py [P]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import moco_flow_amd as M
+from moco_flow_amd import autograd as A
+
+P = int(sys.argv[1]) if len(sys.argv) > 1 else 5120 * 256
+dev = torch.device("cuda")
+D, W = 8, 256
+stride = (D + 1) * W + W // 2
+acts = torch.randn(P, stride, device=dev)
+gpre = torch.randn((P + 127) // 128 * 128, stride, device=dev)[:P]
+ghead = torch.randn(P, 4, device=dev)
+emb64 = torch.randn(P, 64, device=dev)
+ext32 = torch.randn(P, 32, device=dev)
+sl = lambda t, l, w=W: t[:, l * W:l * W + w]
+
+
+def timeit(f, n=5):
+    f(); torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n):
+        f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
+
+
+sets = {
+    "A x9 (256x256)": [(sl(gpre, l), sl(acts, l - 1), 256, 256, True) for l in range(1, 9)] + [(sl(gpre, 8), sl(acts, 7), 256, 256, True)],
+    "A x1": [(sl(gpre, 1), sl(acts, 0), 256, 256, True)],
+    "B x2 (256x64)": [(sl(gpre, 0), emb64, 256, 64, True), (sl(gpre, 4), emb64, 256, 64, False)],
+    "C x1 (128x256)": [(sl(gpre, 9, 128), sl(acts, 8), 128, 256, True)],
+    "D x1 (128x32)": [(sl(gpre, 9, 128), ext32, 128, 32, False)],
+    "E x1 (4x640)": [(ghead, acts[:, 7 * W:7 * W + 640], 4, 640, True)],
+}
+sets["all 13"] = sum((sets[k] for k in ("A x9 (256x256)", "B x2 (256x64)", "C x1 (128x256)", "D x1 (128x32)", "E x1 (4x640)")), [])
+flops = lambda jobs: sum(2.0 * P * a[2] * a[3] for a in jobs)
+byts = lambda jobs: sum(4.0 * P * (a[2] + a[3]) for a in jobs)
+print(f"P = {P} samples")
+for k, jobs in sets.items():
+    ms = timeit(lambda: A.weight_grads(jobs, P, dev))
+    print(f"  {k:18s}: {ms:7.3f} ms  {flops(jobs)/ms/1e9:7.1f} TFLOP/s  {byts(jobs)/ms/1e9:6.2f} TB/s"
+          f"  ({ms/len(jobs)*1e6/((P+15)//16)*256*2.4/1e3:7.0f} CU-cycles/stage/item @2.4GHz)")
+# correctness spot check against library GEMMs
+jobs = sets["all 13"]
+res = A.weight_grads(jobs, P, dev)
+worst = 0.0
+for (G, X, no, ni, b), (dW, db) in zip(jobs, res):
+    ref = G.t() @ X
+    worst = max(worst, float((dW[:no] - ref).abs().max() / ref.abs().max()))
+    if b:
+        rb = G.sum(0)
+        worst = max(worst, float((db[:no] - rb).abs().max() / rb.abs().max()))
+print(f"  max-rel vs library GEMM: {worst:.2e}")
