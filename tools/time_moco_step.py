@@ -1,0 +1,61 @@
+#!/usr/bin/env python3
+"""Time one training step of the joint MoCo-Flow stage (c2f.yaml shape: N_rand = 1024 rays x (128 coarse
++ 256 fine) samples, backward NoF -> NeRF(ind) with local + global consensus chains, trainer_moco_flow.py
+:200-216, 317-328) through the drop-in (HIP forward + HIP/torch backward) and with everything in
+PyTorch-ROCm eager ops (TRAIN_FORWARD=torch: what the reference itself would run on this GPU)."""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import moco_flow_amd as M
+from moco_flow_amd import synth, rendering
+rendering.STRICT_RNG = False
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+S, Mi = 128, 128
+dev = torch.device("cuda")
+
+
+def load(m, sd):
+    m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}); return m.to(dev)
+
+
+nerfs = [load(M.NeRF(8, 256, 63, [4], "ind", 5), synth.nerf_state(0, extra_feat_type="ind", extra_feat_dim=5, regime="dense", tag=t)) for t in ("coarse", "fine")]
+nofs = [load(M.NoF(4, 128, 33, [2], "ind", 33, True), synth.nof_state(0, use_quat=True, tag=t, head_scale=0.25)) for t in ("bw", "fw")]
+embs = [M.Embedding(3, 10), M.Embedding(1, 2), None]
+nof_embs = [M.Embedding(3, 5), M.Embedding(1, 16)]
+r, b = synth.rays(0, N, chained=True)
+rays, bg = torch.from_numpy(r).to(dev), torch.from_numpy(b).to(dev)
+gt = torch.rand(N, 3, device=dev)
+crit = M.get_loss(dict(type="MSE"))
+kw = dict(nof_embeddings=nof_embs, nof_models=nofs, chain_local=True, chain_global=True, N_samples=S,
+          N_importance=Mi, noise_std=0, perturb=1.0)
+mods = nerfs + nofs
+
+
+def timeit(f, n=5):
+    f(); torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(n):
+        f()
+    torch.cuda.synchronize(); return (time.perf_counter() - t) / n * 1e3
+
+
+def fwd_only():
+    with torch.no_grad():
+        M.render_rays(rays, bg, embs, nerfs, **kw)
+
+
+def fwd_bwd():
+    for m in mods:
+        m.zero_grad(set_to_none=True)
+    res = M.render_rays(rays, bg, embs, nerfs, **kw)
+    loss = crit(res, gt)
+    for k in ("nof_local_disp_coarse", "nof_global_disp_coarse", "nof_local_disp_fine", "nof_global_disp_fine"):
+        loss = loss + 0.1 * res[k].mean()            # consensus terms, trainer_moco_flow.py:317-328
+    loss.backward()
+
+
+print(f"N_rand={N} rays x ({S} + {S+Mi}) samples = {N*(2*S+Mi)/1e6:.2f} M samples/step, bw NoF + local + global chains")
+print(f"  HIP forward (no_grad)            : {timeit(fwd_only):8.2f} ms")
+print(f"  HIP forward + backward (shipped) : {timeit(fwd_bwd):8.2f} ms")
+if os.environ.get("MF_ONLY") != "hipbwd":
+    rendering.set_train_forward("torch")
+    print(f"  TRAIN_FORWARD=torch fwd+bwd      : {timeit(fwd_bwd):8.2f} ms")
