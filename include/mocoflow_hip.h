@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 4
+#define MF_ABI_VERSION 5
 
 enum {
   MF_OK = 0,
@@ -145,12 +145,13 @@ int32_t mf_nerf_backward(const mf_nerf_desc* d, const void* packed_bwd, int64_t 
  *     dW_i = G_i[:P]^T X_i[:P]   (n_out x n_in),      db_i = sum_s G_i[s]   (n_out)
  * G_i / X_i: fp32 row-major device matrices (column slices of the mf_nerf_backward gradient buffer, of
  * the forward's activation dump, or of the embedded inputs), 16-byte aligned, strides multiples of 4
- * floats.  Supported blocks (n_out x n_in): 256x256, 256x64, 128x256, 128x32, and 4x640 (the two heads
- * at once: G = ghead (P,4), X = dump columns [h_D | final | extra]).  dW is written as a dense
+ * floats.  Supported blocks (n_out x n_in): NeRF 256x256, 256x64, 128x256, 128x32 and 4x640 (the two heads
+ * at once: G = ghead (P,4), X = dump columns [h_D | final | extra]); NoF 128x128, 128x80 (embedded input,
+ * 66 -> 80) and 12x128 (head, G = d T padded to 12 columns).  dW is written as a dense
  * (max(n_out,16), n_in) matrix, db (optional, may be NULL) as max(n_out,16) floats.  Deterministic
  * (fixed-order partial sums through `scratch`, no atomics).  Replaces the dW/db halves of torch's
  * addmm backward for models/nerf.py:78-102. */
-#define MF_WG_MAX_ITEMS 16
+#define MF_WG_MAX_ITEMS 32
 typedef struct mf_wgrad_item {
   const float* G; int64_t g_stride; int32_t n_out;
   const float* X; int64_t x_stride; int32_t n_in;
@@ -158,6 +159,23 @@ typedef struct mf_wgrad_item {
 } mf_wgrad_item;
 int64_t mf_weight_grads_scratch_bytes(const mf_wgrad_item* items, int32_t n_items, int64_t P);
 int32_t mf_weight_grads(const mf_wgrad_item* items, int32_t n_items, int64_t P, void* scratch, void* stream);
+
+/* ---- backward of one NoF evaluation on points (rendering.py:49-83 + nof.py:69-82; ABI v5) ---------
+ * mf_nof_points_dump: pts (P,3), per-ray image index ind[ray * ind_stride] with ray = sample / S ->
+ *   out (P,3) and the dump the backward reads: acts (P,stride) = [h_1 .. h_D | T padded to 16],
+ *   emb (P,80) = the embedded input [xyz 33 | ind 33 | 0] in the reference's column order.
+ * mf_nof_bwd_packed_bytes / mf_nof_pack_bwd: transposed fragment stream (W=128, at most one skip layer).
+ * mf_nof_backward: g_out (P,3) = dL/d out -> g_pts (P,3, may be NULL) = dL/d pts and
+ *   gpre (round_up(P,128), stride) = [d z_0 .. d z_{D-1} | d T padded to 16] for mf_weight_grads. */
+int32_t mf_nof_points_dump(const mf_nof_desc* d, const void* packed, const mf_embedding* emb_xyz,
+                           const mf_embedding* emb_ind, const float* pts, const float* ind,
+                           int64_t ind_stride, int32_t S, int64_t P, float* out, float* acts,
+                           int64_t stride, float* emb, void* stream);
+int64_t mf_nof_bwd_packed_bytes(const mf_nof_desc* d);
+int32_t mf_nof_pack_bwd(const mf_nof_desc* d, void* packed, void* stream);
+int32_t mf_nof_backward(const mf_nof_desc* d, const void* packed_bwd, const mf_embedding* emb_xyz, int64_t P,
+                        const float* pts, const float* acts, int64_t stride, const float* g_out,
+                        float* gpre, float* g_pts, void* stream);
 
 /* Fused point query: xyz (B,3) -> [backward NoF at image index ind] -> positional encoding -> NeRF
  * trunk -> raw sigma (B,), one launch.  Replaces the per-chunk module sequence forward_nof /

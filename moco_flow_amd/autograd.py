@@ -244,7 +244,8 @@ def nerf_backward_hip(m, g_out, acts, rgbsig):
     return gpre[:P], ghead
 
 
-_WG_BLOCK = {(256, 256): (256, 256), (256, 64): (256, 64), (128, 256): (128, 256), (128, 32): (128, 32), (4, 640): (16, 640)}
+_WG_BLOCK = {(256, 256): (256, 256), (256, 64): (256, 64), (128, 256): (128, 256), (128, 32): (128, 32), (4, 640): (16, 640),
+             (128, 128): (128, 128), (128, 80): (128, 80), (12, 128): (16, 128)}
 
 
 def weight_grads(jobs, P, dev):
@@ -277,6 +278,120 @@ def weight_grads(jobs, P, dev):
     with torch.cuda.device(dev):
         L.check(lib.mf_weight_grads(items, n, P, scratch.data_ptr(), L.current_stream(dev)), "mf_weight_grads")
     return outs
+
+
+# ------------------------------------------------------------------ NoF evaluation on points, HIP forward + backward
+NOF_BACKWARD = "hip"      # "hip": mf_nof_points_dump / mf_nof_backward / mf_weight_grads; "torch": differentiable recompute
+
+
+def set_nof_backward(kind: str) -> None:
+    global NOF_BACKWARD
+    if kind not in ("hip", "torch"):
+        raise ValueError(f"nof backward: {kind} not valid (hip | torch)")
+    NOF_BACKWARD = kind
+
+
+def nof_hip_supported(m, nof_embs) -> bool:
+    skips = [s for s in m.skips if 0 < s < m.D]
+    return (m.W == 128 and m.in_channels_xyz == 33 and m.extra_feat_dim == 33 and len(skips) <= 1
+            and 2 <= m.D <= 8 and nof_embs[0].N_freqs <= 5 and nof_embs[1].N_freqs == 16)
+
+
+class NofPoints(torch.autograd.Function):
+    """out = NoF([embed(pts) | embed(ind)], pts) for free points (rendering.py:49-83 + nof.py:69-82) with
+    the image index given per RAY (sample s belongs to ray s // S).  Forward: mf_nof_points_dump (the
+    fused MFMA core, storing the layer outputs); backward: mf_nof_backward (transform, head, W^T chain,
+    embedding chain rule -> d pts) + mf_weight_grads (dW / db of every layer).  The consensus chains of
+    render_rays are compositions of this node, so torch only sees 1-5 of them per pass."""
+
+    @staticmethod
+    def forward(ctx, m, nof_embs, ray_ind, S, pts, *params):
+        import ctypes as C
+        from . import _lib as L
+        P, dev = pts.shape[0], pts.device
+        pts = pts.detach().contiguous().float()
+        desc, buf = m.packed()
+        stride = m.D * m.W + 16
+        out = torch.empty((P, 3), device=dev, dtype=torch.float32)
+        acts = torch.empty((P, stride), device=dev, dtype=torch.float32)
+        emb = torch.empty((P, 80), device=dev, dtype=torch.float32)
+        ex, ei = nof_embs[0].descriptor(), nof_embs[1].descriptor()
+        with torch.cuda.device(dev):
+            L.check(L.lib().mf_nof_points_dump(C.byref(desc), buf.data_ptr(), C.byref(ex), C.byref(ei), pts.data_ptr(),
+                                               ray_ind.data_ptr(), ray_ind.stride(0), S, P, out.data_ptr(),
+                                               acts.data_ptr(), stride, emb.data_ptr(), L.current_stream(dev)),
+                    "mf_nof_points_dump")
+        ctx.m, ctx.ex, ctx.stride = m, ex, stride
+        ctx.save_for_backward(pts, acts, emb)
+        ctx.pts_grad = pts.requires_grad or True
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        import ctypes as C
+        from . import _lib as L
+        m, stride = ctx.m, ctx.stride
+        pts, acts, emb = ctx.saved_tensors
+        P, dev = pts.shape[0], pts.device
+        D, W = m.D, m.W
+        names = [n for n, _ in m.named_parameters()]
+        req = {n: p.requires_grad for n, p in m.named_parameters()}
+        grads = {n: None for n in names}
+        need_pts = ctx.needs_input_grad[4]
+        with torch.no_grad():
+            desc, buf = m.packed_bwd()
+            g_out = g_out.contiguous().float()
+            gpre = torch.empty(((P + 127) // 128 * 128, stride), device=dev, dtype=torch.float32)
+            g_pts = torch.empty((P, 3), device=dev, dtype=torch.float32) if need_pts else None
+            with torch.cuda.device(dev):
+                L.check(L.lib().mf_nof_backward(C.byref(desc), buf.data_ptr(), C.byref(ctx.ex), P, pts.data_ptr(),
+                                                acts.data_ptr(), stride, g_out.data_ptr(), gpre.data_ptr(),
+                                                g_pts.data_ptr() if need_pts else None, L.current_stream(dev)),
+                        "mf_nof_backward")
+            gpre = gpre[:P]
+            gslot = lambda l: gpre[:, l * W:(l + 1) * W]
+            h = lambda l: acts[:, l * W:(l + 1) * W]
+            cin = m.in_channels_xyz + m.extra_feat_dim
+            wants = lambda prefix: req[prefix + ".weight"] or req[prefix + ".bias"]
+            jobs, sinks = [], []
+            for l in range(D):
+                name = f"nof_encoding_{l+1}.0"
+                if not wants(name):
+                    continue
+                blocks = []
+                if l == 0 or l in m.skips:
+                    jobs.append((gslot(l), emb, 128, 80, l == 0))
+                    blocks.append((len(jobs) - 1, slice(0, cin)))
+                if l > 0:
+                    jobs.append((gslot(l), h(l - 1), 128, 128, True))
+                    blocks.append((len(jobs) - 1, slice(0, W)))
+                sinks.append((name, blocks, blocks[-1][0]))
+            head_job = None
+            if wants("nof_encoding_final"):
+                jobs.append((gpre[:, D * W:D * W + 12], h(D - 1), 12, 128, True))
+                head_job = len(jobs) - 1
+            res = weight_grads(jobs, P, dev)
+            for prefix, blocks, bias_from in sinks:
+                if req[prefix + ".weight"]:
+                    parts = [res[j][0][:, cs] for j, cs in blocks]
+                    grads[prefix + ".weight"] = parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, 1)
+                if req[prefix + ".bias"]:
+                    grads[prefix + ".bias"] = res[bias_from][1].clone()
+            if head_job is not None:
+                nh = m.nof_encoding_final.weight.shape[0]
+                if req["nof_encoding_final.weight"]:
+                    grads["nof_encoding_final.weight"] = res[head_job][0][:nh].contiguous()
+                if req["nof_encoding_final.bias"]:
+                    grads["nof_encoding_final.bias"] = res[head_job][1][:nh].clone()
+        return (None, None, None, None, g_pts) + tuple(grads[n] for n in names)
+
+
+def nof_points(xyz, ray_ind, nof_embs, m):
+    """_nof_points with the HIP forward/backward node when the configuration is built (else torch ops)."""
+    N, S = xyz.shape[0], xyz.shape[1]
+    if NOF_BACKWARD == "hip" and nof_hip_supported(m, nof_embs) and N * S > 0:
+        return NofPoints.apply(m, nof_embs, ray_ind, S, xyz.reshape(-1, 3), *m.parameters()).view(N, S, 3)
+    return _nof_points(xyz, ray_ind, nof_embs, m)
 
 
 class NerfSamples(torch.autograd.Function):

@@ -17,11 +17,10 @@
 #include "mf_host.hpp"
 #include "mf_layout.hpp"
 #include "mf_nets.hpp"
+#include "mf_bwd.hpp"
 #include <cstdlib>
 
 namespace mf {
-
-constexpr int kBwdSigSteps = 4;   // k-steps of the d_sigma block in front of the final^T layer
 
 // Backward "network" of a NeRF(D, W=256): layer 0 = extra_encoding^T (K = W/2), layer 1 =
 // xyz_encoding_final^T (+ the d_sigma block), layers 2..D = trunk layers D-1..1 transposed.
@@ -110,43 +109,6 @@ struct BwdParams {
   int dbg;
 };
 
-// One W-wide layer of the chain: out = W^T-panels * [sig ; in], times the ReLU mask of the forward
-// activation it is the gradient of; stored to this lane's row of the gradient buffer.
-template <int MODE, int NKI, bool MASK>
-MF_D void bwd_layer(const f32x4 (&in)[NKI], const float (&sig)[kBwdSigSteps], f32x4 (&out)[16], int groups,
-                    uint32_t zero_bias, Stream& st, CarryT<Pipe<false>::PD>& carry, const LaneId& id,
-                    const NextLayer& nxt, const float* mask_row, float* store_row) {
-  constexpr int NP = 8;
-#pragma unroll
-  for (int t = 0; t < NP; ++t) {
-    const uint32_t p = st.slot_off(0) + id.lane * 16;
-    const uint32_t pn = st.slot_off(1) + id.lane * 16;
-    f32x4 m0 = {1.f, 1.f, 1.f, 1.f}, m1 = {1.f, 1.f, 1.f, 1.f};
-    auto hook = [&]() {
-      st.template sync_and_dma<true>(t + 2 < NP ? groups : nxt.groups, t == NP - 2 ? nxt.jump : nullptr, id);
-      if constexpr (MASK) {     // behind the barrier: in flight for the rest of the panel
-        m0 = *reinterpret_cast<const f32x4*>(mask_row + 32 * t + 4 * id.g);
-        m1 = *reinterpret_cast<const f32x4*>(mask_row + 32 * t + 16 + 4 * id.g);
-      }
-    };
-    const bool late = id.wave < kWaves / 2;
-    f32x4 E, O;
-    out_pair<MODE, NKI, kBwdSigSteps, false>(carry, in, sig, p, pn, zero_bias, id.g, late, hook, -__builtin_inff(), E, O);
-    if constexpr (MASK) {
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        E[i] = m0[i] > 0.f ? E[i] : 0.f;
-        O[i] = m1[i] > 0.f ? O[i] : 0.f;
-      }
-    }
-    *reinterpret_cast<f32x4*>(store_row + 32 * t + 4 * id.g) = E;
-    *reinterpret_cast<f32x4*>(store_row + 32 * t + 16 + 4 * id.g) = O;
-    out[2 * t] = E;
-    out[2 * t + 1] = O;
-    st.advance();
-  }
-}
-
 __global__ __launch_bounds__(kThreads, 2) void nerf_backward_kernel(BwdParams p) {
   const LaneId id;
   const NetDev net = p.net;
@@ -156,7 +118,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_backward_kernel(BwdParams p)
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = p.dbg;
-  st.keep2 = !(p.dbg & 4);        // every panel ends with two unconditional row stores
+  st.keep2 = false;
   const uint32_t zero_bias = net.res_lds + net.L.off_bias_trunk * 4;
   const char* first = net.packed + net.L.res_bytes;
   st.start(first, bwd_groups(net.L, 0), id);
@@ -205,15 +167,15 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_backward_kernel(BwdParams p)
     const float sig[kBwdSigSteps] = {id.g == 0 ? go.w : 0.f, 0.f, 0.f, 0.f};
     f32x4 a[16], b[16];
     // layer 0: d_g = W_e[:, :W]^T d_e          (no activation on xyz_encoding_final)
-    bwd_layer<2, 8, false>(de, nosig, a, bwd_groups(net.L, 0), zero_bias, st, carry, id, next_of(0), nullptr,
+    bwd_layer<2, 8, 8, false, true>(de, nosig, a, bwd_groups(net.L, 0), zero_bias, st, carry, id, next_of(0), nullptr,
                            grow + (long long)D * W);
     // layer 1: d_z_{D-1} = (W_f^T d_g + w_sigma d_sigma) * [h_D > 0]
-    bwd_layer<3, 16, true>(a, sig, b, bwd_groups(net.L, 1), zero_bias, st, carry, id, next_of(1),
+    bwd_layer<3, 16, 8, true, true>(a, sig, b, bwd_groups(net.L, 1), zero_bias, st, carry, id, next_of(1),
                            arow + (long long)(D - 1) * W, grow + (long long)(D - 1) * W);
     // layers 2..D: d_z_{l-1} = (W_l^T d_z_l) * [h_l > 0],  l = D-1 .. 1
     for (int i = 2; i <= D; ++i) {
       const int l = D + 1 - i;
-      bwd_layer<2, 16, true>(b, nosig, a, bwd_groups(net.L, i), zero_bias, st, carry, id, next_of(i),
+      bwd_layer<2, 16, 8, true, true>(b, nosig, a, bwd_groups(net.L, i), zero_bias, st, carry, id, next_of(i),
                              arow + (long long)(l - 1) * W, grow + (long long)(l - 1) * W);
 #pragma unroll
       for (int t = 0; t < 16; ++t) b[t] = a[t];

@@ -40,6 +40,9 @@ using ShapeB = WgShape<256, 64, 2, 4, 1, 256>;    // hidden x embedded xyz (63 -
 using ShapeC = WgShape<128, 256, 4, 4, 4, 128>;   // extra_encoding x final
 using ShapeD = WgShape<128, 32, 1, 2, 1, 128>;    // extra_encoding x embedded dir / ind (<= 32)
 using ShapeE = WgShape<16, 640, 1, 5, 8, 4>;      // heads: [d rgb(3), d sigma] x [h_D | final | extra]
+using ShapeF = WgShape<128, 128, 2, 4, 2, 128>;   // NoF hidden x hidden
+using ShapeG = WgShape<128, 80, 1, 5, 1, 128>;    // NoF hidden x embedded input (66 -> 80)
+using ShapeH = WgShape<16, 128, 1, 1, 8, 12>;     // NoF head: d T (9 | 3, padded 12) x h_D
 
 // modelled cost of one stage, in CU cycles: max(MFMA time, HBM time at ~7 B/cycle/CU) + fixed part
 MF_HD int wg_stage_cost(int shape) {
@@ -48,7 +51,10 @@ MF_HD int wg_stage_cost(int shape) {
     case 1: return 2925 + 400;
     case 2: return 4096 + 400;
     case 3: return 1460 + 400;
-    default: return 5900 + 400;
+    case 4: return 5900 + 400;
+    case 5: return 2340 + 400;
+    case 6: return 1900 + 400;
+    default: return 1300 + 400;
   }
 }
 MF_HD int wg_out_floats(int shape) {
@@ -57,7 +63,10 @@ MF_HD int wg_out_floats(int shape) {
     case 1: return ShapeB::OUT_FLOATS;
     case 2: return ShapeC::OUT_FLOATS;
     case 3: return ShapeD::OUT_FLOATS;
-    default: return ShapeE::OUT_FLOATS;
+    case 4: return ShapeE::OUT_FLOATS;
+    case 5: return ShapeF::OUT_FLOATS;
+    case 6: return ShapeG::OUT_FLOATS;
+    default: return ShapeH::OUT_FLOATS;
   }
 }
 
@@ -228,7 +237,10 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WgParams p) {
       case 1: wg_segment<ShapeB>(it, b, e, p.P, part, id, p.dbg); break;
       case 2: wg_segment<ShapeC>(it, b, e, p.P, part, id, p.dbg); break;
       case 3: wg_segment<ShapeD>(it, b, e, p.P, part, id, p.dbg); break;
-      default: wg_segment<ShapeE>(it, b, e, p.P, part, id, p.dbg); break;
+      case 4: wg_segment<ShapeE>(it, b, e, p.P, part, id, p.dbg); break;
+      case 5: wg_segment<ShapeF>(it, b, e, p.P, part, id, p.dbg); break;
+      case 6: wg_segment<ShapeG>(it, b, e, p.P, part, id, p.dbg); break;
+      default: wg_segment<ShapeH>(it, b, e, p.P, part, id, p.dbg); break;
     }
   }
 }
@@ -254,7 +266,10 @@ __global__ void wgrad_reduce_kernel(WgParams p) {
     case 1: nout = ShapeB::NOUT; nin = ShapeB::NIN; break;
     case 2: nout = ShapeC::NOUT; nin = ShapeC::NIN; break;
     case 3: nout = ShapeD::NOUT; nin = ShapeD::NIN; break;
-    default: nout = ShapeE::NOUT; nin = ShapeE::NIN; break;
+    case 4: nout = ShapeE::NOUT; nin = ShapeE::NIN; break;
+    case 5: nout = ShapeF::NOUT; nin = ShapeF::NIN; break;
+    case 6: nout = ShapeG::NOUT; nin = ShapeG::NIN; break;
+    default: nout = ShapeH::NOUT; nin = ShapeH::NIN; break;
   }
   if (e < nout * nin) it.dW[e] = s;
   else if (it.db) it.db[e - nout * nin] = s;
@@ -266,6 +281,9 @@ static int shape_of(const mf_wgrad_item& a) {
   if (a.n_out == 128 && a.n_in == 256) return 2;
   if (a.n_out == 128 && a.n_in == 32) return 3;
   if (a.n_out == 4 && a.n_in == 640) return 4;
+  if (a.n_out == 128 && a.n_in == 128) return 5;
+  if (a.n_out == 128 && a.n_in == 80) return 6;
+  if (a.n_out == 12 && a.n_in == 128) return 7;
   return -1;
 }
 
@@ -336,6 +354,9 @@ extern "C" int32_t mf_weight_grads(const mf_wgrad_item* items, int32_t n_items, 
     if (ShapeC::SLOT_BYTES > lds) lds = ShapeC::SLOT_BYTES;
     if (ShapeD::SLOT_BYTES > lds) lds = ShapeD::SLOT_BYTES;
     if (ShapeE::SLOT_BYTES > lds) lds = ShapeE::SLOT_BYTES;
+    if (ShapeF::SLOT_BYTES > lds) lds = ShapeF::SLOT_BYTES;
+    if (ShapeG::SLOT_BYTES > lds) lds = ShapeG::SLOT_BYTES;
+    if (ShapeH::SLOT_BYTES > lds) lds = ShapeH::SLOT_BYTES;
     lds *= 3;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
       return fail(MF_E_LAUNCH, "mf_weight_grads: cannot reserve %d bytes of LDS", lds);

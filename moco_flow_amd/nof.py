@@ -36,6 +36,7 @@ class NoF(nn.Module):
         self.nof_encoding_final = nn.Linear(W, 9 if use_quat else 3)
         self._packed = PackedWeights()
         self._packed_bf16 = PackedWeights()
+        self._packed_bwd = PackedWeights()
 
     def _build_desc(self):
         if self.extra_feat_type == "latent_code":
@@ -62,6 +63,12 @@ class NoF(nn.Module):
             d.trunk_w[i], d.trunk_b[i] = dp(lin.weight), dp(lin.bias)
         d.head_w, d.head_b = dp(self.nof_encoding_final.weight), dp(self.nof_encoding_final.bias)
         return d, keep
+
+    def packed_bwd(self):
+        """(descriptor, transposed fragment stream) for mf_nof_backward; fp32 only."""
+        lib = L.lib()
+        return self._packed_bwd.get(self, self._build_desc, lambda d, _p: lib.mf_nof_bwd_packed_bytes(d),
+                                    lambda d, _p, buf, st: lib.mf_nof_pack_bwd(d, buf, st), "NoF backward", "bwd")
 
     def packed(self, precision=L.MF_PREC_F32):
         lib = L.lib()

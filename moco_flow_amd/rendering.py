@@ -378,16 +378,16 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
         xin = p["xyz_in"]
         if nof_models is not None:
             bw = nof_models[0]
-            canon = A._nof_points(xyz, ind, nof_embs, bw)
+            canon = A.nof_points(xyz, ind, nof_embs, bw)
             if loc:
                 fw = nof_models[1]
-                recon = A._nof_points(canon, ind, nof_embs, fw)
+                recon = A.nof_points(canon, ind, nof_embs, fw)
                 out[f"nof_local_disp_{tag}"] = torch.mean(torch.abs(xyz - recon)[mask], dim=1)
             if glob:
                 cind = rays[:, 9:10]
-                a_ = A._nof_points(canon, cind, nof_embs, fw)
-                b_ = A._nof_points(a_, cind, nof_embs, bw)
-                out[f"nof_global_disp_{tag}"] = torch.mean(torch.abs(xyz - A._nof_points(b_, ind, nof_embs, fw))[mask], dim=1)
+                a_ = A.nof_points(canon, cind, nof_embs, fw)
+                b_ = A.nof_points(a_, cind, nof_embs, bw)
+                out[f"nof_global_disp_{tag}"] = torch.mean(torch.abs(xyz - A.nof_points(b_, ind, nof_embs, fw))[mask], dim=1)
             xin = canon.reshape(-1, 3)
         with torch.no_grad():
             emb_in = A._pad_to(A.embed(nerf_embs[0], p["xyz_in"]), nerf.in_channels_xyz)

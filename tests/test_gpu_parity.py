@@ -639,3 +639,35 @@ def test_explicit_nerf_backward_unit(M, kind, n_rays):
         else:
             assert relerr(got[n], q.grad) <= 1e-4, (n, relerr(got[n], q.grad))
     assert relerr(got_x, x2.grad) <= 1e-4
+
+
+@pytest.mark.parametrize("quat,n_rays,S", [(True, 40, 64), (False, 40, 64), (True, 3, 37), (True, 1, 1)])
+def test_nof_points_backward_unit(M, quat, n_rays, S):
+    """autograd.NofPoints (mf_nof_points_dump + mf_nof_backward + mf_weight_grads) against plain torch
+    autograd of the same evaluation (rendering.py:49-83 + nof.py:69-82 restated with torch ops) on the
+    same points: output to 1e-5, parameter and point gradients to 1e-4; ragged sample counts."""
+    from moco_flow_amd import autograd as A, synth
+    torch.manual_seed(1)
+    nof = M.NoF(4, 128, 33, [2], "ind", 33, quat)
+    nof.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nof_state(5, use_quat=quat, tag="bw", head_scale=0.25).items()})
+    nof = nof.cuda()
+    embs = [M.Embedding(3, 5), M.Embedding(1, 16)]
+    embs[0].weights = [1.0, 1.0, 0.5, 0.25, 0.0]            # coarse-to-fine ramp, trainer_moco_flow.py:270-305
+    rays = torch.zeros(n_rays, 10, device="cuda")
+    rays[:, 8] = torch.linspace(-0.9, 0.8, n_rays, device="cuda")
+    ind = rays[:, 8:9]
+    pts = (torch.randn(n_rays, S, 3, device="cuda") * 0.7).requires_grad_(True)
+    gout = torch.randn(n_rays, S, 3, device="cuda")
+    out = A.nof_points(pts, ind, embs, nof)
+    assert "NofPoints" in type(out.grad_fn.next_functions[0][0]).__name__          # the HIP node, not the torch recompute
+    out.backward(gout)
+    got = {n: q.grad.clone() for n, q in nof.named_parameters()}
+    got_x = pts.grad.clone()
+    nof.zero_grad(set_to_none=True)
+    p2 = pts.detach().clone().requires_grad_(True)
+    ref = A._nof_points(p2, ind, embs, nof)
+    assert relerr(out, ref) <= 1e-5
+    ref.backward(gout)
+    for n, q in nof.named_parameters():
+        assert relerr(got[n], q.grad) <= 1e-4, (n, relerr(got[n], q.grad))
+    assert relerr(got_x, p2.grad) <= 1e-4, relerr(got_x, p2.grad)
