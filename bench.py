@@ -86,6 +86,39 @@ def cpu_baseline(workload, states, rays_np, bg_np, budget_s=20.0):
                        f"torch {torch.__version__} CPU fp32"), out
 
 
+def train_leg(M, models, rays, bg, gt, kw, workload, steps=10):
+    """fwd + bwd of the same batch (reported beside, never instead of, the forward metric):
+    render_rays -> MSE -> backward through the HIP kernels (training forward with dump, mf_nerf_backward,
+    mf_weight_grads; NoF evaluations through mf_nof_points_dump / mf_nof_backward)."""
+    mods = list(models["nerfs"]) + list(models["nofs"] or [])
+    crit = M.get_loss(dict(type="MSE"))
+
+    def one():
+        for m in mods:
+            m.zero_grad(set_to_none=True)
+        res = M.render_rays(rays, bg, models["embs"], models["nerfs"], **kw)
+        loss = crit(res, gt)
+        if "nof_local_disp_coarse" in res:
+            loss = loss + 0.1 * res["nof_local_disp_coarse"].mean()
+        loss.backward()
+
+    one()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        one()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    # Linear-layer MACs x 2: forward + weight gradients (593 408 each) + input-gradient chain (557 696)
+    flops = 2 * (593408 * 2 + 557696) if workload == "nerf" else None
+    out = {"value": N_RAYS * N_SAMPLES / (ms * 1e-3), "unit": "ray-samples/s", "ms_per_step": ms, "steps": steps,
+           "what": "render_rays + MSELoss + backward (all parameter gradients), same batch as the headline"}
+    if flops:
+        out["flops_per_sample"] = flops
+        out["mfma_frac"] = N_RAYS * N_SAMPLES * flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -96,6 +129,8 @@ def main():
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
                     help="f32 = exact-fp32 MFMA (headline, config C2); bf16 = bf16 hidden GEMMs (configs C3-C5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true",
+                    help="skip the extra fwd+bwd measurement (SURVEY.md §8d: reported separately from the graded forward)")
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,6 +224,8 @@ def main():
                      "traffic_unit": "B/launch",
                      "kernel_ms": kernel_ms, "flops_per_launch": N_RAYS * N_SAMPLES * flops_per_sample},
     }
+    if rank == 0 and world == 1 and not a.no_train_leg and a.precision == "f32":
+        line["fwd_bwd"] = train_leg(M, models, rays, bg, gt, kw, a.workload)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         base, ref = cpu_baseline(a.workload, models["states"], rays_np[:N_RAYS], bg_np[:N_RAYS])
         line["cpu_baseline"] = base
