@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Summarise a tools/profile_train.sh output directory: per-kernel time per training step and, for the
+mf:: kernels, MFMA utilisation and HBM traffic per dispatch (FETCH_SIZE doubled per the gfx950 note of
+MI355X_MICROARCH.md)."""
+import csv, glob, os, re, sys
+from collections import defaultdict
+
+out = sys.argv[1]
+STEPS = 6          # the tools run 1 warm-up + 5 timed steps
+
+
+def rows(pattern):
+    for f in glob.glob(os.path.join(out, pattern), recursive=True):
+        with open(f) as fh:
+            for r in csv.DictReader(fh):
+                yield r
+
+
+short = lambda n: re.sub(r"\(.*", "", n.replace("void ", ""))[:60]
+print(open(os.path.join(out, "trace.log")).read().strip().splitlines()[-1] if os.path.exists(os.path.join(out, "trace.log")) else "")
+dur = defaultdict(list)
+for r in rows("trace/**/*kernel_trace.csv"):
+    dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+tot = sum(sum(v) for v in dur.values())
+print(f"\n== kernel time per training step (rocprofv3 --kernel-trace; {STEPS} steps) ==  total {tot/STEPS/1e6:.2f} ms/step")
+print(f"{'kernel':62s} {'calls/step':>10s} {'avg us':>9s} {'ms/step':>8s} {'%':>6s}")
+other = 0.0
+for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
+    if k.startswith("mf::") or k.startswith("void mf::") or sum(v) / tot > 0.01:
+        print(f"{short(k):62s} {len(v)/STEPS:10.1f} {sum(v)/len(v)/1e3:9.1f} {sum(v)/STEPS/1e6:8.2f} {100*sum(v)/tot:6.1f}")
+    else:
+        other += sum(v)
+print(f"{'(all other kernels: torch elementwise / copies / reductions)':62s} {'':10s} {'':9s} {other/STEPS/1e6:8.2f} {100*other/tot:6.1f}")
+
+pmc = defaultdict(lambda: defaultdict(list))
+for sub in ("pmc_mfma", "pmc_fetch", "pmc_write"):
+    for r in rows(f"{sub}/**/*counter_collection.csv"):
+        if "mf::" in r["Kernel_Name"]:
+            pmc[r["Kernel_Name"]][r["Counter_Name"]].append(float(r["Counter_Value"]))
+print("\n== PMC per dispatch (mean), mf:: kernels ==")
+for k, c in sorted(pmc.items(), key=lambda kv: -sum(dur.get(kv[0], [0]))):
+    m = {n: sum(v) / len(v) for n, v in c.items()}
+    line = f"{short(k):48s}"
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in m and m.get("GRBM_GUI_ACTIVE"):
+        cyc = m["GRBM_GUI_ACTIVE"] / 8
+        line += f" MFMA busy {m['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * cyc) * 100:5.1f} % of SIMD-cycles, {m['SQ_INSTS_VALU_MFMA_F32']:.3g} MFMA,"
+    if "FETCH_SIZE" in m:
+        line += f" HBM read {2 * m['FETCH_SIZE'] * 1024 / 1e9:.3f} GB (x2-corrected),"
+    if "WRITE_SIZE" in m:
+        line += f" write {m['WRITE_SIZE'] * 1024 / 1e9:.3f} GB"
+    print(line)
