@@ -274,6 +274,17 @@ int32_t mf_compact_mask(const float* alphas, const float* vals_a, const float* v
  * NULL for camera coordinates).  near/far/idx are the scalars make_rays broadcasts. */
 int32_t mf_make_rays(int32_t H, int32_t W, float focal, float cx, float cy, const float* c2w_host,
                      float nearv, float farv, float idx, float* rays_out, void* stream);
+/* Foreground scatter-back of the full-image drivers (MoCoFlowTrainer.render trainer_moco_flow.py:249-266,
+ * NeRFTrainer.render trainer_nerf.py:128-140), on the device: for every pixel b of the (B) image
+ *   not rendered (rays_msk[b] == 0)            -> img = background[b], depth = 10
+ *   rendered, opacity[rank[b]] > 0             -> img = rgb[rank[b]],  depth = depth[rank[b]]
+ *   rendered, opacity == 0                     -> img = background[b], depth = 8
+ * rays_msk (B) bytes or NULL (all rendered, rank may be NULL); rank (B) int64 = position of pixel b among
+ * the rendered rays. */
+int32_t mf_image_compose(const uint8_t* rays_msk, const int64_t* rank, int64_t B, const float* opacity,
+                         const float* rgb, const float* depth, const float* background, float* img,
+                         float* depth_out, void* stream);
+
 /* knn_cuda.KNN(k=1, transpose_mode=True) of the vendored wheel (datasets/moco_flow_dataset.py:35,120):
  * ref (V,3), query (Q,3) -> dist (Q,) Euclidean distance to, and ind (Q,) int64 0-based index of, the
  * nearest reference point; first minimum on ties. */

@@ -1,5 +1,7 @@
 // mf_aux.hip -- the producers on either side of the hot path:
 //   mf_make_rays : Camera.make_rays / gen_ray_directions / gen_rays   utils/camera.py:29-81, 134-148
+//   mf_image_compose : the foreground scatter-back of MoCoFlowTrainer.render / NeRFTrainer.render
+//                      trainer/trainer_moco_flow.py:249-266, trainer/trainer_nerf.py:128-140
 //   mf_knn1      : knn_cuda.KNN(k=1)  (vendored wheel docker/KNN_CUDA-0.2: knn_cuda/csrc/cuda/knn.cu:29-183)
 #include "mf_host.hpp"
 
@@ -38,6 +40,42 @@ __global__ void make_rays_kernel(RaysParams p) {
   o[0] = ox; o[1] = oy; o[2] = oz;
   o[3] = wx / nrm; o[4] = wy / nrm; o[5] = wz / nrm;
   o[6] = p.nearv; o[7] = p.farv; o[8] = p.idx;
+}
+
+struct ComposeParams {
+  const unsigned char* msk;     // (B) 0/1, or null: every ray was rendered
+  const long long* rank;        // (B) index of ray b in the rendered arrays (valid where msk)
+  long long B;
+  const float* opacity;         // (M)
+  const float* rgb;             // (M,3)
+  const float* depth;           // (M)
+  const float* background;      // (B,3)
+  float* img;                   // (B,3)
+  float* depth_out;             // (B)
+};
+
+// One thread per pixel.  trainer_moco_flow.py:252-263: img = 0, depth = 10; masked rays get depth 8;
+// rays whose rendered opacity is > 0 take the rendered colour / depth; rays with foreground_mask == 0
+// (not rendered, or rendered with opacity exactly 0) take the background colour.
+__global__ void image_compose_kernel(ComposeParams p) {
+  const long long b = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.B) return;
+  const bool m = p.msk ? p.msk[b] != 0 : true;
+  float r = 0.f, g = 0.f, bl = 0.f, d = 10.f, fg = 0.f;
+  long long k = 0;
+  if (m) {
+    k = p.rank ? p.rank[b] : b;
+    fg = p.opacity[k];
+    d = 8.f;
+  }
+  if (fg > 0.f) {
+    r = p.rgb[k * 3]; g = p.rgb[k * 3 + 1]; bl = p.rgb[k * 3 + 2];
+    d = p.depth[k];
+  } else if (fg == 0.f) {
+    r = p.background[b * 3]; g = p.background[b * 3 + 1]; bl = p.background[b * 3 + 2];
+  }
+  p.img[b * 3] = r; p.img[b * 3 + 1] = g; p.img[b * 3 + 2] = bl;
+  p.depth_out[b] = d;
 }
 
 struct KnnParams {
@@ -105,4 +143,16 @@ extern "C" int32_t mf_knn1(const float* ref, int64_t V, const float* query, int6
   KnnParams p{ref, V, query, Q, dist, reinterpret_cast<long long*>(ind)};
   hipLaunchKernelGGL(knn1_kernel, dim3((unsigned)((Q + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   return check_launch("mf_knn1");
+}
+
+extern "C" int32_t mf_image_compose(const uint8_t* rays_msk, const int64_t* rank, int64_t B, const float* opacity,
+                                    const float* rgb, const float* depth, const float* background, float* img,
+                                    float* depth_out, void* stream) {
+  if (B < 0 || (B > 0 && (!opacity || !rgb || !depth || !background || !img || !depth_out)))
+    return fail(MF_E_INVALID, "mf_image_compose: null argument");
+  if (rays_msk && !rank) return fail(MF_E_INVALID, "mf_image_compose: a mask needs the rank array");
+  if (B == 0) return MF_OK;
+  ComposeParams p{rays_msk, reinterpret_cast<const long long*>(rank), B, opacity, rgb, depth, background, img, depth_out};
+  hipLaunchKernelGGL(image_compose_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  return check_launch("mf_image_compose");
 }

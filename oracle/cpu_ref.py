@@ -449,3 +449,40 @@ def knn1(ref, query):
     d2 = ((query[:, None, :].double() - ref[None, :, :].double()) ** 2).sum(-1)
     ind = torch.argmin(d2, dim=1)              # first minimum
     return torch.sqrt(d2.gather(1, ind[:, None])).float(), ind[:, None]
+
+
+def render_image(rays, background, render, N_rand, rays_msk=None):
+    """MoCoFlowTrainer.render, trainer/trainer_moco_flow.py:226-268 (= NeRFTrainer.render,
+    trainer_nerf.py:100-140), with ``render(rays_chunk, background_chunk)`` standing for ``self.forward``:
+    numpy mask selection, the chunk loop over the UNMASKED ray count (empty trailing chunks included),
+    and the foreground scatter-back.  ``np.float`` of :258 (removed from NumPy >= 1.24) is float64."""
+    import numpy as np
+    from collections import defaultdict
+    if rays_msk is not None:
+        msk = np.where(rays_msk == True)  # noqa: E712  (as in the reference)
+        rendered_rays, rendered_background = rays[msk], background[msk]
+    else:
+        rendered_rays, rendered_background = rays, background
+    B = rays.shape[0]
+    results = defaultdict(list)
+    for i in range(0, B, N_rand):
+        chunk = render(rendered_rays[i:i + N_rand], rendered_background[i:i + N_rand])
+        for k, v in chunk.items():
+            results[k] += [v]
+    results = {k: torch.cat(v, 0) for k, v in results.items()}
+    if rays_msk is not None:
+        typ = "fine" if "rgb_fine" in results else "coarse"
+        num_ori_rays = rays.shape[0]
+        img_raw = torch.zeros(num_ori_rays, 3)
+        depth_raw = torch.ones(num_ori_rays) * 10
+        opacity = results["opacity_%s" % typ].cpu().numpy()
+        foreground_idx = np.where(opacity > 0)
+        foreground_mask = np.zeros_like(rays_msk).astype(np.float64)
+        foreground_mask[msk] = opacity
+        img_raw[foreground_mask > 0] = results["rgb_%s" % typ][foreground_idx]
+        depth_raw[msk] = 8
+        depth_raw[foreground_mask > 0] = results["depth_%s" % typ][foreground_idx]
+        img_raw[foreground_mask == 0] = background[foreground_mask == 0]
+        results["rgb_%s" % typ] = img_raw
+        results["depth_%s" % typ] = depth_raw
+    return results

@@ -33,6 +33,7 @@ from moco_flow_amd import synth  # noqa: E402
 
 torch.set_num_threads(8)
 torch.manual_seed(0)
+SIGMA_SHIFT = float(os.environ.get("MF_SIGMA_SHIFT", "-0.044"))   # u_render_image
 
 
 # ----------------------------------------------------------------- model builders
@@ -281,6 +282,56 @@ def unit_camera():
          out_rays=rays, out_dirs_cam=d_cam, out_directions=cam.directions)
 
 
+def unit_render_image():
+    """MoCoFlowTrainer.render (trainer_moco_flow.py:226-268) restated around the imported reference
+    render_rays (the trainer classes cannot be imported here): numpy mask selection, N_rand chunk loop over
+    the unmasked ray count (the last chunk is empty), foreground scatter-back.  The NeRF's sigma bias is
+    shifted so that a share of the rendered rays has opacity exactly 0 (relu)."""
+    from collections import defaultdict
+    H, W = 16, 20
+    B = H * W
+    rays_np, bg_np = synth.rays(41, B)
+    rays, bg = t(rays_np), t(bg_np)
+    rays_msk = np.array([(i * 7) % 5 != 0 for i in range(B)])
+    nerfs = []
+    for tag in ("coarse", "fine"):
+        m = ref_nerf(42, "dir", 27, "default", tag)
+        with torch.no_grad():
+            m.sigma.bias.add_(SIGMA_SHIFT)
+        nerfs.append(m)
+    embs = [ref_embedding(3, 10), None, ref_embedding(3, 4)]
+    N_rand, S, Mi = 96, 16, 16
+
+    def forward(r, b):
+        with torch.no_grad():
+            return ref_rendering.render_rays(r, b, embs, nerfs, N_samples=S, N_importance=Mi, perturb=0, noise_std=0)
+
+    msk = np.where(rays_msk == True)  # noqa: E712
+    rr, rb = rays[msk], bg[msk]
+    results = defaultdict(list)
+    for i in range(0, B, N_rand):
+        for k, v in forward(rr[i:i + N_rand], rb[i:i + N_rand]).items():
+            results[k] += [v]
+    results = {k: torch.cat(v, 0) for k, v in results.items()}
+    img_raw = torch.zeros(B, 3)
+    depth_raw = torch.ones(B) * 10
+    opacity = results["opacity_fine"].cpu().numpy()
+    foreground_idx = np.where(opacity > 0)
+    foreground_mask = np.zeros_like(rays_msk).astype(np.float64)      # np.float in the reference (:258)
+    foreground_mask[msk] = opacity
+    img_raw[foreground_mask > 0] = results["rgb_fine"][foreground_idx]
+    depth_raw[msk] = 8
+    depth_raw[foreground_mask > 0] = results["depth_fine"][foreground_idx]
+    img_raw[foreground_mask == 0] = bg[foreground_mask == 0]
+    n_fg, n_zero = int((opacity > 0).sum()), int((opacity == 0).sum())
+    print(f"u_render_image: {len(opacity)} rendered rays, {n_fg} foreground, {n_zero} with opacity == 0")
+    assert n_fg > 20 and n_zero > 20
+    save("u_render_image", in_rays=rays, in_background=bg, in_rays_msk=rays_msk, in_N_rand=np.int64(N_rand),
+         in_S=np.int64(S), in_M=np.int64(Mi), in_sigma_shift=np.float64(SIGMA_SHIFT), meta_seed=np.int64(42),
+         out_rgb_fine=img_raw, out_depth_fine=depth_raw, out_opacity_fine=results["opacity_fine"],
+         out_rgb_coarse=results["rgb_coarse"], out_opacity_coarse=results["opacity_coarse"])
+
+
 if __name__ == "__main__":
     only = set(sys.argv[1:])
     for name in sorted(RENDER_CASES):
@@ -292,3 +343,5 @@ if __name__ == "__main__":
         unit_sample_pdf()
         unit_trainer_glue()
         unit_camera()
+    if not only or "units" in only or "image" in only:
+        unit_render_image()

@@ -671,3 +671,35 @@ def test_nof_points_backward_unit(M, quat, n_rays, S):
     for n, q in nof.named_parameters():
         assert relerr(got[n], q.grad) <= 1e-4, (n, relerr(got[n], q.grad))
     assert relerr(got_x, p2.grad) <= 1e-4, relerr(got_x, p2.grad)
+
+
+def test_render_image_vs_golden(M):
+    """image.render_image (device-side chunk driver + mf_image_compose) against the fixture
+    made from the reference's render_rays and the scatter-back of trainer_moco_flow.py:249-266: values to
+    1e-4, the foreground / background / not-rendered classification of every pixel exactly, for chunked
+    and single-pass rendering, with and without a mask."""
+    import functools
+    from test_oracle_golden import _image_case
+    from moco_flow_amd import image
+    g, embs, nerfs = _image_case(M, "cuda")
+    rays, bg = torch.from_numpy(g["in_rays"]), torch.from_numpy(g["in_background"])       # host tensors, as the trainers hold them
+    fwd = functools.partial(M.render_rays, nerf_embeddings=embs, nerf_models=nerfs, N_samples=int(g["in_S"]),
+                            N_importance=int(g["in_M"]), perturb=0, noise_std=0)
+    render = lambda r, b: fwd(r, b)
+    with torch.no_grad():
+        for n_rand in (int(g["in_N_rand"]), 100000):
+            res = image.render_image(rays, bg, render, n_rand, g["in_rays_msk"])
+            want_d = torch.from_numpy(g["out_depth_fine"])
+            got_d = res["depth_fine"].cpu()
+            for code in (8.0, 10.0):                                   # rendered-but-empty / not rendered pixels
+                assert torch.equal(got_d == code, want_d == code)
+            assert relerr(res["rgb_fine"], g["out_rgb_fine"]) <= 1e-4
+            assert relerr(got_d, want_d) <= 1e-4
+            assert relerr(res["opacity_fine"], g["out_opacity_fine"]) <= 1e-4
+            assert relerr(res["rgb_coarse"], g["out_rgb_coarse"]) <= 1e-4
+        full = image.render_image(rays.cuda(), bg.cuda(), render, 128, None)
+        assert full["rgb_fine"].shape == (rays.shape[0], 3) and full["depth_fine"].shape == (rays.shape[0],)
+        msk = torch.from_numpy(g["in_rays_msk"])
+        fg = torch.from_numpy(g["out_opacity_fine"]) > 0
+        sel = torch.nonzero(msk).squeeze(1)[fg]
+        assert relerr(full["rgb_fine"].cpu()[sel], torch.from_numpy(g["out_rgb_fine"])[sel]) <= 1e-4

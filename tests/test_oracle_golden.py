@@ -130,3 +130,35 @@ def test_knn1_semantics():
     d, i = R.knn1(ref, q)
     assert i.view(-1).tolist() == [1, 0, 3, 3]          # first minimum on the duplicated point
     assert relerr(d.view(-1), torch.tensor([0.1, 0.9, 0.9, (25 + 9 + 25) ** 0.5])) <= 1e-6
+
+
+def _image_case(backend, device):
+    """u_render_image's networks on ``backend`` (oracle or product): synth seeds + the fixture's sigma shift."""
+    from moco_flow_amd import synth
+    g = load_golden("u_render_image")
+    nerfs = []
+    for tag in ("coarse", "fine"):
+        m = backend.NeRF(8, 256, 63, [4], "dir", 27)
+        sd = synth.nerf_state(int(g["meta_seed"]), regime="default", tag=tag)
+        sd["sigma.bias"] = (sd["sigma.bias"] + np.float32(float(g["in_sigma_shift"]))).astype(np.float32)
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        nerfs.append(m.to(device) if hasattr(m, "to") else m)
+    embs = [backend.Embedding(3, 10, True), None, backend.Embedding(3, 4, True)]
+    return g, embs, nerfs
+
+
+def test_render_image_vectors():
+    """oracle.render_image (trainer_moco_flow.py:226-268 restated) against the fixture made from the
+    reference's render_rays + the same scatter-back lines: chunk loop with an empty last chunk, rays with
+    opacity exactly 0, masked-out rays."""
+    g, embs, nerfs = _image_case(R, "cpu")
+    rays, bg = torch.from_numpy(g["in_rays"]), torch.from_numpy(g["in_background"])
+
+    def fwd(r, b):
+        with torch.no_grad():
+            return R.render_rays(r, b, embs, nerfs, N_samples=int(g["in_S"]), N_importance=int(g["in_M"]), perturb=0, noise_std=0)
+
+    res = R.render_image(rays, bg, fwd, int(g["in_N_rand"]), g["in_rays_msk"])
+    for k in ("rgb_fine", "depth_fine", "opacity_fine", "rgb_coarse", "opacity_coarse"):
+        assert relerr(res[k], g["out_" + k]) <= 1e-6, (k, relerr(res[k], g["out_" + k]))
+    assert res["rgb_fine"].shape == (rays.shape[0], 3) and res["opacity_fine"].shape[0] == int(g["in_rays_msk"].sum())
