@@ -329,16 +329,20 @@ MF_D void out_pair(CarryT<Pipe<BF16>::PD>& carry, const typename ActT<BF16>::T (
       O = MF_MFMA(wO[0], bop(q, 0), O);
       __builtin_amdgcn_sched_barrier(0);
       const int nq = q + PDF;
+#ifndef MF_ABLATE_NOLDS      // (timing ablation builds only: keep re-using the fragments in registers)
       if (nq < Q) {
         nE = lds_f4(panel_lane_off + (2 * nq) * kGroupBytes);
         nO = lds_f4(panel_lane_off + (2 * nq + 1) * kGroupBytes);
       }
+#endif
       if (q == 0 && !late) hook();
       if (q == Q / 2 && late) hook();
+#ifndef MF_ABLATE_NOLDS
       if (nq >= Q) {                                     // runs on into the next panel (after the barrier)
         nE = lds_f4(next_panel_lane_off + (2 * (nq - Q)) * kGroupBytes);
         nO = lds_f4(next_panel_lane_off + (2 * (nq - Q) + 1) * kGroupBytes);
       }
+#endif
       if (q + 1 >= Q) carry.load_bias(next_bias_off, g);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
