@@ -38,6 +38,47 @@ def test_library_exports_every_declared_symbol():
     assert lib.mf_render_pass(None, None) == -1
 
 
+def test_backward_entry_points_validate_on_the_host():
+    """ABI v4-v5 (mf_nerf_backward, mf_nof_*, mf_weight_grads, mf_image_compose): sizes, the scheduler's
+    scratch plan and argument validation are host-side and must not need a GPU."""
+    import moco_flow_amd._lib as L
+    lib = L.lib()
+    d = L.mf_nerf_desc()
+    d.D, d.W, d.in_channels_xyz, d.skip_mask = 8, 256, 63, 1 << 4
+    d.extra_feat_type, d.extra_feat_dim = L.MF_EXTRA_DIR, 27
+    # transposed stream: (W/2 -> W) + (W+sigma -> W) + 7 x (W -> W) panels, 1 KiB groups
+    want = (16 + 34 + 32 * 7) * 8 * 1024
+    got = lib.mf_nerf_bwd_packed_bytes(ctypes.byref(d))
+    assert want < got <= want + 4096
+    d.W = 128
+    assert lib.mf_nerf_bwd_packed_bytes(ctypes.byref(d)) == 0 and b"unsupported" in lib.mf_last_error()
+    assert lib.mf_nerf_backward(None, None, 0, None, None, 0, None, None, None, None) == -1
+    n = L.mf_nof_desc()
+    n.D, n.W, n.in_channels_xyz, n.extra_feat_dim, n.skip_mask, n.use_quat = 4, 128, 33, 33, 1 << 2, 1
+    assert lib.mf_nof_bwd_packed_bytes(ctypes.byref(n)) > (3 * 4 * 16 + 2 * 32) * 1024
+    n.skip_mask = (1 << 1) | (1 << 2)                      # two skip layers: not built
+    assert lib.mf_nof_bwd_packed_bytes(ctypes.byref(n)) == 0
+    assert lib.mf_nof_backward(None, None, None, 0, None, None, 0, None, None, None, None) == -1
+    # weight-gradient plan: every supported block, partial slots bounded by the workgroup count
+    items = (L.mf_wgrad_item * 3)()
+    buf = (ctypes.c_float * 4096)()
+    base = ctypes.addressof(buf) & ~15
+    for it, (no, ni) in zip(items, [(256, 256), (128, 80), (4, 640)]):
+        it.G, it.g_stride, it.n_out, it.X, it.x_stride, it.n_in, it.dW, it.db = base, 2432, no, base, 2432, ni, base, None
+    P = 100000
+    nbytes = lib.mf_weight_grads_scratch_bytes(items, 3, P)
+    lo = (256 * 256 + 256 + 128 * 80 + 128 + 16 * 640 + 16) * 4
+    assert lo <= nbytes <= 300 * lo
+    assert lib.mf_weight_grads_scratch_bytes(items, 3, 0) >= 0
+    items[1].n_in = 77                                       # unsupported block
+    assert lib.mf_weight_grads_scratch_bytes(items, 3, P) == -1 and b"unsupported" in lib.mf_last_error()
+    items[1].n_in, items[1].x_stride = 80, 2431             # stride not a multiple of 4 floats
+    assert lib.mf_weight_grads_scratch_bytes(items, 3, P) == -1
+    assert lib.mf_weight_grads(items, L.MF_WG_MAX_ITEMS + 1, P, None, None) < 0
+    assert lib.mf_image_compose(None, None, 5, None, None, None, None, None, None, None) == -1
+    assert lib.mf_image_compose(None, None, 0, None, None, None, None, None, None, None) == 0
+
+
 def test_packed_layout_sizes():
     """Packed sizes follow from the panel program: NeRF dir/27 = resident 13 KiB +
     (L0 8 + 3x32 + skip 40 + 3x32 + final 32) groups x 8 panels + extra 36 groups x 4 panels."""
