@@ -141,6 +141,16 @@ int32_t mf_nerf_backward(const mf_nerf_desc* d, const void* packed_bwd, int64_t 
                          const float* acts, int64_t stride, const float* rgbsigma, float* gpre,
                          float* ghead, void* stream);
 
+/* Backward of the alpha-composite of nerf_inference (models/rendering.py:157-192) on per-sample planes:
+ * g_rgb (N,3) / g_depth (N) / g_opacity (N) (any may be NULL) = dL/d of the pass's outputs ->
+ * g_rgbsigma (N*S,4) = dL/d[rgb (after the sigmoid), raw sigma] per sample, ready for mf_nerf_backward.
+ * rgbsigma = mf_render_args.dump_rgbsigma of the forward; z_vals / noise / activation / background as in
+ * the forward.  Nothing flows to z_vals (rendering.py:323).  S <= 2048. */
+int32_t mf_composite_backward(const float* rays, int64_t ray_stride, int64_t n_rays, int32_t S,
+                              const float* z_vals, const float* rgbsigma, const float* noise,
+                              int32_t activation, const float* background, const float* g_rgb,
+                              const float* g_depth, const float* g_opacity, float* g_rgbsigma, void* stream);
+
 /* Weight / bias gradients of a set of linear layers over P samples, ONE persistent launch:
  *     dW_i = G_i[:P]^T X_i[:P]   (n_out x n_in),      db_i = sum_s G_i[s]   (n_out)
  * G_i / X_i: fp32 row-major device matrices (column slices of the mf_nerf_backward gradient buffer, of

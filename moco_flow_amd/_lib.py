@@ -90,6 +90,8 @@ SYMBOLS = {
     "mf_nof_pack_bwd": (C.c_int32, [C.POINTER(mf_nof_desc), _fp, _fp]),
     "mf_nof_backward": (C.c_int32, [C.POINTER(mf_nof_desc), _fp, C.POINTER(mf_embedding), C.c_int64, _fp, _fp, C.c_int64,
                                     _fp, _fp, _fp, _fp]),
+    "mf_composite_backward": (C.c_int32, [_fp, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, _fp, C.c_int32, _fp, _fp, _fp, _fp,
+                                          _fp, _fp]),
     "mf_image_compose": (C.c_int32, [_fp, _fp, C.c_int64, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "mf_weight_grads_scratch_bytes": (C.c_int64, [C.POINTER(mf_wgrad_item), C.c_int32, C.c_int64]),
     "mf_weight_grads": (C.c_int32, [C.POINTER(mf_wgrad_item), C.c_int32, C.c_int64, _fp, _fp]),

@@ -535,6 +535,50 @@ class NerfSamples(torch.autograd.Function):
         return (None, None, None, None, None, None, g_xin) + tuple(grads[n] for n in names)
 
 
+COMPOSITE_BACKWARD = "hip"   # "hip": mf_composite_backward; "torch": composite_from_samples under autograd
+
+
+def set_composite_backward(kind: str) -> None:
+    global COMPOSITE_BACKWARD
+    if kind not in ("hip", "torch"):
+        raise ValueError(f"composite backward: {kind} not valid (hip | torch)")
+    COMPOSITE_BACKWARD = kind
+
+
+class CompositeSamples(torch.autograd.Function):
+    """(rgb, depth, opacity) of a pass as a function of the per-sample (rgb, sigma) plane.  Forward: the
+    values the fused HIP pass already produced; backward: mf_composite_backward (rendering.py:157-192
+    differentiated by hand: one wave per ray, product / suffix scans)."""
+
+    @staticmethod
+    def forward(ctx, rgbsig, rays, z_vals, noise, activation, background, rgb_val, depth_val, opacity_val):
+        ctx.save_for_backward(rgbsig, rays, z_vals, noise if noise is not None else rgbsig.new_empty(0),
+                              background if background is not None else rgbsig.new_empty(0))
+        ctx.has_noise, ctx.has_bg, ctx.activation = noise is not None, background is not None, activation
+        return rgb_val.detach().clone(), depth_val.detach().clone(), opacity_val.detach().clone()
+
+    @staticmethod
+    def backward(ctx, g_rgb, g_depth, g_opacity):
+        from . import _lib as L
+        rgbsig, rays, z_vals, noise, background = ctx.saved_tensors
+        N, S = z_vals.shape
+        dev = rgbsig.device
+        f = lambda t: None if t is None else t.contiguous().float()
+        g_rgb, g_depth, g_opacity = f(g_rgb), f(g_depth), f(g_opacity)
+        rays, z_vals, rgbsig = rays.contiguous(), z_vals.contiguous(), rgbsig.contiguous()
+        noise = noise.contiguous() if ctx.has_noise else None
+        background = background.contiguous() if ctx.has_bg else None
+        g = torch.empty((N * S, 4), device=dev, dtype=torch.float32)
+        ptr = lambda t: None if t is None else t.data_ptr()
+        act = L.MF_ACT_RELU if ctx.activation == "relu" else L.MF_ACT_SOFTPLUS
+        with torch.cuda.device(dev):
+            L.check(L.lib().mf_composite_backward(rays.data_ptr(), rays.stride(0), N, S, z_vals.data_ptr(),
+                                                  rgbsig.data_ptr(), ptr(noise), act, ptr(background), ptr(g_rgb),
+                                                  ptr(g_depth), ptr(g_opacity), g.data_ptr(), L.current_stream(dev)),
+                    "mf_composite_backward")
+        return g, None, None, None, None, None, None, None, None
+
+
 def composite_from_samples(rgbsig, z_vals, rays_d, noise, activation, background, sigma_only):
     """rendering.py:157-192 on per-sample (rgb, sigma) planes -- differentiable, (N,S) elementwise only."""
     N, S = z_vals.shape

@@ -398,8 +398,13 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
                 extra_in = A._pad_to(torch.repeat_interleave(A.embed(nerf_embs[2], rays_d), S, dim=0), nerf.extra_feat_dim)
         rgbsig = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, nerf_embs[0], xin,
                                      *nerf.parameters())
-        comp = A.composite_from_samples(rgbsig, z, rays_d, noise, activation, background, False)
-        out[f"rgb_{tag}"], out[f"depth_{tag}"], out[f"opacity_{tag}"] = comp["rgb"], comp["depth"], comp["opacity"]
+        if A.COMPOSITE_BACKWARD == "hip" and activation in ("relu", "softplus") and S <= 2048:
+            out[f"rgb_{tag}"], out[f"depth_{tag}"], out[f"opacity_{tag}"] = A.CompositeSamples.apply(
+                rgbsig, rays, z, noise, activation, background, result[f"rgb_{tag}"], result[f"depth_{tag}"],
+                result[f"opacity_{tag}"])
+        else:
+            comp = A.composite_from_samples(rgbsig, z, rays_d, noise, activation, background, False)
+            out[f"rgb_{tag}"], out[f"depth_{tag}"], out[f"opacity_{tag}"] = comp["rgb"], comp["depth"], comp["opacity"]
 
     one("coarse", nerf_models[0], coarse)
     if fine is not None:

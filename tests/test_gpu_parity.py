@@ -703,3 +703,31 @@ def test_render_image_vs_golden(M):
         fg = torch.from_numpy(g["out_opacity_fine"]) > 0
         sel = torch.nonzero(msk).squeeze(1)[fg]
         assert relerr(full["rgb_fine"].cpu()[sel], torch.from_numpy(g["out_rgb_fine"])[sel]) <= 1e-4
+
+
+@pytest.mark.parametrize("act,use_noise,use_bg,N,S", [("relu", False, True, 33, 64), ("softplus", True, True, 9, 200),
+                                                     ("relu", True, False, 5, 2), ("softplus", False, False, 3, 700)])
+def test_composite_backward_unit(M, act, use_noise, use_bg, N, S):
+    """autograd.CompositeSamples (mf_composite_backward) against torch autograd of the composite restated
+    with torch ops (rendering.py:157-192) on the same planes: dL/d[rgb, sigma] per sample to 1e-4,
+    including the 1e10 last interval, multi-chunk rays (S > 64) and S = 2 (S = 1 is degenerate in the
+    reference itself: `ones_like(deltas[:, :1])` of an empty tensor drops the only interval, rendering.py:158-160)."""
+    from moco_flow_amd import autograd as A
+    torch.manual_seed(3)
+    dev = "cuda"
+    rays = torch.randn(N, 9, device=dev)
+    rays[:, 3:6] = torch.nn.functional.normalize(rays[:, 3:6], dim=1) * 1.3
+    z = torch.sort(torch.rand(N, S, device=dev) * 4 + 2, dim=1).values.contiguous()
+    rgbsig = torch.rand(N * S, 4, device=dev)
+    rgbsig[:, 3] = torch.randn(N * S, device=dev) * 2.0
+    noise = torch.randn(N, S, device=dev) * 0.3 if use_noise else None
+    bg = torch.rand(N, 3, device=dev) if use_bg else None
+    g = [torch.randn(N, 3, device=dev), torch.randn(N, device=dev), torch.randn(N, device=dev)]
+    a = rgbsig.clone().requires_grad_(True)
+    comp = A.composite_from_samples(a, z, rays[:, 3:6], noise, act, bg, False)
+    torch.autograd.backward([comp["rgb"], comp["depth"], comp["opacity"]], g)
+    b = rgbsig.clone().requires_grad_(True)
+    outs = A.CompositeSamples.apply(b, rays, z, noise, act, bg, comp["rgb"].detach(), comp["depth"].detach(), comp["opacity"].detach())
+    torch.autograd.backward(list(outs), g)
+    assert relerr(b.grad[:, :3], a.grad[:, :3]) <= 1e-5
+    assert relerr(b.grad[:, 3], a.grad[:, 3]) <= 1e-4, relerr(b.grad[:, 3], a.grad[:, 3])
