@@ -81,9 +81,15 @@ def cpu_baseline(workload, states, rays_np, bg_np, budget_s=20.0):
             out = R.render_rays(rays, bg, *args, **kw)
             times.append(time.perf_counter() - t0)
     med = float(np.median(times))
+    cpu = "unknown CPU"
+    try:
+        with open("/proc/cpuinfo") as fh:
+            cpu = next(l.split(":", 1)[1].strip() for l in fh if l.startswith("model name"))
+    except (OSError, StopIteration):
+        pass
     return dict(value=N_RAYS * N_SAMPLES / med, unit="ray-samples/s", cores=cores, kind="port",
                 sample=f"{len(times)} full {N_RAYS}x{N_SAMPLES} batches, median {med:.3f} s/batch, "
-                       f"torch {torch.__version__} CPU fp32"), out
+                       f"torch {torch.__version__} CPU fp32, {cores} threads on {cpu}"), out
 
 
 def train_leg(M, models, rays, bg, gt, kw, workload, steps=10):
@@ -229,14 +235,15 @@ def main():
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         base, ref = cpu_baseline(a.workload, models["states"], rays_np[:N_RAYS], bg_np[:N_RAYS])
         line["cpu_baseline"] = base
-        errs = {}
+        errs, l2 = {}, {}
         for k, v in ref.items():
             if k.startswith("nof_"):
                 continue
             g = out[k].cpu().double()
             errs[k] = float((g - v.double()).abs().max() / v.double().abs().max())
+            l2[k] = float((g - v.double()).norm() / v.double().norm())
         mse = float(((out["rgb_coarse"].cpu().double() - ref["rgb_coarse"].double()) ** 2).mean())
-        line["error_vs_cpu"] = {"max_rel": errs, "psnr_equiv_db": (-10 * np.log10(mse)) if mse > 0 else float("inf")}
+        line["error_vs_cpu"] = {"max_rel": errs, "l2_rel": l2, "psnr_equiv_db": (-10 * np.log10(mse)) if mse > 0 else float("inf")}
         line["speedup_vs_cpu"] = value / base["value"]
     if rank == 0:
         print(json.dumps(line))
