@@ -731,3 +731,44 @@ def test_composite_backward_unit(M, act, use_noise, use_bg, N, S):
     torch.autograd.backward(list(outs), g)
     assert relerr(b.grad[:, :3], a.grad[:, :3]) <= 1e-5
     assert relerr(b.grad[:, 3], a.grad[:, 3]) <= 1e-4, relerr(b.grad[:, 3], a.grad[:, 3])
+
+
+@pytest.mark.parametrize("D,skips,extra,extra_dim", [(6, [2], "none", 0), (4, [], "dir", 27), (10, [3], "ind", 5), (8, [7], "dir", 27)])
+def test_nerf_backward_other_shapes(M, D, skips, extra, extra_dim):
+    """The fused backward (mf_nerf_backward + mf_weight_grads) on network shapes other than the configs'
+    8x256 / skip 4: depth, skip position (none / last layer) and extra input type; against torch autograd of
+    the same network on the same points, 1e-4."""
+    from moco_flow_amd import autograd as A, rendering
+    torch.manual_seed(11)
+    nerf = M.NeRF(D, 256, 63, skips, extra, extra_dim).cuda()
+    with torch.no_grad():
+        nerf.sigma.weight.mul_(8.0)
+    embs = [M.Embedding(3, 10), M.Embedding(1, 2) if extra == "ind" else None, M.Embedding(3, 4) if extra == "dir" else None]
+    n_rays, S = 21, 32
+    from moco_flow_amd import synth
+    r, b = synth.rays(3, n_rays)
+    rays, bg = torch.from_numpy(r).cuda(), torch.from_numpy(b).cuda()
+    z = (rays[:, 6:7] * (1 - torch.linspace(0, 1, S, device="cuda")) + rays[:, 7:8] * torch.linspace(0, 1, S, device="cuda")).contiguous()
+    with torch.no_grad():
+        p = rendering._render_pass(rays, bg, z, None, False, None, 0, nerf, embs, None, None, False, False, False, True, dump=True)
+    xin = p["xyz_in"].clone().requires_grad_(True)
+    emb_in = A._pad_to(A.embed(embs[0], p["xyz_in"]), 63)
+    extra_in = None
+    if extra == "ind":
+        extra_in = A._pad_to(torch.repeat_interleave(A.embed(embs[1], rays[:, 8:9]), S, dim=0), extra_dim)
+    elif extra == "dir":
+        extra_in = A._pad_to(torch.repeat_interleave(A.embed(embs[2], rays[:, 3:6]), S, dim=0), extra_dim)
+    gout = torch.randn(n_rays * S, 4, device="cuda")
+    out = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, embs[0], xin, *nerf.parameters())
+    out.backward(gout)
+    got = {n: q.grad.clone() for n, q in nerf.named_parameters()}
+    got_x = xin.grad.clone()
+    nerf.zero_grad(set_to_none=True)
+    x2 = p["xyz_in"].clone().requires_grad_(True)
+    full = A._pad_to(A.embed(embs[0], x2), 63)
+    ref = A.nerf_forward(nerf, full if extra_in is None else torch.cat([full, extra_in], -1))
+    assert relerr(out, ref) <= 1e-5
+    ref.backward(gout)
+    for n, q in nerf.named_parameters():
+        assert relerr(got[n], q.grad) <= 1e-4, (n, relerr(got[n], q.grad))
+    assert relerr(got_x, x2.grad) <= 1e-4
