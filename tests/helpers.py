@@ -17,8 +17,8 @@ def load_golden(name):
 
 def relerr(a, b):
     """max|a-b| / max|b|  (SURVEY.md §8d 'max-rel')."""
-    a = torch.as_tensor(a, dtype=torch.float64).cpu()
-    b = torch.as_tensor(b, dtype=torch.float64).cpu()
+    a = torch.as_tensor(a).detach().to(torch.float64).cpu()
+    b = torch.as_tensor(b).detach().to(torch.float64).cpu()
     assert a.shape == b.shape, (a.shape, b.shape)
     if b.numel() == 0:
         return 0.0

@@ -772,3 +772,30 @@ def test_nerf_backward_other_shapes(M, D, skips, extra, extra_dim):
     for n, q in nerf.named_parameters():
         assert relerr(got[n], q.grad) <= 1e-4, (n, relerr(got[n], q.grad))
     assert relerr(got_x, x2.grad) <= 1e-4
+
+
+@pytest.mark.parametrize("D,skips,quat", [(3, [1], True), (5, [], False), (6, [5], True), (2, [], True)])
+def test_nof_backward_other_shapes(M, D, skips, quat):
+    """NofPoints on depths / skip positions other than the configs' 4x128 / skip 2 (default nn.Linear init)."""
+    from moco_flow_amd import autograd as A
+    torch.manual_seed(5)
+    nof = M.NoF(D, 128, 33, skips, "ind", 33, quat).cuda()
+    embs = [M.Embedding(3, 5), M.Embedding(1, 16)]
+    n_rays, S = 7, 50
+    rays = torch.zeros(n_rays, 10, device="cuda")
+    rays[:, 8] = torch.linspace(-0.7, 0.9, n_rays, device="cuda")
+    pts = (torch.randn(n_rays, S, 3, device="cuda") * 0.6).requires_grad_(True)
+    gout = torch.randn(n_rays, S, 3, device="cuda")
+    assert A.nof_hip_supported(nof, embs)
+    out = A.nof_points(pts, rays[:, 8:9], embs, nof)
+    out.backward(gout)
+    got = {n: q.grad.clone() for n, q in nof.named_parameters()}
+    got_x = pts.grad.clone()
+    nof.zero_grad(set_to_none=True)
+    p2 = pts.detach().clone().requires_grad_(True)
+    ref = A._nof_points(p2, rays[:, 8:9], embs, nof)
+    assert relerr(out, ref) <= 1e-5
+    ref.backward(gout)
+    for n, q in nof.named_parameters():
+        assert relerr(got[n], q.grad) <= 1e-4, (n, relerr(got[n], q.grad))
+    assert relerr(got_x, p2.grad) <= 1e-4
