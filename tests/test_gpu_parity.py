@@ -799,3 +799,35 @@ def test_nof_backward_other_shapes(M, D, skips, quat):
     for n, q in nof.named_parameters():
         assert relerr(got[n], q.grad) <= 1e-4, (n, relerr(got[n], q.grad))
     assert relerr(got_x, p2.grad) <= 1e-4
+
+
+@pytest.mark.parametrize("name", ["r_nerf_dir_fine_train", "r_moco_global_fine"])
+def test_training_gradients_are_reproducible(M, name):
+    """The HIP backward has no atomics (fixed-order partial sums in mf_weight_grads, scans in the
+    composite): two identical training steps give bit-identical gradients, and scaling the loss by 4
+    scales every gradient by exactly 4 (linearity of the backward, a size-independent property)."""
+    c = dict(RENDER_CASES[name])
+    seed = int(load_golden(name)["meta_seed"])
+    n = 700
+    rays, bg = case_inputs(c, seed, n=n)
+    rays, bg = rays.cuda(), bg.cuda()
+    embs, nerfs, kw = build_case(M, c, seed, device="cuda")
+    nets = list(nerfs) + (list(kw["nof_models"]) if kw["nof_models"] else [])
+    gt = torch.rand(n, 3, generator=torch.Generator().manual_seed(1)).cuda()
+
+    def grads(scale):
+        for m in nets:
+            m.zero_grad(set_to_none=True)
+        res = M.render_rays(rays, bg, embs, nerfs, **kw)
+        loss = ((res["rgb_coarse"] - gt) ** 2).mean() + ((res["rgb_fine"] - gt) ** 2).mean()
+        for k in res:
+            if k.startswith("nof_"):
+                loss = loss + 0.25 * res[k].mean()
+        (loss * scale).backward()
+        return [p.grad.clone() for m in nets for p in m.parameters()]
+
+    a, b, c4 = grads(1.0), grads(1.0), grads(4.0)
+    assert len(a) >= 24
+    for x, y, z in zip(a, b, c4):
+        assert torch.equal(x, y)
+        assert torch.equal(4.0 * x, z)
