@@ -40,7 +40,8 @@ enum { MF_MAX_FREQS = 16, MF_MAX_LAYERS = 16 };
 /* Arithmetic of the W-wide ("hidden") GEMMs of the fused pass.  F32: exact-fp32 MFMA everywhere
  * (the reference's arithmetic; BASELINE configs C1-C2).  BF16: hidden-layer weights and
  * activations rounded to bf16 (RNE), fp32 accumulate (v_mfma_f32_16x16x32_bf16); the embedded-
- * input k-ranges, biases, heads and the composite stay fp32 (BASELINE configs C3-C5). */
+ * input k-ranges use a two-term bf16 split of inputs and weights (16 mantissa bits, three products);
+ * biases, heads and the composite stay fp32 (BASELINE configs C3-C5). */
 enum { MF_PREC_F32 = 0, MF_PREC_BF16 = 1 };
 
 /* ---- Embedding: models/embedding.py:4-47 ------------------------------------

@@ -78,6 +78,7 @@ using BlkInd2 = EmbBlock<1, 2>;     // NeRF ind, 5                    -> 2 slots
 
 constexpr int kStepsNerfXyz = round4(BlkXyz10::SLOTS);                    // 16
 constexpr int kStepsNofIn = round4(BlkXyz5::SLOTS + BlkInd16::SLOTS);     // 20
+constexpr int kStepsNofInBf16 = (kStepsNofIn + 7) & ~7;                   // 24: whole 8-slot blocks in bf16 mode
 constexpr int kStepsDir = round4(BlkDir4::SLOTS);                         // 8
 constexpr int kStepsInd = round4(BlkInd2::SLOTS);                         // 4
 constexpr int kStepsExtraMax = kStepsDir;
@@ -136,8 +137,9 @@ struct NetLayout {
   int n_head;              // NoF: 9 | 3
 };
 
-// batches of a panel: an embedded-input batch = one fp32 k-quad (16 k, 8 MFMAs); a hidden batch =
-// one fp32 k-quad (16 k) or, in bf16 mode, one 32-k step (2 MFMAs).  Two 1 KiB groups per batch.
+// batches of a panel: an embedded-input batch = one fp32 k-quad (16 k, 8 MFMAs) -- in bf16 mode the hi
+// (even batch) or lo (odd batch) bf16 weights of one 32-k block; a hidden batch = one fp32 k-quad (16 k)
+// or, in bf16 mode, one 32-k step (2 MFMAs).  Two 1 KiB groups per batch.
 MF_HD int hidden_batches(const NetLayout& L) { return L.bf16 ? L.NP : L.NK; }
 MF_HD int trunk_batches(const NetLayout& L, int layer) {
   return (((L.emb_mask >> layer) & 1) ? L.emb_steps / 4 : 0) + (layer > 0 ? hidden_batches(L) : 0);
@@ -266,6 +268,39 @@ MF_D u32x4 pack8(const f32x4& e, const f32x4& o) {
   v[4] = (__bf16)o[0]; v[5] = (__bf16)o[1]; v[6] = (__bf16)o[2]; v[7] = (__bf16)o[3];
   return __builtin_bit_cast(u32x4, v);
 }
+// bf16 mode feeds the embedded-input k-ranges to the bf16 MFMA as a two-term split  x = hi + lo
+// (hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits) against weights split the same way, three products
+// per 32-k block (hi*hi + hi*lo + lo*hi): 48 matrix-pipe cycles instead of the 256 of eight exact-fp32
+// MFMAs.  The split operands replace the block's eight floats in place: [4 regs hi | 4 regs lo].
+template <int EMB>
+MF_D void emb_split_bf16(float (&emb)[EMB]) {
+  static_assert(EMB % 8 == 0, "bf16 embedded blocks are 8 slots (32 k) wide");
+#pragma unroll
+  for (int b = 0; b < EMB / 8; ++b) {
+    unsigned hb[8], lb[8];     // bf16 bit patterns (scalar conversions: no vector element inserts)
+#pragma unroll
+    for (int p = 0; p < 8; ++p) {
+      const float x = emb[8 * b + p];
+      const __bf16 h = (__bf16)x;
+      const __bf16 l = (__bf16)(x - (float)h);
+      hb[p] = __builtin_bit_cast(unsigned short, h);
+      lb[p] = __builtin_bit_cast(unsigned short, l);
+    }
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      emb[8 * b + w] = __builtin_bit_cast(float, hb[2 * w] | (hb[2 * w + 1] << 16));
+      emb[8 * b + 4 + w] = __builtin_bit_cast(float, lb[2 * w] | (lb[2 * w + 1] << 16));
+    }
+  }
+}
+template <int EMB>
+MF_D u32x4 emb_operand(const float (&emb)[EMB], int block, int lo) {
+  u32x4 v;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) v[w] = __builtin_bit_cast(unsigned, emb[8 * block + 4 * lo + w]);
+  return v;
+}
+
 MF_D float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 MF_D float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
 
@@ -373,6 +408,7 @@ MF_D void out_pair(CarryT<Pipe<BF16>::PD>& carry, const typename ActT<BF16>::T (
   constexpr int QH = (MODE & 2) ? ActLen<BF16, NK>::N : 0;
   constexpr int Q = QE + QH;
   static_assert(Q >= PD, "panel shorter than the fragment pipeline");
+  static_assert(!BF16 || !(MODE & 1) || EMB % 8 == 0, "bf16 embedded blocks are 8 slots wide");
   // the late half must not read the next panel (prefetch of batch b + PD >= Q) before its barrier
   constexpr int LATEQ = (Q / 2 < Q - PD) ? Q / 2 : Q - PD;
   f32x4 E = carry.bE, O = carry.bO;
@@ -382,7 +418,7 @@ MF_D void out_pair(CarryT<Pipe<BF16>::PD>& carry, const typename ActT<BF16>::T (
 #pragma unroll
   for (int b = 0; b < Q; ++b) {
     const int s = b % (PD + 1);
-    const bool f32_batch = !BF16 || b < QE;
+    const bool f32_batch = !BF16;
     if (f32_batch) {
       float bv;
       if (b < QE) bv = emb[4 * b];
@@ -391,8 +427,14 @@ MF_D void out_pair(CarryT<Pipe<BF16>::PD>& carry, const typename ActT<BF16>::T (
       O = MF_MFMA(rO[s][0], bv, O);
     } else {
       if constexpr (BF16) {
-        E = MF_MFMA_BF16(rE[s], hid[b - QE], E);
-        O = MF_MFMA_BF16(rO[s], hid[b - QE], O);
+        if (b < QE) {      // embedded block b/2: even batch = hi weights, odd batch = lo weights, both times x_hi first
+          const u32x4 xh = emb_operand(emb, b >> 1, 0);
+          E = MF_MFMA_BF16(rE[s], xh, E);
+          O = MF_MFMA_BF16(rO[s], xh, O);
+        } else {
+          E = MF_MFMA_BF16(rE[s], hid[b - QE], E);
+          O = MF_MFMA_BF16(rO[s], hid[b - QE], O);
+        }
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -420,6 +462,12 @@ MF_D void out_pair(CarryT<Pipe<BF16>::PD>& carry, const typename ActT<BF16>::T (
         else if constexpr (!BF16) bv = hid[b - QE][r];
         E = MF_MFMA(rE[s][r], bv, E);
         O = MF_MFMA(rO[s][r], bv, O);
+      }
+    } else if constexpr (BF16) {
+      if (b < QE && !(b & 1)) {                          // hi weights x x_lo
+        const u32x4 xl = emb_operand(emb, b >> 1, 1);
+        E = MF_MFMA_BF16(rE[s], xl, E);
+        O = MF_MFMA_BF16(rO[s], xl, O);
       }
     }
     __builtin_amdgcn_sched_barrier(0);

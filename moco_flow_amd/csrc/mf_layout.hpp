@@ -25,7 +25,7 @@ inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L, int bf16 = 0) {
   L.relu_mask = (1u << d.D) - 1u;
   switch (d.extra_feat_type) {
     case MF_EXTRA_NONE: L.extra_steps = 0; break;
-    case MF_EXTRA_IND: L.extra_steps = kStepsInd; if (d.extra_feat_dim < 1) return false; break;
+    case MF_EXTRA_IND: L.extra_steps = bf16 ? 8 : kStepsInd; if (d.extra_feat_dim < 1) return false; break;
     case MF_EXTRA_DIR: L.extra_steps = kStepsDir; if (d.extra_feat_dim < 3) return false; break;
     default: return false;
   }
@@ -63,7 +63,7 @@ inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0) {
   L.NK = d.W / 16;
   L.NP = d.W / 32;
   L.n_trunk = d.D;
-  L.emb_steps = kStepsNofIn;
+  L.emb_steps = bf16 ? kStepsNofInBf16 : kStepsNofIn;
   L.emb_mask = 1u | d.skip_mask;
   L.relu_mask = (1u << d.D) - 1u;
   L.extra_steps = -1;

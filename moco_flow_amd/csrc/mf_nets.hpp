@@ -60,15 +60,29 @@ MF_D void extra_layer(const NetDev& net, const typename ActT<BF16>::T (&act)[Act
     f32x4 E, O;
     out_pair<2, NK, 4, BF16>(carry, act, dummy, p, pn, nb, id.g, id.wave < kWaves / 2 && !(st.dbg & 64), hook,
                              -__builtin_inff(), E, O);
+    if constexpr (BF16) {      // one 32-k block, split operands (ext was converted by emb_split_bf16): hi*hi, hi*lo, lo*hi
+      if (qe > 0) {
+        const f32x4 hE = lds_f4(p + (2 * QH) * kGroupBytes), hO = lds_f4(p + (2 * QH + 1) * kGroupBytes);
+        const f32x4 lE = lds_f4(p + (2 * QH + 2) * kGroupBytes), lO = lds_f4(p + (2 * QH + 3) * kGroupBytes);
+        const u32x4 xh = emb_operand(ext, 0, 0), xl = emb_operand(ext, 0, 1);
+        E = MF_MFMA_BF16(hE, xh, E);
+        O = MF_MFMA_BF16(hO, xh, O);
+        E = MF_MFMA_BF16(hE, xl, E);
+        O = MF_MFMA_BF16(hO, xl, O);
+        E = MF_MFMA_BF16(lE, xh, E);
+        O = MF_MFMA_BF16(lO, xh, O);
+      }
+    } else {
 #pragma unroll
-    for (int q = 0; q < kStepsExtraMax / 4; ++q) {
-      if (q < qe) {
-        const f32x4 wE = lds_f4(p + (2 * (QH + q)) * kGroupBytes);
-        const f32x4 wO = lds_f4(p + (2 * (QH + q) + 1) * kGroupBytes);
+      for (int q = 0; q < kStepsExtraMax / 4; ++q) {
+        if (q < qe) {
+          const f32x4 wE = lds_f4(p + (2 * (QH + q)) * kGroupBytes);
+          const f32x4 wO = lds_f4(p + (2 * (QH + q) + 1) * kGroupBytes);
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          E = MF_MFMA(wE[r], ext[4 * q + r], E);
-          O = MF_MFMA(wO[r], ext[4 * q + r], O);
+          for (int r = 0; r < 4; ++r) {
+            E = MF_MFMA(wE[r], ext[4 * q + r], E);
+            O = MF_MFMA(wO[r], ext[4 * q + r], O);
+          }
         }
       }
     }
@@ -98,7 +112,7 @@ MF_D void extra_layer(const NetDev& net, const typename ActT<BF16>::T (&act)[Act
 // program evaluates after this network (the stream jumps there behind the last panel used).
 // DUMP (training forward): `dump_row` = this lane's sample row [h_0 .. h_{D-1} | final | extra] (nullptr: skip).
 template <int NK, bool BF16, bool DUMP = false>
-MF_D void nerf_eval(const NetDev& net, const float (&embx)[kStepsNerfXyz], const float (&ext)[kStepsExtraMax],
+MF_D void nerf_eval_impl(const NetDev& net, const float (&embx)[kStepsNerfXyz], const float (&ext)[kStepsExtraMax],
                     bool sigma_only, Stream& st, CarryT<Pipe<BF16>::PD>& carry, const LaneId& id,
                     const NextLayer& follow, float& sigma, float (&rgb)[3], float* dump_row = nullptr) {
   typename ActT<BF16>::T act[ActLen<BF16, NK>::N];
@@ -128,6 +142,26 @@ MF_D void nerf_eval(const NetDev& net, const float (&embx)[kStepsNerfXyz], const
   valu_head(e, net.res_lds + net.L.off_rgb_w * 4, net.L.W / 2, net.res_lds + net.L.off_rgb_b * 4, id.g, o);
 #pragma unroll
   for (int c = 0; c < 3; ++c) rgb[c] = 1.f / (1.f + expf(-o[c]));   // nn.Sigmoid, nerf.py:57-59
+}
+
+// bf16 mode hands the embedded inputs over as split (hi | lo) bf16 operands (emb_split_bf16); the fp32
+// instantiations pass the caller's arrays straight through.
+template <int NK, bool BF16, bool DUMP = false>
+MF_D void nerf_eval(const NetDev& net, const float (&embx)[kStepsNerfXyz], const float (&ext)[kStepsExtraMax],
+                    bool sigma_only, Stream& st, CarryT<Pipe<BF16>::PD>& carry, const LaneId& id,
+                    const NextLayer& follow, float& sigma, float (&rgb)[3], float* dump_row = nullptr) {
+  if constexpr (BF16) {
+    float ex[kStepsNerfXyz], et[kStepsExtraMax];
+#pragma unroll
+    for (int e = 0; e < kStepsNerfXyz; ++e) ex[e] = embx[e];
+#pragma unroll
+    for (int e = 0; e < kStepsExtraMax; ++e) et[e] = ext[e];
+    emb_split_bf16(ex);
+    emb_split_bf16(et);
+    nerf_eval_impl<NK, BF16, DUMP>(net, ex, et, sigma_only, st, carry, id, follow, sigma, rgb, dump_row);
+  } else {
+    nerf_eval_impl<NK, BF16, DUMP>(net, embx, ext, sigma_only, st, carry, id, follow, sigma, rgb, dump_row);
+  }
 }
 
 // kornia 0.6.5 quaternion_log_to_exp + quaternion_to_rotation_matrix as restated in
@@ -166,9 +200,20 @@ MF_D void nof_eval(const NetDev& net, const float (&emb)[kStepsNofIn], const flo
 #pragma unroll
     for (int i = 0; i < 4; ++i) act[t][i] = 0;
   const int D = net.L.n_trunk;
-  for (int l = 0; l < D; ++l) {
-    const bool last = l == D - 1;
-    trunk_layer<NK, kStepsNofIn, BF16>(net, l, act, emb, st, carry, id, last ? follow : next_trunk(net, l + 1));
+  if constexpr (BF16) {
+    float e24[kStepsNofInBf16];          // 20 slots padded to three 8-slot blocks, then split hi/lo in place
+#pragma unroll
+    for (int e = 0; e < kStepsNofInBf16; ++e) e24[e] = e < kStepsNofIn ? emb[e < kStepsNofIn ? e : 0] : 0.f;
+    emb_split_bf16(e24);
+    for (int l = 0; l < D; ++l) {
+      const bool last = l == D - 1;
+      trunk_layer<NK, kStepsNofInBf16, BF16>(net, l, act, e24, st, carry, id, last ? follow : next_trunk(net, l + 1));
+    }
+  } else {
+    for (int l = 0; l < D; ++l) {
+      const bool last = l == D - 1;
+      trunk_layer<NK, kStepsNofIn, BF16>(net, l, act, emb, st, carry, id, last ? follow : next_trunk(net, l + 1));
+    }
   }
   const uint32_t wo = net.res_lds + net.L.off_head_w * 4, bo = net.res_lds + net.L.off_head_b * 4;
   if (net.L.n_head == 9) {

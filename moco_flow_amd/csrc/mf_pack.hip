@@ -36,6 +36,12 @@ struct PackJob {
   float* panels;             // packed + res_bytes
 };
 
+__device__ inline unsigned short bf16_rne(float x) {        // round to nearest even (inf / nan pass through)
+  const unsigned u = __float_as_uint(x);
+  const unsigned rnd = u + 0x7fffu + ((u >> 16) & 1u);
+  return (unsigned short)(((u & 0x7f800000u) == 0x7f800000u ? u : rnd) >> 16);
+}
+
 __global__ void pack_panels_kernel(PackJob job) {
   const long long gidx = (long long)blockIdx.x * blockDim.x + threadIdx.x;   // one float4 slot
   const long long grp = gidx >> 6;
@@ -55,7 +61,19 @@ __global__ void pack_panels_kernel(PackJob job) {
   const float* row = R.W + (long long)n * R.n_in;
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   float* pv = &v.x;
-  if (be >= 0 && be < eb) {
+  if (be >= 0 && be < eb && R.bf16) {
+    // bf16 mode: 32-k block be/2 (slots 8*blk + p, p = 0..7), even batch = hi = bf16(w), odd = lo = bf16(w - hi)
+    const int blk = be >> 1, lo = be & 1;
+    unsigned short h8[8];
+    for (int pp = 0; pp < 8; ++pp) {
+      const int f = emb_feature(R.emb_kind, g, 8 * blk + pp, R.xyz_cols);
+      const float w = (f >= 0 && f < R.emb_cols) ? row[R.emb_col0 + f] : 0.f;
+      const unsigned short hi = bf16_rne(w);
+      h8[pp] = lo ? bf16_rne(w - __uint_as_float((unsigned)hi << 16)) : hi;
+    }
+    unsigned* pu = reinterpret_cast<unsigned*>(&v.x);
+    for (int w = 0; w < 4; ++w) pu[w] = (unsigned)h8[2 * w] | ((unsigned)h8[2 * w + 1] << 16);
+  } else if (be >= 0 && be < eb) {
     for (int r = 0; r < 4; ++r) {
       const int f = emb_feature(R.emb_kind, g, 4 * be + r, R.xyz_cols);
       pv[r] = (f >= 0 && f < R.emb_cols) ? row[R.emb_col0 + f] : 0.f;
@@ -69,9 +87,7 @@ __global__ void pack_panels_kernel(PackJob job) {
       unsigned short h8[8];
       for (int pp = 0; pp < 8; ++pp) {
         const int k = 32 * bh + (pp < 4 ? 4 * g + pp : 16 + 4 * g + pp - 4);
-        const unsigned u = __float_as_uint(row[R.hid_col0 + k]);
-        const unsigned rnd = u + 0x7fffu + ((u >> 16) & 1u);           // round to nearest even
-        h8[pp] = (unsigned short)(((u & 0x7f800000u) == 0x7f800000u ? u : rnd) >> 16);
+        h8[pp] = bf16_rne(row[R.hid_col0 + k]);
       }
       unsigned* pu = reinterpret_cast<unsigned*>(&v.x);
       for (int w = 0; w < 4; ++w) pu[w] = (unsigned)h8[2 * w] | ((unsigned)h8[2 * w + 1] << 16);

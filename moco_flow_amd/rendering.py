@@ -18,7 +18,8 @@ from . import autograd as A
 
 # Arithmetic of the hidden (256-/128-wide) GEMMs of the fused pass: "f32" = exact-fp32 MFMA (the
 # reference's arithmetic, BASELINE configs C1-C2; default) or "bf16" = bf16 operands with fp32
-# accumulate (BASELINE configs C3-C5); embedded-input k-ranges, heads and composite stay fp32.
+# accumulate (BASELINE configs C3-C5); embedded-input k-ranges as a two-term bf16 split (16 mantissa
+# bits); heads and composite stay fp32.
 # The reference's render_rays signature has no such knob, so it is a module setting.
 PRECISION = "f32"
 
