@@ -4,29 +4,36 @@ Forward values always come from the fused HIP kernels.  When gradients are reque
 
 * fp32 render passes (the training path): the fused forward additionally DUMPS what the backward
   needs (per-sample post-activation layer outputs, rgb/sigma, NeRF input points; mf_render_args
-  dump_*).  ``NerfSamples`` then back-propagates the 12-layer NeRF with an explicit chain of library
-  GEMMs (PyTorch-ROCm matmul = rocBLAS / hipBLASLt, "plain library GEMMs") over that dump -- no
-  forward recompute and no autograd graph over the MLP; the composite is re-stated on the dumped
-  (N,S) planes (elementwise only) and the 9x smaller NoF chains are recomputed differentiably.
-  Measured on the stage-1 shape (5120 rays x (128 + 256) samples): 118 ms per step vs 152 ms for the
-  reference's own op sequence under PyTorch-ROCm autograd on the same GPU.
+  dump_*) and the backward is HIP too, as a handful of autograd nodes whose backward methods are
+  single launches:
+    ``CompositeSamples``  mf_composite_backward   dL/d(rgb, depth, opacity) -> dL/d(rgb, sigma) per sample
+    ``NerfSamples``       mf_nerf_backward + mf_weight_grads   the 12-layer NeRF: input-gradient chain on the
+                          transposed weights over the dump, then every dW / db in one persistent launch
+    ``NofPoints``         mf_nof_points_dump (forward) / mf_nof_backward + mf_weight_grads   one NoF
+                          evaluation on points; the consensus chains are compositions of this node
+  No forward recompute of the NeRF, no autograd graph over any MLP, no library GEMM.  Measured (MI355X):
+  stage-1 step (5120 rays x (128 + 256) samples) 59 ms vs 154 ms for the reference's own op sequence
+  under PyTorch-ROCm autograd on the same GPU; joint MoCo stage (1024 rays x 384 samples, local + global
+  chains) 31 ms vs 139 ms.  ``set_nerf_backward("gemm")`` / ``set_nof_backward("torch")`` /
+  ``set_composite_backward("torch")`` select the earlier library-GEMM / torch-recompute variants (A/B).
 * everything else (module-level calls, bf16, sigma-only coarse pass): ``RecomputeBackward`` re-runs the
   pass with differentiable device ops (the reference's op sequence: models/nerf.py:78-102,
   models/nof.py:69-82, models/embedding.py:42-46, models/rendering.py:49-192) on exactly the depths /
   noise / masks the kernels used.
 
-All of this runs on the GPU and shares no code with the test-side checker.  A fully fused HIP dX
-chain (transposed fragment stream + ReLU masks from the dump) is the next step; the dW GEMMs stay
-library GEMMs.  Gradients reach every parameter that requires grad (frozen sub-modules are
-honoured, trainer_moco_flow.py:391-404) and do not flow through the resampled depths
-(rendering.py:323).
+All of this runs on the GPU and shares no code with the test-side checker.  Gradients reach every
+parameter that requires grad (frozen sub-modules are honoured, trainer_moco_flow.py:391-404) and do
+not flow through the resampled depths (rendering.py:323).
 """
 from __future__ import annotations
 
+import ctypes as C
 from typing import Dict, List, Optional
 
 import torch
 import torch.nn.functional as F
+
+from . import _lib as L
 
 
 # ------------------------------------------------------------------ differentiable restatement
@@ -229,8 +236,6 @@ def set_nerf_backward(kind: str) -> None:
 
 def nerf_backward_hip(m, g_out, acts, rgbsig):
     """mf_nerf_backward: (gpre (P,stride) in the dump's layout, ghead (P,4)) from dL/d[rgb, sigma]."""
-    import ctypes as C
-    from . import _lib as L
     P, stride = acts.shape
     desc, buf = m.packed_bwd()
     dev = acts.device
@@ -251,8 +256,6 @@ _WG_BLOCK = {(256, 256): (256, 256), (256, 64): (256, 64), (128, 256): (128, 256
 def weight_grads(jobs, P, dev):
     """mf_weight_grads: jobs = [(G, X, n_out, n_in, want_bias)] with G / X fp32 device matrices (column
     slices allowed) -> [(dW (rows, n_in), db (rows,) | None)] in ONE persistent HIP launch."""
-    import ctypes as C
-    from . import _lib as L
     n = len(jobs)
     if n == 0:
         return []
@@ -306,8 +309,6 @@ class NofPoints(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, m, nof_embs, ray_ind, S, pts, *params):
-        import ctypes as C
-        from . import _lib as L
         P, dev = pts.shape[0], pts.device
         pts = pts.detach().contiguous().float()
         desc, buf = m.packed()
@@ -323,13 +324,10 @@ class NofPoints(torch.autograd.Function):
                     "mf_nof_points_dump")
         ctx.m, ctx.ex, ctx.stride = m, ex, stride
         ctx.save_for_backward(pts, acts, emb)
-        ctx.pts_grad = pts.requires_grad or True
         return out
 
     @staticmethod
     def backward(ctx, g_out):
-        import ctypes as C
-        from . import _lib as L
         m, stride = ctx.m, ctx.stride
         pts, acts, emb = ctx.saved_tensors
         P, dev = pts.shape[0], pts.device
@@ -559,7 +557,6 @@ class CompositeSamples(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_opacity):
-        from . import _lib as L
         rgbsig, rays, z_vals, noise, background = ctx.saved_tensors
         N, S = z_vals.shape
         dev = rgbsig.device
