@@ -233,7 +233,7 @@ def render_rays(rays,
         # rendering.py:276-280: fw_nof is only bound under chain_local
         raise UnboundLocalError("local variable 'fw_nof' referenced before assignment")
     all_models = list(nerf_models) + (list(nof_models) if use_nof else [])
-    grad = A.needs_grad(all_models)       # backward = differentiable recompute (autograd.py, interim)
+    grad = A.needs_grad(all_models)       # training call: dump + HIP backward nodes (autograd.py)
     dev = rays.device
     rays = rays.detach().float()
     if rays.dim() != 2 or rays.shape[1] < (10 if (use_nof and chain_global) else 9):
@@ -363,10 +363,10 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
                      activation, coarse, fine):
     """Training graph on top of the fused forward (TRAIN_FORWARD == "hip", fp32): values are the HIP
     kernels' outputs; gradients flow through
-      * autograd.NerfSamples -- explicit library-GEMM backward of the NeRF over the kernel's activation
-        dump (no recompute of the 12-layer MLP),
-      * a differentiable composite on the dumped per-sample (rgb, sigma) ((N,S) elementwise only),
-      * a differentiable recompute of the (9x smaller) NoF chains where they exist.
+      * autograd.CompositeSamples -- mf_composite_backward on the dumped per-sample (rgb, sigma) planes,
+      * autograd.NerfSamples -- mf_nerf_backward + mf_weight_grads over the kernel's activation dump
+        (no recompute of the 12-layer MLP, no library GEMM),
+      * autograd.NofPoints -- one HIP forward-with-dump / backward node per NoF evaluation of the chains.
     Each returned tensor is  hip_value + (torch_value - torch_value.detach())."""
     rays_o, rays_d, ind = rays[:, 0:3], rays[:, 3:6], rays[:, 8:9]
     out = {}

@@ -320,8 +320,8 @@ def _oracle_grads(R, c, seed, rays, bg, loss_fn):
 
 @pytest.mark.parametrize("name", ["r_nerf_dir_dense", "r_moco_global", "r_nerf_ind_dense"])
 def test_gradients_vs_oracle(M, R, name):
-    """Training contract (interim backward, moco_flow_amd/autograd.py): forward values from the HIP
-    kernels, gradients by differentiable recompute on the GPU; both against the CPU oracle's autograd
+    """Training contract (moco_flow_amd/autograd.py): forward values from the HIP kernels, gradients from
+    the HIP backward nodes (composite, NeRF dX chain + weight gradients, NoF evaluations); against the CPU oracle's autograd
     for the reference's loss shape (MSE on rgb + consensus means, trainer_moco_flow.py:317-328)."""
     c = dict(RENDER_CASES[name])
     seed = int(load_golden(name)["meta_seed"])

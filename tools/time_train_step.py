@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Time one training step of the stage-1 objective (trainer_nerf.py:149-169 shape: N_rand rays x
-(128 coarse + 128 fine -> 256) samples) through the drop-in: HIP forward, interim backward, and the
+(128 coarse + 128 fine -> 256) samples) through the drop-in: HIP forward + HIP backward, the library-GEMM backward variant, and the
 same pass done entirely with PyTorch-ROCm ops (what the reference itself would run on this GPU)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
