@@ -426,7 +426,7 @@ class NerfSamples(torch.autograd.Function):
             f = acts[:, D * W:(D + 1) * W]
             e2 = acts[:, (D + 1) * W:(D + 1) * W + W // 2]
             fused = (NERF_BACKWARD == "hip" and acts.shape[0] > 0 and W == 256 and cin <= 64
-                     and m.extra_feat_dim <= 32 and D + len([s for s in m.skips if 0 < s < D]) + 4 <= 16)
+                     and m.extra_feat_dim <= 32 and D + len([s for s in m.skips if 0 < s < D]) + 4 <= L.MF_WG_MAX_ITEMS)
             if fused:
                 gpre, ghead = nerf_backward_hip(m, g_out, acts, rgbsig)
                 P, dev = acts.shape[0], acts.device
