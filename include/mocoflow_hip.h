@@ -26,7 +26,9 @@
 extern "C" {
 #endif
 
-#define MF_ABI_VERSION 5
+/* 3: activation dump of the training forward; 4: mf_nerf_backward, mf_weight_grads; 5: NoF backward
+ * (mf_nof_points_dump, mf_nof_backward); 6: mf_composite_backward, mf_image_compose */
+#define MF_ABI_VERSION 6
 
 enum {
   MF_OK = 0,
