@@ -117,7 +117,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_backward_kernel(BwdParams p)
   CarryT<Pipe<false>::PD> carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
-  st.dbg = p.dbg;
+  st.dbg = MF_TIMING_FLAGS ? p.dbg : 0;
   st.keep2 = false;
   const uint32_t zero_bias = net.res_lds + net.L.off_bias_trunk * 4;
   const char* first = net.packed + net.L.res_bytes;

@@ -71,7 +71,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
   CarryT<Pipe<BF16>::PD> carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
-  st.dbg = p.dbg;
+  st.dbg = MF_TIMING_FLAGS ? p.dbg : 0;
   st.keep2 = false;
   // the panel program of a tile: [bw NoF, fw NoF chains,] NeRF, then around again
   const NextLayer prog_first = MOCO ? follow_of(p.bw) : follow_of(nerf);
@@ -149,7 +149,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
       }
 
       float embx[kStepsNerfXyz], ext[kStepsExtraMax];
-      if (!(p.dbg & 4)) emb_eval<3, 10>(embx, xin, p.exyz, id.g);
+      if (!(MF_TIMING_FLAGS && (p.dbg & 4))) emb_eval<3, 10>(embx, xin, p.exyz, id.g);
       else { for (int e = 0; e < kStepsNerfXyz; ++e) embx[e] = xin[e % 3]; }
 #pragma unroll
       for (int e = BlkXyz10::SLOTS; e < kStepsNerfXyz; ++e) embx[e] = 0.f;
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
     __syncthreads();
 
     // ---- composite (rendering.py:157-192): one wave per ray, lanes over samples
-    for (int rr = id.wave; rr < ((p.dbg & 8) ? 0 : nr); rr += kWaves) {
+    for (int rr = id.wave; rr < ((MF_TIMING_FLAGS && (p.dbg & 8)) ? 0 : nr); rr += kWaves) {
       const long long ray = ray0 + rr;
       const float* rp = p.rays + ray * p.ray_stride;
       const float dnorm = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);  // rendering.py:164

@@ -176,7 +176,7 @@ MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, 
   // stage st: waves 4-7 take it at the start, waves 0-3 (their SIMD partners) in the middle, which
   // keeps the two waves of a SIMD half a stage out of phase -- one is always in MFMA-dense code while
   // the other crosses a stage boundary (barrier, DMA issue, first fragment reads).
-  const bool late = id.wave < kWaves / 2 && !(dbg & 1);
+  const bool late = id.wave < kWaves / 2 && !(MF_TIMING_FLAGS && (dbg & 1));
   for (long long st = sb; st < se; ++st) {
     const uint32_t base = cur * S::SLOT_BYTES;
     auto hook = [&]() {

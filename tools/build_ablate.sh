@@ -1,13 +1,18 @@
 #!/bin/bash
-# Timing-ablation build of the library (results are WRONG, durations are real): fragment ds_reads of the
-# fp32 core removed (-DMF_ABLATE_NOLDS).  Use with  MOCOFLOW_HIP_LIB=moco_flow_amd/libmocoflow_ablate.so
-# FLAGS="0 1 2 3" bash tools/ablate.sh   (profiles/README.md, "Where the last 15 % ... goes").
+# Timing-ablation builds of the library (results are WRONG with flags != 0, durations are real):
+#   libmocoflow_flags.so  : -DMF_TIMING_FLAGS=1, the kernels honour MF_DEBUG_FLAGS (production compiles them out)
+#   libmocoflow_ablate.so : the same + -DMF_ABLATE_NOLDS (fragment ds_reads of the fp32 core removed)
+# Use with  MOCOFLOW_HIP_LIB=moco_flow_amd/libmocoflow_flags.so FLAGS="0 1 2 3" bash tools/ablate.sh
+# (profiles/README.md, "Where the last 15 % ... goes").
 set -e
 cd "$(dirname "$0")/../moco_flow_amd/csrc"
-OBJS=""
-for f in mf_abi mf_pack mf_forward mf_render mf_backward mf_wgrad mf_nofgrad mf_composite mf_sample mf_aux; do
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DMF_ABLATE_NOLDS=1 -c $f.hip -o /tmp/abl_$f.o
-  OBJS="$OBJS /tmp/abl_$f.o"
+for variant in flags ablate; do
+  DEFS="-DMF_TIMING_FLAGS=1"; [ $variant = ablate ] && DEFS="$DEFS -DMF_ABLATE_NOLDS=1"
+  OBJS=""
+  for f in mf_abi mf_pack mf_forward mf_render mf_backward mf_wgrad mf_nofgrad mf_composite mf_sample mf_aux; do
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $DEFS -c $f.hip -o /tmp/${variant}_$f.o
+    OBJS="$OBJS /tmp/${variant}_$f.o"
+  done
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o ../libmocoflow_$variant.so
+  echo built ../libmocoflow_$variant.so
 done
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o ../libmocoflow_ablate.so
-echo built ../libmocoflow_ablate.so
