@@ -225,8 +225,8 @@ def main():
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak,
                      # HBM bytes per launch from the committed PMC passes of this same command
-                     # (profiles/r01c_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); C2 only
-                     "traffic": 25.3e6 if (a.workload == "nerf" and a.precision == "f32") else None,
+                     # (profiles/r01f_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); C2 only
+                     "traffic": 26.2e6 if (a.workload == "nerf" and a.precision == "f32") else None,
                      "traffic_unit": "B/launch",
                      "kernel_ms": kernel_ms, "flops_per_launch": N_RAYS * N_SAMPLES * flops_per_sample},
     }
