@@ -27,8 +27,9 @@ extern "C" {
 #endif
 
 /* 3: activation dump of the training forward; 4: mf_nerf_backward, mf_weight_grads; 5: NoF backward
- * (mf_nof_points_dump, mf_nof_backward); 6: mf_composite_backward, mf_image_compose */
-#define MF_ABI_VERSION 6
+ * (mf_nof_points_dump, mf_nof_backward); 6: mf_composite_backward, mf_image_compose;
+ * 7: mf_nof_forward_dump */
+#define MF_ABI_VERSION 7
 
 enum {
   MF_OK = 0,
@@ -184,6 +185,10 @@ int32_t mf_nof_points_dump(const mf_nof_desc* d, const void* packed, const mf_em
                            const mf_embedding* emb_ind, const float* pts, const float* ind,
                            int64_t ind_stride, int32_t S, int64_t P, float* out, float* acts,
                            int64_t stride, float* emb, void* stream);
+/* NoF.forward (models/nof.py:55-85) on pre-embedded inputs, storing the same activation dump: the forward
+ * half of the module-level training call (trainer_nof.py:85-112, trainer_moco_flow.py:159-187). */
+int32_t mf_nof_forward_dump(const mf_nof_desc* d, const void* packed, const float* inputs, int64_t in_stride,
+                            const float* xyz, int64_t B, float* out, float* acts, int64_t stride, void* stream);
 int64_t mf_nof_bwd_packed_bytes(const mf_nof_desc* d);
 int32_t mf_nof_pack_bwd(const mf_nof_desc* d, void* packed, void* stream);
 int32_t mf_nof_backward(const mf_nof_desc* d, const void* packed_bwd, const mf_embedding* emb_xyz, int64_t P,

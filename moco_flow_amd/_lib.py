@@ -16,7 +16,7 @@ MF_EXTRA_NONE, MF_EXTRA_IND, MF_EXTRA_DIR = 0, 1, 2
 MF_ACT_RELU, MF_ACT_SOFTPLUS = 0, 1
 MF_F_SIGMA_ONLY, MF_F_CHAIN_LOCAL, MF_F_CHAIN_GLOBAL = 1, 2, 4
 MF_PREC_F32, MF_PREC_BF16 = 0, 1
-MF_ABI_VERSION = 6
+MF_ABI_VERSION = 7
 
 LIB_PATH = os.environ.get("MOCOFLOW_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmocoflow_hip.so")   # (override: A/B builds)
 
@@ -86,6 +86,7 @@ SYMBOLS = {
     "mf_nerf_pack_bwd": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, _fp]),
     "mf_nof_points_dump": (C.c_int32, [C.POINTER(mf_nof_desc), _fp, C.POINTER(mf_embedding), C.POINTER(mf_embedding), _fp, _fp,
                                        C.c_int64, C.c_int32, C.c_int64, _fp, _fp, C.c_int64, _fp, _fp]),
+    "mf_nof_forward_dump": (C.c_int32, [C.POINTER(mf_nof_desc), _fp, _fp, C.c_int64, _fp, C.c_int64, _fp, _fp, C.c_int64, _fp]),
     "mf_nof_bwd_packed_bytes": (C.c_int64, [C.POINTER(mf_nof_desc)]),
     "mf_nof_pack_bwd": (C.c_int32, [C.POINTER(mf_nof_desc), _fp, _fp]),
     "mf_nof_backward": (C.c_int32, [C.POINTER(mf_nof_desc), _fp, C.POINTER(mf_embedding), C.c_int64, _fp, _fp, C.c_int64,

@@ -295,9 +295,99 @@ def set_nof_backward(kind: str) -> None:
 
 
 def nof_hip_supported(m, nof_embs) -> bool:
+    """nof_embs = None: module-level call on pre-embedded inputs (no embedding constraints)."""
     skips = [s for s in m.skips if 0 < s < m.D]
-    return (m.W == 128 and m.in_channels_xyz == 33 and m.extra_feat_dim == 33 and len(skips) <= 1
-            and 2 <= m.D <= 8 and nof_embs[0].N_freqs <= 5 and nof_embs[1].N_freqs == 16)
+    ok = m.W == 128 and m.in_channels_xyz == 33 and m.extra_feat_dim == 33 and len(skips) <= 1 and 2 <= m.D <= 8
+    return ok and (nof_embs is None or (nof_embs[0].N_freqs <= 5 and nof_embs[1].N_freqs == 16))
+
+
+def _nof_param_grads(m, gpre, acts, emb80, req):
+    """dW / db of every NoF layer from the gradient buffer of mf_nof_backward and the forward dump:
+    ONE mf_weight_grads launch (emb80 = the embedded input, 66 columns padded to 80)."""
+    P, dev = acts.shape[0], acts.device
+    D, W = m.D, m.W
+    names = [n for n, _ in m.named_parameters()]
+    grads = {n: None for n in names}
+    gslot = lambda l: gpre[:, l * W:(l + 1) * W]
+    h = lambda l: acts[:, l * W:(l + 1) * W]
+    cin = m.in_channels_xyz + m.extra_feat_dim
+    wants = lambda prefix: req[prefix + ".weight"] or req[prefix + ".bias"]
+    jobs, sinks = [], []
+    for l in range(D):
+        name = f"nof_encoding_{l+1}.0"
+        if not wants(name):
+            continue
+        blocks = []
+        if l == 0 or l in m.skips:
+            jobs.append((gslot(l), emb80, 128, 80, l == 0))
+            blocks.append((len(jobs) - 1, slice(0, cin)))
+        if l > 0:
+            jobs.append((gslot(l), h(l - 1), 128, 128, True))
+            blocks.append((len(jobs) - 1, slice(0, W)))
+        sinks.append((name, blocks, blocks[-1][0]))
+    head_job = None
+    if wants("nof_encoding_final"):
+        jobs.append((gpre[:, D * W:D * W + 12], h(D - 1), 12, 128, True))
+        head_job = len(jobs) - 1
+    res = weight_grads(jobs, P, dev)
+    for prefix, blocks, bias_from in sinks:
+        if req[prefix + ".weight"]:
+            parts = [res[j][0][:, cs] for j, cs in blocks]
+            grads[prefix + ".weight"] = parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, 1)
+        if req[prefix + ".bias"]:
+            grads[prefix + ".bias"] = res[bias_from][1].clone()
+    if head_job is not None:
+        nh = m.nof_encoding_final.weight.shape[0]
+        if req["nof_encoding_final.weight"]:
+            grads["nof_encoding_final.weight"] = res[head_job][0][:nh].contiguous()
+        if req["nof_encoding_final.bias"]:
+            grads["nof_encoding_final.bias"] = res[head_job][1][:nh].clone()
+    return grads
+
+
+class NofModule(torch.autograd.Function):
+    """NoF.forward(inputs, xyz) (models/nof.py:55-85) as called directly by the trainers
+    (trainer_nof.py:85-112 -- the whole of stage 2 --, trainer_moco_flow.py:159-187) when only the
+    parameters need gradients: forward mf_nof_forward_dump, backward mf_nof_backward + mf_weight_grads."""
+
+    @staticmethod
+    def forward(ctx, m, inputs, xyz, *params):
+        B, dev = inputs.shape[0], inputs.device
+        desc, buf = m.packed()
+        stride = m.D * m.W + 16
+        x = inputs.detach().float()
+        if x.stride(1) != 1:
+            x = x.contiguous()
+        pts = xyz.detach().float().contiguous()
+        out = torch.empty((B, 3), device=dev, dtype=torch.float32)
+        acts = torch.empty((B, stride), device=dev, dtype=torch.float32)
+        with torch.cuda.device(dev):
+            L.check(L.lib().mf_nof_forward_dump(C.byref(desc), buf.data_ptr(), x.data_ptr(), x.stride(0), pts.data_ptr(), B,
+                                                out.data_ptr(), acts.data_ptr(), stride, L.current_stream(dev)),
+                    "mf_nof_forward_dump")
+        ctx.m, ctx.stride = m, stride
+        ctx.save_for_backward(x, pts, acts)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        m, stride = ctx.m, ctx.stride
+        x, pts, acts = ctx.saved_tensors
+        B, dev = x.shape[0], x.device
+        names = [n for n, _ in m.named_parameters()]
+        req = {n: p.requires_grad for n, p in m.named_parameters()}
+        with torch.no_grad():
+            desc, buf = m.packed_bwd()
+            noemb = L.mf_embedding()
+            noemb.in_channels, noemb.n_freqs = 3, 0               # no point gradient is requested
+            g_out = g_out.contiguous().float()
+            gpre = torch.empty(((B + 127) // 128 * 128, stride), device=dev, dtype=torch.float32)
+            with torch.cuda.device(dev):
+                L.check(L.lib().mf_nof_backward(C.byref(desc), buf.data_ptr(), C.byref(noemb), B, pts.data_ptr(),
+                                                acts.data_ptr(), stride, g_out.data_ptr(), gpre.data_ptr(), None,
+                                                L.current_stream(dev)), "mf_nof_backward")
+            grads = _nof_param_grads(m, gpre[:B], acts, F.pad(x, (0, 80 - x.shape[1])), req)
+        return (None, None, None) + tuple(grads[n] for n in names)
 
 
 class NofPoints(torch.autograd.Function):
@@ -346,41 +436,7 @@ class NofPoints(torch.autograd.Function):
                                                 acts.data_ptr(), stride, g_out.data_ptr(), gpre.data_ptr(),
                                                 g_pts.data_ptr() if need_pts else None, L.current_stream(dev)),
                         "mf_nof_backward")
-            gpre = gpre[:P]
-            gslot = lambda l: gpre[:, l * W:(l + 1) * W]
-            h = lambda l: acts[:, l * W:(l + 1) * W]
-            cin = m.in_channels_xyz + m.extra_feat_dim
-            wants = lambda prefix: req[prefix + ".weight"] or req[prefix + ".bias"]
-            jobs, sinks = [], []
-            for l in range(D):
-                name = f"nof_encoding_{l+1}.0"
-                if not wants(name):
-                    continue
-                blocks = []
-                if l == 0 or l in m.skips:
-                    jobs.append((gslot(l), emb, 128, 80, l == 0))
-                    blocks.append((len(jobs) - 1, slice(0, cin)))
-                if l > 0:
-                    jobs.append((gslot(l), h(l - 1), 128, 128, True))
-                    blocks.append((len(jobs) - 1, slice(0, W)))
-                sinks.append((name, blocks, blocks[-1][0]))
-            head_job = None
-            if wants("nof_encoding_final"):
-                jobs.append((gpre[:, D * W:D * W + 12], h(D - 1), 12, 128, True))
-                head_job = len(jobs) - 1
-            res = weight_grads(jobs, P, dev)
-            for prefix, blocks, bias_from in sinks:
-                if req[prefix + ".weight"]:
-                    parts = [res[j][0][:, cs] for j, cs in blocks]
-                    grads[prefix + ".weight"] = parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, 1)
-                if req[prefix + ".bias"]:
-                    grads[prefix + ".bias"] = res[bias_from][1].clone()
-            if head_job is not None:
-                nh = m.nof_encoding_final.weight.shape[0]
-                if req["nof_encoding_final.weight"]:
-                    grads["nof_encoding_final.weight"] = res[head_job][0][:nh].contiguous()
-                if req["nof_encoding_final.bias"]:
-                    grads["nof_encoding_final.bias"] = res[head_job][1][:nh].clone()
+            grads = _nof_param_grads(m, gpre[:P], acts, emb, req)
         return (None, None, None, None, g_pts) + tuple(grads[n] for n in names)
 
 

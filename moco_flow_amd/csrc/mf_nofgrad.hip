@@ -31,7 +31,9 @@ struct NofDumpParams {
   NetDev net;
   EmbParams exyz, eind;
   const float* pts;          // (P,3)
-  const float* ind;          // per ray: ind[ray * ind_stride]
+  const float* inputs;       // (P, in_stride) pre-embedded [xyz 33 | ind 33] rows (module-level call), or null
+  long long in_stride;
+  const float* ind;          // per ray: ind[ray * ind_stride]   (unused with `inputs`)
   long long ind_stride;
   long long P;
   int S;                     // samples per ray: sample s belongs to ray s / S
@@ -60,10 +62,20 @@ __global__ __launch_bounds__(kThreads, 2) void nof_points_dump_kernel(NofDumpPar
     const bool valid = s < p.P;
     const long long ss = valid ? s : p.P - 1;
     const float x[3] = {p.pts[ss * 3 + 0], p.pts[ss * 3 + 1], p.pts[ss * 3 + 2]};
-    const float indv = p.ind[(ss / p.S) * p.ind_stride];
     float emb[kStepsNofIn];
-    nof_embed(emb, x, indv, p.exyz, p.eind, id.g);
-    if (valid) {
+    if (p.inputs) {
+      const float* row = p.inputs + ss * p.in_stride;
+#pragma unroll
+      for (int e = 0; e < kStepsNofIn; ++e) {
+        const int f = sel4(id.g, emb_feature(kEmbNofIn, 0, e, 33), emb_feature(kEmbNofIn, 1, e, 33),
+                           emb_feature(kEmbNofIn, 2, e, 33), emb_feature(kEmbNofIn, 3, e, 33));
+        emb[e] = f >= 0 ? row[f] : 0.f;
+      }
+    } else {
+      const float indv = p.ind[(ss / p.S) * p.ind_stride];
+      nof_embed(emb, x, indv, p.exyz, p.eind, id.g);
+    }
+    if (valid && p.emb) {
       float* erow = p.emb + s * kNofEmbCols;
 #pragma unroll
       for (int e = 0; e < kStepsNofIn; ++e) {
@@ -437,7 +449,7 @@ extern "C" int32_t mf_nof_points_dump(const mf_nof_desc* d, const void* packed, 
   p.net.res_lds = 0;
   emb_params(*emb_xyz, p.exyz);
   emb_params(*emb_ind, p.eind);
-  p.pts = pts; p.ind = ind; p.ind_stride = ind_stride; p.P = P; p.S = S; p.out = out; p.acts = acts; p.stride = stride; p.emb = emb;
+  p.pts = pts; p.inputs = nullptr; p.in_stride = 0; p.ind = ind; p.ind_stride = ind_stride; p.P = P; p.S = S; p.out = out; p.acts = acts; p.stride = stride; p.emb = emb;
   p.ring_off = (uint32_t)p.net.L.res_bytes;
   p.buf_bytes = (uint32_t)p.net.L.max_groups * kGroupBytes;
   const size_t lds = p.ring_off + 3 * (size_t)p.buf_bytes;
@@ -447,6 +459,30 @@ extern "C" int32_t mf_nof_points_dump(const mf_nof_desc* d, const void* packed, 
   const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
   hipLaunchKernelGGL(nof_points_dump_kernel, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
   return check_launch("mf_nof_points_dump");
+}
+
+extern "C" int32_t mf_nof_forward_dump(const mf_nof_desc* d, const void* packed, const float* inputs, int64_t in_stride,
+                                       const float* xyz, int64_t B, float* out, float* acts, int64_t stride, void* stream) {
+  if (!d || !packed || (B > 0 && (!inputs || !xyz || !out || !acts)))
+    return fail(MF_E_INVALID, "mf_nof_forward_dump: null argument");
+  NofDumpParams p{};
+  if (!nof_layout(*d, p.net.L)) return fail(MF_E_UNSUPPORTED, "mf_nof_forward_dump: unsupported NoF configuration");
+  if (stride < (int64_t)d->D * kNofW + kNofHeadPad || (stride & 3))
+    return fail(MF_E_INVALID, "mf_nof_forward_dump: stride=%lld invalid", (long long)stride);
+  if (B == 0) return MF_OK;
+  p.net.packed = static_cast<const char*>(packed);
+  p.net.res_lds = 0;
+  p.pts = xyz; p.inputs = inputs; p.in_stride = in_stride; p.ind = nullptr; p.ind_stride = 0; p.P = B; p.S = 1;
+  p.out = out; p.acts = acts; p.stride = stride; p.emb = nullptr;
+  p.ring_off = (uint32_t)p.net.L.res_bytes;
+  p.buf_bytes = (uint32_t)p.net.L.max_groups * kGroupBytes;
+  const size_t lds = p.ring_off + 3 * (size_t)p.buf_bytes;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(nof_points_dump_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(MF_E_LAUNCH, "mf_nof_forward_dump: cannot reserve %zu bytes of LDS", lds);
+  const long long ntiles = (B + kTile - 1) / kTile;
+  const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
+  hipLaunchKernelGGL(nof_points_dump_kernel, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+  return check_launch("mf_nof_forward_dump");
 }
 
 extern "C" int64_t mf_nof_bwd_packed_bytes(const mf_nof_desc* d) {

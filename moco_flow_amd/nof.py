@@ -83,18 +83,22 @@ class NoF(nn.Module):
         width = self.in_channels_xyz + self.extra_feat_dim
         if inputs.dim() != 2 or inputs.shape[1] != width or xyz.shape != (inputs.shape[0], 3):
             raise RuntimeError(f"NoF expects inputs (B, {width}) and xyz (B, 3), got {tuple(inputs.shape)}, {tuple(xyz.shape)}")
+        from . import autograd as A
+        wrt = [t for t in (inputs, xyz) if torch.is_grad_enabled() and t.requires_grad]
+        B = inputs.shape[0]
+        if (A.needs_grad([self]) and not wrt and B > 0 and A.NOF_BACKWARD == "hip"
+                and A.nof_hip_supported(self, None)):
+            # training call on data points (stage 2, SMPL-point losses): HIP forward-with-dump + HIP backward
+            return A.NofModule.apply(self, inputs, xyz, *self.parameters())
         desc, buf = self.packed()
         x = inputs.detach().float()
         if x.stride(1) != 1:
             x = x.contiguous()
         p = xyz.detach().float().contiguous()
-        B = x.shape[0]
         out = torch.empty((B, 3), device=x.device, dtype=torch.float32)
         with torch.cuda.device(x.device):
             L.check(L.lib().mf_nof_forward(desc, buf.data_ptr(), L.ptr(x), x.stride(0) if B else width, L.ptr(p), B,
                                            L.ptr(out), L.current_stream(x.device)), "mf_nof_forward")
-        from . import autograd as A
-        wrt = [t for t in (inputs, xyz) if torch.is_grad_enabled() and t.requires_grad]
         if A.needs_grad([self]) or wrt:
             out, = A.attach([out], [p for p in self.parameters()] + wrt, lambda: [A.nof_forward(self, inputs, xyz)])
         return out

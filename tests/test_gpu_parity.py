@@ -831,3 +831,30 @@ def test_training_gradients_are_reproducible(M, name):
     for x, y, z in zip(a, b, c4):
         assert torch.equal(x, y)
         assert torch.equal(4.0 * x, z)
+
+
+@pytest.mark.parametrize("quat,B", [(True, 1000), (False, 333)])
+def test_nof_module_training_call(M, quat, B):
+    """NoF(inputs, xyz) on data points with only the parameters requiring grad (trainer_nof.py:85-125, the
+    stage-2 step; trainer_moco_flow.py:159-187): autograd.NofModule (mf_nof_forward_dump + mf_nof_backward
+    + mf_weight_grads) against torch autograd of the same call, values 1e-5, gradients 1e-4."""
+    from moco_flow_amd import autograd as A, synth
+    torch.manual_seed(2)
+    nof = M.NoF(4, 128, 33, [2], "ind", 33, quat)
+    nof.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nof_state(9, use_quat=quat, tag="fw", head_scale=0.25).items()})
+    nof = nof.cuda()
+    exyz, eind = M.Embedding(3, 5), M.Embedding(1, 16)
+    xyz = torch.randn(B, 3, device="cuda") * 0.6
+    ind = torch.full((B, 1), 0.31, device="cuda")
+    inputs = torch.cat([exyz(xyz), eind(ind)], -1)                  # (B, 66), as forward() of trainer_nof.py builds it
+    target = torch.randn(B, 3, device="cuda")
+    out = nof(inputs, xyz)
+    assert "NofModule" in type(out.grad_fn).__name__
+    torch.nn.functional.mse_loss(out, target).backward()
+    got = {n: q.grad.clone() for n, q in nof.named_parameters()}
+    nof.zero_grad(set_to_none=True)
+    ref = A.nof_forward(nof, inputs, xyz)
+    assert relerr(out, ref) <= 1e-5
+    torch.nn.functional.mse_loss(ref, target).backward()
+    for n, q in nof.named_parameters():
+        assert relerr(got[n], q.grad) <= 1e-4, (n, relerr(got[n], q.grad))

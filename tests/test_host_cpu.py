@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
         assert n in L.SYMBOLS, f"{n} has no ctypes prototype"
-    assert lib.mf_version() == L.MF_ABI_VERSION == 6
+    assert lib.mf_version() == L.MF_ABI_VERSION == 7
     # argument validation is host-side and must not need a GPU
     d = L.mf_nerf_desc()
     d.D, d.W, d.in_channels_xyz, d.skip_mask = 8, 256, 63, 1 << 4
@@ -39,7 +39,7 @@ def test_library_exports_every_declared_symbol():
 
 
 def test_backward_entry_points_validate_on_the_host():
-    """ABI v4-v6 (mf_nerf_backward, mf_nof_*, mf_weight_grads, mf_image_compose): sizes, the scheduler's
+    """ABI v4-v7 (mf_nerf_backward, mf_nof_*, mf_weight_grads, mf_image_compose): sizes, the scheduler's
     scratch plan and argument validation are host-side and must not need a GPU."""
     import moco_flow_amd._lib as L
     lib = L.lib()
