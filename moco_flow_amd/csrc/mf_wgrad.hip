@@ -77,6 +77,7 @@ struct WgItem {
   long long cost0;        // start of this item in the linearised cost space
   long long part_off;     // float offset of its first partial in the scratch buffer
   int slot0, n_slots;     // first workgroup touching it, number of partials
+  int dense;              // every workgroup in [slot0, slot0 + n_slots) wrote a partial (false only for tiny P)
   float* dW; float* db;   // final (NOUT, NIN) / (NOUT)
 };
 
@@ -255,10 +256,14 @@ __global__ void wgrad_reduce_kernel(WgParams p) {
   if (e >= nf) return;
   const float* src = p.scratch + it.part_off + e;
   float s = 0.f;
-  for (int k = 0; k < it.n_slots; ++k) {
-    long long b, en;      // workgroups whose range of this item is empty (tiny P) wrote nothing
-    wg_range(p.total_cost, p.grid, it.slot0 + k, it.cost0, wg_stage_cost(it.shape), p.stages, b, en);
-    if (b < en) s += src[(long long)k * nf];
+  if (it.dense) {
+    for (int k = 0; k < it.n_slots; ++k) s += src[(long long)k * nf];
+  } else {
+    for (int k = 0; k < it.n_slots; ++k) {
+      long long b, en;    // workgroups whose range of this item is empty (tiny P) wrote nothing
+      wg_range(p.total_cost, p.grid, it.slot0 + k, it.cost0, wg_stage_cost(it.shape), p.stages, b, en);
+      if (b < en) s += src[(long long)k * nf];
+    }
   }
   int nout, nin;
   switch (it.shape) {
@@ -312,12 +317,13 @@ static int wg_plan(const mf_wgrad_item* items, int n, long long P, WgParams& p, 
   scratch_floats = 0;
   for (int i = 0; i < n; ++i) {
     WgItem& it = p.it[i];
-    int first = -1, last = -1;
+    int first = -1, last = -1, count = 0;
     for (int w = 0; w < p.grid; ++w) {
       long long b, e;
       wg_range(p.total_cost, p.grid, w, it.cost0, wg_stage_cost(it.shape), p.stages, b, e);
-      if (b < e) { if (first < 0) first = w; last = w; }
+      if (b < e) { if (first < 0) first = w; last = w; ++count; }
     }
+    it.dense = first >= 0 && count == last - first + 1;
     it.slot0 = first < 0 ? 0 : first;
     it.n_slots = first < 0 ? 0 : last - first + 1;
     it.part_off = scratch_floats;
