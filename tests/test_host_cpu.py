@@ -230,3 +230,13 @@ def test_two_rank_gloo_sharding_matches_single_process():
     for r in range(world):
         assert got[r][3]["img_loss"] == pytest.approx(want["img_loss"], rel=1e-12)
         assert np.array_equal(got[r][4], ref["rgb_coarse"].numpy())
+
+
+def test_scripts_compile():
+    """bench.py, __graft_entry__.py and every tools/*.py at least byte-compile (they only run on the GPU box)."""
+    import glob
+    import py_compile
+    files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")] + sorted(glob.glob(os.path.join(ROOT, "tools", "*.py")))
+    assert len(files) >= 8
+    for f in files:
+        py_compile.compile(f, doraise=True, cfile=os.devnull)
