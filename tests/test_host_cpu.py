@@ -235,8 +235,8 @@ def test_two_rank_gloo_sharding_matches_single_process():
 def test_scripts_compile():
     """bench.py, __graft_entry__.py and every tools/*.py at least byte-compile (they only run on the GPU box)."""
     import glob
-    import py_compile
     files = [os.path.join(ROOT, "bench.py"), os.path.join(ROOT, "__graft_entry__.py")] + sorted(glob.glob(os.path.join(ROOT, "tools", "*.py")))
     assert len(files) >= 8
     for f in files:
-        py_compile.compile(f, doraise=True, cfile=os.devnull)
+        with open(f) as fh:
+            compile(fh.read(), f, "exec")
