@@ -858,3 +858,40 @@ def test_nof_module_training_call(M, quat, B):
     torch.nn.functional.mse_loss(ref, target).backward()
     for n, q in nof.named_parameters():
         assert relerr(got[n], q.grad) <= 1e-4, (n, relerr(got[n], q.grad))
+
+
+def test_aux_point_losses_train(M):
+    """The joint stage's point losses (trainer_moco_flow.py:330-363): outside points -> bw NoF (module call,
+    HIP NofModule) -> xyz embedding -> NeRF(sigma_only) -> alphas -> mask loss.  Gradients reach the NoF through
+    the NeRF's input; compared with the same chain in plain torch ops."""
+    from moco_flow_amd import autograd as A, synth
+    torch.manual_seed(4)
+    B = 1000
+    load = lambda m, sd: (m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}), m.cuda())[1]
+    nof = load(M.NoF(4, 128, 33, [2], "ind", 33, True), synth.nof_state(3, use_quat=True, tag="bw", head_scale=0.25))
+    nerf = load(M.NeRF(8, 256, 63, [4], "ind", 5), synth.nerf_state(3, extra_feat_type="ind", extra_feat_dim=5, regime="dense"))
+    exyz, eind, nxyz = M.Embedding(3, 5), M.Embedding(1, 16), M.Embedding(3, 10)
+    pts = torch.randn(B, 3, device="cuda") * 0.5
+    ind = torch.full((B, 1), 0.1, device="cuda")
+
+    def chain(nof_call, emb_call, nerf_call):
+        inp = torch.cat([emb_call(exyz, pts), emb_call(eind, ind)], -1)
+        canon = nof_call(inp, pts)
+        sig = nerf_call(emb_call(nxyz, canon))
+        alphas = 1 - torch.exp(-(1.0 / 128) * torch.nn.functional.softplus(sig))
+        return canon, (alphas ** 2).mean()
+
+    canon, loss = chain(lambda i, x: nof(i, x), lambda e, x: e(x), lambda z: nerf(z, sigma_only=True))
+    loss.backward()
+    got = {("nof", n): q.grad.clone() for n, q in nof.named_parameters()}
+    got.update({("nerf", n): q.grad.clone() for n, q in nerf.named_parameters() if q.grad is not None})
+    nof.zero_grad(set_to_none=True); nerf.zero_grad(set_to_none=True)
+    canon_t, loss_t = chain(lambda i, x: A.nof_forward(nof, i, x), lambda e, x: A.embed(e, x),
+                            lambda z: A.nerf_forward(nerf, z, sigma_only=True))
+    loss_t.backward()
+    assert relerr(canon, canon_t) <= 1e-5 and relerr(loss, loss_t) <= 1e-4
+    for n, q in nof.named_parameters():
+        assert relerr(got[("nof", n)], q.grad) <= 2e-3, (n, relerr(got[("nof", n)], q.grad))
+    for n, q in nerf.named_parameters():
+        if q.grad is not None:
+            assert relerr(got[("nerf", n)], q.grad) <= 2e-3, (n, relerr(got[("nerf", n)], q.grad))
