@@ -12,7 +12,9 @@ metric = ray-samples/s = (rays x samples evaluated by the network) / wall time, 
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W        # N ranks, weak scaling
 With N > 1 every rank renders its own 4096-ray shard (rays are independent units) and the
-per-batch loss partial sums [sum((rgb-gt)^2), count] are all-reduced over RCCL each step.
+per-batch loss partial sums [sum((rgb-gt)^2), count] are all-reduced over RCCL each step, asynchronously
+(moco_flow_amd.dist.OverlappedLossReducer: the collective of step i overlaps step i+1's kernel).
+(MF_BENCH_BACKEND=gloo MF_BENCH_SHARE_GPU=1: control-flow test of the N > 1 path on a single GPU.)
 
 Extra JSON objects: "roofline" (MFMA bound: algorithmic Linear-layer FLOPs / measured kernel
 time vs the 157.3 TFLOP/s fp32-matrix peak) and "cpu_baseline" (the CPU oracle, a PyTorch
@@ -146,13 +148,19 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit(f"--gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py ...`")
         a.gpus = world
+    if os.environ.get("MF_BENCH_SHARE_GPU"):                          # control-flow tests: every rank on GPU 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        backend = os.environ.get("MF_BENCH_BACKEND", "nccl")           # "nccl" is RCCL on ROCm; "gloo": control-flow tests only
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     import moco_flow_amd as M
     from moco_flow_amd import rendering, synth
@@ -171,15 +179,19 @@ def main():
     if a.workload == "moco":
         kw.update(nof_embeddings=models["nof_embs"], nof_models=models["nofs"], chain_local=True)
 
-    loss_buf = torch.zeros(2, device=dev, dtype=torch.float64)
+    # per-step loss partials [sum (rgb - gt)^2, count], all-reduced over RCCL without serialising with the
+    # next step's launch (moco_flow_amd.dist.OverlappedLossReducer)
+    from moco_flow_amd.dist import OverlappedLossReducer
+    reducer = OverlappedLossReducer(2, dev) if dist is not None else None
+    part = torch.zeros(2, device=dev, dtype=torch.float64)
 
     def step():
         out = M.render_rays(rays, bg, models["embs"], models["nerfs"], **kw)
-        if dist is not None:
+        if reducer is not None:
             d = out["rgb_coarse"] - gt
-            loss_buf[0] = (d * d).sum()
-            loss_buf[1] = d.numel()
-            dist.all_reduce(loss_buf)                                 # RCCL over xGMI, 16 bytes
+            part[0] = (d * d).sum()
+            part[1] = d.numel()
+            reducer.push(part)                                        # RCCL over xGMI, 16 bytes, asynchronous
         return out
 
     with torch.no_grad():
@@ -195,6 +207,8 @@ def main():
             ev[i][0].record()
             out = step()
             ev[i][1].record()
+        if reducer is not None:
+            reducer.finish()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()

@@ -232,6 +232,48 @@ def test_two_rank_gloo_sharding_matches_single_process():
         assert np.array_equal(got[r][4], ref["rgb_coarse"].numpy())
 
 
+def _reducer_worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from moco_flow_amd.dist import OverlappedLossReducer
+    red = OverlappedLossReducer(2, "cpu", depth=2)
+    got = []
+    for step in range(5):
+        part = torch.tensor([float(step * 10 + rank + 1), 1.0], dtype=torch.float64)
+        r = red.push(part, collect=True)
+        if r is not None:
+            got.append(r.tolist())
+    got += [r.tolist() for r in red.finish()]
+    q.put((rank, got))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_loss_reducer_two_rank_gloo():
+    """bench.py's per-step loss all-reduce (asynchronous, rotating buffers): totals come back complete, in
+    issue order, on both ranks; a single process degenerates to the identity."""
+    import torch.multiprocessing as mp
+    from moco_flow_amd.dist import OverlappedLossReducer
+    world, port = 2, 31500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_reducer_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = sorted([q.get(timeout=120) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    want = [[float(2 * (s * 10) + 3), 2.0] for s in range(5)]          # (10 s + 1) + (10 s + 2), counts 1 + 1
+    assert got[0][1] == want and got[1][1] == want
+    solo = OverlappedLossReducer(2, "cpu", depth=3)
+    outs = [solo.push(torch.tensor([float(i), 1.0], dtype=torch.float64), collect=True) for i in range(4)]
+    assert outs[:3] == [None, None, None] and outs[3].tolist() == [0.0, 1.0]
+    assert [r.tolist() for r in solo.finish()] == [[1.0, 1.0], [2.0, 1.0], [3.0, 1.0]]
+
+
 def test_scripts_compile():
     """bench.py, __graft_entry__.py and every tools/*.py at least byte-compile (they only run on the GPU box)."""
     import glob
