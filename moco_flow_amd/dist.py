@@ -1,6 +1,6 @@
 """Ray-sharded multi-GPU rendering: one process per GPU, rays split into
 contiguous blocks, no collective on the data path; the per-batch loss partial sums are
-all-reduced (RCCL over xGMI on the GPU box: backend "nccl" IS RCCL on ROCm; gloo in CPU tests).
+all-reduced (96 B; RCCL over xGMI on the GPU box: backend "nccl" IS RCCL on ROCm; gloo in CPU tests).
 
 The reference itself never synchronises anything across ranks (its DDP wrapper is bypassed,
 SURVEY.md §2c), so there is no reference multi-GPU numerics to match beyond "each rank renders
@@ -24,37 +24,51 @@ def shard_bounds(n_rays: int, rank: int, world: int) -> Tuple[int, int]:
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+N_PARTIALS = 12     # 6 (sum, count) pairs: mse_c, mse_f, local_c, local_f, global_c, global_f
+
+
 def loss_partials(result: Dict[str, torch.Tensor], target: torch.Tensor) -> torch.Tensor:
-    """[sum (rgb_c-gt)^2, n_c, sum (rgb_f-gt)^2, n_f, sum nof_local, n_local, sum nof_global, n_global]
-    in float64: the additive pieces of MSELoss (models/losses.py:4-14) and of the consensus
-    means (trainer_moco_flow.py:317-328) over this rank's rays."""
-    p = torch.zeros(8, dtype=torch.float64, device=target.device)
-    if "rgb_coarse" in result:
-        d = (result["rgb_coarse"] - target).double()
-        p[0], p[1] = (d * d).sum(), d.numel()
-    if "rgb_fine" in result:
-        d = (result["rgb_fine"] - target).double()
-        p[2], p[3] = (d * d).sum(), d.numel()
-    for i, key in ((4, "nof_local_disp"), (6, "nof_global_disp")):
-        s = n = 0.0
+    """The additive pieces of the training losses over this rank's rays, float64, one (sum, count) pair per
+    term the reference averages SEPARATELY:
+      [0:4]  sum (rgb_coarse-gt)^2, n | sum (rgb_fine-gt)^2, n            MSELoss, models/losses.py:4-14
+      [4:8]  sum nof_local_disp_coarse, n | sum nof_local_disp_fine, n     trainer_moco_flow.py:317-321
+      [8:12] sum nof_global_disp_coarse, n | sum nof_global_disp_fine, n   trainer_moco_flow.py:323-327
+    (the reference adds mean(coarse) + mean(fine); pooling both passes into one mean would halve the term
+    and weight it by the mask counts).  Built with one stack: no per-slot indexed writes on the device."""
+    dev = target.device
+    zero = torch.zeros((), dtype=torch.float64, device=dev)
+    parts = []
+    for key in ("rgb_coarse", "rgb_fine"):
+        v = result.get(key)
+        if v is None:
+            parts += [zero, zero]
+        else:
+            d = (v - target).double()
+            parts += [(d * d).sum(), torch.full((), float(d.numel()), dtype=torch.float64, device=dev)]
+    for key in ("nof_local_disp", "nof_global_disp"):
         for tag in ("coarse", "fine"):
             v = result.get(f"{key}_{tag}")
-            if v is not None:
-                s = s + v.double().sum()
-                n = n + v.numel()
-        p[i], p[i + 1] = s, n
-    return p
+            if v is None:
+                parts += [zero, zero]
+            else:
+                parts += [v.double().sum(), torch.full((), float(v.numel()), dtype=torch.float64, device=dev)]
+    return torch.stack(parts)
 
 
 def reduce_loss(partials: torch.Tensor, group=None) -> Dict[str, float]:
-    """All-reduce(SUM) the 64-byte partial vector and turn it into the global means."""
+    """All-reduce(SUM) the 96-byte partial vector and turn it into the reference's global loss terms:
+    img_loss = mse_coarse + mse_fine, nof_local = mean_coarse + mean_fine, nof_global likewise."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
         dist.all_reduce(partials, op=dist.ReduceOp.SUM, group=group)
     p = partials.tolist()
-    mean = lambda s, n: s / n if n > 0 else 0.0
-    return {"mse_coarse": mean(p[0], p[1]), "mse_fine": mean(p[2], p[3]),
-            "nof_local": mean(p[4], p[5]), "nof_global": mean(p[6], p[7]),
-            "img_loss": mean(p[0], p[1]) + mean(p[2], p[3])}
+    mean = lambda i: p[i] / p[i + 1] if p[i + 1] > 0 else 0.0
+    out = {"mse_coarse": mean(0), "mse_fine": mean(2),
+           "nof_local_coarse": mean(4), "nof_local_fine": mean(6),
+           "nof_global_coarse": mean(8), "nof_global_fine": mean(10)}
+    out["img_loss"] = out["mse_coarse"] + out["mse_fine"]
+    out["nof_local"] = out["nof_local_coarse"] + out["nof_local_fine"]
+    out["nof_global"] = out["nof_global_coarse"] + out["nof_global_fine"]
+    return out
 
 
 class OverlappedLossReducer:

@@ -79,6 +79,11 @@ class NeRF(nn.Module):
         cache = self._packed if precision == L.MF_PREC_F32 else self._packed_bf16
         return cache.get(self, self._build_desc, lib.mf_nerf_packed_bytes_p, lib.mf_nerf_pack_p, "NeRF", precision)
 
+    def invalidate_packed(self):
+        """Drop the packed-weight caches (needed only after in-place edits through ``param.data``)."""
+        for c in (self._packed, self._packed_bf16, self._packed_bwd):
+            c.invalidate()
+
     def packed_bwd(self):
         """(descriptor, transposed fragment stream) for mf_nerf_backward; fp32 only."""
         lib = L.lib()

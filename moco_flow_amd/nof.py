@@ -64,6 +64,11 @@ class NoF(nn.Module):
         d.head_w, d.head_b = dp(self.nof_encoding_final.weight), dp(self.nof_encoding_final.bias)
         return d, keep
 
+    def invalidate_packed(self):
+        """Drop the packed-weight caches (needed only after in-place edits through ``param.data``)."""
+        for c in (self._packed, self._packed_bf16, self._packed_bwd):
+            c.invalidate()
+
     def packed_bwd(self):
         """(descriptor, transposed fragment stream) for mf_nof_backward; fp32 only."""
         lib = L.lib()

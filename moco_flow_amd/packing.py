@@ -1,7 +1,12 @@
 """Packed-weights cache: nn.Linear tensors -> the kernels' MFMA fragment stream.
 
 The packed buffer is rebuilt whenever any parameter's storage pointer or version
-counter changes (optimizer.step, load_state_dict, .to(device))."""
+counter changes (optimizer.step, load_state_dict, .to(device)).  Edits made THROUGH ``param.data``
+(``p.data.mul_()``, ``p.data.copy_()``: EMA / manual-init idioms) bump no version counter: call
+``module.invalidate_packed()`` (NeRF / NoF) after them.
+
+The cache holds ctypes structures with raw device pointers, which must not travel: pickling
+(``torch.save(model)``) and ``copy.deepcopy(model)`` drop it and the copy re-packs on first use."""
 import torch
 
 from . import _lib as L
@@ -13,6 +18,18 @@ class PackedWeights:
         self.buf = None
         self.desc = None
         self.keep = None   # contiguous fp32 views the descriptor points into
+
+    def invalidate(self):
+        self.key = self.buf = self.desc = self.keep = None
+
+    def __getstate__(self):          # torch.save(module) / pickle: nothing cached travels
+        return {}
+
+    def __setstate__(self, state):
+        self.invalidate()
+
+    def __deepcopy__(self, memo):    # copy.deepcopy(module): the copy packs its own parameters
+        return PackedWeights()
 
     def get(self, module, build_desc, bytes_fn, pack_fn, what, precision=0):
         params = list(module.parameters())

@@ -232,6 +232,81 @@ def test_two_rank_gloo_sharding_matches_single_process():
         assert np.array_equal(got[r][4], ref["rgb_coarse"].numpy())
 
 
+def _trainer_losses(res, gt):
+    """models/losses.py:4-14 (MSELoss over both passes) and trainer_moco_flow.py:317-328 (consensus means,
+    coarse + fine), op for op."""
+    mse = torch.nn.MSELoss(reduction="mean")
+    img = mse(res["rgb_coarse"], gt)
+    if "rgb_fine" in res:
+        img = img + mse(res["rgb_fine"], gt)
+    out = {"img_loss": float(img)}
+    for key in ("nof_local", "nof_global"):
+        if f"{key}_disp_coarse" in res:
+            v = torch.mean(res[f"{key}_disp_coarse"])
+            if f"{key}_disp_fine" in res:
+                v = v + torch.mean(res[f"{key}_disp_fine"])
+            out[key] = float(v)
+    return out
+
+
+def _moco_fine_oracle(n, lo=0, hi=None):
+    from helpers import build_case, case_inputs
+    from oracle import cpu_ref as R
+    case = dict(extra="ind", regime="dense", nof="global", S=12, M=8, n=n)
+    embs, nerfs, kw = build_case(R, case, 5)
+    rays, bg = case_inputs(case, 5)
+    hi = n if hi is None else hi
+    with torch.no_grad():
+        return R.render_rays(rays[lo:hi], bg[lo:hi], embs, nerfs, **kw)
+
+
+def _moco_loss_worker(rank, world, port, n, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from moco_flow_amd import dist as D, synth
+    lo, hi = D.shard_bounds(n, rank, world)
+    gt = torch.from_numpy(synth.uniform01(11, n * 3).reshape(n, 3).astype(np.float32))
+    res = _moco_fine_oracle(n, lo, hi)
+    q.put((rank, D.reduce_loss(D.loss_partials(res, gt[lo:hi]))))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_loss_partials_match_the_trainer_formulas_moco_fine():
+    """the consensus terms are mean(coarse) + mean(fine) (trainer_moco_flow.py:317-328), not one
+    pooled mean.  Single process and 2-rank gloo (ray-sharded) against MSELoss + the trainer's formula on a
+    MoCo coarse+fine result of the oracle."""
+    import torch.multiprocessing as mp
+    from moco_flow_amd import dist as D, synth
+    n = 21
+    gt = torch.from_numpy(synth.uniform01(11, n * 3).reshape(n, 3).astype(np.float32))
+    res = _moco_fine_oracle(n)
+    assert {"nof_local_disp_fine", "nof_global_disp_fine", "rgb_fine"} <= set(res)
+    want = _trainer_losses(res, gt)
+    got = D.reduce_loss(D.loss_partials(res, gt))
+    for k, v in want.items():
+        assert got[k] == pytest.approx(v, rel=1e-6), k
+    assert D.loss_partials(res, gt).shape == (D.N_PARTIALS,)
+    world, port = 2, 33500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_moco_loss_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=180) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for _, loss in outs:
+        for k, v in want.items():
+            assert loss[k] == pytest.approx(v, rel=1e-6), k
+
+
 def _reducer_worker(rank, world, port, q):
     import torch.distributed as dist
     sys.path.insert(0, ROOT)
@@ -272,6 +347,28 @@ def test_overlapped_loss_reducer_two_rank_gloo():
     outs = [solo.push(torch.tensor([float(i), 1.0], dtype=torch.float64), collect=True) for i in range(4)]
     assert outs[:3] == [None, None, None] and outs[3].tolist() == [0.0, 1.0]
     assert [r.tolist() for r in solo.finish()] == [[1.0, 1.0], [2.0, 1.0], [3.0, 1.0]]
+
+
+def test_packed_cache_does_not_travel():
+    """the packed-weights cache holds ctypes structures with device pointers; deepcopy / pickle of a
+    module that has rendered must work (the copy re-packs) and invalidate_packed() must drop every cache."""
+    import copy
+    import io
+    import pickle
+    import moco_flow_amd as M
+    import moco_flow_amd._lib as L
+    for m in (M.NeRF(8, 256, 63, [4], "dir", 27), M.NoF(4, 128, 33, [2], "ind", 33, True)):
+        for c in (m._packed, m._packed_bf16, m._packed_bwd):       # what a first forward leaves behind
+            c.key, c.desc, c.buf, c.keep = ("k",), (L.mf_nerf_desc(), ctypes.pointer(L.mf_nerf_desc())), object(), [1]
+        m2 = copy.deepcopy(m)
+        assert m2._packed.key is None and m2._packed.desc is None and m2._packed is not m._packed
+        m3 = pickle.loads(pickle.dumps(m))
+        assert m3._packed_bwd.key is None and m3._packed_bf16.buf is None
+        buf = io.BytesIO()
+        torch.save(m, buf)
+        assert set(m3.state_dict()) == set(m.state_dict())
+        m.invalidate_packed()
+        assert all(c.key is None and c.buf is None for c in (m._packed, m._packed_bf16, m._packed_bwd))
 
 
 def test_scripts_compile():
