@@ -1,103 +1,239 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark of the MoCo-Flow volume-rendering hot path on MI355X.
+"""bench.py -- benchmark of the MoCo-Flow volume-rendering hot path on MI355X.
 
-Workload (BASELINE.json configs[1], "C2"): canonical NeRF (8x256, xyz F=10 -> 63, dir F=4 -> 27),
-4096 rays x 64 samples per GPU, fp32 (exact-f32 MFMA), synthetic seeded rays and random-init
-("dense" regime) weights, perturb = 0, noise_std = 0.  A "step" is one render_rays-equivalent
-coarse pass over the batch = ONE launch of the fused kernel (mf_render_pass), inputs already
-resident in HBM, outputs (rgb, depth, opacity) left on the device.
+    python bench.py                                   # 1 GPU, headline (BASELINE config C2)
+    python bench.py --gpus N [--steps K --warmup W]   # N ranks on one node; run BARE it spawns its own
+                                                      # N workers (one per GPU, RCCL), or run it under
+                                                      # `python -m torch.distributed.run --nproc-per-node N`
+    python bench.py --config C3|C3g|C4|C5             # make another BASELINE config the main line
 
-metric = ray-samples/s = (rays x samples evaluated by the network) / wall time, whole job.
-  python bench.py                      # 1 GPU
-  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-         --master-port P bench.py --gpus N --steps K --warmup W        # N ranks, weak scaling
-With N > 1 every rank renders its own 4096-ray shard (rays are independent units) and the
-per-batch loss partial sums [sum((rgb-gt)^2), count] are all-reduced over RCCL each step, asynchronously
-(moco_flow_amd.dist.OverlappedLossReducer: the collective of step i overlaps step i+1's kernel).
-(MF_BENCH_BACKEND=gloo MF_BENCH_SHARE_GPU=1: control-flow test of the N > 1 path on a single GPU.)
+A "step" is one render_rays-equivalent call over the rank's batch, inputs resident in HBM, outputs left on the
+device.  metric = ray-samples/s = network-evaluated samples of all ranks / wall time (max over ranks).
 
-Extra JSON objects: "roofline" (MFMA bound: algorithmic Linear-layer FLOPs / measured kernel
-time vs the 157.3 TFLOP/s fp32-matrix peak) and "cpu_baseline" (the CPU oracle, a PyTorch
-restatement of the reference's op sequence, timed on this box's host cores, rank 0, N=1 only).
+BASELINE.json configs:
+  C2   canonical NeRF 8x256 (xyz F=10, dir F=4), fp32 (exact-f32 MFMA), 4096 rays x 64 samples -- THE HEADLINE:
+       the main line at every N (4096 rays per rank, weak scaling), so that the driver's 1/2/4/8-GPU curve
+       compares like with like.
+  C3   bw NoF -> NeRF(ind) -> fw NoF local chain, bf16 hidden GEMMs, 4096 x 64      (C3g: + global chain)
+  C4   C3 ray-sharded, 4096 rays per rank, per-batch loss partials all-reduced over RCCL (N > 1)
+  C5   coarse 64 + fine 128 with the inverse-CDF resample, MoCo local+global chains, bf16, 1024 rays per rank
+       (8192 rays on 8 GPUs)
+The default run also measures the other configs as short extra legs and reports them in the same JSON line under
+"configs" (N = 1: C3, C3g, C5 shard; N > 1: C4, C5), each with its own roofline fraction, so every BASELINE
+config is driver-measured without changing what `value` means.
+
+Extra JSON objects: "roofline" (MFMA bound: algorithmic Linear-layer FLOPs / measured step span on the launch
+stream vs the dense matrix peak of the dtype) and "cpu_baseline" (the CPU oracle -- a PyTorch restatement of the
+reference's op sequence, pinned to the reference's golden vectors -- timed on this box's host cores with the
+best thread count of a sweep; rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
 
-N_RAYS, N_SAMPLES = 4096, 64
-FLOPS_PER_SAMPLE = {"nerf_dir": 1186816, "nerf_ind": 1181184, "nof_quat": 134400}
-PEAK_F32_TFLOPS = 157.3          # MI355X_MICROARCH.md: fp32-input MFMA, 256 CU @ 2.4 GHz
-PEAK_BF16_TFLOPS = 2516.0        # dense bf16 MFMA (only the hidden GEMMs run there in --precision bf16)
+FLOPS = {"nerf_dir": 1186816, "nerf_ind": 1181184, "nof_quat": 134400}   # per sample, SURVEY.md §8d
+PEAK = {"f32": 157.3, "bf16": 2516.0}     # TFLOP/s, MI355X_MICROARCH.md: fp32-input MFMA / dense bf16 MFMA
+
+CONFIGS = {
+    "C2": dict(net="dir", precision="f32", rays=4096, S=64, M=0, nof=None,
+               what="C2: canonical NeRF 8x256 (xyz F=10, dir F=4), fused HIP encode+MLP+composite, fp32 MFMA"),
+    "C3": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="local",
+               what="C3: bw NoF -> NeRF(ind) -> fw NoF local consensus chain, bf16 hidden GEMMs"),
+    "C3g": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="global",
+                what="C3 + global chain (5 NoF evaluations per sample), bf16 hidden GEMMs"),
+    "C4": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="local", loss=True,
+               what="C4: C3 ray-sharded (4096 rays per rank) + all-reduce of the per-batch loss partials"),
+    "C5": dict(net="ind", precision="bf16", rays=1024, S=64, M=128, nof="global", loss=True,
+               what="C5: coarse 64 + fine 128 (inverse-CDF resample), MoCo local+global chains, bf16, 1024 rays per rank"),
+}
 
 
-def build_models(dev, workload):
-    import moco_flow_amd as M
-    from moco_flow_amd import synth
+def n_nof(cfg):
+    return {None: 0, "bw": 1, "local": 2, "global": 5}[cfg["nof"]]
+
+
+def flops_per_sample(cfg):
+    return FLOPS["nerf_" + cfg["net"]] + n_nof(cfg) * FLOPS["nof_quat"]
+
+
+def samples_per_ray(cfg):
+    return cfg["S"] + ((cfg["S"] + cfg["M"]) if cfg["M"] else 0)
+
+
+# ------------------------------------------------------------------ self-spawn (parent: no GPU call, ever)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def spawn_workers(n, argv):
+    """`bench.py --gpus N` invoked bare: start N fresh worker processes (this same file, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in their environment) BEFORE anything here touches the GPU; rank 0 prints the JSON
+    line on the inherited stdout.  Non-zero exit if any worker fails (the others are then terminated)."""
+    port = _free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), MF_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env))
+    rc = 0
+    alive = list(procs)
+    while alive:
+        time.sleep(0.05)
+        for p in list(alive):
+            code = p.poll()
+            if code is None:
+                continue
+            alive.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in alive:          # exact PIDs we started
+                    q.terminate()
+    return rc
+
+
+# ------------------------------------------------------------------ worker
+def build_models(M, synth, dev, cfg):
+    import torch
     to_t = lambda sd: {k: torch.from_numpy(v) for k, v in sd.items()}
-    if workload == "nerf":
-        sd = synth.nerf_state(0, regime="dense")
-        nerf = M.NeRF(8, 256, 63, [4], "dir", 27)
-        nerf.load_state_dict(to_t(sd))
-        return dict(embs=[M.Embedding(3, 10), None, M.Embedding(3, 4)], nerfs=[nerf.to(dev)], nof_embs=None,
-                    nofs=None, states=dict(nerf=sd))
-    sd = synth.nerf_state(0, extra_feat_type="ind", extra_feat_dim=5, regime="dense")
-    nerf = M.NeRF(8, 256, 63, [4], "ind", 5)
-    nerf.load_state_dict(to_t(sd))
-    bw, fw = M.NoF(4, 128, 33, [2], "ind", 33, True), M.NoF(4, 128, 33, [2], "ind", 33, True)
-    sb, sf = synth.nof_state(0, tag="bw", head_scale=0.25), synth.nof_state(0, tag="fw", head_scale=0.25)
-    bw.load_state_dict(to_t(sb))
-    fw.load_state_dict(to_t(sf))
-    return dict(embs=[M.Embedding(3, 10), M.Embedding(1, 2), None], nerfs=[nerf.to(dev)],
-                nof_embs=[M.Embedding(3, 5), M.Embedding(1, 16)], nofs=[bw.to(dev), fw.to(dev)],
-                states=dict(nerf=sd, bw=sb, fw=sf))
+    dims = {"dir": 27, "ind": 5}[cfg["net"]]
+    states, nerfs = {}, []
+    for tag in (["coarse", "fine"] if cfg["M"] else ["coarse"]):
+        sd = synth.nerf_state(0, extra_feat_type=cfg["net"], extra_feat_dim=dims, regime="dense",
+                              tag="nerf" if tag == "coarse" else "nerf_fine")
+        m = M.NeRF(8, 256, 63, [4], cfg["net"], dims)
+        m.load_state_dict(to_t(sd))
+        nerfs.append(m.to(dev) if dev is not None else m)
+        states[tag] = sd
+    embs = [M.Embedding(3, 10), M.Embedding(1, 2) if cfg["net"] == "ind" else None,
+            M.Embedding(3, 4) if cfg["net"] == "dir" else None]
+    nof_embs = nofs = None
+    if cfg["nof"]:
+        nof_embs, nofs = [M.Embedding(3, 5), M.Embedding(1, 16)], []
+        for tag in ("bw", "fw"):
+            sd = synth.nof_state(0, tag=tag, head_scale=0.25)
+            m = M.NoF(4, 128, 33, [2], "ind", 33, True)
+            m.load_state_dict(to_t(sd))
+            nofs.append(m.to(dev) if dev is not None else m)
+            states[tag] = sd
+    return dict(embs=embs, nerfs=nerfs, nof_embs=nof_embs, nofs=nofs, states=states)
 
 
-def cpu_baseline(workload, states, rays_np, bg_np, budget_s=20.0):
-    """The oracle (kind "port": PyTorch-CPU restatement of the reference op-for-op, pinned to the
-    reference's golden vectors) on the same workload, host cores of this box."""
+def render_kwargs(cfg, models):
+    kw = dict(N_samples=cfg["S"], N_importance=cfg["M"], noise_std=0, perturb=0)
+    if cfg["nof"]:
+        kw.update(nof_embeddings=models["nof_embs"], nof_models=models["nofs"],
+                  chain_local=cfg["nof"] in ("local", "global"), chain_global=cfg["nof"] == "global")
+    return kw
+
+
+def oracle_render(cfg, states, rays, bg, z_fine=None):
+    """The oracle on the same workload (checker / cpu_baseline leg only).  ``z_fine``: evaluate the fine pass on
+    the given (the HIP path's own) fine depths, so that the comparison is sample-for-sample."""
+    import torch
     from oracle import cpu_ref as R
-    cores = torch.get_num_threads()
-    rays, bg = torch.from_numpy(rays_np), torch.from_numpy(bg_np)
-    if workload == "nerf":
-        args = ([R.Embedding(3, 10), None, R.Embedding(3, 4)], [R.build_nerf(states["nerf"])])
-        kw = dict(N_samples=N_SAMPLES, noise_std=0)
-    else:
-        args = ([R.Embedding(3, 10), R.Embedding(1, 2), None],
-                [R.build_nerf(states["nerf"], extra_feat_type="ind", extra_feat_dim=5)])
-        kw = dict(N_samples=N_SAMPLES, noise_std=0, nof_embeddings=[R.Embedding(3, 5), R.Embedding(1, 16)],
-                  nof_models=[R.build_nof(states["bw"]), R.build_nof(states["fw"])], chain_local=True)
+    dims = {"dir": 27, "ind": 5}[cfg["net"]]
+    nerfs = [R.build_nerf(states["coarse"], extra_feat_type=cfg["net"], extra_feat_dim=dims)]
+    if cfg["M"]:
+        nerfs.append(R.build_nerf(states["fine"], extra_feat_type=cfg["net"], extra_feat_dim=dims))
+    embs = [R.Embedding(3, 10), R.Embedding(1, 2) if cfg["net"] == "ind" else None,
+            R.Embedding(3, 4) if cfg["net"] == "dir" else None]
+    kw = dict(N_samples=cfg["S"], N_importance=cfg["M"], noise_std=0, perturb=0)
+    if cfg["nof"]:
+        kw.update(nof_embeddings=[R.Embedding(3, 5), R.Embedding(1, 16)],
+                  nof_models=[R.build_nof(states["bw"]), R.build_nof(states["fw"])],
+                  chain_local=cfg["nof"] in ("local", "global"), chain_global=cfg["nof"] == "global")
+    if z_fine is not None:
+        kw["_z_fine_override"] = z_fine
     with torch.no_grad():
-        R.render_rays(rays[:256], bg[:256], *args, **kw)           # warm-up
-        times = []
-        t_start = time.perf_counter()
-        while len(times) < 5 and (time.perf_counter() - t_start) < budget_s:
-            t0 = time.perf_counter()
-            out = R.render_rays(rays, bg, *args, **kw)
-            times.append(time.perf_counter() - t0)
-    med = float(np.median(times))
-    cpu = "unknown CPU"
+        return R.render_rays(rays, bg, embs, nerfs, **kw)
+
+
+def cpu_model():
     try:
         with open("/proc/cpuinfo") as fh:
-            cpu = next(l.split(":", 1)[1].strip() for l in fh if l.startswith("model name"))
+            return next(l.split(":", 1)[1].strip() for l in fh if l.startswith("model name"))
     except (OSError, StopIteration):
+        return "unknown CPU"
+
+
+def cpu_baseline(cfg, states, rays_np, bg_np, budget_s=30.0):
+    """kind "port": the oracle timed on this box's host cores.  Thread sweep first (one batch each), then the
+    median of up to 3 more batches at the fastest thread count; bounded by `budget_s` of CPU work."""
+    import numpy as np
+    import torch
+    rays, bg = torch.from_numpy(rays_np), torch.from_numpy(bg_np)
+    n = rays.shape[0]
+    ncpu = os.cpu_count() or 8
+    sweep = sorted({t for t in (8, 16, 32, 64, 128) if t <= ncpu} | {min(ncpu, 128)})
+    t_start = time.perf_counter()
+    oracle_render(cfg, states, rays[:128], bg[:128])                  # warm-up
+    per_thread, out = {}, None
+    for t in sweep:
+        if per_thread and time.perf_counter() - t_start > budget_s * 0.6:
+            break
+        torch.set_num_threads(t)
+        t0 = time.perf_counter()
+        out = oracle_render(cfg, states, rays, bg)
+        per_thread[t] = time.perf_counter() - t0
+    best = min(per_thread, key=per_thread.get)
+    torch.set_num_threads(best)
+    times = [per_thread[best]]
+    while len(times) < 4 and time.perf_counter() - t_start < budget_s:
+        t0 = time.perf_counter()
+        out = oracle_render(cfg, states, rays, bg)
+        times.append(time.perf_counter() - t0)
+    med = float(np.median(times))
+    sweep_s = ", ".join(f"{t}t {s:.2f}s" for t, s in per_thread.items())
+    return dict(value=n * samples_per_ray(cfg) / med, unit="ray-samples/s", cores=best, kind="port",
+                sample=f"{len(times)} full {n}x{samples_per_ray(cfg)} batches at the fastest of a thread sweep "
+                       f"({sweep_s}), median {med:.3f} s/batch, torch {torch.__version__} CPU fp32, "
+                       f"{best} threads on {cpu_model()} ({ncpu} logical CPUs)"), out
+
+
+def errors_vs(ref, out):
+    import numpy as np
+    errs, l2 = {}, {}
+    for k, v in ref.items():
+        if k.startswith("nof_") or k not in out:
+            continue
+        g, v = out[k].detach().cpu().double(), v.double()
+        errs[k] = float((g - v).abs().max() / v.abs().max())
+        l2[k] = float((g - v).norm() / v.norm())
+    key = "rgb_fine" if "rgb_fine" in ref else "rgb_coarse"
+    mse = float(((out[key].detach().cpu().double() - ref[key].double()) ** 2).mean())
+    return {"max_rel": errs, "l2_rel": l2, "psnr_equiv_db": (-10 * np.log10(mse)) if mse > 0 else float("inf"),
+            "psnr_key": key}
+
+
+def traffic_of(name):
+    """HBM bytes per launch of the dominant kernel from the committed PMC passes of this same command
+    (profiles/traffic.json, written by tools/summarize_prof.py: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE);
+    null when no profile of this configuration is committed.  Never a number invented here."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
+            t = json.load(fh).get(name)
+        if t:
+            return t["bytes_per_launch"], t["source"]
+    except (OSError, ValueError, KeyError):
         pass
-    return dict(value=N_RAYS * N_SAMPLES / med, unit="ray-samples/s", cores=cores, kind="port",
-                sample=f"{len(times)} full {N_RAYS}x{N_SAMPLES} batches, median {med:.3f} s/batch, "
-                       f"torch {torch.__version__} CPU fp32, {cores} threads on {cpu}"), out
+    return None, None
 
 
-def train_leg(M, models, rays, bg, gt, kw, workload, steps=10):
-    """fwd + bwd of the same batch (reported beside, never instead of, the forward metric):
-    render_rays -> MSE -> backward through the HIP kernels (training forward with dump, mf_nerf_backward,
-    mf_weight_grads; NoF evaluations through mf_nof_points_dump / mf_nof_backward)."""
+def train_leg(M, torch, models, rays, bg, gt, kw, cfg, steps=10):
+    """fwd + bwd of the same batch (reported beside, never instead of, the forward metric)."""
     mods = list(models["nerfs"]) + list(models["nofs"] or [])
     crit = M.get_loss(dict(type="MSE"))
 
@@ -117,96 +253,59 @@ def train_leg(M, models, rays, bg, gt, kw, workload, steps=10):
         one()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / steps * 1e3
-    # Linear-layer MACs x 2: forward + weight gradients (593 408 each) + input-gradient chain (557 696)
-    flops = 2 * (593408 * 2 + 557696) if workload == "nerf" else None
-    out = {"value": N_RAYS * N_SAMPLES / (ms * 1e-3), "unit": "ray-samples/s", "ms_per_step": ms, "steps": steps,
-           "what": "render_rays + MSELoss + backward (all parameter gradients), same batch as the headline"}
-    if flops:
+    n = rays.shape[0] * samples_per_ray(cfg)
+    out = {"value": n / (ms * 1e-3), "unit": "ray-samples/s", "ms_per_step": ms, "steps": steps,
+           "what": "render_rays + MSELoss + backward (all parameter gradients), same batch as the main line"}
+    if cfg["nof"] is None and cfg["net"] == "dir":
+        # Linear-layer MACs x 2: forward + weight gradients (593 408 each) + input-gradient chain (557 696)
+        flops = 2 * (593408 * 2 + 557696)
         out["flops_per_sample"] = flops
-        out["mfma_frac"] = N_RAYS * N_SAMPLES * flops / (ms * 1e-3) / 1e12 / PEAK_F32_TFLOPS
+        out["mfma_frac"] = n * flops / (ms * 1e-3) / 1e12 / PEAK["f32"]
     return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["nerf", "moco"], default="nerf",
-                    help="nerf = BASELINE config C2 (headline); moco = C3-shaped chain in fp32")
-    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
-                    help="f32 = exact-fp32 MFMA (headline, config C2); bf16 = bf16 hidden GEMMs (configs C3-C5)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-train-leg", action="store_true",
-                    help="skip the extra fwd+bwd measurement (SURVEY.md §8d: reported separately from the graded forward)")
-    a = ap.parse_args()
+def run_config(name, a, ctx, steps, warmup, main):
+    """Time `steps` steps of configuration `name` on this rank.  Returns the result dict (rank-local timing
+    already reduced with MAX over ranks)."""
+    import numpy as np
+    import torch
+    M, synth, rendering, dist, dev, rank, world = (ctx[k] for k in ("M", "synth", "rendering", "dist", "dev", "rank", "world"))
+    cfg = CONFIGS[name]
+    rendering.set_precision(cfg["precision"])
+    models = build_models(M, synth, dev, cfg)
+    n = cfg["rays"]
+    rays_np, bg_np = synth.rays(0, n * world, chained=(cfg["nof"] == "global"))    # weak scaling: contiguous blocks
+    lo = rank * n
+    rays = torch.from_numpy(rays_np[lo:lo + n]).to(dev)
+    bg = torch.from_numpy(bg_np[lo:lo + n]).to(dev)
+    gt = torch.from_numpy(synth.uniform01(123 + rank, n * 3).reshape(n, 3).astype(np.float32)).to(dev)
+    kw = render_kwargs(cfg, models)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if a.gpus != world:
-        if world == 1 and a.gpus > 1:
-            raise SystemExit(f"--gpus {a.gpus} needs `python -m torch.distributed.run --nproc-per-node {a.gpus} bench.py ...`")
-        a.gpus = world
-    if os.environ.get("MF_BENCH_SHARE_GPU"):                          # control-flow tests: every rank on GPU 0
-        local_rank = 0
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        backend = os.environ.get("MF_BENCH_BACKEND", "nccl")           # "nccl" is RCCL on ROCm; "gloo": control-flow tests only
-        if backend == "nccl":
-            dist.init_process_group(backend="nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend=backend)
+    from moco_flow_amd.dist import N_PARTIALS, OverlappedLossReducer, loss_partials
+    with_loss = world > 1 or cfg.get("loss")
+    reducer = OverlappedLossReducer(N_PARTIALS, dev) if with_loss else None
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
 
-    import moco_flow_amd as M
-    from moco_flow_amd import rendering, synth
-    rendering.STRICT_RNG = False        # noise_std = 0: do not launch the reference's dead randn
-    rendering.set_precision(a.precision)
-    M._lib.lib()                        # fail loudly if the HIP library is missing
-
-    models = build_models(dev, a.workload)
-    # weak scaling: each rank owns a contiguous block of the global batch (global ray order kept)
-    rays_np, bg_np = synth.rays(0, N_RAYS * world, chained=False)
-    lo = rank * N_RAYS
-    rays = torch.from_numpy(rays_np[lo:lo + N_RAYS]).to(dev)
-    bg = torch.from_numpy(bg_np[lo:lo + N_RAYS]).to(dev)
-    gt = torch.from_numpy(synth.uniform01(123 + rank, N_RAYS * 3).reshape(N_RAYS, 3).astype(np.float32)).to(dev)
-    kw = dict(N_samples=N_SAMPLES, noise_std=0, perturb=0)
-    if a.workload == "moco":
-        kw.update(nof_embeddings=models["nof_embs"], nof_models=models["nofs"], chain_local=True)
-
-    # per-step loss partials [sum (rgb - gt)^2, count], all-reduced over RCCL without serialising with the
-    # next step's launch (moco_flow_amd.dist.OverlappedLossReducer)
-    from moco_flow_amd.dist import OverlappedLossReducer
-    reducer = OverlappedLossReducer(2, dev) if dist is not None else None
-    part = torch.zeros(2, device=dev, dtype=torch.float64)
-
-    def step():
+    def step(i=None):
+        if i is not None:
+            ev[i][0].record()
         out = M.render_rays(rays, bg, models["embs"], models["nerfs"], **kw)
+        if i is not None:
+            ev[i][1].record()                      # span of the render pass only: before the loss partials / collective
         if reducer is not None:
-            d = out["rgb_coarse"] - gt
-            part[0] = (d * d).sum()
-            part[1] = d.numel()
-            reducer.push(part)                                        # RCCL over xGMI, 16 bytes, asynchronous
+            reducer.push(loss_partials(out, gt))   # 96 B; RCCL over xGMI when world > 1, asynchronous
         return out
 
     with torch.no_grad():
-        for _ in range(a.warmup):
+        for _ in range(warmup):
             out = step()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.steps)]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for i in range(a.steps):
-            ev[i][0].record()
-            out = step()
-            ev[i][1].record()
+        for i in range(steps):
+            out = step(i)
         if reducer is not None:
             reducer.finish()
         torch.cuda.synchronize()
@@ -217,52 +316,136 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))   # per-launch span on the launch stream
+    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
 
-    samples = N_RAYS * N_SAMPLES * world * a.steps
-    value = samples / elapsed
-    if a.workload == "nerf":
-        flops_per_sample = FLOPS_PER_SAMPLE["nerf_dir"]
-    else:
-        flops_per_sample = FLOPS_PER_SAMPLE["nerf_ind"] + 2 * FLOPS_PER_SAMPLE["nof_quat"]
-    achieved = N_RAYS * N_SAMPLES * flops_per_sample / (kernel_ms * 1e-3) / 1e12
-    peak = PEAK_F32_TFLOPS if a.precision == "f32" else PEAK_BF16_TFLOPS
-    line = {
-        "metric": "ray-samples/sec (4096 rays x 64 samples)", "value": value, "unit": "ray-samples/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": elapsed / a.steps * 1e3,
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": a.precision, "data": "synthetic",
-        "config": {"workload": ("C2: canonical NeRF 8x256 (xyz F=10, dir F=4), fused HIP encode+MLP+composite, "
-                                "fp32 MFMA" if a.workload == "nerf" else
-                                "C3-shaped: bw NoF -> NeRF(ind) -> fw NoF local chain") + f" [{a.precision}]",
-                   "rays_per_gpu": N_RAYS, "samples_per_ray": N_SAMPLES, "global_rays": N_RAYS * world,
-                   "sharding": f"rays{world}" if world > 1 else "none"},
+    spr = samples_per_ray(cfg)
+    value = n * spr * world * steps / elapsed
+    flops_step = n * spr * flops_per_sample(cfg)
+    achieved = flops_step / (kernel_ms * 1e-3) / 1e12
+    peak = PEAK[cfg["precision"]]
+    traffic, traffic_src = traffic_of(name)
+    res = {
+        "value": value, "ms_per_step": elapsed / steps * 1e3, "dtype": cfg["precision"],
+        "config": {"workload": cfg["what"] + f" [{cfg['precision']}]", "rays_per_gpu": n,
+                   "samples_per_ray": spr, "global_rays": n * world,
+                   "sharding": f"rays{world}" if world > 1 else "none",
+                   "loss_allreduce": bool(reducer is not None and world > 1)},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved / peak,
-                     # HBM bytes per launch from the committed PMC passes of this same command
-                     # (profiles/r01f_summary.txt: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE); C2 only
-                     "traffic": 26.2e6 if (a.workload == "nerf" and a.precision == "f32") else None,
-                     "traffic_unit": "B/launch",
-                     "kernel_ms": kernel_ms, "flops_per_launch": N_RAYS * N_SAMPLES * flops_per_sample},
+                     "frac": achieved / peak, "traffic": traffic, "traffic_unit": "B/launch",
+                     "traffic_source": traffic_src, "kernel_ms": kernel_ms,
+                     "launches_per_step": 2 if cfg["M"] else 1, "flops_per_step": flops_step},
     }
-    if rank == 0 and world == 1 and not a.no_train_leg and a.precision == "f32":
-        line["fwd_bwd"] = train_leg(M, models, rays, bg, gt, kw, a.workload)
+    if main and rank == 0 and world == 1 and not a.no_train_leg and cfg["precision"] == "f32":
+        res["fwd_bwd"] = train_leg(M, torch, models, rays, bg, gt, kw, cfg)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
-        base, ref = cpu_baseline(a.workload, models["states"], rays_np[:N_RAYS], bg_np[:N_RAYS])
-        line["cpu_baseline"] = base
-        errs, l2 = {}, {}
-        for k, v in ref.items():
-            if k.startswith("nof_"):
-                continue
-            g = out[k].cpu().double()
-            errs[k] = float((g - v.double()).abs().max() / v.double().abs().max())
-            l2[k] = float((g - v.double()).norm() / v.double().norm())
-        mse = float(((out["rgb_coarse"].cpu().double() - ref["rgb_coarse"].double()) ** 2).mean())
-        line["error_vs_cpu"] = {"max_rel": errs, "l2_rel": l2, "psnr_equiv_db": (-10 * np.log10(mse)) if mse > 0 else float("inf")}
-        line["speedup_vs_cpu"] = value / base["value"]
+        if main:
+            base, ref = cpu_baseline(cfg, models["states"], rays_np[:n], bg_np[:n])
+            res["cpu_baseline"] = base
+            res["speedup_vs_cpu"] = value / base["value"]
+        k = n if (main and not cfg["M"]) else min(512, n)
+        if not (main and not cfg["M"]):             # accuracy on a bounded 512-ray sample; with a fine pass the
+            cap = {}                                # oracle evaluates it on the HIP path's own fine depths
+            with torch.no_grad():
+                out = M.render_rays(rays[:k], bg[:k], models["embs"], models["nerfs"], _capture=cap, **kw)
+            ref = oracle_render(cfg, models["states"], torch.from_numpy(rays_np[:k]), torch.from_numpy(bg_np[:k]),
+                                z_fine=cap["z_fine"].cpu() if cfg["M"] else None)
+        res["error_vs_cpu"] = errors_vs(ref, out)
+        res["error_vs_cpu"]["sample"] = f"first {k} rays of the batch vs the CPU oracle" + (
+            " (fine pass on the HIP path's own resampled depths)" if cfg["M"] else "")
+    return res
+
+
+def dryrun_worker(a, rank, world):
+    """MF_BENCH_DRYRUN=1 (CPU control-flow test of the self-spawn / rendezvous / reduction path, no GPU):
+    gloo process group, the overlapped loss reducer on CPU tensors, MAX-over-ranks timing, one JSON line."""
+    import torch
+    import torch.distributed as dist
+    from moco_flow_amd.dist import N_PARTIALS, OverlappedLossReducer
+    if world > 1:
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    red = OverlappedLossReducer(N_PARTIALS, "cpu")
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        red.push(torch.full((N_PARTIALS,), float(rank + 1), dtype=torch.float64))
+    tot = red.finish()
+    t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dist.barrier()
     if rank == 0:
-        print(json.dumps(line))
+        print(json.dumps({"metric": "dryrun", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+                          "reduced": tot[-1].tolist()[0], "elapsed": float(t.item()), "dryrun": True}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def worker(a):
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if os.environ.get("MF_BENCH_DRYRUN"):
+        return dryrun_worker(a, rank, world)
+    import torch
+    if os.environ.get("MF_BENCH_SHARE_GPU"):                          # control-flow tests: every rank on GPU 0
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        backend = os.environ.get("MF_BENCH_BACKEND", "nccl")           # "nccl" IS RCCL on ROCm; "gloo": control-flow tests only
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
+
+    import moco_flow_amd as M
+    from moco_flow_amd import rendering, synth
+    rendering.STRICT_RNG = False        # noise_std = 0: do not launch the reference's dead randn (rendering.py:166)
+    M._lib.lib()                        # fail loudly if the HIP library is missing
+    ctx = dict(M=M, synth=synth, rendering=rendering, dist=dist, dev=dev, rank=rank, world=world)
+
+    main_cfg = a.config
+    res = run_config(main_cfg, a, ctx, a.steps, a.warmup, main=True)
+    line = {
+        "metric": "ray-samples/sec (4096 rays x 64 samples)", "value": res["value"], "unit": "ray-samples/s",
+        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic",
+        "config": res["config"], "roofline": res["roofline"],
+    }
+    for k in ("fwd_bwd", "cpu_baseline", "error_vs_cpu", "speedup_vs_cpu"):
+        if k in res:
+            line[k] = res[k]
+    if not a.no_extra_legs and a.config == "C2":
+        legs = ["C3", "C3g", "C5"] if world == 1 else ["C4", "C5"]
+        line["configs"] = {}
+        for name in legs:
+            r = run_config(name, a, ctx, min(a.steps, 20), min(a.warmup, 3), main=False)
+            line["configs"][name] = {k: r[k] for k in ("value", "ms_per_step", "dtype", "config", "roofline", "error_vs_cpu") if k in r}
+    if rank == 0:
+        print(json.dumps(line), flush=True)
     if dist is not None:
         dist.destroy_process_group()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--config", choices=sorted(CONFIGS), default="C2",
+                    help="BASELINE.json configuration of the main line (default C2 = the headline, at every N)")
+    ap.add_argument("--no-extra-legs", action="store_true", help="skip the short legs of the other BASELINE configs")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-leg", action="store_true",
+                    help="skip the extra fwd+bwd measurement (SURVEY.md §8d: reported separately from the graded forward)")
+    a = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if a.gpus > 1 and world == 1 and not os.environ.get("MF_BENCH_CHILD"):
+        sys.exit(spawn_workers(a.gpus, sys.argv[1:]))      # nothing above touched the GPU (torch is not even imported)
+    a.gpus = world
+    worker(a)
 
 
 if __name__ == "__main__":

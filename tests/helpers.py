@@ -25,10 +25,11 @@ def relerr(a, b):
     return float((a - b).abs().max() / b.abs().max().clamp_min(1e-30))
 
 
-def build_case(backend, case, seed, device="cpu"):
+def build_case(backend, case, seed, device="cpu", tags=None):
     """backend: a module exposing Embedding / NeRF / NoF classes with the reference's
     constructor signatures and ``load_state_dict``."""
     c = case if isinstance(case, dict) else RENDER_CASES[case]
+    tags = tags or {}          # weight-stream names per role (bench.py draws "nerf" / "nerf_fine" / "bw" / "fw")
     nof = c.get("nof", "none")
     extra = c["extra"]
     extra_dim = {"dir": 27, "ind": 5, "none": 0}[extra]
@@ -42,13 +43,13 @@ def build_case(backend, case, seed, device="cpu"):
     def nerf(tag):
         m = backend.NeRF(8, 256, 63, [4], extra, extra_dim)
         sd = synth.nerf_state(seed, extra_feat_type=extra, extra_feat_dim=extra_dim,
-                              regime=c["regime"], tag=tag)
+                              regime=c["regime"], tag=tags.get(tag, tag))
         m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         return m.to(device) if hasattr(m, "to") else m
 
     def nof_model(tag):
         m = backend.NoF(4, 128, 33, [2], "ind", 33, c.get("quat", True))
-        sd = synth.nof_state(seed, use_quat=c.get("quat", True), tag=tag, head_scale=0.25)
+        sd = synth.nof_state(seed, use_quat=c.get("quat", True), tag=tags.get(tag, tag), head_scale=0.25)
         m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
         return m.to(device) if hasattr(m, "to") else m
 

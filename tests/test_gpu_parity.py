@@ -392,12 +392,36 @@ def test_module_gradients(M):
     assert relerr(x.grad, want) <= 1e-5
 
 
-@pytest.mark.parametrize("name", ["r_nerf_dir_dense", "r_moco_global", "r_nerf_dir_fine_train", "r_nerf_dir_default"])
+def _psnr(a, b):
+    """models/metrics.py:4-13 with unit peak: -10 log10(mean((a-b)^2))."""
+    mse = float(((torch.as_tensor(a).detach().cpu().double() - torch.as_tensor(b).detach().cpu().double()) ** 2).mean())
+    return -10 * np.log10(mse) if mse > 0 else 200.0
+
+
+def _l2rel(a, b):
+    a, b = torch.as_tensor(a).detach().cpu().double(), torch.as_tensor(b).detach().cpu().double()
+    return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+
+# bf16 bars: a few dB / a factor ~2 under what the kernels measure (printed by the tests; profiles/README.md), so
+# that a regression of the bf16 arithmetic fails instead of hiding under a generic "> 38 dB".
+#            case                     PSNR-equiv rgb (dB)   l2-rel rgb   l2-rel depth/opacity
+# measured r2 (dB / l2 rgb / worst l2 of depth, opacity): dense 61.5 / 1.2e-3 / 7.5e-4; fine_train 57.5 / 1.7e-3 /
+# 4.1e-3; default 95.0 / 3.6e-5 / 1.7e-5; moco_global 46.1 / 9.2e-3; moco_global_fine 50.4 / 4.6e-3 / 5.7e-4
+BF16_BARS = {"r_nerf_dir_dense":      (58.0,                3e-3,        2e-3),
+             "r_nerf_dir_fine_train": (55.0,                4e-3,        8e-3),
+             "r_nerf_dir_default":    (92.0,                1e-4,        1e-4),
+             "r_moco_global":         (44.0,                1.4e-2,      2e-2),
+             "r_moco_global_fine":    (48.0,                8e-3,        2e-3)}
+
+
+@pytest.mark.parametrize("name", sorted(BF16_BARS))
 def test_bf16_hidden_gemms(M, R, name):
-    """BASELINE configs C3-C5: bf16 hidden GEMMs (fp32 accumulate; embedded-input k-ranges, heads and
-    composite in fp32). Not the 1e-4 contract -- the metric there is a PSNR-equivalent error
-    (SURVEY.md §8d): require > 38 dB on the rendered colours and 3e-2 max-rel, and exact agreement
-    of everything that does not touch a hidden GEMM."""
+    """BASELINE configs C3-C5: bf16 hidden GEMMs (fp32 accumulate; embedded-input k-ranges as a 16-bit two-term
+    bf16 split; heads and composite in fp32).  Not the 1e-4 contract -- north_star allows a PSNR-equivalent
+    error for bf16 -- but the bars sit just under the measured values (BF16_BARS), per case,
+    with l2-rel bounds on every per-ray output.  With a fine pass the oracle is re-run on the HIP path's own
+    fine depths, so the resample's conditioning does not enter."""
     from moco_flow_amd import rendering
     c = dict(RENDER_CASES[name])
     g = load_golden(name)
@@ -405,21 +429,142 @@ def test_bf16_hidden_gemms(M, R, name):
     embs, nerfs, kw = build_case(M, c, seed, device="cuda")
     rays = torch.from_numpy(g["in_rays"]).cuda()
     bg = torch.from_numpy(g["in_background"]).cuda() if c.get("bg", True) else None
+    cap = {}
     try:
         rendering.set_precision("bf16")
         with torch.no_grad():
-            res = M.render_rays(rays, bg, embs, nerfs, **kw)
+            res = M.render_rays(rays, bg, embs, nerfs, _capture=cap, **kw)
     finally:
         rendering.set_precision("f32")
+    want = {k[4:]: torch.from_numpy(v) for k, v in g.items() if k.startswith("out_")}
+    if c["M"] > 0:
+        embs_o, nerfs_o, kw_o = build_case(R, c, seed)
+        with torch.no_grad():
+            w2 = R.render_rays(rays.cpu(), bg.cpu() if bg is not None else None, embs_o, nerfs_o,
+                               _z_fine_override=cap["z_fine"].cpu(), **kw_o)
+        want.update({k: v for k, v in w2.items() if "fine" in k})
+    bar_db, bar_rgb, bar_other = BF16_BARS[name]
+    for k, v in want.items():
+        if k.startswith("nof_"):
+            continue
+        ps, l2 = _psnr(res[k], v), _l2rel(res[k], v)
+        print(f"{name} {k}: bf16 PSNR-equiv {ps:.1f} dB, l2-rel {l2:.2e}, max-rel {relerr(res[k], v):.2e}")
+        if k.startswith("rgb"):
+            assert ps >= bar_db, (k, ps)
+            assert l2 <= bar_rgb, (k, l2)
+        else:
+            assert l2 <= bar_other, (k, l2)
+
+
+BENCH_TAGS = dict(coarse="nerf", fine="nerf_fine")      # the weight draw bench.py times (tags of synth.*_state)
+
+
+def _full_size_case(M, R, name, n, precision, tags=None):
+    """HIP path at a BASELINE size vs the oracle on the same seeded synthetic batch (bench.py's generator).
+    ``tags``: which random weight draw (None = the golden cases' draw, BENCH_TAGS = bench.py's)."""
+    from moco_flow_amd import rendering, synth
+    c = dict(RENDER_CASES[name])
+    seed = 0
+    rays_np, bg_np = synth.rays(seed, n, chained=(c.get("nof") == "global"))
+    rays, bg = torch.from_numpy(rays_np), torch.from_numpy(bg_np)
+    embs_o, nerfs_o, kw_o = build_case(R, c, seed, tags=tags)
+    embs, nerfs, kw = build_case(M, c, seed, device="cuda", tags=tags)
+    cap = {}
+    try:
+        rendering.set_precision(precision)
+        with torch.no_grad():
+            res = M.render_rays(rays.cuda(), bg.cuda(), embs, nerfs, _capture=cap, **kw)
+    finally:
+        rendering.set_precision("f32")
+    with torch.no_grad():
+        extra = dict(_z_fine_override=cap["z_fine"].cpu()) if c["M"] > 0 else {}
+        want = R.render_rays(rays, bg, embs_o, nerfs_o, **extra, **kw_o)
+    return c, res, want
+
+
+@pytest.mark.parametrize("name", ["r_moco_local", "r_moco_global"])
+def test_c3_full_size_fp32_vs_oracle(M, R, name):
+    """BASELINE config C3's shape (4096 rays x 64 samples, bw NoF -> NeRF(ind) -> fw NoF, local and local+global
+    chains) in fp32 against the oracle: 1e-4 max-rel on every per-ray output and on the consensus vectors."""
+    c, res, want = _full_size_case(M, R, name, 4096, "f32")
+    _check_result(res, {k: v.numpy() for k, v in want.items()}, c, None)
+    for k in ("rgb_coarse", "depth_coarse", "opacity_coarse"):
+        print(f"C3 {name} fp32 {k}: max-rel {relerr(res[k], want[k]):.2e}")
+
+
+# bf16 error of the MoCo chain depends strongly on the weight draw (the canonical point feeds sin(512 x)): two
+# seeded draws, each with bars just under its measured values (r2: bench draw 51.8 dB, l2 4.7e-3 / 5.6e-3 / 2.2e-3;
+# golden-case draw 38.1 dB, l2 3.0e-2 / 6.0e-2 / 3.1e-2).
+C3_BF16_BARS = {"bench": (BENCH_TAGS, 49.0, 8e-3, 1.2e-2, 6e-3), "case": (None, 36.0, 4.5e-2, 9e-2, 5e-2)}
+
+
+@pytest.mark.parametrize("draw", sorted(C3_BF16_BARS))
+@pytest.mark.parametrize("name", ["r_moco_local", "r_moco_global"])
+def test_c3_full_size_bf16_vs_oracle(M, R, name, draw):
+    """BASELINE config C3 proper (4096 x 64, MoCo chain, bf16 hidden GEMMs) against the fp32 oracle: PSNR-equiv
+    and l2-rel bars just under the measured values of each weight draw; the consensus distances
+    (mean |x - fw(bw(x))|) agree to 2 % in the mean."""
+    tags, bar_db, bar_rgb, bar_depth, bar_op = C3_BF16_BARS[draw]
+    c, res, want = _full_size_case(M, R, name, 4096, "bf16", tags=tags)
+    ps = _psnr(res["rgb_coarse"], want["rgb_coarse"])
+    l2 = {k: _l2rel(res[k], want[k]) for k in ("rgb_coarse", "depth_coarse", "opacity_coarse")}
+    print(f"C3 {name} bf16 [{draw} draw]: PSNR-equiv {ps:.1f} dB; l2-rel rgb {l2['rgb_coarse']:.2e} "
+          f"depth {l2['depth_coarse']:.2e} opacity {l2['opacity_coarse']:.2e}")
+    assert ps >= bar_db
+    assert l2["rgb_coarse"] <= bar_rgb and l2["depth_coarse"] <= bar_depth and l2["opacity_coarse"] <= bar_op
+    for k in want:
+        if k.startswith("nof_"):
+            assert abs(float(res[k].mean()) - float(want[k].mean())) <= 2e-2 * abs(float(want[k].mean())), k
+            assert abs(res[k].shape[0] - want[k].shape[0]) <= 0.02 * want[k].shape[0], k
+
+
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+def test_c5_shard_shape_vs_oracle(M, R, precision):
+    """BASELINE config C5's single-GPU shard: 1024 rays x (64 coarse + 128 fine), two NeRFs, MoCo local+global
+    chains in both passes.  The oracle is re-run on the HIP path's own fine depths (rendering.py:323 detaches
+    them), so both passes are compared on identical samples: fp32 1e-4 max-rel; bf16 by PSNR-equiv / l2-rel
+    (bars under the measured values; the fine pass is the worst case of the bf16 mode: 192 thin intervals
+    behind two bf16 NoF evaluations)."""
+    c, res, want = _full_size_case(M, R, "r_moco_global_fine", 1024, precision)
+    assert res["rgb_fine"].shape == (1024, 3)
+    if precision == "f32":
+        _check_result({k: v for k, v in res.items() if "fine" in k},
+                      {k: v.numpy() for k, v in want.items() if "fine" in k}, c, None)
+        for k in ("rgb_coarse", "depth_coarse", "opacity_coarse"):
+            assert relerr(res[k], want[k]) <= TOL, (k, relerr(res[k], want[k]))
+        return
+    for k in ("rgb_coarse", "rgb_fine", "depth_coarse", "depth_fine", "opacity_coarse", "opacity_fine"):
+        print(f"C5 shard bf16 {k}: PSNR-equiv {_psnr(res[k], want[k]):.1f} dB, l2-rel {_l2rel(res[k], want[k]):.2e}")
     for k in ("rgb_coarse", "rgb_fine"):
-        if "out_" + k in g:
-            a, b = res[k].cpu().double(), torch.from_numpy(g["out_" + k]).double()
-            mse = float(((a - b) ** 2).mean())
-            psnr = -10 * np.log10(mse) if mse > 0 else 200.0
-            print(f"{name} {k}: bf16 PSNR-equiv {psnr:.1f} dB, max-rel {relerr(a, b):.2e}")
-            assert psnr > 38.0, (k, psnr)
-    for k in ("opacity_coarse", "depth_coarse"):
-        assert relerr(res[k], g["out_" + k]) <= 6e-2, (k, relerr(res[k], g["out_" + k]))
+        assert _psnr(res[k], want[k]) >= C5_BF16_BARS[0] and _l2rel(res[k], want[k]) <= C5_BF16_BARS[1], k
+    for k in ("depth_coarse", "depth_fine", "opacity_coarse", "opacity_fine"):
+        assert _l2rel(res[k], want[k]) <= C5_BF16_BARS[2], k
+
+
+C5_BF16_BARS = (33.0, 6e-2, 1.2e-1)      # provisional (first measurement pending): PSNR rgb, l2 rgb, l2 depth/opacity
+
+
+def test_c4_shards_moco_bf16_bit_identical(M):
+    """BASELINE config C4: the MoCo bf16 pass split over 8 contiguous ray shards (what the 8 ranks render)
+    reproduces the single-launch result row for row, bit for bit -- per-ray outputs and the compacted consensus
+    vectors (row-major order = global ray order)."""
+    from moco_flow_amd import rendering, synth
+    from moco_flow_amd.dist import shard_bounds
+    n = 4096
+    rays_np, bg_np = synth.rays(0, n, chained=True)
+    rays, bg = torch.from_numpy(rays_np).cuda(), torch.from_numpy(bg_np).cuda()
+    embs, nerfs, kw = build_case(M, dict(RENDER_CASES["r_moco_global"]), 0, device="cuda")
+    try:
+        rendering.set_precision("bf16")
+        with torch.no_grad():
+            a = M.render_rays(rays, bg, embs, nerfs, **kw)
+            parts = [M.render_rays(rays[lo:hi], bg[lo:hi], embs, nerfs, **kw)
+                     for lo, hi in (shard_bounds(n, r, 8) for r in range(8))]
+    finally:
+        rendering.set_precision("f32")
+    assert "nof_global_disp_coarse" in a
+    for k in a:
+        assert torch.equal(a[k], torch.cat([p[k] for p in parts], 0)), k
 
 
 @pytest.mark.parametrize("name", ["r_nerf_dir_fine_train", "r_moco_global_fine"])

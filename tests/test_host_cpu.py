@@ -371,6 +371,27 @@ def test_packed_cache_does_not_travel():
         assert all(c.key is None and c.buf is None for c in (m._packed, m._packed_bf16, m._packed_bwd))
 
 
+def test_bench_self_spawns_its_ranks():
+    """`python bench.py --gpus 2` run BARE (no torch.distributed.run) starts its own two workers before touching
+    the GPU; control flow on CPU with MF_BENCH_DRYRUN (gloo rendezvous on 127.0.0.1, overlapped reducer,
+    MAX-over-ranks timing, exactly one JSON line from rank 0, exit code = worst worker)."""
+    import json
+    import subprocess
+    env = dict(os.environ, MF_BENCH_DRYRUN="1")
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["reduced"] == 3.0      # ranks contribute 1 + 2
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "nope"],
+                         env=env, capture_output=True, text=True, timeout=120)
+    assert bad.returncode != 0
+
+
 def test_scripts_compile():
     """bench.py, __graft_entry__.py and every tools/*.py at least byte-compile (they only run on the GPU box)."""
     import glob
