@@ -1,0 +1,396 @@
+// mf_bf16.hpp -- bf16 mode of the fused MLP core (BASELINE configs C3-C5) on v_mfma_f32_32x32x16_bf16.
+//
+// Same idea as mf_core.hpp -- the MLPs of models/nerf.py:78-102 and models/nof.py:69-82 evaluated TRANSPOSED,
+// H_out^T = W * H_in^T, with the activations living in the register file from the embedding to the heads -- but
+// shaped for the bf16 matrix pipe, which is 16x faster than the exact-fp32 one and therefore needs 4x more
+// arithmetic per LDS byte, per barrier and per instruction issued than the fp32 tiling gives:
+//   * A operand = 32 weight rows x 16 k (one ds_read_b128 per lane = one 1 KiB "group" per wave),
+//     B operand = 16 k x 32 SAMPLES (a wave owns 32 samples, one per lane&31; the two lane halves h = lane>>5
+//     hold the two k-octets of every step), C/D = 32 features x 32 samples, 16 fp32 per lane, 32 matrix cycles:
+//     16 384 MACs per fragment read (8 192 in a 16x16x32 tiling with 16 samples per wave);
+//   * the C/D layout (row = (r&3) + 8*(r>>2) + 4h, col = lane&31) is a B-operand layout for two 16-k steps of the
+//     next layer if the k order inside a step is permuted to  slot 8h + e  ->  feature (e&3) + 8*(e>>2) + 4h.
+//     The weights are packed in that order (mf_pack.hip), so a finished tile -- ReLU, RNE to bf16, pairs packed
+//     into 8 dwords -- IS the next layer's operand: no shuffle, no LDS round trip;
+//   * a panel = ONE 32-row tile x the layer's whole k range (16 groups for a 256-wide hidden range): 16 MFMAs of
+//     32 cycles per wave between two barriers (the 16x16x32 tiling had 16 MFMAs of 16 cycles);
+//   * a workgroup is 8 waves = 256 samples per pass over the weight stream (two waves per SIMD, <= 256 VGPRs).
+// The embedded-input k ranges (positional encodings feed sin(512 x): they need more than 8 mantissa bits) use a
+// two-term bf16 split of inputs and weights, x = hi + lo, three products hi*hi + hi*lo + lo*hi (16 mantissa bits);
+// accumulation, biases, the sigma / rgb / NoF heads and the composite stay fp32.
+#pragma once
+#include "mf_nets.hpp"
+
+namespace mf {
+namespace bf {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr int kWaveSamples = 32;     // samples per wave
+constexpr int kTile = 256;           // samples per workgroup tile (8 waves)
+#ifndef MF_BF_PD
+#define MF_BF_PD 3                   // A-fragment prefetch distance in groups
+#endif
+constexpr int PD = MF_BF_PD;
+
+#define MF_MFMA32(a, b, c) \
+  __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+
+struct Lane {
+  int lane, wave, j, h;
+  MF_D Lane() {
+    lane = threadIdx.x & 63;
+    wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    j = lane & 31;
+    h = lane >> 5;
+  }
+};
+
+MF_D u32x4 lds_u4(uint32_t byte_off) { return *(const u32x4*)(smem + byte_off); }
+
+// Weight-panel stream (see mf_core.hpp Stream): 3-slot LDS ring fed by LDS-DMA, two panels ahead of the MFMAs,
+// one workgroup barrier per panel.
+struct Stream {
+  const char* gnext;      // global address of the panel two ahead of the one being computed
+  uint32_t ring, buf_bytes, cur;
+
+  MF_D uint32_t slot_off(uint32_t k) const {
+    uint32_t s = cur + k;
+    s = s >= 3u ? s - 3u : s;
+    return ring + s * buf_bytes;
+  }
+  MF_D void dma_to(uint32_t dst, int groups, const Lane& id) {
+    const char* g = gnext + id.lane * 16;
+    for (int grp = id.wave; grp < groups; grp += kWaves) glds16(g + grp * kGroupBytes, dst + grp * kGroupBytes);
+    gnext += (size_t)groups * kGroupBytes;
+  }
+  MF_D void sync_and_dma(int groups, const char* jump, const Lane& id) {
+    wait_vm0();                              // this wave's pieces of the NEXT panel have landed
+    __builtin_amdgcn_s_barrier();            // RAW: everybody's have; WAR: everybody left the previous panel
+    asm volatile("" ::: "memory");
+    if (jump) gnext = jump;
+    dma_to(slot_off(2), groups, id);
+  }
+  MF_D void advance() { cur = cur == 2u ? 0u : cur + 1u; }
+  MF_D void start(const char* first, int groups, const Lane& id) {
+    cur = 0;
+    gnext = first;
+    dma_to(ring, groups, id);
+    dma_to(ring + buf_bytes, groups, id);
+    wait_vm0();
+    __syncthreads();
+  }
+};
+
+struct Carry {            // the first PD fragments of the panel that follows, pre-read during the current one's tail
+  u32x4 w[PD];
+  MF_D void load(uint32_t panel_lane_off) {
+#pragma unroll
+    for (int i = 0; i < PD; ++i) w[i] = lds_u4(panel_lane_off + i * kGroupBytes);
+  }
+};
+
+MF_D unsigned pack_bf16x2(float lo, float hi) {
+  const __bf16 a = (__bf16)lo, b = (__bf16)hi;
+  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+}
+
+// One output tile (32 features x the wave's 32 samples):
+//     out = max(bias + W_tile * [emb ; hidden], lo)        EMB_FIRST (trunk layers: embedded input in front)
+//     out = max(bias + W_tile * [hidden ; emb], lo)        !EMB_FIRST (NeRF extra_encoding)
+// NGE = embedded 16-slot k-steps (each: groups hi, lo; MFMAs Whi*xhi, Whi*xlo, Wlo*xhi), KHID = hidden k-steps.
+// The A fragments are fetched PD groups ahead through a register ring that runs on into the NEXT panel's slot.
+// `hook` = the panel's barrier + DMA of the panel two ahead: behind the first group for the early half of the
+// workgroup (waves 4-7), in the middle of the panel for the late half (waves 0-3), so the two waves of a SIMD
+// run half a panel out of phase.  The bias is added in the epilogue (its four ds_reads ride in the panel's tail)
+// and the first MFMA takes C = 0, so nothing at a panel's head waits for the LDS.
+template <int NGE, int KHID, bool EMB_FIRST, class Hook>
+MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4* xlo, uint32_t p, uint32_t pn,
+                   uint32_t bias_off, int h, bool late, Hook&& hook, float lo, u32x4& out0, u32x4& out1) {
+  constexpr int NG = 2 * NGE + KHID;
+  static_assert(NG > PD, "panel shorter than the fragment pipeline");
+  constexpr int LATEQ = (NG / 2 < NG - PD) ? NG / 2 : NG - PD;   // the late half must not read the next panel early
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  u32x4 r[PD + 1];
+#pragma unroll
+  for (int i = 0; i < PD; ++i) r[i] = carry.w[i];
+  f32x4 b0, b1, b2, b3;
+#pragma unroll
+  for (int gi = 0; gi < NG; ++gi) {
+    const int s = gi % (PD + 1);
+    const int ge = EMB_FIRST ? gi : gi - KHID;            // index within the embedded groups
+    if (ge >= 0 && ge < 2 * NGE) {
+      if (!(ge & 1)) {
+        acc = MF_MFMA32(r[s], xhi[ge >> 1], acc);         // Whi * xhi
+      } else {
+        acc = MF_MFMA32(r[s], xhi[ge >> 1], acc);         // Wlo * xhi
+      }
+    } else {
+      acc = MF_MFMA32(r[s], hid[EMB_FIRST ? gi - 2 * NGE : gi], acc);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const int sp = (gi + PD) % (PD + 1), nb = gi + PD;
+    if (nb < NG) r[sp] = lds_u4(p + nb * kGroupBytes);
+    if (gi == 0 && !late) hook();
+    if (gi == LATEQ && late) hook();
+    if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
+    if (gi == NG - 2) {                                    // bias of this tile, C/D order: reg 4q + i <- row 8q + 4h + i
+      b0 = lds_f4(bias_off + (0 + 4 * h) * 4);
+      b1 = lds_f4(bias_off + (8 + 4 * h) * 4);
+      b2 = lds_f4(bias_off + (16 + 4 * h) * 4);
+      b3 = lds_f4(bias_off + (24 + 4 * h) * 4);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (ge >= 0 && ge < 2 * NGE && !(ge & 1)) {
+      acc = MF_MFMA32(r[s], xlo[ge >> 1], acc);           // Whi * xlo
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PD; ++i) carry.w[i] = r[(NG + i) % (PD + 1)];
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    v[i] = fmaxf(acc[i] + b0[i], lo);
+    v[4 + i] = fmaxf(acc[4 + i] + b1[i], lo);
+    v[8 + i] = fmaxf(acc[8 + i] + b2[i], lo);
+    v[12 + i] = fmaxf(acc[12 + i] + b3[i], lo);
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    out0[w] = pack_bf16x2(v[2 * w], v[2 * w + 1]);
+    out1[w] = pack_bf16x2(v[8 + 2 * w], v[8 + 2 * w + 1]);
+  }
+  // The register file is full: the epilogue must retire this tile's accumulators and bias HERE.  Left alone, hipcc
+  // sinks the pure add / max / convert chain down to the outputs' first use (the next layer), keeps every tile's 16
+  // accumulators + 16 bias registers alive until then and spills ~200 registers.  The empty asm makes each packed
+  // dword a value that exists at this point.
+#pragma unroll
+  for (int w = 0; w < 4; ++w) asm volatile("" : "+v"(out0[w]), "+v"(out1[w]));
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// One trunk layer: act <- relu?(W_l [emb ; act] + b_l), NT = KH/2 tiles of 32 features.
+// MODE: 1 = embedded input only (layer 0), 2 = hidden only, 3 = both (skip layers, embedded input first).  A template
+// parameter, not a switch inside the tile loop: the register file is full here and every control-flow merge inside
+// the unrolled tile sequence costs copies.
+template <int KH, int NGE, int MODE>
+MF_D void trunk_layer_m(const NetDev& net, int layer, u32x4 (&act)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE],
+                        Stream& st, Carry& carry, const Lane& id, const NextLayer& nxt) {
+  constexpr int NT = KH / 2;
+  const int groups = trunk_groups(net.L, layer);
+  const float lo = ((net.L.relu_mask >> layer) & 1) ? 0.f : -__builtin_inff();
+  const uint32_t bias_off = net.res_lds + (net.L.off_bias_trunk + layer * net.L.W) * 4;
+  const bool late = id.wave < kWaves / 2;
+  u32x4 out[KH];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const uint32_t p = st.slot_off(0) + id.lane * 16;
+    const uint32_t pn = st.slot_off(1) + id.lane * 16;
+    // panel two ahead: same layer while t+2 < NT, else tile (t+2-NT) of the next layer
+    auto hook = [&]() { st.sync_and_dma(t + 2 < NT ? groups : nxt.groups, t == NT - 2 ? nxt.jump : nullptr, id); };
+    out_tile<(MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, true>(carry, act, xhi, xlo, p, pn, bias_off + 32 * t * 4, id.h, late,
+                                                               hook, lo, out[2 * t], out[2 * t + 1]);
+    st.advance();
+  }
+#pragma unroll
+  for (int t = 0; t < KH; ++t) act[t] = out[t];
+}
+
+template <int KH, int NGE>
+MF_D void trunk_layer(const NetDev& net, int layer, u32x4 (&act)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE],
+                      Stream& st, Carry& carry, const Lane& id, const NextLayer& nxt) {
+  const int has_emb = (net.L.emb_mask >> layer) & 1;
+  if (layer == 0) trunk_layer_m<KH, NGE, 1>(net, layer, act, xhi, xlo, st, carry, id, nxt);
+  else if (has_emb) trunk_layer_m<KH, NGE, 3>(net, layer, act, xhi, xlo, st, carry, id, nxt);
+  else trunk_layer_m<KH, NGE, 2>(net, layer, act, xhi, xlo, st, carry, id, nxt);
+}
+
+MF_D float bflo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+MF_D float bfhi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// VALU head: NOUT dot products of the lane's half of the hidden vector (bf16, unpacked on the fly) with fp32
+// natural-order weight rows in LDS, summed across the two lane halves.  Element e of k-step s is feature
+// 16 s + (e&3) + 8 (e>>2) + 4 h: two 16-byte weight reads per step.
+template <int KH, int NOUT>
+MF_D void valu_head(const u32x4 (&act)[KH], uint32_t w_byte_off, int row_floats, uint32_t b_byte_off, int h,
+                    float (&out)[NOUT]) {
+#pragma unroll
+  for (int o = 0; o < NOUT; ++o) {
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int s = 0; s < KH; ++s) {
+      const f32x4 wa = lds_f4(w_byte_off + (o * row_floats + 16 * s + 4 * h) * 4);
+      const f32x4 wb = lds_f4(w_byte_off + (o * row_floats + 16 * s + 8 + 4 * h) * 4);
+      s0 = __builtin_fmaf(wa[0], bflo(act[s][0]), s0);
+      s1 = __builtin_fmaf(wa[1], bfhi(act[s][0]), s1);
+      s0 = __builtin_fmaf(wa[2], bflo(act[s][1]), s0);
+      s1 = __builtin_fmaf(wa[3], bfhi(act[s][1]), s1);
+      s0 = __builtin_fmaf(wb[0], bflo(act[s][2]), s0);
+      s1 = __builtin_fmaf(wb[1], bfhi(act[s][2]), s1);
+      s0 = __builtin_fmaf(wb[2], bflo(act[s][3]), s0);
+      s1 = __builtin_fmaf(wb[3], bfhi(act[s][3]), s1);
+    }
+    const float part = s0 + s1;
+    out[o] = part + __shfl_xor(part, 32, 64) + lds_f(b_byte_off + o * 4);
+  }
+}
+
+// ------------------------------------------------------------------ embedding in registers (two lane halves)
+// Embedding parameters live in LDS (par_off: freq[16] then weight[16], floats): this kernel keeps its SGPRs for
+// addresses.  dst[0..SLOTS) of block (C,F) for lane half h; arg = freq*x rounded to fp32 before sin/cos exactly as
+// `func(freq*x)` in embedding.py:45.
+template <int C, int F>
+MF_D void emb_eval(float* dst, const float (&v)[C], uint32_t par_off, int h) {
+  using B = EmbBlock2<C, F>;
+#pragma unroll
+  for (int pi = 0; pi < B::NPI; ++pi) {
+    const int p0 = 2 * pi, p1 = 2 * pi + 1;                // the two halves' pairs
+    const bool real0 = p0 < B::NPAIR, real1 = p1 < B::NPAIR;
+    const int f0 = real0 ? p0 / C : 0, c0 = real0 ? p0 % C : 0;
+    const int f1 = real1 ? p1 / C : 0, c1 = real1 ? p1 % C : 0;
+    const int q0 = real0 ? 0 : 2 * (p0 - B::NPAIR), q1 = real1 ? 0 : 2 * (p1 - B::NPAIR);   // raw pseudo-pairs
+    const float ra0 = (!real0 && p0 < B::NALL && q0 < C) ? v[q0 < C ? q0 : 0] : 0.f;
+    const float rb0 = (!real0 && p0 < B::NALL && q0 + 1 < C) ? v[q0 + 1 < C ? q0 + 1 : 0] : 0.f;
+    const float ra1 = (!real1 && p1 < B::NALL && q1 < C) ? v[q1 < C ? q1 : 0] : 0.f;
+    const float rb1 = (!real1 && p1 < B::NALL && q1 + 1 < C) ? v[q1 + 1 < C ? q1 + 1 : 0] : 0.f;
+    if (!real0 && !real1) {                                // (compile time) raw components only
+      dst[2 * pi] = h ? ra1 : ra0;
+      dst[2 * pi + 1] = h ? rb1 : rb0;
+      continue;
+    }
+    const float x = h ? v[c1] : v[c0];
+    const int f = h ? f1 : f0;
+    const float fr = lds_f(par_off + 4 * f);
+    const float w = lds_f(par_off + 64 + 4 * f);
+    const bool real = h ? real1 : real0;
+    // skipped when both halves' frequencies are muted (coarse-to-fine start, trainer_moco_flow.py:113-114)
+    const bool live = lds_f(par_off + 64 + 4 * f0) != 0.f || (real1 && lds_f(par_off + 64 + 4 * f1) != 0.f);
+    float sn = 0.f, cs = 0.f;
+    if (__builtin_amdgcn_readfirstlane((int)live)) sincosf(fr * x, &sn, &cs);
+    dst[2 * pi] = real ? w * sn : (h ? ra1 : ra0);
+    dst[2 * pi + 1] = real ? w * cs : (h ? rb1 : rb0);
+  }
+}
+
+// fp32 slots -> split bf16 operands of the k-steps: xhi[ks] = bf16(x), xlo[ks] = bf16(x - hi)
+template <int KS>
+MF_D void split_operands(const float* emb, int n_slots, u32x4 (&xhi)[KS], u32x4 (&xlo)[KS]) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int e0 = 8 * ks + 2 * w, e1 = e0 + 1;
+      const float a = e0 < n_slots ? emb[e0] : 0.f, b = e1 < n_slots ? emb[e1] : 0.f;
+      const __bf16 ah = (__bf16)a, bh = (__bf16)b;
+      const __bf16 al = (__bf16)(a - (float)ah), bl = (__bf16)(b - (float)bh);
+      xhi[ks][w] = (unsigned)__builtin_bit_cast(unsigned short, ah) | ((unsigned)__builtin_bit_cast(unsigned short, bh) << 16);
+      xlo[ks][w] = (unsigned)__builtin_bit_cast(unsigned short, al) | ((unsigned)__builtin_bit_cast(unsigned short, bl) << 16);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ the two networks
+MF_D void start_program(const NetDev& n, Stream& st, Carry& carry, const Lane& id) {
+  st.start(n.packed + n.L.res_bytes, trunk_groups(n.L, 0), id);
+  carry.load(st.slot_off(0) + id.lane * 16);
+}
+
+MF_D void load_resident(const NetDev& n, const Lane& id) {
+  const int groups = (int)(n.L.res_bytes / kGroupBytes);
+  for (int g = id.wave; g < groups; g += kWaves) glds16(n.packed + g * kGroupBytes + id.lane * 16, n.res_lds + g * kGroupBytes);
+}
+
+// extra_encoding (nerf.py:98): W/2 outputs from [final (W) ; extra block], ReLU.  NGX = extra k-steps (0, 1, 2).
+template <int NGX>
+MF_D void extra_layer(const NetDev& net, const u32x4 (&act)[16], const u32x4* ehi, const u32x4* elo, u32x4 (&out)[8],
+                      Stream& st, Carry& carry, const Lane& id, const NextLayer& nxt) {
+  constexpr int NT = 4;
+  const int groups = extra_groups(net.L);
+  const uint32_t bias_off = net.res_lds + net.L.off_bias_extra * 4;
+  const bool late = id.wave < kWaves / 2;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const uint32_t p = st.slot_off(0) + id.lane * 16;
+    const uint32_t pn = st.slot_off(1) + id.lane * 16;
+    auto hook = [&]() { st.sync_and_dma(t + 2 < NT ? groups : nxt.groups, t == NT - 2 ? nxt.jump : nullptr, id); };
+    out_tile<NGX, 16, false>(carry, act, ehi, elo, p, pn, bias_off + 32 * t * 4, id.h, late, hook, 0.f, out[2 * t], out[2 * t + 1]);
+    st.advance();
+  }
+}
+
+// Canonical NeRF (W = 256) on this wave's 32 samples.  xhi/xlo: split operands of the xyz embedding (4 k-steps).
+// `make_extra(ehi, elo)` builds the extra block's operands; it is called right before extra_encoding so that those
+// registers are not held through the trunk.
+template <class MakeExtra>
+MF_D void nerf_eval(const NetDev& net, const u32x4 (&xhi)[kKsNerfXyz], const u32x4 (&xlo)[kKsNerfXyz],
+                    MakeExtra&& make_extra, bool sigma_only, Stream& st,
+                    Carry& carry, const Lane& id, const NextLayer& follow, float& sigma, float (&rgb)[3]) {
+  u32x4 act[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) act[t][i] = 0;
+  const int D = net.L.n_trunk - 1;
+  for (int l = 0; l < D; ++l) {
+    const bool last = sigma_only && l == D - 1;
+    trunk_layer<16, kKsNerfXyz>(net, l, act, xhi, xlo, st, carry, id, last ? follow : next_trunk(net, l + 1));
+  }
+  float sg[1];
+  valu_head(act, net.res_lds + net.L.off_head_w * 4, net.L.W, net.res_lds + net.L.off_head_b * 4, id.h, sg);
+  sigma = sg[0];
+  if (sigma_only) return;
+  NextLayer ex;
+  ex.groups = extra_groups(net.L);
+  ex.jump = nullptr;
+  ex.bias_off = 0;
+  trunk_layer<16, kKsNerfXyz>(net, D, act, xhi, xlo, st, carry, id, ex);          // xyz_encoding_final (no ReLU)
+  u32x4 e[8], ehi[kKsExtraMax], elo[kKsExtraMax];
+  make_extra(ehi, elo);
+  if (net.L.extra_steps == 2) extra_layer<2>(net, act, ehi, elo, e, st, carry, id, follow);
+  else if (net.L.extra_steps == 1) extra_layer<1>(net, act, ehi, elo, e, st, carry, id, follow);
+  else extra_layer<0>(net, act, ehi, elo, e, st, carry, id, follow);
+  float o[3];
+  valu_head(e, net.res_lds + net.L.off_rgb_w * 4, net.L.W / 2, net.res_lds + net.L.off_rgb_b * 4, id.h, o);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) rgb[c] = 1.f / (1.f + expf(-o[c]));   // nn.Sigmoid, nerf.py:57-59
+}
+
+// Neural motion flow (W = 128) on this wave's 32 samples; xhi/xlo = split operands of [xyz block ; ind block].
+MF_D void nof_eval(const NetDev& net, const u32x4 (&xhi)[kKsNofIn], const u32x4 (&xlo)[kKsNofIn], const float (&xyz)[3],
+                   Stream& st, Carry& carry, const Lane& id, const NextLayer& follow, float (&out)[3]) {
+  u32x4 act[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) act[t][i] = 0;
+  const int D = net.L.n_trunk;
+  for (int l = 0; l < D; ++l)
+    trunk_layer<8, kKsNofIn>(net, l, act, xhi, xlo, st, carry, id, l == D - 1 ? follow : next_trunk(net, l + 1));
+  const uint32_t wo = net.res_lds + net.L.off_head_w * 4, bo = net.res_lds + net.L.off_head_b * 4;
+  if (net.L.n_head == 9) {
+    float T[9];
+    valu_head(act, wo, net.L.W, bo, id.h, T);
+    quat_transform(T, xyz, out);
+  } else {
+    float T[3];
+    valu_head(act, wo, net.L.W, bo, id.h, T);
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = T[c] + xyz[c];
+  }
+}
+
+// NoF input operands from a point and an image index (rendering.py:70-75)
+MF_D void nof_embed(u32x4 (&xhi)[kKsNofIn], u32x4 (&xlo)[kKsNofIn], const float (&xyz)[3], float ind, uint32_t par_xyz,
+                    uint32_t par_ind, int h) {
+  float emb[B2Xyz5::SLOTS + B2Ind16::SLOTS];
+  emb_eval<3, 5>(emb, xyz, par_xyz, h);
+  const float iv[1] = {ind};
+  emb_eval<1, 16>(emb + B2Xyz5::SLOTS, iv, par_ind, h);
+  split_operands<kKsNofIn>(emb, B2Xyz5::SLOTS + B2Ind16::SLOTS, xhi, xlo);
+}
+
+}  // namespace bf
+}  // namespace mf

@@ -108,6 +108,59 @@ MF_HD int emb_feature(int kind, int g, int e, int xyz_cols) {
   }
 }
 
+// The same embeddings for the bf16 kernels' 32x32x16 tiles, where a sample column has TWO lanes (h = lane>>5):
+// half h owns the pairs p = 2*pi + h; SLOTS per half, in k-steps of 8 slots per half (16 k per MFMA).
+template <int C, int F>
+struct EmbBlock2 {
+  static constexpr int NPAIR = C * F;
+  static constexpr int NALL = NPAIR + (C + 1) / 2;
+  static constexpr int NPI = (NALL + 1) / 2;                // pairs per half
+  static constexpr int SLOTS = 2 * NPI;
+  MF_HD static int feature(int h, int e) {
+    const int p = 2 * (e >> 1) + h, sc = e & 1;
+    if (p < NPAIR) {
+      const int f = p / C, c = p % C;
+      return C + 2 * C * f + C * sc + c;
+    }
+    const int raw = 2 * (p - NPAIR) + sc;
+    return (p < NALL && raw < C) ? raw : -1;
+  }
+};
+using B2Xyz10 = EmbBlock2<3, 10>;   // 32 slots per half -> 4 k-steps
+using B2Xyz5 = EmbBlock2<3, 5>;     // 18
+using B2Ind16 = EmbBlock2<1, 16>;   // 18   (NoF input: 36 -> 5 k-steps)
+using B2Dir4 = EmbBlock2<3, 4>;     // 14  -> 2 k-steps
+using B2Ind2 = EmbBlock2<1, 2>;     // 4   -> 1 k-step
+constexpr int kKsNerfXyz = (B2Xyz10::SLOTS + 7) / 8;                       // 4
+constexpr int kKsNofIn = (B2Xyz5::SLOTS + B2Ind16::SLOTS + 7) / 8;         // 5
+constexpr int kKsDir = (B2Dir4::SLOTS + 7) / 8;                            // 2
+constexpr int kKsInd = (B2Ind2::SLOTS + 7) / 8;                            // 1
+constexpr int kKsExtraMax = kKsDir;
+
+// reference column of slot e (0 .. 8*ksteps) of half h; -1 = zero pad
+MF_HD int emb_feature2(int kind, int h, int e, int xyz_cols) {
+  switch (kind) {
+    case kEmbNerfXyz:
+      return e < B2Xyz10::SLOTS ? B2Xyz10::feature(h, e) : -1;
+    case kEmbNofIn:
+      if (e < B2Xyz5::SLOTS) return B2Xyz5::feature(h, e);
+      if (e < B2Xyz5::SLOTS + B2Ind16::SLOTS) {
+        const int f = B2Ind16::feature(h, e - B2Xyz5::SLOTS);
+        return f < 0 ? -1 : xyz_cols + f;
+      }
+      return -1;
+    case kEmbDir:
+      return e < B2Dir4::SLOTS ? B2Dir4::feature(h, e) : -1;
+    case kEmbInd:
+      return e < B2Ind2::SLOTS ? B2Ind2::feature(h, e) : -1;
+    default:
+      return -1;
+  }
+}
+// feature (within a 16-wide k-step) held by element e (0..7) of half h of a 32x32x16 operand: the order in which a
+// finished 32x32 tile's accumulators sit in registers (row = (r&3) + 8*(r>>2) + 4*h, r = e or 8 + e)
+MF_HD int hid_perm2(int h, int e) { return (e & 3) + 8 * (e >> 2) + 4 * h; }
+
 // Embedding parameters as the kernels see them (uniform, lives in SGPRs / kernarg).
 struct EmbParams {
   float freq[16];
@@ -140,15 +193,23 @@ struct NetLayout {
   int n_head;              // NoF: 9 | 3
 };
 
-// batches of a panel: an embedded-input batch = one fp32 k-quad (16 k, 8 MFMAs) -- in bf16 mode the hi
-// (even batch) or lo (odd batch) bf16 weights of one 32-k block; a hidden batch = one fp32 k-quad (16 k)
-// or, in bf16 mode, one 32-k step (2 MFMAs).  Two 1 KiB groups per batch.
-MF_HD int hidden_batches(const NetLayout& L) { return L.bf16 ? L.NP : L.NK; }
+// fp32 -- batches of a panel: an embedded-input batch = one k-quad (16 k, 8 MFMAs); a hidden batch = one k-quad.
+// Two 1 KiB groups per batch (one per 16-row tile of the 32-row panel).
+// bf16 (mf_bf16.hpp) -- a panel is ONE 32-row tile; a group = 32 rows x 16 k of bf16 (one A fragment of
+// v_mfma_f32_32x32x16_bf16); `emb_steps` / `extra_steps` count 16-slot k-steps of the embedded blocks, each stored
+// as two groups (hi = bf16(w), lo = bf16(w - hi)); a W-wide hidden range is NK groups.
+MF_HD int hidden_batches(const NetLayout& L) { return L.NK; }
 MF_HD int trunk_batches(const NetLayout& L, int layer) {
   return (((L.emb_mask >> layer) & 1) ? L.emb_steps / 4 : 0) + (layer > 0 ? hidden_batches(L) : 0);
 }
-MF_HD int trunk_groups(const NetLayout& L, int layer) { return 2 * trunk_batches(L, layer); }
-MF_HD int extra_groups(const NetLayout& L) { return 2 * (hidden_batches(L) + L.extra_steps / 4); }
+MF_HD int trunk_groups(const NetLayout& L, int layer) {
+  if (L.bf16) return (((L.emb_mask >> layer) & 1) ? 2 * L.emb_steps : 0) + (layer > 0 ? L.NK : 0);
+  return 2 * trunk_batches(L, layer);
+}
+MF_HD int extra_groups(const NetLayout& L) {
+  if (L.bf16) return L.NK + 2 * L.extra_steps;
+  return 2 * (hidden_batches(L) + L.extra_steps / 4);
+}
 
 // ------------------------------------------------------------------ device helpers
 extern __shared__ __attribute__((aligned(16))) char smem[];

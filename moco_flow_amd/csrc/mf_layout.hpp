@@ -20,13 +20,14 @@ inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L, int bf16 = 0) {
   L.NK = d.W / 16;
   L.NP = d.W / 32;
   L.n_trunk = d.D + 1;                                // + xyz_encoding_final (no ReLU)
-  L.emb_steps = kStepsNerfXyz;
+  if (bf16 && d.W != 256) return false;
+  L.emb_steps = bf16 ? kKsNerfXyz : kStepsNerfXyz;     // bf16: 16-slot k-steps (mf_bf16.hpp); fp32: 4-k MFMA steps
   L.emb_mask = 1u | d.skip_mask;
   L.relu_mask = (1u << d.D) - 1u;
   switch (d.extra_feat_type) {
     case MF_EXTRA_NONE: L.extra_steps = 0; break;
-    case MF_EXTRA_IND: L.extra_steps = bf16 ? 8 : kStepsInd; if (d.extra_feat_dim < 1) return false; break;
-    case MF_EXTRA_DIR: L.extra_steps = kStepsDir; if (d.extra_feat_dim < 3) return false; break;
+    case MF_EXTRA_IND: L.extra_steps = bf16 ? kKsInd : kStepsInd; if (d.extra_feat_dim < 1) return false; break;
+    case MF_EXTRA_DIR: L.extra_steps = bf16 ? kKsDir : kStepsDir; if (d.extra_feat_dim < 3) return false; break;
     default: return false;
   }
   int off = 0;
@@ -46,7 +47,7 @@ inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L, int bf16 = 0) {
     if (g > L.max_groups) L.max_groups = g;
   }
   const int ge = extra_groups(L);
-  groups += (int64_t)ge * (L.NP / 2);
+  groups += (int64_t)ge * (L.NP / 2);      // (W/2)-wide layer: NP/2 panels in either layout
   if (ge > L.max_groups) L.max_groups = ge;
   L.panel_bytes = groups * kGroupBytes;
   return true;
@@ -63,7 +64,7 @@ inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0) {
   L.NK = d.W / 16;
   L.NP = d.W / 32;
   L.n_trunk = d.D;
-  L.emb_steps = bf16 ? kStepsNofInBf16 : kStepsNofIn;
+  L.emb_steps = bf16 ? kKsNofIn : kStepsNofIn;
   L.emb_mask = 1u | d.skip_mask;
   L.relu_mask = (1u << d.D) - 1u;
   L.extra_steps = -1;

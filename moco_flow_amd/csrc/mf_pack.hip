@@ -16,14 +16,14 @@ struct PackRegion {          // one trunk/extra layer's panels
   int n_in;
   int tiles;                 // panels (n_out / 32)
   int groups;                // groups per panel (2 per k-quad)
-  int emb_steps;             // steps taken from the embedded-input block (0 if none)
+  int emb_steps;             // fp32: MFMA k-steps taken from the embedded-input block; bf16: its 16-slot k-steps (0 if none)
   int emb_first;             // 1: emb steps precede hidden steps (trunk); 0: follow them (extra)
   int emb_kind;
   int emb_col0;              // column of embedded feature 0 in W
   int emb_cols;              // embedded columns present in W (features >= this are zero pad)
   int hid_steps;             // fp32: hidden k-steps 4*NK (= W/4); bf16: unused (see hid_batches)
-  int hid_batches;           // hidden batches per tile row: NK (fp32 k-quads) or NP (bf16 32-k steps); 0 if none
-  int bf16;                  // hidden groups hold 8 bf16 per lane instead of 4 fp32
+  int hid_batches;           // hidden k-quads (fp32) / 16-k steps (bf16) per tile row: NK; 0 if none
+  int bf16;                  // groups hold 8 bf16 per lane (32x32x16 A fragments) instead of 4 fp32
   int hid_col0;              // column of hidden feature 0 in W
   int xyz_cols;
   long long dst_group0;      // first group index (in 1 KiB units) within the panel area
@@ -52,6 +52,34 @@ __global__ void pack_panels_kernel(PackJob job) {
   const PackRegion& R = job.reg[ri];
   const long long local = grp - R.dst_group0;
   const int P = (int)(local / R.groups), gi = (int)(local % R.groups);
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  float* pv = &v.x;
+  if (R.bf16) {
+    // bf16 layout (mf_bf16.hpp): panel = ONE 32-row tile, group = A fragment of v_mfma_f32_32x32x16_bf16:
+    // lane (i = lane&31, h = lane>>5) holds 8 bf16 = W[32P + i][col(k-step, slot 8h + e)], e = 0..7.
+    // Embedded k-step ks is two groups (hi = bf16(w), lo = bf16(w - hi)); hidden k-step ks covers features
+    // 16 ks + hid_perm2(h, e).
+    const int i = lane & 31, h = lane >> 5;
+    const float* row = R.W + (long long)(32 * P + i) * R.n_in;
+    const int ge = R.emb_first ? gi : gi - R.hid_batches;
+    const int gh = R.emb_first ? gi - 2 * R.emb_steps : gi;
+    unsigned short h8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (ge >= 0 && ge < 2 * R.emb_steps) {
+      const int ks = ge >> 1, lo = ge & 1;
+      for (int e = 0; e < 8; ++e) {
+        const int f = emb_feature2(R.emb_kind, h, 8 * ks + e, R.xyz_cols);
+        const float w = (f >= 0 && f < R.emb_cols) ? row[R.emb_col0 + f] : 0.f;
+        const unsigned short hi = bf16_rne(w);
+        h8[e] = lo ? bf16_rne(w - __uint_as_float((unsigned)hi << 16)) : hi;
+      }
+    } else if (gh >= 0 && gh < R.hid_batches) {
+      for (int e = 0; e < 8; ++e) h8[e] = bf16_rne(row[R.hid_col0 + 16 * gh + hid_perm2(h, e)]);
+    }
+    unsigned* pu = reinterpret_cast<unsigned*>(&v.x);
+    for (int w = 0; w < 4; ++w) pu[w] = (unsigned)h8[2 * w] | ((unsigned)h8[2 * w + 1] << 16);
+    reinterpret_cast<float4*>(job.panels)[gidx] = v;
+    return;
+  }
   const int b = gi >> 1, half = gi & 1;                 // batch within the panel, tile half
   const int i = lane & 15, g = lane >> 4;
   const int n = 32 * P + 16 * half + i;
@@ -59,39 +87,13 @@ __global__ void pack_panels_kernel(PackJob job) {
   const int be = R.emb_first ? b : b - R.hid_batches;   // index within the embedded block
   const int bh = R.emb_first ? b - eb : b;              // index within the hidden block
   const float* row = R.W + (long long)n * R.n_in;
-  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-  float* pv = &v.x;
-  if (be >= 0 && be < eb && R.bf16) {
-    // bf16 mode: 32-k block be/2 (slots 8*blk + p, p = 0..7), even batch = hi = bf16(w), odd = lo = bf16(w - hi)
-    const int blk = be >> 1, lo = be & 1;
-    unsigned short h8[8];
-    for (int pp = 0; pp < 8; ++pp) {
-      const int f = emb_feature(R.emb_kind, g, 8 * blk + pp, R.xyz_cols);
-      const float w = (f >= 0 && f < R.emb_cols) ? row[R.emb_col0 + f] : 0.f;
-      const unsigned short hi = bf16_rne(w);
-      h8[pp] = lo ? bf16_rne(w - __uint_as_float((unsigned)hi << 16)) : hi;
-    }
-    unsigned* pu = reinterpret_cast<unsigned*>(&v.x);
-    for (int w = 0; w < 4; ++w) pu[w] = (unsigned)h8[2 * w] | ((unsigned)h8[2 * w + 1] << 16);
-  } else if (be >= 0 && be < eb) {
+  if (be >= 0 && be < eb) {
     for (int r = 0; r < 4; ++r) {
       const int f = emb_feature(R.emb_kind, g, 4 * be + r, R.xyz_cols);
       pv[r] = (f >= 0 && f < R.emb_cols) ? row[R.emb_col0 + f] : 0.f;
     }
   } else if (bh >= 0 && bh < R.hid_batches) {
-    if (!R.bf16) {
-      for (int r = 0; r < 4; ++r) pv[r] = row[R.hid_col0 + 16 * bh + 4 * g + r];
-    } else {
-      // 32-k step bh: position p of lane group g <- k = 32*bh + (p < 4 ? 4g + p : 16 + 4g + p - 4),
-      // the order in which a finished panel's accumulators [E0..3 | O0..3] sit in registers
-      unsigned short h8[8];
-      for (int pp = 0; pp < 8; ++pp) {
-        const int k = 32 * bh + (pp < 4 ? 4 * g + pp : 16 + 4 * g + pp - 4);
-        h8[pp] = bf16_rne(row[R.hid_col0 + k]);
-      }
-      unsigned* pu = reinterpret_cast<unsigned*>(&v.x);
-      for (int w = 0; w < 4; ++w) pu[w] = (unsigned)h8[2 * w] | ((unsigned)h8[2 * w + 1] << 16);
-    }
+    for (int r = 0; r < 4; ++r) pv[r] = row[R.hid_col0 + 16 * bh + 4 * g + r];
   }
   reinterpret_cast<float4*>(job.panels)[gidx] = v;
 }

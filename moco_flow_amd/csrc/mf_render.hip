@@ -249,6 +249,7 @@ static void to_params(const mf_embedding& e, EmbParams& o) {
 }
 
 int device_cus();   // mf_forward.hip
+int render_pass_bf16(const mf_render_args* a, hipStream_t st);   // mf_render_bf16.hip
 
 }  // namespace mf
 
@@ -267,8 +268,10 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
     return fail(MF_E_INVALID, "mf_render_pass: precision %d", a->precision);
   const int bf16 = a->precision == MF_PREC_BF16;
   RenderParams p{};
-  if (!nerf_layout(*a->nerf, p.nerf.L, bf16)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported NeRF configuration");
+  if (!nerf_layout(*a->nerf, p.nerf.L, 0)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported NeRF configuration");
   if (p.nerf.L.NK != 16) return fail(MF_E_UNSUPPORTED, "mf_render_pass: only W=256 NeRF is built");
+  const bool dump = a->dump_acts || a->dump_rgbsigma || a->dump_xyz;
+  if (dump && bf16) return fail(MF_E_UNSUPPORTED, "mf_render_pass: the activation dump (training forward) is fp32 only");
   if (a->emb_xyz.in_channels != 3 || a->emb_xyz.n_freqs > 10)
     return fail(MF_E_UNSUPPORTED, "mf_render_pass: xyz embedding must have 3 channels and <= 10 frequencies");
   const bool sigma_only = a->flags & MF_F_SIGMA_ONLY;
@@ -304,13 +307,13 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
   int max_groups = p.nerf.L.max_groups;
   if (moco) {
     if (!a->nof_bw_packed) return fail(MF_E_INVALID, "mf_render_pass: nof_bw_packed missing");
-    if (!nof_layout(*a->nof_bw, p.bw.L, bf16)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported backward NoF configuration");
+    if (!nof_layout(*a->nof_bw, p.bw.L, 0)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported backward NoF configuration");
     p.bw.packed = static_cast<const char*>(a->nof_bw_packed);
     p.bw.res_lds = lds; lds += (uint32_t)p.bw.L.res_bytes;
     if (p.bw.L.max_groups > max_groups) max_groups = p.bw.L.max_groups;
     if (chains) {
       if (!a->nof_fw || !a->nof_fw_packed) return fail(MF_E_INVALID, "mf_render_pass: chain flags need the forward NoF");
-      if (!nof_layout(*a->nof_fw, p.fw.L, bf16)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported forward NoF configuration");
+      if (!nof_layout(*a->nof_fw, p.fw.L, 0)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported forward NoF configuration");
       p.fw.packed = static_cast<const char*>(a->nof_fw_packed);
       p.fw.res_lds = lds; lds += (uint32_t)p.fw.L.res_bytes;
       if (p.fw.L.max_groups > max_groups) max_groups = p.fw.L.max_groups;
@@ -321,6 +324,7 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
     to_params(a->nof_emb_xyz, p.nxyz);
     to_params(a->nof_emb_ind, p.nind);
   }
+  if (bf16) return render_pass_bf16(a, static_cast<hipStream_t>(stream));     // validated above; own layout / launch
   p.ring_off = lds;
   p.buf_bytes = (uint32_t)max_groups * kGroupBytes;
   lds += 3 * p.buf_bytes;
@@ -349,15 +353,12 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
 
   const int grid = (int)(p.n_groups < device_cus() ? p.n_groups : device_cus());
   hipStream_t st = static_cast<hipStream_t>(stream);
-  const bool dump = a->dump_acts || a->dump_rgbsigma || a->dump_xyz;
-  if (dump && bf16) return fail(MF_E_UNSUPPORTED, "mf_render_pass: the activation dump (training forward) is fp32 only");
   if (a->dump_acts && a->dump_stride < (int64_t)p.nerf.L.n_trunk * p.nerf.L.W + p.nerf.L.W / 2)
     return fail(MF_E_INVALID, "mf_render_pass: dump_stride %lld too small", (long long)a->dump_stride);
   p.dump_acts = a->dump_acts; p.dump_stride = a->dump_stride; p.dump_rgbsigma = a->dump_rgbsigma; p.dump_xyz = a->dump_xyz;
   void (*kern)(RenderParams) =
       dump ? (moco ? render_kernel<true, false, true> : render_kernel<false, false, true>)
-           : (moco ? (bf16 ? render_kernel<true, true, false> : render_kernel<true, false, false>)
-                   : (bf16 ? render_kernel<false, true, false> : render_kernel<false, false, false>));
+           : (moco ? render_kernel<true, false, false> : render_kernel<false, false, false>);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, p);

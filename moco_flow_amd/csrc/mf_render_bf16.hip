@@ -1,0 +1,307 @@
+// mf_render_bf16.hip -- the fused rendering pass of render_rays (models/rendering.py:195-375) with bf16 hidden
+// GEMMs (MF_PREC_BF16, BASELINE configs C3-C5): same launch structure as mf_render.hip -- ray -> z -> xyz ->
+// [NoF chains] -> positional encoding -> NeRF -> per-ray composite, one persistent launch, nothing per-sample
+// written to HBM -- on the 32x32x16 bf16 core of mf_bf16.hpp: a wave owns 32 samples, a workgroup tile is 256
+// samples, a weight panel is one 32-row tile of a layer.
+#include <cstddef>
+
+#include "mf_bf16.hpp"
+#include "mf_host.hpp"
+#include "mf_layout.hpp"
+
+namespace mf {
+namespace bf {
+
+struct Params {
+  const float* rays; long long ray_stride; long long n_rays;
+  const float* bg;
+  int S;
+  const float* z_vals; const float* z_steps; int use_disp;
+  const float* noise;
+  int activation, flags;
+  NetDev nerf, bw, fw;
+  int extra_type;
+  float emb_par[4][32];            // [nerf xyz, nerf extra, nof xyz, nof ind] x (freq[16], weight[16]) -> LDS
+  float *rgb, *depth, *opacity, *weights, *alphas, *disp_local, *disp_global;
+  int G;
+  long long n_groups;
+  uint32_t par_off, ring_off, buf_bytes, sbuf_off, zbuf_off;
+};
+
+MF_D float wave_scan_mul(float v, int lane) {
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const float o = __shfl_up(v, d, 64);
+    if (lane >= d) v *= o;
+  }
+  return v;
+}
+MF_D float wave_sum(float v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+template <bool MOCO>
+__global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p) {
+  const Lane id;
+  load_resident(p.nerf, id);
+  if (MOCO) {
+    load_resident(p.bw, id);
+    if (p.flags & (MF_F_CHAIN_LOCAL | MF_F_CHAIN_GLOBAL)) load_resident(p.fw, id);
+  }
+  if (threadIdx.x < 128) {
+    // the embedding tables go kernarg -> LDS through the kernarg segment pointer: indexing the by-value struct with
+    // a runtime index would make hipcc keep a private (scratch) copy of all of `p`
+    typedef const __attribute__((address_space(4))) char* kptr;
+    const kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(Params, emb_par);
+    *(float*)(smem + p.par_off + threadIdx.x * 4) = ((const __attribute__((address_space(4))) float*)ka)[threadIdx.x];
+  }
+  const uint32_t par_nerf_xyz = p.par_off, par_nerf_ext = p.par_off + 128, par_nof_xyz = p.par_off + 256,
+                 par_nof_ind = p.par_off + 384;
+  Stream st;
+  Carry carry;
+  st.ring = p.ring_off;
+  st.buf_bytes = p.buf_bytes;
+  const NextLayer prog_first = MOCO ? follow_of(p.bw) : follow_of(p.nerf);
+  if (MOCO) start_program(p.bw, st, carry, id);     // (its wait + barrier also publish the resident blocks / tables)
+  else start_program(p.nerf, st, carry, id);
+
+  const int S = p.S;
+  const bool sigma_only = p.flags & MF_F_SIGMA_ONLY;
+  float4* sbuf = reinterpret_cast<float4*>(smem + p.sbuf_off);
+  float* zbuf = reinterpret_cast<float*>(smem + p.zbuf_off);
+
+  for (long long group = blockIdx.x; group < p.n_groups; group += gridDim.x) {
+    const long long ray0 = group * p.G;
+    const int nr = (int)((p.n_rays - ray0) < p.G ? (p.n_rays - ray0) : p.G);
+    const int nsamp = nr * S;
+    const int ntiles = (nsamp + bf::kTile - 1) / bf::kTile;
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+      const int srel = tile * bf::kTile + id.wave * kWaveSamples + id.j;
+      const bool valid = srel < nsamp;
+      const int sl = valid ? srel : nsamp - 1;
+      const int rr = sl / S;
+      const int si = sl - rr * S;
+      const long long ray = ray0 + rr;
+      const float* rp = p.rays + ray * p.ray_stride;
+      const float o[3] = {rp[0], rp[1], rp[2]};
+      const float d[3] = {rp[3], rp[4], rp[5]};
+      float z;
+      if (p.z_vals) {
+        z = p.z_vals[ray * S + si];
+      } else {
+        const float nearv = rp[6], farv = rp[7], t = p.z_steps[si];
+        if (!p.use_disp) z = nearv * (1.f - t) + farv * t;                    // rendering.py:247
+        else z = 1.f / (1.f / nearv * (1.f - t) + 1.f / farv * t);            // rendering.py:249
+      }
+      float x[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) x[c] = o[c] + d[c] * z;                      // rendering.py:262-263
+
+      float xin[3] = {x[0], x[1], x[2]};      // what the canonical NeRF sees
+      if (MOCO) {
+        // chain program (rendering.py:270-282): step 0 bw(x,i) -> canon; local: fw(canon,i) -> recon;
+        // global: fw(canon,j) -> a; bw(a,j) -> b; fw(b,i) -> chained recon.
+        const float ind_i = rp[8];
+        const float ind_j = (p.flags & MF_F_CHAIN_GLOBAL) ? rp[9] : 0.f;
+        const bool loc = p.flags & MF_F_CHAIN_LOCAL, glob = p.flags & MF_F_CHAIN_GLOBAL;
+        const int nsteps = 1 + (loc ? 1 : 0) + (glob ? 3 : 0);
+        float canon[3] = {0.f, 0.f, 0.f}, cur[3] = {x[0], x[1], x[2]};
+        float dl = 0.f, dg = 0.f;
+        for (int step = 0; step < nsteps; ++step) {
+          // role of this step: 0 = bw_i, 1 = local fw_i, 2 = fw_j, 3 = bw_j, 4 = final fw_i
+          const int role = step;
+          const bool use_fw = (role == 1 || role == 2 || role == 4);
+          const NetDev net = use_fw ? p.fw : p.bw;
+          const float ind = (role == 2 || role == 3) ? ind_j : ind_i;
+          if (role == 1 || role == 2) { cur[0] = canon[0]; cur[1] = canon[1]; cur[2] = canon[2]; }
+          const bool last = step == nsteps - 1;
+          const bool next_fw = (role + 1 == 1 || role + 1 == 2 || role + 1 == 4);
+          const NextLayer follow = last ? follow_of(p.nerf) : (next_fw ? follow_of(p.fw) : follow_of(p.bw));
+          u32x4 nhi[kKsNofIn], nlo[kKsNofIn];
+          float out[3];
+          nof_embed(nhi, nlo, cur, ind, par_nof_xyz, par_nof_ind, id.h);
+          nof_eval(net, nhi, nlo, cur, st, carry, id, follow, out);
+          if (role == 0) { canon[0] = out[0]; canon[1] = out[1]; canon[2] = out[2]; }
+          if (role == 1) dl = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
+          if (role == 4) dg = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
+          cur[0] = out[0]; cur[1] = out[1]; cur[2] = out[2];
+        }
+        xin[0] = canon[0]; xin[1] = canon[1]; xin[2] = canon[2];
+        if (valid && id.h == 0) {
+          if (loc && p.disp_local) p.disp_local[ray * S + si] = dl;
+          if (glob && p.disp_global) p.disp_global[ray * S + si] = dg;
+        }
+      }
+
+      u32x4 xhi[kKsNerfXyz], xlo[kKsNerfXyz];
+      {
+        float embx[B2Xyz10::SLOTS];
+        emb_eval<3, 10>(embx, xin, par_nerf_xyz, id.h);
+        split_operands<kKsNerfXyz>(embx, B2Xyz10::SLOTS, xhi, xlo);
+      }
+      auto make_extra = [&](u32x4 (&ehi)[kKsExtraMax], u32x4 (&elo)[kKsExtraMax]) {
+        float ext[8 * kKsExtraMax];
+#pragma unroll
+        for (int e = 0; e < 8 * kKsExtraMax; ++e) ext[e] = 0.f;
+        if (p.extra_type == MF_EXTRA_DIR) {
+          const float dd[3] = {rp[3], rp[4], rp[5]};
+          emb_eval<3, 4>(ext, dd, par_nerf_ext, id.h);                         // rendering.py:138-142
+        } else if (p.extra_type == MF_EXTRA_IND) {
+          const float iv[1] = {rp[8]};
+          emb_eval<1, 2>(ext, iv, par_nerf_ext, id.h);                         // rendering.py:133-137
+        }
+        split_operands<kKsExtraMax>(ext, 8 * kKsExtraMax, ehi, elo);
+      };
+      float sigma, rgb[3] = {0.f, 0.f, 0.f};
+      nerf_eval(p.nerf, xhi, xlo, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb);
+      if (valid && id.h == 0) {
+        sbuf[srel] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
+        zbuf[srel] = z;
+      }
+    }
+    __syncthreads();
+
+    // ---- composite (rendering.py:157-192): one wave per ray, lanes over samples
+    for (int rr = id.wave; rr < nr; rr += kWaves) {
+      const long long ray = ray0 + rr;
+      const float* rp = p.rays + ray * p.ray_stride;
+      const float dnorm = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);  // rendering.py:164
+      float carry_t = 1.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_w = 0.f;
+      for (int base = 0; base < S; base += 64) {
+        const int i = base + id.lane;
+        const bool v = i < S;
+        const int ii = v ? i : S - 1;
+        const float4 s4 = sbuf[rr * S + ii];
+        const float z = zbuf[rr * S + ii];
+        const float znext = zbuf[rr * S + (ii + 1 < S ? ii + 1 : ii)];
+        float delta = (ii == S - 1) ? 1e10f : znext - z;                       // :158-160
+        delta = delta * dnorm;
+        float sg = s4.w;
+        if (p.noise) sg = sg + p.noise[ray * S + ii];                          // :166 (pre-scaled)
+        float a;
+        if (p.activation == MF_ACT_RELU) a = fmaxf(sg, 0.f);
+        else a = sg > 20.f ? sg : log1pf(expf(sg));                            // nn.Softplus(beta=1, threshold=20)
+        float alpha = 1.f - expf(-delta * a);                                  // :170/172
+        if (!v) alpha = 0.f;
+        const float pt = v ? (1.f - alpha) + 1e-10f : 1.f;                     // :176-177
+        const float incl = wave_scan_mul(pt, id.lane);
+        float excl = __shfl_up(incl, 1, 64);
+        if (id.lane == 0) excl = 1.f;
+        const float w = alpha * (carry_t * excl);                              // :178-179
+        carry_t = carry_t * __shfl(incl, 63, 64);
+        if (v) {
+          if (p.weights) p.weights[ray * S + i] = w;
+          if (p.alphas) p.alphas[ray * S + i] = alpha;
+          acc_w += w;
+          acc_r += w * s4.x; acc_g += w * s4.y; acc_b += w * s4.z;
+          acc_d += w * z;
+        }
+      }
+      acc_w = wave_sum(acc_w);                                                 // :180
+      if (!sigma_only) {
+        acc_r = wave_sum(acc_r); acc_g = wave_sum(acc_g); acc_b = wave_sum(acc_b);   // :186
+        acc_d = wave_sum(acc_d);                                               // :187
+      }
+      if (id.lane == 0) {
+        if (p.opacity) p.opacity[ray] = acc_w;
+        if (!sigma_only) {
+          if (p.bg) {                                                          // :189-190
+            const float k = 1.f - acc_w;
+            acc_r = acc_r + p.bg[ray * 3 + 0] * k;
+            acc_g = acc_g + p.bg[ray * 3 + 1] * k;
+            acc_b = acc_b + p.bg[ray * 3 + 2] * k;
+          }
+          if (p.rgb) { p.rgb[ray * 3 + 0] = acc_r; p.rgb[ray * 3 + 1] = acc_g; p.rgb[ray * 3 + 2] = acc_b; }
+          if (p.depth) p.depth[ray] = acc_d;
+        }
+      }
+    }
+    __syncthreads();
+  }
+  wait_vm0();   // the stream runs two panels ahead: drain the LDS-DMA before the workgroup retires
+}
+
+static void emb_table(const mf_embedding& e, float* dst) {
+  for (int k = 0; k < 16; ++k) {
+    dst[k] = k < e.n_freqs ? e.freq[k] : 0.f;
+    dst[16 + k] = k < e.n_freqs ? e.weight[k] : 0.f;
+  }
+}
+
+}  // namespace bf
+
+int device_cus();   // mf_forward.hip
+
+// called by mf_render_pass (mf_render.hip) after argument validation, precision == MF_PREC_BF16
+int render_pass_bf16(const mf_render_args* a, hipStream_t st) {
+  using namespace bf;
+  Params p{};
+  if (!nerf_layout(*a->nerf, p.nerf.L, 1)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported NeRF configuration (bf16: W = 256)");
+  const bool moco = a->nof_bw != nullptr;
+  const bool chains = a->flags & (MF_F_CHAIN_LOCAL | MF_F_CHAIN_GLOBAL);
+  p.rays = a->rays; p.ray_stride = a->ray_stride; p.n_rays = a->n_rays; p.bg = a->background;
+  p.S = a->n_samples; p.z_vals = a->z_vals; p.z_steps = a->z_steps; p.use_disp = a->use_disp;
+  p.noise = a->noise; p.activation = a->activation; p.flags = a->flags;
+  p.nerf.packed = static_cast<const char*>(a->nerf_packed);
+  p.extra_type = a->nerf->extra_feat_type;
+  emb_table(a->emb_xyz, p.emb_par[0]);
+  emb_table(a->emb_extra, p.emb_par[1]);
+  p.rgb = a->rgb; p.depth = a->depth; p.opacity = a->opacity; p.weights = a->weights; p.alphas = a->alphas;
+  p.disp_local = a->disp_local; p.disp_global = a->disp_global;
+
+  uint32_t lds = 0;
+  p.nerf.res_lds = lds; lds += (uint32_t)p.nerf.L.res_bytes;
+  int max_groups = p.nerf.L.max_groups;
+  if (moco) {
+    if (!nof_layout(*a->nof_bw, p.bw.L, 1)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported backward NoF configuration");
+    p.bw.packed = static_cast<const char*>(a->nof_bw_packed);
+    p.bw.res_lds = lds; lds += (uint32_t)p.bw.L.res_bytes;
+    if (p.bw.L.max_groups > max_groups) max_groups = p.bw.L.max_groups;
+    if (chains) {
+      if (!nof_layout(*a->nof_fw, p.fw.L, 1)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported forward NoF configuration");
+      p.fw.packed = static_cast<const char*>(a->nof_fw_packed);
+      p.fw.res_lds = lds; lds += (uint32_t)p.fw.L.res_bytes;
+      if (p.fw.L.max_groups > max_groups) max_groups = p.fw.L.max_groups;
+    }
+    emb_table(a->nof_emb_xyz, p.emb_par[2]);
+    emb_table(a->nof_emb_ind, p.emb_par[3]);
+  }
+  p.par_off = lds; lds += 512;
+  p.ring_off = lds;
+  p.buf_bytes = (uint32_t)max_groups * kGroupBytes;
+  lds += 3 * p.buf_bytes;
+
+  // rays per group: smallest G with G*S a multiple of the 256-sample tile, capped by the LDS left
+  const uint32_t lds_cap = 160 * 1024;
+  const int max_samples = (int)((lds_cap - lds) / 20);
+  const int S = a->n_samples;
+  if (S > max_samples) return fail(MF_E_UNSUPPORTED, "mf_render_pass: n_samples=%d exceeds the %d samples a workgroup can stage", S, max_samples);
+  int G = 1;
+  while ((G * S) % bf::kTile != 0 && (G + 1) * S <= max_samples && G < 64) ++G;
+  if ((G * S) % bf::kTile != 0) {           // no exact fit: take as many rays as reduce the padding waste
+    int best = 1; double best_eff = 0;
+    for (int g = 1; g * S <= max_samples && g <= 64; ++g) {
+      const int tiles = (g * S + bf::kTile - 1) / bf::kTile;
+      const double eff = (double)(g * S) / (tiles * bf::kTile);
+      if (eff > best_eff + 1e-9) { best_eff = eff; best = g; }
+    }
+    G = best;
+  }
+  p.G = G;
+  p.n_groups = (a->n_rays + G - 1) / G;
+  p.sbuf_off = lds; lds += (uint32_t)(G * S) * 16;
+  p.zbuf_off = lds; lds += (uint32_t)(G * S) * 4;
+  lds = (lds + 15u) & ~15u;
+
+  const int grid = (int)(p.n_groups < device_cus() ? p.n_groups : device_cus());
+  void (*kern)(const Params) = moco ? render_kernel_bf16<true> : render_kernel_bf16<false>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, p);
+  return check_launch("mf_render_pass(bf16)");
+}
+
+}  // namespace mf
