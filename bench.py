@@ -22,8 +22,9 @@ The default run also measures the other configs as short extra legs and reports 
 "configs" (N = 1: C3, C3g, C5 shard; N > 1: C4, C5), each with its own roofline fraction, so every BASELINE
 config is driver-measured without changing what `value` means.
 
-Extra JSON objects: "roofline" (MFMA bound: algorithmic Linear-layer FLOPs / measured step span on the launch
-stream vs the dense matrix peak of the dtype) and "cpu_baseline" (the CPU oracle -- a PyTorch restatement of the
+Extra JSON objects: "roofline" (MFMA bound: algorithmic Linear-layer FLOPs of the dominant kernel's launch / its
+average duration, HIP events on the launch stream around the launch alone, vs the dense matrix peak of the dtype;
+"step_span_ms" is the whole render_rays call incl. resample / consensus compaction) and "cpu_baseline" (the CPU oracle -- a PyTorch restatement of the
 reference's op sequence, pinned to the reference's golden vectors -- timed on this box's host cores with the
 best thread count of a sweep; rank 0, N = 1 only).
 """
@@ -264,6 +265,36 @@ def train_leg(M, torch, models, rays, bg, gt, kw, cfg, steps=10):
     return out
 
 
+def kernel_probe(M, rendering, torch, cfg, models, rays, bg, kw, iters=20):
+    """Average duration of the DOMINANT kernel launch alone (mf_render_pass of the largest pass: the fine pass when
+    there is one), HIP events on the launch stream around the C-ABI call itself -- no resample, no compaction, no
+    host sync in the span.  Returns (ms, samples in that launch)."""
+    from moco_flow_amd import _lib as L
+    n, S = rays.shape[0], cfg["S"]
+    loc = bool(cfg["nof"] in ("local", "global"))
+    glob = bool(cfg["nof"] == "global")
+    act = L.MF_ACT_RELU
+    nofs, nof_embs = models["nofs"], models["nof_embs"]
+    with torch.no_grad():
+        if cfg["M"]:
+            cap = {}
+            M.render_rays(rays, bg, models["embs"], models["nerfs"], _capture=cap, **kw)
+            z, zs, nerf, S = cap["z_fine"].contiguous(), None, models["nerfs"][1], S + cfg["M"]
+        else:
+            z, zs, nerf = None, torch.linspace(0, 1, S, device=rays.device), models["nerfs"][0]
+        args = (rays, bg, z, zs, False, None, act, nerf, models["embs"], nofs, nof_embs, loc, glob, False, loc or glob)
+        for _ in range(3):
+            rendering._render_pass(*args)
+        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+        for s, e in ev:
+            s.record()
+            rendering._render_pass(*args)
+            e.record()
+        torch.cuda.synchronize()
+    ms = sorted(s.elapsed_time(e) for s, e in ev)
+    return float(sum(ms) / len(ms)), n * S
+
+
 def run_config(name, a, ctx, steps, warmup, main):
     """Time `steps` steps of configuration `name` on this rank.  Returns the result dict (rank-local timing
     already reduced with MAX over ranks)."""
@@ -321,7 +352,10 @@ def run_config(name, a, ctx, steps, warmup, main):
     spr = samples_per_ray(cfg)
     value = n * spr * world * steps / elapsed
     flops_step = n * spr * flops_per_sample(cfg)
-    achieved = flops_step / (kernel_ms * 1e-3) / 1e12
+    step_span_ms = kernel_ms
+    kernel_ms, launch_samples = kernel_probe(M, rendering, torch, cfg, models, rays, bg, kw)
+    flops_launch = launch_samples * flops_per_sample(cfg)
+    achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
     peak = PEAK[cfg["precision"]]
     traffic, traffic_src = traffic_of(name)
     res = {
@@ -332,8 +366,10 @@ def run_config(name, a, ctx, steps, warmup, main):
                    "loss_allreduce": bool(reducer is not None and world > 1)},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "traffic": traffic, "traffic_unit": "B/launch",
-                     "traffic_source": traffic_src, "kernel_ms": kernel_ms,
-                     "launches_per_step": 2 if cfg["M"] else 1, "flops_per_step": flops_step},
+                     "traffic_source": traffic_src, "kernel": "mf_render_pass" + (" (fine pass)" if cfg["M"] else ""),
+                     "kernel_ms": kernel_ms, "flops_per_launch": flops_launch, "samples_per_launch": launch_samples,
+                     "step_span_ms": step_span_ms, "launches_per_step": 2 if cfg["M"] else 1,
+                     "flops_per_step": flops_step},
     }
     if main and rank == 0 and world == 1 and not a.no_train_leg and cfg["precision"] == "f32":
         res["fwd_bwd"] = train_leg(M, torch, models, rays, bg, gt, kw, cfg)

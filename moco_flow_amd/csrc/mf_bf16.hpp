@@ -65,11 +65,20 @@ struct Stream {
     gnext += (size_t)groups * kGroupBytes;
   }
   MF_D void sync_and_dma(int groups, const char* jump, const Lane& id) {
+    // (MF_BF_ABL_*: timing-ablation builds only, tools/ab_lib.sh; results are garbage there)
+#ifndef MF_BF_ABL_NOWAIT
     wait_vm0();                              // this wave's pieces of the NEXT panel have landed
+#endif
+#ifndef MF_BF_ABL_NOBAR
     __builtin_amdgcn_s_barrier();            // RAW: everybody's have; WAR: everybody left the previous panel
+#endif
     asm volatile("" ::: "memory");
     if (jump) gnext = jump;
+#ifndef MF_BF_ABL_NODMA
     dma_to(slot_off(2), groups, id);
+#else
+    gnext += (size_t)groups * kGroupBytes;
+#endif
   }
   MF_D void advance() { cur = cur == 2u ? 0u : cur + 1u; }
   MF_D void start(const char* first, int groups, const Lane& id) {
@@ -82,6 +91,16 @@ struct Stream {
   }
 };
 
+// What follows the layer being computed in the panel program: its first panel (`groups`, at `jump` if the program
+// leaves the contiguous order there) and its second one (`groups2` / `jump2`: differ from the first when that layer
+// is a single panel, like the NoF head).
+struct Next {
+  int groups; const char* jump;
+  int groups2; const char* jump2;
+};
+MF_D Next next_of(const NextLayer& n) { return Next{n.groups, n.jump, n.groups, nullptr}; }
+MF_D Next next_trunk_bf(const NetDev& n, int layer) { return Next{trunk_groups(n.L, layer), nullptr, trunk_groups(n.L, layer), nullptr}; }
+
 struct Carry {            // the first PD fragments of the panel that follows, pre-read during the current one's tail
   u32x4 w[PD];
   MF_D void load(uint32_t panel_lane_off) {
@@ -90,58 +109,85 @@ struct Carry {            // the first PD fragments of the panel that follows, p
   }
 };
 
+MF_D float bflo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+MF_D float bfhi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+
+// two floats -> one dword of two bf16 (RNE), ONE v_cvt_pk_bf16_f32
 MF_D unsigned pack_bf16x2(float lo, float hi) {
-  const __bf16 a = (__bf16)lo, b = (__bf16)hi;
-  return (unsigned)__builtin_bit_cast(unsigned short, a) | ((unsigned)__builtin_bit_cast(unsigned short, b) << 16);
+  f32x2 v;
+  v[0] = lo; v[1] = hi;
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
+}
+// max(x, floor) on both bf16 halves of a dword through their int16 order: v_pk_max_i16.  floor = 0 is ReLU (every
+// negative bf16, -0 included, has the sign bit set, i.e. is a negative int16); floor = 0x80008000 (int16 min) passes
+// the value through.
+MF_D unsigned pk_floor_bf16(unsigned x, unsigned floor) {
+  return __builtin_bit_cast(unsigned, __builtin_elementwise_max(__builtin_bit_cast(i16x2, x), __builtin_bit_cast(i16x2, floor)));
 }
 
 // One output tile (32 features x the wave's 32 samples):
-//     out = max(bias + W_tile * [emb ; hidden], lo)        EMB_FIRST (trunk layers: embedded input in front)
-//     out = max(bias + W_tile * [hidden ; emb], lo)        !EMB_FIRST (NeRF extra_encoding)
+//     out = max(bias + W_tile * [emb ; hidden], floor)     EMB_FIRST (trunk layers: embedded input in front)
+//     out = max(bias + W_tile * [hidden ; emb], floor)     !EMB_FIRST (NeRF extra_encoding)
 // NGE = embedded 16-slot k-steps (each: groups hi, lo; MFMAs Whi*xhi, Whi*xlo, Wlo*xhi), KHID = hidden k-steps.
 // The A fragments are fetched PD groups ahead through a register ring that runs on into the NEXT panel's slot.
 // `hook` = the panel's barrier + DMA of the panel two ahead: behind the first group for the early half of the
 // workgroup (waves 4-7), in the middle of the panel for the late half (waves 0-3), so the two waves of a SIMD
-// run half a panel out of phase.  The bias is added in the epilogue (its four ds_reads ride in the panel's tail)
-// and the first MFMA takes C = 0, so nothing at a panel's head waits for the LDS.
+// run half a panel out of phase.  The accumulators start as the bias (four ds_reads straight into the C operand: no
+// VALU, no extra registers; the SIMD's other wave covers their latency) and the epilogue is 8 packed converts + 8
+// packed integer max per tile.
 template <int NGE, int KHID, bool EMB_FIRST, class Hook>
 MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4* xlo, uint32_t p, uint32_t pn,
-                   uint32_t bias_off, int h, bool late, Hook&& hook, float lo, u32x4& out0, u32x4& out1) {
+                   uint32_t bias_off, int h, bool late, Hook&& hook, unsigned floor, u32x4& out0, u32x4& out1) {
   constexpr int NG = 2 * NGE + KHID;
   static_assert(NG > PD, "panel shorter than the fragment pipeline");
   constexpr int LATEQ = (NG / 2 < NG - PD) ? NG / 2 : NG - PD;   // the late half must not read the next panel early
   f32x16 acc;
-#pragma unroll
+#ifdef MF_BF_ABL_NOBIAS
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#else
+  {                                                       // C/D order: reg 4q + i <- bias[8q + 4h + i]
+    const f32x4 b0 = lds_f4(bias_off + (0 + 4 * h) * 4), b1 = lds_f4(bias_off + (8 + 4 * h) * 4);
+    const f32x4 b2 = lds_f4(bias_off + (16 + 4 * h) * 4), b3 = lds_f4(bias_off + (24 + 4 * h) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; acc[8 + i] = b2[i]; acc[12 + i] = b3[i]; }
+  }
+#endif
+#ifdef MF_BF_ABL_TWOACC
+  f32x16 acc2;
+  for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
+#endif
   u32x4 r[PD + 1];
 #pragma unroll
   for (int i = 0; i < PD; ++i) r[i] = carry.w[i];
-  f32x4 b0, b1, b2, b3;
 #pragma unroll
   for (int gi = 0; gi < NG; ++gi) {
     const int s = gi % (PD + 1);
     const int ge = EMB_FIRST ? gi : gi - KHID;            // index within the embedded groups
     if (ge >= 0 && ge < 2 * NGE) {
-      if (!(ge & 1)) {
-        acc = MF_MFMA32(r[s], xhi[ge >> 1], acc);         // Whi * xhi
-      } else {
-        acc = MF_MFMA32(r[s], xhi[ge >> 1], acc);         // Wlo * xhi
-      }
+      acc = MF_MFMA32(r[s], xhi[ge >> 1], acc);           // even: Whi * xhi ; odd: Wlo * xhi
     } else {
+#ifdef MF_BF_ABL_TWOACC
+      if (gi & 1) acc2 = MF_MFMA32(r[s], hid[EMB_FIRST ? gi - 2 * NGE : gi], acc2);
+      else
+#endif
       acc = MF_MFMA32(r[s], hid[EMB_FIRST ? gi - 2 * NGE : gi], acc);
     }
     __builtin_amdgcn_sched_barrier(0);
     const int sp = (gi + PD) % (PD + 1), nb = gi + PD;
+#ifndef MF_BF_ABL_NOFRAG
     if (nb < NG) r[sp] = lds_u4(p + nb * kGroupBytes);
+#else
+    r[sp] = r[s];
+#endif
     if (gi == 0 && !late) hook();
     if (gi == LATEQ && late) hook();
+#ifndef MF_BF_ABL_NOFRAG
     if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
-    if (gi == NG - 2) {                                    // bias of this tile, C/D order: reg 4q + i <- row 8q + 4h + i
-      b0 = lds_f4(bias_off + (0 + 4 * h) * 4);
-      b1 = lds_f4(bias_off + (8 + 4 * h) * 4);
-      b2 = lds_f4(bias_off + (16 + 4 * h) * 4);
-      b3 = lds_f4(bias_off + (24 + 4 * h) * 4);
-    }
+#endif
     __builtin_amdgcn_sched_barrier(0);
     if (ge >= 0 && ge < 2 * NGE && !(ge & 1)) {
       acc = MF_MFMA32(r[s], xlo[ge >> 1], acc);           // Whi * xlo
@@ -150,26 +196,56 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
   }
 #pragma unroll
   for (int i = 0; i < PD; ++i) carry.w[i] = r[(NG + i) % (PD + 1)];
-  float v[16];
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    v[i] = fmaxf(acc[i] + b0[i], lo);
-    v[4 + i] = fmaxf(acc[4 + i] + b1[i], lo);
-    v[8 + i] = fmaxf(acc[8 + i] + b2[i], lo);
-    v[12 + i] = fmaxf(acc[12 + i] + b3[i], lo);
-  }
+#ifdef MF_BF_ABL_TWOACC
+  for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
+#endif
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
-    out0[w] = pack_bf16x2(v[2 * w], v[2 * w + 1]);
-    out1[w] = pack_bf16x2(v[8 + 2 * w], v[8 + 2 * w + 1]);
+#ifdef MF_BF_ABL_NOEPI
+    out0[w] = __builtin_bit_cast(unsigned, acc[2 * w]); out1[w] = __builtin_bit_cast(unsigned, acc[8 + 2 * w]); continue;
+#endif
+    out0[w] = pk_floor_bf16(pack_bf16x2(acc[2 * w], acc[2 * w + 1]), floor);
+    out1[w] = pk_floor_bf16(pack_bf16x2(acc[8 + 2 * w], acc[8 + 2 * w + 1]), floor);
   }
-  // The register file is full: the epilogue must retire this tile's accumulators and bias HERE.  Left alone, hipcc
-  // sinks the pure add / max / convert chain down to the outputs' first use (the next layer), keeps every tile's 16
-  // accumulators + 16 bias registers alive until then and spills ~200 registers.  The empty asm makes each packed
-  // dword a value that exists at this point.
+  // The register file is full: the epilogue must retire this tile's accumulators HERE.  Left alone, hipcc sinks the
+  // pure convert / max chain down to the outputs' first use (the next layer), keeps every tile's 16 accumulators
+  // alive until then and spills ~200 registers.  The empty asm makes each packed dword a value that exists at this
+  // point.
 #pragma unroll
   for (int w = 0; w < 4; ++w) asm volatile("" : "+v"(out0[w]), "+v"(out1[w]));
   __builtin_amdgcn_sched_barrier(0);
+}
+
+// Head tile (NoF 3|9-row head): acc = bias + (Whi + Wlo) * hidden, raw fp32 accumulators (rows (r&3)+8(r>>2)+4h).
+template <int KHID, class Hook>
+MF_D f32x16 head_tile(Carry& carry, const u32x4* hid, uint32_t p, uint32_t pn, uint32_t bias_off, int h, bool late, Hook&& hook) {
+  constexpr int NG = 2 * KHID;
+  constexpr int LATEQ = (NG / 2 < NG - PD) ? NG / 2 : NG - PD;
+  f32x16 acc;
+  {
+    const f32x4 b0 = lds_f4(bias_off + (0 + 4 * h) * 4), b1 = lds_f4(bias_off + (8 + 4 * h) * 4);
+    const f32x4 b2 = lds_f4(bias_off + (16 + 4 * h) * 4), b3 = lds_f4(bias_off + (24 + 4 * h) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; acc[8 + i] = b2[i]; acc[12 + i] = b3[i]; }
+  }
+  u32x4 r[PD + 1];
+#pragma unroll
+  for (int i = 0; i < PD; ++i) r[i] = carry.w[i];
+#pragma unroll
+  for (int gi = 0; gi < NG; ++gi) {
+    const int s = gi % (PD + 1);
+    acc = MF_MFMA32(r[s], hid[gi >> 1], acc);
+    __builtin_amdgcn_sched_barrier(0);
+    const int sp = (gi + PD) % (PD + 1), nb = gi + PD;
+    if (nb < NG) r[sp] = lds_u4(p + nb * kGroupBytes);
+    if (gi == 0 && !late) hook();
+    if (gi == LATEQ && late) hook();
+    if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int i = 0; i < PD; ++i) carry.w[i] = r[(NG + i) % (PD + 1)];
+  return acc;
 }
 
 // One trunk layer: act <- relu?(W_l [emb ; act] + b_l), NT = KH/2 tiles of 32 features.
@@ -178,19 +254,26 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
 // the unrolled tile sequence costs copies.
 template <int KH, int NGE, int MODE>
 MF_D void trunk_layer_m(const NetDev& net, int layer, u32x4 (&act)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE],
-                        Stream& st, Carry& carry, const Lane& id, const NextLayer& nxt) {
+                        Stream& st, Carry& carry, const Lane& id, const Next& nxt) {
   constexpr int NT = KH / 2;
   const int groups = trunk_groups(net.L, layer);
-  const float lo = ((net.L.relu_mask >> layer) & 1) ? 0.f : -__builtin_inff();
+  const unsigned lo = ((net.L.relu_mask >> layer) & 1) ? 0u : 0x80008000u;      // ReLU / pass-through floor
   const uint32_t bias_off = net.res_lds + (net.L.off_bias_trunk + layer * net.L.W) * 4;
+#ifndef MF_BF_ABL_NOSTAGGER
   const bool late = id.wave < kWaves / 2;
+#else
+  const bool late = false;
+#endif
   u32x4 out[KH];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const uint32_t p = st.slot_off(0) + id.lane * 16;
     const uint32_t pn = st.slot_off(1) + id.lane * 16;
-    // panel two ahead: same layer while t+2 < NT, else tile (t+2-NT) of the next layer
-    auto hook = [&]() { st.sync_and_dma(t + 2 < NT ? groups : nxt.groups, t == NT - 2 ? nxt.jump : nullptr, id); };
+    // panel two ahead: same layer while t+2 < NT, else panel (t+2-NT) of the next layer
+    auto hook = [&]() {
+      st.sync_and_dma(t + 2 < NT ? groups : (t == NT - 2 ? nxt.groups : nxt.groups2),
+                      t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id);
+    };
     out_tile<(MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, true>(carry, act, xhi, xlo, p, pn, bias_off + 32 * t * 4, id.h, late,
                                                                hook, lo, out[2 * t], out[2 * t + 1]);
     st.advance();
@@ -201,29 +284,34 @@ MF_D void trunk_layer_m(const NetDev& net, int layer, u32x4 (&act)[KH], const u3
 
 template <int KH, int NGE>
 MF_D void trunk_layer(const NetDev& net, int layer, u32x4 (&act)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE],
-                      Stream& st, Carry& carry, const Lane& id, const NextLayer& nxt) {
+                      Stream& st, Carry& carry, const Lane& id, const Next& nxt) {
   const int has_emb = (net.L.emb_mask >> layer) & 1;
   if (layer == 0) trunk_layer_m<KH, NGE, 1>(net, layer, act, xhi, xlo, st, carry, id, nxt);
   else if (has_emb) trunk_layer_m<KH, NGE, 3>(net, layer, act, xhi, xlo, st, carry, id, nxt);
   else trunk_layer_m<KH, NGE, 2>(net, layer, act, xhi, xlo, st, carry, id, nxt);
 }
 
-MF_D float bflo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
-MF_D float bfhi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
-
 // VALU head: NOUT dot products of the lane's half of the hidden vector (bf16, unpacked on the fly) with fp32
 // natural-order weight rows in LDS, summed across the two lane halves.  Element e of k-step s is feature
 // 16 s + (e&3) + 8 (e>>2) + 4 h: two 16-byte weight reads per step.
+// Rows are 16 KH floats long (compile time), so every read is ONE per-lane base register (w_byte_off + 16 h) plus an
+// immediate: runtime row lengths made hipcc hoist a separate address register per (row, step) to the kernel entry and
+// spill them all.
 template <int KH, int NOUT>
-MF_D void valu_head(const u32x4 (&act)[KH], uint32_t w_byte_off, int row_floats, uint32_t b_byte_off, int h,
-                    float (&out)[NOUT]) {
+MF_D void valu_head(const u32x4 (&act)[KH], uint32_t w_byte_off, uint32_t b_byte_off, int h, float (&out)[NOUT]) {
+  constexpr int row_floats = 16 * KH;
+  const uint32_t wl = w_byte_off + 16 * h;
+#ifdef MF_BF_ABL_NOHEAD
+  for (int o = 0; o < NOUT; ++o) out[o] = bflo(act[o % KH][0]);
+  return;
+#endif
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) {
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int s = 0; s < KH; ++s) {
-      const f32x4 wa = lds_f4(w_byte_off + (o * row_floats + 16 * s + 4 * h) * 4);
-      const f32x4 wb = lds_f4(w_byte_off + (o * row_floats + 16 * s + 8 + 4 * h) * 4);
+      const f32x4 wa = lds_f4(wl + (o * row_floats + 16 * s) * 4);
+      const f32x4 wb = lds_f4(wl + (o * row_floats + 16 * s + 8) * 4);
       s0 = __builtin_fmaf(wa[0], bflo(act[s][0]), s0);
       s1 = __builtin_fmaf(wa[1], bfhi(act[s][0]), s1);
       s0 = __builtin_fmaf(wa[2], bflo(act[s][1]), s0);
@@ -269,7 +357,11 @@ MF_D void emb_eval(float* dst, const float (&v)[C], uint32_t par_off, int h) {
     // skipped when both halves' frequencies are muted (coarse-to-fine start, trainer_moco_flow.py:113-114)
     const bool live = lds_f(par_off + 64 + 4 * f0) != 0.f || (real1 && lds_f(par_off + 64 + 4 * f1) != 0.f);
     float sn = 0.f, cs = 0.f;
+#ifndef MF_BF_ABL_NOSINCOS
     if (__builtin_amdgcn_readfirstlane((int)live)) sincosf(fr * x, &sn, &cs);
+#else
+    sn = fr * x; cs = fr - x;
+#endif
     dst[2 * pi] = real ? w * sn : (h ? ra1 : ra0);
     dst[2 * pi + 1] = real ? w * cs : (h ? rb1 : rb0);
   }
@@ -284,10 +376,9 @@ MF_D void split_operands(const float* emb, int n_slots, u32x4 (&xhi)[KS], u32x4 
     for (int w = 0; w < 4; ++w) {
       const int e0 = 8 * ks + 2 * w, e1 = e0 + 1;
       const float a = e0 < n_slots ? emb[e0] : 0.f, b = e1 < n_slots ? emb[e1] : 0.f;
-      const __bf16 ah = (__bf16)a, bh = (__bf16)b;
-      const __bf16 al = (__bf16)(a - (float)ah), bl = (__bf16)(b - (float)bh);
-      xhi[ks][w] = (unsigned)__builtin_bit_cast(unsigned short, ah) | ((unsigned)__builtin_bit_cast(unsigned short, bh) << 16);
-      xlo[ks][w] = (unsigned)__builtin_bit_cast(unsigned short, al) | ((unsigned)__builtin_bit_cast(unsigned short, bl) << 16);
+      const unsigned hi = pack_bf16x2(a, b);
+      xhi[ks][w] = hi;
+      xlo[ks][w] = pack_bf16x2(a - bflo(hi), b - bfhi(hi));
     }
   }
 }
@@ -306,7 +397,7 @@ MF_D void load_resident(const NetDev& n, const Lane& id) {
 // extra_encoding (nerf.py:98): W/2 outputs from [final (W) ; extra block], ReLU.  NGX = extra k-steps (0, 1, 2).
 template <int NGX>
 MF_D void extra_layer(const NetDev& net, const u32x4 (&act)[16], const u32x4* ehi, const u32x4* elo, u32x4 (&out)[8],
-                      Stream& st, Carry& carry, const Lane& id, const NextLayer& nxt) {
+                      Stream& st, Carry& carry, const Lane& id, const Next& nxt) {
   constexpr int NT = 4;
   const int groups = extra_groups(net.L);
   const uint32_t bias_off = net.res_lds + net.L.off_bias_extra * 4;
@@ -315,8 +406,11 @@ MF_D void extra_layer(const NetDev& net, const u32x4 (&act)[16], const u32x4* eh
   for (int t = 0; t < NT; ++t) {
     const uint32_t p = st.slot_off(0) + id.lane * 16;
     const uint32_t pn = st.slot_off(1) + id.lane * 16;
-    auto hook = [&]() { st.sync_and_dma(t + 2 < NT ? groups : nxt.groups, t == NT - 2 ? nxt.jump : nullptr, id); };
-    out_tile<NGX, 16, false>(carry, act, ehi, elo, p, pn, bias_off + 32 * t * 4, id.h, late, hook, 0.f, out[2 * t], out[2 * t + 1]);
+    auto hook = [&]() {
+      st.sync_and_dma(t + 2 < NT ? groups : (t == NT - 2 ? nxt.groups : nxt.groups2),
+                      t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id);
+    };
+    out_tile<NGX, 16, false>(carry, act, ehi, elo, p, pn, bias_off + 32 * t * 4, id.h, late, hook, 0u, out[2 * t], out[2 * t + 1]);
     st.advance();
   }
 }
@@ -327,7 +421,7 @@ MF_D void extra_layer(const NetDev& net, const u32x4 (&act)[16], const u32x4* eh
 template <class MakeExtra>
 MF_D void nerf_eval(const NetDev& net, const u32x4 (&xhi)[kKsNerfXyz], const u32x4 (&xlo)[kKsNerfXyz],
                     MakeExtra&& make_extra, bool sigma_only, Stream& st,
-                    Carry& carry, const Lane& id, const NextLayer& follow, float& sigma, float (&rgb)[3]) {
+                    Carry& carry, const Lane& id, const Next& follow, float& sigma, float (&rgb)[3]) {
   u32x4 act[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t)
@@ -336,16 +430,13 @@ MF_D void nerf_eval(const NetDev& net, const u32x4 (&xhi)[kKsNerfXyz], const u32
   const int D = net.L.n_trunk - 1;
   for (int l = 0; l < D; ++l) {
     const bool last = sigma_only && l == D - 1;
-    trunk_layer<16, kKsNerfXyz>(net, l, act, xhi, xlo, st, carry, id, last ? follow : next_trunk(net, l + 1));
+    trunk_layer<16, kKsNerfXyz>(net, l, act, xhi, xlo, st, carry, id, last ? follow : next_trunk_bf(net, l + 1));
   }
   float sg[1];
-  valu_head(act, net.res_lds + net.L.off_head_w * 4, net.L.W, net.res_lds + net.L.off_head_b * 4, id.h, sg);
+  valu_head(act, net.res_lds + net.L.off_head_w * 4, net.res_lds + net.L.off_head_b * 4, id.h, sg);
   sigma = sg[0];
   if (sigma_only) return;
-  NextLayer ex;
-  ex.groups = extra_groups(net.L);
-  ex.jump = nullptr;
-  ex.bias_off = 0;
+  const Next ex{extra_groups(net.L), nullptr, extra_groups(net.L), nullptr};
   trunk_layer<16, kKsNerfXyz>(net, D, act, xhi, xlo, st, carry, id, ex);          // xyz_encoding_final (no ReLU)
   u32x4 e[8], ehi[kKsExtraMax], elo[kKsExtraMax];
   make_extra(ehi, elo);
@@ -353,32 +444,51 @@ MF_D void nerf_eval(const NetDev& net, const u32x4 (&xhi)[kKsNerfXyz], const u32
   else if (net.L.extra_steps == 1) extra_layer<1>(net, act, ehi, elo, e, st, carry, id, follow);
   else extra_layer<0>(net, act, ehi, elo, e, st, carry, id, follow);
   float o[3];
-  valu_head(e, net.res_lds + net.L.off_rgb_w * 4, net.L.W / 2, net.res_lds + net.L.off_rgb_b * 4, id.h, o);
+  valu_head(e, net.res_lds + net.L.off_rgb_w * 4, net.res_lds + net.L.off_rgb_b * 4, id.h, o);
 #pragma unroll
   for (int c = 0; c < 3; ++c) rgb[c] = 1.f / (1.f + expf(-o[c]));   // nn.Sigmoid, nerf.py:57-59
 }
 
 // Neural motion flow (W = 128) on this wave's 32 samples; xhi/xlo = split operands of [xyz block ; ind block].
 MF_D void nof_eval(const NetDev& net, const u32x4 (&xhi)[kKsNofIn], const u32x4 (&xlo)[kKsNofIn], const float (&xyz)[3],
-                   Stream& st, Carry& carry, const Lane& id, const NextLayer& follow, float (&out)[3]) {
+                   Stream& st, Carry& carry, const Lane& id, const Next& follow, float (&out)[3]) {
   u32x4 act[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) act[t][i] = 0;
   const int D = net.L.n_trunk;
+  // the head panel follows the last trunk layer contiguously; behind it comes `follow`'s first panel
+  const Next hd{head_groups(net.L), nullptr, follow.groups, follow.jump};
   for (int l = 0; l < D; ++l)
-    trunk_layer<8, kKsNofIn>(net, l, act, xhi, xlo, st, carry, id, l == D - 1 ? follow : next_trunk(net, l + 1));
-  const uint32_t wo = net.res_lds + net.L.off_head_w * 4, bo = net.res_lds + net.L.off_head_b * 4;
+    trunk_layer<8, kKsNofIn>(net, l, act, xhi, xlo, st, carry, id, l == D - 1 ? hd : next_trunk_bf(net, l + 1));
+  // head on the matrix pipe (16 MFMAs instead of 9 x 64 dependent FMAs + 144 LDS reads per lane); T[0..3] come
+  // out in half 0's registers 0-3, T[4..7] in half 1's registers 0-3, T[8] in half 0's register 4
+  f32x16 acc;
+  {
+    const uint32_t p = st.slot_off(0) + id.lane * 16, pn = st.slot_off(1) + id.lane * 16;
+    // panel two ahead of the head panel = the SECOND panel of whatever follows
+    auto hook = [&]() { st.sync_and_dma(follow.groups2, follow.jump2, id); };
+#ifndef MF_BF_ABL_NOSTAGGER
+    const bool late = id.wave < kWaves / 2;
+#else
+    const bool late = false;
+#endif
+    acc = head_tile<8>(carry, act, p, pn, net.res_lds + net.L.off_head_b * 4, id.h, late, hook);
+    st.advance();
+  }
+  float own[5], oth[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { own[i] = acc[i]; oth[i] = __shfl_xor(acc[i], 32, 64); }
   if (net.L.n_head == 9) {
     float T[9];
-    valu_head(act, wo, net.L.W, bo, id.h, T);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { T[i] = id.h ? oth[i] : own[i]; T[4 + i] = id.h ? own[i] : oth[i]; }
+    T[8] = id.h ? oth[4] : own[4];
     quat_transform(T, xyz, out);
   } else {
-    float T[3];
-    valu_head(act, wo, net.L.W, bo, id.h, T);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) out[c] = T[c] + xyz[c];
+    for (int c = 0; c < 3; ++c) out[c] = (id.h ? oth[c] : own[c]) + xyz[c];
   }
 }
 

@@ -206,6 +206,9 @@ MF_HD int trunk_groups(const NetLayout& L, int layer) {
   if (L.bf16) return (((L.emb_mask >> layer) & 1) ? 2 * L.emb_steps : 0) + (layer > 0 ? L.NK : 0);
   return 2 * trunk_batches(L, layer);
 }
+// bf16 NoF: the 3|9-row head (nof.py:75-82) as one more panel behind the trunk: a 32-row tile (rows >= n_head zero)
+// whose hidden k-steps are split (hi, lo) group pairs -- the head's weights keep 16 mantissa bits.
+MF_HD int head_groups(const NetLayout& L) { return 2 * L.NK; }
 MF_HD int extra_groups(const NetLayout& L) {
   if (L.bf16) return L.NK + 2 * L.extra_steps;
   return 2 * (hidden_batches(L) + L.extra_steps / 4);

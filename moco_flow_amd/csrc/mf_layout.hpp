@@ -72,7 +72,7 @@ inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0) {
   int off = 0;
   L.off_bias_trunk = off; off += L.n_trunk * L.W;
   L.off_head_w = off; off += L.n_head * L.W;
-  L.off_head_b = off; off += 12;
+  L.off_head_b = off; off += bf16 ? 32 : 12;          // bf16: the head is an MFMA tile, its bias a 32-row vector
   L.res_bytes = round_up((int64_t)off * 4, kGroupBytes);
   int64_t groups = 0;
   L.max_groups = 0;
@@ -80,6 +80,10 @@ inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0) {
     const int g = trunk_groups(L, l);
     groups += (int64_t)g * L.NP;
     if (g > L.max_groups) L.max_groups = g;
+  }
+  if (bf16) {                                          // head panel: one 32-row tile, hidden k-steps as (hi, lo) group pairs
+    groups += head_groups(L);
+    if (head_groups(L) > L.max_groups) L.max_groups = head_groups(L);
   }
   L.panel_bytes = groups * kGroupBytes;
   return true;

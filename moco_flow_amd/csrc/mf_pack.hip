@@ -26,6 +26,8 @@ struct PackRegion {          // one trunk/extra layer's panels
   int bf16;                  // groups hold 8 bf16 per lane (32x32x16 A fragments) instead of 4 fp32
   int hid_col0;              // column of hidden feature 0 in W
   int xyz_cols;
+  int n_rows;                // rows present in W (bf16 head panel: 3|9 of its 32; 0 = all)
+  int hid_split;             // bf16: hidden k-step ks is TWO groups (hi, lo) instead of one
   long long dst_group0;      // first group index (in 1 KiB units) within the panel area
 };
 
@@ -64,7 +66,16 @@ __global__ void pack_panels_kernel(PackJob job) {
     const int ge = R.emb_first ? gi : gi - R.hid_batches;
     const int gh = R.emb_first ? gi - 2 * R.emb_steps : gi;
     unsigned short h8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (ge >= 0 && ge < 2 * R.emb_steps) {
+    if (R.n_rows && 32 * P + i >= R.n_rows) {
+      // zero row of a partial tile
+    } else if (R.hid_split) {
+      const int ks = gi >> 1, lo = gi & 1;
+      for (int e = 0; e < 8; ++e) {
+        const float w = row[R.hid_col0 + 16 * ks + hid_perm2(h, e)];
+        const unsigned short hi = bf16_rne(w);
+        h8[e] = lo ? bf16_rne(w - __uint_as_float((unsigned)hi << 16)) : hi;
+      }
+    } else if (ge >= 0 && ge < 2 * R.emb_steps) {
       const int ks = ge >> 1, lo = ge & 1;
       for (int e = 0; e < 8; ++e) {
         const int f = emb_feature2(R.emb_kind, h, 8 * ks + e, R.xyz_cols);
@@ -242,6 +253,21 @@ extern "C" int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* 
     rj.c[rj.n++] = ResCopy{d->trunk_b[l], L.off_bias_trunk + l * L.W, L.W};
   }
   if (!d->head_w || !d->head_b) return fail(MF_E_INVALID, "mf_nof_pack: missing head parameters");
+  if (L.bf16) {
+    PackRegion& R = job.reg[nr++];
+    R.W = d->head_w;
+    R.n_in = L.W;
+    R.tiles = 1;
+    R.groups = head_groups(L);
+    R.emb_first = 1;
+    R.emb_kind = kEmbNone;
+    R.hid_batches = L.NK;
+    R.bf16 = 1;
+    R.n_rows = L.n_head;
+    R.hid_split = 1;
+    R.dst_group0 = g0;
+    g0 += R.groups;
+  }
   rj.c[rj.n++] = ResCopy{d->head_w, L.off_head_w, L.n_head * L.W};
   rj.c[rj.n++] = ResCopy{d->head_b, L.off_head_b, L.n_head};
   job.n_regions = nr;

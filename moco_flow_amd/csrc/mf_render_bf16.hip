@@ -63,7 +63,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
   Carry carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
-  const NextLayer prog_first = MOCO ? follow_of(p.bw) : follow_of(p.nerf);
+  const Next prog_first = next_of(MOCO ? follow_of(p.bw) : follow_of(p.nerf));
   if (MOCO) start_program(p.bw, st, carry, id);     // (its wait + barrier also publish the resident blocks / tables)
   else start_program(p.nerf, st, carry, id);
 
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
           if (role == 1 || role == 2) { cur[0] = canon[0]; cur[1] = canon[1]; cur[2] = canon[2]; }
           const bool last = step == nsteps - 1;
           const bool next_fw = (role + 1 == 1 || role + 1 == 2 || role + 1 == 4);
-          const NextLayer follow = last ? follow_of(p.nerf) : (next_fw ? follow_of(p.fw) : follow_of(p.bw));
+          const Next follow = next_of(last ? follow_of(p.nerf) : (next_fw ? follow_of(p.fw) : follow_of(p.bw)));
           u32x4 nhi[kKsNofIn], nlo[kKsNofIn];
           float out[3];
           nof_embed(nhi, nlo, cur, ind, par_nof_xyz, par_nof_ind, id.h);
