@@ -52,19 +52,15 @@ MF_D u32x4 lds_u4(uint32_t byte_off) { return *(const u32x4*)(smem + byte_off); 
 // one workgroup barrier per panel.
 struct Stream {
   const char* gnext;      // global address of the panel two ahead of the one being computed
-  uint32_t ring, buf_bytes, cur;
+  uint32_t off0, off1, off2;   // LDS byte offsets of the slots holding the current panel, the next one, the one after
+                               // (rotated by advance(): no modulo / multiply per panel)
 
-  MF_D uint32_t slot_off(uint32_t k) const {
-    uint32_t s = cur + k;
-    s = s >= 3u ? s - 3u : s;
-    return ring + s * buf_bytes;
-  }
-  MF_D void dma_to(uint32_t dst, int groups, const Lane& id) {
-    const char* g = gnext + id.lane * 16;
-    for (int grp = id.wave; grp < groups; grp += kWaves) glds16(g + grp * kGroupBytes, dst + grp * kGroupBytes);
-    gnext += (size_t)groups * kGroupBytes;
-  }
-  MF_D void sync_and_dma(int groups, const char* jump, const Lane& id) {
+  MF_D uint32_t slot_off(uint32_t k) const { return k == 0 ? off0 : (k == 1 ? off1 : off2); }
+  // The panel hook, in two parts.  sync(): barrier of the panel, then the DMA source / destination of the panel two
+  // ahead are latched.  piece(k): this wave's k-th 1 KiB piece of that panel (k = 0..2: a panel is at most 24 groups
+  // over 8 waves); the pieces are issued one per MFMA gap behind the barrier instead of as a burst.
+  const char* dsrc; uint32_t ddst; uint32_t pmask;
+  MF_D void sync(int groups, const char* jump, const Lane& id) {
     // (MF_BF_ABL_*: timing-ablation builds only, tools/ab_lib.sh; results are garbage there)
 #ifndef MF_BF_ABL_NOWAIT
     wait_vm0();                              // this wave's pieces of the NEXT panel have landed
@@ -74,22 +70,50 @@ struct Stream {
 #endif
     asm volatile("" ::: "memory");
     if (jump) gnext = jump;
-#ifndef MF_BF_ABL_NODMA
-    dma_to(slot_off(2), groups, id);
-#else
+    dsrc = gnext + id.wave * kGroupBytes;    // this wave's first piece
+    ddst = off2 + id.wave * kGroupBytes;
+    const int mine = (groups - id.wave + kWaves - 1) / kWaves;      // pieces of this wave: groups wave, wave + 8, ...
+    pmask = (1u << (mine < 0 ? 0 : mine)) - 1u;
     gnext += (size_t)groups * kGroupBytes;
+  }
+  MF_D void piece(int k, const Lane& id) {
+#ifndef MF_BF_ABL_NODMA
+    if ((pmask >> k) & 1u) glds16(dsrc + k * (kWaves * kGroupBytes) + (uint32_t)(id.lane * 16), ddst + k * (kWaves * kGroupBytes));
 #endif
   }
-  MF_D void advance() { cur = cur == 2u ? 0u : cur + 1u; }
-  MF_D void start(const char* first, int groups, const Lane& id) {
-    cur = 0;
-    gnext = first;
-    dma_to(ring, groups, id);
-    dma_to(ring + buf_bytes, groups, id);
+  MF_D void advance() {
+    const uint32_t t = off0;
+    off0 = off1; off1 = off2; off2 = t;
+  }
+  MF_D void start(const char* first, int groups, uint32_t ring, uint32_t buf_bytes, const Lane& id) {
+    off0 = ring; off1 = ring + buf_bytes; off2 = ring + 2 * buf_bytes;
+    const char* g = first + id.lane * 16;
+    for (int grp = id.wave; grp < groups; grp += kWaves) {
+      glds16(g + grp * kGroupBytes, off0 + grp * kGroupBytes);
+      glds16(g + (size_t)(groups + grp) * kGroupBytes, off1 + grp * kGroupBytes);
+    }
+    gnext = first + (size_t)2 * groups * kGroupBytes;
     wait_vm0();
     __syncthreads();
   }
 };
+
+// Uniform per-network state of the bf16 kernels: SIX scalars.  (The fp32 kernels hand a whole NetLayout -- ~25 derived
+// offsets per network -- through SGPRs; with three networks that alone overflowed the scalar file here and every
+// access became a v_readlane from a spill register.)  Everything else follows from the compile-time shape (KH = W/16,
+// EKS = embedded k-steps) and D:
+//   resident block (floats): NeRF  [bias_trunk (D+1) W | bias_extra W/2 | sigma_w W | sigma_b 4 | rgb_w 3 W/2 | rgb_b 4]
+//                            NoF   [bias_trunk D W | head_w n_head W | head_b 32]
+struct Net {
+  const char* packed;      // global base of the packed buffer
+  uint32_t res_lds;        // LDS byte offset of its resident block
+  uint32_t res_bytes;      // size of the resident block (panels start there)
+  int D;                   // NeRF: trunk layers WITHOUT xyz_encoding_final; NoF: trunk layers
+  uint32_t emb_mask;       // trunk layers that consume the embedded input (layer 0 + skips)
+  int aux;                 // NeRF: k-steps of the extra block (0, 1, 2); NoF: head rows (3 | 9)
+};
+template <int KH, int EKS>
+MF_D int tgroups(const Net& n, int layer) { return (((n.emb_mask >> layer) & 1) ? 2 * EKS : 0) + (layer > 0 ? KH : 0); }
 
 // What follows the layer being computed in the panel program: its first panel (`groups`, at `jump` if the program
 // leaves the contiguous order there) and its second one (`groups2` / `jump2`: differ from the first when that layer
@@ -98,8 +122,10 @@ struct Next {
   int groups; const char* jump;
   int groups2; const char* jump2;
 };
-MF_D Next next_of(const NextLayer& n) { return Next{n.groups, n.jump, n.groups, nullptr}; }
-MF_D Next next_trunk_bf(const NetDev& n, int layer) { return Next{trunk_groups(n.L, layer), nullptr, trunk_groups(n.L, layer), nullptr}; }
+template <int KH, int EKS>
+MF_D Next first_of(const Net& n) { return Next{2 * EKS, n.packed + n.res_bytes, 2 * EKS, nullptr}; }   // layer 0: embedded input only
+template <int KH, int EKS>
+MF_D Next next_trunk_bf(const Net& n, int layer) { return Next{tgroups<KH, EKS>(n, layer), nullptr, tgroups<KH, EKS>(n, layer), nullptr}; }
 
 struct Carry {            // the first PD fragments of the panel that follows, pre-read during the current one's tail
   u32x4 w[PD];
@@ -139,12 +165,14 @@ MF_D unsigned pk_floor_bf16(unsigned x, unsigned floor) {
 // run half a panel out of phase.  The accumulators start as the bias (four ds_reads straight into the C operand: no
 // VALU, no extra registers; the SIMD's other wave covers their latency) and the epilogue is 8 packed converts + 8
 // packed integer max per tile.
-template <int NGE, int KHID, bool EMB_FIRST, class Hook>
+template <int NGE, int KHID, bool EMB_FIRST, class Hook, class Piece>
 MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4* xlo, uint32_t p, uint32_t pn,
-                   uint32_t bias_off, int h, bool late, Hook&& hook, unsigned floor, u32x4& out0, u32x4& out1) {
+                   uint32_t bias_off, int h, bool late, Hook&& hook, Piece&& piece, unsigned floor, u32x4& out0, u32x4& out1) {
   constexpr int NG = 2 * NGE + KHID;
   static_assert(NG > PD, "panel shorter than the fragment pipeline");
-  constexpr int LATEQ = (NG / 2 < NG - PD) ? NG / 2 : NG - PD;   // the late half must not read the next panel early
+  constexpr int LATEQ0 = (NG / 2 < NG - PD) ? NG / 2 : NG - PD;  // the late half must not read the next panel early
+  constexpr int LATEQ = LATEQ0 + 3 < NG ? LATEQ0 : NG - 4;       // ... and needs three MFMA gaps behind its barrier
+  static_assert(LATEQ >= 0 && NG >= 4, "panel too short for the DMA pieces");
   f32x16 acc;
 #ifdef MF_BF_ABL_NOBIAS
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -183,8 +211,11 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
 #else
     r[sp] = r[s];
 #endif
-    if (gi == 0 && !late) hook();
-    if (gi == LATEQ && late) hook();
+    {
+      const int hp = late ? LATEQ : 0;                       // (uniform) position of this wave's barrier
+      if (gi == hp) hook();
+      if (gi > hp && gi <= hp + 3) piece(gi - hp - 1);
+    }
 #ifndef MF_BF_ABL_NOFRAG
     if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
 #endif
@@ -217,10 +248,12 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
 }
 
 // Head tile (NoF 3|9-row head): acc = bias + (Whi + Wlo) * hidden, raw fp32 accumulators (rows (r&3)+8(r>>2)+4h).
-template <int KHID, class Hook>
-MF_D f32x16 head_tile(Carry& carry, const u32x4* hid, uint32_t p, uint32_t pn, uint32_t bias_off, int h, bool late, Hook&& hook) {
+template <int KHID, class Hook, class Piece>
+MF_D f32x16 head_tile(Carry& carry, const u32x4* hid, uint32_t p, uint32_t pn, uint32_t bias_off, int h, bool late, Hook&& hook,
+                      Piece&& piece) {
   constexpr int NG = 2 * KHID;
-  constexpr int LATEQ = (NG / 2 < NG - PD) ? NG / 2 : NG - PD;
+  constexpr int LATEQ0 = (NG / 2 < NG - PD) ? NG / 2 : NG - PD;
+  constexpr int LATEQ = LATEQ0 + 3 < NG ? LATEQ0 : NG - 4;
   f32x16 acc;
   {
     const f32x4 b0 = lds_f4(bias_off + (0 + 4 * h) * 4), b1 = lds_f4(bias_off + (8 + 4 * h) * 4);
@@ -238,8 +271,11 @@ MF_D f32x16 head_tile(Carry& carry, const u32x4* hid, uint32_t p, uint32_t pn, u
     __builtin_amdgcn_sched_barrier(0);
     const int sp = (gi + PD) % (PD + 1), nb = gi + PD;
     if (nb < NG) r[sp] = lds_u4(p + nb * kGroupBytes);
-    if (gi == 0 && !late) hook();
-    if (gi == LATEQ && late) hook();
+    {
+      const int hp = late ? LATEQ : 0;
+      if (gi == hp) hook();
+      if (gi > hp && gi <= hp + 3) piece(gi - hp - 1);
+    }
     if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -253,12 +289,12 @@ MF_D f32x16 head_tile(Carry& carry, const u32x4* hid, uint32_t p, uint32_t pn, u
 // parameter, not a switch inside the tile loop: the register file is full here and every control-flow merge inside
 // the unrolled tile sequence costs copies.
 template <int KH, int NGE, int MODE>
-MF_D void trunk_layer_m(const NetDev& net, int layer, u32x4 (&act)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE],
+MF_D void trunk_layer_m(const Net& net, int layer, bool relu, u32x4 (&act)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE],
                         Stream& st, Carry& carry, const Lane& id, const Next& nxt) {
   constexpr int NT = KH / 2;
-  const int groups = trunk_groups(net.L, layer);
-  const unsigned lo = ((net.L.relu_mask >> layer) & 1) ? 0u : 0x80008000u;      // ReLU / pass-through floor
-  const uint32_t bias_off = net.res_lds + (net.L.off_bias_trunk + layer * net.L.W) * 4;
+  const int groups = tgroups<KH, NGE>(net, layer);
+  const unsigned lo = relu ? 0u : 0x80008000u;      // ReLU / pass-through floor
+  const uint32_t bias_off = net.res_lds + layer * (16 * KH) * 4;
 #ifndef MF_BF_ABL_NOSTAGGER
   const bool late = id.wave < kWaves / 2;
 #else
@@ -271,11 +307,12 @@ MF_D void trunk_layer_m(const NetDev& net, int layer, u32x4 (&act)[KH], const u3
     const uint32_t pn = st.slot_off(1) + id.lane * 16;
     // panel two ahead: same layer while t+2 < NT, else panel (t+2-NT) of the next layer
     auto hook = [&]() {
-      st.sync_and_dma(t + 2 < NT ? groups : (t == NT - 2 ? nxt.groups : nxt.groups2),
-                      t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id);
+      st.sync(t + 2 < NT ? groups : (t == NT - 2 ? nxt.groups : nxt.groups2),
+              t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id);
     };
+    auto piece = [&](int k) { st.piece(k, id); };
     out_tile<(MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, true>(carry, act, xhi, xlo, p, pn, bias_off + 32 * t * 4, id.h, late,
-                                                               hook, lo, out[2 * t], out[2 * t + 1]);
+                                                               hook, piece, lo, out[2 * t], out[2 * t + 1]);
     st.advance();
   }
 #pragma unroll
@@ -283,12 +320,12 @@ MF_D void trunk_layer_m(const NetDev& net, int layer, u32x4 (&act)[KH], const u3
 }
 
 template <int KH, int NGE>
-MF_D void trunk_layer(const NetDev& net, int layer, u32x4 (&act)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE],
+MF_D void trunk_layer(const Net& net, int layer, bool relu, u32x4 (&act)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE],
                       Stream& st, Carry& carry, const Lane& id, const Next& nxt) {
-  const int has_emb = (net.L.emb_mask >> layer) & 1;
-  if (layer == 0) trunk_layer_m<KH, NGE, 1>(net, layer, act, xhi, xlo, st, carry, id, nxt);
-  else if (has_emb) trunk_layer_m<KH, NGE, 3>(net, layer, act, xhi, xlo, st, carry, id, nxt);
-  else trunk_layer_m<KH, NGE, 2>(net, layer, act, xhi, xlo, st, carry, id, nxt);
+  const int has_emb = (net.emb_mask >> layer) & 1;
+  if (layer == 0) trunk_layer_m<KH, NGE, 1>(net, layer, relu, act, xhi, xlo, st, carry, id, nxt);
+  else if (has_emb) trunk_layer_m<KH, NGE, 3>(net, layer, relu, act, xhi, xlo, st, carry, id, nxt);
+  else trunk_layer_m<KH, NGE, 2>(net, layer, relu, act, xhi, xlo, st, carry, id, nxt);
 }
 
 // VALU head: NOUT dot products of the lane's half of the hidden vector (bf16, unpacked on the fly) with fp32
@@ -384,33 +421,35 @@ MF_D void split_operands(const float* emb, int n_slots, u32x4 (&xhi)[KS], u32x4 
 }
 
 // ------------------------------------------------------------------ the two networks
-MF_D void start_program(const NetDev& n, Stream& st, Carry& carry, const Lane& id) {
-  st.start(n.packed + n.L.res_bytes, trunk_groups(n.L, 0), id);
+template <int KH, int EKS>
+MF_D void start_program(const Net& n, Stream& st, Carry& carry, uint32_t ring, uint32_t buf_bytes, const Lane& id) {
+  st.start(n.packed + n.res_bytes, 2 * EKS, ring, buf_bytes, id);
   carry.load(st.slot_off(0) + id.lane * 16);
 }
 
-MF_D void load_resident(const NetDev& n, const Lane& id) {
-  const int groups = (int)(n.L.res_bytes / kGroupBytes);
+MF_D void load_resident(const Net& n, const Lane& id) {
+  const int groups = (int)(n.res_bytes / kGroupBytes);
   for (int g = id.wave; g < groups; g += kWaves) glds16(n.packed + g * kGroupBytes + id.lane * 16, n.res_lds + g * kGroupBytes);
 }
 
 // extra_encoding (nerf.py:98): W/2 outputs from [final (W) ; extra block], ReLU.  NGX = extra k-steps (0, 1, 2).
 template <int NGX>
-MF_D void extra_layer(const NetDev& net, const u32x4 (&act)[16], const u32x4* ehi, const u32x4* elo, u32x4 (&out)[8],
+MF_D void extra_layer(const Net& net, const u32x4 (&act)[16], const u32x4* ehi, const u32x4* elo, u32x4 (&out)[8],
                       Stream& st, Carry& carry, const Lane& id, const Next& nxt) {
   constexpr int NT = 4;
-  const int groups = extra_groups(net.L);
-  const uint32_t bias_off = net.res_lds + net.L.off_bias_extra * 4;
+  const int groups = 16 + 2 * NGX;
+  const uint32_t bias_off = net.res_lds + (net.D + 1) * 256 * 4;
   const bool late = id.wave < kWaves / 2;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const uint32_t p = st.slot_off(0) + id.lane * 16;
     const uint32_t pn = st.slot_off(1) + id.lane * 16;
     auto hook = [&]() {
-      st.sync_and_dma(t + 2 < NT ? groups : (t == NT - 2 ? nxt.groups : nxt.groups2),
-                      t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id);
+      st.sync(t + 2 < NT ? groups : (t == NT - 2 ? nxt.groups : nxt.groups2),
+              t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id);
     };
-    out_tile<NGX, 16, false>(carry, act, ehi, elo, p, pn, bias_off + 32 * t * 4, id.h, late, hook, 0u, out[2 * t], out[2 * t + 1]);
+    auto piece = [&](int k) { st.piece(k, id); };
+    out_tile<NGX, 16, false>(carry, act, ehi, elo, p, pn, bias_off + 32 * t * 4, id.h, late, hook, piece, 0u, out[2 * t], out[2 * t + 1]);
     st.advance();
   }
 }
@@ -419,7 +458,7 @@ MF_D void extra_layer(const NetDev& net, const u32x4 (&act)[16], const u32x4* eh
 // `make_extra(ehi, elo)` builds the extra block's operands; it is called right before extra_encoding so that those
 // registers are not held through the trunk.
 template <class MakeExtra>
-MF_D void nerf_eval(const NetDev& net, const u32x4 (&xhi)[kKsNerfXyz], const u32x4 (&xlo)[kKsNerfXyz],
+MF_D void nerf_eval(const Net& net, const u32x4 (&xhi)[kKsNerfXyz], const u32x4 (&xlo)[kKsNerfXyz],
                     MakeExtra&& make_extra, bool sigma_only, Stream& st,
                     Carry& carry, const Lane& id, const Next& follow, float& sigma, float (&rgb)[3]) {
   u32x4 act[16];
@@ -427,60 +466,65 @@ MF_D void nerf_eval(const NetDev& net, const u32x4 (&xhi)[kKsNerfXyz], const u32
   for (int t = 0; t < 16; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) act[t][i] = 0;
-  const int D = net.L.n_trunk - 1;
+  const int D = net.D;
   for (int l = 0; l < D; ++l) {
     const bool last = sigma_only && l == D - 1;
-    trunk_layer<16, kKsNerfXyz>(net, l, act, xhi, xlo, st, carry, id, last ? follow : next_trunk_bf(net, l + 1));
+    trunk_layer<16, kKsNerfXyz>(net, l, true, act, xhi, xlo, st, carry, id, last ? follow : next_trunk_bf<16, kKsNerfXyz>(net, l + 1));
   }
+  // resident block: [bias_trunk (D+1) 256 | bias_extra 128 | sigma_w 256 | sigma_b 4 | rgb_w 384 | rgb_b 4]
+  const uint32_t r_sigma_w = net.res_lds + ((D + 1) * 256 + 128) * 4;
   float sg[1];
-  valu_head(act, net.res_lds + net.L.off_head_w * 4, net.res_lds + net.L.off_head_b * 4, id.h, sg);
+  valu_head(act, r_sigma_w, r_sigma_w + 256 * 4, id.h, sg);
   sigma = sg[0];
   if (sigma_only) return;
-  const Next ex{extra_groups(net.L), nullptr, extra_groups(net.L), nullptr};
-  trunk_layer<16, kKsNerfXyz>(net, D, act, xhi, xlo, st, carry, id, ex);          // xyz_encoding_final (no ReLU)
+  const int xg = 16 + 2 * net.aux;
+  const Next ex{xg, nullptr, xg, nullptr};
+  trunk_layer<16, kKsNerfXyz>(net, D, false, act, xhi, xlo, st, carry, id, ex);          // xyz_encoding_final (no ReLU)
   u32x4 e[8], ehi[kKsExtraMax], elo[kKsExtraMax];
   make_extra(ehi, elo);
-  if (net.L.extra_steps == 2) extra_layer<2>(net, act, ehi, elo, e, st, carry, id, follow);
-  else if (net.L.extra_steps == 1) extra_layer<1>(net, act, ehi, elo, e, st, carry, id, follow);
+  if (net.aux == 2) extra_layer<2>(net, act, ehi, elo, e, st, carry, id, follow);
+  else if (net.aux == 1) extra_layer<1>(net, act, ehi, elo, e, st, carry, id, follow);
   else extra_layer<0>(net, act, ehi, elo, e, st, carry, id, follow);
   float o[3];
-  valu_head(e, net.res_lds + net.L.off_rgb_w * 4, net.res_lds + net.L.off_rgb_b * 4, id.h, o);
+  valu_head(e, r_sigma_w + (256 + 4) * 4, r_sigma_w + (256 + 4 + 384) * 4, id.h, o);
 #pragma unroll
   for (int c = 0; c < 3; ++c) rgb[c] = 1.f / (1.f + expf(-o[c]));   // nn.Sigmoid, nerf.py:57-59
 }
 
 // Neural motion flow (W = 128) on this wave's 32 samples; xhi/xlo = split operands of [xyz block ; ind block].
-MF_D void nof_eval(const NetDev& net, const u32x4 (&xhi)[kKsNofIn], const u32x4 (&xlo)[kKsNofIn], const float (&xyz)[3],
+MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofIn], const u32x4 (&xlo)[kKsNofIn], const float (&xyz)[3],
                    Stream& st, Carry& carry, const Lane& id, const Next& follow, float (&out)[3]) {
   u32x4 act[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) act[t][i] = 0;
-  const int D = net.L.n_trunk;
-  // the head panel follows the last trunk layer contiguously; behind it comes `follow`'s first panel
-  const Next hd{head_groups(net.L), nullptr, follow.groups, follow.jump};
+  const int D = net.D;
+  // the head panel (16 groups) follows the last trunk layer contiguously; behind it comes `follow`'s first panel
+  const Next hd{16, nullptr, follow.groups, follow.jump};
   for (int l = 0; l < D; ++l)
-    trunk_layer<8, kKsNofIn>(net, l, act, xhi, xlo, st, carry, id, l == D - 1 ? hd : next_trunk_bf(net, l + 1));
+    trunk_layer<8, kKsNofIn>(net, l, true, act, xhi, xlo, st, carry, id, l == D - 1 ? hd : next_trunk_bf<8, kKsNofIn>(net, l + 1));
   // head on the matrix pipe (16 MFMAs instead of 9 x 64 dependent FMAs + 144 LDS reads per lane); T[0..3] come
   // out in half 0's registers 0-3, T[4..7] in half 1's registers 0-3, T[8] in half 0's register 4
   f32x16 acc;
   {
     const uint32_t p = st.slot_off(0) + id.lane * 16, pn = st.slot_off(1) + id.lane * 16;
     // panel two ahead of the head panel = the SECOND panel of whatever follows
-    auto hook = [&]() { st.sync_and_dma(follow.groups2, follow.jump2, id); };
+    auto hook = [&]() { st.sync(follow.groups2, follow.jump2, id); };
+    auto piece = [&](int k) { st.piece(k, id); };
 #ifndef MF_BF_ABL_NOSTAGGER
     const bool late = id.wave < kWaves / 2;
 #else
     const bool late = false;
 #endif
-    acc = head_tile<8>(carry, act, p, pn, net.res_lds + net.L.off_head_b * 4, id.h, late, hook);
+    // resident block: [bias_trunk D 128 | head_w n_head 128 | head_b 32]
+    acc = head_tile<8>(carry, act, p, pn, net.res_lds + (D + net.aux) * 128 * 4, id.h, late, hook, piece);
     st.advance();
   }
   float own[5], oth[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) { own[i] = acc[i]; oth[i] = __shfl_xor(acc[i], 32, 64); }
-  if (net.L.n_head == 9) {
+  if (net.aux == 9) {
     float T[9];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { T[i] = id.h ? oth[i] : own[i]; T[4 + i] = id.h ? own[i] : oth[i]; }

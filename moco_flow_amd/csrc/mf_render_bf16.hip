@@ -19,7 +19,7 @@ struct Params {
   const float* z_vals; const float* z_steps; int use_disp;
   const float* noise;
   int activation, flags;
-  NetDev nerf, bw, fw;
+  Net nerf, bw, fw;
   int extra_type;
   float emb_par[4][32];            // [nerf xyz, nerf extra, nof xyz, nof ind] x (freq[16], weight[16]) -> LDS
   float *rgb, *depth, *opacity, *weights, *alphas, *disp_local, *disp_global;
@@ -61,11 +61,9 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
                  par_nof_ind = p.par_off + 384;
   Stream st;
   Carry carry;
-  st.ring = p.ring_off;
-  st.buf_bytes = p.buf_bytes;
-  const Next prog_first = next_of(MOCO ? follow_of(p.bw) : follow_of(p.nerf));
-  if (MOCO) start_program(p.bw, st, carry, id);     // (its wait + barrier also publish the resident blocks / tables)
-  else start_program(p.nerf, st, carry, id);
+  const Next prog_first = MOCO ? first_of<8, kKsNofIn>(p.bw) : first_of<16, kKsNerfXyz>(p.nerf);
+  if (MOCO) start_program<8, kKsNofIn>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);   // (its wait + barrier also publish the resident blocks / tables)
+  else start_program<16, kKsNerfXyz>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
 
   const int S = p.S;
   const bool sigma_only = p.flags & MF_F_SIGMA_ONLY;
@@ -114,12 +112,12 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
           // role of this step: 0 = bw_i, 1 = local fw_i, 2 = fw_j, 3 = bw_j, 4 = final fw_i
           const int role = step;
           const bool use_fw = (role == 1 || role == 2 || role == 4);
-          const NetDev net = use_fw ? p.fw : p.bw;
+          const Net net = use_fw ? p.fw : p.bw;
           const float ind = (role == 2 || role == 3) ? ind_j : ind_i;
           if (role == 1 || role == 2) { cur[0] = canon[0]; cur[1] = canon[1]; cur[2] = canon[2]; }
           const bool last = step == nsteps - 1;
           const bool next_fw = (role + 1 == 1 || role + 1 == 2 || role + 1 == 4);
-          const Next follow = next_of(last ? follow_of(p.nerf) : (next_fw ? follow_of(p.fw) : follow_of(p.bw)));
+          const Next follow = last ? first_of<16, kKsNerfXyz>(p.nerf) : first_of<8, kKsNofIn>(next_fw ? p.fw : p.bw);
           u32x4 nhi[kKsNofIn], nlo[kKsNofIn];
           float out[3];
           nof_embed(nhi, nlo, cur, ind, par_nof_xyz, par_nof_ind, id.h);
@@ -239,13 +237,13 @@ int device_cus();   // mf_forward.hip
 int render_pass_bf16(const mf_render_args* a, hipStream_t st) {
   using namespace bf;
   Params p{};
-  if (!nerf_layout(*a->nerf, p.nerf.L, 1)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported NeRF configuration (bf16: W = 256)");
+  NetLayout Ln, Lb, Lf;
+  if (!nerf_layout(*a->nerf, Ln, 1)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported NeRF configuration (bf16: W = 256)");
   const bool moco = a->nof_bw != nullptr;
   const bool chains = a->flags & (MF_F_CHAIN_LOCAL | MF_F_CHAIN_GLOBAL);
   p.rays = a->rays; p.ray_stride = a->ray_stride; p.n_rays = a->n_rays; p.bg = a->background;
   p.S = a->n_samples; p.z_vals = a->z_vals; p.z_steps = a->z_steps; p.use_disp = a->use_disp;
   p.noise = a->noise; p.activation = a->activation; p.flags = a->flags;
-  p.nerf.packed = static_cast<const char*>(a->nerf_packed);
   p.extra_type = a->nerf->extra_feat_type;
   emb_table(a->emb_xyz, p.emb_par[0]);
   emb_table(a->emb_extra, p.emb_par[1]);
@@ -253,18 +251,27 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st) {
   p.disp_local = a->disp_local; p.disp_global = a->disp_global;
 
   uint32_t lds = 0;
-  p.nerf.res_lds = lds; lds += (uint32_t)p.nerf.L.res_bytes;
-  int max_groups = p.nerf.L.max_groups;
+  auto net_of = [&](const NetLayout& L, const void* packed, int D, int aux) {
+    Net n;
+    n.packed = static_cast<const char*>(packed);
+    n.res_lds = lds;
+    n.res_bytes = (uint32_t)L.res_bytes;
+    n.D = D;
+    n.emb_mask = L.emb_mask;
+    n.aux = aux;
+    lds += (uint32_t)L.res_bytes;
+    return n;
+  };
+  p.nerf = net_of(Ln, a->nerf_packed, Ln.n_trunk - 1, Ln.extra_steps);
+  int max_groups = Ln.max_groups;
   if (moco) {
-    if (!nof_layout(*a->nof_bw, p.bw.L, 1)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported backward NoF configuration");
-    p.bw.packed = static_cast<const char*>(a->nof_bw_packed);
-    p.bw.res_lds = lds; lds += (uint32_t)p.bw.L.res_bytes;
-    if (p.bw.L.max_groups > max_groups) max_groups = p.bw.L.max_groups;
+    if (!nof_layout(*a->nof_bw, Lb, 1)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported backward NoF configuration");
+    p.bw = net_of(Lb, a->nof_bw_packed, Lb.n_trunk, Lb.n_head);
+    if (Lb.max_groups > max_groups) max_groups = Lb.max_groups;
     if (chains) {
-      if (!nof_layout(*a->nof_fw, p.fw.L, 1)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported forward NoF configuration");
-      p.fw.packed = static_cast<const char*>(a->nof_fw_packed);
-      p.fw.res_lds = lds; lds += (uint32_t)p.fw.L.res_bytes;
-      if (p.fw.L.max_groups > max_groups) max_groups = p.fw.L.max_groups;
+      if (!nof_layout(*a->nof_fw, Lf, 1)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported forward NoF configuration");
+      p.fw = net_of(Lf, a->nof_fw_packed, Lf.n_trunk, Lf.n_head);
+      if (Lf.max_groups > max_groups) max_groups = Lf.max_groups;
     }
     emb_table(a->nof_emb_xyz, p.emb_par[2]);
     emb_table(a->nof_emb_ind, p.emb_par[3]);
