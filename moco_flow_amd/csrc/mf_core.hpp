@@ -619,14 +619,18 @@ MF_D void trunk_layer(const NetDev& net, int layer, typename ActT<BF16>::T (&act
 // weight rows in LDS (broadcast ds_read_b128), summed across the four lane groups.  Every lane
 // of a sample column ends up with the full sums.
 template <int NK, int NOUT>
-MF_D void valu_head(const f32x4 (&act)[NK], uint32_t w_byte_off, int row_floats, uint32_t b_byte_off, int g,
-                    float (&out)[NOUT]) {
+MF_D void valu_head(const f32x4 (&act)[NK], uint32_t w_byte_off, int /*row_floats == 16 NK at every call site*/,
+                    uint32_t b_byte_off, int g, float (&out)[NOUT]) {
+  // rows are 16 NK floats (compile time): every read is ONE per-lane base (w_byte_off + 16 g) plus an immediate; with a
+  // runtime row length hipcc hoisted one address register per (row, tile) to the kernel entry and spilled them
+  constexpr int row_floats = 16 * NK;
+  const uint32_t wl = w_byte_off + 16 * g;
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) {
     float s0 = 0.f, s1 = 0.f;
 #pragma unroll
     for (int t = 0; t < NK; ++t) {
-      const f32x4 w = lds_f4(w_byte_off + (o * row_floats + 16 * t + 4 * g) * 4);
+      const f32x4 w = lds_f4(wl + (o * row_floats + 16 * t) * 4);
       s0 = __builtin_fmaf(w[0], act[t][0], s0);
       s1 = __builtin_fmaf(w[1], act[t][1], s1);
       s0 = __builtin_fmaf(w[2], act[t][2], s0);
@@ -692,6 +696,51 @@ MF_D void emb_eval(float* dst, const float (&v)[C], const EmbParams& ep, int g) 
     const bool real = sel4(g, rl[0], rl[1], rl[2], rl[3]);
     float s = 0.f, c = 0.f;
     if (any_live) sincosf(fr * x, &s, &c);   // skipped when every frequency of this slot is muted
+    dst[2 * pi] = real ? w * s : sel4(g, r0[0], r0[1], r0[2], r0[3]);
+    dst[2 * pi + 1] = real ? w * c : sel4(g, r1[0], r1[1], r1[2], r1[3]);
+  }
+}
+
+// The same with the embedding's parameters in LDS (par_off: freq[16] then weight[16], floats) instead of the kernarg:
+// four EmbParams are 128 scalars, which the fused pass cannot afford in SGPRs (they were spilled to VGPR lanes).
+template <int C, int F>
+MF_D void emb_eval_lds(float* dst, const float (&v)[C], uint32_t par_off, int g) {
+  using B = EmbBlock<C, F>;
+#pragma unroll
+  for (int pi = 0; pi < B::NPI; ++pi) {
+    float xs[4], r0[4], r1[4];
+    int fs[4];
+    bool rl[4];
+    bool any_real = false;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int p = 4 * pi + k;
+      const bool real = p < B::NPAIR;
+      const int f = real ? p / C : 0, c = real ? p % C : 0;
+      rl[k] = real;
+      any_real |= real;
+      xs[k] = v[c];
+      fs[k] = f;
+      const int raw = real ? 0 : 2 * (p - B::NPAIR);
+      r0[k] = (!real && raw < C) ? v[raw < C ? raw : 0] : 0.f;
+      r1[k] = (!real && raw + 1 < C) ? v[raw + 1 < C ? raw + 1 : 0] : 0.f;
+    }
+    if (!any_real) {                                     // (compile time) raw components only
+      dst[2 * pi] = sel4(g, r0[0], r0[1], r0[2], r0[3]);
+      dst[2 * pi + 1] = sel4(g, r1[0], r1[1], r1[2], r1[3]);
+      continue;
+    }
+    const float x = sel4(g, xs[0], xs[1], xs[2], xs[3]);
+    const int f = sel4(g, fs[0], fs[1], fs[2], fs[3]);
+    const bool real = sel4(g, rl[0], rl[1], rl[2], rl[3]);
+    const float fr = lds_f(par_off + 4 * f);
+    const float w = real ? lds_f(par_off + 64 + 4 * f) : 0.f;
+    bool live = false;                                   // wave-uniform: any of the four groups' frequencies un-muted
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      if (rl[k]) live |= lds_f(par_off + 64 + 4 * fs[k]) != 0.f;
+    float s = 0.f, c = 0.f;
+    if (__builtin_amdgcn_readfirstlane((int)live)) sincosf(fr * x, &s, &c);
     dst[2 * pi] = real ? w * s : sel4(g, r0[0], r0[1], r0[2], r0[3]);
     dst[2 * pi + 1] = real ? w * c : sel4(g, r1[0], r1[1], r1[2], r1[3]);
   }

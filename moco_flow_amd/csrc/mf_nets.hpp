@@ -238,4 +238,12 @@ MF_D void nof_embed(float (&emb)[kStepsNofIn], const float (&xyz)[3], float ind,
   for (int e = BlkXyz5::SLOTS + BlkInd16::SLOTS; e < kStepsNofIn; ++e) emb[e] = 0.f;
 }
 
+MF_D void nof_embed_lds(float (&emb)[kStepsNofIn], const float (&xyz)[3], float ind, uint32_t par_xyz, uint32_t par_ind, int g) {
+  emb_eval_lds<3, 5>(emb, xyz, par_xyz, g);
+  const float iv[1] = {ind};
+  emb_eval_lds<1, 16>(emb + BlkXyz5::SLOTS, iv, par_ind, g);
+#pragma unroll
+  for (int e = BlkXyz5::SLOTS + BlkInd16::SLOTS; e < kStepsNofIn; ++e) emb[e] = 0.f;
+}
+
 }  // namespace mf

@@ -15,6 +15,7 @@
 // k-quarters of every MFMA step -- and keeps each sample's (r,g,b,sigma,z) in LDS until the
 // group's rays are composited by one wave per ray with a wavefront product-scan.  Workgroups
 // are persistent (grid = #CUs) so the weight stream never drains between tiles.
+#include <cstddef>
 #include <cstdlib>
 
 #include "mf_host.hpp"
@@ -31,10 +32,10 @@ struct RenderParams {
   const float* noise;
   int activation, flags;
   NetDev nerf;
-  EmbParams exyz, eext;
   int extra_type;
   NetDev bw, fw;
-  EmbParams nxyz, nind;
+  float emb_par[4][32];            // [nerf xyz, nerf extra, nof xyz, nof ind] x (freq[16], weight[16]) -> LDS at par_off
+  uint32_t par_off;
   float *rgb, *depth, *opacity, *weights, *alphas, *disp_local, *disp_global;
   int G;
   long long n_groups;
@@ -67,6 +68,15 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
     load_resident(p.bw, id);
     if (p.flags & (MF_F_CHAIN_LOCAL | MF_F_CHAIN_GLOBAL)) load_resident(p.fw, id);
   }
+  if (threadIdx.x < 128) {
+    // embedding tables kernarg -> LDS through the kernarg segment pointer (a runtime index into the by-value struct
+    // would make hipcc keep a scratch copy of all of `p`); published by start_program's barrier
+    typedef const __attribute__((address_space(4))) char* kptr;
+    const kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(RenderParams, emb_par);
+    *(float*)(smem + p.par_off + threadIdx.x * 4) = ((const __attribute__((address_space(4))) float*)ka)[threadIdx.x];
+  }
+  const uint32_t par_nerf_xyz = p.par_off, par_nerf_ext = p.par_off + 128, par_nof_xyz = p.par_off + 256,
+                 par_nof_ind = p.par_off + 384;
   Stream st;
   CarryT<Pipe<BF16>::PD> carry;
   st.ring = p.ring_off;
@@ -134,7 +144,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
           const bool next_fw = (role + 1 == 1 || role + 1 == 2 || role + 1 == 4);
           const NextLayer follow = last ? follow_of(nerf) : (next_fw ? follow_of(p.fw) : follow_of(p.bw));
           float emb[kStepsNofIn], out[3];
-          nof_embed(emb, cur, ind, p.nxyz, p.nind, id.g);
+          nof_embed_lds(emb, cur, ind, par_nof_xyz, par_nof_ind, id.g);
           nof_eval<BF16>(net, emb, cur, st, carry, id, follow, out);
           if (role == 0) { canon[0] = out[0]; canon[1] = out[1]; canon[2] = out[2]; }
           if (role == 1) dl = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
@@ -149,7 +159,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
       }
 
       float embx[kStepsNerfXyz], ext[kStepsExtraMax];
-      if (!(MF_TIMING_FLAGS && (p.dbg & 4))) emb_eval<3, 10>(embx, xin, p.exyz, id.g);
+      if (!(MF_TIMING_FLAGS && (p.dbg & 4))) emb_eval_lds<3, 10>(embx, xin, par_nerf_xyz, id.g);
       else { for (int e = 0; e < kStepsNerfXyz; ++e) embx[e] = xin[e % 3]; }
 #pragma unroll
       for (int e = BlkXyz10::SLOTS; e < kStepsNerfXyz; ++e) embx[e] = 0.f;
@@ -157,10 +167,10 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
       for (int e = 0; e < kStepsExtraMax; ++e) ext[e] = 0.f;
       if (!sigma_only) {
         if (p.extra_type == MF_EXTRA_DIR) {
-          emb_eval<3, 4>(ext, d, p.eext, id.g);                                // rendering.py:138-142
+          emb_eval_lds<3, 4>(ext, d, par_nerf_ext, id.g);                                // rendering.py:138-142
         } else if (p.extra_type == MF_EXTRA_IND) {
           const float iv[1] = {rp[8]};
-          emb_eval<1, 2>(ext, iv, p.eext, id.g);                               // rendering.py:133-137
+          emb_eval_lds<1, 2>(ext, iv, par_nerf_ext, id.g);                               // rendering.py:133-137
         }
       }
       float sigma, rgb[3] = {0.f, 0.f, 0.f};
@@ -241,10 +251,10 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
   wait_vm0();   // the stream runs two panels ahead: drain the LDS-DMA before the workgroup retires
 }
 
-static void to_params(const mf_embedding& e, EmbParams& o) {
+static void to_table(const mf_embedding& e, float* o) {
   for (int k = 0; k < 16; ++k) {
-    o.freq[k] = k < e.n_freqs ? e.freq[k] : 0.f;
-    o.weight[k] = k < e.n_freqs ? e.weight[k] : 0.f;
+    o[k] = k < e.n_freqs ? e.freq[k] : 0.f;
+    o[16 + k] = k < e.n_freqs ? e.weight[k] : 0.f;
   }
 }
 
@@ -295,8 +305,8 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
   p.S = a->n_samples; p.z_vals = a->z_vals; p.z_steps = a->z_steps; p.use_disp = a->use_disp;
   p.noise = a->noise; p.activation = a->activation; p.flags = a->flags;
   p.nerf.packed = static_cast<const char*>(a->nerf_packed);
-  to_params(a->emb_xyz, p.exyz);
-  to_params(a->emb_extra, p.eext);
+  to_table(a->emb_xyz, p.emb_par[0]);
+  to_table(a->emb_extra, p.emb_par[1]);
   p.extra_type = a->nerf->extra_feat_type;
   p.rgb = a->rgb; p.depth = a->depth; p.opacity = a->opacity; p.weights = a->weights; p.alphas = a->alphas;
   p.disp_local = a->disp_local; p.disp_global = a->disp_global;
@@ -321,10 +331,11 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
     if (a->nof_emb_xyz.in_channels != 3 || a->nof_emb_xyz.n_freqs > 5 || a->nof_emb_ind.in_channels != 1 ||
         a->nof_emb_ind.n_freqs != 16)
       return fail(MF_E_UNSUPPORTED, "mf_render_pass: NoF embeddings must be xyz(3, <=5 freqs) and ind(1, 16 freqs)");
-    to_params(a->nof_emb_xyz, p.nxyz);
-    to_params(a->nof_emb_ind, p.nind);
+    to_table(a->nof_emb_xyz, p.emb_par[2]);
+    to_table(a->nof_emb_ind, p.emb_par[3]);
   }
   if (bf16) return render_pass_bf16(a, static_cast<hipStream_t>(stream));     // validated above; own layout / launch
+  p.par_off = lds; lds += 512;
   p.ring_off = lds;
   p.buf_bytes = (uint32_t)max_groups * kGroupBytes;
   lds += 3 * p.buf_bytes;

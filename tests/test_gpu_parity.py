@@ -541,7 +541,9 @@ def test_c5_shard_shape_vs_oracle(M, R, precision):
         assert _l2rel(res[k], want[k]) <= C5_BF16_BARS[2], k
 
 
-C5_BF16_BARS = (33.0, 6e-2, 1.2e-1)      # provisional (first measurement pending): PSNR rgb, l2 rgb, l2 depth/opacity
+# measured r2 (golden-case draw): rgb_coarse 40.2 dB / 2.4e-2, rgb_fine 53.0 dB / 3.2e-3, depth_coarse 3.9e-2,
+# opacity_coarse 2.1e-2, depth_fine 9.0e-4
+C5_BF16_BARS = (38.0, 3.2e-2, 5.5e-2)     # PSNR rgb, l2 rgb, l2 depth / opacity
 
 
 def test_c4_shards_moco_bf16_bit_identical(M):
