@@ -318,7 +318,17 @@ def _oracle_grads(R, c, seed, rays, bg, loss_fn):
     return res, {f"{i}.{k}": g for (i, k), g in zip(flat, grads)}
 
 
-@pytest.mark.parametrize("name", ["r_nerf_dir_dense", "r_moco_global", "r_nerf_ind_dense"])
+# end-to-end gradient bars (max-rel per parameter tensor).  NeRF-only passes are well conditioned: measured 1e-6 .. 2e-6.
+# r_moco_global (dense regime behind two NoFs) is not: the gradient runs through sin(512 x) of a canonical point, and
+# the ORACLE's own fp32 and fp64 autograd differ by 30-120 % on the NeRF / backward-NoF tensors of this very case
+# (measured in the build container, seed of the fixture) -- its 5e-2 (measured 2e-2 vs the fp32 oracle) is already far
+# inside the reference's own noise.  What pins the HIP backward is test_*_backward_vs_oracle* (same function at the same
+# points: 2e-6).  The default-init MoCo case is smoother but still carries the 512 x phase: oracle fp32 vs fp64 differ
+# by up to 5.9e-3 there; HIP vs the fp32 oracle measures 1.3e-3.
+GRAD_BARS = {"r_nerf_dir_dense": 1e-4, "r_nerf_ind_dense": 1e-4, "r_moco_global": 5e-2, "r_moco_global_default": 3e-3}
+
+
+@pytest.mark.parametrize("name", sorted(GRAD_BARS))
 def test_gradients_vs_oracle(M, R, name):
     """Training contract (moco_flow_amd/autograd.py): forward values from the HIP kernels, gradients from
     the HIP backward nodes (composite, NeRF dX chain + weight gradients, NoF evaluations); against the CPU oracle's autograd
@@ -345,7 +355,7 @@ def test_gradients_vs_oracle(M, R, name):
     res = M.render_rays(rays.cuda(), bg.cuda(), embs, nerfs, **kw)
     assert res["rgb_coarse"].requires_grad
     loss_fn(res).backward()
-    checked = 0
+    checked, worst = 0, (0.0, "")
     for i, m in enumerate(nets):
         for k, p in m.named_parameters():
             w = want[f"{i}.{k}"]
@@ -356,15 +366,11 @@ def test_gradients_vs_oracle(M, R, name):
                 assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
                 continue
             assert p.grad is not None, k
-            # fp32 gradients of an 8-layer He-regime net: GEMM summation order (rocBLAS vs MKL) alone
-            # moves them by ~1e-3 of the largest entry
-            # Under NoF the NeRF is differentiated at the kernel's canonical points, which differ from
-            # the oracle's by ~1e-6; in the dense regime a few samples sit on a ReLU kink (sigma ~ 0) and
-            # flip, which moves a summed gradient by ~1 %. The explicit backward itself is pinned to 1e-4
-            # on identical points in test_explicit_nerf_backward_unit.
-            tol = 5e-2 if c.get("nof", "none") != "none" else 5e-3
+            tol = GRAD_BARS[name]
+            worst = max(worst, (relerr(p.grad, w), f"{i}.{k}"))
             assert relerr(p.grad, w) <= tol, (k, relerr(p.grad, w))
             checked += 1
+    print(f"{name}: end-to-end gradients vs oracle autograd, worst max-rel {worst[0]:.2e} at {worst[1]}")
     assert checked >= 10
 
 
@@ -739,6 +745,128 @@ def test_train_forward_torch_mode_matches_hip_mode(M):
             assert relerr(a[k], b[k]) <= (2e-3 if "fine" in k else TOL), k     # fine: resample conditioning
     for x, y in zip(ga, gb):
         assert relerr(x, y) <= 5e-2           # kink flips at points 1e-6 apart, see test_gradients_vs_oracle
+
+
+def _oracle_param_grads(model, out, gout, extra_inputs=()):
+    """d <out, gout> / d (every parameter of the oracle model, extra inputs) by CPU autograd."""
+    names = list(model.p)
+    wrt = [model.p[k] for k in names] + list(extra_inputs)
+    got = torch.autograd.grad(out, wrt, gout, allow_unused=True)
+    return dict(zip(names, got[:len(names)])), got[len(names):]
+
+
+def _with_grad(model):
+    for k in model.p:
+        model.p[k] = model.p[k].clone().requires_grad_(True)
+    return model
+
+
+def test_nerf_backward_vs_oracle_on_dumped_points(M, R):
+    """the HIP backward of the NeRF (mf_nerf_backward + mf_weight_grads over the kernel's own
+    activation dump) against the ORACLE's CPU autograd -- not the product's torch restatement -- evaluated on the
+    points the kernel dumped (so the two sides differentiate the same function at the same place): every
+    parameter gradient and the input-point gradient to 1e-4 max-rel."""
+    from moco_flow_amd import autograd as A, rendering
+    torch.manual_seed(0)
+    c = dict(RENDER_CASES["r_nerf_ind_dense"])
+    seed, n_rays, S = 21, 40, 64
+    embs, nerfs, kw = build_case(M, c, seed, device="cuda")
+    embs_o, nerfs_o, _ = build_case(R, c, seed)
+    nerf, onerf = nerfs[0], _with_grad(nerfs_o[0])
+    rays, bg = case_inputs(c, seed, n=n_rays)
+    rays_g = rays.cuda()
+    t = torch.linspace(0, 1, S, device="cuda")
+    z = (rays_g[:, 6:7] * (1 - t) + rays_g[:, 7:8] * t).contiguous()
+    with torch.no_grad():
+        p = rendering._render_pass(rays_g, bg.cuda(), z, None, False, None, 0, nerf, embs, None, None, False, False,
+                                   False, True, dump=True)
+    xin = p["xyz_in"].clone().requires_grad_(True)
+    ind = rays_g[:, 8:9]
+    with torch.no_grad():
+        emb_in = A._pad_to(A.embed(embs[0], p["xyz_in"]), 63)
+        extra_in = A._pad_to(torch.repeat_interleave(A.embed(embs[1], ind), S, dim=0), 5)
+    gout = torch.randn(n_rays * S, 4, device="cuda")
+    out = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, embs[0], xin, *nerf.parameters())
+    out.backward(gout)
+    # oracle, CPU, on the kernel's dumped points
+    x_o = p["xyz_in"].cpu().clone().requires_grad_(True)
+    e_ind = torch.repeat_interleave(embs_o[1](rays[:, 8:9]), S, dim=0)
+    inp = torch.cat([R._embed_padded(embs_o[0], x_o, 63), e_ind], -1)
+    ref = onerf(inp)
+    assert relerr(out, ref) <= 1e-5                                  # same function, same place
+    want, (want_x,) = _oracle_param_grads(onerf, ref, gout.cpu(), (x_o,))
+    worst = 0.0
+    for name, q in nerf.named_parameters():
+        e = relerr(q.grad, want[name])
+        worst = max(worst, e)
+        assert e <= 1e-4, (name, e)
+    ex = relerr(xin.grad, want_x)
+    print(f"NeRF backward vs oracle autograd on dumped points: worst parameter max-rel {worst:.2e}, d/d point {ex:.2e}")
+    assert ex <= 1e-4
+
+
+@pytest.mark.parametrize("quat", [True, False])
+def test_nof_backward_vs_oracle(M, R, quat):
+    """One NoF evaluation on points (rendering.py:49-83 + nof.py:69-82): HIP forward-with-dump / backward node
+    (autograd.NofPoints) against the oracle's CPU autograd of nof_inference on the same points: output, every
+    parameter gradient and d/d point to 1e-4 (quaternion head: kornia restated, like the forward)."""
+    from moco_flow_amd import autograd as A
+    torch.manual_seed(1)
+    c = dict(RENDER_CASES["r_moco_global" if quat else "r_moco_global_flowhead"])
+    seed, N, S = 5, 24, 40
+    _, _, kw = build_case(M, c, seed, device="cuda")
+    _, _, kw_o = build_case(R, c, seed)
+    nof, onof = kw["nof_models"][1], _with_grad(kw_o["nof_models"][1])
+    pts = (torch.randn(N, S, 3) * 0.7)
+    ind = torch.rand(N, 1) * 2 - 1
+    pts_g = pts.cuda().requires_grad_(True)
+    out = A.nof_points(pts_g, ind.cuda(), kw["nof_embeddings"], nof)
+    gout = torch.randn(N, S, 3)
+    out.backward(gout.cuda())
+    pts_o = pts.clone().requires_grad_(True)
+    ref = R.nof_inference(pts_o, ind, kw_o["nof_embeddings"], onof)
+    assert relerr(out, ref) <= 1e-5
+    want, (want_x,) = _oracle_param_grads(onof, ref, gout, (pts_o,))
+    worst = 0.0
+    for name, q in nof.named_parameters():
+        e = relerr(q.grad, want[name])
+        worst = max(worst, e)
+        assert e <= 1e-4, (name, e)
+    ex = relerr(pts_g.grad, want_x)
+    print(f"NoF(quat={quat}) backward vs oracle autograd: worst parameter max-rel {worst:.2e}, d/d point {ex:.2e}")
+    assert ex <= 1e-4
+
+
+@pytest.mark.parametrize("act,use_noise,use_bg", [("relu", False, True), ("softplus", True, True), ("relu", True, False)])
+def test_composite_backward_vs_oracle(M, R, act, use_noise, use_bg):
+    """mf_composite_backward (rendering.py:157-192 differentiated by hand) against the oracle's CPU autograd of
+    its own composite() on the same per-sample planes: d/d(rgb, sigma) per sample to 1e-4."""
+    from moco_flow_amd import autograd as A
+    torch.manual_seed(2)
+    N, S = 33, 64
+    c = dict(RENDER_CASES["r_nerf_dir_dense"])
+    rays, bg = case_inputs(c, 3, n=N)
+    t = torch.linspace(0, 1, S)
+    z = (rays[:, 6:7] * (1 - t) + rays[:, 7:8] * t).contiguous()
+    rgbsig = torch.cat([torch.rand(N * S, 3), torch.randn(N * S, 1) * 2.0], -1)
+    noise = torch.randn(N, S) * 0.5 if use_noise else None
+    background = bg if use_bg else None
+    x = rgbsig.cuda().requires_grad_(True)
+    with torch.no_grad():
+        ref0 = R.composite(rgbsig[:, 3].view(N, S), rgbsig[:, :3].view(N, S, 3), z, rays[:, 3:6],
+                           noise if use_noise else torch.zeros(N, S), act, background)
+    vals = [v.cuda() for v in (ref0[0], ref0[1], ref0[2].sum(1))]
+    rgb, depth, opac = A.CompositeSamples.apply(x, rays.cuda(), z.cuda(), noise.cuda() if use_noise else None, act,
+                                                background.cuda() if use_bg else None, *vals)
+    g = [torch.randn(N, 3), torch.randn(N), torch.randn(N)]
+    torch.autograd.backward([rgb, depth, opac], [t_.cuda() for t_ in g])
+    xo = rgbsig.clone().requires_grad_(True)
+    r_rgb, r_depth, r_w, _ = R.composite(xo[:, 3].view(N, S), xo[:, :3].view(N, S, 3), z, rays[:, 3:6],
+                                         noise if use_noise else torch.zeros(N, S), act, background)
+    (want,) = torch.autograd.grad([r_rgb, r_depth, r_w.sum(1)], [xo], g)
+    e = relerr(x.grad, want)
+    print(f"composite backward ({act}, noise={use_noise}, bg={use_bg}) vs oracle autograd: max-rel {e:.2e}")
+    assert e <= 1e-4
 
 
 @pytest.mark.parametrize("kind,n_rays", [("hip", 40), ("hip", 37), ("hip", 1), ("gemm", 40)])
