@@ -28,8 +28,8 @@ extern "C" {
 
 /* 3: activation dump of the training forward; 4: mf_nerf_backward, mf_weight_grads; 5: NoF backward
  * (mf_nof_points_dump, mf_nof_backward); 6: mf_composite_backward, mf_image_compose;
- * 7: mf_nof_forward_dump */
-#define MF_ABI_VERSION 7
+ * 7: mf_nof_forward_dump; 8: mf_loss_partials, new packed layout of MF_PREC_BF16 (32x32x16 fragments) */
+#define MF_ABI_VERSION 8
 
 enum {
   MF_OK = 0,
@@ -42,9 +42,9 @@ enum { MF_MAX_FREQS = 16, MF_MAX_LAYERS = 16 };
 
 /* Arithmetic of the W-wide ("hidden") GEMMs of the fused pass.  F32: exact-fp32 MFMA everywhere
  * (the reference's arithmetic; BASELINE configs C1-C2).  BF16: hidden-layer weights and
- * activations rounded to bf16 (RNE), fp32 accumulate (v_mfma_f32_16x16x32_bf16); the embedded-
- * input k-ranges use a two-term bf16 split of inputs and weights (16 mantissa bits, three products);
- * biases, heads and the composite stay fp32 (BASELINE configs C3-C5). */
+ * activations rounded to bf16 (RNE), fp32 accumulate (v_mfma_f32_32x32x16_bf16, 32 samples per wave); the
+ * embedded-input k-ranges and the NoF head use a two-term bf16 split (16 mantissa bits); biases, the NeRF
+ * heads and the composite stay fp32 (BASELINE configs C3-C5). */
 enum { MF_PREC_F32 = 0, MF_PREC_BF16 = 1 };
 
 /* ---- Embedding: models/embedding.py:4-47 ------------------------------------
@@ -284,6 +284,27 @@ int64_t mf_compact_scratch_bytes(int64_t n_rays);
 int32_t mf_compact_mask(const float* alphas, const float* vals_a, const float* vals_b,
                         int64_t n_rays, int32_t S, float* out_a, float* out_b,
                         int64_t* count, void* scratch, void* stream);
+
+/* ---- fused loss partials (second half): the additive pieces of MSELoss over both passes
+ * (models/losses.py:4-14) and of the consensus means over mask = alphas >= 0.01, all-true if none
+ * (models/rendering.py:306-314, trainer/trainer_moco_flow.py:317-328), from the arrays a render pass already wrote:
+ * no mask compaction, no data-dependent length, no host sync.  out12 (device, 12 doubles) = one (sum, count) pair
+ * per term the reference averages separately:
+ *   [0:4]  sum (rgb_coarse - target)^2, 3N | sum (rgb_fine - target)^2, 3N
+ *   [4:8]  sum_masked disp_local_coarse, n_masked | ... fine        (disp_* = mf_render_args.disp_local/global planes)
+ *   [8:12] sum_masked disp_global_coarse, n_masked | ... fine
+ * A NULL array (or a NULL `fine`) leaves its pair at (0, 0).  loss terms = sum / count; the multi-GPU caller
+ * all-reduces the 96 bytes first.  Deterministic (fixed-order partial sums through `scratch`). */
+typedef struct mf_loss_pass {
+  const float* rgb;          /* (N,3) rendered colour of the pass, or NULL            */
+  const float* alphas;       /* (N,S) of the pass: the consensus mask source, or NULL */
+  const float* disp_local;   /* (N,S) or NULL                                         */
+  const float* disp_global;  /* (N,S) or NULL                                         */
+  int32_t n_samples;         /* S of the pass                                         */
+} mf_loss_pass;
+int64_t mf_loss_partials_scratch_bytes(void);
+int32_t mf_loss_partials(const mf_loss_pass* coarse, const mf_loss_pass* fine, const float* target, int64_t n_rays,
+                         double* out12, void* scratch, void* stream);
 
 /* ---- producers either side of the path -----------------------------
  * Camera.make_rays (utils/camera.py:134-148 with gen_ray_directions :29-50 and gen_rays :52-81):

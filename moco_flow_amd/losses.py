@@ -28,3 +28,17 @@ class MSELoss(nn.Module):
         for t in terms[1:]:
             total = total + t
         return total
+
+
+def from_partials(partials: torch.Tensor):
+    """The reference's loss terms from the 12 (sum, count) partials of ``render_rays(..., _loss_target=gt)``
+    (mf_loss_partials; layout of dist.loss_partials), as differentiable device scalars with no host sync:
+    ``img_loss`` = MSE coarse + fine (models/losses.py:4-14), ``nof_local`` / ``nof_global`` = mean over the
+    masked points, coarse + fine (trainer_moco_flow.py:317-328).  A term whose count is 0 (pass / chain absent) is 0."""
+    p = partials
+    one = torch.ones((), dtype=p.dtype, device=p.device)
+
+    def mean(i):
+        return p[i] / torch.where(p[i + 1] > 0, p[i + 1], one)
+
+    return {"img_loss": mean(0) + mean(2), "nof_local": mean(4) + mean(6), "nof_global": mean(8) + mean(10)}

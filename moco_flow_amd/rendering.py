@@ -123,6 +123,33 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
     return out
 
 
+def _loss_partials_hip(c, f, target, N):
+    """mf_loss_partials over the arrays the passes wrote: 12 float64 on the device, no host sync."""
+    dev = target.device
+    lib = L.lib()
+    tgt = target.detach().contiguous().float()
+    if tgt.shape != (N, 3):
+        raise RuntimeError(f"_loss_target must be (N, 3) = ({N}, 3), got {tuple(tgt.shape)}")
+
+    def desc(p):
+        d = L.mf_loss_pass()
+        d.rgb = L.ptr(p.get("rgb"))
+        planes = p.get("disp_local") is not None or p.get("disp_global") is not None
+        d.alphas = L.ptr(p.get("alphas")) if planes else None
+        d.disp_local, d.disp_global = L.ptr(p.get("disp_local")), L.ptr(p.get("disp_global"))
+        d.n_samples = p["alphas"].shape[1] if planes else 0
+        return d
+
+    dc = desc(c)
+    df = desc(f) if f is not None else None
+    out = torch.empty(12, dtype=torch.float64, device=dev)
+    scratch = torch.empty(int(lib.mf_loss_partials_scratch_bytes()), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        L.check(lib.mf_loss_partials(C.byref(dc), C.byref(df) if df is not None else None, tgt.data_ptr(), N,
+                                     out.data_ptr(), scratch.data_ptr(), L.current_stream(dev)), "mf_loss_partials")
+    return out
+
+
 def _compact(alphas, vals_a, vals_b):
     """rendering.py:306-314: (vals[mask] for mask = alphas >= 0.01, all-true if empty)."""
     dev = alphas.device
@@ -213,13 +240,21 @@ def render_rays(rays,
                 test_time=False,
                 _capture=None,
                 _rng=None,
+                _loss_target=None,
                 ):
     """Same contract as the reference's render_rays (rendering.py:195-375): rays (N, 9|10),
     background (N,3)|None -> dict with rgb/depth/opacity_{coarse,fine} and, in training with NoF,
     nof_{local,global}_disp_{coarse,fine}. ``_capture`` (dict, test hook) receives the per-pass
     (N,S) planes the kernels produced (z, weights, alphas) without changing the result; ``_rng`` (dict,
     test hook) supplies the random draws instead of torch.rand / randn: perturb_rand (N,S),
-    noise_coarse (N,S), noise_fine (N,S+M) (already scaled by noise_std), u (N,M)."""
+    noise_coarse (N,S), noise_fine (N,S+M) (already scaled by noise_std), u (N,M).
+
+    ``_loss_target`` (N,3), the fast path of the mean-only caller (trainer_moco_flow.py:317-328 takes
+    ``torch.mean`` of each consensus vector right away): the data-dependent-length ``nof_*_disp_*`` vectors are NOT
+    built (no mask compaction, no host sync); instead the result carries ``loss_partials``, 12 float64 on the device
+    = (sum, count) of MSE coarse / fine, nof_local coarse / fine, nof_global coarse / fine (dist.loss_partials
+    layout; mf_loss_partials), differentiable in training.  ``dist.reduce_loss`` / ``losses.from_partials`` turn
+    them into the reference's loss terms."""
     _rng = _rng or {}
     L.require_gpu(rays, "render_rays")
     if nerf_activate_type == 'relu':
@@ -290,7 +325,8 @@ def render_rays(rays,
         result = {'opacity_coarse': c["opacity"]}
     else:
         result = {'rgb_coarse': c["rgb"], 'depth_coarse': c["depth"], 'opacity_coarse': c["opacity"]}
-    if loc or glob:
+    fused_loss = _loss_target is not None
+    if (loc or glob) and not fused_loss:
         la, ga = _compact(c["alphas"], c.get("disp_local"), c.get("disp_global"))
         if loc:
             result['nof_local_disp_coarse'] = la
@@ -311,16 +347,19 @@ def render_rays(rays,
         result['rgb_fine'] = f["rgb"]
         result['depth_fine'] = f["depth"]
         result['opacity_fine'] = f["opacity"]
-        if loc or glob:
+        if (loc or glob) and not fused_loss:
             la, ga = _compact(f["alphas"], f.get("disp_local"), f.get("disp_global"))
             if loc:
                 result['nof_local_disp_fine'] = la
             if glob:
                 result['nof_global_disp_fine'] = ga
+    if fused_loss and not (grad and N > 0):
+        result['loss_partials'] = _loss_partials_hip(c, f if need_fine else None, _loss_target, N)
     if grad and N > 0 and "acts" in c and (not need_fine or "acts" in f):
         result = _attach_explicit(result, rays, background, nerf_embeddings, nerf_models, nof_embeddings,
                                   nof_models if use_nof else None, loc, glob, nerf_activate_type,
-                                  (c, z_vals, noise_c), (f, z_all, noise_f) if need_fine else None)
+                                  (c, z_vals, noise_c), (f, z_all, noise_f) if need_fine else None,
+                                  loss_target=_loss_target)
     elif grad and N > 0:
         result = _attach_backward(result, rays, background, all_models, nerf_embeddings, nerf_models,
                                   nof_embeddings, nof_models if use_nof else None, loc, glob, nerf_activate_type,
@@ -360,7 +399,7 @@ def _torch_training_render(rays, background, nerf_embs, nerf_models, nof_embs, n
 
 
 def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs, nof_models, loc, glob,
-                     activation, coarse, fine):
+                     activation, coarse, fine, loss_target=None):
     """Training graph on top of the fused forward (TRAIN_FORWARD == "hip", fp32): values are the HIP
     kernels' outputs; gradients flow through
       * autograd.CompositeSamples -- mf_composite_backward on the dumped per-sample (rgb, sigma) planes,
@@ -369,13 +408,15 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
       * autograd.NofPoints -- one HIP forward-with-dump / backward node per NoF evaluation of the chains.
     Each returned tensor is  hip_value + (torch_value - torch_value.detach())."""
     rays_o, rays_d, ind = rays[:, 0:3], rays[:, 3:6], rays[:, 8:9]
-    out = {}
+    out, cons = {}, {}
 
     def one(tag, nerf, pack):
         p, z, noise = pack
         N, S = z.shape
         xyz = rays_o.unsqueeze(1) + rays_d.unsqueeze(1) * z.unsqueeze(2)
-        mask = _mask_of(p["alphas"]) if (loc or glob) else None
+        mask = None
+        if loc or glob:
+            mask = _mask_of(p["alphas"]) if loss_target is None else _mask_nosync(p["alphas"])
         xin = p["xyz_in"]
         if nof_models is not None:
             bw = nof_models[0]
@@ -383,12 +424,19 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
             if loc:
                 fw = nof_models[1]
                 recon = A.nof_points(canon, ind, nof_embs, fw)
-                out[f"nof_local_disp_{tag}"] = torch.mean(torch.abs(xyz - recon)[mask], dim=1)
+                if loss_target is None:
+                    out[f"nof_local_disp_{tag}"] = torch.mean(torch.abs(xyz - recon)[mask], dim=1)
+                else:
+                    cons[f"local_{tag}"] = _masked_sum(torch.abs(xyz - recon), mask)
             if glob:
                 cind = rays[:, 9:10]
                 a_ = A.nof_points(canon, cind, nof_embs, fw)
                 b_ = A.nof_points(a_, cind, nof_embs, bw)
-                out[f"nof_global_disp_{tag}"] = torch.mean(torch.abs(xyz - A.nof_points(b_, ind, nof_embs, fw))[mask], dim=1)
+                gd = torch.abs(xyz - A.nof_points(b_, ind, nof_embs, fw))
+                if loss_target is None:
+                    out[f"nof_global_disp_{tag}"] = torch.mean(gd[mask], dim=1)
+                else:
+                    cons[f"global_{tag}"] = _masked_sum(gd, mask)
             xin = canon.reshape(-1, 3)
         with torch.no_grad():
             emb_in = A._pad_to(A.embed(nerf_embs[0], p["xyz_in"]), nerf.in_channels_xyz)
@@ -414,7 +462,34 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
     for k, v in result.items():
         t = out[k]
         final[k] = v.detach() + (t - t.detach())
+    if loss_target is not None:
+        # differentiable (sum, count) pairs in the layout of dist.loss_partials / mf_loss_partials
+        tgt = loss_target.detach().float()
+        zero = torch.zeros((), dtype=torch.float64, device=tgt.device)
+        parts = []
+        for tag in ("coarse", "fine"):
+            if f"rgb_{tag}" in final:
+                d = (final[f"rgb_{tag}"] - tgt).double()
+                parts += [(d * d).sum(), torch.full((), float(d.numel()), dtype=torch.float64, device=tgt.device)]
+            else:
+                parts += [zero, zero]
+        for key in ("local", "global"):
+            for tag in ("coarse", "fine"):
+                parts += list(cons.get(f"{key}_{tag}", (zero, zero)))
+        final["loss_partials"] = torch.stack(parts)
     return final
+
+
+def _mask_nosync(alphas):
+    """rendering.py:306-308 without the host round trip of ``if not torch.any(mask)``."""
+    mask = alphas.ge(0.01)
+    return torch.where(mask.any(), mask, torch.ones_like(mask))
+
+
+def _masked_sum(dist3, mask):
+    """(sum over masked points of the per-point mean distance, number of masked points), float64 scalars."""
+    m = mask.to(dist3.dtype)
+    return (dist3.mean(-1) * m).sum().double(), m.sum().double()
 
 
 def _mask_of(alphas):

@@ -1170,3 +1170,74 @@ def test_aux_point_losses_train(M):
     for n, q in nerf.named_parameters():
         if q.grad is not None:
             assert relerr(got[("nerf", n)], q.grad) <= 2e-3, (n, relerr(got[("nerf", n)], q.grad))
+
+
+@pytest.mark.parametrize("name", ["r_moco_global_fine", "r_moco_local", "r_nerf_dir_fine_train", "r_nerf_dir_dense"])
+def test_fused_loss_partials_vs_trainer_formulas(M, R, name):
+    """render_rays(..., _loss_target=gt): the 12 partials of mf_loss_partials (no compaction, no host sync) give the
+    reference's loss terms -- MSELoss over both passes (models/losses.py:4-14) and mean(coarse) + mean(fine) of the
+    consensus vectors (trainer_moco_flow.py:317-328) -- as computed op for op from the ORACLE's result dict; and the
+    default call (with the vectors) agrees with the fast path."""
+    from moco_flow_amd import dist as D, losses
+    c = dict(RENDER_CASES[name])
+    seed = int(load_golden(name)["meta_seed"])
+    n = 96
+    rays, bg = case_inputs(c, seed, n=n)
+    gt = torch.rand(n, 3, generator=torch.Generator().manual_seed(3))
+    embs_o, nerfs_o, kw_o = build_case(R, c, seed)
+    embs, nerfs, kw = build_case(M, c, seed, device="cuda")
+    cap = {}
+    with torch.no_grad():
+        fast = M.render_rays(rays.cuda(), bg.cuda(), embs, nerfs, _loss_target=gt.cuda(), _capture=cap, **kw)
+        full = M.render_rays(rays.cuda(), bg.cuda(), embs, nerfs, **kw)
+        extra = dict(_z_fine_override=cap["z_fine"].cpu()) if c["M"] > 0 else {}
+        want = R.render_rays(rays, bg, embs_o, nerfs_o, **extra, **kw_o)
+    assert not any(k.startswith("nof_") for k in fast) and fast["loss_partials"].shape == (12,)
+    mse = torch.nn.MSELoss(reduction="mean")
+    ref = {"img_loss": float(mse(want["rgb_coarse"], gt) + (mse(want["rgb_fine"], gt) if "rgb_fine" in want else 0.0))}
+    for key in ("nof_local", "nof_global"):
+        if f"{key}_disp_coarse" in want:
+            ref[key] = float(torch.mean(want[f"{key}_disp_coarse"]) +
+                             (torch.mean(want[f"{key}_disp_fine"]) if f"{key}_disp_fine" in want else 0.0))
+    got = {k: float(v) for k, v in losses.from_partials(fast["loss_partials"]).items()}
+    slow = D.reduce_loss(D.loss_partials(full, gt.cuda()))
+    for k, v in ref.items():
+        assert got[k] == pytest.approx(v, rel=2e-4), (k, got[k], v)            # a mask flip at alpha ~ 0.01 moves a mean by 1/n
+        assert got[k] == pytest.approx(slow[k], rel=1e-6), k                     # same kernels, two routes
+    for k in ("nof_local", "nof_global"):
+        if k not in ref:
+            assert got[k] == 0.0
+
+
+def test_fused_loss_partials_train_without_sync(M):
+    """Training through the fast path: loss from losses.from_partials(res["loss_partials"]) back-propagates the same
+    gradients as the reference-shaped loss on the full result dict (MSE + 0.1 * consensus means)."""
+    from moco_flow_amd import losses
+    c = dict(RENDER_CASES["r_moco_global_fine"])
+    seed = int(load_golden("r_moco_global_fine")["meta_seed"])
+    embs, nerfs, kw = build_case(M, c, seed, device="cuda")
+    rays, bg = case_inputs(c, seed, n=24)
+    rays, bg = rays.cuda(), bg.cuda()
+    gt = torch.rand(24, 3, device="cuda")
+    nets = list(nerfs) + list(kw["nof_models"])
+
+    def grads(fast):
+        for m in nets:
+            m.zero_grad(set_to_none=True)
+        if fast:
+            res = M.render_rays(rays, bg, embs, nerfs, _loss_target=gt, **kw)
+            t = losses.from_partials(res["loss_partials"])
+            loss = t["img_loss"] + 0.1 * (t["nof_local"] + t["nof_global"])
+        else:
+            res = M.render_rays(rays, bg, embs, nerfs, **kw)
+            loss = M.get_loss(dict(type="MSE"))(res, gt)
+            for key in ("nof_local_disp", "nof_global_disp"):
+                loss = loss + 0.1 * (res[key + "_coarse"].mean() + res[key + "_fine"].mean())
+        loss.backward()
+        return float(loss), [p.grad.clone() for m in nets for p in m.parameters()]
+
+    la, ga = grads(False)
+    lb, gb = grads(True)
+    assert lb == pytest.approx(la, rel=1e-5)
+    for x, y in zip(ga, gb):
+        assert relerr(y, x) <= 1e-4

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
         assert n in L.SYMBOLS, f"{n} has no ctypes prototype"
-    assert lib.mf_version() == L.MF_ABI_VERSION == 7
+    assert lib.mf_version() == L.MF_ABI_VERSION == 8
     # argument validation is host-side and must not need a GPU
     d = L.mf_nerf_desc()
     d.D, d.W, d.in_channels_xyz, d.skip_mask = 8, 256, 63, 1 << 4
@@ -96,6 +96,14 @@ def test_packed_layout_sizes():
     n.D, n.W, n.in_channels_xyz, n.extra_feat_dim, n.skip_mask, n.use_quat = 4, 128, 33, 33, 1 << 2, 1
     groups = (10 + 16 + 26 + 16) * 4
     assert lib.mf_nof_packed_bytes(ctypes.byref(n)) == 7 * 1024 + groups * 1024
+    # MF_PREC_BF16 (mf_bf16.hpp): a panel is ONE 32-row tile, a group one A fragment of v_mfma_f32_32x32x16_bf16;
+    # embedded k-steps are (hi, lo) group pairs; the NoF head is one more 16-group panel
+    assert lib.mf_nof_packed_bytes_p(ctypes.byref(n), L.MF_PREC_BF16) == 7 * 1024 + ((10 + 8 + 18 + 8) * 4 + 16) * 1024
+    d.extra_feat_type, d.extra_feat_dim = L.MF_EXTRA_DIR, 27
+    groups = (8 + 3 * 16 + 24 + 3 * 16 + 16) * 8 + (16 + 4) * 4
+    assert lib.mf_nerf_packed_bytes_p(ctypes.byref(d), L.MF_PREC_BF16) == 13 * 1024 + groups * 1024
+    assert lib.mf_loss_partials_scratch_bytes() == 256 * 12 * 8
+    assert lib.mf_loss_partials(None, None, None, 0, None, None, None) == -1
 
 
 def test_modules_keep_reference_contract():
