@@ -313,6 +313,13 @@ int32_t mf_loss_partials(const mf_loss_pass* coarse, const mf_loss_pass* fine, c
  * NULL for camera coordinates).  near/far/idx are the scalars make_rays broadcasts. */
 int32_t mf_make_rays(int32_t H, int32_t W, float focal, float cx, float cy, const float* c2w_host,
                      float nearv, float farv, float idx, float* rays_out, void* stream);
+/* Camera.get_valid_rays_mask (utils/camera.py:119-132): mask_out (H*W bytes, device, row-major) = 1 inside the filled
+ * convex hull of the projected AABB corners pts_xy (host, n_pts x (x = column, y = row) int32: the output of
+ * calculate_2d_projections, camera.py:83-103), else 0.  Hull on the host, fill on the device, one thread per pixel.
+ * Rule = cv2.fillConvexPoly's scan-line fill (line_type 8) with exact intersections: row y in [ymin, ymax] sets
+ * pixels round_half_up(XL(y)) .. round_half_up(XR(y)).  PARITY UNPINNED vs cv2 itself (absent from the image). */
+int32_t mf_valid_rays_mask(int32_t H, int32_t W, const int32_t* pts_xy_host, int32_t n_pts, uint8_t* mask_out,
+                           void* stream);
 /* Foreground scatter-back of the full-image drivers (MoCoFlowTrainer.render trainer_moco_flow.py:249-266,
  * NeRFTrainer.render trainer_nerf.py:128-140), on the device: for every pixel b of the (B) image
  *   not rendered (rays_msk[b] == 0)            -> img = background[b], depth = 10

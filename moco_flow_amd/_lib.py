@@ -111,6 +111,7 @@ SYMBOLS = {
     "mf_make_rays": (C.c_int32, [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float),
                                  C.c_float, C.c_float, C.c_float, _fp, _fp]),
     "mf_knn1": (C.c_int32, [_fp, C.c_int64, _fp, C.c_int64, _fp, _fp, _fp]),
+    "mf_valid_rays_mask": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _fp, _fp]),
     "mf_loss_partials_scratch_bytes": (C.c_int64, []),
     "mf_loss_partials": (C.c_int32, [C.POINTER(mf_loss_pass), C.POINTER(mf_loss_pass), _fp, C.c_int64, _fp, _fp, _fp]),
     "mf_compact_scratch_bytes": (C.c_int64, [C.c_int64]),

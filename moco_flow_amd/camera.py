@@ -33,3 +33,32 @@ def near_far_from_aabb(aabb_verts, c2w):
     """camera.py:138-139: min / max distance from the camera origin to the AABB corners (host scalars)."""
     d = np.sqrt(np.sum((np.asarray(aabb_verts) - np.asarray(c2w)[:3, 3]) ** 2, axis=-1))
     return float(min(d)), float(max(d))
+
+
+def project_aabb(aabb_verts, c2w, K):
+    """calculate_2d_projections (camera.py:83-103): the 8 AABB corners in integer pixel coordinates (x = column,
+    y = row), host side (8 points), same numpy operations in the same order as the reference."""
+    pts = np.asarray(aabb_verts).transpose()
+    homo = np.vstack([pts, np.ones((1, pts.shape[1]), dtype=np.float32)])
+    cam = np.linalg.inv(np.asarray(c2w)) @ homo
+    cam = cam[:3, :] / cam[3, :]
+    cam[1:, :] *= -1
+    pix = np.asarray(K) @ cam[:3, :]
+    pix = (pix[:2, :] / pix[2, :]).transpose()
+    return np.array(pix, dtype=np.int32)
+
+
+def valid_rays_mask(aabb_verts, c2w, K, size, device="cuda"):
+    """Camera.get_valid_rays_mask (camera.py:119-132): bool (H*W,) on ``device`` -- the filled convex hull of the
+    projected AABB, written by mf_valid_rays_mask (no H x W host image, no cv2).  ``size`` = (H, W)."""
+    dev = torch.device(device)
+    if dev.type != "cuda":
+        raise RuntimeError("moco_flow_amd.camera.valid_rays_mask: this is the MI355X (HIP) path; no CPU implementation")
+    H, W = int(size[0]), int(size[1])
+    pix = np.ascontiguousarray(project_aabb(aabb_verts, c2w, K).reshape(-1, 2), dtype=np.int32)
+    out = torch.empty(H * W, device=dev, dtype=torch.uint8)
+    arr = (C.c_int32 * pix.size)(*pix.reshape(-1).tolist())
+    with torch.cuda.device(dev):
+        L.check(L.lib().mf_valid_rays_mask(H, W, arr, pix.shape[0], out.data_ptr(), L.current_stream(dev)),
+                "mf_valid_rays_mask")
+    return out.bool()

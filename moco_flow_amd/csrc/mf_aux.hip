@@ -2,6 +2,7 @@
 //   mf_make_rays : Camera.make_rays / gen_ray_directions / gen_rays   utils/camera.py:29-81, 134-148
 //   mf_image_compose : the foreground scatter-back of MoCoFlowTrainer.render / NeRFTrainer.render
 //                      trainer/trainer_moco_flow.py:249-266, trainer/trainer_nerf.py:128-140
+//   mf_valid_rays_mask : Camera.get_valid_rays_mask  utils/camera.py:119-132 (hull + fill of the projected AABB)
 //   mf_knn1      : knn_cuda.KNN(k=1)  (vendored wheel docker/KNN_CUDA-0.2: knn_cuda/csrc/cuda/knn.cu:29-183)
 #include "mf_host.hpp"
 
@@ -78,6 +79,51 @@ __global__ void image_compose_kernel(ComposeParams p) {
   p.depth_out[b] = d;
 }
 
+struct MaskParams {
+  int H, W, n;
+  int hx[8], hy[8];            // convex hull vertices (x = column, y = row), any orientation
+  int ymin, ymax;
+  unsigned char* out;
+};
+
+__device__ inline long long floor_div(long long a, long long b) {      // b > 0
+  const long long q = a / b;
+  return (a % b != 0 && a < 0) ? q - 1 : q;
+}
+
+// Camera.get_valid_rays_mask (utils/camera.py:119-132): one thread per pixel.  Rule (cv2.fillConvexPoly's scan-line
+// fill, line_type 8, with exact intersections; PARITY UNPINNED vs cv2 itself, see oracle/cpu_ref.py::valid_rays_mask):
+// pixel (x, y) is set iff ymin <= y <= ymax and round_half_up(XL(y)) <= x <= round_half_up(XR(y)), [XL, XR] = the
+// intersection of row y with the closed hull.  Integer arithmetic throughout.
+__global__ void valid_mask_kernel(MaskParams p) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (long long)p.H * p.W) return;
+  const int y = (int)(idx / p.W), x = (int)(idx - (long long)y * p.W);
+  bool in = false;
+  if (y >= p.ymin && y <= p.ymax) {
+    // min / max of the rational intersections num/den (den > 0), compared by cross-multiplication
+    long long ln = 0, ld = 0, rn = 0, rd = 0;
+    auto take = [&](long long num, long long den) {
+      if (ld == 0 || num * ld < ln * den) { ln = num; ld = den; }
+      if (rd == 0 || num * rd > rn * den) { rn = num; rd = den; }
+    };
+    const int n = p.n;
+    for (int e = 0; e < (n > 1 ? n : 1); ++e) {
+      const int ax = p.hx[e], ay = p.hy[e], bx = p.hx[(e + 1) % n], by = p.hy[(e + 1) % n];
+      if ((long long)(y - ay) * (y - by) > 0) continue;
+      if (ay == by) { take(ax, 1); take(bx, 1); continue; }
+      long long den = by - ay, num = (long long)ax * den + (long long)(y - ay) * (bx - ax);
+      if (den < 0) { den = -den; num = -num; }
+      take(num, den);
+    }
+    if (ld != 0) {
+      const long long lo = floor_div(2 * ln + ld, 2 * ld), hi = floor_div(2 * rn + rd, 2 * rd);   // floor(v + 1/2)
+      in = x >= lo && x <= hi;
+    }
+  }
+  p.out[idx] = in ? 1 : 0;
+}
+
 struct KnnParams {
   const float* ref; long long V;
   const float* query; long long Q;
@@ -133,6 +179,58 @@ extern "C" int32_t mf_make_rays(int32_t H, int32_t W, float focal, float cx, flo
   const long long n = (long long)H * W;
   hipLaunchKernelGGL(make_rays_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   return check_launch("mf_make_rays");
+}
+
+extern "C" int32_t mf_valid_rays_mask(int32_t H, int32_t W, const int32_t* pts_xy_host, int32_t n_pts, uint8_t* mask_out,
+                                      void* stream) {
+  if (H < 0 || W < 0 || n_pts < 0 || n_pts > 64 || (n_pts > 0 && !pts_xy_host))
+    return fail(MF_E_INVALID, "mf_valid_rays_mask: H=%d W=%d n_pts=%d", H, W, n_pts);
+  if ((long long)H * W == 0) return MF_OK;
+  if (!mask_out) return fail(MF_E_INVALID, "mf_valid_rays_mask: null output");
+  // convex hull on the host (Andrew's monotone chain; <= 64 points, the reference passes the 8 AABB corners)
+  long long px[64], py[64];
+  int m = 0;
+  for (int i = 0; i < n_pts; ++i) { px[m] = pts_xy_host[2 * i]; py[m] = pts_xy_host[2 * i + 1]; ++m; }
+  for (int i = 1; i < m; ++i)                                    // insertion sort by (x, y)
+    for (int j = i; j > 0 && (px[j] < px[j - 1] || (px[j] == px[j - 1] && py[j] < py[j - 1])); --j) {
+      long long t = px[j]; px[j] = px[j - 1]; px[j - 1] = t;
+      t = py[j]; py[j] = py[j - 1]; py[j - 1] = t;
+    }
+  int u = 0;
+  for (int i = 0; i < m; ++i)                                    // unique
+    if (i == 0 || px[i] != px[u - 1] || py[i] != py[u - 1]) { px[u] = px[i]; py[u] = py[i]; ++u; }
+  m = u;
+  long long hx[130], hy[130];
+  int k = 0;
+  auto cross = [&](int o, long long ax, long long ay, long long bx, long long by) {
+    return (ax - hx[o]) * (by - hy[o]) - (ay - hy[o]) * (bx - hx[o]);
+  };
+  if (m <= 2) {
+    for (int i = 0; i < m; ++i) { hx[k] = px[i]; hy[k] = py[i]; ++k; }
+  } else {
+    for (int i = 0; i < m; ++i) {
+      while (k >= 2 && cross(k - 2, hx[k - 1], hy[k - 1], px[i], py[i]) <= 0) --k;
+      hx[k] = px[i]; hy[k] = py[i]; ++k;
+    }
+    const int lower = k + 1;
+    for (int i = m - 2; i >= 0; --i) {
+      while (k >= lower && cross(k - 2, hx[k - 1], hy[k - 1], px[i], py[i]) <= 0) --k;
+      hx[k] = px[i]; hy[k] = py[i]; ++k;
+    }
+    --k;                                                         // the last point repeats the first
+  }
+  if (k > 8) return fail(MF_E_UNSUPPORTED, "mf_valid_rays_mask: hull with %d vertices (max 8: the AABB corners)", k);
+  MaskParams p{};
+  p.H = H; p.W = W; p.n = k; p.out = mask_out;
+  p.ymin = 1; p.ymax = 0;
+  for (int i = 0; i < k; ++i) {
+    p.hx[i] = (int)hx[i]; p.hy[i] = (int)hy[i];
+    if (i == 0 || p.hy[i] < p.ymin) p.ymin = p.hy[i];
+    if (i == 0 || p.hy[i] > p.ymax) p.ymax = p.hy[i];
+  }
+  const long long n = (long long)H * W;
+  hipLaunchKernelGGL(valid_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  return check_launch("mf_valid_rays_mask");
 }
 
 extern "C" int32_t mf_knn1(const float* ref, int64_t V, const float* query, int64_t Q, float* dist, int64_t* ind,

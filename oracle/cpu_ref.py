@@ -442,6 +442,73 @@ def make_rays(H, W, focal, center, c2w, near, far, idx):
     return torch.cat([rays_o, rays_d, near * one, far * one, idx * one], dim=1)
 
 
+def project_aabb(aabb_verts, c2w, K):
+    """utils/camera.py:83-103 (calculate_2d_projections): world points -> integer pixel coordinates (x = column,
+    y = row); the cast to int32 truncates toward zero."""
+    pts = np.asarray(aabb_verts).transpose()
+    homo = np.vstack([pts, np.ones((1, pts.shape[1]), dtype=np.float32)])
+    cam = np.linalg.inv(np.asarray(c2w)) @ homo
+    cam = cam[:3, :] / cam[3, :]
+    cam[1:, :] *= -1
+    pix = np.asarray(K) @ cam[:3, :]
+    pix = (pix[:2, :] / pix[2, :]).transpose()
+    return np.array(pix, dtype=np.int32)
+
+
+def convex_hull_int(points):
+    """Convex hull of integer points, counter-clockwise in (x, y) with y down-screen irrelevant: Andrew's monotone
+    chain, collinear points dropped.  (cv2.convexHull, utils/camera.py:123, returns the same vertex set.)"""
+    pts = sorted(set((int(x), int(y)) for x, y in points))
+    if len(pts) <= 2:
+        return pts
+
+    def cross(o, a, b):
+        return (a[0] - o[0]) * (b[1] - o[1]) - (a[1] - o[1]) * (b[0] - o[0])
+
+    lower, upper = [], []
+    for q in pts:
+        while len(lower) >= 2 and cross(lower[-2], lower[-1], q) <= 0:
+            lower.pop()
+        lower.append(q)
+    for q in reversed(pts):
+        while len(upper) >= 2 and cross(upper[-2], upper[-1], q) <= 0:
+            upper.pop()
+        upper.append(q)
+    return lower[:-1] + upper[:-1]
+
+
+def valid_rays_mask(projected_pixels, H, W):
+    """Camera.get_valid_rays_mask (utils/camera.py:119-132) by brute force with exact rational arithmetic.
+    PARITY UNPINNED vs cv2.fillConvexPoly (cv2 is absent from this image): the rasterisation rule restated here is
+    cv2's scan-line fill for line_type 8 -- for every row y in [ymin, ymax] of the hull the pixels
+    round_half_up(XL(y)) .. round_half_up(XR(y)) are set, [XL, XR] = the row's intersection with the closed hull --
+    evaluated with exact intersections (cv2 steps the edges in 16.16 fixed point, which can move a boundary pixel
+    when an intersection is within 2^-16 of a half)."""
+    from fractions import Fraction
+    import math
+    hull = convex_hull_int(projected_pixels)
+    mask = np.zeros((H, W), dtype=bool)
+    if not hull:
+        return mask.reshape(-1)
+    ys = [q[1] for q in hull]
+    n = len(hull)
+    edges = [(hull[i], hull[(i + 1) % n]) for i in range(n)] if n > 1 else [(hull[0], hull[0])]
+    for y in range(max(min(ys), 0), min(max(ys), H - 1) + 1):
+        xs = []
+        for (ax, ay), (bx, by) in edges:
+            if (y - ay) * (y - by) > 0:
+                continue
+            if ay == by:
+                xs += [Fraction(ax), Fraction(bx)]
+            else:
+                xs.append(Fraction(ax) + Fraction((y - ay) * (bx - ax), by - ay))
+        lo = math.floor(min(xs) + Fraction(1, 2))
+        hi = math.floor(max(xs) + Fraction(1, 2))
+        for x in range(max(lo, 0), min(hi, W - 1) + 1):
+            mask[y, x] = True
+    return mask.reshape(-1)
+
+
 def knn1(ref, query):
     """k = 1 brute force with the wheel's semantics (knn_cuda/csrc/cuda/knn.cu:29-183, __init__.py:42-46):
     Euclidean distance and 0-based index of the nearest reference point, FIRST minimum on ties.

@@ -267,7 +267,7 @@ def unit_camera():
     the import). Camera.make_rays for two poses + camera-space rays."""
     import types
     sys.modules.setdefault("cv2", types.ModuleType("cv2"))
-    from utils.camera import Camera, gen_rays, convert_AABB_to_verts
+    from utils.camera import Camera, gen_rays, convert_AABB_to_verts, calculate_2d_projections
     H, W = 24, 40
     K = np.array([[55.5, 0, 19.25], [0, 57.0, 12.5], [0, 0, 1]], dtype=np.float64)
     cam = Camera((H, W), K)
@@ -278,8 +278,11 @@ def unit_camera():
     verts = convert_AABB_to_verts(np.array([[-0.6, -0.9, -0.4], [0.5, 0.8, 0.45]]))
     rays = cam.make_rays(verts, 0.375)
     o_cam, d_cam = gen_rays(cam.directions, None)
+    # the projection half of Camera.get_valid_rays_mask (camera.py:119-122) is plain numpy and runs here; its cv2 half
+    # (convexHull + fillConvexPoly, :123-124) cannot (cv2 absent): the mask itself is therefore not a fixture
+    proj = calculate_2d_projections(verts, cam.c2w, cam.K)
     save("u_camera", in_K=K, in_c2w=c2w, in_aabb_verts=verts, in_HW=np.array([H, W]), in_idx=np.float64(0.375),
-         out_rays=rays, out_dirs_cam=d_cam, out_directions=cam.directions)
+         out_rays=rays, out_dirs_cam=d_cam, out_directions=cam.directions, out_projected_pixels=proj)
 
 
 def unit_render_image():
@@ -342,6 +345,7 @@ if __name__ == "__main__":
         unit_networks()
         unit_sample_pdf()
         unit_trainer_glue()
+    if not only or "units" in only or "camera" in only:
         unit_camera()
     if not only or "units" in only or "image" in only:
         unit_render_image()

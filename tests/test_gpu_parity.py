@@ -1241,3 +1241,50 @@ def test_fused_loss_partials_train_without_sync(M):
     assert lb == pytest.approx(la, rel=1e-5)
     for x, y in zip(ga, gb):
         assert relerr(y, x) <= 1e-4
+
+
+def test_valid_rays_mask_bit_exact(M, R):
+    """mf_valid_rays_mask (Camera.get_valid_rays_mask, utils/camera.py:119-132) against the brute-force oracle:
+    bit-exact masks (index bookkeeping) for the fixture's camera, 40 random poses / boxes at a full image size, and
+    degenerate hulls (point, segment, off-screen, partially clipped).  The projection is pinned to the reference's
+    calculate_2d_projections output; hull + fill: parity unpinned vs cv2 (absent), rule stated in the header."""
+    from moco_flow_amd import camera
+    import moco_flow_amd._lib as L
+    import ctypes as C
+    g = load_golden("u_camera")
+    H, W = [int(v) for v in g["in_HW"]]
+    assert np.array_equal(camera.project_aabb(g["in_aabb_verts"], g["in_c2w"], g["in_K"]), g["out_projected_pixels"])
+    got = camera.valid_rays_mask(g["in_aabb_verts"], g["in_c2w"], g["in_K"], (H, W))
+    want = R.valid_rays_mask(g["out_projected_pixels"], H, W)
+    assert got.dtype == torch.bool and got.shape == (H * W,) and np.array_equal(got.cpu().numpy(), want)
+    rng = np.random.default_rng(0)
+    H, W = 135, 240
+    K = np.array([[180.0, 0, 120.0], [0, 180.0, 67.5], [0, 0, 1]])
+    n_nonempty = 0
+    for it in range(40):
+        th, ph = rng.uniform(-0.9, 0.9), rng.uniform(-0.4, 0.4)
+        Rz = np.array([[np.cos(th), 0, np.sin(th)], [0, 1, 0], [-np.sin(th), 0, np.cos(th)]])
+        Rx = np.array([[1, 0, 0], [0, np.cos(ph), -np.sin(ph)], [0, np.sin(ph), np.cos(ph)]])
+        c2w = np.eye(4)
+        c2w[:3, :3] = Rz @ Rx
+        c2w[:3, 3] = rng.uniform(-0.5, 0.5, 3) + np.array([0, 0, 2.8])
+        lo = rng.uniform(-0.9, -0.2, 3)
+        hi = rng.uniform(0.2, 0.9, 3)
+        verts = np.array([[x, y, z] for x in (lo[0], hi[0]) for y in (lo[1], hi[1]) for z in (lo[2], hi[2])])
+        pix = camera.project_aabb(verts, c2w, K)
+        got = camera.valid_rays_mask(verts, c2w, K, (H, W)).cpu().numpy()
+        want = R.valid_rays_mask(pix, H, W)
+        assert np.array_equal(got, want), it
+        n_nonempty += int(want.any())
+    assert n_nonempty >= 30
+
+    def raw(points, H, W):
+        pts = np.ascontiguousarray(np.asarray(points, dtype=np.int32).reshape(-1, 2))
+        out = torch.empty(H * W, dtype=torch.uint8, device="cuda")
+        arr = (C.c_int32 * pts.size)(*pts.reshape(-1).tolist())
+        L.check(L.lib().mf_valid_rays_mask(H, W, arr, pts.shape[0], out.data_ptr(), L.current_stream(out.device)), "mask")
+        return out.cpu().numpy().astype(bool)
+
+    for pts, H, W in ([[(1, 1)] * 8, 3, 3], [[(0, 0), (3, 3)], 4, 4], [[(-9, -9), (-5, -9), (-7, -3)], 4, 4],
+                      [[(0, 0), (3, 0), (0, 2)], 3, 4], [[(-4, 2), (9, -3), (5, 12), (-2, 7)], 8, 6]):
+        assert np.array_equal(raw(pts, H, W), R.valid_rays_mask(np.array(pts), H, W)), pts

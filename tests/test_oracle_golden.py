@@ -124,6 +124,32 @@ def test_camera_vectors():
     assert relerr(cam[:, 3:6], g["out_dirs_cam"]) <= TOL
 
 
+def test_valid_rays_mask_oracle():
+    """Camera.get_valid_rays_mask (utils/camera.py:119-132).  The projection (calculate_2d_projections, :83-103) is
+    pinned to the reference's own output; the hull + fill half is cv2 (absent): PARITY UNPINNED, the oracle restates
+    cv2.fillConvexPoly's scan-line rule with exact intersections -- checked here on hand-countable polygons."""
+    g = load_golden("u_camera")
+    pix = R.project_aabb(g["in_aabb_verts"], g["in_c2w"], g["in_K"])
+    assert pix.dtype == np.int32 and np.array_equal(pix, g["out_projected_pixels"])
+    H, W = [int(v) for v in g["in_HW"]]
+    m = R.valid_rays_mask(pix, H, W).reshape(H, W)
+    assert m.sum() == 115 and m[0, 34] and not m[0, 33] and m[:, -1].all()
+    # axis-aligned rectangle: closed on all four sides
+    sq = R.valid_rays_mask(np.array([[2, 1], [5, 1], [5, 3], [2, 3], [3, 2]]), 6, 8).reshape(6, 8)
+    assert sq.sum() == 12 and sq[1:4, 2:6].all()
+    # right triangle (0,0) (4,0) (0,4): row y spans x = 0 .. round_half_up(4 - y)
+    tri = R.valid_rays_mask(np.array([[0, 0], [4, 0], [0, 4]]), 5, 5).reshape(5, 5)
+    assert [int(r.sum()) for r in tri] == [5, 4, 3, 2, 1]
+    # slanted edge with half-pixel intersections: (0,0) (3,0) (0,2): row 1 ends at x = 1.5 -> rounds up to 2
+    t2 = R.valid_rays_mask(np.array([[0, 0], [3, 0], [0, 2]]), 3, 4).reshape(3, 4)
+    assert [int(r.sum()) for r in t2] == [4, 3, 1]
+    # degenerate inputs: a single point, a segment, everything off-screen
+    assert R.valid_rays_mask(np.array([[1, 1]] * 8), 3, 3).sum() == 1
+    assert R.valid_rays_mask(np.array([[0, 0], [3, 3]]), 4, 4).reshape(4, 4).diagonal().all()
+    assert R.valid_rays_mask(np.array([[-9, -9], [-5, -9], [-7, -3]]), 4, 4).sum() == 0
+    assert R.convex_hull_int([(0, 0), (2, 0), (1, 0), (2, 2), (0, 2), (1, 1)]) == [(0, 0), (2, 0), (2, 2), (0, 2)]
+
+
 def test_knn1_semantics():
     ref = torch.tensor([[0., 0, 0], [1, 0, 0], [1, 0, 0], [0, 2, 0]])
     q = torch.tensor([[0.9, 0, 0], [0, 0.9, 0], [0, 1.1, 0], [5, 5, 5]])
