@@ -28,8 +28,9 @@ extern "C" {
 
 /* 3: activation dump of the training forward; 4: mf_nerf_backward, mf_weight_grads; 5: NoF backward
  * (mf_nof_points_dump, mf_nof_backward); 6: mf_composite_backward, mf_image_compose;
- * 7: mf_nof_forward_dump; 8: mf_loss_partials, new packed layout of MF_PREC_BF16 (32x32x16 fragments) */
-#define MF_ABI_VERSION 8
+ * 7: mf_nof_forward_dump; 8: mf_loss_partials, new packed layout of MF_PREC_BF16 (32x32x16 fragments);
+ * 9: mf_valid_rays_mask, mf_nerf_backward_x (embedded-input gradient in the chain launch), mf_embedding_backward */
+#define MF_ABI_VERSION 9
 
 enum {
   MF_OK = 0,
@@ -144,6 +145,19 @@ int32_t mf_nerf_pack_bwd(const mf_nerf_desc* d, void* packed, void* stream);
 int32_t mf_nerf_backward(const mf_nerf_desc* d, const void* packed_bwd, int64_t P, const float* g_out,
                          const float* acts, int64_t stride, const float* rgbsigma, float* gpre,
                          float* ghead, void* stream);
+
+/* The same launch, additionally producing the gradient of the EMBEDDED INPUT (ABI v9): g_emb (P,64), natural column
+ * order of the 63-wide xyz embedding (column 63 = 0), = xyz_encoding_1[:, :63]^T d_z_0 + (one skip layer)
+ * xyz_encoding_{skip+1}[:, :63]^T d_z_skip, as two more panels of the transposed stream behind the chain; NULL =
+ * mf_nerf_backward.  mf_nerf_pack_bwd packs those panels; more than one skip layer: MF_E_UNSUPPORTED. */
+int32_t mf_nerf_backward_x(const mf_nerf_desc* d, const void* packed_bwd, int64_t P, const float* g_out,
+                           const float* acts, int64_t stride, const float* rgbsigma, float* gpre,
+                           float* ghead, float* g_emb, void* stream);
+/* Backward of Embedding.forward (models/embedding.py:42-46) through the embedded values themselves:
+ * g_x[c] = g_emb[c] + sum_k f_k (emb[cos_kc] g_emb[sin_kc] - emb[sin_kc] g_emb[cos_kc]);  g_emb (P, >= C(2F+1))
+ * with row stride g_stride, emb = the forward's output rows (stride e_stride), g_x (P, C). */
+int32_t mf_embedding_backward(const mf_embedding* e, const float* g_emb, int64_t g_stride, const float* emb,
+                              int64_t e_stride, int64_t P, float* g_x, void* stream);
 
 /* Backward of the alpha-composite of nerf_inference (models/rendering.py:157-192) on per-sample planes:
  * g_rgb (N,3) / g_depth (N) / g_opacity (N) (any may be NULL) = dL/d of the pass's outputs ->

@@ -234,19 +234,34 @@ def set_nerf_backward(kind: str) -> None:
     NERF_BACKWARD = kind
 
 
-def nerf_backward_hip(m, g_out, acts, rgbsig):
-    """mf_nerf_backward: (gpre (P,stride) in the dump's layout, ghead (P,4)) from dL/d[rgb, sigma]."""
+def nerf_backward_hip(m, g_out, acts, rgbsig, want_emb=False):
+    """mf_nerf_backward_x: (gpre (P,stride) in the dump's layout, ghead (P,4), g_emb (P,64) | None) from
+    dL/d[rgb, sigma]; g_emb = the gradient of the embedded input, produced by the same launch."""
     P, stride = acts.shape
     desc, buf = m.packed_bwd()
     dev = acts.device
     g_out = g_out.contiguous().float()
     gpre = torch.empty(((P + 127) // 128 * 128, stride), device=dev, dtype=torch.float32)
     ghead = torch.empty((P, 4), device=dev, dtype=torch.float32)
+    g_emb = torch.empty((P, 64), device=dev, dtype=torch.float32) if want_emb else None
     with torch.cuda.device(dev):
-        L.check(L.lib().mf_nerf_backward(C.byref(desc), buf.data_ptr(), P, g_out.data_ptr(), acts.data_ptr(), stride,
-                                         rgbsig.data_ptr(), gpre.data_ptr(), ghead.data_ptr(),
-                                         L.current_stream(dev)), "mf_nerf_backward")
-    return gpre[:P], ghead
+        L.check(L.lib().mf_nerf_backward_x(C.byref(desc), buf.data_ptr(), P, g_out.data_ptr(), acts.data_ptr(), stride,
+                                           rgbsig.data_ptr(), gpre.data_ptr(), ghead.data_ptr(), L.ptr(g_emb),
+                                           L.current_stream(dev)), "mf_nerf_backward")
+    return gpre[:P], ghead, g_emb
+
+
+def embed_backward_hip(emb, emb_vals, g_emb):
+    """mf_embedding_backward: d/dx of embedding.py:42-46 through the embedded values (their sin / cos columns already
+    carry the per-frequency weights): (P, C) from g_emb (P, >= width), emb_vals (P, >= width)."""
+    P, dev = g_emb.shape[0], g_emb.device
+    desc = emb.descriptor()
+    g_x = torch.empty((P, emb.in_channels), device=dev, dtype=torch.float32)
+    with torch.cuda.device(dev):
+        L.check(L.lib().mf_embedding_backward(C.byref(desc), g_emb.data_ptr(), g_emb.stride(0), emb_vals.data_ptr(),
+                                              emb_vals.stride(0), P, g_x.data_ptr(), L.current_stream(dev)),
+                "mf_embedding_backward")
+    return g_x
 
 
 _WG_BLOCK = {(256, 256): (256, 256), (256, 64): (256, 64), (128, 256): (128, 256), (128, 32): (128, 32), (4, 640): (16, 640),
@@ -484,7 +499,9 @@ class NerfSamples(torch.autograd.Function):
             fused = (NERF_BACKWARD == "hip" and acts.shape[0] > 0 and W == 256 and cin <= 64
                      and m.extra_feat_dim <= 32 and D + len([s for s in m.skips if 0 < s < D]) + 4 <= L.MF_WG_MAX_ITEMS)
             if fused:
-                gpre, ghead = nerf_backward_hip(m, g_out, acts, rgbsig)
+                n_skip = len([s_ for s_ in m.skips if 0 < s_ < D])
+                emb_hip = need_in and n_skip <= 1 and cin == ctx.emb_xyz.out_channels and cin <= 64
+                gpre, ghead, g_emb_hip = nerf_backward_hip(m, g_out, acts, rgbsig, want_emb=emb_hip)
                 P, dev = acts.shape[0], acts.device
                 gslot = lambda l: gpre[:, l * W:(l + 1) * W]
                 g_e2 = gpre[:, (D + 1) * W:(D + 1) * W + W // 2]
@@ -541,7 +558,10 @@ class NerfSamples(torch.autograd.Function):
                     if req["rgb.0.bias"]:
                         grads["rgb.0.bias"] = hb[0:3].clone()
                 g_emb = None
-                if need_in:
+                if emb_hip:      # produced by the chain launch itself; the sin / cos chain rule is one more small launch
+                    g_xin = embed_backward_hip(ctx.emb_xyz, emb64, g_emb_hip)
+                    return (None, None, None, None, None, None, g_xin) + tuple(grads[n] for n in names)
+                if need_in:      # (several skip layers / a narrower embedding: library GEMMs)
                     for l in range(D):
                         if l == 0 or l in m.skips:
                             lin = getattr(m, f"xyz_encoding_{l+1}")[0]

@@ -24,12 +24,23 @@ namespace mf {
 
 // Backward "network" of a NeRF(D, W=256): layer 0 = extra_encoding^T (K = W/2), layer 1 =
 // xyz_encoding_final^T (+ the d_sigma block), layers 2..D = trunk layers D-1..1 transposed.
+// Behind them, the embedded-input gradient (ABI v9): layer D+1 = xyz_encoding_1[:, :64]^T (64 output rows = embedded
+// features, K = W) and, with one skip layer, layer D+2 = that layer's embedded columns transposed:
+//     d emb = W_0[:, :63]^T d_z_0 + W_skip[:, :63]^T d_z_skip.
+// (More than one skip layer: not built; n_head = number of these layers, 0 = g_emb unsupported.)
+inline int bwd_skip_layer(const mf_nerf_desc& d) {      // the single skip layer, 0 = none, -1 = several
+  int s = 0;
+  for (int l = 1; l < d.D; ++l)
+    if ((d.skip_mask >> l) & 1u) { if (s) return -1; s = l; }
+  return s;
+}
 inline bool nerf_bwd_layout(const mf_nerf_desc& d, NetLayout& L) {
   NetLayout F;
   if (!nerf_layout(d, F, 0) || F.W != 256) return false;
   L = NetLayout{};
   L.W = F.W; L.NK = F.NK; L.NP = F.NP;
   L.n_trunk = d.D + 1;
+  L.n_head = bwd_skip_layer(d) < 0 ? 0 : (bwd_skip_layer(d) > 0 ? 2 : 1);
   L.emb_steps = kBwdSigSteps;
   L.emb_mask = 2u;
   L.relu_mask = 0;
@@ -39,7 +50,8 @@ inline bool nerf_bwd_layout(const mf_nerf_desc& d, NetLayout& L) {
   L.off_rgb_w = off; off += 3 * (L.W / 2);       // rgb.0.weight, natural order (VALU prologue)
   L.res_bytes = round_up((int64_t)off * 4, kGroupBytes);
   L.max_groups = 2 * (L.NK + 1);
-  L.panel_bytes = (int64_t)(L.NK + 2 * (L.NK + 1) + 2 * L.NK * (d.D - 1)) * L.NP * kGroupBytes;
+  L.panel_bytes = ((int64_t)(L.NK + 2 * (L.NK + 1) + 2 * L.NK * (d.D - 1)) * L.NP +
+                   (int64_t)L.n_head * 2 * L.NK * 2 /* 64 rows = 2 panels */) * kGroupBytes;
   return true;
 }
 MF_HD int bwd_groups(const NetLayout& L, int layer) {
@@ -50,11 +62,12 @@ int device_cus();   // mf_forward.hip
 
 // ------------------------------------------------------------------ packing (transposed fragment stream)
 struct BwdPackJob {
-  const float* W[MF_MAX_LAYERS + 1];   // forward weight feeding backward layer i
-  int ld[MF_MAX_LAYERS + 1];           // its row length (forward in-features)
-  int col0[MF_MAX_LAYERS + 1];         // first hidden column
-  int groups[MF_MAX_LAYERS + 1];
-  long long g0[MF_MAX_LAYERS + 2];
+  const float* W[MF_MAX_LAYERS + 3];   // forward weight feeding backward layer i
+  int ld[MF_MAX_LAYERS + 3];           // its row length (forward in-features)
+  int col0[MF_MAX_LAYERS + 3];         // first hidden column
+  int groups[MF_MAX_LAYERS + 3];
+  long long g0[MF_MAX_LAYERS + 4];
+  int ncols[MF_MAX_LAYERS + 3];        // forward input columns present (output rows beyond are zero): emb layers
   int n_layers, NP;
   const float* sigma_w;
   const float* rgb_w;
@@ -89,7 +102,7 @@ __global__ void pack_bwd_kernel(BwdPackJob job) {
     float* pv = &v.x;
     for (int r = 0; r < 4; ++r) {
       const int k = 16 * bh + 4 * g + r;           // forward output row
-      pv[r] = job.W[li][(long long)k * job.ld[li] + job.col0[li] + n];
+      pv[r] = n < job.ncols[li] ? job.W[li][(long long)k * job.ld[li] + job.col0[li] + n] : 0.f;
     }
   }
   reinterpret_cast<float4*>(job.panels)[gidx] = v;
@@ -105,6 +118,8 @@ struct BwdParams {
   const float* rgbsigma;   // (P,4)
   float* gpre;             // (round_up(P,128), stride)
   float* ghead;            // (P,4)  [d rgb pre-sigmoid, d sigma]
+  float* g_emb;            // (P,64) dL/d embedded input (natural column order, column 63 = 0), or null
+  int skip;                // the skip layer (0 = none)
   uint32_t ring_off, buf_bytes;
   int dbg;
 };
@@ -125,10 +140,11 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_backward_kernel(BwdParams p)
   carry.load(st.slot_off(0) + id.lane * 16, zero_bias, id.g);
   const int D = p.D, W = net.L.W;
   const uint32_t rgbw = net.res_lds + net.L.off_rgb_w * 4;
+  const int last_layer = p.g_emb ? D + net.L.n_head : D;      // the embedded-input layers run only when asked for
   auto next_of = [&](int layer) {                 // the layer after `layer` in program order
     NextLayer f;
-    const int nl = layer + 1 <= D ? layer + 1 : 0;
-    f.groups = bwd_groups(net.L, nl);
+    const int nl = layer + 1 <= last_layer ? layer + 1 : 0;
+    f.groups = nl > D ? 2 * net.L.NK : bwd_groups(net.L, nl);
     f.jump = nl == 0 ? first : nullptr;
     f.bias_off = zero_bias;
     return f;
@@ -180,8 +196,51 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_backward_kernel(BwdParams p)
 #pragma unroll
       for (int t = 0; t < 16; ++t) b[t] = a[t];
     }
+    if (p.g_emb) {
+      // d emb = W_0[:, :64]^T d_z_0 (+ W_skip[:, :64]^T d_z_skip): 64 output rows = 2 panels, K = W each
+      f32x4 ge[4];
+      bwd_layer<2, 16, 2, false, false>(b, nosig, ge, 2 * net.L.NK, zero_bias, st, carry, id, next_of(D + 1), nullptr, nullptr);
+      if (p.skip > 0) {
+        // d_z_skip was stored by this very lane several layers ago (its hooks' vmcnt waits retired the stores)
+        const float* zrow = grow + (long long)p.skip * W;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+          a[2 * t] = *reinterpret_cast<const f32x4*>(zrow + 32 * t + 4 * id.g);
+          a[2 * t + 1] = *reinterpret_cast<const f32x4*>(zrow + 32 * t + 16 + 4 * id.g);
+        }
+        f32x4 g2[4];
+        bwd_layer<2, 16, 2, false, false>(a, nosig, g2, 2 * net.L.NK, zero_bias, st, carry, id, next_of(D + 2), nullptr, nullptr);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) ge[t] += g2[t];
+      }
+      if (valid) {
+        float* er = p.g_emb + s * 64;
+        *reinterpret_cast<f32x4*>(er + 4 * id.g) = ge[0];
+        *reinterpret_cast<f32x4*>(er + 16 + 4 * id.g) = ge[1];
+        *reinterpret_cast<f32x4*>(er + 32 + 4 * id.g) = ge[2];
+        *reinterpret_cast<f32x4*>(er + 48 + 4 * id.g) = ge[3];
+      }
+    }
   }
   wait_vm0();
+}
+
+// embedding.py:42-46 differentiated: g_x[c] = g_emb[c] + sum_k f_k (emb[cos_kc] g_emb[sin_kc] - emb[sin_kc] g_emb[cos_kc]),
+// emb = the embedded input itself (its sin / cos columns already carry the per-frequency weight w_k).
+struct EmbBwdParams { const float* g_emb; long long g_stride; const float* emb; long long e_stride; long long P; int C, F; float freq[16]; float* g_x; };
+__global__ void embed_backward_kernel(EmbBwdParams p) {
+  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= p.P) return;
+  const float* g = p.g_emb + s * p.g_stride;
+  const float* e = p.emb + s * p.e_stride;
+  for (int c = 0; c < p.C; ++c) {
+    float acc = g[c];
+    for (int k = 0; k < p.F; ++k) {
+      const int is = p.C + 2 * p.C * k + c, ic = is + p.C;
+      acc += p.freq[k] * (e[ic] * g[is] - e[is] * g[ic]);
+    }
+    p.g_x[s * p.C + c] = acc;
+  }
 }
 
 }  // namespace mf
@@ -218,7 +277,20 @@ extern "C" int32_t mf_nerf_pack_bwd(const mf_nerf_desc* d, void* packed, void* s
     job.g0[i] = g0;
     g0 += (long long)job.groups[i] * L.NP;
   }
-  job.g0[d->D + 1] = g0;
+  for (int i = 0; i <= d->D; ++i) job.ncols[i] = 1 << 30;
+  for (int e = 0; e < L.n_head; ++e) {                      // embedded-input gradient layers
+    const int i = d->D + 1 + e, l = e == 0 ? 0 : bwd_skip_layer(*d);
+    job.W[i] = d->trunk_w[l];
+    if (!job.W[i]) return fail(MF_E_INVALID, "mf_nerf_pack_bwd: missing weight pointer (layer %d)", l);
+    job.ld[i] = (l == 0 ? 0 : L.W) + d->in_channels_xyz;
+    job.col0[i] = 0;
+    job.ncols[i] = d->in_channels_xyz;
+    job.groups[i] = 2 * L.NK;
+    job.g0[i] = g0;
+    g0 += (long long)job.groups[i] * 2;
+  }
+  job.n_layers = d->D + 1 + L.n_head;
+  job.g0[job.n_layers] = g0;
   if (!d->sigma_w || !d->rgb_w) return fail(MF_E_INVALID, "mf_nerf_pack_bwd: missing sigma / rgb weight");
   job.sigma_w = d->sigma_w;
   job.rgb_w = d->rgb_w;
@@ -237,10 +309,34 @@ extern "C" int32_t mf_nerf_pack_bwd(const mf_nerf_desc* d, void* packed, void* s
 extern "C" int32_t mf_nerf_backward(const mf_nerf_desc* d, const void* packed_bwd, int64_t P, const float* g_out,
                                     const float* acts, int64_t stride, const float* rgbsigma, float* gpre,
                                     float* ghead, void* stream) {
+  return mf_nerf_backward_x(d, packed_bwd, P, g_out, acts, stride, rgbsigma, gpre, ghead, nullptr, stream);
+}
+
+extern "C" int32_t mf_embedding_backward(const mf_embedding* e, const float* g_emb, int64_t g_stride, const float* emb,
+                                         int64_t e_stride, int64_t P, float* g_x, void* stream) {
+  if (!e || P < 0 || (P > 0 && (!g_emb || !emb || !g_x))) return fail(MF_E_INVALID, "mf_embedding_backward: null argument");
+  if (e->in_channels < 1 || e->n_freqs < 0 || e->n_freqs > MF_MAX_FREQS) return fail(MF_E_INVALID, "mf_embedding_backward: bad embedding");
+  const int width = e->in_channels * (2 * e->n_freqs + 1);
+  if (g_stride < width || e_stride < width) return fail(MF_E_INVALID, "mf_embedding_backward: strides shorter than %d", width);
+  if (P == 0) return MF_OK;
+  EmbBwdParams p{};
+  p.g_emb = g_emb; p.g_stride = g_stride; p.emb = emb; p.e_stride = e_stride; p.P = P; p.C = e->in_channels; p.F = e->n_freqs;
+  for (int k = 0; k < e->n_freqs; ++k) p.freq[k] = e->weight[k] != 0.f ? e->freq[k] : 0.f;   // muted frequency: emb columns are 0 anyway
+  p.g_x = g_x;
+  hipLaunchKernelGGL(embed_backward_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  return check_launch("mf_embedding_backward");
+}
+
+extern "C" int32_t mf_nerf_backward_x(const mf_nerf_desc* d, const void* packed_bwd, int64_t P, const float* g_out,
+                                      const float* acts, int64_t stride, const float* rgbsigma, float* gpre,
+                                      float* ghead, float* g_emb, void* stream) {
   if (!d || !packed_bwd || (P > 0 && (!g_out || !acts || !rgbsigma || !gpre || !ghead)))
     return fail(MF_E_INVALID, "mf_nerf_backward: null argument");
   BwdParams p{};
   if (!nerf_bwd_layout(*d, p.net.L)) return fail(MF_E_UNSUPPORTED, "mf_nerf_backward: unsupported NeRF configuration");
+  if (g_emb && p.net.L.n_head == 0) return fail(MF_E_UNSUPPORTED, "mf_nerf_backward: the embedded-input gradient is built for at most one skip layer");
+  p.g_emb = g_emb;
+  p.skip = bwd_skip_layer(*d) > 0 ? bwd_skip_layer(*d) : 0;
   if (stride < (int64_t)(d->D + 1) * d->W + d->W / 2 || (stride & 3))
     return fail(MF_E_INVALID, "mf_nerf_backward: stride %lld too small or not a multiple of 4", (long long)stride);
   if (P == 0) return MF_OK;

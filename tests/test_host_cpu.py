@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
         assert n in L.SYMBOLS, f"{n} has no ctypes prototype"
-    assert lib.mf_version() == L.MF_ABI_VERSION == 8
+    assert lib.mf_version() == L.MF_ABI_VERSION == 9
     # argument validation is host-side and must not need a GPU
     d = L.mf_nerf_desc()
     d.D, d.W, d.in_channels_xyz, d.skip_mask = 8, 256, 63, 1 << 4
@@ -47,7 +47,7 @@ def test_backward_entry_points_validate_on_the_host():
     d.D, d.W, d.in_channels_xyz, d.skip_mask = 8, 256, 63, 1 << 4
     d.extra_feat_type, d.extra_feat_dim = L.MF_EXTRA_DIR, 27
     # transposed stream: (W/2 -> W) + (W+sigma -> W) + 7 x (W -> W) panels, 1 KiB groups
-    want = (16 + 34 + 32 * 7) * 8 * 1024
+    want = ((16 + 34 + 32 * 7) * 8 + 2 * 32 * 2) * 1024     # + the two embedded-input-gradient layers (64 rows each)
     got = lib.mf_nerf_bwd_packed_bytes(ctypes.byref(d))
     assert want < got <= want + 4096
     d.W = 128
