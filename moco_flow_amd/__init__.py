@@ -2,8 +2,10 @@
 
 Drop-in surface (same names / signatures as the reference's ``models`` package):
     Embedding, NeRF, NoF, get_model, get_loss, render_rays, sample_pdf
-Everything computes in hand-written HIP kernels reached through the C ABI in
-include/mocoflow_hip.h (libmocoflow_hip.so); there is no CPU or eager-PyTorch fallback.
+Every forward value comes from hand-written HIP kernels reached through the C ABI in include/mocoflow_hip.h
+(libmocoflow_hip.so); CPU tensors and a missing library raise.  Backward: HIP for fp32 render_rays passes and the
+NoF module call; a recompute with PyTorch-ROCm device ops for bf16 passes, the sigma-only coarse pass of test_time
+and module-level NeRF / Embedding calls under grad (rendering.py header).
 """
 from .embedding import Embedding
 from .factory import get_loss, get_model
@@ -11,7 +13,7 @@ from .losses import MSELoss
 from .nerf import NeRF
 from .nof import NoF
 from .points import query_sigma
-from .rendering import render_rays, resample_merge, sample_pdf, set_precision, set_train_forward
+from .rendering import render_rays, resample_merge, sample_pdf, set_precision
 
 __all__ = ["Embedding", "NeRF", "NoF", "get_model", "get_loss", "render_rays", "sample_pdf",
-           "resample_merge", "set_precision", "set_train_forward", "query_sigma", "MSELoss"]
+           "resample_merge", "set_precision", "query_sigma", "MSELoss"]

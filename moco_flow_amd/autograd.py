@@ -14,8 +14,8 @@ Forward values always come from the fused HIP kernels.  When gradients are reque
   No forward recompute of the NeRF, no autograd graph over any MLP, no library GEMM.  Measured (MI355X):
   stage-1 step (5120 rays x (128 + 256) samples) 59 ms vs 154 ms for the reference's own op sequence
   under PyTorch-ROCm autograd on the same GPU; joint MoCo stage (1024 rays x 384 samples, local + global
-  chains) 31 ms vs 139 ms.  ``set_nerf_backward("gemm")`` / ``set_nof_backward("torch")`` /
-  ``set_composite_backward("torch")`` select the earlier library-GEMM / torch-recompute variants (A/B).
+  chains) 29 ms vs 138 ms.  (_NERF_BACKWARD / _NOF_BACKWARD / _COMPOSITE_BACKWARD are timing-comparison hooks for
+  tools/ab_switches.py -- library-GEMM / torch-recompute variants -- not part of the drop-in surface.)
 * everything else (module-level calls, bf16, sigma-only coarse pass): ``RecomputeBackward`` re-runs the
   pass with differentiable device ops (the reference's op sequence: models/nerf.py:78-102,
   models/nof.py:69-82, models/embedding.py:42-46, models/rendering.py:49-192) on exactly the depths /
@@ -224,14 +224,7 @@ def embed_backward(emb, x, g_emb):
     return g
 
 
-NERF_BACKWARD = "hip"     # "hip": fused dX chain (mf_nerf_backward) + library dW GEMMs; "gemm": library GEMMs only
-
-
-def set_nerf_backward(kind: str) -> None:
-    global NERF_BACKWARD
-    if kind not in ("hip", "gemm"):
-        raise ValueError(f"nerf backward: {kind} not valid (hip | gemm)")
-    NERF_BACKWARD = kind
+_NERF_BACKWARD = "hip"     # "hip": fused dX chain + mf_weight_grads; "gemm" (tools/ab_switches.py): library GEMMs only
 
 
 def nerf_backward_hip(m, g_out, acts, rgbsig, want_emb=False):
@@ -299,14 +292,7 @@ def weight_grads(jobs, P, dev):
 
 
 # ------------------------------------------------------------------ NoF evaluation on points, HIP forward + backward
-NOF_BACKWARD = "hip"      # "hip": mf_nof_points_dump / mf_nof_backward / mf_weight_grads; "torch": differentiable recompute
-
-
-def set_nof_backward(kind: str) -> None:
-    global NOF_BACKWARD
-    if kind not in ("hip", "torch"):
-        raise ValueError(f"nof backward: {kind} not valid (hip | torch)")
-    NOF_BACKWARD = kind
+_NOF_BACKWARD = "hip"      # "hip": mf_nof_points_dump / mf_nof_backward / mf_weight_grads; "torch" (tools/ab_switches.py)
 
 
 def nof_hip_supported(m, nof_embs) -> bool:
@@ -458,7 +444,7 @@ class NofPoints(torch.autograd.Function):
 def nof_points(xyz, ray_ind, nof_embs, m):
     """_nof_points with the HIP forward/backward node when the configuration is built (else torch ops)."""
     N, S = xyz.shape[0], xyz.shape[1]
-    if NOF_BACKWARD == "hip" and nof_hip_supported(m, nof_embs) and N * S > 0:
+    if _NOF_BACKWARD == "hip" and nof_hip_supported(m, nof_embs) and N * S > 0:
         return NofPoints.apply(m, nof_embs, ray_ind, S, xyz.reshape(-1, 3), *m.parameters()).view(N, S, 3)
     return _nof_points(xyz, ray_ind, nof_embs, m)
 
@@ -468,9 +454,9 @@ class NerfSamples(torch.autograd.Function):
     kernel's output (``rgbsig``, dumped).  Backward, per layer
         g_pre = g (.) (h > 0),   g_in = g_pre @ W,   dW = g_pre^T @ input,   db = sum g_pre:
     the g_pre / g_in chain of all layers is ONE fused HIP launch over the kernel's activation dump
-    (mf_nerf_backward: the forward's register-resident MFMA core on the transposed weights); the dW
-    are plain library GEMMs (PyTorch-ROCm matmul = rocBLAS/hipBLASLt) on (dump, g_pre).  No forward
-    recompute, no autograd graph over the 12-layer MLP.  Inputs that may need grad: the points
+    (mf_nerf_backward_x: the forward's register-resident MFMA core on the transposed weights, incl. the gradient of
+    the embedded input); every dW / db comes from ONE persistent launch (mf_weight_grads) on (dump, g_pre).  No
+    forward recompute, no autograd graph over the 12-layer MLP, no library GEMM.  Inputs that may need grad: the points
     ``xin`` (under NoF) and every NeRF parameter."""
 
     @staticmethod
@@ -496,7 +482,7 @@ class NerfSamples(torch.autograd.Function):
             h = lambda l: acts[:, l * W:(l + 1) * W]
             f = acts[:, D * W:(D + 1) * W]
             e2 = acts[:, (D + 1) * W:(D + 1) * W + W // 2]
-            fused = (NERF_BACKWARD == "hip" and acts.shape[0] > 0 and W == 256 and cin <= 64
+            fused = (_NERF_BACKWARD == "hip" and acts.shape[0] > 0 and W == 256 and cin <= 64
                      and m.extra_feat_dim <= 32 and D + len([s for s in m.skips if 0 < s < D]) + 4 <= L.MF_WG_MAX_ITEMS)
             if fused:
                 n_skip = len([s_ for s_ in m.skips if 0 < s_ < D])
@@ -609,14 +595,7 @@ class NerfSamples(torch.autograd.Function):
         return (None, None, None, None, None, None, g_xin) + tuple(grads[n] for n in names)
 
 
-COMPOSITE_BACKWARD = "hip"   # "hip": mf_composite_backward; "torch": composite_from_samples under autograd
-
-
-def set_composite_backward(kind: str) -> None:
-    global COMPOSITE_BACKWARD
-    if kind not in ("hip", "torch"):
-        raise ValueError(f"composite backward: {kind} not valid (hip | torch)")
-    COMPOSITE_BACKWARD = kind
+_COMPOSITE_BACKWARD = "hip"   # "hip": mf_composite_backward; "torch" (tools/ab_switches.py): composite_from_samples under autograd
 
 
 class CompositeSamples(torch.autograd.Function):

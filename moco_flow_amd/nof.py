@@ -91,7 +91,7 @@ class NoF(nn.Module):
         from . import autograd as A
         wrt = [t for t in (inputs, xyz) if torch.is_grad_enabled() and t.requires_grad]
         B = inputs.shape[0]
-        if (A.needs_grad([self]) and not wrt and B > 0 and A.NOF_BACKWARD == "hip"
+        if (A.needs_grad([self]) and not wrt and B > 0 and A._NOF_BACKWARD == "hip"
                 and A.nof_hip_supported(self, None)):
             # training call on data points (stage 2, SMPL-point losses): HIP forward-with-dump + HIP backward
             return A.NofModule.apply(self, inputs, xyz, *self.parameters())

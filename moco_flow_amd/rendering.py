@@ -31,20 +31,15 @@ def set_precision(p: str):
     PRECISION = p
 
 
-# What runs when gradients are requested (training):
-#   "hip"   (default) forward values from the fused HIP kernels, backward = differentiable recompute
-#           (autograd.py). Every number a caller sees comes from the kernels; costs one extra forward.
-#   "torch" the differentiable PyTorch-ROCm device path is the forward too (no duplicate work):
-#           reference-speed training until the fused HIP backward lands. The
-#           resampling still runs in the HIP kernel. Inference (no_grad) is always the HIP path.
-TRAIN_FORWARD = "hip"
-
-
-def set_train_forward(mode: str):
-    global TRAIN_FORWARD
-    if mode not in ("hip", "torch"):
-        raise ValueError(f"train forward must be 'hip' or 'torch', got {mode!r}")
-    TRAIN_FORWARD = mode
+# Training (gradients requested): forward values ALWAYS come from the fused HIP kernels.  The backward is
+#   * hand-written HIP for every fp32 render_rays pass that evaluates the full NeRF: mf_composite_backward,
+#     mf_nerf_backward_x (+ mf_embedding_backward under NoF), mf_weight_grads, mf_nof_points_dump / mf_nof_backward
+#     (autograd.py); torch evaluates only the loss;
+#   * a differentiable recompute with PyTorch-ROCm device ops (autograd.RecomputeBackward) for what is not built in
+#     HIP: bf16 passes, the sigma-only coarse pass of test_time, network shapes outside the fused envelope.
+# _TRAIN_FORWARD is a timing-comparison hook for tools/ab_switches.py ("torch": the whole pass as eager device ops,
+# i.e. what the reference itself would run on this GPU); it is not part of the drop-in surface.
+_TRAIN_FORWARD = "hip"
 
 
 # Draw torch.randn(N,S) in every pass even when noise_std == 0, as the reference does
@@ -312,7 +307,7 @@ def render_rays(rays,
     coarse_sigma_only = bool(need_fine and test_time)                  # rendering.py:290-294
     want_planes = need_fine or loc or glob or grad or _capture is not None
     noise_c = draw_noise((N, S), "noise_coarse")
-    if grad and N > 0 and TRAIN_FORWARD == "torch":
+    if grad and N > 0 and _TRAIN_FORWARD == "torch":
         return _torch_training_render(rays, background, nerf_embeddings, nerf_models, nof_embeddings,
                                       nof_models if use_nof else None, loc, glob, nerf_activate_type,
                                       coarse_sigma_only, z_vals, noise_c, N_importance, perturb == 0,
@@ -370,7 +365,7 @@ def render_rays(rays,
 
 def _torch_training_render(rays, background, nerf_embs, nerf_models, nof_embs, nof_models, loc, glob, activation,
                            coarse_sigma_only, z_c, noise_c, n_importance, det, draw_noise_f, u):
-    """TRAIN_FORWARD == "torch": both passes with differentiable device ops (autograd.render_pass);
+    """_TRAIN_FORWARD == "torch": both passes with differentiable device ops (autograd.render_pass);
     only the (detached) hierarchical resample runs in the HIP kernel."""
     result = {}
 
@@ -400,7 +395,7 @@ def _torch_training_render(rays, background, nerf_embs, nerf_models, nof_embs, n
 
 def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs, nof_models, loc, glob,
                      activation, coarse, fine, loss_target=None):
-    """Training graph on top of the fused forward (TRAIN_FORWARD == "hip", fp32): values are the HIP
+    """Training graph on top of the fused forward (fp32): values are the HIP
     kernels' outputs; gradients flow through
       * autograd.CompositeSamples -- mf_composite_backward on the dumped per-sample (rgb, sigma) planes,
       * autograd.NerfSamples -- mf_nerf_backward + mf_weight_grads over the kernel's activation dump
@@ -447,7 +442,7 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
                 extra_in = A._pad_to(torch.repeat_interleave(A.embed(nerf_embs[2], rays_d), S, dim=0), nerf.extra_feat_dim)
         rgbsig = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, nerf_embs[0], xin,
                                      *nerf.parameters())
-        if A.COMPOSITE_BACKWARD == "hip" and activation in ("relu", "softplus") and S <= 2048:
+        if A._COMPOSITE_BACKWARD == "hip" and activation in ("relu", "softplus") and S <= 2048:
             out[f"rgb_{tag}"], out[f"depth_{tag}"], out[f"opacity_{tag}"] = A.CompositeSamples.apply(
                 rgbsig, rays, z, noise, activation, background, result[f"rgb_{tag}"], result[f"depth_{tag}"],
                 result[f"opacity_{tag}"])

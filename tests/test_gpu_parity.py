@@ -11,6 +11,11 @@ from helpers import build_case, case_inputs, load_golden, relerr
 
 pytestmark = pytest.mark.gpu
 
+import os as _os
+import sys as _sys
+_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools"))
+import ab_switches as AB   # noqa: E402  (tools/ab_switches.py: timing-comparison switches, not package surface)
+
 TOL = 1e-4
 
 
@@ -715,8 +720,8 @@ def test_training_loop_converges(M):
 
 
 def test_train_forward_torch_mode_matches_hip_mode(M):
-    """TRAIN_FORWARD="torch" (reference-speed training path) returns the same values and gradients as the
-    default mode (HIP forward + recompute backward), with the same keys in the same order."""
+    """The eager-torch comparison path of the timing tools (tools/ab_switches.py) returns the same values and
+    gradients as the shipped path (HIP forward + HIP backward nodes), with the same keys in the same order."""
     from moco_flow_amd import rendering
     c = dict(RENDER_CASES["r_moco_global_fine"])
     seed = int(load_golden("r_moco_global_fine")["meta_seed"])
@@ -735,10 +740,10 @@ def test_train_forward_torch_mode_matches_hip_mode(M):
 
     a, ga = run()
     try:
-        rendering.set_train_forward("torch")
+        AB.set_train_forward("torch")
         b, gb = run()
     finally:
-        rendering.set_train_forward("hip")
+        AB.set_train_forward("hip")
     assert list(a.keys()) == list(b.keys())
     for k in a:
         if a[k].shape == b[k].shape:
@@ -878,7 +883,7 @@ def test_explicit_nerf_backward_unit(M, kind, n_rays):
     from moco_flow_amd import autograd as A, rendering, synth
     import ctypes as C
     torch.manual_seed(0)
-    A.set_nerf_backward(kind)
+    AB.set_nerf_backward(kind)
     c = dict(RENDER_CASES["r_nerf_ind_dense"])
     embs, nerfs, kw = build_case(M, c, 21, device="cuda")
     nerf = nerfs[0]
@@ -900,7 +905,7 @@ def test_explicit_nerf_backward_unit(M, kind, n_rays):
     try:
         out.backward(gout)
     finally:
-        A.set_nerf_backward("hip")
+        AB.set_nerf_backward("hip")
     got = {n: (q.grad.clone() if q.grad is not None else None) for n, q in nerf.named_parameters()}
     got_x = xin.grad.clone()
     nerf.zero_grad(set_to_none=True)

@@ -51,3 +51,22 @@ for sub in ("pmc_mfma", "pmc_fetch", "pmc_write", "pmc_wait"):
         if k == "WRITE_SIZE":
             kb = sum(v) / len(v)
             print(f"{'':10s} -> HBM write {kb*1024/1e6:.3f} MB per launch (uncalibrated)")
+
+# traffic.json entry for bench.py's roofline.traffic (HBM bytes per launch of the dominant kernel: FETCH_SIZE x2 per
+# the gfx950 note + WRITE_SIZE, both in KiB units as rocprofv3 reports them)
+import json
+vals = {}
+for sub in ("pmc_fetch", "pmc_write"):
+    acc = defaultdict(list)
+    for r in rows(f"{sub}/**/*counter_collection.csv"):
+        if dom and r["Kernel_Name"] != dom:
+            continue
+        acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for k, v in acc.items():
+        vals[k] = sum(v) / len(v)
+if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
+    entry = {"bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
+             "fetch_kib_raw": vals["FETCH_SIZE"], "write_kib": vals["WRITE_SIZE"], "kernel": dom}
+    with open(os.path.join(out, "traffic_entry.json"), "w") as fh:
+        json.dump(entry, fh)
+    print("\ntraffic entry:", json.dumps(entry))

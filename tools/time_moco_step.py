@@ -6,7 +6,9 @@ PyTorch-ROCm eager ops (TRAIN_FORWARD=torch: what the reference itself would run
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import moco_flow_amd as M
+import ab_switches as AB   # tools/ab_switches.py
 from moco_flow_amd import synth, rendering
 rendering.STRICT_RNG = False
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
@@ -57,5 +59,5 @@ print(f"N_rand={N} rays x ({S} + {S+Mi}) samples = {N*(2*S+Mi)/1e6:.2f} M sample
 print(f"  HIP forward (no_grad)            : {timeit(fwd_only):8.2f} ms")
 print(f"  HIP forward + backward (shipped) : {timeit(fwd_bwd):8.2f} ms")
 if os.environ.get("MF_ONLY") != "hipbwd":
-    rendering.set_train_forward("torch")
+    AB.set_train_forward("torch")
     print(f"  TRAIN_FORWARD=torch fwd+bwd      : {timeit(fwd_bwd):8.2f} ms")

@@ -5,7 +5,9 @@ through the backward and the forward NoF called as modules, L2 losses) through t
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import moco_flow_amd as M
+import ab_switches as AB   # tools/ab_switches.py
 from moco_flow_amd import autograd as A, synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 dev = torch.device("cuda")
@@ -36,7 +38,7 @@ def timeit(f, n=5):
 
 print(f"{B} correspondence points, bw + fw NoF, forward + backward")
 print(f"  HIP forward + HIP backward (shipped)      : {timeit(lambda: step(lambda m, i, x: m(i, x))):7.2f} ms")
-A.set_nof_backward("torch")
+AB.set_nof_backward("torch")
 print(f"  HIP forward + torch-recompute backward   : {timeit(lambda: step(lambda m, i, x: m(i, x))):7.2f} ms")
-A.set_nof_backward("hip")
+AB.set_nof_backward("hip")
 print(f"  PyTorch-ROCm eager (reference op sequence): {timeit(lambda: step(lambda m, i, x: A.nof_forward(m, i, x))):7.2f} ms")

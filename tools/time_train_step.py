@@ -5,7 +5,9 @@ same pass done entirely with PyTorch-ROCm ops (what the reference itself would r
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import moco_flow_amd as M
+import ab_switches as AB   # tools/ab_switches.py
 from moco_flow_amd import synth, autograd as A, rendering
 rendering.STRICT_RNG = False
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
@@ -42,8 +44,8 @@ print(f"N_rand={N} rays x ({S} + {S+Mi}) samples = {N*(2*S+Mi)/1e6:.2f} M sample
 print(f"  HIP forward (no_grad)            : {timeit(fwd_only):8.2f} ms")
 print(f"  PyTorch-ROCm eager forward        : {timeit(eager_fwd):8.2f} ms")
 print(f"  HIP forward + HIP dX chain + dW GEMMs : {timeit(fwd_bwd):8.2f} ms")
-A.set_nerf_backward("gemm")
+AB.set_nerf_backward("gemm")
 print(f"  HIP forward + library-GEMM backward   : {timeit(fwd_bwd):8.2f} ms")
-A.set_nerf_backward("hip")
-rendering.set_train_forward("torch")
+AB.set_nerf_backward("hip")
+AB.set_train_forward("torch")
 print(f"  TRAIN_FORWARD=torch fwd+bwd       : {timeit(fwd_bwd):8.2f} ms")
