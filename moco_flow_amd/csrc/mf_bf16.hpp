@@ -36,6 +36,20 @@ constexpr int PD = MF_BF_PD;
 #define MF_MFMA32(a, b, c) \
   __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
+#ifdef MF_BF_DBG_JITTER
+MF_D void jitter() {       // race screen: a pseudo-random stall per wave
+  const unsigned t = (unsigned)__builtin_readcyclecounter();
+  switch ((t >> 3) & 3u) {
+    case 1: __builtin_amdgcn_s_sleep(3); break;
+    case 2: __builtin_amdgcn_s_sleep(11); break;
+    case 3: __builtin_amdgcn_s_sleep(40); break;
+    default: break;
+  }
+}
+#else
+MF_D void jitter() {}
+#endif
+
 struct Lane {
   int lane, wave, j, h;
   MF_D Lane() {
@@ -62,6 +76,7 @@ struct Stream {
   const char* dsrc; uint32_t ddst; uint32_t pmask;
   MF_D void sync(int groups, const char* jump, const Lane& id) {
     // (MF_BF_ABL_*: timing-ablation builds only, tools/ab_lib.sh; results are garbage there)
+    jitter();
 #ifndef MF_BF_ABL_NOWAIT
     wait_vm0();                              // this wave's pieces of the NEXT panel have landed
 #endif
@@ -295,7 +310,7 @@ MF_D void trunk_layer_m(const Net& net, int layer, bool relu, u32x4 (&act)[KH], 
   const int groups = tgroups<KH, NGE>(net, layer);
   const unsigned lo = relu ? 0u : 0x80008000u;      // ReLU / pass-through floor
   const uint32_t bias_off = net.res_lds + layer * (16 * KH) * 4;
-#ifndef MF_BF_ABL_NOSTAGGER
+#if !defined(MF_BF_ABL_NOSTAGGER)
   const bool late = id.wave < kWaves / 2;
 #else
   const bool late = false;
@@ -368,7 +383,7 @@ MF_D void valu_head(const u32x4 (&act)[KH], uint32_t w_byte_off, uint32_t b_byte
 // addresses.  dst[0..SLOTS) of block (C,F) for lane half h; arg = freq*x rounded to fp32 before sin/cos exactly as
 // `func(freq*x)` in embedding.py:45.
 template <int C, int F>
-MF_D void emb_eval(float* dst, const float (&v)[C], uint32_t par_off, int h) {
+MF_D void emb_eval_direct(float* dst, const float (&v)[C], uint32_t par_off, int h) {
   using B = EmbBlock2<C, F>;
 #pragma unroll
   for (int pi = 0; pi < B::NPI; ++pi) {
@@ -401,6 +416,63 @@ MF_D void emb_eval(float* dst, const float (&v)[C], uint32_t par_off, int h) {
 #endif
     dst[2 * pi] = real ? w * sn : (h ? ra1 : ra0);
     dst[2 * pi + 1] = real ? w * cs : (h ? rb1 : rb0);
+  }
+}
+
+// The same for the logscale tables every configuration of the reference uses (freq_bands = 2^k, embedding.py:19;
+// `pow2` is checked on the host): a lane half owns, for each of its C chains (chain j = pi mod C: component
+// (2j + h) mod C), every SECOND frequency f = f_start + 2m, so consecutive entries of a chain are angle quadruplings:
+//     sin 2a = 2 sin a cos a,  cos 2a = 1 - 2 sin^2 a,   twice.
+// An exact sincosf re-seeds each chain every third entry, so no value is more than two quadruplings (four doublings:
+// <= 16 x the 1e-7 of the seed, 2e-6) from an exact one -- an order of magnitude under the 2^-16 of the split bf16
+// operands the values are rounded to.  6 sincosf instead of 15 per NeRF encoding and lane, 6 instead of 18 per NoF input.
+template <int C, int F>
+MF_D void emb_eval(float* dst, const float (&v)[C], uint32_t par_off, int h, bool pow2) {
+  using B = EmbBlock2<C, F>;
+#ifdef MF_BF_ABL_NODOUBLING
+  pow2 = false;
+#endif
+  if (!pow2) { emb_eval_direct<C, F>(dst, v, par_off, h); return; }
+  float cs_[C], sn_[C];                                    // the chains' current (cos, sin)
+#pragma unroll
+  for (int pi = 0; pi < B::NPI; ++pi) {
+    const int p0 = 2 * pi, p1 = 2 * pi + 1;
+    const bool real0 = p0 < B::NPAIR, real1 = p1 < B::NPAIR;
+    const int q0 = real0 ? 0 : 2 * (p0 - B::NPAIR), q1 = real1 ? 0 : 2 * (p1 - B::NPAIR);
+    const float ra0 = (!real0 && p0 < B::NALL && q0 < C) ? v[q0 < C ? q0 : 0] : 0.f;
+    const float rb0 = (!real0 && p0 < B::NALL && q0 + 1 < C) ? v[q0 + 1 < C ? q0 + 1 : 0] : 0.f;
+    const float ra1 = (!real1 && p1 < B::NALL && q1 < C) ? v[q1 < C ? q1 : 0] : 0.f;
+    const float rb1 = (!real1 && p1 < B::NALL && q1 + 1 < C) ? v[q1 + 1 < C ? q1 + 1 : 0] : 0.f;
+    if (!real0 && !real1) {
+      dst[2 * pi] = h ? ra1 : ra0;
+      dst[2 * pi + 1] = h ? rb1 : rb0;
+      continue;
+    }
+    const int j = pi % C, m = pi / C;                      // chain, entry within the chain
+    const int f0 = real0 ? p0 / C : 0, c0 = real0 ? p0 % C : 0;
+    const int f1 = real1 ? p1 / C : 0, c1 = real1 ? p1 % C : 0;
+    const int f = h ? f1 : f0;
+    if (m % 3 == 0) {                                      // seed: exact
+      const float x = h ? v[c1] : v[c0];
+      const float fr = lds_f(par_off + 4 * f);
+#ifndef MF_BF_ABL_NOSINCOS
+      sincosf(fr * x, &sn_[j], &cs_[j]);
+#else
+      sn_[j] = fr * x; cs_[j] = fr - x;
+#endif
+    } else {                                               // two doublings: f -> f + 2
+#pragma unroll
+      for (int d = 0; d < 2; ++d) {
+        const float t = sn_[j] + sn_[j];
+        const float s2 = t * cs_[j];
+        cs_[j] = __builtin_fmaf(-t, sn_[j], 1.f);
+        sn_[j] = s2;
+      }
+    }
+    const float w = lds_f(par_off + 64 + 4 * f);
+    const bool real = h ? real1 : real0;
+    dst[2 * pi] = real ? w * sn_[j] : (h ? ra1 : ra0);
+    dst[2 * pi + 1] = real ? w * cs_[j] : (h ? rb1 : rb0);
   }
 }
 
@@ -538,11 +610,11 @@ MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofIn], const u32x4 (&x
 
 // NoF input operands from a point and an image index (rendering.py:70-75)
 MF_D void nof_embed(u32x4 (&xhi)[kKsNofIn], u32x4 (&xlo)[kKsNofIn], const float (&xyz)[3], float ind, uint32_t par_xyz,
-                    uint32_t par_ind, int h) {
+                    uint32_t par_ind, int h, bool pow2_xyz, bool pow2_ind) {
   float emb[B2Xyz5::SLOTS + B2Ind16::SLOTS];
-  emb_eval<3, 5>(emb, xyz, par_xyz, h);
+  emb_eval<3, 5>(emb, xyz, par_xyz, h, pow2_xyz);
   const float iv[1] = {ind};
-  emb_eval<1, 16>(emb + B2Xyz5::SLOTS, iv, par_ind, h);
+  emb_eval<1, 16>(emb + B2Xyz5::SLOTS, iv, par_ind, h, pow2_ind);
   split_operands<kKsNofIn>(emb, B2Xyz5::SLOTS + B2Ind16::SLOTS, xhi, xlo);
 }
 

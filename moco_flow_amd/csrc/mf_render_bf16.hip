@@ -26,6 +26,7 @@ struct Params {
   int G;
   long long n_groups;
   uint32_t par_off, ring_off, buf_bytes, sbuf_off, zbuf_off;
+  int pow2;                        // bit t: table t's frequencies are exactly 2^k (the logscale default)
 };
 
 MF_D float wave_scan_mul(float v, int lane) {
@@ -120,7 +121,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
           const Next follow = last ? first_of<16, kKsNerfXyz>(p.nerf) : first_of<8, kKsNofIn>(next_fw ? p.fw : p.bw);
           u32x4 nhi[kKsNofIn], nlo[kKsNofIn];
           float out[3];
-          nof_embed(nhi, nlo, cur, ind, par_nof_xyz, par_nof_ind, id.h);
+          nof_embed(nhi, nlo, cur, ind, par_nof_xyz, par_nof_ind, id.h, p.pow2 & 4, p.pow2 & 8);
           nof_eval(net, nhi, nlo, cur, st, carry, id, follow, out);
           if (role == 0) { canon[0] = out[0]; canon[1] = out[1]; canon[2] = out[2]; }
           if (role == 1) dl = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
@@ -137,7 +138,8 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
       u32x4 xhi[kKsNerfXyz], xlo[kKsNerfXyz];
       {
         float embx[B2Xyz10::SLOTS];
-        emb_eval<3, 10>(embx, xin, par_nerf_xyz, id.h);
+        jitter();
+        emb_eval<3, 10>(embx, xin, par_nerf_xyz, id.h, p.pow2 & 1);
         split_operands<kKsNerfXyz>(embx, B2Xyz10::SLOTS, xhi, xlo);
       }
       auto make_extra = [&](u32x4 (&ehi)[kKsExtraMax], u32x4 (&elo)[kKsExtraMax]) {
@@ -146,10 +148,10 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
         for (int e = 0; e < 8 * kKsExtraMax; ++e) ext[e] = 0.f;
         if (p.extra_type == MF_EXTRA_DIR) {
           const float dd[3] = {rp[3], rp[4], rp[5]};
-          emb_eval<3, 4>(ext, dd, par_nerf_ext, id.h);                         // rendering.py:138-142
+          emb_eval<3, 4>(ext, dd, par_nerf_ext, id.h, p.pow2 & 2);                         // rendering.py:138-142
         } else if (p.extra_type == MF_EXTRA_IND) {
           const float iv[1] = {rp[8]};
-          emb_eval<1, 2>(ext, iv, par_nerf_ext, id.h);                         // rendering.py:133-137
+          emb_eval<1, 2>(ext, iv, par_nerf_ext, id.h, p.pow2 & 2);                         // rendering.py:133-137
         }
         split_operands<kKsExtraMax>(ext, 8 * kKsExtraMax, ehi, elo);
       };
@@ -222,11 +224,14 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
   wait_vm0();   // the stream runs two panels ahead: drain the LDS-DMA before the workgroup retires
 }
 
-static void emb_table(const mf_embedding& e, float* dst) {
+static bool emb_table(const mf_embedding& e, float* dst) {      // returns: frequencies are exactly 2^k
+  bool pow2 = true;
   for (int k = 0; k < 16; ++k) {
     dst[k] = k < e.n_freqs ? e.freq[k] : 0.f;
     dst[16 + k] = k < e.n_freqs ? e.weight[k] : 0.f;
+    if (k < e.n_freqs && e.freq[k] != (float)(1 << k)) pow2 = false;
   }
+  return pow2;
 }
 
 }  // namespace bf
@@ -245,8 +250,7 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st) {
   p.S = a->n_samples; p.z_vals = a->z_vals; p.z_steps = a->z_steps; p.use_disp = a->use_disp;
   p.noise = a->noise; p.activation = a->activation; p.flags = a->flags;
   p.extra_type = a->nerf->extra_feat_type;
-  emb_table(a->emb_xyz, p.emb_par[0]);
-  emb_table(a->emb_extra, p.emb_par[1]);
+  p.pow2 = (emb_table(a->emb_xyz, p.emb_par[0]) ? 1 : 0) | (emb_table(a->emb_extra, p.emb_par[1]) ? 2 : 0);
   p.rgb = a->rgb; p.depth = a->depth; p.opacity = a->opacity; p.weights = a->weights; p.alphas = a->alphas;
   p.disp_local = a->disp_local; p.disp_global = a->disp_global;
 
@@ -273,8 +277,7 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st) {
       p.fw = net_of(Lf, a->nof_fw_packed, Lf.n_trunk, Lf.n_head);
       if (Lf.max_groups > max_groups) max_groups = Lf.max_groups;
     }
-    emb_table(a->nof_emb_xyz, p.emb_par[2]);
-    emb_table(a->nof_emb_ind, p.emb_par[3]);
+    p.pow2 |= (emb_table(a->nof_emb_xyz, p.emb_par[2]) ? 4 : 0) | (emb_table(a->nof_emb_ind, p.emb_par[3]) ? 8 : 0);
   }
   p.par_off = lds; lds += 512;
   p.ring_off = lds;

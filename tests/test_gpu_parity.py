@@ -580,6 +580,34 @@ def test_c4_shards_moco_bf16_bit_identical(M):
         assert torch.equal(a[k], torch.cat([p[k] for p in parts], 0)), k
 
 
+@pytest.mark.parametrize("precision", ["f32", "bf16"])
+@pytest.mark.parametrize("name", ["r_nerf_dir_dense", "r_moco_local", "r_moco_global", "r_moco_global_fine"])
+def test_repeat_runs_bit_identical(M, name, precision):
+    """Race / hazard screen of the fused render kernels: the same call, repeated, returns the same bits in every
+    plane.  (The weight stream is LDS-DMA under one barrier per panel with two wave roles; a bf16 build whose
+    embedding used packed-fp32 VALU ops differed between runs in ~6 % of the rays -- csrc/Makefile.)"""
+    from moco_flow_amd import rendering, synth
+    c = dict(RENDER_CASES[name])
+    n = 4096 if c["M"] == 0 else 1024
+    rays_np, bg_np = synth.rays(0, n, chained=(c.get("nof") == "global"))
+    rays, bg = torch.from_numpy(rays_np).cuda(), torch.from_numpy(bg_np).cuda()
+    embs, nerfs, kw = build_case(M, c, 0, device="cuda")
+    strict = rendering.STRICT_RNG
+    try:
+        rendering.STRICT_RNG = False
+        rendering.set_precision(precision)
+        with torch.no_grad():
+            ref = M.render_rays(rays, bg, embs, nerfs, **kw)
+            for rep in range(10):
+                out = M.render_rays(rays, bg, embs, nerfs, **kw)
+                for k in ref:
+                    assert ref[k].shape == out[k].shape, (k, rep)
+                    assert torch.equal(ref[k], out[k]), (k, rep, int((ref[k] != out[k]).sum()))
+    finally:
+        rendering.set_precision("f32")
+        rendering.STRICT_RNG = strict
+
+
 @pytest.mark.parametrize("name", ["r_nerf_dir_fine_train", "r_moco_global_fine"])
 def test_stochastic_branches_with_injected_draws(M, R, name):
     """perturb > 0 (stratified jitter, rendering.py:253-260), noise_std > 0 (:166) and the stochastic
