@@ -30,7 +30,7 @@ extern "C" {
  * (mf_nof_points_dump, mf_nof_backward); 6: mf_composite_backward, mf_image_compose;
  * 7: mf_nof_forward_dump; 8: mf_loss_partials, new packed layout of MF_PREC_BF16 (32x32x16 fragments);
  * 9: mf_valid_rays_mask, mf_nerf_backward_x (embedded-input gradient in the chain launch), mf_embedding_backward */
-#define MF_ABI_VERSION 9
+#define MF_ABI_VERSION 10
 
 enum {
   MF_OK = 0,
@@ -123,6 +123,14 @@ int32_t mf_embedding_forward(const mf_embedding* e, const float* x, int64_t B, f
  * stride `in_stride` floats -> out (B,4) = [rgb, sigma], or (B,1) sigma when sigma_only. */
 int32_t mf_nerf_forward(const mf_nerf_desc* d, const void* packed, const float* inputs,
                         int64_t in_stride, int64_t B, int32_t sigma_only, float* out, void* stream);
+
+/* The same call when gradients are wanted (trainer_moco_flow.py:146-157 `forwarf_nerf`, :337-362: NeRF called on
+ * embedded points with requires_grad inputs): the full forward (out (B,4)) that also writes the per-sample layer
+ * outputs [h_0 .. h_{D-1} | xyz_encoding_final | extra_encoding] to dump_acts (B, dump_stride >= (D+1) W + W/2),
+ * the layout mf_nerf_backward / mf_weight_grads consume -- the module-level counterpart of
+ * mf_render_args.dump_acts.  (ABI v10) */
+int32_t mf_nerf_forward_dump(const mf_nerf_desc* d, const void* packed, const float* inputs, int64_t in_stride,
+                             int64_t B, float* out, float* dump_acts, int64_t dump_stride, void* stream);
 
 /* NoF.forward, models/nof.py:55-85: inputs (B, in_channels_xyz+extra_feat_dim), xyz (B,3) -> (B,3). */
 int32_t mf_nof_forward(const mf_nof_desc* d, const void* packed, const float* inputs,

@@ -16,7 +16,7 @@ MF_EXTRA_NONE, MF_EXTRA_IND, MF_EXTRA_DIR = 0, 1, 2
 MF_ACT_RELU, MF_ACT_SOFTPLUS = 0, 1
 MF_F_SIGMA_ONLY, MF_F_CHAIN_LOCAL, MF_F_CHAIN_GLOBAL = 1, 2, 4
 MF_PREC_F32, MF_PREC_BF16 = 0, 1
-MF_ABI_VERSION = 9
+MF_ABI_VERSION = 10
 
 LIB_PATH = os.environ.get("MOCOFLOW_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmocoflow_hip.so")   # (override: A/B builds)
 
@@ -85,6 +85,7 @@ SYMBOLS = {
     "mf_nof_pack_p": (C.c_int32, [C.POINTER(mf_nof_desc), C.c_int32, _fp, _fp]),
     "mf_embedding_forward": (C.c_int32, [C.POINTER(mf_embedding), _fp, C.c_int64, _fp, _fp]),
     "mf_nerf_forward": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, _fp, C.c_int64, C.c_int64, C.c_int32, _fp, _fp]),
+    "mf_nerf_forward_dump": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, _fp, C.c_int64, C.c_int64, _fp, _fp, C.c_int64, _fp]),
     "mf_nof_forward": (C.c_int32, [C.POINTER(mf_nof_desc), _fp, _fp, C.c_int64, _fp, C.c_int64, _fp, _fp]),
     "mf_nerf_bwd_packed_bytes": (C.c_int64, [C.POINTER(mf_nerf_desc)]),
     "mf_nerf_pack_bwd": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, _fp]),

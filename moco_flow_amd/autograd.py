@@ -16,7 +16,9 @@ Forward values always come from the fused HIP kernels.  When gradients are reque
   under PyTorch-ROCm autograd on the same GPU; joint MoCo stage (1024 rays x 384 samples, local + global
   chains) 29 ms vs 138 ms.  (_NERF_BACKWARD / _NOF_BACKWARD / _COMPOSITE_BACKWARD are timing-comparison hooks for
   tools/ab_switches.py -- library-GEMM / torch-recompute variants -- not part of the drop-in surface.)
-* everything else (module-level calls, bf16, sigma-only coarse pass): ``RecomputeBackward`` re-runs the
+* ``NeRF(x[, sigma_only])`` / ``NoF(x, xyz)`` called directly (the joint stage's point losses): ``NerfModule`` /
+  ``NofModule`` -- a dumping forward launch, then the same backward launches.
+* everything else (shapes the fused backward is not built for, the sigma-only coarse pass): ``RecomputeBackward`` re-runs the
   pass with differentiable device ops (the reference's op sequence: models/nerf.py:78-102,
   models/nof.py:69-82, models/embedding.py:42-46, models/rendering.py:49-192) on exactly the depths /
   noise / masks the kernels used.
@@ -257,6 +259,30 @@ def embed_backward_hip(emb, emb_vals, g_emb):
     return g_x
 
 
+class EmbeddingModule(torch.autograd.Function):
+    """``Embedding(x)`` with x requiring grad (embedding.py:30-47; trainer_moco_flow.py:147-149): forward
+    mf_embedding_forward, backward mf_embedding_backward on the saved embedded values."""
+
+    @staticmethod
+    def forward(ctx, emb, x):
+        xc = x.detach().contiguous().float()
+        out = torch.empty((xc.shape[0], emb.out_channels), device=xc.device, dtype=torch.float32)
+        d = emb.descriptor()
+        with torch.cuda.device(xc.device):
+            L.check(L.lib().mf_embedding_forward(d, L.ptr(xc), xc.shape[0], L.ptr(out), L.current_stream(xc.device)),
+                    "mf_embedding_forward")
+        ctx.emb = emb
+        ctx.save_for_backward(out)
+        return out.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        out, = ctx.saved_tensors
+        if out.shape[0] == 0:
+            return None, g.new_zeros((0, ctx.emb.in_channels))
+        return None, embed_backward_hip(ctx.emb, out, g.contiguous().float())
+
+
 _WG_BLOCK = {(256, 256): (256, 256), (256, 64): (256, 64), (128, 256): (128, 256), (128, 32): (128, 32), (4, 640): (16, 640),
              (128, 128): (128, 128), (128, 80): (128, 80), (12, 128): (16, 128)}
 
@@ -449,6 +475,147 @@ def nof_points(xyz, ray_ind, nof_embs, m):
     return _nof_points(xyz, ray_ind, nof_embs, m)
 
 
+def nerf_fused_eligible(m, P):
+    """Shapes the fused dX chain + mf_weight_grads launches are built for."""
+    D, W = m.D, m.W
+    return (P > 0 and W == 256 and m.in_channels_xyz <= 64 and m.extra_feat_dim <= 32
+            and D + len([s for s in m.skips if 0 < s < D]) + 4 <= L.MF_WG_MAX_ITEMS)
+
+
+def nerf_fused_grads(m, g_out, acts, rgbsig, emb, extra, want_emb, sigma_path_only=False):
+    """The HIP backward of one NeRF evaluation over its dump: mf_nerf_backward_x (every pre-activation gradient +
+    the embedded input's gradient) and ONE mf_weight_grads launch for all dW / db.
+    -> ({parameter name: grad | None}, gpre, g_emb (P,64) | None).  ``sigma_path_only``: the call was
+    NeRF(x, sigma_only=True) (nerf.py:81-95) -- xyz_encoding_final / extra_encoding / rgb did not take part and get
+    no gradient, as under torch autograd."""
+    D, W = m.D, m.W
+    cin = m.in_channels_xyz
+    names = [n for n, _ in m.named_parameters()]
+    req = {n: p.requires_grad for n, p in m.named_parameters()}
+    if sigma_path_only:
+        for n in names:
+            if n.startswith(("xyz_encoding_final", "extra_encoding", "rgb")):
+                req[n] = False
+    grads = {n: None for n in names}
+    h = lambda l: acts[:, l * W:(l + 1) * W]
+    f = acts[:, D * W:(D + 1) * W]
+    gpre, ghead, g_emb_hip = nerf_backward_hip(m, g_out, acts, rgbsig, want_emb=want_emb)
+    P, dev = acts.shape[0], acts.device
+    gslot = lambda l: gpre[:, l * W:(l + 1) * W]
+    g_e2 = gpre[:, (D + 1) * W:(D + 1) * W + W // 2]
+    wants = lambda prefix: req[prefix + ".weight"] or req[prefix + ".bias"]
+    emb64 = F.pad(emb, (0, 64 - emb.shape[1])) if emb.shape[1] < 64 else emb
+    jobs, sinks = [], []
+
+    def put(prefix, blocks, bias_from=0):
+        """blocks: [(job index, row slice, col slice)] concatenated along the columns"""
+        sinks.append((prefix, blocks, bias_from))
+
+    for l in range(D):
+        name = f"xyz_encoding_{l+1}.0"
+        if not wants(name):
+            continue
+        blocks = []
+        if l == 0 or l in m.skips:
+            jobs.append((gslot(l), emb64, 256, 64, l == 0))
+            blocks.append((len(jobs) - 1, slice(0, W), slice(0, cin)))
+        if l > 0:
+            jobs.append((gslot(l), h(l - 1), 256, 256, True))
+            blocks.append((len(jobs) - 1, slice(0, W), slice(0, W)))
+        put(name, blocks, blocks[-1][0])
+    if wants("xyz_encoding_final"):
+        jobs.append((gslot(D), h(D - 1), 256, 256, True))
+        put("xyz_encoding_final", [(len(jobs) - 1, slice(0, W), slice(0, W))], len(jobs) - 1)
+    if wants("extra_encoding.0"):
+        jobs.append((g_e2, f, 128, 256, True))
+        blocks = [(len(jobs) - 1, slice(0, W // 2), slice(0, W))]
+        if extra is not None:
+            ext32 = F.pad(extra, (0, 32 - extra.shape[1])) if extra.shape[1] < 32 else extra
+            jobs.append((g_e2, ext32, 128, 32, False))
+            blocks.append((len(jobs) - 1, slice(0, W // 2), slice(0, extra.shape[1])))
+        put("extra_encoding.0", blocks, blocks[0][0])
+    head_job = None
+    if wants("sigma") or wants("rgb.0"):
+        jobs.append((ghead, acts[:, (D - 1) * W:(D - 1) * W + 640], 4, 640, True))
+        head_job = len(jobs) - 1
+    res = weight_grads(jobs, P, dev) if jobs else []
+    for prefix, blocks, bias_from in sinks:
+        if req[prefix + ".weight"]:
+            parts = [res[j][0][rs, cs] for j, rs, cs in blocks]
+            grads[prefix + ".weight"] = parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, 1)
+        if req[prefix + ".bias"]:
+            grads[prefix + ".bias"] = res[bias_from][1][blocks[0][1]].clone()
+    if head_job is not None:
+        hW, hb = res[head_job]
+        if req["sigma.weight"]:
+            grads["sigma.weight"] = hW[3:4, 0:W].contiguous()
+        if req["sigma.bias"]:
+            grads["sigma.bias"] = hb[3:4].clone()
+        if req["rgb.0.weight"]:
+            grads["rgb.0.weight"] = hW[0:3, 2 * W:2 * W + W // 2].contiguous()
+        if req["rgb.0.bias"]:
+            grads["rgb.0.bias"] = hb[0:3].clone()
+    return grads, gpre, g_emb_hip, emb64
+
+
+class NerfModule(torch.autograd.Function):
+    """``NeRF(inputs, sigma_only)`` called directly with gradients wanted (trainer_moco_flow.py:146-157 `forwarf_nerf`
+    under the mask loss :337-362; nerf.py:61-102).  Forward: mf_nerf_forward_dump (the fused forward, also writing
+    the per-sample layer outputs).  Backward: the same two launches as a render pass' NeRF node -- mf_nerf_backward_x
+    (all pre-activation gradients + the gradient of the embedded input) and mf_weight_grads (every dW / db).
+    A sigma_only call runs the full forward on a zero extra block (its rgb branch gets zero output gradient and its
+    parameters None, as torch autograd leaves them)."""
+
+    @staticmethod
+    def forward(ctx, m, inputs, sigma_only, *params):
+        x = inputs.detach().float()
+        cin, ext_dim = m.in_channels_xyz, m.extra_feat_dim
+        if sigma_only and ext_dim > 0:
+            x = F.pad(x, (0, ext_dim))                        # the kernel reads the extra block of every row
+        x = x.contiguous()
+        B, dev = x.shape[0], x.device
+        stride = (m.D + 1) * m.W + m.W // 2
+        acts = torch.empty((B, stride), device=dev, dtype=torch.float32)
+        out = torch.empty((B, 4), device=dev, dtype=torch.float32)
+        desc, buf = m.packed()
+        with torch.cuda.device(dev):
+            L.check(L.lib().mf_nerf_forward_dump(desc, buf.data_ptr(), L.ptr(x), x.stride(0), B, L.ptr(out), L.ptr(acts),
+                                                 stride, L.current_stream(dev)), "mf_nerf_forward_dump")
+        ctx.m, ctx.sigma_only, ctx.in_grad, ctx.in_width = m, bool(sigma_only), inputs.requires_grad, inputs.shape[1]
+        ctx.save_for_backward(acts, out, x)
+        return out[:, 3:4].clone() if sigma_only else out.clone()
+
+    @staticmethod
+    def backward(ctx, g):
+        m, sigma_only = ctx.m, ctx.sigma_only
+        acts, rgbsig, x = ctx.saved_tensors
+        D, W, cin, ext_dim = m.D, m.W, m.in_channels_xyz, m.extra_feat_dim
+        names = [n for n, _ in m.named_parameters()]
+        with torch.no_grad():
+            if sigma_only:
+                g_out = torch.zeros_like(rgbsig)
+                g_out[:, 3] = g[:, 0]
+            else:
+                g_out = g.contiguous().float()
+            emb = x[:, :cin]
+            extra = x[:, cin:cin + ext_dim] if (ext_dim > 0 and not sigma_only) else None
+            n_skip = len([s_ for s_ in m.skips if 0 < s_ < D])
+            emb_hip = ctx.in_grad and n_skip <= 1
+            grads, gpre, g_emb, _ = nerf_fused_grads(m, g_out, acts, rgbsig, emb, extra, emb_hip, sigma_path_only=sigma_only)
+            g_in = None
+            if ctx.in_grad:
+                g_in = torch.zeros((x.shape[0], ctx.in_width), device=x.device, dtype=torch.float32)
+                if emb_hip:
+                    g_in[:, :cin] = g_emb[:, :cin]
+                else:                                         # several skip layers: small library GEMMs
+                    for l in range(D):
+                        if l == 0 or l in m.skips:
+                            g_in[:, :cin] += gpre[:, l * W:(l + 1) * W] @ getattr(m, f"xyz_encoding_{l+1}")[0].weight[:, :cin]
+                if extra is not None:                         # (B,128) x (128, extra_dim): the one library GEMM of this node
+                    g_in[:, cin:] = gpre[:, (D + 1) * W:(D + 1) * W + W // 2] @ m.extra_encoding[0].weight[:, W:W + ext_dim]
+        return (None, g_in, None) + tuple(grads[n] for n in names)
+
+
 class NerfSamples(torch.autograd.Function):
     """Per-sample (rgb, sigma) of the canonical NeRF as an autograd node whose forward IS the fused HIP
     kernel's output (``rgbsig``, dumped).  Backward, per layer
@@ -482,67 +649,12 @@ class NerfSamples(torch.autograd.Function):
             h = lambda l: acts[:, l * W:(l + 1) * W]
             f = acts[:, D * W:(D + 1) * W]
             e2 = acts[:, (D + 1) * W:(D + 1) * W + W // 2]
-            fused = (_NERF_BACKWARD == "hip" and acts.shape[0] > 0 and W == 256 and cin <= 64
-                     and m.extra_feat_dim <= 32 and D + len([s for s in m.skips if 0 < s < D]) + 4 <= L.MF_WG_MAX_ITEMS)
+            fused = _NERF_BACKWARD == "hip" and nerf_fused_eligible(m, acts.shape[0])
             if fused:
                 n_skip = len([s_ for s_ in m.skips if 0 < s_ < D])
                 emb_hip = need_in and n_skip <= 1 and cin == ctx.emb_xyz.out_channels and cin <= 64
-                gpre, ghead, g_emb_hip = nerf_backward_hip(m, g_out, acts, rgbsig, want_emb=emb_hip)
-                P, dev = acts.shape[0], acts.device
+                grads, gpre, g_emb_hip, emb64 = nerf_fused_grads(m, g_out, acts, rgbsig, emb, extra, emb_hip)
                 gslot = lambda l: gpre[:, l * W:(l + 1) * W]
-                g_e2 = gpre[:, (D + 1) * W:(D + 1) * W + W // 2]
-                wants = lambda prefix: req[prefix + ".weight"] or req[prefix + ".bias"]
-                emb64 = F.pad(emb, (0, 64 - emb.shape[1])) if emb.shape[1] < 64 else emb
-                jobs, sinks = [], []
-
-                def put(prefix, blocks, bias_from=0):
-                    """blocks: [(job index, row slice, col slice)] concatenated along the columns"""
-                    sinks.append((prefix, blocks, bias_from))
-
-                for l in range(D):
-                    name = f"xyz_encoding_{l+1}.0"
-                    if not wants(name):
-                        continue
-                    blocks = []
-                    if l == 0 or l in m.skips:
-                        jobs.append((gslot(l), emb64, 256, 64, l == 0))
-                        blocks.append((len(jobs) - 1, slice(0, W), slice(0, cin)))
-                    if l > 0:
-                        jobs.append((gslot(l), h(l - 1), 256, 256, True))
-                        blocks.append((len(jobs) - 1, slice(0, W), slice(0, W)))
-                    put(name, blocks, blocks[-1][0])
-                if wants("xyz_encoding_final"):
-                    jobs.append((gslot(D), h(D - 1), 256, 256, True))
-                    put("xyz_encoding_final", [(len(jobs) - 1, slice(0, W), slice(0, W))], len(jobs) - 1)
-                if wants("extra_encoding.0"):
-                    jobs.append((g_e2, f, 128, 256, True))
-                    blocks = [(len(jobs) - 1, slice(0, W // 2), slice(0, W))]
-                    if extra is not None:
-                        ext32 = F.pad(extra, (0, 32 - extra.shape[1])) if extra.shape[1] < 32 else extra
-                        jobs.append((g_e2, ext32, 128, 32, False))
-                        blocks.append((len(jobs) - 1, slice(0, W // 2), slice(0, extra.shape[1])))
-                    put("extra_encoding.0", blocks, blocks[0][0])
-                head_job = None
-                if wants("sigma") or wants("rgb.0"):
-                    jobs.append((ghead, acts[:, (D - 1) * W:(D - 1) * W + 640], 4, 640, True))
-                    head_job = len(jobs) - 1
-                res = weight_grads(jobs, P, dev)
-                for prefix, blocks, bias_from in sinks:
-                    if req[prefix + ".weight"]:
-                        parts = [res[j][0][rs, cs] for j, rs, cs in blocks]
-                        grads[prefix + ".weight"] = parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, 1)
-                    if req[prefix + ".bias"]:
-                        grads[prefix + ".bias"] = res[bias_from][1][blocks[0][1]].clone()
-                if head_job is not None:
-                    hW, hb = res[head_job]
-                    if req["sigma.weight"]:
-                        grads["sigma.weight"] = hW[3:4, 0:W].contiguous()
-                    if req["sigma.bias"]:
-                        grads["sigma.bias"] = hb[3:4].clone()
-                    if req["rgb.0.weight"]:
-                        grads["rgb.0.weight"] = hW[0:3, 2 * W:2 * W + W // 2].contiguous()
-                    if req["rgb.0.bias"]:
-                        grads["rgb.0.bias"] = hb[0:3].clone()
                 g_emb = None
                 if emb_hip:      # produced by the chain launch itself; the sin / cos chain rule is one more small launch
                     g_xin = embed_backward_hip(ctx.emb_xyz, emb64, g_emb_hip)

@@ -36,20 +36,6 @@ constexpr int PD = MF_BF_PD;
 #define MF_MFMA32(a, b, c) \
   __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
 
-#ifdef MF_BF_DBG_JITTER
-MF_D void jitter() {       // race screen: a pseudo-random stall per wave
-  const unsigned t = (unsigned)__builtin_readcyclecounter();
-  switch ((t >> 3) & 3u) {
-    case 1: __builtin_amdgcn_s_sleep(3); break;
-    case 2: __builtin_amdgcn_s_sleep(11); break;
-    case 3: __builtin_amdgcn_s_sleep(40); break;
-    default: break;
-  }
-}
-#else
-MF_D void jitter() {}
-#endif
-
 struct Lane {
   int lane, wave, j, h;
   MF_D Lane() {

@@ -223,6 +223,22 @@ MF_D void glds16(const char* g, uint32_t lds_off) {
 }
 MF_D void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// Race / hazard screen (-DMF_DBG_JITTER, tools/ab_lib.sh): a pseudo-random stall per wave in front of every panel barrier
+// and embedding evaluation.  Results must stay bit-identical between runs (tools/stress_determinism.py).
+#ifdef MF_DBG_JITTER
+MF_D void jitter() {       // race screen: a pseudo-random stall per wave
+  const unsigned t = (unsigned)__builtin_readcyclecounter();
+  switch ((t >> 3) & 3u) {
+    case 1: __builtin_amdgcn_s_sleep(3); break;
+    case 2: __builtin_amdgcn_s_sleep(11); break;
+    case 3: __builtin_amdgcn_s_sleep(40); break;
+    default: break;
+  }
+}
+#else
+MF_D void jitter() {}
+#endif
+
 // sum over the four lane groups of a sample column (lanes j, j+16, j+32, j+48)
 MF_D float xgroup_sum(float v) {
   v += __shfl_xor(v, 16, 64);
@@ -289,6 +305,7 @@ struct Stream {
   // and the stores stay in flight across the barrier instead of being drained at it.
   template <bool KEEP2 = false>
   MF_D void sync_and_dma(int groups, const char* jump, const LaneId& id) {
+    jitter();
     if (KEEP2 && keep2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
     else if (!(dbg & 16)) wait_vm0();
     if (!(dbg & 1)) __builtin_amdgcn_s_barrier();

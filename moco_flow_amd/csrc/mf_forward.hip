@@ -47,9 +47,11 @@ struct NerfFwdParams {
   long long in_stride, B;
   int sigma_only, extra_kind, extra_cols, xyz_cols;
   float* out;
+  float* dump; long long dump_stride;          // DUMP: per-sample layer outputs [h_0 .. h_{D-1} | final | extra], as mf_render_pass dumps them
   uint32_t ring_off, buf_bytes;
 };
 
+template <bool DUMP>
 __global__ __launch_bounds__(kThreads, 2) void nerf_forward_kernel(NerfFwdParams p) {
   const LaneId id;
   NetDev net = p.net;
@@ -85,7 +87,11 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_forward_kernel(NerfFwdParams
       ext[e] = (!p.sigma_only && f >= 0 && f < p.extra_cols) ? row[p.xyz_cols + f] : 0.f;
     }
     float sigma, rgb[3] = {0.f, 0.f, 0.f};
-    nerf_eval<16, false>(net, embx, ext, p.sigma_only != 0, st, carry, id, follow_of(net), sigma, rgb);
+    float* dump_row = nullptr;
+    if constexpr (DUMP) {
+      if (valid) dump_row = p.dump + b * p.dump_stride;
+    }
+    nerf_eval<16, false, DUMP>(net, embx, ext, p.sigma_only != 0, st, carry, id, follow_of(net), sigma, rgb, dump_row);
     if (valid && id.g == 0) {
       if (p.sigma_only) p.out[b] = sigma;
       else *reinterpret_cast<float4*>(p.out + b * 4) = make_float4(rgb[0], rgb[1], rgb[2], sigma);
@@ -227,28 +233,44 @@ extern "C" int32_t mf_embedding_forward(const mf_embedding* e, const float* x, i
   return check_launch("mf_embedding_forward");
 }
 
-extern "C" int32_t mf_nerf_forward(const mf_nerf_desc* d, const void* packed, const float* inputs, int64_t in_stride,
-                                   int64_t B, int32_t sigma_only, float* out, void* stream) {
-  if (!d || !packed || (B > 0 && (!inputs || !out))) return fail(MF_E_INVALID, "mf_nerf_forward: null argument");
+static int32_t nerf_forward_launch(const char* who, const mf_nerf_desc* d, const void* packed, const float* inputs, int64_t in_stride,
+                                   int64_t B, int32_t sigma_only, float* out, float* dump, int64_t dump_stride, void* stream) {
+  if (!d || !packed || (B > 0 && (!inputs || !out))) return fail(MF_E_INVALID, "%s: null argument", who);
   NerfFwdParams p{};
-  if (!nerf_layout(*d, p.net.L)) return fail(MF_E_UNSUPPORTED, "mf_nerf_forward: unsupported NeRF configuration");
-  if (p.net.L.NK != 16) return fail(MF_E_UNSUPPORTED, "mf_nerf_forward: only W=256 is built");
+  if (!nerf_layout(*d, p.net.L)) return fail(MF_E_UNSUPPORTED, "%s: unsupported NeRF configuration", who);
+  if (p.net.L.NK != 16) return fail(MF_E_UNSUPPORTED, "%s: only W=256 is built", who);
+  if (dump && dump_stride < (int64_t)p.net.L.n_trunk * p.net.L.W + p.net.L.W / 2)
+    return fail(MF_E_INVALID, "%s: dump_stride %lld too small", who, (long long)dump_stride);
   if (B == 0) return MF_OK;
   p.net.packed = static_cast<const char*>(packed);
   p.net.res_lds = 0;
   p.in = inputs; p.in_stride = in_stride; p.B = B; p.sigma_only = sigma_only; p.out = out;
+  p.dump = dump; p.dump_stride = dump_stride;
   p.extra_kind = d->extra_feat_type == MF_EXTRA_DIR ? kEmbDir : (d->extra_feat_type == MF_EXTRA_IND ? kEmbInd : kEmbNone);
   p.extra_cols = d->extra_feat_type == MF_EXTRA_NONE ? 0 : d->extra_feat_dim;
   p.xyz_cols = d->in_channels_xyz;
   p.ring_off = (uint32_t)p.net.L.res_bytes;
   p.buf_bytes = (uint32_t)p.net.L.max_groups * kGroupBytes;
   const size_t lds = p.ring_off + 3 * (size_t)p.buf_bytes;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(nerf_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return fail(MF_E_LAUNCH, "mf_nerf_forward: cannot reserve %zu bytes of LDS", lds);
+  const void* fn = dump ? reinterpret_cast<const void*>(nerf_forward_kernel<true>) : reinterpret_cast<const void*>(nerf_forward_kernel<false>);
+  if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(MF_E_LAUNCH, "%s: cannot reserve %zu bytes of LDS", who, lds);
   const long long ntiles = (B + kTile - 1) / kTile;
   const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
-  hipLaunchKernelGGL(nerf_forward_kernel, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
-  return check_launch("mf_nerf_forward");
+  if (dump) hipLaunchKernelGGL(nerf_forward_kernel<true>, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+  else hipLaunchKernelGGL(nerf_forward_kernel<false>, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+  return check_launch(who);
+}
+
+extern "C" int32_t mf_nerf_forward(const mf_nerf_desc* d, const void* packed, const float* inputs, int64_t in_stride,
+                                   int64_t B, int32_t sigma_only, float* out, void* stream) {
+  return nerf_forward_launch("mf_nerf_forward", d, packed, inputs, in_stride, B, sigma_only, out, nullptr, 0, stream);
+}
+
+extern "C" int32_t mf_nerf_forward_dump(const mf_nerf_desc* d, const void* packed, const float* inputs, int64_t in_stride,
+                                        int64_t B, float* out, float* dump_acts, int64_t dump_stride, void* stream) {
+  if (B > 0 && !dump_acts) return fail(MF_E_INVALID, "mf_nerf_forward_dump: null dump buffer");
+  return nerf_forward_launch("mf_nerf_forward_dump", d, packed, inputs, in_stride, B, 0, out, dump_acts, dump_stride, stream);
 }
 
 extern "C" int32_t mf_nof_forward(const mf_nof_desc* d, const void* packed, const float* inputs, int64_t in_stride,

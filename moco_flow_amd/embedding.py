@@ -46,13 +46,13 @@ class Embedding(nn.Module):
         L.require_gpu(x, "Embedding.forward")
         if x.dim() != 2 or x.shape[1] != self.in_channels:
             raise RuntimeError(f"Embedding expects (B, {self.in_channels}), got {tuple(x.shape)}")
+        if torch.is_grad_enabled() and x.requires_grad:
+            from . import autograd as A
+            return A.EmbeddingModule.apply(self, x)
         xc = x.detach().contiguous().float()
         out = torch.empty((x.shape[0], self.out_channels), device=x.device, dtype=torch.float32)
         d = self.descriptor()
         with torch.cuda.device(x.device):
             L.check(L.lib().mf_embedding_forward(d, L.ptr(xc), x.shape[0], L.ptr(out),
                                                  L.current_stream(x.device)), "mf_embedding_forward")
-        if torch.is_grad_enabled() and x.requires_grad:
-            from . import autograd as A
-            out, = A.attach([out], [x], lambda: [A.embed(self, x)])
         return out

@@ -101,6 +101,10 @@ class NeRF(nn.Module):
             raise RuntimeError(f"NeRF.forward expects (B, {width}) [in_channels_xyz={self.in_channels_xyz}, "
                                f"extra_feat_dim={self.extra_feat_dim}, sigma_only={sigma_only}], "
                                f"got {tuple(inputs.shape)}")
+        from . import autograd as A
+        want_grad = A.needs_grad([self]) or (torch.is_grad_enabled() and inputs.requires_grad)
+        if want_grad and A._NERF_BACKWARD == "hip" and A.nerf_fused_eligible(self, inputs.shape[0]):
+            return A.NerfModule.apply(self, inputs, bool(sigma_only), *self.parameters())
         desc, buf = self.packed()
         x = inputs.detach().float()
         if x.stride(1) != 1:
@@ -111,8 +115,7 @@ class NeRF(nn.Module):
             L.check(L.lib().mf_nerf_forward(desc, buf.data_ptr(), L.ptr(x), x.stride(0) if B else width, B,
                                             1 if sigma_only else 0, L.ptr(out), L.current_stream(x.device)),
                     "mf_nerf_forward")
-        from . import autograd as A
-        if A.needs_grad([self]) or (torch.is_grad_enabled() and inputs.requires_grad):
+        if want_grad:       # shapes the fused backward is not built for (W != 256, many skips): differentiable recompute
             params = [p for p in self.parameters()] + ([inputs] if inputs.requires_grad else [])
             out, = A.attach([out], params, lambda: [A.nerf_forward(self, inputs, sigma_only)])
         return out

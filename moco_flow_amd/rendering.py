@@ -35,8 +35,10 @@ def set_precision(p: str):
 #   * hand-written HIP for every fp32 render_rays pass that evaluates the full NeRF: mf_composite_backward,
 #     mf_nerf_backward_x (+ mf_embedding_backward under NoF), mf_weight_grads, mf_nof_points_dump / mf_nof_backward
 #     (autograd.py); torch evaluates only the loss;
+#     -- also when the module setting is "bf16": a pass that records gradients runs the fp32 kernels (the reference
+#     trains in fp32; bf16 is the throughput mode of gradient-free passes);
 #   * a differentiable recompute with PyTorch-ROCm device ops (autograd.RecomputeBackward) for what is not built in
-#     HIP: bf16 passes, the sigma-only coarse pass of test_time, network shapes outside the fused envelope.
+#     HIP: the sigma-only coarse pass of test_time under grad, network shapes outside the fused envelope.
 # _TRAIN_FORWARD is a timing-comparison hook for tools/ab_switches.py ("torch": the whole pass as eager device ops,
 # i.e. what the reference itself would run on this GPU); it is not part of the drop-in surface.
 _TRAIN_FORWARD = "hip"
@@ -52,8 +54,8 @@ def _emb_desc(e):
 
 
 def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation, nerf, nerf_embs,
-                 nof_models, nof_embs, chain_local, chain_global, sigma_only, want_planes, dump=False):
-    """One mf_render_pass call. Returns dict of fresh tensors."""
+                 nof_models, nof_embs, chain_local, chain_global, sigma_only, want_planes, dump=False, precision=None):
+    """One mf_render_pass call. Returns dict of fresh tensors.  ``precision``: None = the module setting."""
     dev = rays.device
     N = rays.shape[0]
     S = z_vals.shape[1] if z_vals is not None else z_steps.shape[0]
@@ -72,7 +74,7 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
     if chain_global:
         flags |= L.MF_F_CHAIN_GLOBAL
     a.flags = flags
-    prec = L.MF_PREC_BF16 if PRECISION == "bf16" else L.MF_PREC_F32
+    prec = L.MF_PREC_BF16 if (precision or PRECISION) == "bf16" else L.MF_PREC_F32
     a.precision = prec
     desc, buf = nerf.packed(prec)
     a.nerf, a.nerf_packed = C.pointer(desc), buf.data_ptr()
@@ -305,6 +307,7 @@ def render_rays(rays,
         return None
 
     coarse_sigma_only = bool(need_fine and test_time)                  # rendering.py:290-294
+    pass_prec = "f32" if grad else None       # a pass that records gradients runs the reference's fp32 arithmetic
     want_planes = need_fine or loc or glob or grad or _capture is not None
     noise_c = draw_noise((N, S), "noise_coarse")
     if grad and N > 0 and _TRAIN_FORWARD == "torch":
@@ -315,7 +318,7 @@ def render_rays(rays,
     c = _render_pass(rays, background, z_vals, None if z_vals is not None else z_steps, use_disp,
                      noise_c, act, nerf_models[0], nerf_embeddings,
                      nof_models if use_nof else None, nof_embeddings, loc, glob, coarse_sigma_only, want_planes,
-                     dump=grad and PRECISION == "f32" and not coarse_sigma_only)
+                     dump=grad and not coarse_sigma_only, precision=pass_prec)
     if coarse_sigma_only:
         result = {'opacity_coarse': c["opacity"]}
     else:
@@ -336,7 +339,7 @@ def render_rays(rays,
         f = _render_pass(rays, background, z_all, None, use_disp, noise_f, act,
                          nerf_models[1], nerf_embeddings, nof_models if use_nof else None, nof_embeddings,
                          loc, glob, False, loc or glob or grad or _capture is not None,
-                         dump=grad and PRECISION == "f32")
+                         dump=grad, precision=pass_prec)
         if _capture is not None:
             _capture.update(z_fine=z_all, weights_fine=f.get("weights"), alphas_fine=f.get("alphas"))
         result['rgb_fine'] = f["rgb"]

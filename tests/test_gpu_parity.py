@@ -838,6 +838,75 @@ def test_nerf_backward_vs_oracle_on_dumped_points(M, R):
     assert ex <= 1e-4
 
 
+@pytest.mark.parametrize("extra,extra_dim,sigma_only,B", [("ind", 5, True, 1000), ("dir", 27, False, 700),
+                                                           ("ind", 5, False, 129), ("none", 0, True, 1)])
+def test_nerf_module_backward_vs_oracle(M, R, extra, extra_dim, sigma_only, B):
+    """``NeRF(inputs, sigma_only)`` called directly with gradients (trainer_moco_flow.py:146-157, 337-362): the HIP
+    node (autograd.NerfModule: mf_nerf_forward_dump + mf_nerf_backward_x + mf_weight_grads) against the ORACLE's CPU
+    autograd of the same module call on the same embedded inputs: value 1e-5, every parameter gradient and the
+    gradient of the inputs 1e-4; parameters off the sigma path get no gradient, as under torch."""
+    from moco_flow_amd import synth
+    torch.manual_seed(6)
+    sd = {k: torch.from_numpy(v) for k, v in synth.nerf_state(11, extra_feat_type=extra, extra_feat_dim=extra_dim,
+                                                              regime="dense").items()}
+    nerf = M.NeRF(8, 256, 63, [4], extra, extra_dim)
+    nerf.load_state_dict(sd)
+    nerf = nerf.cuda()
+    onerf = R.NeRF(8, 256, 63, [4], extra, extra_dim)
+    onerf.load_state_dict(sd)
+    onerf = _with_grad(onerf)
+    exyz = M.Embedding(3, 10)
+    width = 63 + (0 if sigma_only else extra_dim)
+    with torch.no_grad():
+        x0 = torch.cat([exyz(torch.randn(B, 3, device="cuda") * 0.7), torch.randn(B, extra_dim, device="cuda")], -1)[:, :width]
+    x = x0.clone().requires_grad_(True)
+    out = nerf(x, sigma_only=sigma_only)
+    assert "NerfModule" in type(out.grad_fn).__name__
+    gout = torch.randn_like(out)
+    out.backward(gout)
+    x_o = x0.cpu().clone().requires_grad_(True)
+    ref = onerf(x_o, sigma_only=sigma_only)
+    assert relerr(out, ref) <= 1e-5
+    want, (want_x,) = _oracle_param_grads(onerf, ref, gout.cpu(), (x_o,))
+    off_path = ("xyz_encoding_final", "extra_encoding", "rgb")
+    for name, q in nerf.named_parameters():
+        if sigma_only and name.startswith(off_path):
+            assert q.grad is None and want[name] is None, name
+            continue
+        assert relerr(q.grad, want[name]) <= 1e-4, (name, relerr(q.grad, want[name]))
+    assert relerr(x.grad, want_x) <= 1e-4, relerr(x.grad, want_x)
+    # only the parameters require grad (the usual module-level training call)
+    nerf.zero_grad(set_to_none=True)
+    out2 = nerf(x0, sigma_only=sigma_only)
+    assert torch.equal(out2, out.detach())
+    out2.backward(gout)
+    for name, q in nerf.named_parameters():
+        if not (sigma_only and name.startswith(off_path)):
+            assert relerr(q.grad, want[name]) <= 1e-4, name
+
+
+def test_embedding_module_backward_vs_oracle(M, R):
+    """Embedding(x) with x requiring grad: mf_embedding_forward / mf_embedding_backward vs the oracle's autograd,
+    incl. muted frequencies (coarse-to-fine weights, trainer_moco_flow.py:113-114) and an empty batch."""
+    torch.manual_seed(7)
+    for cin, nf, w in ((3, 10, None), (3, 5, [1.0, 1.0, 0.4, 0.0, 0.0]), (1, 16, None)):
+        e, eo = M.Embedding(cin, nf), R.Embedding(cin, nf)
+        if w is not None:
+            e.weights, eo.weights = list(w), list(w)
+        x = (torch.randn(257, cin, device="cuda") * 0.5).requires_grad_(True)
+        out = e(x)
+        g = torch.randn_like(out)
+        out.backward(g)
+        xo = x.detach().cpu().requires_grad_(True)
+        ref = eo(xo)
+        ref.backward(g.cpu())
+        assert relerr(out, ref) <= 2e-6
+        assert relerr(x.grad, xo.grad) <= 1e-5, (cin, nf, relerr(x.grad, xo.grad))
+    x = torch.zeros(0, 3, device="cuda", requires_grad=True)
+    M.Embedding(3, 4)(x).sum().backward()
+    assert x.grad.shape == (0, 3)
+
+
 @pytest.mark.parametrize("quat", [True, False])
 def test_nof_backward_vs_oracle(M, R, quat):
     """One NoF evaluation on points (rendering.py:49-83 + nof.py:69-82): HIP forward-with-dump / backward node

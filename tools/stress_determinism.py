@@ -31,4 +31,5 @@ for name, n in (("r_nerf_dir_dense", 4096), ("r_moco_local", 4096), ("r_moco_glo
                     d = (ref[k] - out[k]).abs().reshape(ref[k].shape[0], -1).amax(1)
                     idx = torch.nonzero(d > 0).view(-1)
                     bad.setdefault(k, []).append((r, int(idx.numel()), float(d.max()), idx[:12].tolist()))
-    print(f"{prec} {name} n={n}: " + ("deterministic" if not bad else f"DIFFERS {bad}"), flush=True)
+    brief = {k: (len(v), str(v[0])[:80]) for k, v in bad.items()}
+    print(f"{prec} {name} n={n}: " + ("deterministic" if not bad else f"DIFFERS (plane: runs that differ, first) {brief}"), flush=True)
