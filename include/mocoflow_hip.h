@@ -359,6 +359,35 @@ int32_t mf_image_compose(const uint8_t* rays_msk, const int64_t* rank, int64_t B
 int32_t mf_knn1(const float* ref, int64_t V, const float* query, int64_t Q, float* dist, int64_t* ind,
                 void* stream);
 
+/* ---- SMPL linear blend skinning + per-vertex frame transforms (ABI v10) ------------
+ * The model arrays of utils/smpl/smpl_model.py:60-82 as device pointers (fp32, row-major):
+ *   v_template (V,3), shapedirs (V*3,10) [= shapedirs[:, :, :10]], posedirs (V*3,207), j_regressor (24,V) dense,
+ *   weights (V,24); parent[i] (i = 1..23) = index of joint i's parent (an earlier joint), parent[0] ignored. */
+typedef struct mf_smpl_model {
+  int32_t n_verts;
+  const float* v_template;
+  const float* shapedirs;
+  const float* posedirs;
+  const float* j_regressor;
+  const float* weights;
+  int32_t parent[24];
+} mf_smpl_model;
+
+/* SMPL.forward (smpl_model.py:96-139) and SMPL.get_vertex_transformation (:141-186) in one call:
+ * pose (B,72) axis-angle, or (B,24,3,3) rotation matrices when pose_is_rotmat; betas (B,10) ->
+ * verts (B,V,3) and / or T (B,V,4,4) (either may be NULL).  scratch: mf_smpl_scratch_bytes(V,B) bytes. */
+int64_t mf_smpl_scratch_bytes(int64_t n_verts, int64_t B);
+int32_t mf_smpl_lbs(const mf_smpl_model* m, const float* pose, int32_t pose_is_rotmat, const float* betas, int64_t B,
+                    float* verts, float* T, void* scratch, void* stream);
+
+/* datasets/moco_flow_dataset.py:96-99: trans (V,4,4) = T_tgt @ inverse(T_src), per vertex. */
+int32_t mf_smpl_frame_transforms(const float* T_src, const float* T_tgt, int64_t V, float* trans, void* stream);
+
+/* datasets/moco_flow_dataset.py:127-129: cano (Q,3) = (trans[ind] @ [query, 1])[:3]; ind (Q,) int64 into the V
+ * transforms (mf_knn1's output). */
+int32_t mf_apply_vertex_transforms(const float* trans, const int64_t* ind, int64_t V, const float* query, int64_t Q,
+                                   float* cano, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -28,6 +28,11 @@ class mf_embedding(C.Structure):
                 ("freq", C.c_float * MF_MAX_FREQS), ("weight", C.c_float * MF_MAX_FREQS)]
 
 
+class mf_smpl_model(C.Structure):
+    _fields_ = [("n_verts", C.c_int32), ("v_template", _fp), ("shapedirs", _fp), ("posedirs", _fp),
+                ("j_regressor", _fp), ("weights", _fp), ("parent", C.c_int32 * 24)]
+
+
 class mf_nerf_desc(C.Structure):
     _fields_ = [("D", C.c_int32), ("W", C.c_int32), ("in_channels_xyz", C.c_int32),
                 ("skip_mask", C.c_uint32), ("extra_feat_type", C.c_int32), ("extra_feat_dim", C.c_int32),
@@ -112,6 +117,10 @@ SYMBOLS = {
     "mf_make_rays": (C.c_int32, [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float),
                                  C.c_float, C.c_float, C.c_float, _fp, _fp]),
     "mf_knn1": (C.c_int32, [_fp, C.c_int64, _fp, C.c_int64, _fp, _fp, _fp]),
+    "mf_smpl_scratch_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
+    "mf_smpl_lbs": (C.c_int32, [C.POINTER(mf_smpl_model), _fp, C.c_int32, _fp, C.c_int64, _fp, _fp, _fp, _fp]),
+    "mf_smpl_frame_transforms": (C.c_int32, [_fp, _fp, C.c_int64, _fp, _fp]),
+    "mf_apply_vertex_transforms": (C.c_int32, [_fp, _fp, C.c_int64, _fp, C.c_int64, _fp, _fp]),
     "mf_nerf_backward_x": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, C.c_int64, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp, _fp]),
     "mf_embedding_backward": (C.c_int32, [C.POINTER(mf_embedding), _fp, C.c_int64, _fp, C.c_int64, C.c_int64, _fp, _fp]),
     "mf_valid_rays_mask": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _fp, _fp]),

@@ -146,3 +146,36 @@ def rays(seed=0, n_rays=4096, chained=False, near=2.0, far=6.0, img_ind=-0.25,
     r = np.concatenate(cols, axis=1).astype(np.float32)
     bg = uniform01(_stream_seed(seed, "background"), n_rays * 3).reshape(n_rays, 3).astype(np.float32)
     return r, bg
+
+
+# kinematic tree of the 24-joint body model (parent of joint 1..23; public SMPL topology)
+SMPL_PARENTS = (0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21)
+
+
+def smpl_model(seed=0, n_verts=6890):
+    """A synthetic body model with the array shapes of the licensed SMPL pickle the reference loads
+    (/root/reference/utils/smpl/smpl_model.py:60-82; the assets themselves are not redistributable):
+    v_template (V,3), shapedirs (V,3,10), posedirs (V,3,207), J_regressor (24,V) (rows sum to 1), weights (V,24)
+    (4 non-zero blend weights per vertex, rows sum to 1), parent (23,).  float32 numpy."""
+    V = n_verts
+    vt = (uniform01(_stream_seed(seed, "smpl.v_template"), V * 3).reshape(V, 3) - 0.5) * np.array([0.6, 1.7, 0.3])
+    sd = normal(_stream_seed(seed, "smpl.shapedirs"), V * 3 * 10).reshape(V, 3, 10) * 0.01
+    pd = normal(_stream_seed(seed, "smpl.posedirs"), V * 3 * 207).reshape(V, 3, 207) * 0.002
+    jr = uniform01(_stream_seed(seed, "smpl.J_regressor"), 24 * V).reshape(24, V) ** 8      # a few dominant vertices per joint
+    jr = jr / jr.sum(1, keepdims=True)
+    w = np.zeros((V, 24))
+    pick = (uniform01(_stream_seed(seed, "smpl.weights.j"), V * 4).reshape(V, 4) * 24).astype(np.int64)
+    val = uniform01(_stream_seed(seed, "smpl.weights.v"), V * 4).reshape(V, 4) + 0.05
+    for k in range(4):
+        np.add.at(w, (np.arange(V), pick[:, k]), val[:, k])
+    w = w / w.sum(1, keepdims=True)
+    return dict(v_template=vt.astype(np.float32), shapedirs=sd.astype(np.float32), posedirs=pd.astype(np.float32),
+                J_regressor=jr.astype(np.float32), weights=w.astype(np.float32),
+                parent=np.array(SMPL_PARENTS, dtype=np.int64))
+
+
+def smpl_pose(seed=0, batch=1, scale=0.4):
+    """(pose (B,72) axis-angle, betas (B,10)) float32."""
+    p = normal(_stream_seed(seed, "smpl.pose"), batch * 72).reshape(batch, 72) * scale
+    b = normal(_stream_seed(seed, "smpl.betas"), batch * 10).reshape(batch, 10)
+    return p.astype(np.float32), b.astype(np.float32)

@@ -1390,3 +1390,59 @@ def test_valid_rays_mask_bit_exact(M, R):
     for pts, H, W in ([[(1, 1)] * 8, 3, 3], [[(0, 0), (3, 3)], 4, 4], [[(-9, -9), (-5, -9), (-7, -3)], 4, 4],
                       [[(0, 0), (3, 0), (0, 2)], 3, 4], [[(-4, 2), (9, -3), (5, 12), (-2, 7)], 8, 6]):
         assert np.array_equal(raw(pts, H, W), R.valid_rays_mask(np.array(pts), H, W)), pts
+
+
+@pytest.mark.gpu
+def test_smpl_lbs_vs_reference_golden(M):
+    """SMPL.forward / get_vertex_transformation / the correspondence transforms (utils/smpl/smpl_model.py:96-186,
+    datasets/moco_flow_dataset.py:96-99,127-129) on the HIP kernels against the REFERENCE's outputs on the synthetic
+    assets (tests/golden/u_smpl.npz): axis-angle poses incl. exactly-zero rotations, rotation-matrix poses, B = 3."""
+    from moco_flow_amd import smpl as S, synth
+    g = load_golden("u_smpl")
+    m = S.SMPL(model=synth.smpl_model(int(g["meta_seed"]), int(g["meta_V"]))).cuda()
+    pose, betas = torch.from_numpy(g["in_pose"]).cuda(), torch.from_numpy(g["in_betas"]).cuda()
+    assert relerr(m(pose, betas), g["out_verts"]) <= 1e-5
+    T = m.get_vertex_transformation(pose, betas)
+    assert relerr(T, g["out_T"]) <= 1e-5
+    assert relerr(m(torch.from_numpy(g["out_R"]).cuda(), betas), g["out_verts_from_R"]) <= 1e-5
+    trans = S.frame_transforms(T[0], T[1])
+    assert relerr(trans, g["out_trans"]) <= 1e-4
+    ind = torch.from_numpy(g["out_ind"]).cuda()
+    query = torch.from_numpy(g["in_query"]).cuda()
+    assert relerr(S.apply_vertex_transforms(trans, ind, query), g["out_cano"]) <= 1e-4
+    # the nearest-vertex search of the same pipeline reproduces the fixture's indices
+    from moco_flow_amd.knn import KNN
+    d, i = KNN(k=1, transpose_mode=True)(m(pose[:1], betas[:1]), query[None])
+    assert torch.equal(i[0, :, 0].cpu(), torch.from_numpy(g["out_ind"]))
+    assert relerr(d[0], g["out_dist"]) <= 1e-5
+
+
+@pytest.mark.gpu
+def test_smpl_full_size_vs_oracle(M):
+    """The standard model size (6890 vertices, the shape the datasets run: B = 1 per frame) against oracle/smpl_ref.py,
+    end to end through frame_correspondence; plus the empty cases."""
+    from moco_flow_amd import smpl as S, synth
+    from oracle import smpl_ref
+    assets = synth.smpl_model(1, 6890)
+    m, o = S.SMPL(model=assets).cuda(), smpl_ref.SMPL(assets)
+    pose, betas = synth.smpl_pose(5, batch=2, scale=0.6)
+    pose_t, betas_t = torch.from_numpy(pose), torch.from_numpy(betas)
+    verts, T = m(pose_t.cuda(), betas_t.cuda()), m.get_vertex_transformation(pose_t.cuda(), betas_t.cuda())
+    assert relerr(verts, o.forward(pose_t, betas_t)) <= 1e-5
+    T_o = o.get_vertex_transformation(pose_t, betas_t)
+    assert relerr(T, T_o) <= 1e-5
+    Q = 20000                                        # 2 x num_sampled of c2f.yaml
+    query = torch.from_numpy(((synth.uniform01(3, Q * 3).reshape(Q, 3) - 0.5) * 3.0).astype(np.float32))
+    inside, outside = S.frame_correspondence(m, pose_t[:1].cuda(), betas_t[:1].cuda(), pose_t[1:].cuda(), betas_t[1:].cuda(),
+                                             query.cuda(), thickness=0.2)
+    src = o.forward(pose_t[:1], betas_t[:1])[0]
+    d2 = torch.cdist(query.double(), src.double())
+    dist, ind = d2.min(1)
+    cano = smpl_ref.apply_vertex_transforms(smpl_ref.frame_transforms(T_o[0], T_o[1]), ind, query)
+    ins_o, out_o = smpl_ref.split_inside_outside(query, cano, dist.float(), 0.2)
+    assert inside.shape == ins_o.shape and outside.shape == out_o.shape and inside.shape[0] > 100
+    assert relerr(inside, ins_o) <= 1e-4 and relerr(outside, out_o) <= 1e-4
+    assert S.apply_vertex_transforms(T[0], torch.zeros(0, dtype=torch.int64, device="cuda"), torch.zeros(0, 3, device="cuda")).shape == (0, 3)
+    assert m(pose_t[:0].cuda(), betas_t[:0].cuda()).shape == (0, 6890, 3)
+    with pytest.raises(RuntimeError):
+        m(pose_t[:, :10].cuda(), betas_t.cuda())

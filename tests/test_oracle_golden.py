@@ -188,3 +188,23 @@ def test_render_image_vectors():
     for k in ("rgb_fine", "depth_fine", "opacity_fine", "rgb_coarse", "opacity_coarse"):
         assert relerr(res[k], g["out_" + k]) <= 1e-6, (k, relerr(res[k], g["out_" + k]))
     assert res["rgb_fine"].shape == (rays.shape[0], 3) and res["opacity_fine"].shape[0] == int(g["in_rays_msk"].sum())
+
+
+def test_smpl_oracle_vs_reference_golden():
+    """oracle/smpl_ref.py against tests/golden/u_smpl.npz = the REFERENCE's own SMPL.forward /
+    get_vertex_transformation / correspondence lines run on moco_flow_amd.synth.smpl_model assets
+    (utils/smpl/smpl_model.py:96-186, datasets/moco_flow_dataset.py:96-99,127-129)."""
+    from moco_flow_amd import synth
+    from oracle import smpl_ref
+    g = load_golden("u_smpl")
+    m = smpl_ref.SMPL(synth.smpl_model(int(g["meta_seed"]), int(g["meta_V"])))
+    pose, betas = torch.from_numpy(g["in_pose"]), torch.from_numpy(g["in_betas"])
+    assert relerr(smpl_ref.rodrigues(pose.view(-1, 3)).view(-1, 24, 3, 3), g["out_R"]) <= 1e-6
+    assert relerr(m.forward(pose, betas), g["out_verts"]) <= 1e-6
+    T = m.get_vertex_transformation(pose, betas)
+    assert relerr(T, g["out_T"]) <= 1e-6
+    assert relerr(m.forward(torch.from_numpy(g["out_R"]), betas), g["out_verts_from_R"]) <= 1e-6
+    trans = smpl_ref.frame_transforms(T[0], T[1])
+    assert relerr(trans, g["out_trans"]) <= 1e-5
+    cano = smpl_ref.apply_vertex_transforms(trans, torch.from_numpy(g["out_ind"]), torch.from_numpy(g["in_query"]))
+    assert relerr(cano, g["out_cano"]) <= 1e-5
