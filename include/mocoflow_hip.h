@@ -276,6 +276,15 @@ typedef struct mf_render_args {
   float* dump_acts; int64_t dump_stride;
   float* dump_rgbsigma;
   float* dump_xyz;
+  /* The same for the NoF evaluations of the chain program (rendering.py:270-282), one plane per step k in
+   * [bw(x,i), fw(canon,i), fw(canon,j), bw(.,j), fw(.,i)] (as many as the flags run), each N*S rows:
+   * dump_nof_acts (steps, N*S, dump_nof_stride): [h_1 | ... | h_D | T (9 | 3) zero-padded to 16]
+   * (dump_nof_stride >= D*W + 16), dump_nof_emb (steps, N*S, 80): the embedded input [xyz 33 | ind 33 | 0 x 14],
+   * dump_nof_out (steps, N*S, 3): the step's output points.  This is what mf_nof_points_dump writes for one
+   * evaluation; with it the backward needs no forward re-evaluation of the chains.  All three or none. */
+  float* dump_nof_acts; int64_t dump_nof_stride;
+  float* dump_nof_emb;
+  float* dump_nof_out;
 } mf_render_args;
 
 int32_t mf_render_pass(const mf_render_args* a, void* stream);

@@ -467,6 +467,44 @@ class NofPoints(torch.autograd.Function):
         return (None, None, None, None, g_pts) + tuple(grads[n] for n in names)
 
 
+class NofPointsDumped(torch.autograd.Function):
+    """The same node when the fused render pass already evaluated and dumped this step of the chain
+    (mf_render_args.dump_nof_*): forward = the dumped output points, no launch; backward as NofPoints."""
+
+    @staticmethod
+    def forward(ctx, m, nof_embs, acts, emb, out, pts, *params):
+        ctx.m, ctx.ex, ctx.stride = m, nof_embs[0].descriptor(), acts.shape[1]
+        ctx.save_for_backward(pts.detach().contiguous().float(), acts, emb)
+        return out.clone()
+
+    @staticmethod
+    def backward(ctx, g_out):
+        m, stride = ctx.m, ctx.stride
+        pts, acts, emb = ctx.saved_tensors
+        P, dev = pts.shape[0], pts.device
+        names = [n for n, _ in m.named_parameters()]
+        req = {n: p.requires_grad for n, p in m.named_parameters()}
+        need_pts = ctx.needs_input_grad[5]
+        with torch.no_grad():
+            desc, buf = m.packed_bwd()
+            g_out = g_out.contiguous().float()
+            gpre = torch.empty(((P + 127) // 128 * 128, stride), device=dev, dtype=torch.float32)
+            g_pts = torch.empty((P, 3), device=dev, dtype=torch.float32) if need_pts else None
+            with torch.cuda.device(dev):
+                L.check(L.lib().mf_nof_backward(C.byref(desc), buf.data_ptr(), C.byref(ctx.ex), P, pts.data_ptr(),
+                                                acts.data_ptr(), stride, g_out.data_ptr(), gpre.data_ptr(),
+                                                g_pts.data_ptr() if need_pts else None, L.current_stream(dev)),
+                        "mf_nof_backward")
+            grads = _nof_param_grads(m, gpre[:P], acts, emb, req)
+        return (None, None, None, None, None, g_pts) + tuple(grads[n] for n in names)
+
+
+def nof_points_dumped(xyz, nof_embs, m, acts, emb, out):
+    """(N,S,3) points -> the dumped NoF output (N,S,3), differentiable w.r.t. the points and the NoF parameters."""
+    N, S = xyz.shape[:2]
+    return NofPointsDumped.apply(m, nof_embs, acts, emb, out, xyz.reshape(-1, 3), *m.parameters()).view(N, S, 3)
+
+
 def nof_points(xyz, ray_ind, nof_embs, m):
     """_nof_points with the HIP forward/backward node when the configuration is built (else torch ops)."""
     N, S = xyz.shape[0], xyz.shape[1]

@@ -190,9 +190,12 @@ MF_D void quat_transform(const float (&T)[9], const float (&xyz)[3], float (&out
 }
 
 // Neural motion flow on this wave's 16 samples; emb = [xyz block ; ind block] (kStepsNofIn).
-template <bool BF16>
+// DUMP (training forward): `drow` = this lane's sample row [h_1 .. h_D | T (9 | 3) zero-padded to 16] (nullptr: skip),
+// the layout mf_nof_backward / mf_weight_grads read (mf_nofgrad.hip).
+template <bool BF16, bool DUMP = false>
 MF_D void nof_eval(const NetDev& net, const float (&emb)[kStepsNofIn], const float (&xyz)[3], Stream& st,
-                   CarryT<Pipe<BF16>::PD>& carry, const LaneId& id, const NextLayer& follow, float (&out)[3]) {
+                   CarryT<Pipe<BF16>::PD>& carry, const LaneId& id, const NextLayer& follow, float (&out)[3],
+                   float* drow = nullptr) {
   constexpr int NK = 8;
   typename ActT<BF16>::T act[ActLen<BF16, NK>::N];
 #pragma unroll
@@ -212,19 +215,29 @@ MF_D void nof_eval(const NetDev& net, const float (&emb)[kStepsNofIn], const flo
   } else {
     for (int l = 0; l < D; ++l) {
       const bool last = l == D - 1;
-      trunk_layer<NK, kStepsNofIn, BF16>(net, l, act, emb, st, carry, id, last ? follow : next_trunk(net, l + 1));
+      trunk_layer<NK, kStepsNofIn, BF16, DUMP>(net, l, act, emb, st, carry, id, last ? follow : next_trunk(net, l + 1),
+                                               drow ? drow + l * net.L.W : nullptr);
     }
   }
   const uint32_t wo = net.res_lds + net.L.off_head_w * 4, bo = net.res_lds + net.L.off_head_b * 4;
+  float T[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (net.L.n_head == 9) {
-    float T[9];
     valu_head(act, wo, net.L.W, bo, id.g, T);
     quat_transform(T, xyz, out);
   } else {
-    float T[3];
-    valu_head(act, wo, net.L.W, bo, id.g, T);
+    float T3[3];
+    valu_head(act, wo, net.L.W, bo, id.g, T3);
 #pragma unroll
-    for (int c = 0; c < 3; ++c) out[c] = T[c] + xyz[c];
+    for (int c = 0; c < 3; ++c) { T[c] = T3[c]; out[c] = T3[c] + xyz[c]; }
+  }
+  if constexpr (DUMP) {
+    if (drow && id.g == 0) {
+      float4* tr = reinterpret_cast<float4*>(drow + D * net.L.W);
+      tr[0] = make_float4(T[0], T[1], T[2], T[3]);
+      tr[1] = make_float4(T[4], T[5], T[6], T[7]);
+      tr[2] = make_float4(T[8], 0.f, 0.f, 0.f);
+      tr[3] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
   }
 }
 

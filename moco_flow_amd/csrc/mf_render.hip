@@ -42,6 +42,7 @@ struct RenderParams {
   uint32_t ring_off, buf_bytes, sbuf_off, zbuf_off;
   int dbg;
   float* dump_acts; long long dump_stride; float* dump_rgbsigma; float* dump_xyz;   // training forward
+  float* dump_nof_acts; long long dump_nof_stride; float* dump_nof_emb; float* dump_nof_out;   // per chain step
 };
 
 // inclusive product scan across the 64 lanes of a wave
@@ -145,7 +146,32 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
           const NextLayer follow = last ? follow_of(nerf) : (next_fw ? follow_of(p.fw) : follow_of(p.bw));
           float emb[kStepsNofIn], out[3];
           nof_embed_lds(emb, cur, ind, par_nof_xyz, par_nof_ind, id.g);
-          nof_eval<BF16>(net, emb, cur, st, carry, id, follow, out);
+          float* nof_row = nullptr;
+          long long nof_idx = 0;
+          if constexpr (DUMP) {
+            if (valid && p.dump_nof_acts) {
+              // training forward: what autograd.NofPoints' backward reads, per chain step (step-major planes)
+              nof_idx = (long long)step * p.n_rays * S + (ray * S + si);
+              nof_row = p.dump_nof_acts + nof_idx * p.dump_nof_stride;
+              float* erow = p.dump_nof_emb + nof_idx * 80;
+#pragma unroll
+              for (int e = 0; e < kStepsNofIn; ++e) {
+                const int f = sel4(id.g, emb_feature(kEmbNofIn, 0, e, 33), emb_feature(kEmbNofIn, 1, e, 33),
+                                   emb_feature(kEmbNofIn, 2, e, 33), emb_feature(kEmbNofIn, 3, e, 33));
+                if (f >= 0) erow[f] = emb[e];
+              }
+              if (id.g == 0)
+                for (int c = 66; c < 80; ++c) erow[c] = 0.f;
+            }
+            st.keep2 = false;
+          }
+          nof_eval<BF16, DUMP>(net, emb, cur, st, carry, id, follow, out, nof_row);
+          if constexpr (DUMP) {
+            if (nof_row && id.g == 0) {
+              float* q = p.dump_nof_out + nof_idx * 3;
+              q[0] = out[0]; q[1] = out[1]; q[2] = out[2];
+            }
+          }
           if (role == 0) { canon[0] = out[0]; canon[1] = out[1]; canon[2] = out[2]; }
           if (role == 1) dl = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
           if (role == 4) dg = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
@@ -280,7 +306,7 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
   RenderParams p{};
   if (!nerf_layout(*a->nerf, p.nerf.L, 0)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported NeRF configuration");
   if (p.nerf.L.NK != 16) return fail(MF_E_UNSUPPORTED, "mf_render_pass: only W=256 NeRF is built");
-  const bool dump = a->dump_acts || a->dump_rgbsigma || a->dump_xyz;
+  const bool dump = a->dump_acts || a->dump_rgbsigma || a->dump_xyz || a->dump_nof_acts;
   if (dump && bf16) return fail(MF_E_UNSUPPORTED, "mf_render_pass: the activation dump (training forward) is fp32 only");
   if (a->emb_xyz.in_channels != 3 || a->emb_xyz.n_freqs > 10)
     return fail(MF_E_UNSUPPORTED, "mf_render_pass: xyz embedding must have 3 channels and <= 10 frequencies");
@@ -367,6 +393,15 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
   if (a->dump_acts && a->dump_stride < (int64_t)p.nerf.L.n_trunk * p.nerf.L.W + p.nerf.L.W / 2)
     return fail(MF_E_INVALID, "mf_render_pass: dump_stride %lld too small", (long long)a->dump_stride);
   p.dump_acts = a->dump_acts; p.dump_stride = a->dump_stride; p.dump_rgbsigma = a->dump_rgbsigma; p.dump_xyz = a->dump_xyz;
+  if (a->dump_nof_acts) {
+    if (!moco || !a->dump_nof_emb || !a->dump_nof_out) return fail(MF_E_INVALID, "mf_render_pass: dump_nof_acts needs NoF models, dump_nof_emb and dump_nof_out");
+    if (a->dump_nof_stride < (int64_t)p.bw.L.n_trunk * p.bw.L.W + 16 || (a->dump_nof_stride & 3))
+      return fail(MF_E_INVALID, "mf_render_pass: dump_nof_stride %lld invalid", (long long)a->dump_nof_stride);
+    if (a->nof_fw && (p.fw.L.n_trunk != p.bw.L.n_trunk || p.fw.L.W != p.bw.L.W))
+      return fail(MF_E_UNSUPPORTED, "mf_render_pass: NoF dumps need bw and fw of the same depth and width");
+    if (a->precision != MF_PREC_F32) return fail(MF_E_UNSUPPORTED, "mf_render_pass: NoF dumps are fp32 only");
+  }
+  p.dump_nof_acts = a->dump_nof_acts; p.dump_nof_stride = a->dump_nof_stride; p.dump_nof_emb = a->dump_nof_emb; p.dump_nof_out = a->dump_nof_out;
   void (*kern)(RenderParams) =
       dump ? (moco ? render_kernel<true, false, true> : render_kernel<false, false, true>)
            : (moco ? render_kernel<true, false, false> : render_kernel<false, false, false>);

@@ -114,6 +114,15 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
         a.dump_stride = stride
         a.dump_rgbsigma = alloc("rgbsig", (N * S, 4))
         a.dump_xyz = alloc("xyz_in", (N * S, 3))
+        if nof_models is not None and all(A.nof_hip_supported(m, nof_embs) for m in nof_models) \
+                and len({(m.D, m.W) for m in nof_models}) == 1 and A._NOF_BACKWARD == "hip":
+            # the chain's NoF evaluations dump too (one plane per step): no re-evaluation in the backward graph
+            steps = 1 + (1 if chain_local else 0) + (3 if chain_global else 0)
+            nstride = nof_models[0].D * nof_models[0].W + 16
+            a.dump_nof_acts = alloc("nof_acts", (steps, N * S, nstride))
+            a.dump_nof_stride = nstride
+            a.dump_nof_emb = alloc("nof_emb", (steps, N * S, 80))
+            a.dump_nof_out = alloc("nof_out", (steps, N * S, 3))
     with torch.cuda.device(dev):
         L.check(L.lib().mf_render_pass(C.byref(a), L.current_stream(dev)), "mf_render_pass")
     del keep
@@ -418,31 +427,41 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
         xin = p["xyz_in"]
         if nof_models is not None:
             bw = nof_models[0]
-            canon = A.nof_points(xyz, ind, nof_embs, bw)
+            if "nof_acts" in p:       # the fused pass dumped every evaluation of the chain: nodes without a forward launch
+                step = [0]
+
+                def nof_points(pts, ray_ind, embs_, m):
+                    k = step[0]
+                    step[0] += 1
+                    return A.nof_points_dumped(pts, nof_embs, m, p["nof_acts"][k], p["nof_emb"][k], p["nof_out"][k])
+            else:
+                nof_points = A.nof_points
+            canon = nof_points(xyz, ind, nof_embs, bw)
             if loc:
                 fw = nof_models[1]
-                recon = A.nof_points(canon, ind, nof_embs, fw)
+                recon = nof_points(canon, ind, nof_embs, fw)
                 if loss_target is None:
                     out[f"nof_local_disp_{tag}"] = torch.mean(torch.abs(xyz - recon)[mask], dim=1)
                 else:
                     cons[f"local_{tag}"] = _masked_sum(torch.abs(xyz - recon), mask)
             if glob:
                 cind = rays[:, 9:10]
-                a_ = A.nof_points(canon, cind, nof_embs, fw)
-                b_ = A.nof_points(a_, cind, nof_embs, bw)
-                gd = torch.abs(xyz - A.nof_points(b_, ind, nof_embs, fw))
+                a_ = nof_points(canon, cind, nof_embs, fw)
+                b_ = nof_points(a_, cind, nof_embs, bw)
+                gd = torch.abs(xyz - nof_points(b_, ind, nof_embs, fw))
                 if loss_target is None:
                     out[f"nof_global_disp_{tag}"] = torch.mean(gd[mask], dim=1)
                 else:
                     cons[f"global_{tag}"] = _masked_sum(gd, mask)
             xin = canon.reshape(-1, 3)
         with torch.no_grad():
-            emb_in = A._pad_to(A.embed(nerf_embs[0], p["xyz_in"]), nerf.in_channels_xyz)
+            # (mf_embedding_forward: one launch each instead of ~60 elementwise ones)
+            emb_in = A._pad_to(nerf_embs[0](p["xyz_in"]), nerf.in_channels_xyz)
             extra_in = None
             if nerf.extra_feat_type == "ind":
-                extra_in = A._pad_to(torch.repeat_interleave(A.embed(nerf_embs[1], ind), S, dim=0), nerf.extra_feat_dim)
+                extra_in = A._pad_to(torch.repeat_interleave(nerf_embs[1](ind.contiguous()), S, dim=0), nerf.extra_feat_dim)
             elif nerf.extra_feat_type == "dir":
-                extra_in = A._pad_to(torch.repeat_interleave(A.embed(nerf_embs[2], rays_d), S, dim=0), nerf.extra_feat_dim)
+                extra_in = A._pad_to(torch.repeat_interleave(nerf_embs[2](rays_d.contiguous()), S, dim=0), nerf.extra_feat_dim)
         rgbsig = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, nerf_embs[0], xin,
                                      *nerf.parameters())
         if A._COMPOSITE_BACKWARD == "hip" and activation in ("relu", "softplus") and S <= 2048:
