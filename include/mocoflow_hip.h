@@ -29,7 +29,9 @@ extern "C" {
 /* 3: activation dump of the training forward; 4: mf_nerf_backward, mf_weight_grads; 5: NoF backward
  * (mf_nof_points_dump, mf_nof_backward); 6: mf_composite_backward, mf_image_compose;
  * 7: mf_nof_forward_dump; 8: mf_loss_partials, new packed layout of MF_PREC_BF16 (32x32x16 fragments);
- * 9: mf_valid_rays_mask, mf_nerf_backward_x (embedded-input gradient in the chain launch), mf_embedding_backward */
+ * 9: mf_valid_rays_mask, mf_nerf_backward_x (embedded-input gradient in the chain launch), mf_embedding_backward;
+ * 10: mf_nerf_forward_dump, mf_render_args.dump_nof_* (+ mf_nof_emb_slot_features), mf_smpl_lbs,
+ *     mf_smpl_frame_transforms, mf_apply_vertex_transforms */
 #define MF_ABI_VERSION 10
 
 enum {
@@ -279,15 +281,22 @@ typedef struct mf_render_args {
   /* The same for the NoF evaluations of the chain program (rendering.py:270-282), one plane per step k in
    * [bw(x,i), fw(canon,i), fw(canon,j), bw(.,j), fw(.,i)] (as many as the flags run), each N*S rows:
    * dump_nof_acts (steps, N*S, dump_nof_stride): [h_1 | ... | h_D | T (9 | 3) zero-padded to 16]
-   * (dump_nof_stride >= D*W + 16), dump_nof_emb (steps, N*S, 80): the embedded input [xyz 33 | ind 33 | 0 x 14],
+   * (dump_nof_stride >= D*W + 16), dump_nof_emb (steps, N*S, 80): the embedded input [xyz 33 | ind 33] in the
+   * kernel's register-slot order (column c holds reference column mf_nof_emb_slot_features()[c], -1 = zero pad: the
+   * weight gradient taken against it is un-permuted once per launch, on 128 x 80 numbers),
    * dump_nof_out (steps, N*S, 3): the step's output points.  This is what mf_nof_points_dump writes for one
-   * evaluation; with it the backward needs no forward re-evaluation of the chains.  All three or none. */
+   * evaluation (there in natural column order); with it the backward needs no forward re-evaluation of the chains.
+   * All three or none. */
   float* dump_nof_acts; int64_t dump_nof_stride;
   float* dump_nof_emb;
   float* dump_nof_out;
 } mf_render_args;
 
 int32_t mf_render_pass(const mf_render_args* a, void* stream);
+
+/* Column map of mf_render_args.dump_nof_emb: features80[c] = column of the NoF's embedded input ([xyz 33 | ind 33])
+ * stored at dump column c, or -1 (zero).  Host-side, no stream. */
+int32_t mf_nof_emb_slot_features(int32_t* features80);
 
 /* ---- hierarchical resampling: sample_pdf (rendering.py:5-46) [+ cat + sort, :321-326] ------
  * General form.  Per ray: n_bins bin positions -- either explicit `bins` (N, n_bins), the

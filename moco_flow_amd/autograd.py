@@ -328,9 +328,28 @@ def nof_hip_supported(m, nof_embs) -> bool:
     return ok and (nof_embs is None or (nof_embs[0].N_freqs <= 5 and nof_embs[1].N_freqs == 16))
 
 
-def _nof_param_grads(m, gpre, acts, emb80, req):
+_SLOT_COLS = {}
+
+
+def _nof_slot_columns(dev):
+    """For each of the 66 embedded-input columns, its column in the slot-ordered dump of the fused pass
+    (mf_render_args.dump_nof_emb, map from mf_nof_emb_slot_features)."""
+    key = str(dev)
+    if key not in _SLOT_COLS:
+        feats = (C.c_int32 * 80)()
+        L.check(L.lib().mf_nof_emb_slot_features(feats), "mf_nof_emb_slot_features")
+        where = [0] * 66
+        for c, f in enumerate(feats):
+            if f >= 0:
+                where[f] = c
+        _SLOT_COLS[key] = torch.tensor(where, dtype=torch.int64, device=dev)
+    return _SLOT_COLS[key]
+
+
+def _nof_param_grads(m, gpre, acts, emb80, req, slot_order=False):
     """dW / db of every NoF layer from the gradient buffer of mf_nof_backward and the forward dump:
-    ONE mf_weight_grads launch (emb80 = the embedded input, 66 columns padded to 80)."""
+    ONE mf_weight_grads launch (emb80 = the embedded input, 66 columns padded to 80; ``slot_order``: its columns are in
+    the fused pass' register-slot order and the 128 x 80 result is gathered back)."""
     P, dev = acts.shape[0], acts.device
     D, W = m.D, m.W
     names = [n for n, _ in m.named_parameters()]
@@ -347,7 +366,7 @@ def _nof_param_grads(m, gpre, acts, emb80, req):
         blocks = []
         if l == 0 or l in m.skips:
             jobs.append((gslot(l), emb80, 128, 80, l == 0))
-            blocks.append((len(jobs) - 1, slice(0, cin)))
+            blocks.append((len(jobs) - 1, _nof_slot_columns(dev)[:cin] if slot_order else slice(0, cin)))
         if l > 0:
             jobs.append((gslot(l), h(l - 1), 128, 128, True))
             blocks.append((len(jobs) - 1, slice(0, W)))
@@ -495,7 +514,7 @@ class NofPointsDumped(torch.autograd.Function):
                                                 acts.data_ptr(), stride, g_out.data_ptr(), gpre.data_ptr(),
                                                 g_pts.data_ptr() if need_pts else None, L.current_stream(dev)),
                         "mf_nof_backward")
-            grads = _nof_param_grads(m, gpre[:P], acts, emb, req)
+            grads = _nof_param_grads(m, gpre[:P], acts, emb, req, slot_order=True)
         return (None, None, None, None, None, g_pts) + tuple(grads[n] for n in names)
 
 

@@ -153,15 +153,11 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
               // training forward: what autograd.NofPoints' backward reads, per chain step (step-major planes)
               nof_idx = (long long)step * p.n_rays * S + (ray * S + si);
               nof_row = p.dump_nof_acts + nof_idx * p.dump_nof_stride;
-              float* erow = p.dump_nof_emb + nof_idx * 80;
+              // embedded input in the kernel's own slot order (column 20 g + e = slot e of lane group g: five 16-byte
+              // stores per lane instead of twenty scattered dwords; mf_nof_emb_slot_features gives the column map)
+              float4* e4 = reinterpret_cast<float4*>(p.dump_nof_emb + nof_idx * 80 + 20 * id.g);
 #pragma unroll
-              for (int e = 0; e < kStepsNofIn; ++e) {
-                const int f = sel4(id.g, emb_feature(kEmbNofIn, 0, e, 33), emb_feature(kEmbNofIn, 1, e, 33),
-                                   emb_feature(kEmbNofIn, 2, e, 33), emb_feature(kEmbNofIn, 3, e, 33));
-                if (f >= 0) erow[f] = emb[e];
-              }
-              if (id.g == 0)
-                for (int c = 66; c < 80; ++c) erow[c] = 0.f;
+              for (int q = 0; q < kStepsNofIn / 4; ++q) e4[q] = make_float4(emb[4 * q], emb[4 * q + 1], emb[4 * q + 2], emb[4 * q + 3]);
             }
             st.keep2 = false;
           }
@@ -224,7 +220,11 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
       const float dnorm = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);  // rendering.py:164
       float carry = 1.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_w = 0.f;
       for (int base = 0; base < S; base += 64) {
-        const int i = base + id.lane;
+        // (opaque lane index: keeps hipcc from hoisting `plane + 4 lane` of every output plane out of the group loop
+        //  as 64-bit per-lane addresses that then sit in -- or spill from -- registers across the MFMA section)
+        int ln = id.lane;
+        asm volatile("" : "+v"(ln));
+        const int i = base + ln;
         const bool v = i < S;
         const int ii = v ? i : S - 1;
         const float4 s4 = sbuf[rr * S + ii];
@@ -290,6 +290,13 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st);   // mf_render_bf
 }  // namespace mf
 
 using namespace mf;
+
+extern "C" int32_t mf_nof_emb_slot_features(int32_t* features80) {
+  if (!features80) return fail(MF_E_INVALID, "mf_nof_emb_slot_features: null argument");
+  for (int g = 0; g < 4; ++g)
+    for (int e = 0; e < kStepsNofIn; ++e) features80[kStepsNofIn * g + e] = emb_feature(kEmbNofIn, g, e, 33);
+  return MF_OK;
+}
 
 extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
   if (!a || !a->nerf || !a->nerf_packed) return fail(MF_E_INVALID, "mf_render_pass: null argument");

@@ -171,7 +171,11 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
       const float dnorm = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);  // rendering.py:164
       float carry_t = 1.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_w = 0.f;
       for (int base = 0; base < S; base += 64) {
-        const int i = base + id.lane;
+        // (the lane index is made opaque here: hipcc otherwise hoists `plane + 4 lane` of every output plane out of the
+        //  whole group loop as 64-bit per-lane addresses and spills them across the MFMA section)
+        int ln = id.lane;
+        asm volatile("" : "+v"(ln));
+        const int i = base + ln;
         const bool v = i < S;
         const int ii = v ? i : S - 1;
         const float4 s4 = sbuf[rr * S + ii];
