@@ -286,10 +286,13 @@ typedef struct mf_render_args {
    * weight gradient taken against it is un-permuted once per launch, on 128 x 80 numbers),
    * dump_nof_out (steps, N*S, 3): the step's output points.  This is what mf_nof_points_dump writes for one
    * evaluation (there in natural column order); with it the backward needs no forward re-evaluation of the chains.
-   * All three or none. */
+   * All three or none.  dump_nof_plane[k] = plane (0 .. steps-1, a permutation) that step k writes: lets the caller
+   * keep the evaluations of one network adjacent (bw: steps 0, 3; fw: steps 1, 2, 4), so that its weight gradients
+   * are one contraction over all of them. */
   float* dump_nof_acts; int64_t dump_nof_stride;
   float* dump_nof_emb;
   float* dump_nof_out;
+  int32_t dump_nof_plane[5];
 } mf_render_args;
 
 int32_t mf_render_pass(const mf_render_args* a, void* stream);

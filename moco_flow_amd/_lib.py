@@ -74,7 +74,8 @@ class mf_render_args(C.Structure):
                 ("rgb", _fp), ("depth", _fp), ("opacity", _fp), ("weights", _fp), ("alphas", _fp),
                 ("disp_local", _fp), ("disp_global", _fp), ("precision", C.c_int32),
                 ("dump_acts", _fp), ("dump_stride", C.c_int64), ("dump_rgbsigma", _fp), ("dump_xyz", _fp),
-                ("dump_nof_acts", _fp), ("dump_nof_stride", C.c_int64), ("dump_nof_emb", _fp), ("dump_nof_out", _fp)]
+                ("dump_nof_acts", _fp), ("dump_nof_stride", C.c_int64), ("dump_nof_emb", _fp), ("dump_nof_out", _fp),
+                ("dump_nof_plane", C.c_int32 * 5)]
 
 
 # every symbol include/mocoflow_hip.h declares: (restype, argtypes)

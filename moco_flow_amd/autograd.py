@@ -486,13 +486,70 @@ class NofPoints(torch.autograd.Function):
         return (None, None, None, None, g_pts) + tuple(grads[n] for n in names)
 
 
-class NofPointsDumped(torch.autograd.Function):
-    """The same node when the fused render pass already evaluated and dumped this step of the chain
-    (mf_render_args.dump_nof_*): forward = the dumped output points, no launch; backward as NofPoints."""
+class NofGradSink:
+    """Weight gradients of ONE NoF over all of its evaluations in a render pass.  The chain's nodes (NofPointsDumped)
+    leave their pre-activation gradients in planes of one buffer laid out like the forward dump (the fused pass keeps a
+    network's evaluations in adjacent planes); NofParamGate's backward -- which autograd runs after every consumer of
+    the gated parameters -- turns all of them into dW / db with one mf_weight_grads launch (instead of one launch and
+    one gradient accumulation per evaluation)."""
+
+    def __init__(self, m, acts, emb):
+        self.m, self.acts, self.emb = m, acts, emb           # (n, P, stride), (n, P, 80): this network's planes
+        self.gpre, self.filled = None, set()
+
+    def plane(self, k):
+        if self.gpre is None:
+            self.gpre = torch.empty_like(self.acts)
+        self.filled.add(k)
+        return self.gpre[k]
+
+    def flush(self):
+        m = self.m
+        names = [n for n, _ in m.named_parameters()]
+        req = {n: p.requires_grad for n, p in m.named_parameters()}
+        total = {n: None for n in names}
+        ks = sorted(self.filled)
+        runs, i = [], 0
+        while i < len(ks):                                    # maximal runs of adjacent planes (normally one)
+            j = i
+            while j + 1 < len(ks) and ks[j + 1] == ks[j] + 1:
+                j += 1
+            runs.append((ks[i], ks[j] + 1))
+            i = j + 1
+        for lo, hi in runs:
+            flat = lambda t: t[lo:hi].reshape(-1, t.shape[-1])
+            g = _nof_param_grads(m, flat(self.gpre), flat(self.acts), flat(self.emb), req, slot_order=True)
+            for n in names:
+                if g[n] is not None:
+                    total[n] = g[n] if total[n] is None else total[n] + g[n]
+        self.gpre, self.filled = None, set()
+        return [total[n] for n in names]
+
+
+class NofParamGate(torch.autograd.Function):
+    """Identity on a network's parameters whose backward is NofGradSink.flush (see there)."""
 
     @staticmethod
-    def forward(ctx, m, nof_embs, acts, emb, out, pts, *params):
+    def forward(ctx, sink, *params):
+        ctx.sink = sink
+        ctx.set_materialize_grads(False)
+        return tuple(p.view_as(p) for p in params)
+
+    @staticmethod
+    def backward(ctx, *_unused):
+        with torch.no_grad():
+            return (None,) + tuple(ctx.sink.flush())
+
+
+class NofPointsDumped(torch.autograd.Function):
+    """The same node when the fused render pass already evaluated and dumped this step of the chain
+    (mf_render_args.dump_nof_*): forward = the dumped output points, no launch; backward as NofPoints, the weight
+    gradients either here or -- with a ``sink`` -- deferred to the network's NofParamGate."""
+
+    @staticmethod
+    def forward(ctx, m, nof_embs, acts, emb, out, sink, sink_plane, pts, *params):
         ctx.m, ctx.ex, ctx.stride = m, nof_embs[0].descriptor(), acts.shape[1]
+        ctx.sink, ctx.sink_plane = sink, sink_plane
         ctx.save_for_backward(pts.detach().contiguous().float(), acts, emb)
         return out.clone()
 
@@ -503,25 +560,32 @@ class NofPointsDumped(torch.autograd.Function):
         P, dev = pts.shape[0], pts.device
         names = [n for n, _ in m.named_parameters()]
         req = {n: p.requires_grad for n, p in m.named_parameters()}
-        need_pts = ctx.needs_input_grad[5]
+        need_pts = ctx.needs_input_grad[7]
         with torch.no_grad():
             desc, buf = m.packed_bwd()
             g_out = g_out.contiguous().float()
-            gpre = torch.empty(((P + 127) // 128 * 128, stride), device=dev, dtype=torch.float32)
+            if ctx.sink is not None:
+                gpre = ctx.sink.plane(ctx.sink_plane)                 # (P, stride), P % 128 == 0
+            else:
+                gpre = torch.empty(((P + 127) // 128 * 128, stride), device=dev, dtype=torch.float32)
             g_pts = torch.empty((P, 3), device=dev, dtype=torch.float32) if need_pts else None
             with torch.cuda.device(dev):
                 L.check(L.lib().mf_nof_backward(C.byref(desc), buf.data_ptr(), C.byref(ctx.ex), P, pts.data_ptr(),
                                                 acts.data_ptr(), stride, g_out.data_ptr(), gpre.data_ptr(),
                                                 g_pts.data_ptr() if need_pts else None, L.current_stream(dev)),
                         "mf_nof_backward")
+            if ctx.sink is not None:
+                return (None,) * 7 + (g_pts,) + (None,) * len(names)
             grads = _nof_param_grads(m, gpre[:P], acts, emb, req, slot_order=True)
-        return (None, None, None, None, None, g_pts) + tuple(grads[n] for n in names)
+        return (None,) * 7 + (g_pts,) + tuple(grads[n] for n in names)
 
 
-def nof_points_dumped(xyz, nof_embs, m, acts, emb, out):
-    """(N,S,3) points -> the dumped NoF output (N,S,3), differentiable w.r.t. the points and the NoF parameters."""
+def nof_points_dumped(xyz, nof_embs, m, acts, emb, out, sink=None, sink_plane=0, params=None):
+    """(N,S,3) points -> the dumped NoF output (N,S,3), differentiable w.r.t. the points and the NoF parameters
+    (``params``: the network's NofParamGate outputs when the weight gradients go through ``sink``)."""
     N, S = xyz.shape[:2]
-    return NofPointsDumped.apply(m, nof_embs, acts, emb, out, xyz.reshape(-1, 3), *m.parameters()).view(N, S, 3)
+    params = tuple(m.parameters()) if params is None else params
+    return NofPointsDumped.apply(m, nof_embs, acts, emb, out, sink, sink_plane, xyz.reshape(-1, 3), *params).view(N, S, 3)
 
 
 def nof_points(xyz, ray_ind, nof_embs, m):

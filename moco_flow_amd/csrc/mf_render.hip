@@ -43,6 +43,7 @@ struct RenderParams {
   int dbg;
   float* dump_acts; long long dump_stride; float* dump_rgbsigma; float* dump_xyz;   // training forward
   float* dump_nof_acts; long long dump_nof_stride; float* dump_nof_emb; float* dump_nof_out;   // per chain step
+  uint32_t nof_plane_pack;     // plane of step k = (pack >> 3k) & 7   (a packed scalar: no runtime index into the kernarg)
 };
 
 // inclusive product scan across the 64 lanes of a wave
@@ -151,7 +152,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
           if constexpr (DUMP) {
             if (valid && p.dump_nof_acts) {
               // training forward: what autograd.NofPoints' backward reads, per chain step (step-major planes)
-              nof_idx = (long long)step * p.n_rays * S + (ray * S + si);
+              nof_idx = (long long)((p.nof_plane_pack >> (3 * step)) & 7u) * p.n_rays * S + (ray * S + si);
               nof_row = p.dump_nof_acts + nof_idx * p.dump_nof_stride;
               // embedded input in the kernel's own slot order (column 20 g + e = slot e of lane group g: five 16-byte
               // stores per lane instead of twenty scattered dwords; mf_nof_emb_slot_features gives the column map)
@@ -409,6 +410,16 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
     if (a->precision != MF_PREC_F32) return fail(MF_E_UNSUPPORTED, "mf_render_pass: NoF dumps are fp32 only");
   }
   p.dump_nof_acts = a->dump_nof_acts; p.dump_nof_stride = a->dump_nof_stride; p.dump_nof_emb = a->dump_nof_emb; p.dump_nof_out = a->dump_nof_out;
+  if (a->dump_nof_acts) {
+    const int nsteps = 1 + ((a->flags & MF_F_CHAIN_LOCAL) ? 1 : 0) + ((a->flags & MF_F_CHAIN_GLOBAL) ? 3 : 0);
+    uint32_t seen = 0;
+    for (int k = 0; k < nsteps; ++k) {
+      const int pl = a->dump_nof_plane[k];
+      if (pl < 0 || pl >= nsteps || ((seen >> pl) & 1u)) return fail(MF_E_INVALID, "mf_render_pass: dump_nof_plane must be a permutation of 0..%d", nsteps - 1);
+      seen |= 1u << pl;
+      p.nof_plane_pack |= (uint32_t)pl << (3 * k);
+    }
+  }
   void (*kern)(RenderParams) =
       dump ? (moco ? render_kernel<true, false, true> : render_kernel<false, false, true>)
            : (moco ? render_kernel<true, false, false> : render_kernel<false, false, false>);

@@ -118,6 +118,11 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
                 and len({(m.D, m.W) for m in nof_models}) == 1 and A._NOF_BACKWARD == "hip":
             # the chain's NoF evaluations dump too (one plane per step): no re-evaluation in the backward graph
             steps = 1 + (1 if chain_local else 0) + (3 if chain_global else 0)
+            # planes grouped by network (bw: steps 0, 3; fw: steps 1, 2, 4): one weight-gradient contraction per network
+            order = [k for k in range(steps) if k in (0, 3)] + [k for k in range(steps) if k in (1, 2, 4)]
+            out["nof_plane"] = [order.index(k) for k in range(steps)]
+            for k in range(steps):
+                a.dump_nof_plane[k] = out["nof_plane"][k]
             nstride = nof_models[0].D * nof_models[0].W + 16
             a.dump_nof_acts = alloc("nof_acts", (steps, N * S, nstride))
             a.dump_nof_stride = nstride
@@ -429,11 +434,24 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
             bw = nof_models[0]
             if "nof_acts" in p:       # the fused pass dumped every evaluation of the chain: nodes without a forward launch
                 step = [0]
+                plane = p["nof_plane"]
+                n_bw = sum(1 for k in range(len(plane)) if k in (0, 3))
+                # per network: its planes are adjacent; with whole 128-row blocks per plane the nodes leave their
+                # pre-activation gradients in one buffer and ONE mf_weight_grads launch per network follows them
+                batched = (N * S) % 128 == 0
+                sinks = {}
+                if batched:
+                    sinks[id(bw)] = (A.NofGradSink(bw, p["nof_acts"][:n_bw], p["nof_emb"][:n_bw]), 0)
+                    if len(plane) > n_bw:
+                        sinks[id(nof_models[1])] = (A.NofGradSink(nof_models[1], p["nof_acts"][n_bw:], p["nof_emb"][n_bw:]), n_bw)
+                gated = {key: A.NofParamGate.apply(sk, *sk.m.parameters()) for key, (sk, _) in sinks.items()}
 
                 def nof_points(pts, ray_ind, embs_, m):
-                    k = step[0]
+                    k = plane[step[0]]
                     step[0] += 1
-                    return A.nof_points_dumped(pts, nof_embs, m, p["nof_acts"][k], p["nof_emb"][k], p["nof_out"][k])
+                    sk, first = sinks.get(id(m), (None, 0))
+                    return A.nof_points_dumped(pts, nof_embs, m, p["nof_acts"][k], p["nof_emb"][k], p["nof_out"][k],
+                                               sink=sk, sink_plane=k - first, params=gated.get(id(m)))
             else:
                 nof_points = A.nof_points
             canon = nof_points(xyz, ind, nof_embs, bw)
@@ -441,7 +459,7 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
                 fw = nof_models[1]
                 recon = nof_points(canon, ind, nof_embs, fw)
                 if loss_target is None:
-                    out[f"nof_local_disp_{tag}"] = torch.mean(torch.abs(xyz - recon)[mask], dim=1)
+                    out[f"nof_local_disp_{tag}"] = _masked_point_means(torch.abs(xyz - recon), mask)
                 else:
                     cons[f"local_{tag}"] = _masked_sum(torch.abs(xyz - recon), mask)
             if glob:
@@ -450,7 +468,7 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
                 b_ = nof_points(a_, cind, nof_embs, bw)
                 gd = torch.abs(xyz - nof_points(b_, ind, nof_embs, fw))
                 if loss_target is None:
-                    out[f"nof_global_disp_{tag}"] = torch.mean(gd[mask], dim=1)
+                    out[f"nof_global_disp_{tag}"] = _masked_point_means(gd, mask)
                 else:
                     cons[f"global_{tag}"] = _masked_sum(gd, mask)
             xin = canon.reshape(-1, 3)
@@ -495,6 +513,12 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
                 parts += list(cons.get(f"{key}_{tag}", (zero, zero)))
         final["loss_partials"] = torch.stack(parts)
     return final
+
+
+def _masked_point_means(dist3, mask):
+    """torch.mean(dist3[mask], dim=1) of rendering.py:310-314 as mean-then-select: the same numbers, but the backward
+    is a masked scatter instead of the sort + accumulate of boolean-index backward."""
+    return torch.masked_select(dist3.mean(-1), mask)
 
 
 def _mask_nosync(alphas):
