@@ -6,7 +6,7 @@ import csv, glob, os, re, sys
 from collections import defaultdict
 
 out = sys.argv[1]
-STEPS = 6          # the tools run 1 warm-up + 5 timed steps
+STEPS = 6          # fallback; normally derived below from the backward launches (two NeRF passes per step)
 
 
 def rows(pattern):
@@ -22,6 +22,9 @@ dur = defaultdict(list)
 for r in rows("trace/**/*kernel_trace.csv"):
     dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
 tot = sum(sum(v) for v in dur.values())
+nb = sum(len(v) for k, v in dur.items() if "nerf_backward_kernel" in k)
+if nb:
+    STEPS = nb / 2
 print(f"\n== kernel time per training step (rocprofv3 --kernel-trace; {STEPS} steps) ==  total {tot/STEPS/1e6:.2f} ms/step")
 print(f"{'kernel':62s} {'calls/step':>10s} {'avg us':>9s} {'ms/step':>8s} {'%':>6s}")
 other = 0.0

@@ -72,6 +72,9 @@ def fwd_bwd_fast():
     (t["img_loss"] + 0.1 * (t["nof_local"] + t["nof_global"])).backward()
 
 
+if os.environ.get("MF_ONLY") == "step":       # profiling: only the shipped training step
+    print(f"  HIP forward + backward (shipped) : {timeit(fwd_bwd):8.2f} ms")
+    sys.exit(0)
 print(f"N_rand={N} rays x ({S} + {S+Mi}) samples = {N*(2*S+Mi)/1e6:.2f} M samples/step, bw NoF + local + global chains")
 print(f"  HIP forward (no_grad)            : {timeit(fwd_only):8.2f} ms")
 print(f"  HIP forward + backward (shipped) : {timeit(fwd_bwd):8.2f} ms")

@@ -37,7 +37,7 @@ def eager_fwd():
         c = A.render_pass(rays, bg, z, None, "relu", nerfs[0], embs, None, None, False, False, False, None)
         z2 = rendering.resample_merge(z, c["weights"], Mi)
         A.render_pass(rays, bg, z2, None, "relu", nerfs[1], embs, None, None, False, False, False, None)
-if os.environ.get("MF_ONLY") == "hipbwd":      # profiling: only the shipped training path
+if os.environ.get("MF_ONLY") in ("hipbwd", "step"):      # profiling: only the shipped training path
     print(f"  HIP forward + HIP dX chain + dW GEMMs : {timeit(fwd_bwd):8.2f} ms")
     sys.exit(0)
 print(f"N_rand={N} rays x ({S} + {S+Mi}) samples = {N*(2*S+Mi)/1e6:.2f} M samples/step")
