@@ -44,17 +44,21 @@ using ShapeF = WgShape<128, 128, 2, 4, 2, 128>;   // NoF hidden x hidden
 using ShapeG = WgShape<128, 80, 1, 5, 1, 128>;    // NoF hidden x embedded input (66 -> 80)
 using ShapeH = WgShape<16, 128, 1, 1, 8, 12>;     // NoF head: d T (9 | 3, padded 12) x h_D
 
-// modelled cost of one stage, in CU cycles: max(MFMA time, HBM time at ~7 B/cycle/CU) + fixed part
+// cost of one stage of each block shape in CU cycles, MEASURED (tools/bench_wgrad.py: each shape alone at 1.3 M samples,
+// launch overhead subtracted).  Only the ratios matter: they decide where the linearised (item, stage) space is cut, and
+// a shape that is under-priced by 20 % makes its workgroups -- and the launch -- 20 % late (the first-principles model
+// max(MFMA, HBM) + 400 this replaces had C / D 20 % low and E 30 % high: the 13-item NeRF launch ran 12 % slower than
+// its items one by one).
 MF_HD int wg_stage_cost(int shape) {
   switch (shape) {
-    case 0: return 8192 + 400;
-    case 1: return 2925 + 400;
-    case 2: return 4096 + 400;
-    case 3: return 1460 + 400;
-    case 4: return 5900 + 400;
-    case 5: return 2340 + 400;
-    case 6: return 1900 + 400;
-    default: return 1300 + 400;
+    case 0: return 9640;
+    case 1: return 3700;
+    case 2: return 5990;
+    case 3: return 2500;
+    case 4: return 4790;
+    case 5: return 3440;
+    case 6: return 2690;
+    default: return 2560;
   }
 }
 MF_HD int wg_out_floats(int shape) {
@@ -155,8 +159,19 @@ MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, 
   for (int a = 0; a < WR; ++a)
 #pragma unroll
     for (int b = 0; b < WC; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
-  float bsum = 0.f;
-  const bool want_bias = it.want_bias != 0 && tid < S::NOUT;
+  // db: column sums of the G tile already in LDS.  Spread over the whole workgroup -- thread t owns the column pair
+  // (t mod NOUT/2) of the row group t / (NOUT/2): one ds_read_b64 + two adds per row -- instead of one column x 16 rows
+  // on the first NOUT threads (that left half of the waves 16 LDS reads per stage behind the others at every
+  // barrier: 6 % of a 256x256 item); the row groups' partial sums meet in LDS when the segment ends.
+  // (Only where a stage is matrix-bound: on the lighter shapes -- measured on 256x64 and 128x256 -- the waves that
+  //  had no column to sum were hiding the others' reads, and sharing the sums costs 4-16 %.)
+  constexpr bool kSpread = S::WR * S::WC >= 32;
+  constexpr int BC = kSpread ? S::NOUT / 2 : S::NOUT;               // column pairs (single columns when not spread)
+  constexpr int BG = kSpread ? ((kThreads / BC) < kWgStage ? (kThreads / BC) : kWgStage) : 1;   // row groups
+  constexpr int BR = kWgStage / BG;                                 // rows per group
+  const int bcol = tid % BC, bgrp = tid / BC;
+  float bsum0 = 0.f, bsum1 = 0.f;
+  const bool want_bias = it.want_bias != 0 && bgrp < BG;
   WgSource src;
   {
     const long long gs = it.g_stride * 4, xs = it.x_stride * 4;
@@ -180,17 +195,31 @@ MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, 
   const bool late = id.wave < kWaves / 2 && !(MF_TIMING_FLAGS && (dbg & 1));
   for (long long st = sb; st < se; ++st) {
     const uint32_t base = cur * S::SLOT_BYTES;
-    auto hook = [&]() {
+    auto hook = [&]() {      // (MF_WG_ABL_*: timing-ablation builds only, tools/ab_lib.sh; results are garbage there)
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+#ifndef MF_WG_ABL_NOBAR
       __builtin_amdgcn_s_barrier();
+#endif
       asm volatile("" ::: "memory");
+#ifndef MF_WG_ABL_NODMA
       if (st + 2 < se) wg_load_stage<S>(src, P, (cur >= 1 ? cur - 1 : 2) * S::SLOT_BYTES, id);
+#endif
     };
     if (!late || st == sb) hook();      // (a segment's first stage has no earlier barrier to rely on)
+#ifndef MF_WG_ABL_NOBIAS
     if (want_bias) {
 #pragma unroll
-      for (int s = 0; s < kWgStage; ++s) bsum += lds_f(base + (s * S::PG + tid) * 4);
+      for (int s = 0; s < BR; ++s) {
+        if constexpr (kSpread) {
+          const float2 g2 = *reinterpret_cast<const float2*>(smem + base + ((bgrp * BR + s) * S::PG + 2 * bcol) * 4);
+          bsum0 += g2.x;
+          bsum1 += g2.y;
+        } else {
+          bsum0 += lds_f(base + (s * S::PG + tid) * 4);
+        }
+      }
     }
+#endif
     float a[2][WR], b[2][WC];
 #pragma unroll
     for (int t = 0; t < WR; ++t) a[0][t] = lds_f(base + aoff + (16 * t) * 4);
@@ -200,12 +229,17 @@ MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, 
     for (int m = 0; m < 4; ++m) {
       const int c = m & 1, n = c ^ 1;
       if (m == 2 && late && st != sb) hook();
+#ifndef MF_WG_ABL_NOFRAG
       if (m + 1 < 4) {
 #pragma unroll
         for (int t = 0; t < WR; ++t) a[n][t] = lds_f(base + aoff + ((m + 1) * S::PG + 16 * t) * 4);
 #pragma unroll
         for (int t = 0; t < WC; ++t) b[n][t] = lds_f(base + boff + ((m + 1) * S::PX + 16 * t) * 4);
       }
+#else
+      for (int t = 0; t < WR; ++t) a[n][t] = a[c][t];
+      for (int t = 0; t < WC; ++t) b[n][t] = b[c][t];
+#endif
 #pragma unroll
       for (int ti = 0; ti < WR; ++ti)
 #pragma unroll
@@ -221,7 +255,20 @@ MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, 
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         part[(long long)(row0 + 16 * ti + 4 * id.g + r) * S::NIN + col0 + 16 * tj + id.j] = acc[ti][tj][r];
-  if (tid < S::NOUT) part[(long long)S::NOUT * S::NIN + tid] = bsum;
+  // the row groups' column sums: through LDS (the ring is idle now), fixed order
+  if constexpr (kSpread) {
+    __syncthreads();
+    if (bgrp < BG) *reinterpret_cast<float2*>(smem + (bgrp * S::NOUT + 2 * bcol) * 4) = make_float2(bsum0, bsum1);
+    __syncthreads();
+    if (tid < S::NOUT) {
+      float b = 0.f;
+#pragma unroll
+      for (int g = 0; g < BG; ++g) b += lds_f((g * S::NOUT + tid) * 4);
+      part[(long long)S::NOUT * S::NIN + tid] = b;
+    }
+  } else {
+    if (tid < S::NOUT) part[(long long)S::NOUT * S::NIN + tid] = bsum0;
+  }
 }
 
 __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WgParams p) {

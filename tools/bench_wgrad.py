@@ -35,6 +35,16 @@ sets = {
     "D x1 (128x32)": [(sl(gpre, 9, 128), ext32, 128, 32, False)],
     "E x1 (4x640)": [(ghead, acts[:, 7 * W:7 * W + 640], 4, 640, True)],
 }
+# NoF shapes (one evaluation: D = 4, W = 128, skip at 2; dump stride 4*128 + 16, embedded input 80 columns)
+nacts = torch.randn(P, 4 * 128 + 16, device=dev)
+ngpre = torch.randn((P + 127) // 128 * 128, 4 * 128 + 16, device=dev)[:P]
+emb80 = torch.randn(P, 80, device=dev)
+nsl = lambda t, l, w=128: t[:, l * 128:l * 128 + w]
+sets["F x3 (128x128)"] = [(nsl(ngpre, l), nsl(nacts, l - 1), 128, 128, True) for l in (1, 2, 3)]
+sets["F x1"] = sets["F x3 (128x128)"][:1]
+sets["G x2 (128x80)"] = [(nsl(ngpre, 0), emb80, 128, 80, True), (nsl(ngpre, 2), emb80, 128, 80, False)]
+sets["H x1 (12x128)"] = [(ngpre[:, 512:524], nsl(nacts, 3), 12, 128, True)]
+sets["NoF all 6"] = sets["F x3 (128x128)"] + sets["G x2 (128x80)"] + sets["H x1 (12x128)"]
 sets["all 13"] = sum((sets[k] for k in ("A x9 (256x256)", "B x2 (256x64)", "C x1 (128x256)", "D x1 (128x32)", "E x1 (4x640)")), [])
 flops = lambda jobs: sum(2.0 * P * a[2] * a[3] for a in jobs)
 byts = lambda jobs: sum(4.0 * P * (a[2] + a[3]) for a in jobs)
@@ -44,8 +54,8 @@ for k, jobs in sets.items():
     print(f"  {k:18s}: {ms:7.3f} ms  {flops(jobs)/ms/1e9:7.1f} TFLOP/s  {byts(jobs)/ms/1e9:6.2f} TB/s"
           f"  ({ms/len(jobs)*1e6/((P+15)//16)*256*2.4/1e3:7.0f} CU-cycles/stage/item @2.4GHz)")
 # correctness spot check against library GEMMs
-jobs = sets["all 13"]
-res = A.weight_grads(jobs, P, dev)
+jobs = sets["all 13"] + sets["NoF all 6"]
+res = A.weight_grads(jobs[:13], P, dev) + A.weight_grads(jobs[13:], P, dev)
 worst = 0.0
 for (G, X, no, ni, b), (dW, db) in zip(jobs, res):
     ref = G.t() @ X
