@@ -46,6 +46,8 @@ PEAK = {"f32": 157.3, "bf16": 2516.0}     # TFLOP/s, MI355X_MICROARCH.md: fp32-i
 CONFIGS = {
     "C2": dict(net="dir", precision="f32", rays=4096, S=64, M=0, nof=None,
                what="C2: canonical NeRF 8x256 (xyz F=10, dir F=4), fused HIP encode+MLP+composite, fp32 MFMA"),
+    "C2b": dict(net="dir", precision="bf16", rays=4096, S=64, M=0, nof=None,
+                what="C2 shape in bf16 (canonical NeRF, bf16 hidden GEMMs; a kernel-tuning leg, not a BASELINE config)"),
     "C3": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="local",
                what="C3: bw NoF -> NeRF(ind) -> fw NoF local consensus chain, bf16 hidden GEMMs"),
     "C3g": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="global",
