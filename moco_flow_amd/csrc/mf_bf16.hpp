@@ -50,7 +50,32 @@ MF_D u32x4 lds_u4(uint32_t byte_off) { return *(const u32x4*)(smem + byte_off); 
 
 // Weight-panel stream (see mf_core.hpp Stream): 3-slot LDS ring fed by LDS-DMA, two panels ahead of the MFMAs,
 // one workgroup barrier per panel.
+// Phase timeline (-DMF_BF_TIMELINE, tools/timeline_bf16.py): lane 0 of waves 0 and 4 of workgroup 0 store the shader
+// clock at phase boundaries into the pass's `alphas` plane (which this build does not otherwise write).
+struct Timeline {
+#ifdef MF_BF_TIMELINE
+  float* buf; unsigned long long t0; int n; bool on;
+  MF_D void start(float* b, const Lane& id) {
+    on = blockIdx.x == 0 && (id.wave == 0 || id.wave == 4);
+    buf = b + (id.wave == 4 ? 512 : 0);
+    n = 0;
+    t0 = __builtin_amdgcn_s_memtime();
+  }
+  MF_D void stamp(int tag, const Lane& id) {
+    if (on && buf && n < 250) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (id.lane == 0) { buf[2 * n] = (float)tag; buf[2 * n + 1] = (float)(long long)(t - t0); }
+      ++n;
+    }
+  }
+#else
+  MF_D void start(float*, const Lane&) {}
+  MF_D void stamp(int, const Lane&) {}
+#endif
+};
+
 struct Stream {
+  Timeline tl;
   const char* gnext;      // global address of the panel two ahead of the one being computed
   uint32_t off0, off1, off2;   // LDS byte offsets of the slots holding the current panel, the next one, the one after
                                // (rotated by advance(): no modulo / multiply per panel)
@@ -76,10 +101,16 @@ struct Stream {
     const int mine = (groups - id.wave + kWaves - 1) / kWaves;      // pieces of this wave: groups wave, wave + 8, ...
     pmask = (1u << (mine < 0 ? 0 : mine)) - 1u;
     gnext += (size_t)groups * kGroupBytes;
+#ifdef MF_BF_BURST
+#pragma unroll
+    for (int k = 0; k < 3; ++k)
+      if ((pmask >> k) & 1u) blds16(dsrc, id.lane * 16, k * (kWaves * kGroupBytes), ddst + k * (kWaves * kGroupBytes));
+    pmask = 0;
+#endif
   }
   MF_D void piece(int k, const Lane& id) {
-#ifndef MF_BF_ABL_NODMA
-    if ((pmask >> k) & 1u) glds16(dsrc + k * (kWaves * kGroupBytes) + (uint32_t)(id.lane * 16), ddst + k * (kWaves * kGroupBytes));
+#if !defined(MF_BF_ABL_NODMA) && !defined(MF_BF_BURST)
+    if ((pmask >> k) & 1u) blds16(dsrc, id.lane * 16, k * (kWaves * kGroupBytes), ddst + k * (kWaves * kGroupBytes));
 #endif
   }
   MF_D void advance() {
@@ -88,10 +119,9 @@ struct Stream {
   }
   MF_D void start(const char* first, int groups, uint32_t ring, uint32_t buf_bytes, const Lane& id) {
     off0 = ring; off1 = ring + buf_bytes; off2 = ring + 2 * buf_bytes;
-    const char* g = first + id.lane * 16;
     for (int grp = id.wave; grp < groups; grp += kWaves) {
-      glds16(g + grp * kGroupBytes, off0 + grp * kGroupBytes);
-      glds16(g + (size_t)(groups + grp) * kGroupBytes, off1 + grp * kGroupBytes);
+      blds16(first, id.lane * 16, grp * kGroupBytes, off0 + grp * kGroupBytes);
+      blds16(first, id.lane * 16, (groups + grp) * kGroupBytes, off1 + grp * kGroupBytes);
     }
     gnext = first + (size_t)2 * groups * kGroupBytes;
     wait_vm0();
@@ -487,7 +517,7 @@ MF_D void start_program(const Net& n, Stream& st, Carry& carry, uint32_t ring, u
 
 MF_D void load_resident(const Net& n, const Lane& id) {
   const int groups = (int)(n.res_bytes / kGroupBytes);
-  for (int g = id.wave; g < groups; g += kWaves) glds16(n.packed + g * kGroupBytes + id.lane * 16, n.res_lds + g * kGroupBytes);
+  for (int g = id.wave; g < groups; g += kWaves) blds16(n.packed, id.lane * 16, g * kGroupBytes, n.res_lds + g * kGroupBytes);
 }
 
 // extra_encoding (nerf.py:98): W/2 outputs from [final (W) ; extra block], ReLU.  NGX = extra k-steps (0, 1, 2).
@@ -528,21 +558,26 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xhi)[kKsNerfXyz], const u32x4 
   for (int l = 0; l < D; ++l) {
     const bool last = sigma_only && l == D - 1;
     trunk_layer<16, kKsNerfXyz>(net, l, true, act, xhi, xlo, st, carry, id, last ? follow : next_trunk_bf<16, kKsNerfXyz>(net, l + 1));
+    st.tl.stamp(10 + l, id);
   }
   // resident block: [bias_trunk (D+1) 256 | bias_extra 128 | sigma_w 256 | sigma_b 4 | rgb_w 384 | rgb_b 4]
   const uint32_t r_sigma_w = net.res_lds + ((D + 1) * 256 + 128) * 4;
   float sg[1];
   valu_head(act, r_sigma_w, r_sigma_w + 256 * 4, id.h, sg);
   sigma = sg[0];
+  st.tl.stamp(30, id);
   if (sigma_only) return;
   const int xg = 16 + 2 * net.aux;
   const Next ex{xg, nullptr, xg, nullptr};
   trunk_layer<16, kKsNerfXyz>(net, D, false, act, xhi, xlo, st, carry, id, ex);          // xyz_encoding_final (no ReLU)
+  st.tl.stamp(31, id);
   u32x4 e[8], ehi[kKsExtraMax], elo[kKsExtraMax];
   make_extra(ehi, elo);
+  st.tl.stamp(32, id);
   if (net.aux == 2) extra_layer<2>(net, act, ehi, elo, e, st, carry, id, follow);
   else if (net.aux == 1) extra_layer<1>(net, act, ehi, elo, e, st, carry, id, follow);
   else extra_layer<0>(net, act, ehi, elo, e, st, carry, id, follow);
+  st.tl.stamp(33, id);
   float o[3];
   valu_head(e, r_sigma_w + (256 + 4) * 4, r_sigma_w + (256 + 4 + 384) * 4, id.h, o);
 #pragma unroll

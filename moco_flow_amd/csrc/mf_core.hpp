@@ -221,6 +221,18 @@ MF_D void glds16(const char* g, uint32_t lds_off) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
                                    (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
 }
+// The same transfer through a buffer descriptor (buffer_load_dwordx4 ... offen lds): wave-uniform base address in
+// SGPRs + ONE per-lane VGPR offset (lane * 16) + a scalar offset, instead of a 64-bit address per lane.  This is the
+// form the weight streams use.  Measured on the bf16 trunk prototype (tools/proto/bf16_trunk2.hip, MI355X): 57 -> 74 %
+// of the bf16 matrix peak from this change alone, for two reasons: (i) no v_lshl_add_u64 per piece and no 64 address
+// pairs through the address path; (ii) global_load_lds is FLAT-encoded, and with a FLAT operation that may touch LDS
+// pending, hipcc's waitcnt pass treats the LGKM counter as out of order and turns EVERY fragment wait into
+// s_waitcnt lgkmcnt(0) -- draining the prefetched ds_read_b128s it was meant to overlap; with the MUBUF form it counts
+// them (lgkmcnt(2..3)).  `base`, `soff`, `lds_off` must be wave-uniform.
+MF_D void blds16(const char* base, uint32_t lane16, uint32_t soff, uint32_t lds_off) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, -1, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + lds_off), 16, (int)lane16, (int)soff, 0, 0);
+}
 MF_D void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Race / hazard screen (-DMF_DBG_JITTER, tools/ab_lib.sh): a pseudo-random stall per wave in front of every panel barrier
@@ -284,17 +296,15 @@ struct Stream {
     return ring + s * buf_bytes;
   }
   MF_D void dma_to(uint32_t dst, int groups, const LaneId& id) {
-    const char* g = gnext + id.lane * 16;
-    for (int grp = id.wave; grp < groups; grp += kWaves) glds16(g + grp * kGroupBytes, dst + grp * kGroupBytes);
+    for (int grp = id.wave; grp < groups; grp += kWaves) blds16(gnext, id.lane * 16, grp * kGroupBytes, dst + grp * kGroupBytes);
     gnext += (size_t)groups * kGroupBytes;
   }
   // variant kept for A/B runs: only the "early" half of the workgroup (waves 4-7, one per SIMD)
   // issues the DMA (measured 1 % slower than all eight waves issuing, profiles/r01 notes)
   MF_D void dma_early_half(uint32_t dst, int groups, const LaneId& id) {
     if (id.wave >= kWaves / 2) {
-      const char* g = gnext + id.lane * 16;
       for (int grp = id.wave - kWaves / 2; grp < groups; grp += kWaves / 2)
-        glds16(g + grp * kGroupBytes, dst + grp * kGroupBytes);
+        blds16(gnext, id.lane * 16, grp * kGroupBytes, dst + grp * kGroupBytes);
     }
     gnext += (size_t)groups * kGroupBytes;
   }

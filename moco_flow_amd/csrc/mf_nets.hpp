@@ -28,7 +28,7 @@ MF_D NextLayer next_trunk(const NetDev& n, int layer) {   // trunk layer `layer`
 // Copy a network's resident block (biases + VALU head weights) global -> LDS.
 MF_D void load_resident(const NetDev& n, const LaneId& id) {
   const int groups = (int)(n.L.res_bytes / kGroupBytes);
-  for (int g = id.wave; g < groups; g += kWaves) glds16(n.packed + g * kGroupBytes + id.lane * 16, n.res_lds + g * kGroupBytes);
+  for (int g = id.wave; g < groups; g += kWaves) blds16(n.packed, id.lane * 16, g * kGroupBytes, n.res_lds + g * kGroupBytes);
 }
 
 // Prime the stream and the carry at the first panel of network `n` (kernel start).

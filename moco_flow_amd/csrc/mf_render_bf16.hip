@@ -61,6 +61,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
   const uint32_t par_nerf_xyz = p.par_off, par_nerf_ext = p.par_off + 128, par_nof_xyz = p.par_off + 256,
                  par_nof_ind = p.par_off + 384;
   Stream st;
+  st.tl.start(p.alphas, id);
   Carry carry;
   const Next prog_first = MOCO ? first_of<8, kKsNofIn>(p.bw) : first_of<16, kKsNerfXyz>(p.nerf);
   if (MOCO) start_program<8, kKsNofIn>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);   // (its wait + barrier also publish the resident blocks / tables)
@@ -78,6 +79,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
     const int ntiles = (nsamp + bf::kTile - 1) / bf::kTile;
 
     for (int tile = 0; tile < ntiles; ++tile) {
+      st.tl.stamp(1, id);
       const int srel = tile * bf::kTile + id.wave * kWaveSamples + id.j;
       const bool valid = srel < nsamp;
       const int sl = valid ? srel : nsamp - 1;
@@ -99,6 +101,10 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
 #pragma unroll
       for (int c = 0; c < 3; ++c) x[c] = o[c] + d[c] * z;                      // rendering.py:262-263
 
+#ifdef MF_BF_TIMELINE
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
+#endif
+      st.tl.stamp(2, id);
       float xin[3] = {x[0], x[1], x[2]};      // what the canonical NeRF sees
       if (MOCO) {
         // chain program (rendering.py:270-282): step 0 bw(x,i) -> canon; local: fw(canon,i) -> recon;
@@ -135,6 +141,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
         }
       }
 
+      st.tl.stamp(3, id);
       u32x4 xhi[kKsNerfXyz], xlo[kKsNerfXyz];
       {
         float embx[B2Xyz10::SLOTS];
@@ -155,14 +162,17 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
         }
         split_operands<kKsExtraMax>(ext, 8 * kKsExtraMax, ehi, elo);
       };
+      st.tl.stamp(4, id);
       float sigma, rgb[3] = {0.f, 0.f, 0.f};
       nerf_eval(p.nerf, xhi, xlo, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb);
       if (valid && id.h == 0) {
         sbuf[srel] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
         zbuf[srel] = z;
       }
+      st.tl.stamp(5, id);
     }
     __syncthreads();
+    st.tl.stamp(6, id);
 
     // ---- composite (rendering.py:157-192): one wave per ray, lanes over samples
     for (int rr = id.wave; rr < nr; rr += kWaves) {
@@ -198,7 +208,9 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
         carry_t = carry_t * __shfl(incl, 63, 64);
         if (v) {
           if (p.weights) p.weights[ray * S + i] = w;
+#ifndef MF_BF_TIMELINE
           if (p.alphas) p.alphas[ray * S + i] = alpha;
+#endif
           acc_w += w;
           acc_r += w * s4.x; acc_g += w * s4.y; acc_b += w * s4.z;
           acc_d += w * z;
@@ -223,7 +235,9 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
         }
       }
     }
+    st.tl.stamp(7, id);
     __syncthreads();
+    st.tl.stamp(8, id);
   }
   wait_vm0();   // the stream runs two panels ahead: drain the LDS-DMA before the workgroup retires
 }

@@ -1,0 +1,241 @@
+// timing-only prototype #2 of the bf16 trunk (see README.md here): 8 waves x 32 samples, 256x256 layers, 16 KiB panels
+// through a 3-slot LDS-DMA ring -- the structure of csrc/mf_bf16.hpp -- with switches that price single changes:
+//   O_TWOCHAIN  even / odd k-steps accumulate into two independent chains (no final add: timing only)
+//   O_DEFER     the epilogue (cvt + relu) of tile t is issued one op per MFMA gap inside tile t+1 (ping-pong accumulators)
+//   O_ASMLDS    fragment reads as asm ds_read_b128 with hand-counted lgkmcnt
+//   O_BUFLDS    LDS-DMA pieces as buffer_load_dwordx4 ... offen lds (SGPR base + one VGPR lane offset)
+//   O_NOCOPY    layers unrolled in pairs (act -> nxt -> act): no 64-register copy per layer
+//   O_NOSTAG    no half-panel stagger
+//   O_BURST2/4  MFMAs issued back to back in pairs / quads, their fragment reads (and everything else) in ONE gap behind them
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdlib>
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef short i16x2 __attribute__((ext_vector_type(2)));
+extern __shared__ __attribute__((aligned(16))) char smem[];
+#define D __device__ __forceinline__
+enum { O_TWOCHAIN = 1, O_DEFER = 2, O_ASMLDS = 4, O_BUFLDS = 8, O_NOCOPY = 16, O_NOSTAG = 32, O_BURST2 = 64, O_BURST4 = 128 };
+
+D void glds16(const char* g, uint32_t off) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(smem + off), 16, 0, 0);
+}
+D u32x4 lds_u4(uint32_t off) { return *(const u32x4*)(smem + off); }
+D unsigned pack2(float a, float b) { f32x2 v = {a, b}; return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2)); }
+D unsigned relu2(unsigned x) { i16x2 v = __builtin_bit_cast(i16x2, x); i16x2 z = {0, 0}; return __builtin_bit_cast(unsigned, __builtin_elementwise_max(v, z)); }
+#define MFMA(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
+constexpr int KH = 16, PANEL = 16 * 1024, PD = 3, WAVES = 8;
+#define NBUF_OF(O) (((O) & O_BURST4) ? 8 : (((O) & O_BURST2) ? 4 : PD + 1))
+
+struct Ring {
+  const char* gnext; const char* w; long long wbytes;
+  uint32_t off0, off1, off2;
+  i32x4 rsrc;          // buffer resource over the whole weight buffer (O_BUFLDS)
+  uint32_t goff;       // byte offset of gnext inside it
+};
+
+template <int OPT>
+D void hook(Ring& r, int wave, int lane, uint32_t lane16) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+  if (OPT & O_BUFLDS) {
+#pragma unroll
+    for (int q = 0; q < 16 / WAVES; ++q) {
+      const uint32_t grp = wave + q * WAVES;
+      const uint32_t dst = r.off2 + grp * 1024;
+      const uint32_t soff = r.goff + grp * 1024;
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(lane16), "s"(r.rsrc), "s"(soff) : "memory", "m0");
+    }
+    r.goff += PANEL;
+    if (r.goff + PANEL > (uint32_t)r.wbytes) r.goff = 0;
+  } else {
+    for (int grp = wave; grp < 16; grp += WAVES) glds16(r.gnext + grp * 1024 + lane * 16, r.off2 + grp * 1024);
+    r.gnext += PANEL;
+    if (r.gnext + PANEL > r.w + r.wbytes) r.gnext = r.w;
+  }
+}
+
+// one epilogue op (of 16) of a finished tile: ops 0-7 convert, 8-15 relu
+D void epi_op(int i, const f32x16& a, u32x4& o0, u32x4& o1) {
+  if (i < 4) o0[i] = pack2(a[2 * i], a[2 * i + 1]);
+  else if (i < 8) o1[i - 4] = pack2(a[8 + 2 * (i - 4)], a[8 + 2 * (i - 4) + 1]);
+  else if (i < 12) o0[i - 8] = relu2(o0[i - 8]);
+  else o1[i - 12] = relu2(o1[i - 12]);
+}
+
+template <int OPT>
+D void layer(const u32x4 (&act)[KH], u32x4 (&nxt)[KH], Ring& r, int wave, int lane, uint32_t lane16, bool late, f32x16& pend, u32x4 (&pin)[KH], bool have_pend) {
+  // pend: accumulators of the previous layer's last tile (O_DEFER): its outputs are pin[14], pin[15] = act[14], act[15]
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const uint32_t p = r.off0 + lane * 16, pn = r.off1 + lane * 16;
+    f32x16 acc, acc2;
+    for (int i = 0; i < 16; ++i) { acc[i] = 0.f; acc2[i] = 0.f; }
+    u32x4 fr[NBUF_OF(OPT)];
+    if (OPT & (O_BURST2 | O_BURST4)) {
+#pragma unroll
+      for (int k = 0; k < NBUF_OF(OPT); ++k) fr[k] = lds_u4(p + k * 1024);
+    } else if (OPT & O_ASMLDS) {
+#pragma unroll
+      for (int k = 0; k < PD; ++k) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[k]) : "v"(p), "i"(k * 1024));
+    } else {
+#pragma unroll
+      for (int k = 0; k < PD; ++k) fr[k] = lds_u4(p + k * 1024);
+    }
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      if (k == (late ? 8 : 0)) hook<OPT>(r, wave, lane, lane16);
+      const int s = k % NBUF_OF(OPT), sp = (k + PD) % (PD + 1);
+      if (OPT & O_ASMLDS) {
+        if (k + PD < KH) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[sp]) : "v"(p), "i"((k + PD) * 1024));
+        // outstanding reads younger than fragment k: min(PD, KH-1-k)
+        constexpr int dummy = 0; (void)dummy;
+        const int young = (KH - 1 - k) < PD ? (KH - 1 - k) : PD;
+        if (young == 3) asm volatile("s_waitcnt lgkmcnt(3)" : "+v"(fr[s]));
+        else if (young == 2) asm volatile("s_waitcnt lgkmcnt(2)" : "+v"(fr[s]));
+        else if (young == 1) asm volatile("s_waitcnt lgkmcnt(1)" : "+v"(fr[s]));
+        else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[s]));
+      } else if (OPT & (O_BURST2 | O_BURST4)) {
+        // reads are issued after the burst (below)
+      } else {
+        if (k + PD < KH) fr[sp] = lds_u4(p + (k + PD) * 1024);
+      }
+      // act[14], act[15] of this layer come out of the deferred epilogue of the previous layer's last tile
+      const u32x4 b = ((OPT & O_DEFER) && k >= 14) ? pin[k] : act[k];
+      if ((OPT & O_TWOCHAIN) && (k & 1)) acc2 = MFMA(fr[s], b, acc2);
+      else acc = MFMA(fr[s], b, acc);
+      if (OPT & O_DEFER) {
+        // previous tile's epilogue: tile t-1 of this layer -> nxt[2t-2], nxt[2t-1]; for t == 0 the previous LAYER's
+        // last tile -> pin[14], pin[15], two ops per gap so that it is done before k = 14
+        if (t == 0) { if (have_pend && k < 8) { epi_op(2 * k, pend, pin[14], pin[15]); epi_op(2 * k + 1, pend, pin[14], pin[15]); } }
+        else epi_op(k, pend, nxt[2 * t - 2], nxt[2 * t - 1]);
+      }
+      if (OPT & (O_BURST2 | O_BURST4)) {
+        constexpr int B = (OPT & O_BURST4) ? 4 : 2;
+        if (k % B == B - 1) {                 // end of a burst: refill the B slots it used
+          __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+          for (int q = 0; q < B; ++q) {
+            const int kk = k - (B - 1) + q + NBUF_OF(OPT);
+            if (kk < KH) fr[kk % NBUF_OF(OPT)] = lds_u4(p + kk * 1024);
+          }
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      } else
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (OPT & O_TWOCHAIN) for (int i = 0; i < 16; i += 5) acc[i] += acc2[i];     // keep acc2 alive cheaply (4 adds)
+    if (OPT & O_DEFER) {
+      pend = acc;
+    } else {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        nxt[2 * t][q] = relu2(pack2(acc[2 * q], acc[2 * q + 1]));
+        nxt[2 * t + 1][q] = relu2(pack2(acc[8 + 2 * q], acc[8 + 2 * q + 1]));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(nxt[2 * t][q]), "+v"(nxt[2 * t + 1][q]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t tmp = r.off0; r.off0 = r.off1; r.off1 = r.off2; r.off2 = tmp;
+  }
+}
+
+template <int OPT>
+__global__ __launch_bounds__(WAVES * 64, 2) void proto(const char* w, long long wbytes, float* out, int layers, int reps) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane16 = lane * 16;
+  u32x4 act[KH], nxt[KH];
+  for (int k = 0; k < KH; ++k) { act[k] = u32x4{(unsigned)lane * 7u + k, 0x3f803f80u, 1u, 0x3f003f00u}; nxt[k] = act[k]; }
+  Ring r;
+  r.w = w; r.wbytes = wbytes;
+  r.gnext = w + (blockIdx.x % 4) * PANEL;
+  r.goff = (blockIdx.x % 4) * PANEL;
+  r.off0 = 0; r.off1 = PANEL; r.off2 = 2 * PANEL;
+  {
+    const unsigned long long base = (unsigned long long)w;
+    r.rsrc[0] = __builtin_amdgcn_readfirstlane((int)(base & 0xffffffffu));
+    r.rsrc[1] = __builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffffu));
+    r.rsrc[2] = __builtin_amdgcn_readfirstlane((int)wbytes);
+    r.rsrc[3] = 0x00020000;
+  }
+  for (int grp = wave; grp < 16; grp += WAVES) { glds16(r.gnext + grp * 1024 + lane * 16, r.off0 + grp * 1024); glds16(r.gnext + PANEL + grp * 1024 + lane * 16, r.off1 + grp * 1024); }
+  r.gnext += 2 * PANEL; r.goff += 2 * PANEL;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  const bool late = !(OPT & O_NOSTAG) && wave < 4;
+  f32x16 pend;
+  for (int i = 0; i < 16; ++i) pend[i] = 0.f;
+  for (int rep = 0; rep < reps; ++rep) {
+    if (OPT & O_NOCOPY) {
+      for (int l = 0; l < layers; l += 2) {
+        layer<OPT>(act, nxt, r, wave, lane, lane16, late, pend, act, true);
+        layer<OPT>(nxt, act, r, wave, lane, lane16, late, pend, nxt, true);
+      }
+    } else {
+      for (int l = 0; l < layers; ++l) {
+        layer<OPT>(act, nxt, r, wave, lane, lane16, late, pend, act, true);
+        if (OPT & O_DEFER) {
+#pragma unroll
+          for (int k = 0; k < KH - 2; ++k) act[k] = nxt[k];
+        } else {
+#pragma unroll
+          for (int k = 0; k < KH; ++k) act[k] = nxt[k];
+        }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned s = 0;
+  for (int k = 0; k < KH; ++k) s += act[k][0] ^ act[k][3];
+  s += __builtin_bit_cast(unsigned, pend[3]);
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (float)s;
+}
+
+template <int OPT>
+static void run(const char* name, const char* w, long long wbytes, float* out, int layers, int reps) {
+  hipFuncSetAttribute(reinterpret_cast<const void*>(proto<OPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PANEL);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  const int grid = 256;
+  float best = 1e9f;
+  for (int it = 0; it < 4; ++it) {
+    hipEventRecord(a);
+    hipLaunchKernelGGL((proto<OPT>), dim3(grid), dim3(WAVES * 64), 3 * PANEL, 0, w, wbytes, out, layers, reps);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    if (it > 0 && ms < best) best = ms;
+  }
+  const double samples = (double)grid * (WAVES * 32) * reps, flops = samples * layers * 256.0 * 256.0 * 2.0;
+  printf("%-34s: %.3f ms  %.1f TFLOP/s (%.1f %% of 2516)  err=%d\n", name, best, flops / best / 1e9, flops / best / 1e9 / 25.16, (int)hipGetLastError());
+}
+int main() {
+  const long long wbytes = 64ll << 20;
+  char* w; float* out;
+  hipMalloc(&w, wbytes); hipMemset(w, 0x3c, wbytes); hipMalloc(&out, 256 * 512 * 4);
+  for (int pass = 0; pass < 2; ++pass) {
+    run<O_BUFLDS | O_TWOCHAIN>("buf + two chains", w, wbytes, out, 8, 16);
+    run<O_BUFLDS | O_BURST2>("buf + burst2", w, wbytes, out, 8, 16);
+    run<O_BUFLDS | O_BURST4>("buf + burst4", w, wbytes, out, 8, 16);
+    run<O_BUFLDS | O_BURST2 | O_DEFER | O_NOCOPY>("buf + burst2 + defer + nocopy", w, wbytes, out, 8, 16);
+    run<O_BUFLDS | O_BURST4 | O_DEFER | O_NOCOPY>("buf + burst4 + defer + nocopy", w, wbytes, out, 8, 16);
+    run<O_BUFLDS | O_DEFER | O_NOCOPY>("buf + defer + nocopy", w, wbytes, out, 8, 16);
+    run<O_BUFLDS | O_NOSTAG>("buf + no stagger", w, wbytes, out, 8, 16);
+    run<0>("base", w, wbytes, out, 8, 16);
+    run<O_NOSTAG>("no stagger", w, wbytes, out, 8, 16);
+    run<O_TWOCHAIN>("two chains", w, wbytes, out, 8, 16);
+    run<O_NOCOPY>("no layer copy", w, wbytes, out, 8, 16);
+    run<O_DEFER>("deferred epilogue", w, wbytes, out, 8, 16);
+    run<O_DEFER | O_NOCOPY>("deferred + no copy", w, wbytes, out, 8, 16);
+    run<O_ASMLDS>("asm ds_read, counted waits", w, wbytes, out, 8, 16);
+    run<O_BUFLDS>("buffer_load lds", w, wbytes, out, 8, 16);
+    run<O_DEFER | O_NOCOPY | O_ASMLDS>("defer + nocopy + asm", w, wbytes, out, 8, 16);
+    run<O_DEFER | O_NOCOPY | O_ASMLDS | O_BUFLDS>("defer + nocopy + asm + buf", w, wbytes, out, 8, 16);
+    run<O_DEFER | O_NOCOPY | O_ASMLDS | O_BUFLDS | O_TWOCHAIN>("all + two chains", w, wbytes, out, 8, 16);
+  }
+  return 0;
+}
