@@ -258,6 +258,35 @@ MF_D float xgroup_sum(float v) {
   return v;
 }
 
+// Wavefront product scan / sum on the DPP network (row_shr 1, 2, 4, 8 inside the 16-lane rows, then row_bcast:15 and
+// row_bcast:31): six VALU steps of a few cycles each instead of six ds_bpermute round trips (~100 cycles each) per
+// scan or reduction -- the per-ray composite was 5.3 k cycles per 256-sample tile of the bf16 pass (4 % of the tile,
+// during which no wave of the workgroup feeds the matrix pipe), tools/timeline_bf16.py.
+template <int CTRL, int ROW_MASK>
+MF_D float dpp_f(float identity, float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+MF_D float wave_scan_mul_dpp(float v) {          // inclusive product scan over the 64 lanes
+  v *= dpp_f<0x111, 0xf>(1.f, v);
+  v *= dpp_f<0x112, 0xf>(1.f, v);
+  v *= dpp_f<0x114, 0xf>(1.f, v);
+  v *= dpp_f<0x118, 0xf>(1.f, v);
+  v *= dpp_f<0x142, 0xa>(1.f, v);                // row_bcast:15 -> rows 1, 3
+  v *= dpp_f<0x143, 0xc>(1.f, v);                // row_bcast:31 -> rows 2, 3
+  return v;
+}
+MF_D float wave_shr1_dpp(float first, float v) { return dpp_f<0x138, 0xf>(first, v); }   // lane i <- lane i-1, lane 0 <- first
+MF_D float wave_last(float v) { return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63)); }
+MF_D float wave_sum_dpp(float v) {               // sum over the 64 lanes, returned wave-uniform
+  v += dpp_f<0x111, 0xf>(0.f, v);
+  v += dpp_f<0x112, 0xf>(0.f, v);
+  v += dpp_f<0x114, 0xf>(0.f, v);
+  v += dpp_f<0x118, 0xf>(0.f, v);
+  v += dpp_f<0x142, 0xa>(0.f, v);
+  v += dpp_f<0x143, 0xc>(0.f, v);
+  return wave_last(v);
+}
+
 struct LaneId {
   int lane, wave, j, g;
   MF_D LaneId() {

@@ -47,19 +47,6 @@ struct RenderParams {
 };
 
 // inclusive product scan across the 64 lanes of a wave
-MF_D float wave_scan_mul(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_up(v, d, 64);
-    if (lane >= d) v *= o;
-  }
-  return v;
-}
-MF_D float wave_sum(float v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
-}
 
 template <bool MOCO, bool BF16, bool DUMP>
 __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
@@ -241,11 +228,10 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
         float alpha = 1.f - expf(-delta * a);                                  // :170/172
         if (!v) alpha = 0.f;
         const float pt = v ? (1.f - alpha) + 1e-10f : 1.f;                     // :176-177
-        const float incl = wave_scan_mul(pt, id.lane);
-        float excl = __shfl_up(incl, 1, 64);
-        if (id.lane == 0) excl = 1.f;
+        const float incl = wave_scan_mul_dpp(pt);
+        const float excl = wave_shr1_dpp(1.f, incl);
         const float w = alpha * (carry * excl);                                // :178-179
-        carry = carry * __shfl(incl, 63, 64);
+        carry = carry * wave_last(incl);
         if (v) {
           if (p.weights) p.weights[ray * S + i] = w;
           if (p.alphas) p.alphas[ray * S + i] = alpha;
@@ -254,10 +240,10 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
           acc_d += w * z;
         }
       }
-      acc_w = wave_sum(acc_w);                                                 // :180
+      acc_w = wave_sum_dpp(acc_w);                                                 // :180
       if (!sigma_only) {
-        acc_r = wave_sum(acc_r); acc_g = wave_sum(acc_g); acc_b = wave_sum(acc_b);   // :186
-        acc_d = wave_sum(acc_d);                                               // :187
+        acc_r = wave_sum_dpp(acc_r); acc_g = wave_sum_dpp(acc_g); acc_b = wave_sum_dpp(acc_b);   // :186
+        acc_d = wave_sum_dpp(acc_d);                                               // :187
       }
       if (id.lane == 0) {
         if (p.opacity) p.opacity[ray] = acc_w;

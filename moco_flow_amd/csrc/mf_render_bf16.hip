@@ -29,19 +29,6 @@ struct Params {
   int pow2;                        // bit t: table t's frequencies are exactly 2^k (the logscale default)
 };
 
-MF_D float wave_scan_mul(float v, int lane) {
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    const float o = __shfl_up(v, d, 64);
-    if (lane >= d) v *= o;
-  }
-  return v;
-}
-MF_D float wave_sum(float v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
-}
 
 template <bool MOCO>
 __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p) {
@@ -201,11 +188,10 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
         float alpha = 1.f - expf(-delta * a);                                  // :170/172
         if (!v) alpha = 0.f;
         const float pt = v ? (1.f - alpha) + 1e-10f : 1.f;                     // :176-177
-        const float incl = wave_scan_mul(pt, id.lane);
-        float excl = __shfl_up(incl, 1, 64);
-        if (id.lane == 0) excl = 1.f;
+        const float incl = wave_scan_mul_dpp(pt);
+        const float excl = wave_shr1_dpp(1.f, incl);
         const float w = alpha * (carry_t * excl);                              // :178-179
-        carry_t = carry_t * __shfl(incl, 63, 64);
+        carry_t = carry_t * wave_last(incl);
         if (v) {
           if (p.weights) p.weights[ray * S + i] = w;
 #ifndef MF_BF_TIMELINE
@@ -216,10 +202,10 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
           acc_d += w * z;
         }
       }
-      acc_w = wave_sum(acc_w);                                                 // :180
+      acc_w = wave_sum_dpp(acc_w);                                                 // :180
       if (!sigma_only) {
-        acc_r = wave_sum(acc_r); acc_g = wave_sum(acc_g); acc_b = wave_sum(acc_b);   // :186
-        acc_d = wave_sum(acc_d);                                               // :187
+        acc_r = wave_sum_dpp(acc_r); acc_g = wave_sum_dpp(acc_g); acc_b = wave_sum_dpp(acc_b);   // :186
+        acc_d = wave_sum_dpp(acc_d);                                               // :187
       }
       if (id.lane == 0) {
         if (p.opacity) p.opacity[ray] = acc_w;

@@ -110,8 +110,8 @@ MF_D void lds_zero(uint32_t byte_off) { *(float*)(smem + byte_off) = 0.f; }
 // Held in registers -- re-reading the item from kernarg memory at every stage put four dependent
 // s_load round trips between the barrier and the first MFMAs (measured 12 % of a 256x256 stage).
 struct WgSource {
-  const char* g;            // G row `wave` of the next stage (+ lane * 16)
-  const char* x;            // X row `wave` of the next stage (+ lane * 16)
+  const char* g;            // G row `wave` of the next stage (wave-uniform)
+  const char* x;            // X row `wave` of the next stage
   long long g_stage, x_stage, g_half, x_half;   // byte steps: one stage (16 rows), half a stage (8 rows)
   long long row;            // sample index of that row
 };
@@ -125,10 +125,11 @@ MF_D void wg_load_stage(WgSource& src, long long P, uint32_t slot, const LaneId&
     if (src.row + 8 * k < P) {
       const char* gsrc = src.g + (k ? src.g_half : 0);
       const char* xsrc = src.x + (k ? src.x_half : 0);
-      if (id.lane < S::GW / 4) glds16(gsrc, dg);
+      // (buffer form of the LDS-DMA: wave-uniform row address + lane * 16, see blds16)
+      if (id.lane < S::GW / 4) blds16(gsrc, id.lane * 16, 0, dg);
 #pragma unroll
       for (int c0 = 0; c0 < S::NIN / 4; c0 += 64)
-        if (c0 + id.lane < S::NIN / 4) glds16(xsrc + c0 * 16, dx + c0 * 16);
+        if (c0 + id.lane < S::NIN / 4) blds16(xsrc, id.lane * 16, c0 * 16, dx + c0 * 16);
     } else {      // past the last sample: the rows contribute nothing
       for (int c = id.lane; c < S::GW; c += 64) lds_zero(dg + c * 4);
       for (int c = id.lane; c < S::NIN; c += 64) lds_zero(dx + c * 4);
@@ -176,8 +177,8 @@ MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, 
   {
     const long long gs = it.g_stride * 4, xs = it.x_stride * 4;
     src.row = sb * kWgStage + id.wave;
-    src.g = reinterpret_cast<const char*>(it.G) + src.row * gs + id.lane * 16;
-    src.x = reinterpret_cast<const char*>(it.X) + src.row * xs + id.lane * 16;
+    src.g = reinterpret_cast<const char*>(it.G) + src.row * gs;
+    src.x = reinterpret_cast<const char*>(it.X) + src.row * xs;
     src.g_stage = gs * kWgStage; src.x_stage = xs * kWgStage;
     src.g_half = gs * 8; src.x_half = xs * 8;
   }

@@ -19,7 +19,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef short i16x2 __attribute__((ext_vector_type(2)));
 extern __shared__ __attribute__((aligned(16))) char smem[];
 #define D __device__ __forceinline__
-enum { O_TWOCHAIN = 1, O_DEFER = 2, O_ASMLDS = 4, O_BUFLDS = 8, O_NOCOPY = 16, O_NOSTAG = 32, O_BURST2 = 64, O_BURST4 = 128 };
+enum { O_TWOCHAIN = 1, O_DEFER = 2, O_ASMLDS = 4, O_BUFLDS = 8, O_NOCOPY = 16, O_NOSTAG = 32, O_BURST2 = 64, O_BURST4 = 128, O_MFMAONLY = 256 };
 
 D void glds16(const char* g, uint32_t off) {
   __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g, (__attribute__((address_space(3))) void*)(smem + off), 16, 0, 0);
@@ -89,7 +89,7 @@ D void layer(const u32x4 (&act)[KH], u32x4 (&nxt)[KH], Ring& r, int wave, int la
     }
 #pragma unroll
     for (int k = 0; k < KH; ++k) {
-      if (k == (late ? 8 : 0)) hook<OPT>(r, wave, lane, lane16);
+      if (!(OPT & O_MFMAONLY) && k == (late ? 8 : 0)) hook<OPT>(r, wave, lane, lane16);
       const int s = k % NBUF_OF(OPT), sp = (k + PD) % (PD + 1);
       if (OPT & O_ASMLDS) {
         if (k + PD < KH) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(fr[sp]) : "v"(p), "i"((k + PD) * 1024));
@@ -102,7 +102,7 @@ D void layer(const u32x4 (&act)[KH], u32x4 (&nxt)[KH], Ring& r, int wave, int la
         else asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fr[s]));
       } else if (OPT & (O_BURST2 | O_BURST4)) {
         // reads are issued after the burst (below)
-      } else {
+      } else if (!(OPT & O_MFMAONLY)) {
         if (k + PD < KH) fr[sp] = lds_u4(p + (k + PD) * 1024);
       }
       // act[14], act[15] of this layer come out of the deferred epilogue of the previous layer's last tile
@@ -130,7 +130,9 @@ D void layer(const u32x4 (&act)[KH], u32x4 (&nxt)[KH], Ring& r, int wave, int la
       __builtin_amdgcn_sched_barrier(0);
     }
     if (OPT & O_TWOCHAIN) for (int i = 0; i < 16; i += 5) acc[i] += acc2[i];     // keep acc2 alive cheaply (4 adds)
-    if (OPT & O_DEFER) {
+    if (OPT & O_MFMAONLY) {
+      for (int q = 0; q < 4; ++q) { nxt[2 * t][q] = __builtin_bit_cast(unsigned, acc[q]); nxt[2 * t + 1][q] = __builtin_bit_cast(unsigned, acc[8 + q]); }
+    } else if (OPT & O_DEFER) {
       pend = acc;
     } else {
 #pragma unroll
@@ -147,7 +149,7 @@ D void layer(const u32x4 (&act)[KH], u32x4 (&nxt)[KH], Ring& r, int wave, int la
 }
 
 template <int OPT>
-__global__ __launch_bounds__(WAVES * 64, 2) void proto(const char* w, long long wbytes, float* out, int layers, int reps) {
+__global__ __launch_bounds__(WAVES * 64, 2) void proto(const char* w, long long wbytes, float* out, int layers, int reps, long long* ticks_out) {
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t lane16 = lane * 16;
   u32x4 act[KH], nxt[KH];
@@ -169,6 +171,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void proto(const char* w, long long 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   const bool late = !(OPT & O_NOSTAG) && wave < 4;
+  const unsigned long long tick0 = __builtin_amdgcn_s_memtime();
   f32x16 pend;
   for (int i = 0; i < 16; ++i) pend[i] = 0.f;
   for (int rep = 0; rep < reps; ++rep) {
@@ -194,9 +197,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void proto(const char* w, long long 
   unsigned s = 0;
   for (int k = 0; k < KH; ++k) s += act[k][0] ^ act[k][3];
   s += __builtin_bit_cast(unsigned, pend[3]);
+  const unsigned long long tick1 = __builtin_amdgcn_s_memtime();
   out[blockIdx.x * blockDim.x + threadIdx.x] = (float)s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ticks_out[0] = (long long)(tick1 - tick0);
 }
 
+static long long* g_ticks;
 template <int OPT>
 static void run(const char* name, const char* w, long long wbytes, float* out, int layers, int reps) {
   hipFuncSetAttribute(reinterpret_cast<const void*>(proto<OPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PANEL);
@@ -205,19 +211,24 @@ static void run(const char* name, const char* w, long long wbytes, float* out, i
   float best = 1e9f;
   for (int it = 0; it < 4; ++it) {
     hipEventRecord(a);
-    hipLaunchKernelGGL((proto<OPT>), dim3(grid), dim3(WAVES * 64), 3 * PANEL, 0, w, wbytes, out, layers, reps);
+    hipLaunchKernelGGL((proto<OPT>), dim3(grid), dim3(WAVES * 64), 3 * PANEL, 0, w, wbytes, out, layers, reps, g_ticks);
     hipEventRecord(b); hipEventSynchronize(b);
     float ms; hipEventElapsedTime(&ms, a, b);
     if (it > 0 && ms < best) best = ms;
   }
   const double samples = (double)grid * (WAVES * 32) * reps, flops = samples * layers * 256.0 * 256.0 * 2.0;
-  printf("%-34s: %.3f ms  %.1f TFLOP/s (%.1f %% of 2516)  err=%d\n", name, best, flops / best / 1e9, flops / best / 1e9 / 25.16, (int)hipGetLastError());
+  long long ticks = 0; hipMemcpy(&ticks, g_ticks, 8, hipMemcpyDeviceToHost);
+  const double mfma_cyc = (double)reps * layers * 8 * 16 * 32 * 2;      // MFMA pipe cycles per SIMD (two waves)
+  printf("%-34s: %.3f ms  %.1f TFLOP/s (%.1f %% of 2516)  ticks %lld = %.2f GHz, MFMA busy %.1f %% of ticks  err=%d\n", name, best, flops / best / 1e9,
+         flops / best / 1e9 / 25.16, ticks, ticks / best / 1e6, 100.0 * mfma_cyc / ticks, (int)hipGetLastError());
 }
 int main() {
   const long long wbytes = 64ll << 20;
   char* w; float* out;
-  hipMalloc(&w, wbytes); hipMemset(w, 0x3c, wbytes); hipMalloc(&out, 256 * 512 * 4);
+  hipMalloc(&w, wbytes); hipMemset(w, 0x3c, wbytes); hipMalloc(&out, 256 * 512 * 4); hipMalloc(&g_ticks, 8);
   for (int pass = 0; pass < 2; ++pass) {
+    run<O_MFMAONLY>("MFMA only", w, wbytes, out, 8, 16);
+    run<O_MFMAONLY | O_NOCOPY>("MFMA only, no copy", w, wbytes, out, 8, 16);
     run<O_BUFLDS | O_TWOCHAIN>("buf + two chains", w, wbytes, out, 8, 16);
     run<O_BUFLDS | O_BURST2>("buf + burst2", w, wbytes, out, 8, 16);
     run<O_BUFLDS | O_BURST4>("buf + burst4", w, wbytes, out, 8, 16);
