@@ -15,9 +15,12 @@
 //   * a panel = ONE 32-row tile x the layer's whole k range (16 groups for a 256-wide hidden range): 16 MFMAs of
 //     32 cycles per wave between two barriers (the 16x16x32 tiling had 16 MFMAs of 16 cycles);
 //   * a workgroup is 8 waves = 256 samples per pass over the weight stream (two waves per SIMD, <= 256 VGPRs).
-// The embedded-input k ranges (positional encodings feed sin(512 x): they need more than 8 mantissa bits) use a
-// two-term bf16 split of inputs and weights, x = hi + lo, three products hi*hi + hi*lo + lo*hi (16 mantissa bits);
-// accumulation, biases, the sigma / rgb / NoF heads and the composite stay fp32.
+// The NoF's embedded-input k ranges and its head use a two-term bf16 split of inputs and weights, x = hi + lo, three
+// products hi*hi + hi*lo + lo*hi (16 mantissa bits): its output POINT feeds sin(512 x) of the canonical NeRF's
+// encoding.  The NeRF's own encodings are plain bf16 operands like every hidden range (SPLIT = false): measured on the
+// C2 shape the split bought 0.1 dB (61.15 vs 61.00 dB against the fp32 oracle -- the rounding of the 63 O(1) inputs is
+// one more layer's worth of activation rounding) for 10 % more matrix instructions, and the pass is power-bound
+// (DESIGN.md).  Accumulation, biases, the sigma / rgb / NoF heads and the composite stay fp32.
 #pragma once
 #include "mf_nets.hpp"
 
@@ -143,8 +146,8 @@ struct Net {
   uint32_t emb_mask;       // trunk layers that consume the embedded input (layer 0 + skips)
   int aux;                 // NeRF: k-steps of the extra block (0, 1, 2); NoF: head rows (3 | 9)
 };
-template <int KH, int EKS>
-MF_D int tgroups(const Net& n, int layer) { return (((n.emb_mask >> layer) & 1) ? 2 * EKS : 0) + (layer > 0 ? KH : 0); }
+template <int KH, int EKS, bool SPLIT>
+MF_D int tgroups(const Net& n, int layer) { return (((n.emb_mask >> layer) & 1) ? (SPLIT ? 2 : 1) * EKS : 0) + (layer > 0 ? KH : 0); }
 
 // What follows the layer being computed in the panel program: its first panel (`groups`, at `jump` if the program
 // leaves the contiguous order there) and its second one (`groups2` / `jump2`: differ from the first when that layer
@@ -153,10 +156,14 @@ struct Next {
   int groups; const char* jump;
   int groups2; const char* jump2;
 };
-template <int KH, int EKS>
-MF_D Next first_of(const Net& n) { return Next{2 * EKS, n.packed + n.res_bytes, 2 * EKS, nullptr}; }   // layer 0: embedded input only
-template <int KH, int EKS>
-MF_D Next next_trunk_bf(const Net& n, int layer) { return Next{tgroups<KH, EKS>(n, layer), nullptr, tgroups<KH, EKS>(n, layer), nullptr}; }
+template <int KH, int EKS, bool SPLIT>
+MF_D Next first_of(const Net& n) {       // layer 0: embedded input only
+  return Next{(SPLIT ? 2 : 1) * EKS, n.packed + n.res_bytes, (SPLIT ? 2 : 1) * EKS, nullptr};
+}
+template <int KH, int EKS, bool SPLIT>
+MF_D Next next_trunk_bf(const Net& n, int layer) {
+  return Next{tgroups<KH, EKS, SPLIT>(n, layer), nullptr, tgroups<KH, EKS, SPLIT>(n, layer), nullptr};
+}
 
 struct Carry {            // the first PD fragments of the panel that follows, pre-read during the current one's tail
   u32x4 w[PD];
@@ -189,17 +196,19 @@ MF_D unsigned pk_floor_bf16(unsigned x, unsigned floor) {
 // One output tile (32 features x the wave's 32 samples):
 //     out = max(bias + W_tile * [emb ; hidden], floor)     EMB_FIRST (trunk layers: embedded input in front)
 //     out = max(bias + W_tile * [hidden ; emb], floor)     !EMB_FIRST (NeRF extra_encoding)
-// NGE = embedded 16-slot k-steps (each: groups hi, lo; MFMAs Whi*xhi, Whi*xlo, Wlo*xhi), KHID = hidden k-steps.
+// NGE = embedded 16-slot k-steps (SPLIT: each is the groups hi, lo and the MFMAs Whi*xhi, Whi*xlo, Wlo*xhi; else one
+// group, one MFMA), KHID = hidden k-steps.
 // The A fragments are fetched PD groups ahead through a register ring that runs on into the NEXT panel's slot.
 // `hook` = the panel's barrier + DMA of the panel two ahead: behind the first group for the early half of the
 // workgroup (waves 4-7), in the middle of the panel for the late half (waves 0-3), so the two waves of a SIMD
 // run half a panel out of phase.  The accumulators start as the bias (four ds_reads straight into the C operand: no
 // VALU, no extra registers; the SIMD's other wave covers their latency) and the epilogue is 8 packed converts + 8
 // packed integer max per tile.
-template <int NGE, int KHID, bool EMB_FIRST, class Hook, class Piece>
+template <int NGE, int KHID, bool EMB_FIRST, bool SPLIT, class Hook, class Piece>
 MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4* xlo, uint32_t p, uint32_t pn,
                    uint32_t bias_off, int h, bool late, Hook&& hook, Piece&& piece, unsigned floor, u32x4& out0, u32x4& out1) {
-  constexpr int NG = 2 * NGE + KHID;
+  constexpr int NEG = (SPLIT ? 2 : 1) * NGE;            // groups of the embedded block
+  constexpr int NG = NEG + KHID;
   static_assert(NG > PD, "panel shorter than the fragment pipeline");
   constexpr int LATEQ0 = (NG / 2 < NG - PD) ? NG / 2 : NG - PD;  // the late half must not read the next panel early
   constexpr int LATEQ = LATEQ0 + 3 < NG ? LATEQ0 : NG - 4;       // ... and needs three MFMA gaps behind its barrier
@@ -226,14 +235,14 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
   for (int gi = 0; gi < NG; ++gi) {
     const int s = gi % (PD + 1);
     const int ge = EMB_FIRST ? gi : gi - KHID;            // index within the embedded groups
-    if (ge >= 0 && ge < 2 * NGE) {
-      acc = MF_MFMA32(r[s], xhi[ge >> 1], acc);           // even: Whi * xhi ; odd: Wlo * xhi
+    if (ge >= 0 && ge < NEG) {
+      acc = MF_MFMA32(r[s], xhi[SPLIT ? ge >> 1 : ge], acc);   // SPLIT: even: Whi * xhi ; odd: Wlo * xhi
     } else {
 #ifdef MF_BF_ABL_TWOACC
-      if (gi & 1) acc2 = MF_MFMA32(r[s], hid[EMB_FIRST ? gi - 2 * NGE : gi], acc2);
+      if (gi & 1) acc2 = MF_MFMA32(r[s], hid[EMB_FIRST ? gi - NEG : gi], acc2);
       else
 #endif
-      acc = MF_MFMA32(r[s], hid[EMB_FIRST ? gi - 2 * NGE : gi], acc);
+      acc = MF_MFMA32(r[s], hid[EMB_FIRST ? gi - NEG : gi], acc);
     }
     __builtin_amdgcn_sched_barrier(0);
     const int sp = (gi + PD) % (PD + 1), nb = gi + PD;
@@ -251,7 +260,7 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
     if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
 #endif
     __builtin_amdgcn_sched_barrier(0);
-    if (ge >= 0 && ge < 2 * NGE && !(ge & 1)) {
+    if (SPLIT && ge >= 0 && ge < NEG && !(ge & 1)) {
       acc = MF_MFMA32(r[s], xlo[ge >> 1], acc);           // Whi * xlo
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -319,11 +328,11 @@ MF_D f32x16 head_tile(Carry& carry, const u32x4* hid, uint32_t p, uint32_t pn, u
 // MODE: 1 = embedded input only (layer 0), 2 = hidden only, 3 = both (skip layers, embedded input first).  A template
 // parameter, not a switch inside the tile loop: the register file is full here and every control-flow merge inside
 // the unrolled tile sequence costs copies.
-template <int KH, int NGE, int MODE>
-MF_D void trunk_layer_m(const Net& net, int layer, bool relu, u32x4 (&act)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE],
-                        Stream& st, Carry& carry, const Lane& id, const Next& nxt) {
+template <int KH, int NGE, int MODE, bool SPLIT>
+MF_D void trunk_layer_m(const Net& net, int layer, bool relu, const u32x4 (&act)[KH], u32x4 (&out)[KH], const u32x4 (&xhi)[NGE],
+                        const u32x4 (&xlo)[NGE], Stream& st, Carry& carry, const Lane& id, const Next& nxt) {
   constexpr int NT = KH / 2;
-  const int groups = tgroups<KH, NGE>(net, layer);
+  const int groups = tgroups<KH, NGE, SPLIT>(net, layer);
   const unsigned lo = relu ? 0u : 0x80008000u;      // ReLU / pass-through floor
   const uint32_t bias_off = net.res_lds + layer * (16 * KH) * 4;
 #if !defined(MF_BF_ABL_NOSTAGGER)
@@ -331,7 +340,6 @@ MF_D void trunk_layer_m(const Net& net, int layer, bool relu, u32x4 (&act)[KH], 
 #else
   const bool late = false;
 #endif
-  u32x4 out[KH];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const uint32_t p = st.slot_off(0) + id.lane * 16;
@@ -342,21 +350,39 @@ MF_D void trunk_layer_m(const Net& net, int layer, bool relu, u32x4 (&act)[KH], 
               t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id);
     };
     auto piece = [&](int k) { st.piece(k, id); };
-    out_tile<(MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, true>(carry, act, xhi, xlo, p, pn, bias_off + 32 * t * 4, id.h, late,
+    out_tile<(MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, true, SPLIT>(carry, act, xhi, xlo, p, pn, bias_off + 32 * t * 4, id.h, late,
                                                                hook, piece, lo, out[2 * t], out[2 * t + 1]);
     st.advance();
   }
-#pragma unroll
-  for (int t = 0; t < KH; ++t) act[t] = out[t];
 }
 
-template <int KH, int NGE>
-MF_D void trunk_layer(const Net& net, int layer, bool relu, u32x4 (&act)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE],
-                      Stream& st, Carry& carry, const Lane& id, const Next& nxt) {
+// in -> out (two register sets: the callers alternate them from layer to layer, so no layer ends in a 64-register copy)
+template <int KH, int NGE, bool SPLIT>
+MF_D void trunk_layer(const Net& net, int layer, bool relu, const u32x4 (&act)[KH], u32x4 (&out)[KH], const u32x4 (&xhi)[NGE],
+                      const u32x4 (&xlo)[NGE], Stream& st, Carry& carry, const Lane& id, const Next& nxt) {
   const int has_emb = (net.emb_mask >> layer) & 1;
-  if (layer == 0) trunk_layer_m<KH, NGE, 1>(net, layer, relu, act, xhi, xlo, st, carry, id, nxt);
-  else if (has_emb) trunk_layer_m<KH, NGE, 3>(net, layer, relu, act, xhi, xlo, st, carry, id, nxt);
-  else trunk_layer_m<KH, NGE, 2>(net, layer, relu, act, xhi, xlo, st, carry, id, nxt);
+  if (layer == 0) trunk_layer_m<KH, NGE, 1, SPLIT>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt);
+  else if (has_emb) trunk_layer_m<KH, NGE, 3, SPLIT>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt);
+  else trunk_layer_m<KH, NGE, 2, SPLIT>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt);
+}
+
+// the D trunk layers of a network, in pairs a -> b -> a; returns with the last layer's output in `a`
+template <int KH, int NGE, bool SPLIT, class NextOf>
+MF_D void trunk(const Net& net, int D, u32x4 (&a)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE], Stream& st, Carry& carry,
+                const Lane& id, NextOf&& next_of) {
+  u32x4 b[KH];
+  int l = 0;
+  for (; l + 1 < D; l += 2) {
+    trunk_layer<KH, NGE, SPLIT>(net, l, true, a, b, xhi, xlo, st, carry, id, next_of(l));
+    st.tl.stamp(10 + l, id);
+    trunk_layer<KH, NGE, SPLIT>(net, l + 1, true, b, a, xhi, xlo, st, carry, id, next_of(l + 1));
+    st.tl.stamp(11 + l, id);
+  }
+  if (l < D) {
+    trunk_layer<KH, NGE, SPLIT>(net, l, true, a, b, xhi, xlo, st, carry, id, next_of(l));
+#pragma unroll
+    for (int t = 0; t < KH; ++t) a[t] = b[t];
+  }
 }
 
 // VALU head: NOUT dot products of the lane's half of the hidden vector (bf16, unpacked on the fly) with fp32
@@ -508,10 +534,22 @@ MF_D void split_operands(const float* emb, int n_slots, u32x4 (&xhi)[KS], u32x4 
   }
 }
 
+// fp32 slots -> plain bf16 operands (the NeRF's encodings)
+template <int KS>
+MF_D void pack_operands(const float* emb, int n_slots, u32x4 (&x)[KS]) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int e0 = 8 * ks + 2 * w, e1 = e0 + 1;
+      x[ks][w] = pack_bf16x2(e0 < n_slots ? emb[e0] : 0.f, e1 < n_slots ? emb[e1] : 0.f);
+    }
+}
+
 // ------------------------------------------------------------------ the two networks
-template <int KH, int EKS>
+template <int KH, int EKS, bool SPLIT>
 MF_D void start_program(const Net& n, Stream& st, Carry& carry, uint32_t ring, uint32_t buf_bytes, const Lane& id) {
-  st.start(n.packed + n.res_bytes, 2 * EKS, ring, buf_bytes, id);
+  st.start(n.packed + n.res_bytes, (SPLIT ? 2 : 1) * EKS, ring, buf_bytes, id);
   carry.load(st.slot_off(0) + id.lane * 16);
 }
 
@@ -522,10 +560,10 @@ MF_D void load_resident(const Net& n, const Lane& id) {
 
 // extra_encoding (nerf.py:98): W/2 outputs from [final (W) ; extra block], ReLU.  NGX = extra k-steps (0, 1, 2).
 template <int NGX>
-MF_D void extra_layer(const Net& net, const u32x4 (&act)[16], const u32x4* ehi, const u32x4* elo, u32x4 (&out)[8],
+MF_D void extra_layer(const Net& net, const u32x4 (&act)[16], const u32x4* ex, u32x4 (&out)[8],
                       Stream& st, Carry& carry, const Lane& id, const Next& nxt) {
   constexpr int NT = 4;
-  const int groups = 16 + 2 * NGX;
+  const int groups = 16 + NGX;
   const uint32_t bias_off = net.res_lds + (net.D + 1) * 256 * 4;
   const bool late = id.wave < kWaves / 2;
 #pragma unroll
@@ -537,16 +575,16 @@ MF_D void extra_layer(const Net& net, const u32x4 (&act)[16], const u32x4* ehi, 
               t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id);
     };
     auto piece = [&](int k) { st.piece(k, id); };
-    out_tile<NGX, 16, false>(carry, act, ehi, elo, p, pn, bias_off + 32 * t * 4, id.h, late, hook, piece, 0u, out[2 * t], out[2 * t + 1]);
+    out_tile<NGX, 16, false, false>(carry, act, ex, ex, p, pn, bias_off + 32 * t * 4, id.h, late, hook, piece, 0u, out[2 * t], out[2 * t + 1]);
     st.advance();
   }
 }
 
-// Canonical NeRF (W = 256) on this wave's 32 samples.  xhi/xlo: split operands of the xyz embedding (4 k-steps).
-// `make_extra(ehi, elo)` builds the extra block's operands; it is called right before extra_encoding so that those
+// Canonical NeRF (W = 256) on this wave's 32 samples.  xe: bf16 operands of the xyz embedding (4 k-steps).
+// `make_extra(ex)` builds the extra block's operands; it is called right before extra_encoding so that those
 // registers are not held through the trunk.
 template <class MakeExtra>
-MF_D void nerf_eval(const Net& net, const u32x4 (&xhi)[kKsNerfXyz], const u32x4 (&xlo)[kKsNerfXyz],
+MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
                     MakeExtra&& make_extra, bool sigma_only, Stream& st,
                     Carry& carry, const Lane& id, const Next& follow, float& sigma, float (&rgb)[3]) {
   u32x4 act[16];
@@ -555,11 +593,9 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xhi)[kKsNerfXyz], const u32x4 
 #pragma unroll
     for (int i = 0; i < 4; ++i) act[t][i] = 0;
   const int D = net.D;
-  for (int l = 0; l < D; ++l) {
-    const bool last = sigma_only && l == D - 1;
-    trunk_layer<16, kKsNerfXyz>(net, l, true, act, xhi, xlo, st, carry, id, last ? follow : next_trunk_bf<16, kKsNerfXyz>(net, l + 1));
-    st.tl.stamp(10 + l, id);
-  }
+  trunk<16, kKsNerfXyz, false>(net, D, act, xe, xe, st, carry, id, [&](int l) {
+    return (sigma_only && l == D - 1) ? follow : next_trunk_bf<16, kKsNerfXyz, false>(net, l + 1);
+  });
   // resident block: [bias_trunk (D+1) 256 | bias_extra 128 | sigma_w 256 | sigma_b 4 | rgb_w 384 | rgb_b 4]
   const uint32_t r_sigma_w = net.res_lds + ((D + 1) * 256 + 128) * 4;
   float sg[1];
@@ -567,16 +603,17 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xhi)[kKsNerfXyz], const u32x4 
   sigma = sg[0];
   st.tl.stamp(30, id);
   if (sigma_only) return;
-  const int xg = 16 + 2 * net.aux;
+  const int xg = 16 + net.aux;
   const Next ex{xg, nullptr, xg, nullptr};
-  trunk_layer<16, kKsNerfXyz>(net, D, false, act, xhi, xlo, st, carry, id, ex);          // xyz_encoding_final (no ReLU)
+  u32x4 fin[16];
+  trunk_layer_m<16, kKsNerfXyz, 2, false>(net, D, false, act, fin, xe, xe, st, carry, id, ex);   // xyz_encoding_final (no ReLU, hidden input only)
   st.tl.stamp(31, id);
-  u32x4 e[8], ehi[kKsExtraMax], elo[kKsExtraMax];
-  make_extra(ehi, elo);
+  u32x4 e[8], eo[kKsExtraMax];
+  make_extra(eo);
   st.tl.stamp(32, id);
-  if (net.aux == 2) extra_layer<2>(net, act, ehi, elo, e, st, carry, id, follow);
-  else if (net.aux == 1) extra_layer<1>(net, act, ehi, elo, e, st, carry, id, follow);
-  else extra_layer<0>(net, act, ehi, elo, e, st, carry, id, follow);
+  if (net.aux == 2) extra_layer<2>(net, fin, eo, e, st, carry, id, follow);
+  else if (net.aux == 1) extra_layer<1>(net, fin, eo, e, st, carry, id, follow);
+  else extra_layer<0>(net, fin, eo, e, st, carry, id, follow);
   st.tl.stamp(33, id);
   float o[3];
   valu_head(e, r_sigma_w + (256 + 4) * 4, r_sigma_w + (256 + 4 + 384) * 4, id.h, o);
@@ -595,8 +632,7 @@ MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofIn], const u32x4 (&x
   const int D = net.D;
   // the head panel (16 groups) follows the last trunk layer contiguously; behind it comes `follow`'s first panel
   const Next hd{16, nullptr, follow.groups, follow.jump};
-  for (int l = 0; l < D; ++l)
-    trunk_layer<8, kKsNofIn>(net, l, true, act, xhi, xlo, st, carry, id, l == D - 1 ? hd : next_trunk_bf<8, kKsNofIn>(net, l + 1));
+  trunk<8, kKsNofIn, true>(net, D, act, xhi, xlo, st, carry, id, [&](int l) { return l == D - 1 ? hd : next_trunk_bf<8, kKsNofIn, true>(net, l + 1); });
   // head on the matrix pipe (16 MFMAs instead of 9 x 64 dependent FMAs + 144 LDS reads per lane); T[0..3] come
   // out in half 0's registers 0-3, T[4..7] in half 1's registers 0-3, T[8] in half 0's register 4
   f32x16 acc;

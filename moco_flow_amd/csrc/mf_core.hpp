@@ -177,6 +177,8 @@ struct NetLayout {
   int bf16;                // 1: hidden (W-wide) k-ranges are stored as bf16 and run on v_mfma_f32_16x16x32_bf16
   int n_trunk;             // trunk layers streamed through the generic loop (NeRF: D+1 incl. final)
   int emb_steps;           // k-steps of the embedded-input block
+  int emb_split;           // bf16: every embedded k-step is TWO groups (hi = bf16(w), lo = bf16(w - hi)) -- the NoF
+                           // (its output point feeds sin(512 x)); 0: plain bf16 like the hidden ranges -- the NeRF
   uint32_t emb_mask;       // trunk layers that consume the embedded input (layer 0 + skips)
   uint32_t relu_mask;      // trunk layers followed by ReLU
   int extra_steps;         // NeRF extra_encoding: k-steps of the extra block (0, 4, 8); -1 = no extra layer
@@ -197,20 +199,20 @@ struct NetLayout {
 // Two 1 KiB groups per batch (one per 16-row tile of the 32-row panel).
 // bf16 (mf_bf16.hpp) -- a panel is ONE 32-row tile; a group = 32 rows x 16 k of bf16 (one A fragment of
 // v_mfma_f32_32x32x16_bf16); `emb_steps` / `extra_steps` count 16-slot k-steps of the embedded blocks, each stored
-// as two groups (hi = bf16(w), lo = bf16(w - hi)); a W-wide hidden range is NK groups.
+// as one group, or with `emb_split` as two (hi = bf16(w), lo = bf16(w - hi)); a W-wide hidden range is NK groups.
 MF_HD int hidden_batches(const NetLayout& L) { return L.NK; }
 MF_HD int trunk_batches(const NetLayout& L, int layer) {
   return (((L.emb_mask >> layer) & 1) ? L.emb_steps / 4 : 0) + (layer > 0 ? hidden_batches(L) : 0);
 }
 MF_HD int trunk_groups(const NetLayout& L, int layer) {
-  if (L.bf16) return (((L.emb_mask >> layer) & 1) ? 2 * L.emb_steps : 0) + (layer > 0 ? L.NK : 0);
+  if (L.bf16) return (((L.emb_mask >> layer) & 1) ? (L.emb_split ? 2 : 1) * L.emb_steps : 0) + (layer > 0 ? L.NK : 0);
   return 2 * trunk_batches(L, layer);
 }
 // bf16 NoF: the 3|9-row head (nof.py:75-82) as one more panel behind the trunk: a 32-row tile (rows >= n_head zero)
 // whose hidden k-steps are split (hi, lo) group pairs -- the head's weights keep 16 mantissa bits.
 MF_HD int head_groups(const NetLayout& L) { return 2 * L.NK; }
 MF_HD int extra_groups(const NetLayout& L) {
-  if (L.bf16) return L.NK + 2 * L.extra_steps;
+  if (L.bf16) return L.NK + (L.emb_split ? 2 : 1) * L.extra_steps;
   return 2 * (hidden_batches(L) + L.extra_steps / 4);
 }
 

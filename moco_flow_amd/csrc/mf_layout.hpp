@@ -22,6 +22,7 @@ inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L, int bf16 = 0) {
   L.n_trunk = d.D + 1;                                // + xyz_encoding_final (no ReLU)
   if (bf16 && d.W != 256) return false;
   L.emb_steps = bf16 ? kKsNerfXyz : kStepsNerfXyz;     // bf16: 16-slot k-steps (mf_bf16.hpp); fp32: 4-k MFMA steps
+  L.emb_split = 0;                                     // bf16: the NeRF's encodings are plain bf16 operands (mf_bf16.hpp)
   L.emb_mask = 1u | d.skip_mask;
   L.relu_mask = (1u << d.D) - 1u;
   switch (d.extra_feat_type) {
@@ -65,6 +66,7 @@ inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0) {
   L.NP = d.W / 32;
   L.n_trunk = d.D;
   L.emb_steps = bf16 ? kKsNofIn : kStepsNofIn;
+  L.emb_split = bf16 ? 1 : 0;                          // bf16: the NoF's embedded input keeps 16 mantissa bits
   L.emb_mask = 1u | d.skip_mask;
   L.relu_mask = (1u << d.D) - 1u;
   L.extra_steps = -1;

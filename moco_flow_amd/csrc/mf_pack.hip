@@ -28,6 +28,7 @@ struct PackRegion {          // one trunk/extra layer's panels
   int xyz_cols;
   int n_rows;                // rows present in W (bf16 head panel: 3|9 of its 32; 0 = all)
   int hid_split;             // bf16: hidden k-step ks is TWO groups (hi, lo) instead of one
+  int emb_split;             // bf16: embedded k-step ks is TWO groups (hi, lo) instead of one
   long long dst_group0;      // first group index (in 1 KiB units) within the panel area
 };
 
@@ -59,12 +60,13 @@ __global__ void pack_panels_kernel(PackJob job) {
   if (R.bf16) {
     // bf16 layout (mf_bf16.hpp): panel = ONE 32-row tile, group = A fragment of v_mfma_f32_32x32x16_bf16:
     // lane (i = lane&31, h = lane>>5) holds 8 bf16 = W[32P + i][col(k-step, slot 8h + e)], e = 0..7.
-    // Embedded k-step ks is two groups (hi = bf16(w), lo = bf16(w - hi)); hidden k-step ks covers features
+    // Embedded k-step ks is one group, or two with emb_split (hi = bf16(w), lo = bf16(w - hi)); hidden k-step ks covers features
     // 16 ks + hid_perm2(h, e).
     const int i = lane & 31, h = lane >> 5;
     const float* row = R.W + (long long)(32 * P + i) * R.n_in;
+    const int eg = (R.emb_split ? 2 : 1) * R.emb_steps;      // groups of the embedded block
     const int ge = R.emb_first ? gi : gi - R.hid_batches;
-    const int gh = R.emb_first ? gi - 2 * R.emb_steps : gi;
+    const int gh = R.emb_first ? gi - eg : gi;
     unsigned short h8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (R.n_rows && 32 * P + i >= R.n_rows) {
       // zero row of a partial tile
@@ -75,8 +77,8 @@ __global__ void pack_panels_kernel(PackJob job) {
         const unsigned short hi = bf16_rne(w);
         h8[e] = lo ? bf16_rne(w - __uint_as_float((unsigned)hi << 16)) : hi;
       }
-    } else if (ge >= 0 && ge < 2 * R.emb_steps) {
-      const int ks = ge >> 1, lo = ge & 1;
+    } else if (ge >= 0 && ge < eg) {
+      const int ks = R.emb_split ? ge >> 1 : ge, lo = R.emb_split ? ge & 1 : 0;
       for (int e = 0; e < 8; ++e) {
         const int f = emb_feature2(R.emb_kind, h, 8 * ks + e, R.xyz_cols);
         const float w = (f >= 0 && f < R.emb_cols) ? row[R.emb_col0 + f] : 0.f;
@@ -174,6 +176,7 @@ extern "C" int32_t mf_nerf_pack_p(const mf_nerf_desc* d, int32_t precision, void
     R.hid_steps = l > 0 ? L.NK * 4 : 0;
     R.hid_batches = l > 0 ? hidden_batches(L) : 0;
     R.bf16 = L.bf16;
+    R.emb_split = L.emb_split;
     R.hid_col0 = has_emb ? d->in_channels_xyz : 0;
     R.xyz_cols = d->in_channels_xyz;
     R.dst_group0 = g0;
@@ -197,6 +200,7 @@ extern "C" int32_t mf_nerf_pack_p(const mf_nerf_desc* d, int32_t precision, void
     R.hid_steps = L.NK * 4;
     R.hid_batches = hidden_batches(L);
     R.bf16 = L.bf16;
+    R.emb_split = L.emb_split;
     R.hid_col0 = 0;
     R.xyz_cols = 0;
     R.dst_group0 = g0;
@@ -246,6 +250,7 @@ extern "C" int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* 
     R.hid_steps = l > 0 ? L.NK * 4 : 0;
     R.hid_batches = l > 0 ? hidden_batches(L) : 0;
     R.bf16 = L.bf16;
+    R.emb_split = L.emb_split;
     R.hid_col0 = has_emb ? cin : 0;
     R.xyz_cols = d->in_channels_xyz;
     R.dst_group0 = g0;

@@ -50,9 +50,9 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
   Stream st;
   st.tl.start(p.alphas, id);
   Carry carry;
-  const Next prog_first = MOCO ? first_of<8, kKsNofIn>(p.bw) : first_of<16, kKsNerfXyz>(p.nerf);
-  if (MOCO) start_program<8, kKsNofIn>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);   // (its wait + barrier also publish the resident blocks / tables)
-  else start_program<16, kKsNerfXyz>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
+  const Next prog_first = MOCO ? first_of<8, kKsNofIn, true>(p.bw) : first_of<16, kKsNerfXyz, false>(p.nerf);
+  if (MOCO) start_program<8, kKsNofIn, true>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);   // (its wait + barrier also publish the resident blocks / tables)
+  else start_program<16, kKsNerfXyz, false>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
 
   const int S = p.S;
   const bool sigma_only = p.flags & MF_F_SIGMA_ONLY;
@@ -111,7 +111,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
           if (role == 1 || role == 2) { cur[0] = canon[0]; cur[1] = canon[1]; cur[2] = canon[2]; }
           const bool last = step == nsteps - 1;
           const bool next_fw = (role + 1 == 1 || role + 1 == 2 || role + 1 == 4);
-          const Next follow = last ? first_of<16, kKsNerfXyz>(p.nerf) : first_of<8, kKsNofIn>(next_fw ? p.fw : p.bw);
+          const Next follow = last ? first_of<16, kKsNerfXyz, false>(p.nerf) : first_of<8, kKsNofIn, true>(next_fw ? p.fw : p.bw);
           u32x4 nhi[kKsNofIn], nlo[kKsNofIn];
           float out[3];
           nof_embed(nhi, nlo, cur, ind, par_nof_xyz, par_nof_ind, id.h, p.pow2 & 4, p.pow2 & 8);
@@ -129,14 +129,14 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
       }
 
       st.tl.stamp(3, id);
-      u32x4 xhi[kKsNerfXyz], xlo[kKsNerfXyz];
+      u32x4 xe[kKsNerfXyz];
       {
         float embx[B2Xyz10::SLOTS];
         jitter();
         emb_eval<3, 10>(embx, xin, par_nerf_xyz, id.h, p.pow2 & 1);
-        split_operands<kKsNerfXyz>(embx, B2Xyz10::SLOTS, xhi, xlo);
+        pack_operands<kKsNerfXyz>(embx, B2Xyz10::SLOTS, xe);
       }
-      auto make_extra = [&](u32x4 (&ehi)[kKsExtraMax], u32x4 (&elo)[kKsExtraMax]) {
+      auto make_extra = [&](u32x4 (&eo)[kKsExtraMax]) {
         float ext[8 * kKsExtraMax];
 #pragma unroll
         for (int e = 0; e < 8 * kKsExtraMax; ++e) ext[e] = 0.f;
@@ -147,11 +147,11 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
           const float iv[1] = {rp[8]};
           emb_eval<1, 2>(ext, iv, par_nerf_ext, id.h, p.pow2 & 2);                         // rendering.py:133-137
         }
-        split_operands<kKsExtraMax>(ext, 8 * kKsExtraMax, ehi, elo);
+        pack_operands<kKsExtraMax>(ext, 8 * kKsExtraMax, eo);
       };
       st.tl.stamp(4, id);
       float sigma, rgb[3] = {0.f, 0.f, 0.f};
-      nerf_eval(p.nerf, xhi, xlo, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb);
+      nerf_eval(p.nerf, xe, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb);
       if (valid && id.h == 0) {
         sbuf[srel] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
         zbuf[srel] = z;

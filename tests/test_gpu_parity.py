@@ -419,17 +419,20 @@ def _l2rel(a, b):
 #            case                     PSNR-equiv rgb (dB)   l2-rel rgb   l2-rel depth/opacity
 # measured r2 (dB / l2 rgb / worst l2 of depth, opacity): dense 61.5 / 1.2e-3 / 7.5e-4; fine_train 57.5 / 1.7e-3 /
 # 4.1e-3; default 95.0 / 3.6e-5 / 1.7e-5; moco_global 46.1 / 9.2e-3; moco_global_fine 50.4 / 4.6e-3 / 5.7e-4
+# measured with the NeRF's encodings as plain bf16 operands (later in r2): dense 61.8 / 1.2e-3 / 7.1e-4; fine_train
+# 57.4 / 1.7e-3 / 5.0e-3; default 90.4 / 6.0e-5; moco_global 46.5 / 8.8e-3 / 1.4e-2; moco_global_fine 50.8 / 4.4e-3
 BF16_BARS = {"r_nerf_dir_dense":      (58.0,                3e-3,        2e-3),
              "r_nerf_dir_fine_train": (55.0,                4e-3,        8e-3),
-             "r_nerf_dir_default":    (92.0,                1e-4,        1e-4),
+             "r_nerf_dir_default":    (88.0,                1e-4,        1e-4),
              "r_moco_global":         (44.0,                1.4e-2,      2e-2),
              "r_moco_global_fine":    (48.0,                8e-3,        2e-3)}
 
 
 @pytest.mark.parametrize("name", sorted(BF16_BARS))
 def test_bf16_hidden_gemms(M, R, name):
-    """BASELINE configs C3-C5: bf16 hidden GEMMs (fp32 accumulate; embedded-input k-ranges as a 16-bit two-term
-    bf16 split; heads and composite in fp32).  Not the 1e-4 contract -- north_star allows a PSNR-equivalent
+    """BASELINE configs C3-C5: bf16 hidden GEMMs (fp32 accumulate; the NoF's embedded-input k-ranges and head as a
+    16-bit two-term bf16 split, the NeRF's encodings as plain bf16 operands -- measured 90.4 dB at default init (95.0
+    with the split), 61.8 dB dense (unchanged); heads and composite in fp32).  Not the 1e-4 contract -- north_star allows a PSNR-equivalent
     error for bf16 -- but the bars sit just under the measured values (BF16_BARS), per case,
     with l2-rel bounds on every per-ray output.  With a fine pass the oracle is re-run on the HIP path's own
     fine depths, so the resample's conditioning does not enter."""

@@ -97,10 +97,11 @@ def test_packed_layout_sizes():
     groups = (10 + 16 + 26 + 16) * 4
     assert lib.mf_nof_packed_bytes(ctypes.byref(n)) == 7 * 1024 + groups * 1024
     # MF_PREC_BF16 (mf_bf16.hpp): a panel is ONE 32-row tile, a group one A fragment of v_mfma_f32_32x32x16_bf16;
-    # embedded k-steps are (hi, lo) group pairs; the NoF head is one more 16-group panel
+    # the NoF's embedded k-steps are (hi, lo) group pairs and its head is one more 16-group panel; the NeRF's encodings
+    # are single groups (plain bf16 operands: 4 k-steps of the xyz block, 2 of the direction block)
     assert lib.mf_nof_packed_bytes_p(ctypes.byref(n), L.MF_PREC_BF16) == 7 * 1024 + ((10 + 8 + 18 + 8) * 4 + 16) * 1024
     d.extra_feat_type, d.extra_feat_dim = L.MF_EXTRA_DIR, 27
-    groups = (8 + 3 * 16 + 24 + 3 * 16 + 16) * 8 + (16 + 4) * 4
+    groups = (4 + 3 * 16 + 20 + 3 * 16 + 16) * 8 + (16 + 2) * 4
     assert lib.mf_nerf_packed_bytes_p(ctypes.byref(d), L.MF_PREC_BF16) == 13 * 1024 + groups * 1024
     assert lib.mf_loss_partials_scratch_bytes() == 256 * 12 * 8
     assert lib.mf_loss_partials(None, None, None, 0, None, None, None) == -1

@@ -222,11 +222,109 @@ static void run(const char* name, const char* w, long long wbytes, float* out, i
   printf("%-34s: %.3f ms  %.1f TFLOP/s (%.1f %% of 2516)  ticks %lld = %.2f GHz, MFMA busy %.1f %% of ticks  err=%d\n", name, best, flops / best / 1e9,
          flops / best / 1e9 / 25.16, ticks, ticks / best / 1e6, 100.0 * mfma_cyc / ticks, (int)hipGetLastError());
 }
+
+// ---- 4 waves x (NG x 32) samples: one wave per SIMD, up to 512 registers; each fragment read feeds NG MFMAs
+template <int NG, int OPT>
+D void layer_w(const u32x4 (&act)[NG][KH], u32x4 (&nxt)[NG][KH], Ring& r, int wave, int lane, uint32_t lane16) {
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const uint32_t p = r.off0 + lane * 16;
+    f32x16 acc[NG];
+    for (int g = 0; g < NG; ++g) for (int i = 0; i < 16; ++i) acc[g][i] = 0.f;
+    u32x4 fr[PD + 1];
+#pragma unroll
+    for (int k = 0; k < PD; ++k) fr[k] = lds_u4(p + k * 1024);
+#pragma unroll
+    for (int k = 0; k < KH; ++k) {
+      if (k == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const uint32_t grp = wave + q * 4;
+          const uint32_t dst = r.off2 + grp * 1024, soff = r.goff + grp * 1024;
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(dst), "v"(lane16), "s"(r.rsrc), "s"(soff) : "memory", "m0");
+        }
+        r.goff += PANEL;
+        if (r.goff + PANEL > (uint32_t)r.wbytes) r.goff = 0;
+      }
+      const int s = k % (PD + 1), sp = (k + PD) % (PD + 1);
+      if (k + PD < KH) fr[sp] = lds_u4(p + (k + PD) * 1024);
+#pragma unroll
+      for (int g = 0; g < NG; ++g) acc[g] = MFMA(fr[s], act[g][k], acc[g]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#pragma unroll
+    for (int g = 0; g < NG; ++g) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        nxt[g][2 * t][q] = relu2(pack2(acc[g][2 * q], acc[g][2 * q + 1]));
+        nxt[g][2 * t + 1][q] = relu2(pack2(acc[g][8 + 2 * q], acc[g][8 + 2 * q + 1]));
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) asm volatile("" : "+v"(nxt[g][2 * t][q]), "+v"(nxt[g][2 * t + 1][q]));
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    const uint32_t tmp = r.off0; r.off0 = r.off1; r.off1 = r.off2; r.off2 = tmp;
+  }
+}
+template <int NG, int OPT>
+__global__ __launch_bounds__(256) void proto_w(const char* w, long long wbytes, float* out, int layers, int reps, long long* ticks_out) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t lane16 = lane * 16;
+  u32x4 act[NG][KH], nxt[NG][KH];
+  for (int g = 0; g < NG; ++g) for (int k = 0; k < KH; ++k) { act[g][k] = u32x4{(unsigned)lane * 7u + k, 0x3f803f80u, (unsigned)g, 0x3f003f00u}; nxt[g][k] = act[g][k]; }
+  Ring r;
+  r.w = w; r.wbytes = wbytes;
+  r.gnext = w + (blockIdx.x % 4) * PANEL;
+  r.goff = (blockIdx.x % 4) * PANEL;
+  r.off0 = 0; r.off1 = PANEL; r.off2 = 2 * PANEL;
+  {
+    const unsigned long long base = (unsigned long long)w;
+    r.rsrc[0] = __builtin_amdgcn_readfirstlane((int)(base & 0xffffffffu));
+    r.rsrc[1] = __builtin_amdgcn_readfirstlane((int)((base >> 32) & 0xffffu));
+    r.rsrc[2] = __builtin_amdgcn_readfirstlane((int)wbytes);
+    r.rsrc[3] = 0x00020000;
+  }
+  for (int grp = wave; grp < 16; grp += 4) { glds16(r.gnext + grp * 1024 + lane * 16, r.off0 + grp * 1024); glds16(r.gnext + PANEL + grp * 1024 + lane * 16, r.off1 + grp * 1024); }
+  r.goff += 2 * PANEL;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int rep = 0; rep < reps; ++rep)
+    for (int l = 0; l < layers; l += 2) {
+      layer_w<NG, OPT>(act, nxt, r, wave, lane, lane16);
+      layer_w<NG, OPT>(nxt, act, r, wave, lane, lane16);
+    }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  unsigned s = 0;
+  for (int g = 0; g < NG; ++g) for (int k = 0; k < KH; ++k) s += act[g][k][0] ^ act[g][k][3];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = (float)s;
+  if (blockIdx.x == 0 && threadIdx.x == 0) ticks_out[0] = 0;
+}
+template <int NG, int OPT>
+static void run_w(const char* name, const char* w, long long wbytes, float* out, int layers, int reps) {
+  hipFuncSetAttribute(reinterpret_cast<const void*>(proto_w<NG, OPT>), hipFuncAttributeMaxDynamicSharedMemorySize, 3 * PANEL);
+  hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
+  const int grid = 256;
+  float best = 1e9f;
+  for (int it = 0; it < 4; ++it) {
+    hipEventRecord(a);
+    hipLaunchKernelGGL((proto_w<NG, OPT>), dim3(grid), dim3(256), 3 * PANEL, 0, w, wbytes, out, layers, reps, g_ticks);
+    hipEventRecord(b); hipEventSynchronize(b);
+    float ms; hipEventElapsedTime(&ms, a, b);
+    if (it > 0 && ms < best) best = ms;
+  }
+  const double samples = (double)grid * (4 * 32 * NG) * reps, flops = samples * layers * 256.0 * 256.0 * 2.0;
+  printf("%-34s: %.3f ms  %.1f TFLOP/s (%.1f %% of 2516)  err=%d\n", name, best, flops / best / 1e9, flops / best / 1e9 / 25.16, (int)hipGetLastError());
+}
 int main() {
   const long long wbytes = 64ll << 20;
   char* w; float* out;
   hipMalloc(&w, wbytes); hipMemset(w, 0x3c, wbytes); hipMalloc(&out, 256 * 512 * 4); hipMalloc(&g_ticks, 8);
   for (int pass = 0; pass < 2; ++pass) {
+    run_w<2, 0>("4 waves x 64, buf, nocopy", w, wbytes, out, 8, 16);
+    run_w<1, 0>("4 waves x 32, buf, nocopy", w, wbytes, out, 8, 16);
     run<O_MFMAONLY>("MFMA only", w, wbytes, out, 8, 16);
     run<O_MFMAONLY | O_NOCOPY>("MFMA only, no copy", w, wbytes, out, 8, 16);
     run<O_BUFLDS | O_TWOCHAIN>("buf + two chains", w, wbytes, out, 8, 16);
