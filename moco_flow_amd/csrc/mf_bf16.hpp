@@ -53,30 +53,6 @@ MF_D u32x4 lds_u4(uint32_t byte_off) { return *(const u32x4*)(smem + byte_off); 
 
 // Weight-panel stream (see mf_core.hpp Stream): 3-slot LDS ring fed by LDS-DMA, two panels ahead of the MFMAs,
 // one workgroup barrier per panel.
-// Phase timeline (-DMF_BF_TIMELINE, tools/timeline_bf16.py): lane 0 of waves 0 and 4 of workgroup 0 store the shader
-// clock at phase boundaries into the pass's `alphas` plane (which this build does not otherwise write).
-struct Timeline {
-#ifdef MF_BF_TIMELINE
-  float* buf; unsigned long long t0; int n; bool on;
-  MF_D void start(float* b, const Lane& id) {
-    on = blockIdx.x == 0 && (id.wave == 0 || id.wave == 4);
-    buf = b + (id.wave == 4 ? 512 : 0);
-    n = 0;
-    t0 = __builtin_amdgcn_s_memtime();
-  }
-  MF_D void stamp(int tag, const Lane& id) {
-    if (on && buf && n < 250) {
-      const unsigned long long t = __builtin_amdgcn_s_memtime();
-      if (id.lane == 0) { buf[2 * n] = (float)tag; buf[2 * n + 1] = (float)(long long)(t - t0); }
-      ++n;
-    }
-  }
-#else
-  MF_D void start(float*, const Lane&) {}
-  MF_D void stamp(int, const Lane&) {}
-#endif
-};
-
 struct Stream {
   Timeline tl;
   const char* gnext;      // global address of the panel two ahead of the one being computed

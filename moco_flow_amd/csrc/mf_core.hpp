@@ -306,6 +306,30 @@ MF_D T sel4(int g, T a0, T a1, T a2, T a3) {
   return (g & 2) ? hi : lo;
 }
 
+// Phase timeline (-DMF_TIMELINE, tools/timeline.py): lane 0 of waves 0 and 4 of workgroup 0 store the shader
+// clock at phase boundaries into the pass's `alphas` plane (which this build does not otherwise write).
+struct Timeline {
+#ifdef MF_TIMELINE
+  float* buf; unsigned long long t0; int n; bool on;
+  template <class Id> MF_D void start(float* b, const Id& id) {
+    on = blockIdx.x == 0 && (id.wave == 0 || id.wave == 4);
+    buf = b + (id.wave == 4 ? 512 : 0);
+    n = 0;
+    t0 = __builtin_amdgcn_s_memtime();
+  }
+  template <class Id> MF_D void stamp(int tag, const Id& id) {
+    if (on && buf && n < 250) {
+      const unsigned long long t = __builtin_amdgcn_s_memtime();
+      if (id.lane == 0) { buf[2 * n] = (float)tag; buf[2 * n + 1] = (float)(long long)(t - t0); }
+      ++n;
+    }
+  }
+#else
+  template <class Id> MF_D void start(float*, const Id&) {}
+  template <class Id> MF_D void stamp(int, const Id&) {}
+#endif
+};
+
 // Weight-panel stream: a 3-slot LDS ring fed by LDS-DMA (global_load_lds_dwordx4), running
 // TWO panels ahead of the MFMAs.  While panel c is being multiplied, panel c+1 is already
 // complete and visible (so its first fragments and bias can be pre-read during c's tail: no
@@ -314,6 +338,7 @@ MF_D T sel4(int g, T a0, T a1, T a2, T a3) {
 //   RAW: every wave waited vmcnt(0) for its own pieces of c+1 before arriving;
 //   WAR: every wave has started c, hence finished reading c-1, whose slot c+2 overwrites.
 struct Stream {
+  Timeline tl;
   const char* gnext;      // global address of the panel two ahead of the one being computed
   uint32_t ring;          // LDS byte offset of slot 0
   uint32_t buf_bytes;     // bytes per slot

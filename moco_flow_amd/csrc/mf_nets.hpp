@@ -125,10 +125,12 @@ MF_D void nerf_eval_impl(const NetDev& net, const float (&embx)[kStepsNerfXyz], 
     const bool last = sigma_only && l == D - 1;
     trunk_layer<NK, kStepsNerfXyz, BF16, DUMP>(net, l, act, embx, st, carry, id, last ? follow : next_trunk(net, l + 1),
                                                dump_row ? dump_row + l * net.L.W : nullptr);
+    st.tl.stamp(10 + l, id);
   }
   float sg[1];
   valu_head(act, net.res_lds + net.L.off_head_w * 4, net.L.W, net.res_lds + net.L.off_head_b * 4, id.g, sg);
   sigma = sg[0];
+  st.tl.stamp(30, id);
   if (sigma_only) return;
   NextLayer ex;
   ex.groups = extra_groups(net.L);
@@ -136,8 +138,10 @@ MF_D void nerf_eval_impl(const NetDev& net, const float (&embx)[kStepsNerfXyz], 
   ex.bias_off = net.res_lds + net.L.off_bias_extra * 4;
   trunk_layer<NK, kStepsNerfXyz, BF16, DUMP>(net, D, act, embx, st, carry, id, ex,          // xyz_encoding_final
                                              dump_row ? dump_row + D * net.L.W : nullptr);
+  st.tl.stamp(31, id);
   typename ActT<BF16>::T e[ActLen<BF16, NK / 2>::N];
   extra_layer<NK, BF16, DUMP>(net, act, ext, e, st, carry, id, follow, dump_row ? dump_row + (D + 1) * net.L.W : nullptr);
+  st.tl.stamp(33, id);
   float o[3];
   valu_head(e, net.res_lds + net.L.off_rgb_w * 4, net.L.W / 2, net.res_lds + net.L.off_rgb_b * 4, id.g, o);
 #pragma unroll

@@ -72,6 +72,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
   st.buf_bytes = p.buf_bytes;
   st.dbg = MF_TIMING_FLAGS ? p.dbg : 0;
   st.keep2 = false;
+  st.tl.start(p.alphas, id);
   // the panel program of a tile: [bw NoF, fw NoF chains,] NeRF, then around again
   const NextLayer prog_first = MOCO ? follow_of(p.bw) : follow_of(nerf);
   if (MOCO) start_program(p.bw, st, carry, id);
@@ -89,6 +90,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
     const int ntiles = (nsamp + kTile - 1) / kTile;
 
     for (int tile = 0; tile < ntiles; ++tile) {
+      st.tl.stamp(1, id);
       const int srel = tile * kTile + id.wave * kWaveSamples + id.j;
       const bool valid = srel < nsamp;
       const int sl = valid ? srel : nsamp - 1;
@@ -110,6 +112,10 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) x[c] = o[c] + d[c] * z;                      // rendering.py:262-263
 
+#ifdef MF_TIMELINE
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
+#endif
+      st.tl.stamp(2, id);
       float xin[3] = {x[0], x[1], x[2]};      // what the canonical NeRF sees
       if (MOCO) {
         // chain program (rendering.py:270-282): step 0 bw(x,i) -> canon; local: fw(canon,i) -> recon;
@@ -183,6 +189,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
           emb_eval_lds<1, 2>(ext, iv, par_nerf_ext, id.g);                               // rendering.py:133-137
         }
       }
+      st.tl.stamp(4, id);
       float sigma, rgb[3] = {0.f, 0.f, 0.f};
       float* dump_row = nullptr;
       if constexpr (DUMP) {
@@ -198,8 +205,10 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
           if (p.dump_xyz) { float* q = p.dump_xyz + (ray * S + si) * 3; q[0] = xin[0]; q[1] = xin[1]; q[2] = xin[2]; }
         }
       }
+      st.tl.stamp(5, id);
     }
     __syncthreads();
+    st.tl.stamp(6, id);
 
     // ---- composite (rendering.py:157-192): one wave per ray, lanes over samples
     for (int rr = id.wave; rr < ((MF_TIMING_FLAGS && (p.dbg & 8)) ? 0 : nr); rr += kWaves) {
@@ -234,7 +243,9 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
         carry = carry * wave_last(incl);
         if (v) {
           if (p.weights) p.weights[ray * S + i] = w;
+#ifndef MF_TIMELINE
           if (p.alphas) p.alphas[ray * S + i] = alpha;
+#endif
           acc_w += w;
           acc_r += w * s4.x; acc_g += w * s4.y; acc_b += w * s4.z;
           acc_d += w * z;
@@ -259,7 +270,9 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
         }
       }
     }
+    st.tl.stamp(7, id);
     __syncthreads();
+    st.tl.stamp(8, id);
   }
   wait_vm0();   // the stream runs two panels ahead: drain the LDS-DMA before the workgroup retires
 }

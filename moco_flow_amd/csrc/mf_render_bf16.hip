@@ -88,7 +88,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
 #pragma unroll
       for (int c = 0; c < 3; ++c) x[c] = o[c] + d[c] * z;                      // rendering.py:262-263
 
-#ifdef MF_BF_TIMELINE
+#ifdef MF_TIMELINE
       asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
 #endif
       st.tl.stamp(2, id);
@@ -194,7 +194,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
         carry_t = carry_t * wave_last(incl);
         if (v) {
           if (p.weights) p.weights[ray * S + i] = w;
-#ifndef MF_BF_TIMELINE
+#ifndef MF_TIMELINE
           if (p.alphas) p.alphas[ray * S + i] = alpha;
 #endif
           acc_w += w;

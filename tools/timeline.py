@@ -1,6 +1,6 @@
-"""Phase timeline of the bf16 render kernel (timing tool; needs a library built with -DMF_BF_TIMELINE:
-tools/ab_lib.sh build mf_render_bf16.hip "tl=-fno-slp-vectorize -DMF_BF_TIMELINE", run with
-MOCOFLOW_HIP_LIB=build/ab/lib_tl.so).  Prints, for waves 0 and 4 of workgroup 0, the shader-clock deltas between the
+"""Phase timeline of the fused render kernels (timing tool; needs a library built with -DMF_TIMELINE:
+make -C moco_flow_amd/csrc EXTRA=-DMF_TIMELINE OUT=$PWD/build/ab/lib_tl.so, run with
+MOCOFLOW_HIP_LIB=build/ab/lib_tl.so python tools/timeline.py C2|C2b|C3|C3g).  Prints, for waves 0 and 4 of workgroup 0, the shader-clock deltas between the
 stamps of csrc/mf_render_bf16.hip / mf_bf16.hpp (tags: 1 tile start, 2 rays loaded, 3 NoF chain done, 4 encoded,
 10+l trunk layer l done, 30 sigma head, 31 final layer, 32 extra operands, 33 extra layer, 5 tile end, 6 barrier,
 7 composite, 8 barrier)."""
@@ -24,7 +24,7 @@ z_steps = torch.linspace(0, 1, S, device=dev)
 loc, glob = cfg["nof"] in ("local", "global"), cfg["nof"] == "global"
 for it in range(3):
     out = R._render_pass(rays, bg, None, z_steps, False, None, 0, models["nerfs"][0], models["embs"], models["nofs"],
-                         models["nof_embs"], loc, glob, False, True, precision="bf16")
+                         models["nof_embs"], loc, glob, False, True, precision=cfg["precision"])
 torch.cuda.synchronize()
 a = out["alphas"].flatten().cpu()
 for w, base in ((0, 0), (4, 512)):
