@@ -20,8 +20,9 @@ MF_D void bwd_layer(const f32x4 (&in)[NKI], const float (&sig)[kBwdSigSteps], f3
     const uint32_t p = st.slot_off(0) + id.lane * 16;
     const uint32_t pn = st.slot_off(1) + id.lane * 16;
     f32x4 m0 = {1.f, 1.f, 1.f, 1.f}, m1 = {1.f, 1.f, 1.f, 1.f};
-    auto hook = [&]() {
-      st.template sync_and_dma<true>(t + 2 < NPO ? groups : nxt.groups, t == NPO - 2 ? nxt.jump : nullptr, id);
+    auto hook = [&](int ph) {
+      st.template sync_and_dma<true>(t + 2 < NPO ? groups : nxt.groups, t == NPO - 2 ? nxt.jump : nullptr, id, ph);
+      if (ph == 1) return;
       if constexpr (MASK) {     // behind the barrier: in flight for the rest of the panel
         m0 = *reinterpret_cast<const f32x4*>(mask_row + 32 * t + 4 * id.g);
         m1 = *reinterpret_cast<const f32x4*>(mask_row + 32 * t + 16 + 4 * id.g);

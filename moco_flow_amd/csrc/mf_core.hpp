@@ -25,6 +25,9 @@
 #define MF_F32_PD 1   // fp32 fragment prefetch distance in batches (1 or 2; 2 measured 1.3 % slower: more spills)
 #endif
 #include <stdint.h>
+#ifndef MF_F32_DMA_DELAY
+#define MF_F32_DMA_DELAY 8   // batches (8 MFMAs each) between the late half's panel barrier and its LDS-DMA pieces
+#endif
 #ifndef MF_TIMING_FLAGS
 #define MF_TIMING_FLAGS 0   // 1 (tools/build_ablate.sh): the kernels honour MF_DEBUG_FLAGS (timing ablations).
 #endif                      // Production compiles the switches out: the tests on them cost 1.5 % of the C2 kernel.
@@ -369,17 +372,25 @@ struct Stream {
   // backward chain): the wave's two youngest vector-memory operations are those stores; the VM counter
   // retires in issue order, so vmcnt(2) already guarantees the panel DMA issued before them has landed
   // and the stores stay in flight across the barrier instead of being drained at it.
+  // `ph`: 0 = the barrier half only, 1 = the DMA half only, 2 = both.  The late half of the workgroup (waves 0-3, barrier
+  // in the middle of their panel) issues its pieces MF_F32_DMA_DELAY batches behind the barrier: straight behind it the
+  // SIMD's other wave is issuing ITS pieces, and with both waves of a SIMD inside their 4-5 buffer_load ... lds at the
+  // same time (60-100+ cycles of issue each) nobody feeds the matrix pipe.
   template <bool KEEP2 = false>
-  MF_D void sync_and_dma(int groups, const char* jump, const LaneId& id) {
-    jitter();
-    if (KEEP2 && keep2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if (!(dbg & 16)) wait_vm0();
-    if (!(dbg & 1)) __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (jump) gnext = jump;
-    if (dbg & 32) dma_early_half(slot_off(2), groups, id);         // ablation: one issuing wave per SIMD
-    else if (!(dbg & 2)) dma_to(slot_off(2), groups, id);
-    else gnext += (size_t)groups * kGroupBytes;
+  MF_D void sync_and_dma(int groups, const char* jump, const LaneId& id, int ph = 2) {
+    if (ph != 1) {
+      jitter();
+      if (KEEP2 && keep2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (!(dbg & 16)) wait_vm0();
+      if (!(dbg & 1)) __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+    if (ph != 0) {
+      if (jump) gnext = jump;
+      if (dbg & 32) dma_early_half(slot_off(2), groups, id);         // ablation: one issuing wave per SIMD
+      else if (!(dbg & 2)) dma_to(slot_off(2), groups, id);
+      else gnext += (size_t)groups * kGroupBytes;
+    }
   }
   MF_D void advance() { cur = cur == 2u ? 0u : cur + 1u; }
   // cold start: the program's first two panels (same layer, `groups` each) into slots 0 and 1
@@ -523,8 +534,15 @@ MF_D void out_pair(CarryT<Pipe<BF16>::PD>& carry, const typename ActT<BF16>::T (
         nO = lds_f4(panel_lane_off + (2 * nq + 1) * kGroupBytes);
       }
 #endif
-      if (q == 0 && !late) hook();
-      if (q == Q / 2 && late) hook();
+      {
+        constexpr int QD = (Q / 2 + MF_F32_DMA_DELAY < Q) ? Q / 2 + MF_F32_DMA_DELAY : Q - 1;   // the late half's DMA batch
+        if (q == 0 && !late) hook(2);
+        if (QD == Q / 2) { if (q == Q / 2 && late) hook(2); }
+        else {
+          if (q == Q / 2 && late) hook(0);
+          if (q == QD && late) hook(1);
+        }
+      }
 #ifndef MF_ABLATE_NOLDS
       if (nq >= Q) {                                     // runs on into the next panel (after the barrier)
         nE = lds_f4(next_panel_lane_off + (2 * (nq - Q)) * kGroupBytes);
@@ -599,8 +617,8 @@ MF_D void out_pair(CarryT<Pipe<BF16>::PD>& carry, const typename ActT<BF16>::T (
       rE[sp] = lds_f4(panel_lane_off + (2 * nbp) * kGroupBytes);
       rO[sp] = lds_f4(panel_lane_off + (2 * nbp + 1) * kGroupBytes);
     }
-    if (b == 0 && !late) hook();
-    if (b == LATEQ && late) hook();
+    if (b == 0 && !late) hook(2);
+    if (b == LATEQ && late) hook(2);
     if (nbp >= Q) {
       rE[sp] = lds_f4(next_panel_lane_off + (2 * (nbp - Q)) * kGroupBytes);
       rO[sp] = lds_f4(next_panel_lane_off + (2 * (nbp - Q) + 1) * kGroupBytes);
@@ -672,7 +690,7 @@ MF_D void trunk_layer(const NetDev& net, int layer, typename ActT<BF16>::T (&act
     const uint32_t pn = st.slot_off(1) + id.lane * 16;
     const uint32_t nb = (t + 1 < NP) ? bias_off + 32 * (t + 1) * 4 : nxt.bias_off;
     // panel two ahead: same layer while t+2 < NP, else panel (t+2-NP) of the next layer
-    auto hook = [&]() { st.template sync_and_dma<DUMP>(t + 2 < NP ? groups : nxt.groups, t == NP - 2 ? nxt.jump : nullptr, id); };
+    auto hook = [&](int ph) { st.template sync_and_dma<DUMP>(t + 2 < NP ? groups : nxt.groups, t == NP - 2 ? nxt.jump : nullptr, id, ph); };
     const bool late = id.wave < kWaves / 2 && !(st.dbg & 64);
     f32x4 E, O;
     const bool prio = (st.dbg & 256) != 0;

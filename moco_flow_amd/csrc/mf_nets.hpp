@@ -55,7 +55,7 @@ MF_D void extra_layer(const NetDev& net, const typename ActT<BF16>::T (&act)[Act
     const uint32_t p = st.slot_off(0) + id.lane * 16;
     const uint32_t pn = st.slot_off(1) + id.lane * 16;
     const uint32_t nb = (t + 1 < NPO) ? bias_off + 32 * (t + 1) * 4 : nxt.bias_off;
-    auto hook = [&]() { st.template sync_and_dma<DUMP>(t + 2 < NPO ? groups : nxt.groups, t == NPO - 2 ? nxt.jump : nullptr, id); };
+    auto hook = [&](int ph) { st.template sync_and_dma<DUMP>(t + 2 < NPO ? groups : nxt.groups, t == NPO - 2 ? nxt.jump : nullptr, id, ph); };
     // hidden part through the common path (kept linear: lo = -inf), then the <= 2 extra k-quads (fp32)
     f32x4 E, O;
     out_pair<2, NK, 4, BF16>(carry, act, dummy, p, pn, nb, id.g, id.wave < kWaves / 2 && !(st.dbg & 64), hook,
