@@ -34,12 +34,18 @@ class Embedding(nn.Module):
     def descriptor(self) -> "L.mf_embedding":
         if self.N_freqs > L.MF_MAX_FREQS:
             raise NotImplementedError(f"Embedding with N_freqs={self.N_freqs} > {L.MF_MAX_FREQS} is not built")
+        fb = self.freq_bands
+        key = (id(fb), getattr(fb, "_version", 0), tuple(self.weights))      # the trainer re-assigns / edits `weights`
+        cached = self.__dict__.get("_desc_cache")
+        if cached is not None and cached[0] == key:
+            return cached[1]
         d = L.mf_embedding()
         d.in_channels = self.in_channels
         d.n_freqs = self.N_freqs
         for k in range(self.N_freqs):
-            d.freq[k] = float(self.freq_bands[k])
+            d.freq[k] = float(fb[k])
             d.weight[k] = float(self.weights[k])
+        self.__dict__["_desc_cache"] = (key, d)
         return d
 
     def forward(self, x):

@@ -18,9 +18,11 @@ class PackedWeights:
         self.buf = None
         self.desc = None
         self.keep = None   # contiguous fp32 views the descriptor points into
+        self.slots = None  # [(sub-module's _parameters dict, name)]: where the module's parameters live
 
     def invalidate(self):
         self.key = self.buf = self.desc = self.keep = None
+        self.slots = None
 
     def __getstate__(self):          # torch.save(module) / pickle: nothing cached travels
         return {}
@@ -32,7 +34,11 @@ class PackedWeights:
         return PackedWeights()
 
     def get(self, module, build_desc, bytes_fn, pack_fn, what, precision=0):
-        params = list(module.parameters())
+        # (module.parameters() walks named_modules() on every call: ~50 us per network and render pass, a tenth of a
+        #  bf16 pass; the parameter SLOTS are fixed for these module classes, the tensors in them are read afresh)
+        if self.slots is None:
+            self.slots = [(m._parameters, n) for m in module.modules() for n, p in m._parameters.items() if p is not None]
+        params = [d[n] for d, n in self.slots]
         if not params:
             raise RuntimeError(f"{what}: module has no parameters")
         dev = params[0].device

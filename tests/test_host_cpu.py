@@ -380,6 +380,43 @@ def test_packed_cache_does_not_travel():
         assert all(c.key is None and c.buf is None for c in (m._packed, m._packed_bf16, m._packed_bwd))
 
 
+def test_descriptor_and_slot_caches_follow_edits():
+    """The per-call host work of a render pass is cached (embedding descriptors, the parameter slots of the packed-weights
+    key): the caches must follow what the trainer does to these objects -- `emb.weights` re-assigned or edited in place
+    (trainer_moco_flow.py:289,301), parameters replaced -- and must survive deepcopy / pickle."""
+    import copy
+    import io
+    import moco_flow_amd as M
+    from moco_flow_amd.packing import PackedWeights
+    e = M.Embedding(3, 10)
+    d = e.descriptor()
+    assert e.descriptor() is d and d.n_freqs == 10 and d.freq[9] == 512.0 and d.weight[9] == 1.0
+    e.weights = [0.5] * 10
+    assert e.descriptor() is not d and e.descriptor().weight[3] == 0.5
+    e.weights[2] = 0.25
+    assert e.descriptor().weight[2] == 0.25
+    e.set_weights(0)
+    assert e.descriptor().weight[2] == 0.0
+    assert copy.deepcopy(e).descriptor().weight[2] == 0.0
+    buf = io.BytesIO()
+    torch.save(e, buf)
+    buf.seek(0)
+    assert torch.load(buf, weights_only=False).descriptor().n_freqs == 10
+    # parameter slots: read afresh on every call, so a replaced Parameter object is seen (the CPU device check fires
+    # with the NEW tensor's device in the message path; here: the slots list is stable and indexes the live dicts)
+    m = M.NoF(4, 128, 33, [2], "ind", 33, True)
+    c = PackedWeights()
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        c.get(m, None, None, None, "NoF")
+    n0 = len(c.slots)
+    assert n0 == len(list(m.parameters()))
+    first = m.nof_encoding_1[0]
+    first.weight = torch.nn.Parameter(torch.zeros_like(first.weight))
+    assert any(d[n] is first.weight for d, n in c.slots)
+    c.invalidate()
+    assert c.slots is None
+
+
 def test_bench_self_spawns_its_ranks():
     """`python bench.py --gpus 2` run BARE (no torch.distributed.run) starts its own two workers before touching
     the GPU; control flow on CPU with MF_BENCH_DRYRUN (gloo rendezvous on 127.0.0.1, overlapped reducer,
