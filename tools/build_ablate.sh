@@ -5,14 +5,16 @@
 # Use with  MOCOFLOW_HIP_LIB=moco_flow_amd/libmocoflow_flags.so FLAGS="0 1 2 3" bash tools/ablate.sh
 # (profiles/README.md, "Where the last 15 % ... goes").
 set -e
-cd "$(dirname "$0")/../moco_flow_amd/csrc"
+REPO=$(cd "$(dirname "$0")/.." && pwd)
+cd $REPO/moco_flow_amd/csrc
 for variant in flags ablate; do
   DEFS="-DMF_TIMING_FLAGS=1"; [ $variant = ablate ] && DEFS="$DEFS -DMF_ABLATE_NOLDS=1"
-  OBJS=""
-  for f in mf_abi mf_pack mf_forward mf_render mf_backward mf_wgrad mf_nofgrad mf_composite mf_sample mf_aux; do
-    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $DEFS -c $f.hip -o /tmp/${variant}_$f.o
-    OBJS="$OBJS /tmp/${variant}_$f.o"
+  mkdir -p /tmp/abl_$variant
+  for f in *.hip; do
+    X=""; [ $f = mf_render_bf16.hip ] && X="-fno-slp-vectorize"
+    /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $DEFS $X -c $f -o /tmp/abl_$variant/${f%.hip}.o &
   done
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $OBJS -o ../libmocoflow_$variant.so
+  wait
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/abl_$variant/*.o -o ../libmocoflow_$variant.so
   echo built ../libmocoflow_$variant.so
 done
