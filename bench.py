@@ -48,6 +48,8 @@ CONFIGS = {
                what="C2: canonical NeRF 8x256 (xyz F=10, dir F=4), fused HIP encode+MLP+composite, fp32 MFMA"),
     "C2b": dict(net="dir", precision="bf16", rays=4096, S=64, M=0, nof=None,
                 what="C2 shape in bf16 (canonical NeRF, bf16 hidden GEMMs; a kernel-tuning leg, not a BASELINE config)"),
+    "C3f": dict(net="ind", precision="f32", rays=4096, S=64, M=0, nof="local",
+                what="C3 chain in fp32 (bw NoF -> NeRF(ind) -> fw NoF, exact-fp32 MFMA; a kernel-tuning leg, not a BASELINE config)"),
     "C3": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="local",
                what="C3: bw NoF -> NeRF(ind) -> fw NoF local consensus chain, bf16 hidden GEMMs"),
     "C3g": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="global",

@@ -174,6 +174,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
         }
       }
 
+      st.tl.stamp(3, id);
       float embx[kStepsNerfXyz], ext[kStepsExtraMax];
       if (!(MF_TIMING_FLAGS && (p.dbg & 4))) emb_eval_lds<3, 10>(embx, xin, par_nerf_xyz, id.g);
       else { for (int e = 0; e < kStepsNerfXyz; ++e) embx[e] = xin[e % 3]; }
