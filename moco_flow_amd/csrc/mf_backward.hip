@@ -129,7 +129,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_backward_kernel(BwdParams p)
   const NetDev net = p.net;
   load_resident(net, id);
   Stream st;
-  CarryT<Pipe<false>::PD> carry;
+  CarryT<kPD> carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = MF_TIMING_FLAGS ? p.dbg : 0;

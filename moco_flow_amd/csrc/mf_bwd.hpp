@@ -13,7 +13,7 @@ constexpr int kBwdSigSteps = 4;   // k-steps of the optional leading block (NeRF
 // store_row (both rows in the activation dump's natural feature order, offset to this layer's slot).
 template <int MODE, int NKI, int NPO, bool MASK, bool STORE>
 MF_D void bwd_layer(const f32x4 (&in)[NKI], const float (&sig)[kBwdSigSteps], f32x4 (&out)[2 * NPO], int groups,
-                    uint32_t zero_bias, Stream& st, CarryT<Pipe<false>::PD>& carry, const LaneId& id,
+                    uint32_t zero_bias, Stream& st, CarryT<kPD>& carry, const LaneId& id,
                     const NextLayer& nxt, const float* mask_row, float* store_row) {
 #pragma unroll
   for (int t = 0; t < NPO; ++t) {
@@ -30,7 +30,7 @@ MF_D void bwd_layer(const f32x4 (&in)[NKI], const float (&sig)[kBwdSigSteps], f3
     };
     const bool late = id.wave < kWaves / 2;
     f32x4 E, O;
-    out_pair<MODE, NKI, kBwdSigSteps, false>(carry, in, sig, p, pn, zero_bias, id.g, late, hook, -__builtin_inff(), E, O);
+    out_pair<MODE, NKI, kBwdSigSteps>(carry, in, sig, p, pn, zero_bias, id.g, late, hook, -__builtin_inff(), E, O);
     if constexpr (MASK) {
 #pragma unroll
       for (int i = 0; i < 4; ++i) {

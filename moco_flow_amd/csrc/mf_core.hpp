@@ -84,7 +84,6 @@ using BlkInd2 = EmbBlock<1, 2>;     // NeRF ind, 5                    -> 2 slots
 
 constexpr int kStepsNerfXyz = round4(BlkXyz10::SLOTS);                    // 16
 constexpr int kStepsNofIn = round4(BlkXyz5::SLOTS + BlkInd16::SLOTS);     // 20
-constexpr int kStepsNofInBf16 = (kStepsNofIn + 7) & ~7;                   // 24: whole 8-slot blocks in bf16 mode
 constexpr int kStepsDir = round4(BlkDir4::SLOTS);                         // 8
 constexpr int kStepsInd = round4(BlkInd2::SLOTS);                         // 4
 constexpr int kStepsExtraMax = kStepsDir;
@@ -177,7 +176,7 @@ struct EmbParams {
 // two tiles: [tile0 k-quad 0][tile1 k-quad 0][tile0 k-quad 1] ...  (k-quad = 4 k-steps = 16 k).
 struct NetLayout {
   int W, NK, NP;           // hidden width, k-tiles (W/16), panels per W-wide layer (W/32)
-  int bf16;                // 1: hidden (W-wide) k-ranges are stored as bf16 and run on v_mfma_f32_16x16x32_bf16
+  int bf16;                // 1: the layout of the bf16 kernels (mf_bf16.hpp: 32x32x16 bf16 A fragments, one 32-row tile per panel)
   int n_trunk;             // trunk layers streamed through the generic loop (NeRF: D+1 incl. final)
   int emb_steps;           // k-steps of the embedded-input block
   int emb_split;           // bf16: every embedded k-step is TWO groups (hi = bf16(w), lo = bf16(w - hi)) -- the NoF
@@ -409,64 +408,9 @@ MF_D float lds_f(uint32_t byte_off) { return *(const float*)(smem + byte_off); }
 
 #define MF_MFMA(a, b, c) __builtin_amdgcn_mfma_f32_16x16x4f32((a), (b), (c), 0, 0, 0)
 
-#define MF_MFMA_BF16(a, b, c) \
-  __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
-
-// Activation storage of one wave (16 samples).  fp32: one f32x4 per 16-feature k-tile.
-// bf16: one u32x4 (8 bf16) per 32-feature block, holding exactly a finished panel's two
-// accumulators [E0..E3 | O0..O3] = features 32P + {4g..4g+3} and 32P + 16 + {4g..4g+3}: the
-// B operand of the 32-k step P of the next layer (weights are packed in the same k order).
-template <bool BF16> struct ActT { using T = f32x4; };
-template <> struct ActT<true> { using T = u32x4; };
-template <bool BF16, int NK> struct ActLen { static constexpr int N = BF16 ? NK / 2 : NK; };
-// fragment prefetch distance in batches: a bf16 batch is only 2 MFMAs (32 cycles), so the LDS
-// latency needs several of them; an fp32 batch is 8 MFMAs (256 cycles).
-#ifndef MF_BF16_PD
-#define MF_BF16_PD 3   // bf16 fragment prefetch distance in batches (2 / 3 / 4 measured: 0.423 / 0.419 / 0.428 ms on C2)
-#endif
-template <bool BF16> struct Pipe { static constexpr int PD = BF16 ? MF_BF16_PD : MF_F32_PD; };
-
-MF_D u32x4 pack8(const f32x4& e, const f32x4& o) {
-  bf16x8 v;
-  v[0] = (__bf16)e[0]; v[1] = (__bf16)e[1]; v[2] = (__bf16)e[2]; v[3] = (__bf16)e[3];
-  v[4] = (__bf16)o[0]; v[5] = (__bf16)o[1]; v[6] = (__bf16)o[2]; v[7] = (__bf16)o[3];
-  return __builtin_bit_cast(u32x4, v);
-}
-// bf16 mode feeds the embedded-input k-ranges to the bf16 MFMA as a two-term split  x = hi + lo
-// (hi = bf16(x), lo = bf16(x - hi): 16 mantissa bits) against weights split the same way, three products
-// per 32-k block (hi*hi + hi*lo + lo*hi): 48 matrix-pipe cycles instead of the 256 of eight exact-fp32
-// MFMAs.  The split operands replace the block's eight floats in place: [4 regs hi | 4 regs lo].
-template <int EMB>
-MF_D void emb_split_bf16(float (&emb)[EMB]) {
-  static_assert(EMB % 8 == 0, "bf16 embedded blocks are 8 slots (32 k) wide");
-#pragma unroll
-  for (int b = 0; b < EMB / 8; ++b) {
-    unsigned hb[8], lb[8];     // bf16 bit patterns (scalar conversions: no vector element inserts)
-#pragma unroll
-    for (int p = 0; p < 8; ++p) {
-      const float x = emb[8 * b + p];
-      const __bf16 h = (__bf16)x;
-      const __bf16 l = (__bf16)(x - (float)h);
-      hb[p] = __builtin_bit_cast(unsigned short, h);
-      lb[p] = __builtin_bit_cast(unsigned short, l);
-    }
-#pragma unroll
-    for (int w = 0; w < 4; ++w) {
-      emb[8 * b + w] = __builtin_bit_cast(float, hb[2 * w] | (hb[2 * w + 1] << 16));
-      emb[8 * b + 4 + w] = __builtin_bit_cast(float, lb[2 * w] | (lb[2 * w + 1] << 16));
-    }
-  }
-}
-template <int EMB>
-MF_D u32x4 emb_operand(const float (&emb)[EMB], int block, int lo) {
-  u32x4 v;
-#pragma unroll
-  for (int w = 0; w < 4; ++w) v[w] = __builtin_bit_cast(unsigned, emb[8 * block + 4 * lo + w]);
-  return v;
-}
-
-MF_D float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
-MF_D float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+// Activation storage of one wave (16 samples): one f32x4 per 16-feature k-tile.
+// Fragment prefetch distance in batches: a batch is 8 MFMAs (256 matrix cycles), one of them covers the LDS latency.
+constexpr int kPD = MF_F32_PD;
 
 // What a panel needs before its first MFMAs, pre-read during the previous panel's tail: the
 // fragment groups of its first PD batches (two tiles each) and the two tiles' bias in C/D order
@@ -491,7 +435,7 @@ struct CarryT {
 // One panel = two 16-row output tiles (E: rows 0-15, O: rows 16-31) x 16 samples:
 //   (E, O) = max(bias + W_panel * [emb ; hidden], lo)      (lo = 0: ReLU, -inf: linear)
 // MODE: 1 = embedded input only, 2 = hidden only, 3 = both (skip layers, emb first).
-// Per batch two ds_read_b128 (one group per tile) feed 8 fp32 MFMAs (or 2 bf16 MFMAs); the E
+// Per batch two ds_read_b128 (one group per tile) feed 8 fp32 MFMAs; the E
 // and O chains alternate and share every B operand, so no MFMA directly follows its own
 // predecessor and the ds_reads sit between independent MFMAs.  Groups are fetched PD batches
 // ahead through a register ring that runs on into the NEXT panel's slot, so a panel boundary
@@ -501,153 +445,71 @@ struct CarryT {
 // eight waves meet at that barrier, the two waves that share a SIMD run half a panel out of
 // phase, so one of them is always in MFMA-dense code while the other crosses a panel boundary
 // (epilogue, branches, DMA issue).
-template <int MODE, int NK, int EMB, bool BF16, class Hook>
-MF_D void out_pair(CarryT<Pipe<BF16>::PD>& carry, const typename ActT<BF16>::T (&hid)[ActLen<BF16, NK>::N],
+template <int MODE, int NK, int EMB, class Hook>
+MF_D void out_pair(CarryT<kPD>& carry, const f32x4 (&hid)[NK],
                    const float (&emb)[EMB], uint32_t panel_lane_off, uint32_t next_panel_lane_off,
                    uint32_t next_bias_off, int g, bool late, Hook&& hook, float lo, f32x4& outE, f32x4& outO,
                    bool late_prio = false) {
-  if constexpr (!BF16) {
-    // fp32: one batch (8 MFMAs) of prefetch is enough; this hand-shaped form of the loop below (two
-    // named fragment registers instead of the ring) is what hipcc allocates best (12 % faster).
-    constexpr int QE = (MODE & 1) ? EMB / 4 : 0;
-    constexpr int QH = (MODE & 2) ? NK : 0;
-    constexpr int Q = QE + QH;
-    auto bop = [&](int q, int r) -> float {
-      if (q < QE) return emb[4 * q + r];
-      else return hid[q - QE][r];
-    };
-    constexpr int PDF = Pipe<false>::PD;                 // 1 or 2 batches of fragment prefetch
-    f32x4 E = carry.bE, O = carry.bO;
-    f32x4 wE = carry.wE[0], wO = carry.wO[0];
-    f32x4 xE = carry.wE[PDF - 1], xO = carry.wO[PDF - 1];   // second pipeline stage (PDF == 2)
-    if (late_prio) __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-    for (int q = 0; q < Q; ++q) {
-      f32x4 nE = wE, nO = wO;
-      E = MF_MFMA(wE[0], bop(q, 0), E);
-      O = MF_MFMA(wO[0], bop(q, 0), O);
-      __builtin_amdgcn_sched_barrier(0);
-      const int nq = q + PDF;
-#ifndef MF_ABLATE_NOLDS      // (timing ablation builds only: keep re-using the fragments in registers)
-      if (nq < Q) {
-        nE = lds_f4(panel_lane_off + (2 * nq) * kGroupBytes);
-        nO = lds_f4(panel_lane_off + (2 * nq + 1) * kGroupBytes);
-      }
-#endif
-      {
-        constexpr int QD = (Q / 2 + MF_F32_DMA_DELAY < Q) ? Q / 2 + MF_F32_DMA_DELAY : Q - 1;   // the late half's DMA batch
-        if (q == 0 && !late) hook(2);
-        if (QD == Q / 2) { if (q == Q / 2 && late) hook(2); }
-        else {
-          if (q == Q / 2 && late) hook(0);
-          if (q == QD && late) hook(1);
-        }
-      }
-#ifndef MF_ABLATE_NOLDS
-      if (nq >= Q) {                                     // runs on into the next panel (after the barrier)
-        nE = lds_f4(next_panel_lane_off + (2 * (nq - Q)) * kGroupBytes);
-        nO = lds_f4(next_panel_lane_off + (2 * (nq - Q) + 1) * kGroupBytes);
-      }
-#endif
-      if (q + 1 >= Q) carry.load_bias(next_bias_off, g);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int r = 1; r < 4; ++r) {
-        E = MF_MFMA(wE[r], bop(q, r), E);
-        O = MF_MFMA(wO[r], bop(q, r), O);
-      }
-      __builtin_amdgcn_sched_barrier(0);
-      if constexpr (PDF == 2) {
-        wE = xE; wO = xO;
-        xE = nE; xO = nO;
-      } else {
-        wE = nE; wO = nO;
-      }
-    }
-    carry.wE[0] = wE; carry.wO[0] = wO;
-    if constexpr (PDF == 2) { carry.wE[1] = xE; carry.wO[1] = xO; }
-    if (late_prio) __builtin_amdgcn_s_setprio(0);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      outE[i] = fmaxf(E[i], lo);
-      outO[i] = fmaxf(O[i], lo);
-    }
-    return;
-  }
-  constexpr int PD = Pipe<BF16>::PD;
+  // fp32: one batch (8 MFMAs) of prefetch is enough; this hand-shaped form of the loop below (two
+  // named fragment registers instead of the ring) is what hipcc allocates best (12 % faster).
   constexpr int QE = (MODE & 1) ? EMB / 4 : 0;
-  constexpr int QH = (MODE & 2) ? ActLen<BF16, NK>::N : 0;
+  constexpr int QH = (MODE & 2) ? NK : 0;
   constexpr int Q = QE + QH;
-  static_assert(Q >= PD, "panel shorter than the fragment pipeline");
-  static_assert(!BF16 || !(MODE & 1) || EMB % 8 == 0, "bf16 embedded blocks are 8 slots wide");
-  // the late half must not read the next panel (prefetch of batch b + PD >= Q) before its barrier
-  constexpr int LATEQ = (Q / 2 < Q - PD) ? Q / 2 : Q - PD;
+  auto bop = [&](int q, int r) -> float {
+    if (q < QE) return emb[4 * q + r];
+    else return hid[q - QE][r];
+  };
+  constexpr int PDF = kPD;                 // 1 or 2 batches of fragment prefetch
   f32x4 E = carry.bE, O = carry.bO;
-  f32x4 rE[PD + 1], rO[PD + 1];
+  f32x4 wE = carry.wE[0], wO = carry.wO[0];
+  f32x4 xE = carry.wE[PDF - 1], xO = carry.wO[PDF - 1];   // second pipeline stage (PDF == 2)
+  if (late_prio) __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-  for (int i = 0; i < PD; ++i) { rE[i] = carry.wE[i]; rO[i] = carry.wO[i]; }
+  for (int q = 0; q < Q; ++q) {
+    f32x4 nE = wE, nO = wO;
+    E = MF_MFMA(wE[0], bop(q, 0), E);
+    O = MF_MFMA(wO[0], bop(q, 0), O);
+    __builtin_amdgcn_sched_barrier(0);
+    const int nq = q + PDF;
+#ifndef MF_ABLATE_NOLDS      // (timing ablation builds only: keep re-using the fragments in registers)
+    if (nq < Q) {
+      nE = lds_f4(panel_lane_off + (2 * nq) * kGroupBytes);
+      nO = lds_f4(panel_lane_off + (2 * nq + 1) * kGroupBytes);
+    }
+#endif
+    {
+      constexpr int QD = (Q / 2 + MF_F32_DMA_DELAY < Q) ? Q / 2 + MF_F32_DMA_DELAY : Q - 1;   // the late half's DMA batch
+      if (q == 0 && !late) hook(2);
+      if (QD == Q / 2) { if (q == Q / 2 && late) hook(2); }
+      else {
+        if (q == Q / 2 && late) hook(0);
+        if (q == QD && late) hook(1);
+      }
+    }
+#ifndef MF_ABLATE_NOLDS
+    if (nq >= Q) {                                     // runs on into the next panel (after the barrier)
+      nE = lds_f4(next_panel_lane_off + (2 * (nq - Q)) * kGroupBytes);
+      nO = lds_f4(next_panel_lane_off + (2 * (nq - Q) + 1) * kGroupBytes);
+    }
+#endif
+    if (q + 1 >= Q) carry.load_bias(next_bias_off, g);
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-  for (int b = 0; b < Q; ++b) {
-    const int s = b % (PD + 1);
-    const bool f32_batch = !BF16;
-    if (f32_batch) {
-      float bv;
-      if (b < QE) bv = emb[4 * b];
-      else if constexpr (!BF16) bv = hid[b - QE][0];
-      E = MF_MFMA(rE[s][0], bv, E);
-      O = MF_MFMA(rO[s][0], bv, O);
+    for (int r = 1; r < 4; ++r) {
+      E = MF_MFMA(wE[r], bop(q, r), E);
+      O = MF_MFMA(wO[r], bop(q, r), O);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (PDF == 2) {
+      wE = xE; wO = xO;
+      xE = nE; xO = nO;
     } else {
-      if constexpr (BF16) {
-        if (b < QE) {      // embedded block b/2: even batch = hi weights, odd batch = lo weights, both times x_hi first
-          const u32x4 xh = emb_operand(emb, b >> 1, 0);
-          E = MF_MFMA_BF16(rE[s], xh, E);
-          O = MF_MFMA_BF16(rO[s], xh, O);
-        } else {
-          E = MF_MFMA_BF16(rE[s], hid[b - QE], E);
-          O = MF_MFMA_BF16(rO[s], hid[b - QE], O);
-        }
-      }
+      wE = nE; wO = nO;
     }
-    __builtin_amdgcn_sched_barrier(0);
-    // fragment prefetch of batch b + PD: reads of the CURRENT panel go ahead of the barrier (the
-    // wave then sits in it with its loads in flight); reads of the NEXT panel must follow it
-    const int sp = (b + PD) % (PD + 1);
-    const int nbp = b + PD;
-    if (nbp < Q) {
-      rE[sp] = lds_f4(panel_lane_off + (2 * nbp) * kGroupBytes);
-      rO[sp] = lds_f4(panel_lane_off + (2 * nbp + 1) * kGroupBytes);
-    }
-    if (b == 0 && !late) hook(2);
-    if (b == LATEQ && late) hook(2);
-    if (nbp >= Q) {
-      rE[sp] = lds_f4(next_panel_lane_off + (2 * (nbp - Q)) * kGroupBytes);
-      rO[sp] = lds_f4(next_panel_lane_off + (2 * (nbp - Q) + 1) * kGroupBytes);
-    }
-    if (b == Q - 1) carry.load_bias(next_bias_off, g);
-    __builtin_amdgcn_sched_barrier(0);
-    if (f32_batch) {
-#pragma unroll
-      for (int r = 1; r < 4; ++r) {
-        float bv;
-        if (b < QE) bv = emb[4 * b + r];
-        else if constexpr (!BF16) bv = hid[b - QE][r];
-        E = MF_MFMA(rE[s][r], bv, E);
-        O = MF_MFMA(rO[s][r], bv, O);
-      }
-    } else if constexpr (BF16) {
-      if (b < QE && !(b & 1)) {                          // hi weights x x_lo
-        const u32x4 xl = emb_operand(emb, b >> 1, 1);
-        E = MF_MFMA_BF16(rE[s], xl, E);
-        O = MF_MFMA_BF16(rO[s], xl, O);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
   }
-#pragma unroll
-  for (int i = 0; i < PD; ++i) {
-    carry.wE[i] = rE[(Q + i) % (PD + 1)];
-    carry.wO[i] = rO[(Q + i) % (PD + 1)];
-  }
+  carry.wE[0] = wE; carry.wO[0] = wO;
+  if constexpr (PDF == 2) { carry.wE[1] = xE; carry.wO[1] = xO; }
+  if (late_prio) __builtin_amdgcn_s_setprio(0);
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     outE[i] = fmaxf(E[i], lo);
@@ -673,9 +535,9 @@ struct NextLayer {
 // `dump_row` (training forward only, DUMP instantiations): this lane's sample row of the activation
 // dump, already offset to this layer; the layer's post-activation outputs are stored there in
 // natural feature order (the dW GEMMs of the backward read them).  nullptr: nothing stored.
-template <int NK, int EMB, bool BF16, bool DUMP = false>
-MF_D void trunk_layer(const NetDev& net, int layer, typename ActT<BF16>::T (&act)[ActLen<BF16, NK>::N],
-                      const float (&emb)[EMB], Stream& st, CarryT<Pipe<BF16>::PD>& carry, const LaneId& id,
+template <int NK, int EMB, bool DUMP = false>
+MF_D void trunk_layer(const NetDev& net, int layer, f32x4 (&act)[NK],
+                      const float (&emb)[EMB], Stream& st, CarryT<kPD>& carry, const LaneId& id,
                       const NextLayer& nxt, float* dump_row = nullptr) {
   constexpr int NP = NK / 2;
   const int has_emb = (net.L.emb_mask >> layer) & 1;
@@ -683,7 +545,7 @@ MF_D void trunk_layer(const NetDev& net, int layer, typename ActT<BF16>::T (&act
   const int groups = trunk_groups(net.L, layer);
   const float lo = ((net.L.relu_mask >> layer) & 1) ? 0.f : -__builtin_inff();
   const uint32_t bias_off = net.res_lds + (net.L.off_bias_trunk + layer * net.L.W) * 4;
-  typename ActT<BF16>::T out[ActLen<BF16, NK>::N];
+  f32x4 out[NK];
 #pragma unroll
   for (int t = 0; t < NP; ++t) {
     const uint32_t p = st.slot_off(0) + id.lane * 16;
@@ -694,15 +556,11 @@ MF_D void trunk_layer(const NetDev& net, int layer, typename ActT<BF16>::T (&act
     const bool late = id.wave < kWaves / 2 && !(st.dbg & 64);
     f32x4 E, O;
     const bool prio = (st.dbg & 256) != 0;
-    if (mode == 2) out_pair<2, NK, EMB, BF16>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, E, O, prio);
-    else if (mode == 3) out_pair<3, NK, EMB, BF16>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, E, O, prio);
-    else out_pair<1, NK, EMB, BF16>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, E, O, prio);
-    if constexpr (BF16) {
-      out[t] = pack8(E, O);
-    } else {
-      out[2 * t] = E;
-      out[2 * t + 1] = O;
-    }
+    if (mode == 2) out_pair<2, NK, EMB>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, E, O, prio);
+    else if (mode == 3) out_pair<3, NK, EMB>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, E, O, prio);
+    else out_pair<1, NK, EMB>(carry, act, emb, p, pn, nb, id.g, late, hook, lo, E, O, prio);
+    out[2 * t] = E;
+    out[2 * t + 1] = O;
     if constexpr (DUMP) {
       if (dump_row) {
         *reinterpret_cast<f32x4*>(dump_row + 32 * t + 4 * id.g) = E;
@@ -713,7 +571,7 @@ MF_D void trunk_layer(const NetDev& net, int layer, typename ActT<BF16>::T (&act
     st.advance();
   }
 #pragma unroll
-  for (int t = 0; t < ActLen<BF16, NK>::N; ++t) act[t] = out[t];
+  for (int t = 0; t < NK; ++t) act[t] = out[t];
 }
 
 // VALU head: NOUT dot products of the lane's quarter of the hidden vector with natural-order
@@ -736,30 +594,6 @@ MF_D void valu_head(const f32x4 (&act)[NK], uint32_t w_byte_off, int /*row_float
       s1 = __builtin_fmaf(w[1], act[t][1], s1);
       s0 = __builtin_fmaf(w[2], act[t][2], s0);
       s1 = __builtin_fmaf(w[3], act[t][3], s1);
-    }
-    out[o] = xgroup_sum(s0 + s1) + lds_f(b_byte_off + o * 4);
-  }
-}
-
-// Same head on bf16-packed activations (unpacked on the fly; weights and accumulation fp32).
-template <int NA, int NOUT>
-MF_D void valu_head(const u32x4 (&act)[NA], uint32_t w_byte_off, int row_floats, uint32_t b_byte_off, int g,
-                    float (&out)[NOUT]) {
-#pragma unroll
-  for (int o = 0; o < NOUT; ++o) {
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int t = 0; t < NA; ++t) {
-      const f32x4 wE = lds_f4(w_byte_off + (o * row_floats + 32 * t + 4 * g) * 4);
-      const f32x4 wO = lds_f4(w_byte_off + (o * row_floats + 32 * t + 16 + 4 * g) * 4);
-      s0 = __builtin_fmaf(wE[0], bf_lo(act[t][0]), s0);
-      s1 = __builtin_fmaf(wE[1], bf_hi(act[t][0]), s1);
-      s0 = __builtin_fmaf(wE[2], bf_lo(act[t][1]), s0);
-      s1 = __builtin_fmaf(wE[3], bf_hi(act[t][1]), s1);
-      s0 = __builtin_fmaf(wO[0], bf_lo(act[t][2]), s0);
-      s1 = __builtin_fmaf(wO[1], bf_hi(act[t][2]), s1);
-      s0 = __builtin_fmaf(wO[2], bf_lo(act[t][3]), s0);
-      s1 = __builtin_fmaf(wO[3], bf_hi(act[t][3]), s1);
     }
     out[o] = xgroup_sum(s0 + s1) + lds_f(b_byte_off + o * 4);
   }

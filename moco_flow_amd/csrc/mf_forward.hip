@@ -57,7 +57,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_forward_kernel(NerfFwdParams
   NetDev net = p.net;
   load_resident(net, id);
   Stream st;
-  CarryT<Pipe<false>::PD> carry;
+  CarryT<kPD> carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = 0;
@@ -91,7 +91,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_forward_kernel(NerfFwdParams
     if constexpr (DUMP) {
       if (valid) dump_row = p.dump + b * p.dump_stride;
     }
-    nerf_eval<16, false, DUMP>(net, embx, ext, p.sigma_only != 0, st, carry, id, follow_of(net), sigma, rgb, dump_row);
+    nerf_eval<16, DUMP>(net, embx, ext, p.sigma_only != 0, st, carry, id, follow_of(net), sigma, rgb, dump_row);
     if (valid && id.g == 0) {
       if (p.sigma_only) p.out[b] = sigma;
       else *reinterpret_cast<float4*>(p.out + b * 4) = make_float4(rgb[0], rgb[1], rgb[2], sigma);
@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kThreads, 2) void nof_forward_kernel(NofFwdParams p
   NetDev net = p.net;
   load_resident(net, id);
   Stream st;
-  CarryT<Pipe<false>::PD> carry;
+  CarryT<kPD> carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = 0;
@@ -136,7 +136,7 @@ __global__ __launch_bounds__(kThreads, 2) void nof_forward_kernel(NofFwdParams p
     }
     const float xyz[3] = {p.xyz[bb * 3 + 0], p.xyz[bb * 3 + 1], p.xyz[bb * 3 + 2]};
     float o[3];
-    nof_eval<false>(net, emb, xyz, st, carry, id, follow_of(net), o);
+    nof_eval<>(net, emb, xyz, st, carry, id, follow_of(net), o);
     if (valid && id.g == 0) {
       p.out[b * 3 + 0] = o[0];
       p.out[b * 3 + 1] = o[1];
@@ -169,7 +169,7 @@ __global__ __launch_bounds__(kThreads, 2) void points_kernel(PointsParams p) {
   load_resident(p.nerf, id);
   if (NOF) load_resident(p.nof, id);
   Stream st;
-  CarryT<Pipe<false>::PD> carry;
+  CarryT<kPD> carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = 0;
@@ -187,7 +187,7 @@ __global__ __launch_bounds__(kThreads, 2) void points_kernel(PointsParams p) {
       const float ind = p.ind ? p.ind[bb] : p.ind_scalar;
       float emb[kStepsNofIn], out[3];
       nof_embed(emb, x, ind, p.nxyz, p.nind, id.g);
-      nof_eval<false>(p.nof, emb, x, st, carry, id, follow_of(p.nerf), out);
+      nof_eval<>(p.nof, emb, x, st, carry, id, follow_of(p.nerf), out);
       x[0] = out[0]; x[1] = out[1]; x[2] = out[2];
       if (valid && id.g == 0 && p.canon) {
         p.canon[b * 3 + 0] = x[0]; p.canon[b * 3 + 1] = x[1]; p.canon[b * 3 + 2] = x[2];
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(kThreads, 2) void points_kernel(PointsParams p) {
 #pragma unroll
     for (int e = 0; e < kStepsExtraMax; ++e) ext[e] = 0.f;
     float sigma, rgb[3];
-    nerf_eval<16, false>(p.nerf, embx, ext, true, st, carry, id, prog_first, sigma, rgb);
+    nerf_eval<16>(p.nerf, embx, ext, true, st, carry, id, prog_first, sigma, rgb);
     if (valid && id.g == 0) p.sigma[b] = sigma;
   }
   wait_vm0();

@@ -39,13 +39,13 @@ MF_D void start_program(const NetDev& n, Stream& st, CarryT<PD>& carry, const La
 }
 
 // extra_encoding (nerf.py:98): (W/2) outputs from [final(W) ; extra block], ReLU.
-template <int NK, bool BF16, bool DUMP = false>
-MF_D void extra_layer(const NetDev& net, const typename ActT<BF16>::T (&act)[ActLen<BF16, NK>::N],
-                      const float (&ext)[kStepsExtraMax], typename ActT<BF16>::T (&out)[ActLen<BF16, NK / 2>::N],
-                      Stream& st, CarryT<Pipe<BF16>::PD>& carry, const LaneId& id, const NextLayer& nxt,
+template <int NK, bool DUMP = false>
+MF_D void extra_layer(const NetDev& net, const f32x4 (&act)[NK],
+                      const float (&ext)[kStepsExtraMax], f32x4 (&out)[NK / 2],
+                      Stream& st, CarryT<kPD>& carry, const LaneId& id, const NextLayer& nxt,
                       float* dump_row = nullptr) {
   constexpr int NPO = NK / 4;                      // panels of the (W/2)-wide layer
-  constexpr int QH = ActLen<BF16, NK>::N;          // hidden batches in front of the extra block
+  constexpr int QH = NK;                           // hidden batches in front of the extra block
   const int groups = extra_groups(net.L);
   const int qe = net.L.extra_steps / 4;
   const uint32_t bias_off = net.res_lds + net.L.off_bias_extra * 4;
@@ -58,31 +58,17 @@ MF_D void extra_layer(const NetDev& net, const typename ActT<BF16>::T (&act)[Act
     auto hook = [&](int ph) { st.template sync_and_dma<DUMP>(t + 2 < NPO ? groups : nxt.groups, t == NPO - 2 ? nxt.jump : nullptr, id, ph); };
     // hidden part through the common path (kept linear: lo = -inf), then the <= 2 extra k-quads (fp32)
     f32x4 E, O;
-    out_pair<2, NK, 4, BF16>(carry, act, dummy, p, pn, nb, id.g, id.wave < kWaves / 2 && !(st.dbg & 64), hook,
+    out_pair<2, NK, 4>(carry, act, dummy, p, pn, nb, id.g, id.wave < kWaves / 2 && !(st.dbg & 64), hook,
                              -__builtin_inff(), E, O);
-    if constexpr (BF16) {      // one 32-k block, split operands (ext was converted by emb_split_bf16): hi*hi, hi*lo, lo*hi
-      if (qe > 0) {
-        const f32x4 hE = lds_f4(p + (2 * QH) * kGroupBytes), hO = lds_f4(p + (2 * QH + 1) * kGroupBytes);
-        const f32x4 lE = lds_f4(p + (2 * QH + 2) * kGroupBytes), lO = lds_f4(p + (2 * QH + 3) * kGroupBytes);
-        const u32x4 xh = emb_operand(ext, 0, 0), xl = emb_operand(ext, 0, 1);
-        E = MF_MFMA_BF16(hE, xh, E);
-        O = MF_MFMA_BF16(hO, xh, O);
-        E = MF_MFMA_BF16(hE, xl, E);
-        O = MF_MFMA_BF16(hO, xl, O);
-        E = MF_MFMA_BF16(lE, xh, E);
-        O = MF_MFMA_BF16(lO, xh, O);
-      }
-    } else {
 #pragma unroll
-      for (int q = 0; q < kStepsExtraMax / 4; ++q) {
-        if (q < qe) {
-          const f32x4 wE = lds_f4(p + (2 * (QH + q)) * kGroupBytes);
-          const f32x4 wO = lds_f4(p + (2 * (QH + q) + 1) * kGroupBytes);
+    for (int q = 0; q < kStepsExtraMax / 4; ++q) {
+      if (q < qe) {
+        const f32x4 wE = lds_f4(p + (2 * (QH + q)) * kGroupBytes);
+        const f32x4 wO = lds_f4(p + (2 * (QH + q) + 1) * kGroupBytes);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            E = MF_MFMA(wE[r], ext[4 * q + r], E);
-            O = MF_MFMA(wO[r], ext[4 * q + r], O);
-          }
+        for (int r = 0; r < 4; ++r) {
+          E = MF_MFMA(wE[r], ext[4 * q + r], E);
+          O = MF_MFMA(wO[r], ext[4 * q + r], O);
         }
       }
     }
@@ -91,12 +77,8 @@ MF_D void extra_layer(const NetDev& net, const typename ActT<BF16>::T (&act)[Act
       E[i] = fmaxf(E[i], 0.f);
       O[i] = fmaxf(O[i], 0.f);
     }
-    if constexpr (BF16) {
-      out[t] = pack8(E, O);
-    } else {
-      out[2 * t] = E;
-      out[2 * t + 1] = O;
-    }
+    out[2 * t] = E;
+    out[2 * t + 1] = O;
     if constexpr (DUMP) {
       if (dump_row) {
         *reinterpret_cast<f32x4*>(dump_row + 32 * t + 4 * id.g) = E;
@@ -111,19 +93,19 @@ MF_D void extra_layer(const NetDev& net, const typename ActT<BF16>::T (&act)[Act
 // Canonical NeRF on this wave's 16 samples.  `follow`: the first layer of whatever the panel
 // program evaluates after this network (the stream jumps there behind the last panel used).
 // DUMP (training forward): `dump_row` = this lane's sample row [h_0 .. h_{D-1} | final | extra] (nullptr: skip).
-template <int NK, bool BF16, bool DUMP = false>
-MF_D void nerf_eval_impl(const NetDev& net, const float (&embx)[kStepsNerfXyz], const float (&ext)[kStepsExtraMax],
-                    bool sigma_only, Stream& st, CarryT<Pipe<BF16>::PD>& carry, const LaneId& id,
+template <int NK, bool DUMP = false>
+MF_D void nerf_eval(const NetDev& net, const float (&embx)[kStepsNerfXyz], const float (&ext)[kStepsExtraMax],
+                    bool sigma_only, Stream& st, CarryT<kPD>& carry, const LaneId& id,
                     const NextLayer& follow, float& sigma, float (&rgb)[3], float* dump_row = nullptr) {
-  typename ActT<BF16>::T act[ActLen<BF16, NK>::N];
+  f32x4 act[NK];
 #pragma unroll
-  for (int t = 0; t < ActLen<BF16, NK>::N; ++t)
+  for (int t = 0; t < NK; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) act[t][i] = 0;
   const int D = net.L.n_trunk - 1;
   for (int l = 0; l < D; ++l) {
     const bool last = sigma_only && l == D - 1;
-    trunk_layer<NK, kStepsNerfXyz, BF16, DUMP>(net, l, act, embx, st, carry, id, last ? follow : next_trunk(net, l + 1),
+    trunk_layer<NK, kStepsNerfXyz, DUMP>(net, l, act, embx, st, carry, id, last ? follow : next_trunk(net, l + 1),
                                                dump_row ? dump_row + l * net.L.W : nullptr);
     st.tl.stamp(10 + l, id);
   }
@@ -136,36 +118,16 @@ MF_D void nerf_eval_impl(const NetDev& net, const float (&embx)[kStepsNerfXyz], 
   ex.groups = extra_groups(net.L);
   ex.jump = nullptr;
   ex.bias_off = net.res_lds + net.L.off_bias_extra * 4;
-  trunk_layer<NK, kStepsNerfXyz, BF16, DUMP>(net, D, act, embx, st, carry, id, ex,          // xyz_encoding_final
+  trunk_layer<NK, kStepsNerfXyz, DUMP>(net, D, act, embx, st, carry, id, ex,          // xyz_encoding_final
                                              dump_row ? dump_row + D * net.L.W : nullptr);
   st.tl.stamp(31, id);
-  typename ActT<BF16>::T e[ActLen<BF16, NK / 2>::N];
-  extra_layer<NK, BF16, DUMP>(net, act, ext, e, st, carry, id, follow, dump_row ? dump_row + (D + 1) * net.L.W : nullptr);
+  f32x4 e[NK / 2];
+  extra_layer<NK, DUMP>(net, act, ext, e, st, carry, id, follow, dump_row ? dump_row + (D + 1) * net.L.W : nullptr);
   st.tl.stamp(33, id);
   float o[3];
   valu_head(e, net.res_lds + net.L.off_rgb_w * 4, net.L.W / 2, net.res_lds + net.L.off_rgb_b * 4, id.g, o);
 #pragma unroll
   for (int c = 0; c < 3; ++c) rgb[c] = 1.f / (1.f + expf(-o[c]));   // nn.Sigmoid, nerf.py:57-59
-}
-
-// bf16 mode hands the embedded inputs over as split (hi | lo) bf16 operands (emb_split_bf16); the fp32
-// instantiations pass the caller's arrays straight through.
-template <int NK, bool BF16, bool DUMP = false>
-MF_D void nerf_eval(const NetDev& net, const float (&embx)[kStepsNerfXyz], const float (&ext)[kStepsExtraMax],
-                    bool sigma_only, Stream& st, CarryT<Pipe<BF16>::PD>& carry, const LaneId& id,
-                    const NextLayer& follow, float& sigma, float (&rgb)[3], float* dump_row = nullptr) {
-  if constexpr (BF16) {
-    float ex[kStepsNerfXyz], et[kStepsExtraMax];
-#pragma unroll
-    for (int e = 0; e < kStepsNerfXyz; ++e) ex[e] = embx[e];
-#pragma unroll
-    for (int e = 0; e < kStepsExtraMax; ++e) et[e] = ext[e];
-    emb_split_bf16(ex);
-    emb_split_bf16(et);
-    nerf_eval_impl<NK, BF16, DUMP>(net, ex, et, sigma_only, st, carry, id, follow, sigma, rgb, dump_row);
-  } else {
-    nerf_eval_impl<NK, BF16, DUMP>(net, embx, ext, sigma_only, st, carry, id, follow, sigma, rgb, dump_row);
-  }
 }
 
 // kornia 0.6.5 quaternion_log_to_exp + quaternion_to_rotation_matrix as restated in
@@ -196,32 +158,21 @@ MF_D void quat_transform(const float (&T)[9], const float (&xyz)[3], float (&out
 // Neural motion flow on this wave's 16 samples; emb = [xyz block ; ind block] (kStepsNofIn).
 // DUMP (training forward): `drow` = this lane's sample row [h_1 .. h_D | T (9 | 3) zero-padded to 16] (nullptr: skip),
 // the layout mf_nof_backward / mf_weight_grads read (mf_nofgrad.hip).
-template <bool BF16, bool DUMP = false>
+template <bool DUMP = false>
 MF_D void nof_eval(const NetDev& net, const float (&emb)[kStepsNofIn], const float (&xyz)[3], Stream& st,
-                   CarryT<Pipe<BF16>::PD>& carry, const LaneId& id, const NextLayer& follow, float (&out)[3],
+                   CarryT<kPD>& carry, const LaneId& id, const NextLayer& follow, float (&out)[3],
                    float* drow = nullptr) {
   constexpr int NK = 8;
-  typename ActT<BF16>::T act[ActLen<BF16, NK>::N];
+  f32x4 act[NK];
 #pragma unroll
-  for (int t = 0; t < ActLen<BF16, NK>::N; ++t)
+  for (int t = 0; t < NK; ++t)
 #pragma unroll
     for (int i = 0; i < 4; ++i) act[t][i] = 0;
   const int D = net.L.n_trunk;
-  if constexpr (BF16) {
-    float e24[kStepsNofInBf16];          // 20 slots padded to three 8-slot blocks, then split hi/lo in place
-#pragma unroll
-    for (int e = 0; e < kStepsNofInBf16; ++e) e24[e] = e < kStepsNofIn ? emb[e < kStepsNofIn ? e : 0] : 0.f;
-    emb_split_bf16(e24);
-    for (int l = 0; l < D; ++l) {
-      const bool last = l == D - 1;
-      trunk_layer<NK, kStepsNofInBf16, BF16>(net, l, act, e24, st, carry, id, last ? follow : next_trunk(net, l + 1));
-    }
-  } else {
-    for (int l = 0; l < D; ++l) {
-      const bool last = l == D - 1;
-      trunk_layer<NK, kStepsNofIn, BF16, DUMP>(net, l, act, emb, st, carry, id, last ? follow : next_trunk(net, l + 1),
-                                               drow ? drow + l * net.L.W : nullptr);
-    }
+  for (int l = 0; l < D; ++l) {
+    const bool last = l == D - 1;
+    trunk_layer<NK, kStepsNofIn, DUMP>(net, l, act, emb, st, carry, id, last ? follow : next_trunk(net, l + 1),
+                                       drow ? drow + l * net.L.W : nullptr);
   }
   const uint32_t wo = net.res_lds + net.L.off_head_w * 4, bo = net.res_lds + net.L.off_head_b * 4;
   float T[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

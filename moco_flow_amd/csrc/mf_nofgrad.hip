@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kThreads, 2) void nof_points_dump_kernel(NofDumpPar
   const NetDev net = p.net;
   load_resident(net, id);
   Stream st;
-  CarryT<Pipe<false>::PD> carry;
+  CarryT<kPD> carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = 0;
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(kThreads, 2) void nof_points_dump_kernel(NofDumpPar
     for (int t = 0; t < 8; ++t) act[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     st.keep2 = false;
     for (int l = 0; l < D; ++l)
-      trunk_layer<8, kStepsNofIn, false, true>(net, l, act, emb, st, carry, id,
+      trunk_layer<8, kStepsNofIn, true>(net, l, act, emb, st, carry, id,
                                                l == D - 1 ? follow_of(net) : next_trunk(net, l + 1),
                                                drow ? drow + l * kNofW : nullptr);
     const uint32_t wo = net.res_lds + net.L.off_head_w * 4, bo = net.res_lds + net.L.off_head_b * 4;
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(kThreads, 2) void nof_backward_kernel(NofBwdParams 
   const NetDev net = p.net;
   load_resident(net, id);
   Stream st;
-  CarryT<Pipe<false>::PD> carry;
+  CarryT<kPD> carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = MF_TIMING_FLAGS ? p.dbg : 0;

@@ -48,7 +48,7 @@ struct RenderParams {
 
 // inclusive product scan across the 64 lanes of a wave
 
-template <bool MOCO, bool BF16, bool DUMP>
+template <bool MOCO, bool DUMP>
 __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
   const LaneId id;
   const NetDev nerf = p.nerf;
@@ -67,7 +67,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
   const uint32_t par_nerf_xyz = p.par_off, par_nerf_ext = p.par_off + 128, par_nof_xyz = p.par_off + 256,
                  par_nof_ind = p.par_off + 384;
   Stream st;
-  CarryT<Pipe<BF16>::PD> carry;
+  CarryT<kPD> carry;
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = MF_TIMING_FLAGS ? p.dbg : 0;
@@ -155,7 +155,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
             }
             st.keep2 = false;
           }
-          nof_eval<BF16, DUMP>(net, emb, cur, st, carry, id, follow, out, nof_row);
+          nof_eval<DUMP>(net, emb, cur, st, carry, id, follow, out, nof_row);
           if constexpr (DUMP) {
             if (nof_row && id.g == 0) {
               float* q = p.dump_nof_out + nof_idx * 3;
@@ -197,7 +197,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
         if (valid && p.dump_acts) dump_row = p.dump_acts + (ray * S + si) * p.dump_stride;
       }
       st.keep2 = false;      // the first panel's barrier drains everything (see Stream::sync_and_dma)
-      nerf_eval<16, BF16, DUMP>(nerf, embx, ext, sigma_only, st, carry, id, prog_first, sigma, rgb, dump_row);
+      nerf_eval<16, DUMP>(nerf, embx, ext, sigma_only, st, carry, id, prog_first, sigma, rgb, dump_row);
       if (valid && id.g == 0) {
         sbuf[srel] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
         zbuf[srel] = z;
@@ -421,8 +421,8 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
     }
   }
   void (*kern)(RenderParams) =
-      dump ? (moco ? render_kernel<true, false, true> : render_kernel<false, false, true>)
-           : (moco ? render_kernel<true, false, false> : render_kernel<false, false, false>);
+      dump ? (moco ? render_kernel<true, true> : render_kernel<false, true>)
+           : (moco ? render_kernel<true, false> : render_kernel<false, false>);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, p);
