@@ -390,6 +390,18 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
     }
     G = best;
   }
+  // Several such ray sets per group (up to 8): the composite phase between two groups keeps at most G of the 8 waves
+  // busy and costs two workgroup barriers (~4 k cycles per 128-sample tile at G = 2: tools/timeline.py), so it should
+  // come once per several tiles -- as long as the CUs' shares stay what they were (same makespan in rays).
+  {
+    const long long cus = device_cus();
+    auto makespan = [&](long long g) { const long long groups = (a->n_rays + g - 1) / g; return (groups + cus - 1) / cus * g; };
+    const long long base = makespan(G);
+    int best = 1;
+    for (int c = 2; c <= 8; ++c)
+      if ((long long)G * c * S <= max_samples && (long long)G * c <= 64 && makespan((long long)G * c) <= base) best = c;
+    G *= best;
+  }
   p.G = G;
   p.n_groups = (a->n_rays + G - 1) / G;
   p.sbuf_off = lds; lds += (uint32_t)(G * S) * 16;
