@@ -265,7 +265,7 @@ MF_D float xgroup_sum(float v) {
 // Wavefront product scan / sum on the DPP network (row_shr 1, 2, 4, 8 inside the 16-lane rows, then row_bcast:15 and
 // row_bcast:31): six VALU steps of a few cycles each instead of six ds_bpermute round trips (~100 cycles each) per
 // scan or reduction -- the per-ray composite was 5.3 k cycles per 256-sample tile of the bf16 pass (4 % of the tile,
-// during which no wave of the workgroup feeds the matrix pipe), tools/timeline_bf16.py.
+// during which no wave of the workgroup feeds the matrix pipe), tools/timeline.py.
 template <int CTRL, int ROW_MASK>
 MF_D float dpp_f(float identity, float v) {
   return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, identity), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
