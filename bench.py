@@ -377,6 +377,21 @@ def run_config(name, a, ctx, steps, warmup, main):
                      "step_span_ms": step_span_ms, "launches_per_step": 2 if cfg["M"] else 1,
                      "flops_per_step": flops_step},
     }
+    if cfg["nof"] and reducer is None and world == 1:
+        # the same pass for a mean-only caller (the trainer's loss terms): consensus sums from mf_loss_partials instead of
+        # the compacted data-dependent-length vectors -- no host sync, so consecutive steps pipeline
+        with torch.no_grad():
+            for _ in range(warmup):
+                M.render_rays(rays, bg, models["embs"], models["nerfs"], _loss_target=gt, **kw)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(steps):
+                M.render_rays(rays, bg, models["embs"], models["nerfs"], _loss_target=gt, **kw)
+            torch.cuda.synchronize()
+            ms = (time.perf_counter() - t1) / steps * 1e3
+        res["loss_path"] = {"ms_per_step": ms, "value": n * spr / (ms * 1e-3), "unit": "ray-samples/s",
+                            "what": "render_rays(_loss_target=gt): the 12 loss partials instead of the masked consensus "
+                                    "vectors (no compaction, no host sync; INTEGRATION.md)"}
     if main and rank == 0 and world == 1 and not a.no_train_leg and cfg["precision"] == "f32":
         res["fwd_bwd"] = train_leg(M, torch, models, rays, bg, gt, kw, cfg)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -456,7 +471,7 @@ def worker(a):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic",
         "config": res["config"], "roofline": res["roofline"],
     }
-    for k in ("fwd_bwd", "cpu_baseline", "error_vs_cpu", "speedup_vs_cpu"):
+    for k in ("fwd_bwd", "cpu_baseline", "error_vs_cpu", "speedup_vs_cpu", "loss_path"):
         if k in res:
             line[k] = res[k]
     if not a.no_extra_legs and a.config == "C2":
@@ -464,7 +479,7 @@ def worker(a):
         line["configs"] = {}
         for name in legs:
             r = run_config(name, a, ctx, min(a.steps, 20), min(a.warmup, 3), main=False)
-            line["configs"][name] = {k: r[k] for k in ("value", "ms_per_step", "dtype", "config", "roofline", "error_vs_cpu") if k in r}
+            line["configs"][name] = {k: r[k] for k in ("value", "ms_per_step", "dtype", "config", "roofline", "error_vs_cpu", "loss_path") if k in r}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:
