@@ -70,11 +70,25 @@ __global__ __launch_bounds__(kLossThreads) void loss_partials_kernel(LossParams 
   }
 }
 
-__global__ void loss_finish_kernel(LossParams p, int n_blocks) {
+// One workgroup of kLossBlocks threads: thread b holds block b's 12 partials (independent loads), then a fixed tree --
+// xor-shuffles inside a wave, the waves' sums in wave order -- so the result is the same in every run.  (Twelve
+// threads walking the blocks one dependent load at a time took 24 us, longer than the partials kernel itself.)
+__global__ __launch_bounds__(kLossBlocks) void loss_finish_kernel(LossParams p, int n_blocks) {
   __shared__ double tot[kLossSlots];
+  __shared__ double red[kLossBlocks / 64][kLossSlots];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double v[kLossSlots];
+#pragma unroll
+  for (int k = 0; k < kLossSlots; ++k) v[k] = (int)threadIdx.x < n_blocks ? p.scratch[(long long)threadIdx.x * kLossSlots + k] : 0.0;
+#pragma unroll
+  for (int k = 0; k < kLossSlots; ++k) {
+    const double s = wave_sum_d(v[k]);
+    if (lane == 0) red[wave][k] = s;
+  }
+  __syncthreads();
   if (threadIdx.x < kLossSlots) {
     double s = 0.0;
-    for (int b = 0; b < n_blocks; ++b) s += p.scratch[(long long)b * kLossSlots + threadIdx.x];   // fixed order
+    for (int w = 0; w < kLossBlocks / 64; ++w) s += red[w][threadIdx.x];
     tot[threadIdx.x] = s;
   }
   __syncthreads();
@@ -124,6 +138,6 @@ extern "C" int32_t mf_loss_partials(const mf_loss_pass* coarse, const mf_loss_pa
   blocks = blocks < 1 ? 1 : (blocks > kLossBlocks ? kLossBlocks : blocks);
   hipStream_t st = static_cast<hipStream_t>(stream);
   hipLaunchKernelGGL(loss_partials_kernel, dim3(blocks), dim3(kLossThreads), 0, st, p);
-  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(64), 0, st, p, blocks);
+  hipLaunchKernelGGL(loss_finish_kernel, dim3(1), dim3(kLossBlocks), 0, st, p, blocks);
   return check_launch("mf_loss_partials");
 }
