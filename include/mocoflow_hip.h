@@ -32,7 +32,7 @@ extern "C" {
  * 9: mf_valid_rays_mask, mf_nerf_backward_x (embedded-input gradient in the chain launch), mf_embedding_backward;
  * 10: mf_nerf_forward_dump, mf_render_args.dump_nof_* (+ mf_nof_emb_slot_features), mf_smpl_lbs,
  *     mf_smpl_frame_transforms, mf_apply_vertex_transforms */
-#define MF_ABI_VERSION 10
+#define MF_ABI_VERSION 11
 
 enum {
   MF_OK = 0,
@@ -348,6 +348,14 @@ typedef struct mf_loss_pass {
 int64_t mf_loss_partials_scratch_bytes(void);
 int32_t mf_loss_partials(const mf_loss_pass* coarse, const mf_loss_pass* fine, const float* target, int64_t n_rays,
                          double* out12, void* scratch, void* stream);
+
+/* The sample depths of a pass as render_rays materialises them when something outside the fused kernel needs them
+ * (the resample, stratified jitter, the backward): z_out (N, S) = near*(1-t) + far*t, or 1/(1/near*(1-t) + 1/far*t)
+ * with use_disp (models/rendering.py:245-251; near / far = columns 6 / 7 of the ray rows, t = z_steps (S) = linspace(0,1,S));
+ * every product and sum separately rounded, bit-identical to the torch expression and to the fused pass's own z.
+ * (ABI v11) */
+int32_t mf_z_vals(const float* rays, int64_t ray_stride, int64_t n_rays, const float* z_steps, int32_t n_samples,
+                  int32_t use_disp, float* z_out, void* stream);
 
 /* ---- producers either side of the path -----------------------------
  * Camera.make_rays (utils/camera.py:134-148 with gen_ray_directions :29-50 and gen_rays :52-81):

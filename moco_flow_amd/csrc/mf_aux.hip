@@ -157,9 +157,36 @@ __global__ __launch_bounds__(256) void knn1_kernel(KnnParams p) {
   }
 }
 
+// rendering.py:245-251: z_vals (N, S) from the rays' near / far and the S linspace steps, separately rounded
+// multiplies and adds exactly as the torch expression (and as the fused pass computes them in registers)
+__global__ void z_vals_kernel(const float* rays, long long ray_stride, long long n_rays, const float* z_steps, int S,
+                              int use_disp, float* out) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rays * S) return;
+  const long long ray = i / S;
+  const int si = (int)(i - ray * S);
+  const float nearv = rays[ray * ray_stride + 6], farv = rays[ray * ray_stride + 7], t = z_steps[si];
+  float z;
+  if (!use_disp) z = nearv * (1.f - t) + farv * t;
+  else z = 1.f / (1.f / nearv * (1.f - t) + 1.f / farv * t);
+  out[i] = z;
+}
+
 }  // namespace mf
 
 using namespace mf;
+
+extern "C" int32_t mf_z_vals(const float* rays, int64_t ray_stride, int64_t n_rays, const float* z_steps, int32_t n_samples,
+                             int32_t use_disp, float* z_out, void* stream) {
+  if (n_rays < 0 || n_samples < 1 || ray_stride < 8) return fail(MF_E_INVALID, "mf_z_vals: n_rays=%lld n_samples=%d ray_stride=%lld",
+                                                                  (long long)n_rays, n_samples, (long long)ray_stride);
+  if (n_rays == 0) return MF_OK;
+  if (!rays || !z_steps || !z_out) return fail(MF_E_INVALID, "mf_z_vals: null argument");
+  const long long n = n_rays * n_samples;
+  hipLaunchKernelGGL(z_vals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), rays,
+                     (long long)ray_stride, (long long)n_rays, z_steps, n_samples, use_disp, z_out);
+  return check_launch("mf_z_vals");
+}
 
 extern "C" int32_t mf_make_rays(int32_t H, int32_t W, float focal, float cx, float cy, const float* c2w_host,
                                 float nearv, float farv, float idx, float* rays_out, void* stream) {

@@ -297,12 +297,10 @@ def render_rays(rays,
     z_steps = torch.linspace(0, 1, S, device=dev)                     # rendering.py:245
     z_vals = None
     if perturb > 0 or need_fine or grad:
-        near, far = rays[:, 6:7], rays[:, 7:8]
-        if not use_disp:
-            z_vals = near * (1 - z_steps) + far * z_steps
-        else:
-            z_vals = 1 / (1 / near * (1 - z_steps) + 1 / far * z_steps)
-        z_vals = z_vals.expand(N, S)
+        z_vals = torch.empty((N, S), device=dev, dtype=torch.float32)   # rendering.py:245-251, one launch (mf_z_vals)
+        with torch.cuda.device(dev):
+            L.check(L.lib().mf_z_vals(L.ptr(rays), rays.stride(0), N, L.ptr(z_steps), S, 1 if use_disp else 0,
+                                      L.ptr(z_vals), L.current_stream(dev)), "mf_z_vals")
         if perturb > 0:                                                # rendering.py:253-260
             z_mid = 0.5 * (z_vals[:, :-1] + z_vals[:, 1:])
             upper = torch.cat([z_mid, z_vals[:, -1:]], -1)

@@ -190,6 +190,26 @@ def test_render_rays_vs_oracle_larger(M, R, name):
     _check_result(res, {k: v.numpy() for k, v in want.items()}, c, flipped, fine_tol=3e-4)
 
 
+def test_z_vals_bit_identical_to_the_torch_expression(M):
+    """mf_z_vals (rendering.py:245-251): the (N, S) sample depths render_rays materialises for the resample / jitter /
+    backward must be the very floats of `near * (1 - t) + far * t` (and of the disparity form): they decide
+    searchsorted indices downstream.  torch.equal against the reference's own expression evaluated by torch on the GPU."""
+    import moco_flow_amd._lib as L
+    torch.manual_seed(3)
+    for N, S in ((0, 64), (1, 1), (37, 40), (600, 64), (1024, 192)):
+        rays = torch.randn(N, 9, device="cuda")
+        rays[:, 6] = 0.5 + 3.0 * torch.rand(N, device="cuda")
+        rays[:, 7] = rays[:, 6] + 0.1 + 5.0 * torch.rand(N, device="cuda")
+        t = torch.linspace(0, 1, S, device="cuda")
+        near, far = rays[:, 6:7], rays[:, 7:8]
+        for use_disp in (0, 1):
+            want = (near * (1 - t) + far * t) if not use_disp else 1 / (1 / near * (1 - t) + 1 / far * t)
+            got = torch.empty(N, S, device="cuda")
+            L.check(L.lib().mf_z_vals(L.ptr(rays), rays.stride(0), N, L.ptr(t), S, use_disp, L.ptr(got),
+                                      L.current_stream(rays.device)), "mf_z_vals")
+            assert torch.equal(got, want.expand(N, S)), (N, S, use_disp, float((got - want).abs().max()) if N else 0)
+
+
 def test_sample_pdf_indices_bit_exact(M):
     """Index parity at unit level: the search fed the golden cdf and u must
     return identical indices; samples within 1e-6."""
