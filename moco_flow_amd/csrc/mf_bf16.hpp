@@ -80,15 +80,9 @@ struct Stream {
     const int mine = (groups - id.wave + kWaves - 1) / kWaves;      // pieces of this wave: groups wave, wave + 8, ...
     pmask = (1u << (mine < 0 ? 0 : mine)) - 1u;
     gnext += (size_t)groups * kGroupBytes;
-#ifdef MF_BF_BURST
-#pragma unroll
-    for (int k = 0; k < 3; ++k)
-      if ((pmask >> k) & 1u) blds16(dsrc, id.lane * 16, k * (kWaves * kGroupBytes), ddst + k * (kWaves * kGroupBytes));
-    pmask = 0;
-#endif
   }
   MF_D void piece(int k, const Lane& id) {
-#if !defined(MF_BF_ABL_NODMA) && !defined(MF_BF_BURST)
+#ifndef MF_BF_ABL_NODMA
     if ((pmask >> k) & 1u) blds16(dsrc, id.lane * 16, k * (kWaves * kGroupBytes), ddst + k * (kWaves * kGroupBytes));
 #endif
   }
@@ -200,10 +194,6 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
     for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; acc[8 + i] = b2[i]; acc[12 + i] = b3[i]; }
   }
 #endif
-#ifdef MF_BF_ABL_TWOACC
-  f32x16 acc2;
-  for (int i = 0; i < 16; ++i) acc2[i] = 0.f;
-#endif
   u32x4 r[PD + 1];
 #pragma unroll
   for (int i = 0; i < PD; ++i) r[i] = carry.w[i];
@@ -214,10 +204,6 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
     if (ge >= 0 && ge < NEG) {
       acc = MF_MFMA32(r[s], xhi[SPLIT ? ge >> 1 : ge], acc);   // SPLIT: even: Whi * xhi ; odd: Wlo * xhi
     } else {
-#ifdef MF_BF_ABL_TWOACC
-      if (gi & 1) acc2 = MF_MFMA32(r[s], hid[EMB_FIRST ? gi - NEG : gi], acc2);
-      else
-#endif
       acc = MF_MFMA32(r[s], hid[EMB_FIRST ? gi - NEG : gi], acc);
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -243,9 +229,6 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
   }
 #pragma unroll
   for (int i = 0; i < PD; ++i) carry.w[i] = r[(NG + i) % (PD + 1)];
-#ifdef MF_BF_ABL_TWOACC
-  for (int i = 0; i < 16; ++i) acc[i] += acc2[i];
-#endif
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
 #ifdef MF_BF_ABL_NOEPI
