@@ -1,13 +1,14 @@
 #!/bin/bash
-# build/ab/lib_tl.so: the library with the phase timeline compiled in (-DMF_TIMELINE; tools/timeline.py reads it)
+# build/ab/lib_tl.so: the library with the phase timeline compiled in (-DMF_TIMELINE; tools/timeline.py reads it).
+# Other whole-library variants: MF_VARIANT_FLAGS=-DMF_DBG_JITTER MF_VARIANT_NAME=jit tools/build_timeline.sh (race screen)
 set -e
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p /tmp/tlobj $REPO/build/ab
 cd $REPO/moco_flow_amd/csrc
 for f in mf_abi mf_pack mf_forward mf_render mf_render_bf16 mf_backward mf_wgrad mf_nofgrad mf_composite mf_sample mf_aux mf_loss mf_smpl; do
   X=""; [ $f = mf_render_bf16 ] && X="-fno-slp-vectorize"
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -DMF_TIMELINE $X "$@" -c $f.hip -o /tmp/tlobj/$f.o &
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off ${MF_VARIANT_FLAGS:--DMF_TIMELINE} $X "$@" -c $f.hip -o /tmp/tlobj/$f.o &
 done
 wait
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/tlobj/*.o -o $REPO/build/ab/lib_tl.so
-ls -la $REPO/build/ab/lib_tl.so
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC /tmp/tlobj/*.o -o $REPO/build/ab/lib_${MF_VARIANT_NAME:-tl}.so
+ls -la $REPO/build/ab/lib_${MF_VARIANT_NAME:-tl}.so
