@@ -228,18 +228,34 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_backward_kernel(BwdParams p)
 // embedding.py:42-46 differentiated: g_x[c] = g_emb[c] + sum_k f_k (emb[cos_kc] g_emb[sin_kc] - emb[sin_kc] g_emb[cos_kc]),
 // emb = the embedded input itself (its sin / cos columns already carry the per-frequency weight w_k).
 struct EmbBwdParams { const float* g_emb; long long g_stride; const float* emb; long long e_stride; long long P; int C, F; float freq[16]; float* g_x; };
-__global__ void embed_backward_kernel(EmbBwdParams p) {
-  const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= p.P) return;
-  const float* g = p.g_emb + s * p.g_stride;
-  const float* e = p.emb + s * p.e_stride;
-  for (int c = 0; c < p.C; ++c) {
+// A workgroup takes 64 samples: their gradient and embedding rows go through LDS with row-contiguous (coalesced) loads --
+// one thread per sample walking its own two rows column by column re-fetched every cache line 16 times (rocprofv3: 6x the
+// algorithmic HBM bytes, 177 us for 393 k samples) -- then one thread per (sample, component) does the sum; odd LDS
+// pitch: conflict-free.
+constexpr int kEmbBwdSamples = 64;
+__global__ __launch_bounds__(256) void embed_backward_kernel(EmbBwdParams p) {
+  extern __shared__ __attribute__((aligned(16))) float eb_sm[];
+  const int ncols = p.C * (2 * p.F + 1), pitch = ncols | 1;
+  float* gs = eb_sm;
+  float* es = eb_sm + kEmbBwdSamples * pitch;
+  const long long s0 = (long long)blockIdx.x * kEmbBwdSamples;
+  const int ns = (int)((p.P - s0) < kEmbBwdSamples ? (p.P - s0) : kEmbBwdSamples);
+  for (int i = threadIdx.x; i < ns * ncols; i += blockDim.x) {
+    const int r = i / ncols, c = i - r * ncols;
+    gs[r * pitch + c] = p.g_emb[(s0 + r) * p.g_stride + c];
+    es[r * pitch + c] = p.emb[(s0 + r) * p.e_stride + c];
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < ns * p.C; i += blockDim.x) {
+    const int r = i / p.C, c = i - r * p.C;
+    const float* g = gs + r * pitch;
+    const float* e = es + r * pitch;
     float acc = g[c];
     for (int k = 0; k < p.F; ++k) {
       const int is = p.C + 2 * p.C * k + c, ic = is + p.C;
       acc += p.freq[k] * (e[ic] * g[is] - e[is] * g[ic]);
     }
-    p.g_x[s * p.C + c] = acc;
+    p.g_x[(s0 + r) * p.C + c] = acc;
   }
 }
 
@@ -323,7 +339,10 @@ extern "C" int32_t mf_embedding_backward(const mf_embedding* e, const float* g_e
   p.g_emb = g_emb; p.g_stride = g_stride; p.emb = emb; p.e_stride = e_stride; p.P = P; p.C = e->in_channels; p.F = e->n_freqs;
   for (int k = 0; k < e->n_freqs; ++k) p.freq[k] = e->weight[k] != 0.f ? e->freq[k] : 0.f;   // muted frequency: emb columns are 0 anyway
   p.g_x = g_x;
-  hipLaunchKernelGGL(embed_backward_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  const int ncols = p.C * (2 * p.F + 1);
+  const size_t lds = (size_t)2 * kEmbBwdSamples * (ncols | 1) * sizeof(float);
+  hipLaunchKernelGGL(embed_backward_kernel, dim3((unsigned)((P + kEmbBwdSamples - 1) / kEmbBwdSamples)), dim3(256), lds,
+                     static_cast<hipStream_t>(stream), p);
   return check_launch("mf_embedding_backward");
 }
 
