@@ -35,9 +35,11 @@ class Embedding(nn.Module):
         if self.N_freqs > L.MF_MAX_FREQS:
             raise NotImplementedError(f"Embedding with N_freqs={self.N_freqs} > {L.MF_MAX_FREQS} is not built")
         fb = self.freq_bands
-        key = (id(fb), getattr(fb, "_version", 0), tuple(self.weights))      # the trainer re-assigns / edits `weights`
+        key = (getattr(fb, "_version", 0), tuple(self.weights))      # the trainer re-assigns / edits `weights`
         cached = self.__dict__.get("_desc_cache")
-        if cached is not None and cached[0] == key:
+        # (`cached[2] is fb`: the cache keeps the tensor it was built from alive, so a re-assigned freq_bands can never
+        #  be mistaken for it through a recycled id())
+        if cached is not None and cached[2] is fb and cached[0] == key:
             return cached[1]
         d = L.mf_embedding()
         d.in_channels = self.in_channels
@@ -45,7 +47,7 @@ class Embedding(nn.Module):
         for k in range(self.N_freqs):
             d.freq[k] = float(fb[k])
             d.weight[k] = float(self.weights[k])
-        self.__dict__["_desc_cache"] = (key, d)
+        self.__dict__["_desc_cache"] = (key, d, fb)
         return d
 
     def forward(self, x):

@@ -397,24 +397,29 @@ def test_descriptor_and_slot_caches_follow_edits():
     assert e.descriptor().weight[2] == 0.25
     e.set_weights(0)
     assert e.descriptor().weight[2] == 0.0
+    e.freq_bands = torch.linspace(1, 512, 10)              # a re-assigned table (logscale=False spacing) is seen
+    assert abs(e.descriptor().freq[1] - float(e.freq_bands[1])) < 1e-6
+    e.freq_bands[1] = 3.0                                  # and so is an in-place edit (version counter)
+    assert e.descriptor().freq[1] == 3.0
     assert copy.deepcopy(e).descriptor().weight[2] == 0.0
     buf = io.BytesIO()
     torch.save(e, buf)
     buf.seek(0)
     assert torch.load(buf, weights_only=False).descriptor().n_freqs == 10
-    # parameter slots: read afresh on every call, so a replaced Parameter object is seen (the CPU device check fires
-    # with the NEW tensor's device in the message path; here: the slots list is stable and indexes the live dicts)
+    # the packed-weights key walks the module tree itself (no named_modules()): same tensors, same order as
+    # module.parameters(), and a replaced parameter or sub-module is seen on the next call
+    from moco_flow_amd.packing import _collect_params
+    for m in (M.NoF(4, 128, 33, [2], "ind", 33, True), M.NeRF(8, 256, 63, [4], "dir", 27)):
+        got = []
+        _collect_params(m, got)
+        assert len(got) == len(list(m.parameters())) and all(a is b for a, b in zip(got, m.parameters()))
     m = M.NoF(4, 128, 33, [2], "ind", 33, True)
-    c = PackedWeights()
+    m.nof_encoding_1 = torch.nn.Sequential(torch.nn.Linear(66, 128), torch.nn.ReLU(True))
+    got = []
+    _collect_params(m, got)
+    assert any(p is m.nof_encoding_1[0].weight for p in got)
     with pytest.raises(RuntimeError, match="no CPU implementation"):
-        c.get(m, None, None, None, "NoF")
-    n0 = len(c.slots)
-    assert n0 == len(list(m.parameters()))
-    first = m.nof_encoding_1[0]
-    first.weight = torch.nn.Parameter(torch.zeros_like(first.weight))
-    assert any(d[n] is first.weight for d, n in c.slots)
-    c.invalidate()
-    assert c.slots is None
+        PackedWeights().get(m, None, None, None, "NoF")
 
 
 def test_bench_self_spawns_its_ranks():
