@@ -113,6 +113,9 @@ SYMBOLS = {
     "mf_points_sigma": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, C.POINTER(mf_embedding), C.POINTER(mf_nof_desc), _fp,
                                     C.POINTER(mf_embedding), C.POINTER(mf_embedding), _fp, _fp, C.c_float, C.c_int64,
                                     _fp, _fp, _fp]),
+    "mf_points_sigma_p": (C.c_int32, [C.c_int32, C.POINTER(mf_nerf_desc), _fp, C.POINTER(mf_embedding), C.POINTER(mf_nof_desc), _fp,
+                                      C.POINTER(mf_embedding), C.POINTER(mf_embedding), _fp, _fp, C.c_float, C.c_int64,
+                                      _fp, _fp, _fp]),
     "mf_sample_pdf_merge": (C.c_int32, [_fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
     "mf_sample_pdf": (C.c_int32, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_int64,
                                   _fp, _fp, _fp, _fp, _fp]),

@@ -300,12 +300,39 @@ static void emb_to_params(const mf_embedding& e, EmbParams& o) {
   }
 }
 
+namespace mf {
+int points_sigma_bf16(const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz, const mf_nof_desc* nof,
+                      const void* nof_packed, const mf_embedding* nof_emb_xyz, const mf_embedding* nof_emb_ind, const float* xyz,
+                      const float* ind, float ind_scalar, int64_t B, float* sigma, float* canon, hipStream_t st);   // mf_render_bf16.hip
+}
+
 extern "C" int32_t mf_points_sigma(const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz,
                                    const mf_nof_desc* nof, const void* nof_packed, const mf_embedding* nof_emb_xyz,
                                    const mf_embedding* nof_emb_ind, const float* xyz, const float* ind,
                                    float ind_scalar, int64_t B, float* sigma, float* canon, void* stream) {
+  return mf_points_sigma_p(MF_PREC_F32, nerf, nerf_packed, emb_xyz, nof, nof_packed, nof_emb_xyz, nof_emb_ind, xyz, ind, ind_scalar, B,
+                           sigma, canon, stream);
+}
+
+extern "C" int32_t mf_points_sigma_p(int32_t precision, const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz,
+                                     const mf_nof_desc* nof, const void* nof_packed, const mf_embedding* nof_emb_xyz,
+                                     const mf_embedding* nof_emb_ind, const float* xyz, const float* ind,
+                                     float ind_scalar, int64_t B, float* sigma, float* canon, void* stream) {
   if (!nerf || !nerf_packed || !emb_xyz || (B > 0 && (!xyz || !sigma)))
     return fail(MF_E_INVALID, "mf_points_sigma: null argument");
+  if (precision != MF_PREC_F32 && precision != MF_PREC_BF16) return fail(MF_E_INVALID, "mf_points_sigma: precision %d", precision);
+  if (precision == MF_PREC_BF16) {
+    if (emb_xyz->in_channels != 3 || emb_xyz->n_freqs > 10)
+      return fail(MF_E_UNSUPPORTED, "mf_points_sigma: xyz embedding must have 3 channels and <= 10 frequencies");
+    if (nof) {
+      if (!nof_packed || !nof_emb_xyz || !nof_emb_ind) return fail(MF_E_INVALID, "mf_points_sigma: NoF arguments missing");
+      if (nof_emb_xyz->in_channels != 3 || nof_emb_xyz->n_freqs > 5 || nof_emb_ind->in_channels != 1 || nof_emb_ind->n_freqs != 16)
+        return fail(MF_E_UNSUPPORTED, "mf_points_sigma: NoF embeddings must be xyz(3, <=5 freqs) and ind(1, 16 freqs)");
+    }
+    if (B == 0) return MF_OK;
+    return points_sigma_bf16(nerf, nerf_packed, emb_xyz, nof, nof_packed, nof_emb_xyz, nof_emb_ind, xyz, ind, ind_scalar, B, sigma, canon,
+                             static_cast<hipStream_t>(stream));
+  }
   PointsParams p{};
   if (!nerf_layout(*nerf, p.nerf.L) || p.nerf.L.NK != 16)
     return fail(MF_E_UNSUPPORTED, "mf_points_sigma: unsupported NeRF configuration");

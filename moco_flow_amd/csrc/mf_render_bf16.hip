@@ -228,6 +228,73 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
   wait_vm0();   // the stream runs two panels ahead: drain the LDS-DMA before the workgroup retires
 }
 
+// sigma (and the canonical position) of free points in bf16 mode: the lattice / SMPL-point query of mf_forward.hip's
+// points_kernel (trainer_moco_flow.py:146-187, 500-526) on the 32x32x16 core -- xyz -> [bw NoF(ind)] -> encode -> NeRF
+// trunk -> sigma, 256 points per workgroup tile, nothing else written.
+struct PointsParamsBf {
+  Net nerf, bw;
+  float emb_par[4][32];            // [nerf xyz, -, nof xyz, nof ind] x (freq[16], weight[16]) -> LDS
+  const float* xyz;                // (B,3)
+  const float* ind;                // (B,) per-point image index, or null -> ind_scalar
+  float ind_scalar;
+  long long B;
+  float* sigma;                    // (B,) raw sigma
+  float* canon;                    // (B,3) or null
+  uint32_t par_off, ring_off, buf_bytes;
+  int pow2;
+};
+
+template <bool NOF>
+__global__ __launch_bounds__(kThreads, 2) void points_kernel_bf16(const PointsParamsBf p) {
+  const Lane id;
+  load_resident(p.nerf, id);
+  if (NOF) load_resident(p.bw, id);
+  if (threadIdx.x < 128) {
+    typedef const __attribute__((address_space(4))) char* kptr;
+    const kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(PointsParamsBf, emb_par);
+    *(float*)(smem + p.par_off + threadIdx.x * 4) = ((const __attribute__((address_space(4))) float*)ka)[threadIdx.x];
+  }
+  const uint32_t par_nerf_xyz = p.par_off, par_nof_xyz = p.par_off + 256, par_nof_ind = p.par_off + 384;
+  Stream st;
+  st.tl.start(nullptr, id);
+  Carry carry;
+  const Next prog_first = NOF ? first_of<8, kKsNofIn, true>(p.bw) : first_of<16, kKsNerfXyz, false>(p.nerf);
+  if (NOF) start_program<8, kKsNofIn, true>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);
+  else start_program<16, kKsNerfXyz, false>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
+  const long long ntiles = (p.B + bf::kTile - 1) / bf::kTile;
+  for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long long b = tile * bf::kTile + id.wave * kWaveSamples + id.j;
+    const bool valid = b < p.B;
+    const long long bb = valid ? b : p.B - 1;
+    float x[3] = {p.xyz[bb * 3 + 0], p.xyz[bb * 3 + 1], p.xyz[bb * 3 + 2]};
+    if (NOF) {
+      const float ind = p.ind ? p.ind[bb] : p.ind_scalar;
+      u32x4 nhi[kKsNofIn], nlo[kKsNofIn];
+      float out[3];
+      nof_embed(nhi, nlo, x, ind, par_nof_xyz, par_nof_ind, id.h, p.pow2 & 4, p.pow2 & 8);
+      nof_eval(p.bw, nhi, nlo, x, st, carry, id, first_of<16, kKsNerfXyz, false>(p.nerf), out);
+      x[0] = out[0]; x[1] = out[1]; x[2] = out[2];
+      if (valid && id.h == 0 && p.canon) {
+        p.canon[b * 3 + 0] = x[0]; p.canon[b * 3 + 1] = x[1]; p.canon[b * 3 + 2] = x[2];
+      }
+    }
+    u32x4 xe[kKsNerfXyz];
+    {
+      float embx[B2Xyz10::SLOTS];
+      emb_eval<3, 10>(embx, x, par_nerf_xyz, id.h, p.pow2 & 1);
+      pack_operands<kKsNerfXyz>(embx, B2Xyz10::SLOTS, xe);
+    }
+    auto make_extra = [&](u32x4 (&eo)[kKsExtraMax]) {          // (sigma only: the extra block is never reached)
+#pragma unroll
+      for (int k = 0; k < kKsExtraMax; ++k) eo[k] = u32x4{0u, 0u, 0u, 0u};
+    };
+    float sigma, rgb[3] = {0.f, 0.f, 0.f};
+    nerf_eval(p.nerf, xe, make_extra, true, st, carry, id, prog_first, sigma, rgb);
+    if (valid && id.h == 0) p.sigma[b] = sigma;
+  }
+  wait_vm0();
+}
+
 static bool emb_table(const mf_embedding& e, float* dst) {      // returns: frequencies are exactly 2^k
   bool pow2 = true;
   for (int k = 0; k < 16; ++k) {
@@ -316,6 +383,49 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st) {
     return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, p);
   return check_launch("mf_render_pass(bf16)");
+}
+
+// called by mf_points_sigma_p (mf_forward.hip) after argument validation, precision == MF_PREC_BF16
+int points_sigma_bf16(const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz, const mf_nof_desc* nof,
+                      const void* nof_packed, const mf_embedding* nof_emb_xyz, const mf_embedding* nof_emb_ind, const float* xyz,
+                      const float* ind, float ind_scalar, int64_t B, float* sigma, float* canon, hipStream_t st) {
+  using namespace bf;
+  PointsParamsBf p{};
+  NetLayout Ln, Lb;
+  if (!nerf_layout(*nerf, Ln, 1)) return fail(MF_E_UNSUPPORTED, "mf_points_sigma: unsupported NeRF configuration (bf16: W = 256)");
+  uint32_t lds = 0;
+  auto net_of = [&](const NetLayout& L, const void* packed, int D, int aux) {
+    Net n;
+    n.packed = static_cast<const char*>(packed);
+    n.res_lds = lds;
+    n.res_bytes = (uint32_t)L.res_bytes;
+    n.D = D;
+    n.emb_mask = L.emb_mask;
+    n.aux = aux;
+    lds += (uint32_t)L.res_bytes;
+    return n;
+  };
+  p.nerf = net_of(Ln, nerf_packed, Ln.n_trunk - 1, Ln.extra_steps);
+  int max_groups = Ln.max_groups;
+  p.pow2 = emb_table(*emb_xyz, p.emb_par[0]) ? 1 : 0;
+  if (nof) {
+    if (!nof_layout(*nof, Lb, 1)) return fail(MF_E_UNSUPPORTED, "mf_points_sigma: unsupported NoF configuration");
+    p.bw = net_of(Lb, nof_packed, Lb.n_trunk, Lb.n_head);
+    if (Lb.max_groups > max_groups) max_groups = Lb.max_groups;
+    p.pow2 |= (emb_table(*nof_emb_xyz, p.emb_par[2]) ? 4 : 0) | (emb_table(*nof_emb_ind, p.emb_par[3]) ? 8 : 0);
+  }
+  p.par_off = lds; lds += 512;
+  p.ring_off = lds;
+  p.buf_bytes = (uint32_t)max_groups * kGroupBytes;
+  lds += 3 * p.buf_bytes;
+  p.xyz = xyz; p.ind = ind; p.ind_scalar = ind_scalar; p.B = B; p.sigma = sigma; p.canon = canon;
+  const long long ntiles = (B + bf::kTile - 1) / bf::kTile;
+  const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
+  void (*kern)(const PointsParamsBf) = nof ? points_kernel_bf16<true> : points_kernel_bf16<false>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(MF_E_LAUNCH, "mf_points_sigma: cannot reserve %u bytes of LDS", lds);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, p);
+  return check_launch("mf_points_sigma(bf16)");
 }
 
 }  // namespace mf

@@ -8,24 +8,29 @@ import torch
 from . import _lib as L
 
 
-def query_sigma(xyz, nerf, nerf_embedding_xyz, bw_nof=None, nof_embeddings=None, ind=None, return_canonical=False):
+def query_sigma(xyz, nerf, nerf_embedding_xyz, bw_nof=None, nof_embeddings=None, ind=None, return_canonical=False,
+                precision=None):
     """xyz (B,3) observation-space points -> raw sigma (B,1) of the canonical NeRF.
 
     bw_nof / nof_embeddings=[xyz, ind] / ind: optional backward flow at image index ``ind`` (a python
     float in [-1,1) for all points, or a (B,) / (B,1) tensor); without them the query is made in
-    canonical space (visualize_mesh with frame_idx == -1). Inference only."""
+    canonical space (visualize_mesh with frame_idx == -1). Inference only.
+    ``precision``: "f32" | "bf16" (None = the module setting of ``rendering.set_precision``); bf16 = hidden GEMMs on the
+    bf16 matrix pipe as in render_rays' gradient-free passes (the mesh-extraction lattice ~8x faster)."""
+    from . import rendering
+    prec = L.MF_PREC_BF16 if (precision or rendering.PRECISION) == "bf16" else L.MF_PREC_F32
     L.require_gpu(xyz, "query_sigma")
     x = xyz.detach().float().contiguous()
     B = x.shape[0]
     dev = x.device
     sigma = torch.empty((B, 1), device=dev, dtype=torch.float32)
     canon = torch.empty((B, 3), device=dev, dtype=torch.float32) if (return_canonical and bw_nof is not None) else None
-    nd, nb = nerf.packed()
+    nd, nb = nerf.packed(prec)
     ex = nerf_embedding_xyz.descriptor()
     fd = fb = fx = fi = None
     ind_t, ind_s = None, 0.0
     if bw_nof is not None:
-        fd, fb = bw_nof.packed()
+        fd, fb = bw_nof.packed(prec)
         fx, fi = nof_embeddings[0].descriptor(), nof_embeddings[1].descriptor()
         if torch.is_tensor(ind):
             ind_t = ind.detach().float().reshape(-1).contiguous().to(dev)
@@ -36,8 +41,8 @@ def query_sigma(xyz, nerf, nerf_embedding_xyz, bw_nof=None, nof_embeddings=None,
         else:
             ind_s = float(ind)
     with torch.cuda.device(dev):
-        L.check(L.lib().mf_points_sigma(nd, nb.data_ptr(), C.byref(ex), fd, L.ptr(fb),
-                                        C.byref(fx) if fx is not None else None,
-                                        C.byref(fi) if fi is not None else None, L.ptr(x), L.ptr(ind_t), ind_s, B,
-                                        L.ptr(sigma), L.ptr(canon), L.current_stream(dev)), "mf_points_sigma")
+        L.check(L.lib().mf_points_sigma_p(prec, nd, nb.data_ptr(), C.byref(ex), fd, L.ptr(fb),
+                                          C.byref(fx) if fx is not None else None,
+                                          C.byref(fi) if fi is not None else None, L.ptr(x), L.ptr(ind_t), ind_s, B,
+                                          L.ptr(sigma), L.ptr(canon), L.current_stream(dev)), "mf_points_sigma")
     return (sigma, canon) if return_canonical else sigma
