@@ -17,7 +17,7 @@
 // that share every B operand).  A workgroup is 8 waves = 128 samples, two waves per SIMD at
 // <= 256 registers each: while one wave is in a prologue / epilogue / barrier, its SIMD
 // partner keeps the matrix pipe busy.  The 8 waves share the weight stream, which is DMA'd
-// global->LDS (global_load_lds_dwordx4) in "panels" (32 output rows of one layer), running
+// global->LDS (buffer_load_dwordx4 ... lds, see blds16) in "panels" (32 output rows of one layer), running
 // two panels ahead of the MFMAs in a 3-slot ring.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -221,13 +221,9 @@ MF_HD int extra_groups(const NetLayout& L) {
 // ------------------------------------------------------------------ device helpers
 extern __shared__ __attribute__((aligned(16))) char smem[];
 
-MF_D void glds16(const char* g, uint32_t lds_off) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)g,
-                                   (__attribute__((address_space(3))) void*)(smem + lds_off), 16, 0, 0);
-}
-// The same transfer through a buffer descriptor (buffer_load_dwordx4 ... offen lds): wave-uniform base address in
-// SGPRs + ONE per-lane VGPR offset (lane * 16) + a scalar offset, instead of a 64-bit address per lane.  This is the
-// form the weight streams use.  Measured on the bf16 trunk prototype (tools/proto/bf16_trunk2.hip, MI355X): 57 -> 74 %
+// LDS-DMA (global -> LDS without registers, 16 bytes per lane) through a buffer descriptor
+// (buffer_load_dwordx4 ... offen lds): wave-uniform base address in SGPRs + ONE per-lane VGPR offset (lane * 16) + a
+// scalar offset -- not global_load_lds with its 64-bit address per lane.  Measured on the bf16 trunk prototype (tools/proto/bf16_trunk2.hip, MI355X): 57 -> 74 %
 // of the bf16 matrix peak from this change alone, for two reasons: (i) no v_lshl_add_u64 per piece and no 64 address
 // pairs through the address path; (ii) global_load_lds is FLAT-encoded, and with a FLAT operation that may touch LDS
 // pending, hipcc's waitcnt pass treats the LGKM counter as out of order and turns EVERY fragment wait into
@@ -332,7 +328,7 @@ struct Timeline {
 #endif
 };
 
-// Weight-panel stream: a 3-slot LDS ring fed by LDS-DMA (global_load_lds_dwordx4), running
+// Weight-panel stream: a 3-slot LDS ring fed by LDS-DMA (blds16), running
 // TWO panels ahead of the MFMAs.  While panel c is being multiplied, panel c+1 is already
 // complete and visible (so its first fragments and bias can be pre-read during c's tail: no
 // exposed LDS latency at a panel boundary) and panel c+2 is in flight.  One workgroup barrier
