@@ -1,0 +1,56 @@
+"""Compile-time properties the performance claims rest on (README / DESIGN): the fused inference kernels hold everything in
+registers -- no VGPR spills, no scratch -- and the weight streams use the buffer form of the LDS-DMA.  Checked by compiling
+the two translation units for gfx950 with hipcc's resource-usage remarks (no GPU needed; ~1 min, both units in parallel)."""
+import os
+import re
+import shutil
+import subprocess
+from concurrent.futures import ThreadPoolExecutor
+
+import pytest
+
+CSRC = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "moco_flow_amd", "csrc")
+HIPCC = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "--cuda-device-only",
+         "-Rpass-analysis=kernel-resource-usage", "-S", "-o"]
+
+
+def _compile(unit, extra):
+    out = f"/tmp/mf_props_{os.getpid()}_{unit}.s"
+    r = subprocess.run([HIPCC] + FLAGS + [out] + extra + [unit + ".hip"], cwd=CSRC, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    asm = open(out).read()
+    os.remove(out)
+    usage = {}
+    name = None
+    for line in r.stderr.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+            usage[name] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z ]+?)(?: \[bytes/lane\])?: (\d+)", line)
+        if m and name:
+            usage[name][m.group(1).strip()] = int(m.group(2))
+    return usage, asm
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
+def test_inference_kernels_have_no_spills_and_stream_weights_by_buffer_dma():
+    with ThreadPoolExecutor(2) as ex:
+        f32 = ex.submit(_compile, "mf_render", [])
+        b16 = ex.submit(_compile, "mf_render_bf16", ["-fno-slp-vectorize"])      # csrc/Makefile builds this unit so
+        (u32, a32), (u16, a16) = f32.result(), b16.result()
+    # render_kernel<MOCO, DUMP>: the two inference instantiations (DUMP = false) and every bf16 kernel
+    want = [k for k in u32 if re.search(r"render_kernelILb[01]ELb0EE", k)] + \
+           [k for k in u16 if "render_kernel_bf16" in k or "points_kernel_bf16" in k]
+    assert len(want) == 2 + 4, sorted(list(u32) + list(u16))
+    for k in want:
+        u = {**u32, **u16}[k]
+        assert u["VGPRs Spill"] == 0 and u["ScratchSize"] == 0, (k, u)
+        assert u["VGPRs"] <= 256, (k, u)
+    for asm in (a32, a16):
+        assert "global_load_lds" not in asm                       # FLAT-encoded LDS-DMA: forces lgkmcnt(0) waits
+        assert len(re.findall(r"buffer_load_dwordx4 .* lds", asm)) > 50
+    # the bf16 unit must hold no packed-fp32 VALU op (run-to-run differences on MI355X, csrc/Makefile)
+    assert not re.search(r"v_pk_(mul|fma|add)_f32", a16)
