@@ -383,7 +383,19 @@ MF_D void valu_head(const u32x4 (&act)[KH], uint32_t w_byte_off, uint32_t b_byte
 // Embedding parameters live in LDS (par_off: freq[16] then weight[16], floats): this kernel keeps its SGPRs for
 // addresses.  dst[0..SLOTS) of block (C,F) for lane half h; arg = freq*x rounded to fp32 before sin/cos exactly as
 // `func(freq*x)` in embedding.py:45.
-template <int C, int F>
+// sin / cos of an angle in radians on the transcendental unit: v_sin_f32 / v_cos_f32 take REVOLUTIONS in [-256, 256], so
+// the angle is scaled by 1/(2 pi) and reduced with v_fract_f32.  Error: the fp32 rounding of the scaled angle, |rev| x
+// 6e-8 revolutions (2e-4 rad at the NeRF's largest argument, 512 x 6 / 2 pi = 490 revolutions; 1e-6 rad where the angle
+// stays under a few revolutions) -- an order of magnitude under the 4e-3 of the bf16 operands the values become.  Four
+// instructions per pair against ~110 for OCML's sincosf with its exact range reduction: on a power-bound pass
+// the VALU work saved is worth more than the cycles.
+MF_D void sincos_rev(float rad, float& sn, float& cs) {
+  const float f = __builtin_amdgcn_fractf(rad * 0.15915494309189535f);
+  sn = __builtin_amdgcn_sinf(f);
+  cs = __builtin_amdgcn_cosf(f);
+}
+
+template <int C, int F, bool HW = false>
 MF_D void emb_eval_direct(float* dst, const float (&v)[C], uint32_t par_off, int h) {
   using B = EmbBlock2<C, F>;
 #pragma unroll
@@ -411,7 +423,10 @@ MF_D void emb_eval_direct(float* dst, const float (&v)[C], uint32_t par_off, int
     const bool live = lds_f(par_off + 64 + 4 * f0) != 0.f || (real1 && lds_f(par_off + 64 + 4 * f1) != 0.f);
     float sn = 0.f, cs = 0.f;
 #ifndef MF_BF_ABL_NOSINCOS
-    if (__builtin_amdgcn_readfirstlane((int)live)) sincosf(fr * x, &sn, &cs);
+    if (__builtin_amdgcn_readfirstlane((int)live)) {
+      if (HW) sincos_rev(fr * x, sn, cs);
+      else sincosf(fr * x, &sn, &cs);
+    }
 #else
     sn = fr * x; cs = fr - x;
 #endif
@@ -427,11 +442,17 @@ MF_D void emb_eval_direct(float* dst, const float (&v)[C], uint32_t par_off, int
 // An exact sincosf re-seeds each chain every third entry, so no value is more than two quadruplings (four doublings:
 // <= 16 x the 1e-7 of the seed, 2e-6) from an exact one -- an order of magnitude under the 2^-16 of the split bf16
 // operands the values are rounded to.  6 sincosf instead of 15 per NeRF encoding and lane, 6 instead of 18 per NoF input.
-template <int C, int F>
+// HW: every pair straight from the transcendental unit (sincos_rev) -- the blocks whose values become plain bf16 operands
+// or whose arguments stay small (NeRF xyz / dir / ind, NoF xyz); the NoF's image-index block (arguments up to 2^15, split
+// operands) keeps the exact seeds + doubling chains.
+template <int C, int F, bool HW = false>
 MF_D void emb_eval(float* dst, const float (&v)[C], uint32_t par_off, int h, bool pow2) {
   using B = EmbBlock2<C, F>;
 #ifdef MF_BF_ABL_NODOUBLING
   pow2 = false;
+#endif
+#ifndef MF_BF_NO_HWSIN
+  if (HW) { emb_eval_direct<C, F, true>(dst, v, par_off, h); return; }
 #endif
   if (!pow2) { emb_eval_direct<C, F>(dst, v, par_off, h); return; }
   float cs_[C], sn_[C];                                    // the chains' current (cos, sin)
@@ -628,7 +649,7 @@ MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofIn], const u32x4 (&x
 MF_D void nof_embed(u32x4 (&xhi)[kKsNofIn], u32x4 (&xlo)[kKsNofIn], const float (&xyz)[3], float ind, uint32_t par_xyz,
                     uint32_t par_ind, int h, bool pow2_xyz, bool pow2_ind) {
   float emb[B2Xyz5::SLOTS + B2Ind16::SLOTS];
-  emb_eval<3, 5>(emb, xyz, par_xyz, h, pow2_xyz);
+  emb_eval<3, 5, true>(emb, xyz, par_xyz, h, pow2_xyz);
   const float iv[1] = {ind};
   emb_eval<1, 16>(emb + B2Xyz5::SLOTS, iv, par_ind, h, pow2_ind);
   split_operands<kKsNofIn>(emb, B2Xyz5::SLOTS + B2Ind16::SLOTS, xhi, xlo);

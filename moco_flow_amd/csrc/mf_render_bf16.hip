@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
       {
         float embx[B2Xyz10::SLOTS];
         jitter();
-        emb_eval<3, 10>(embx, xin, par_nerf_xyz, id.h, p.pow2 & 1);
+        emb_eval<3, 10, true>(embx, xin, par_nerf_xyz, id.h, p.pow2 & 1);
         pack_operands<kKsNerfXyz>(embx, B2Xyz10::SLOTS, xe);
       }
       auto make_extra = [&](u32x4 (&eo)[kKsExtraMax]) {
@@ -142,10 +142,10 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
         for (int e = 0; e < 8 * kKsExtraMax; ++e) ext[e] = 0.f;
         if (p.extra_type == MF_EXTRA_DIR) {
           const float dd[3] = {rp[3], rp[4], rp[5]};
-          emb_eval<3, 4>(ext, dd, par_nerf_ext, id.h, p.pow2 & 2);                         // rendering.py:138-142
+          emb_eval<3, 4, true>(ext, dd, par_nerf_ext, id.h, p.pow2 & 2);                         // rendering.py:138-142
         } else if (p.extra_type == MF_EXTRA_IND) {
           const float iv[1] = {rp[8]};
-          emb_eval<1, 2>(ext, iv, par_nerf_ext, id.h, p.pow2 & 2);                         // rendering.py:133-137
+          emb_eval<1, 2, true>(ext, iv, par_nerf_ext, id.h, p.pow2 & 2);                         // rendering.py:133-137
         }
         pack_operands<kKsExtraMax>(ext, 8 * kKsExtraMax, eo);
       };
@@ -281,7 +281,7 @@ __global__ __launch_bounds__(kThreads, 2) void points_kernel_bf16(const PointsPa
     u32x4 xe[kKsNerfXyz];
     {
       float embx[B2Xyz10::SLOTS];
-      emb_eval<3, 10>(embx, x, par_nerf_xyz, id.h, p.pow2 & 1);
+      emb_eval<3, 10, true>(embx, x, par_nerf_xyz, id.h, p.pow2 & 1);
       pack_operands<kKsNerfXyz>(embx, B2Xyz10::SLOTS, xe);
     }
     auto make_extra = [&](u32x4 (&eo)[kKsExtraMax]) {          // (sigma only: the extra block is never reached)
