@@ -19,7 +19,7 @@
 // products hi*hi + hi*lo + lo*hi (16 mantissa bits): its output POINT feeds sin(512 x) of the canonical NeRF's
 // encoding.  The NeRF's own encodings are plain bf16 operands like every hidden range (SPLIT = false): measured on the
 // C2 shape the split bought 0.1 dB (61.15 vs 61.00 dB against the fp32 oracle -- the rounding of the 63 O(1) inputs is
-// one more layer's worth of activation rounding) for 10 % more matrix instructions, and the pass is power-bound
+// one more layer's worth of activation rounding) for 10 % more matrix instructions, and the pass is throttled by its own activity
 // (DESIGN.md).  Accumulation, biases, the sigma / rgb / NoF heads and the composite stay fp32.
 #pragma once
 #include "mf_nets.hpp"
@@ -387,7 +387,7 @@ MF_D void valu_head(const u32x4 (&act)[KH], uint32_t w_byte_off, uint32_t b_byte
 // the angle is scaled by 1/(2 pi) and reduced with v_fract_f32.  Error: the fp32 rounding of the scaled angle, |rev| x
 // 6e-8 revolutions (2e-4 rad at the NeRF's largest argument, 512 x 6 / 2 pi = 490 revolutions; 1e-6 rad where the angle
 // stays under a few revolutions) -- an order of magnitude under the 4e-3 of the bf16 operands the values become.  Four
-// instructions per pair against ~110 for OCML's sincosf with its exact range reduction: on a power-bound pass
+// instructions per pair against ~110 for OCML's sincosf with its exact range reduction: on a pass whose clock drops with its activity
 // the VALU work saved is worth more than the cycles.
 MF_D void sincos_rev(float rad, float& sn, float& cs) {
   const float f = __builtin_amdgcn_fractf(rad * 0.15915494309189535f);
