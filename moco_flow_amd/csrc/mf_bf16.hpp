@@ -169,20 +169,19 @@ MF_D unsigned pk_floor_bf16(unsigned x, unsigned floor) {
 // NGE = embedded 16-slot k-steps (SPLIT: each is the groups hi, lo and the MFMAs Whi*xhi, Whi*xlo, Wlo*xhi; else one
 // group, one MFMA), KHID = hidden k-steps.
 // The A fragments are fetched PD groups ahead through a register ring that runs on into the NEXT panel's slot.
-// `hook` = the panel's barrier + DMA of the panel two ahead: behind the first group for the early half of the
-// workgroup (waves 4-7), in the middle of the panel for the late half (waves 0-3), so the two waves of a SIMD
-// run half a panel out of phase.  The accumulators start as the bias (four ds_reads straight into the C operand: no
+// `hook` = the panel's barrier + DMA of the panel two ahead, behind the first group; its pieces go into the three MFMA
+// gaps that follow.  (No half-panel stagger of the SIMD partners here, unlike the fp32 core: this pass does not gain from
+// hidden stalls -- DESIGN.md -- and the second barrier position cost 4 % in scalar bookkeeping and branches.)
+// The accumulators start as the bias (four ds_reads straight into the C operand: no
 // VALU, no extra registers; the SIMD's other wave covers their latency) and the epilogue is 8 packed converts + 8
 // packed integer max per tile.
 template <int NGE, int KHID, bool EMB_FIRST, bool SPLIT, class Hook, class Piece>
 MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4* xlo, uint32_t p, uint32_t pn,
-                   uint32_t bias_off, int h, bool late, Hook&& hook, Piece&& piece, unsigned floor, u32x4& out0, u32x4& out1) {
+                   uint32_t bias_off, int h, Hook&& hook, Piece&& piece, unsigned floor, u32x4& out0, u32x4& out1) {
   constexpr int NEG = (SPLIT ? 2 : 1) * NGE;            // groups of the embedded block
   constexpr int NG = NEG + KHID;
   static_assert(NG > PD, "panel shorter than the fragment pipeline");
-  constexpr int LATEQ0 = (NG / 2 < NG - PD) ? NG / 2 : NG - PD;  // the late half must not read the next panel early
-  constexpr int LATEQ = LATEQ0 + 3 < NG ? LATEQ0 : NG - 4;       // ... and needs three MFMA gaps behind its barrier
-  static_assert(LATEQ >= 0 && NG >= 4, "panel too short for the DMA pieces");
+  static_assert(NG >= 4, "panel too short for the DMA pieces");
   f32x16 acc;
 #ifdef MF_BF_ABL_NOBIAS
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -213,11 +212,8 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
 #else
     r[sp] = r[s];
 #endif
-    {
-      const int hp = late ? LATEQ : 0;                       // (uniform) position of this wave's barrier
-      if (gi == hp) hook();
-      if (gi > hp && gi <= hp + 3) piece(gi - hp - 1);
-    }
+    if (gi == 0) hook();
+    if (gi >= 1 && gi <= 3) piece(gi - 1);
 #ifndef MF_BF_ABL_NOFRAG
     if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
 #endif
@@ -248,11 +244,9 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
 
 // Head tile (NoF 3|9-row head): acc = bias + (Whi + Wlo) * hidden, raw fp32 accumulators (rows (r&3)+8(r>>2)+4h).
 template <int KHID, class Hook, class Piece>
-MF_D f32x16 head_tile(Carry& carry, const u32x4* hid, uint32_t p, uint32_t pn, uint32_t bias_off, int h, bool late, Hook&& hook,
+MF_D f32x16 head_tile(Carry& carry, const u32x4* hid, uint32_t p, uint32_t pn, uint32_t bias_off, int h, Hook&& hook,
                       Piece&& piece) {
   constexpr int NG = 2 * KHID;
-  constexpr int LATEQ0 = (NG / 2 < NG - PD) ? NG / 2 : NG - PD;
-  constexpr int LATEQ = LATEQ0 + 3 < NG ? LATEQ0 : NG - 4;
   f32x16 acc;
   {
     const f32x4 b0 = lds_f4(bias_off + (0 + 4 * h) * 4), b1 = lds_f4(bias_off + (8 + 4 * h) * 4);
@@ -270,11 +264,8 @@ MF_D f32x16 head_tile(Carry& carry, const u32x4* hid, uint32_t p, uint32_t pn, u
     __builtin_amdgcn_sched_barrier(0);
     const int sp = (gi + PD) % (PD + 1), nb = gi + PD;
     if (nb < NG) r[sp] = lds_u4(p + nb * kGroupBytes);
-    {
-      const int hp = late ? LATEQ : 0;
-      if (gi == hp) hook();
-      if (gi > hp && gi <= hp + 3) piece(gi - hp - 1);
-    }
+    if (gi == 0) hook();
+    if (gi >= 1 && gi <= 3) piece(gi - 1);
     if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
     __builtin_amdgcn_sched_barrier(0);
   }
@@ -294,11 +285,6 @@ MF_D void trunk_layer_m(const Net& net, int layer, bool relu, const u32x4 (&act)
   const int groups = tgroups<KH, NGE, SPLIT>(net, layer);
   const unsigned lo = relu ? 0u : 0x80008000u;      // ReLU / pass-through floor
   const uint32_t bias_off = net.res_lds + layer * (16 * KH) * 4;
-#if !defined(MF_BF_ABL_NOSTAGGER)
-  const bool late = id.wave < kWaves / 2;
-#else
-  const bool late = false;
-#endif
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const uint32_t p = st.slot_off(0) + id.lane * 16;
@@ -309,7 +295,7 @@ MF_D void trunk_layer_m(const Net& net, int layer, bool relu, const u32x4 (&act)
               t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id);
     };
     auto piece = [&](int k) { st.piece(k, id); };
-    out_tile<(MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, true, SPLIT>(carry, act, xhi, xlo, p, pn, bias_off + 32 * t * 4, id.h, late,
+    out_tile<(MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, true, SPLIT>(carry, act, xhi, xlo, p, pn, bias_off + 32 * t * 4, id.h,
                                                                hook, piece, lo, out[2 * t], out[2 * t + 1]);
     st.advance();
   }
@@ -545,7 +531,6 @@ MF_D void extra_layer(const Net& net, const u32x4 (&act)[16], const u32x4* ex, u
   constexpr int NT = 4;
   const int groups = 16 + NGX;
   const uint32_t bias_off = net.res_lds + (net.D + 1) * 256 * 4;
-  const bool late = id.wave < kWaves / 2;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const uint32_t p = st.slot_off(0) + id.lane * 16;
@@ -555,7 +540,7 @@ MF_D void extra_layer(const Net& net, const u32x4 (&act)[16], const u32x4* ex, u
               t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id);
     };
     auto piece = [&](int k) { st.piece(k, id); };
-    out_tile<NGX, 16, false, false>(carry, act, ex, ex, p, pn, bias_off + 32 * t * 4, id.h, late, hook, piece, 0u, out[2 * t], out[2 * t + 1]);
+    out_tile<NGX, 16, false, false>(carry, act, ex, ex, p, pn, bias_off + 32 * t * 4, id.h, hook, piece, 0u, out[2 * t], out[2 * t + 1]);
     st.advance();
   }
 }
@@ -621,13 +606,8 @@ MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofIn], const u32x4 (&x
     // panel two ahead of the head panel = the SECOND panel of whatever follows
     auto hook = [&]() { st.sync(follow.groups2, follow.jump2, id); };
     auto piece = [&](int k) { st.piece(k, id); };
-#ifndef MF_BF_ABL_NOSTAGGER
-    const bool late = id.wave < kWaves / 2;
-#else
-    const bool late = false;
-#endif
     // resident block: [bias_trunk D 128 | head_w n_head 128 | head_b 32]
-    acc = head_tile<8>(carry, act, p, pn, net.res_lds + (D + net.aux) * 128 * 4, id.h, late, hook, piece);
+    acc = head_tile<8>(carry, act, p, pn, net.res_lds + (D + net.aux) * 128 * 4, id.h, hook, piece);
     st.advance();
   }
   float own[5], oth[5];
