@@ -1591,3 +1591,66 @@ def test_smpl_full_size_vs_oracle(M):
     assert m(pose_t[:0].cuda(), betas_t[:0].cuda()).shape == (0, 6890, 3)
     with pytest.raises(RuntimeError):
         m(pose_t[:, :10].cuda(), betas_t.cuda())
+
+
+# (kept last in the file: a failed stream capture can leave the process unable to run further GPU work)
+@pytest.mark.parametrize("mode", ["bf16_inference", "f32_training"])
+def test_pass_and_training_step_replay_in_a_hip_graph(M, mode):
+    """With the loss fast path nothing in a pass synchronises with the host: a gradient-free pass and a whole training step
+    (HIP forward with dumps, mf_loss_partials, the HIP backward nodes) capture into a torch.cuda.CUDAGraph and replay
+    bit for bit (outputs / every parameter gradient).  Guards against a host sync, a pageable copy or a launch on a
+    foreign stream creeping into the path."""
+    from moco_flow_amd import rendering, synth, losses
+    c = dict(RENDER_CASES["r_moco_global_fine"])
+    n = 512
+    rays_np, bg_np = synth.rays(0, n, chained=True)
+    rays, bg = torch.from_numpy(rays_np).cuda(), torch.from_numpy(bg_np).cuda()
+    gt = torch.rand(n, 3, device="cuda")
+    embs, nerfs, kw = build_case(M, c, 0, device="cuda")
+    kw = dict(kw, perturb=0, noise_std=0)
+    params = [p for m in list(nerfs) + list(kw["nof_models"]) for p in m.parameters()]
+    train = mode == "f32_training"
+    strict = rendering.STRICT_RNG
+
+    def step():
+        if train:
+            res = M.render_rays(rays, bg, embs, nerfs, _loss_target=gt, **kw)
+            t = losses.from_partials(res["loss_partials"])
+            (t["img_loss"] + 0.1 * (t["nof_local"] + t["nof_global"])).backward()
+            return res
+        with torch.no_grad():
+            return M.render_rays(rays, bg, embs, nerfs, _loss_target=gt, **kw)
+
+    def clear():
+        for p in params:
+            p.grad = None
+
+    try:
+        rendering.STRICT_RNG = False
+        rendering.set_precision("f32" if train else "bf16")
+        clear()
+        ref = step()
+        ref = {k: v.detach().clone() for k, v in ref.items() if torch.is_tensor(v)}
+        ref_g = [p.grad.clone() for p in params] if train else []
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(2):
+                clear()
+                step()
+        torch.cuda.current_stream().wait_stream(s)
+        clear()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            out = step()
+        for _ in range(2):
+            g.replay()
+        torch.cuda.synchronize()
+        for k, v in ref.items():
+            assert torch.equal(out[k].detach(), v), k
+        for p, q in zip(params, ref_g):
+            assert torch.equal(p.grad, q)
+    finally:
+        rendering.set_precision("f32")
+        rendering.STRICT_RNG = strict
+        clear()
