@@ -85,7 +85,9 @@ class OverlappedLossReducer:
         self.work = [None] * depth
         self.group = group
         self.i = 0
-        self.active = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        # an initialised process group is used at ANY world size (a 1-rank group still issues the collective through
+        # RCCL: tests/rccl_child.py runs exactly that on one GPU); without a group the pushes are plain copies
+        self.active = dist.is_available() and dist.is_initialized()
 
     def push(self, partials: torch.Tensor, collect: bool = False) -> Optional[torch.Tensor]:
         k = self.i % len(self.bufs)

@@ -1,5 +1,7 @@
 import os
+import subprocess
 import sys
+import tempfile
 
 import pytest
 
@@ -9,9 +11,41 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
+# the 1-rank RCCL child (tests/rccl_child.py): {"proc": Popen, "log": path} once started
+RCCL_CHILD = {}
+
+
+def _gpu_run_selected(config):
+    """-m gpu (or no marker filter at all) on a box that has a device.  torch.cuda.device_count() does not
+    initialise the GPU on this image; torch.cuda.is_available() would."""
+    expr = config.getoption("-m") or ""
+    if "not gpu" in expr:
+        return False
+    try:
+        import torch
+        return torch.cuda.device_count() > 0
+    except Exception:  # pragma: no cover
+        return False
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # Start the RCCL child NOW, while this process has not touched the GPU: a process that has initialised the GPU
+    # must not exec another program on the GPU pool, and every later point of a -m gpu session is behind such a call.
+    if _gpu_run_selected(config) and not os.environ.get("MF_NO_RCCL_CHILD") and not hasattr(config, "workerinput"):
+        log = tempfile.NamedTemporaryFile(prefix="mf_rccl_child_", suffix=".log", delete=False)
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        RCCL_CHILD["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_child.py")],
+                                              stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
+        RCCL_CHILD["log"] = log.name
+        log.close()
+
+
+def pytest_unconfigure(config):
+    p = RCCL_CHILD.get("proc")
+    if p is not None and p.poll() is None:       # the exact process we started
+        p.kill()
 
 
 def pytest_collection_modifyitems(config, items):
@@ -28,3 +62,8 @@ def pytest_collection_modifyitems(config, items):
     for item in items:
         if "gpu" in item.keywords:
             item.add_marker(skip)
+
+
+@pytest.fixture(scope="session")
+def rccl_child():
+    return RCCL_CHILD

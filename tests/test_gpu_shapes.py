@@ -1,0 +1,194 @@
+"""GPU parity at the sizes and shapes the reference actually runs (-m gpu):
+* BASELINE config C2 at full size (4096 rays x 64 samples, canonical NeRF dir/27, fp32) against the oracle;
+* the reference's own training shapes -- the joint MoCo stage (configs/people_snapshot/male-3-casual/c2f.yaml:34-41,
+  105-109: S = 128, M = 128, NeRF(ind/5), quaternion NoFs, local + global chains, perturb = 1.0) and stage 1
+  (init_nerf.yaml:29-36: S = 128, M = 128, NeRF(dir/27), xyz N_freqs = 0, softplus, perturb = 1.0) -- on a ray slice
+  the oracle finishes in seconds, in TRAINING mode (gradients recorded: the dumping kernels are the ones checked);
+* the 1-rank RCCL leg (tests/rccl_child.py, started by conftest.py before this process touched the GPU).
+Bars: 1e-4 max-rel (north_star) unless a comment says why not."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+from cases import RENDER_CASES
+from helpers import build_case, relerr
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+
+
+@pytest.fixture(scope="module")
+def M():
+    import moco_flow_amd
+    assert torch.cuda.is_available()
+    moco_flow_amd._lib.lib()          # fail loudly if the HIP library is missing
+    return moco_flow_amd
+
+
+@pytest.fixture(scope="module")
+def R():
+    from oracle import cpu_ref
+    return cpu_ref
+
+
+def test_c2_full_size_fp32_vs_oracle(M, R):
+    """BASELINE config C2 (the headline workload of bench.py, its weight draw and its ray generator): every per-ray
+    output of the one fused launch against the oracle at 4096 x 64, 1e-4 max-rel."""
+    from moco_flow_amd import synth
+    c = dict(RENDER_CASES["r_nerf_dir_dense"])
+    tags = dict(coarse="nerf")
+    rays_np, bg_np = synth.rays(0, 4096)
+    rays, bg = torch.from_numpy(rays_np), torch.from_numpy(bg_np)
+    embs_o, nerfs_o, kw_o = build_case(R, c, 0, tags=tags)
+    embs, nerfs, kw = build_case(M, c, 0, device="cuda", tags=tags)
+    cap = {}
+    with torch.no_grad():
+        res = M.render_rays(rays.cuda(), bg.cuda(), embs, nerfs, _capture=cap, **kw)
+        cap_o = {}
+        want = R.render_rays(rays, bg, embs_o, nerfs_o, _capture=cap_o, **kw_o)
+    assert sorted(res) == sorted(want) == ["depth_coarse", "opacity_coarse", "rgb_coarse"]
+    for k in want:
+        assert res[k].shape == want[k].shape
+        e = relerr(res[k], want[k])
+        print(f"C2 full size {k}: max-rel {e:.2e}")
+        assert e <= TOL, (k, e)
+    for k in ("weights_coarse", "alphas_coarse"):
+        assert relerr(cap[k], cap_o[k]) <= TOL, k
+    # the opacity spans (0, 1): the dense regime is not a degenerate all-0 / all-1 batch
+    op = want["opacity_coarse"]
+    assert float(op.min()) < 0.2 and float(op.max()) > 0.8
+
+
+def _draws(n, S, Mi, seed=11):
+    gen = torch.Generator().manual_seed(seed)
+    return dict(perturb_rand=torch.rand(n, S, generator=gen), u=torch.rand(n, Mi, generator=gen))
+
+
+def _with_grads(nets):
+    for m in nets:
+        for k in m.p:
+            m.p[k] = m.p[k].clone().requires_grad_(True)
+
+
+C2F = dict(n=256, S=128, M=128, extra="ind", regime="dense", nof="global")
+STAGE1 = dict(n=256, S=128, M=128, extra="dir", regime="dense", act="softplus", xyz_freqs=0)
+
+
+def test_c2f_training_shape_vs_oracle(M, R):
+    """Joint MoCo stage shape (c2f.yaml: 128 coarse + 128 importance samples, two NeRF(ind), bw / fw quaternion NoFs,
+    local + global chains, perturb = 1.0) on 256 of its 1024 rays, in training mode: the values come from the DUMPING
+    forward (`render_kernel<true, true>`), both passes.  The stratified jitter and the stochastic resample take
+    injected draws; the fine pass is compared on the HIP path's own fine depths (rendering.py:323 detaches them)."""
+    from moco_flow_amd import synth
+    c = dict(C2F)
+    n, S, Mi = c["n"], c["S"], c["M"]
+    rays_np, bg_np = synth.rays(11, n, chained=True)
+    rays, bg = torch.from_numpy(rays_np), torch.from_numpy(bg_np)
+    rng = _draws(n, S, Mi)
+    embs_o, nerfs_o, kw_o = build_case(R, c, 11)
+    embs, nerfs, kw = build_case(M, c, 11, device="cuda")
+    for k_ in (kw, kw_o):
+        k_.update(perturb=1.0, noise_std=0.0)
+    cap = {}
+    res = M.render_rays(rays.cuda(), bg.cuda(), embs, nerfs, _rng={k: v.cuda() for k, v in rng.items()}, _capture=cap, **kw)
+    assert res["rgb_fine"].requires_grad and res["nof_global_disp_fine"].requires_grad     # training graph attached
+    assert cap["z_fine"].shape == (n, S + Mi)
+    cap_o = {}
+    with torch.no_grad():
+        want = R.render_rays(rays, bg, embs_o, nerfs_o, _rng=rng, _z_fine_override=cap["z_fine"].cpu(), _capture=cap_o, **kw_o)
+    assert list(res.keys()) == list(want.keys())
+    assert relerr(cap["z_coarse"], cap_o["z_coarse"]) <= 1e-6
+    # seed 11: neither pass is degenerate (mean opacity 0.46 coarse / 0.33 fine, masks neither empty nor full)
+    assert 0.1 < float(want["opacity_coarse"].mean()) < 0.9 and 0.1 < float(want["opacity_fine"].mean()) < 0.9
+    worst = 0.0
+    for k, v in want.items():
+        got = res[k].detach()
+        if k.startswith("nof_"):
+            # alpha >= 0.01 can flip for an alpha within an ulp of 0.01: lengths agree to a couple of entries
+            assert abs(got.shape[0] - v.shape[0]) <= max(2, int(0.002 * v.shape[0])), (k, got.shape, v.shape)
+            if got.shape[0] == v.shape[0]:
+                e = relerr(got, v)
+            else:
+                e = abs(float(got.mean()) - float(v.mean())) / abs(float(v.mean()))
+        else:
+            assert got.shape == v.shape, k
+            e = relerr(got, v)
+        print(f"c2f shape (training forward) {k}: max-rel {e:.2e}")
+        worst = max(worst, e)
+        assert e <= TOL, (k, e)
+    # the step is trainable end to end at this shape: every parameter of the five networks receives a finite gradient
+    loss = M.get_loss(dict(type="MSE"))(res, torch.rand(n, 3, device="cuda"))
+    for key in ("nof_local_disp", "nof_global_disp"):
+        loss = loss + 0.2 * (res[key + "_coarse"].mean() + res[key + "_fine"].mean())
+    loss.backward()
+    for m in list(nerfs) + list(kw["nof_models"]):
+        for name, p in m.named_parameters():
+            assert p.grad is not None and bool(torch.isfinite(p.grad).all()), name
+
+
+def test_stage1_training_shape_vs_oracle(M, R):
+    """Stage 1 shape (init_nerf.yaml: 128 + 128 samples, NeRF(dir/27) with the xyz encoding at N_freqs = 0 zero-padded
+    to 63 columns, softplus densities, perturb = 1.0) on 256 of its 5120 rays: training-mode forward 1e-4 against the
+    oracle, and the END-TO-END gradients of the reference's loss (MSE coarse + fine, models/losses.py:4-14) against the
+    oracle's CPU autograd on the same depths, 1e-4 max-rel per parameter tensor (NeRF-only passes are well conditioned)."""
+    from moco_flow_amd import synth
+    c = dict(STAGE1)
+    n, S, Mi = c["n"], c["S"], c["M"]
+    rays_np, bg_np = synth.rays(4, n)
+    rays, bg = torch.from_numpy(rays_np), torch.from_numpy(bg_np)
+    gt = torch.rand(n, 3, generator=torch.Generator().manual_seed(1))
+    rng = _draws(n, S, Mi)
+    embs_o, nerfs_o, kw_o = build_case(R, c, 4)
+    embs, nerfs, kw = build_case(M, c, 4, device="cuda")
+    assert embs[0].N_freqs == 0 and embs[0].out_channels == 3
+    for k_ in (kw, kw_o):
+        k_.update(perturb=1.0, noise_std=0.0)
+    cap = {}
+    res = M.render_rays(rays.cuda(), bg.cuda(), embs, nerfs, _rng={k: v.cuda() for k, v in rng.items()}, _capture=cap, **kw)
+    M.get_loss(dict(type="MSE"))(res, gt.cuda()).backward()
+    _with_grads(nerfs_o)
+    want = R.render_rays(rays, bg, embs_o, nerfs_o, _rng=rng, _z_fine_override=cap["z_fine"].cpu(), **kw_o)
+    loss_o = ((want["rgb_coarse"] - gt) ** 2).mean() + ((want["rgb_fine"] - gt) ** 2).mean()
+    flat = [(i, k) for i, m in enumerate(nerfs_o) for k in m.p]
+    grads = torch.autograd.grad(loss_o, [nerfs_o[i].p[k] for i, k in flat], allow_unused=True)
+    for k, v in want.items():
+        e = relerr(res[k].detach(), v.detach())
+        print(f"stage-1 shape (training forward) {k}: max-rel {e:.2e}")
+        assert e <= TOL, (k, e)
+    checked, worst = 0, (0.0, "")
+    for (i, k), g in zip(flat, grads):
+        p = dict(nerfs[i].named_parameters())[k]
+        if g is None:
+            assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
+            continue
+        # layer 0 sees 3 live input columns of 63: the 60 padded columns carry an exactly-zero gradient on both sides
+        e = relerr(p.grad, g)
+        worst = max(worst, (e, f"{i}.{k}"))
+        assert e <= TOL, (i, k, e)
+        checked += 1
+    print(f"stage-1 shape: end-to-end gradients vs oracle autograd, worst max-rel {worst[0]:.2e} at {worst[1]} ({checked} tensors)")
+    assert checked == 2 * 24
+
+
+def test_rccl_one_rank_child(rccl_child):
+    """BASELINE config C4's collective leg on one GPU (trainer/base.py:104-106): tests/rccl_child.py -- a 1-rank "nccl"
+    (RCCL) process group, 50 MoCo bf16 steps whose loss partials go through OverlappedLossReducer's real all-reduce Work
+    objects under torch's sync-debug "error" mode -- was started by conftest.py before this process touched the GPU."""
+    p = rccl_child.get("proc")
+    assert p is not None, "conftest.py did not start tests/rccl_child.py (MF_NO_RCCL_CHILD set?)"
+    try:
+        rc = p.wait(timeout=600)
+    except Exception:
+        p.kill()
+        raise
+    log = open(rccl_child["log"]).read()
+    print(log[-3000:])
+    assert rc == 0, log[-3000:]
+    line = [ln for ln in log.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["ok"] and out["backend"] == "nccl" and out["world"] == 1
+    assert out["steps"] == 50 and out["mismatching_steps"] == 0
+    assert all("Done" not in t for t in out["work_types"]), out["work_types"]
