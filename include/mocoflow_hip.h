@@ -31,8 +31,10 @@ extern "C" {
  * 7: mf_nof_forward_dump; 8: mf_loss_partials, new packed layout of MF_PREC_BF16 (32x32x16 fragments);
  * 9: mf_valid_rays_mask, mf_nerf_backward_x (embedded-input gradient in the chain launch), mf_embedding_backward;
  * 10: mf_nerf_forward_dump, mf_render_args.dump_nof_* (+ mf_nof_emb_slot_features), mf_smpl_lbs,
- *     mf_smpl_frame_transforms, mf_apply_vertex_transforms */
-#define MF_ABI_VERSION 11
+ *     mf_smpl_frame_transforms, mf_apply_vertex_transforms
+ * 12: MF_PREC_BF16 NoF takes its image-index block as a per-ray fp32 bias: mf_render_args.workspace(+_bytes),
+ *     mf_render_workspace_bytes, mf_points_sigma_workspace_bytes, workspace arguments of mf_points_sigma_p */
+#define MF_ABI_VERSION 12
 
 enum {
   MF_OK = 0,
@@ -235,7 +237,12 @@ int32_t mf_points_sigma(const mf_nerf_desc* nerf, const void* nerf_packed, const
 int32_t mf_points_sigma_p(int32_t precision, const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz,
                           const mf_nof_desc* nof, const void* nof_packed, const mf_embedding* nof_emb_xyz,
                           const mf_embedding* nof_emb_ind, const float* xyz, const float* ind,
-                          float ind_scalar, int64_t B, float* sigma, float* canon, void* stream);
+                          float ind_scalar, int64_t B, float* sigma, float* canon, void* workspace,
+                          int64_t workspace_bytes, void* stream);
+/* Bytes of `workspace` the bf16 query needs when a NoF is given (ABI v12): the per-point (ind array) or single
+ * (ind_scalar) fp32 bias  b_l + W_l[:, 33:66] emb(ind)  of the NoF layers that consume the embedded input -- in bf16 mode
+ * the image index does not go through the matrix pipe (see mf_render_args.workspace).  0 for MF_PREC_F32 / no NoF. */
+int64_t mf_points_sigma_workspace_bytes(int32_t precision, const mf_nof_desc* nof, int32_t per_point_ind, int64_t B);
 
 /* ---- one rendering pass: nof_inference* + nerf_inference of models/rendering.py:49-192 as
  * called from render_rays (rendering.py:262-314 coarse, 329-373 fine) -------------------- */
@@ -300,9 +307,16 @@ typedef struct mf_render_args {
   float* dump_nof_emb;
   float* dump_nof_out;
   int32_t dump_nof_plane[5];
+  /* MF_PREC_BF16 with NoF (ABI v12): caller-allocated device scratch of mf_render_workspace_bytes(a) bytes.  It receives,
+   * per ray and (network, image index) combination of the chain program, the fp32 vectors  b_l + W_l[:, 33:66] emb(ind)
+   * of the NoF layers that consume the embedded input (models/rendering.py:73-75, models/nof.py:69-73: the index block
+   * is constant along a ray), written by a small launch in front of the fused one and read by it as the accumulators'
+   * initial values.  Ignored (may be NULL) otherwise. */
+  void* workspace; int64_t workspace_bytes;
 } mf_render_args;
 
 int32_t mf_render_pass(const mf_render_args* a, void* stream);
+int64_t mf_render_workspace_bytes(const mf_render_args* a);
 
 /* Column map of mf_render_args.dump_nof_emb: features80[c] = column of the NoF's embedded input ([xyz 33 | ind 33])
  * stored at dump column c, or -1 (zero).  Host-side, no stream. */

@@ -16,7 +16,7 @@ MF_EXTRA_NONE, MF_EXTRA_IND, MF_EXTRA_DIR = 0, 1, 2
 MF_ACT_RELU, MF_ACT_SOFTPLUS = 0, 1
 MF_F_SIGMA_ONLY, MF_F_CHAIN_LOCAL, MF_F_CHAIN_GLOBAL = 1, 2, 4
 MF_PREC_F32, MF_PREC_BF16 = 0, 1
-MF_ABI_VERSION = 11
+MF_ABI_VERSION = 12
 
 LIB_PATH = os.environ.get("MOCOFLOW_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmocoflow_hip.so")   # (override: A/B builds)
 
@@ -75,7 +75,8 @@ class mf_render_args(C.Structure):
                 ("disp_local", _fp), ("disp_global", _fp), ("precision", C.c_int32),
                 ("dump_acts", _fp), ("dump_stride", C.c_int64), ("dump_rgbsigma", _fp), ("dump_xyz", _fp),
                 ("dump_nof_acts", _fp), ("dump_nof_stride", C.c_int64), ("dump_nof_emb", _fp), ("dump_nof_out", _fp),
-                ("dump_nof_plane", C.c_int32 * 5)]
+                ("dump_nof_plane", C.c_int32 * 5),
+                ("workspace", _fp), ("workspace_bytes", C.c_int64)]
 
 
 # every symbol include/mocoflow_hip.h declares: (restype, argtypes)
@@ -110,12 +111,14 @@ SYMBOLS = {
     "mf_weight_grads": (C.c_int32, [C.POINTER(mf_wgrad_item), C.c_int32, C.c_int64, _fp, _fp]),
     "mf_nerf_backward": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, C.c_int64, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp]),
     "mf_render_pass": (C.c_int32, [C.POINTER(mf_render_args), _fp]),
+    "mf_render_workspace_bytes": (C.c_int64, [C.POINTER(mf_render_args)]),
+    "mf_points_sigma_workspace_bytes": (C.c_int64, [C.c_int32, C.POINTER(mf_nof_desc), C.c_int32, C.c_int64]),
     "mf_points_sigma": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, C.POINTER(mf_embedding), C.POINTER(mf_nof_desc), _fp,
                                     C.POINTER(mf_embedding), C.POINTER(mf_embedding), _fp, _fp, C.c_float, C.c_int64,
                                     _fp, _fp, _fp]),
     "mf_points_sigma_p": (C.c_int32, [C.c_int32, C.POINTER(mf_nerf_desc), _fp, C.POINTER(mf_embedding), C.POINTER(mf_nof_desc), _fp,
                                       C.POINTER(mf_embedding), C.POINTER(mf_embedding), _fp, _fp, C.c_float, C.c_int64,
-                                      _fp, _fp, _fp]),
+                                      _fp, _fp, _fp, C.c_int64, _fp]),
     "mf_sample_pdf_merge": (C.c_int32, [_fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
     "mf_sample_pdf": (C.c_int32, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_int64,
                                   _fp, _fp, _fp, _fp, _fp]),

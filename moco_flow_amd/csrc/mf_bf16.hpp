@@ -175,9 +175,12 @@ MF_D unsigned pk_floor_bf16(unsigned x, unsigned floor) {
 // The accumulators start as the bias (four ds_reads straight into the C operand: no
 // VALU, no extra registers; the SIMD's other wave covers their latency) and the epilogue is 8 packed converts + 8
 // packed integer max per tile.
-template <int NGE, int KHID, bool EMB_FIRST, bool SPLIT, class Hook, class Piece>
+// RB (the NoF's embedded-input layers): the accumulators start from `rb` = this lane's 16 rows of the per-ray vector
+// b + W[:, ind columns] emb(ind) (nof_raybias_kernel; C/D order: rb[4q + i] = row 8q + 4h + i) instead of the LDS bias.
+template <int NGE, int KHID, bool EMB_FIRST, bool SPLIT, bool RB, class Hook, class Piece>
 MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4* xlo, uint32_t p, uint32_t pn,
-                   uint32_t bias_off, int h, Hook&& hook, Piece&& piece, unsigned floor, u32x4& out0, u32x4& out1) {
+                   uint32_t bias_off, const f32x16& rb, int h, Hook&& hook, Piece&& piece, unsigned floor, u32x4& out0,
+                   u32x4& out1) {
   constexpr int NEG = (SPLIT ? 2 : 1) * NGE;            // groups of the embedded block
   constexpr int NG = NEG + KHID;
   static_assert(NG > PD, "panel shorter than the fragment pipeline");
@@ -186,7 +189,9 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
 #ifdef MF_BF_ABL_NOBIAS
   for (int i = 0; i < 16; ++i) acc[i] = 0.f;
 #else
-  {                                                       // C/D order: reg 4q + i <- bias[8q + 4h + i]
+  if constexpr (RB) {
+    acc = rb;
+  } else {                                                // C/D order: reg 4q + i <- bias[8q + 4h + i]
     const f32x4 b0 = lds_f4(bias_off + (0 + 4 * h) * 4), b1 = lds_f4(bias_off + (8 + 4 * h) * 4);
     const f32x4 b2 = lds_f4(bias_off + (16 + 4 * h) * 4), b3 = lds_f4(bias_off + (24 + 4 * h) * 4);
 #pragma unroll
@@ -278,9 +283,15 @@ MF_D f32x16 head_tile(Carry& carry, const u32x4* hid, uint32_t p, uint32_t pn, u
 // MODE: 1 = embedded input only (layer 0), 2 = hidden only, 3 = both (skip layers, embedded input first).  A template
 // parameter, not a switch inside the tile loop: the register file is full here and every control-flow merge inside
 // the unrolled tile sequence costs copies.
-template <int KH, int NGE, int MODE, bool SPLIT>
+// RB: the layer's accumulators start from the per-ray bias `rb` (one f32x4[4] per tile, see out_tile).
+struct RayBias { f32x16 t[4]; };    // per tile of a 128-wide layer: the accumulators' initial value (whole vectors: a
+                                    // f32x4[16] read back as f32x16 defeats SROA and lands in scratch)
+struct NoRayBias {};
+template <int KH, int NGE, int MODE, bool SPLIT, class RBT = NoRayBias>
 MF_D void trunk_layer_m(const Net& net, int layer, bool relu, const u32x4 (&act)[KH], u32x4 (&out)[KH], const u32x4 (&xhi)[NGE],
-                        const u32x4 (&xlo)[NGE], Stream& st, Carry& carry, const Lane& id, const Next& nxt) {
+                        const u32x4 (&xlo)[NGE], Stream& st, Carry& carry, const Lane& id, const Next& nxt, const RBT& rb) {
+  constexpr bool RB = !__is_same(RBT, NoRayBias);
+  static_assert(!RB || KH == 8, "per-ray bias: 128-wide layers (4 tiles)");
   constexpr int NT = KH / 2;
   const int groups = tgroups<KH, NGE, SPLIT>(net, layer);
   const unsigned lo = relu ? 0u : 0x80008000u;      // ReLU / pass-through floor
@@ -295,36 +306,74 @@ MF_D void trunk_layer_m(const Net& net, int layer, bool relu, const u32x4 (&act)
               t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id);
     };
     auto piece = [&](int k) { st.piece(k, id); };
-    out_tile<(MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, true, SPLIT>(carry, act, xhi, xlo, p, pn, bias_off + 32 * t * 4, id.h,
-                                                               hook, piece, lo, out[2 * t], out[2 * t + 1]);
+    if constexpr (RB && (MODE & 1)) {
+      out_tile<NGE, (MODE & 2) ? KH : 0, true, SPLIT, true>(carry, act, xhi, xlo, p, pn, 0u, rb.t[t < 4 ? t : 0], id.h, hook, piece, lo,
+                                                            out[2 * t], out[2 * t + 1]);
+    } else {
+      const f32x16 none = {};
+      out_tile<(MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, true, SPLIT, false>(carry, act, xhi, xlo, p, pn, bias_off + 32 * t * 4, none,
+                                                                             id.h, hook, piece, lo, out[2 * t], out[2 * t + 1]);
+    }
     st.advance();
   }
 }
 
 // in -> out (two register sets: the callers alternate them from layer to layer, so no layer ends in a 64-register copy)
-template <int KH, int NGE, bool SPLIT>
+template <int KH, int NGE, bool SPLIT, class RBT = NoRayBias>
 MF_D void trunk_layer(const Net& net, int layer, bool relu, const u32x4 (&act)[KH], u32x4 (&out)[KH], const u32x4 (&xhi)[NGE],
-                      const u32x4 (&xlo)[NGE], Stream& st, Carry& carry, const Lane& id, const Next& nxt) {
+                      const u32x4 (&xlo)[NGE], Stream& st, Carry& carry, const Lane& id, const Next& nxt, const RBT& rb) {
   const int has_emb = (net.emb_mask >> layer) & 1;
-  if (layer == 0) trunk_layer_m<KH, NGE, 1, SPLIT>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt);
-  else if (has_emb) trunk_layer_m<KH, NGE, 3, SPLIT>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt);
-  else trunk_layer_m<KH, NGE, 2, SPLIT>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt);
+  if (layer == 0) trunk_layer_m<KH, NGE, 1, SPLIT, RBT>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt, rb);
+  else if (has_emb) trunk_layer_m<KH, NGE, 3, SPLIT, RBT>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt, rb);
+  else trunk_layer_m<KH, NGE, 2, SPLIT, RBT>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt, rb);
 }
 
+// This lane's rows of the per-ray bias of embedded layer number `el` (0 = layer 0, 1 = the first skip layer, ...):
+// rbp = table row of the lane's (ray, network, index value) + 4 h floats; 16 global loads of 16 bytes (L2 hits: a wave's
+// 32 samples share one or two rays), issued a whole layer ahead of their use.
+MF_D void load_raybias(RayBias& rb, const float* rbp, int el) {
+  const float* src = rbp + el * 128;
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(src + 32 * t), b = *reinterpret_cast<const f32x4*>(src + 32 * t + 8);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(src + 32 * t + 16), d = *reinterpret_cast<const f32x4*>(src + 32 * t + 24);
+    const f32x8 lo = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7), hi = __builtin_shufflevector(c, d, 0, 1, 2, 3, 4, 5, 6, 7);
+    rb.t[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+  }
+}
+MF_D void load_raybias(NoRayBias&, const float*, int) {}
+
 // the D trunk layers of a network, in pairs a -> b -> a; returns with the last layer's output in `a`
-template <int KH, int NGE, bool SPLIT, class NextOf>
+// RB: `rb` arrives loaded for layer 0; the set of the next embedded layer is fetched at the START of the layer in front of
+// it (a whole layer of MFMAs to land) -- or, when that layer consumes the current set itself (adjacent embedded layers),
+// right behind it.  One set is live at a time.
+template <int KH, int NGE, bool SPLIT, class NextOf, class RBT>
 MF_D void trunk(const Net& net, int D, u32x4 (&a)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE], Stream& st, Carry& carry,
-                const Lane& id, NextOf&& next_of) {
+                const Lane& id, NextOf&& next_of, RBT& rb, const float* rbp) {
+  constexpr bool RB = !__is_same(RBT, NoRayBias);
   u32x4 b[KH];
   int l = 0;
+  int el = 1;                                               // ordinal of the next embedded layer behind layer 0
+  auto one = [&](int layer, const u32x4 (&in)[KH], u32x4 (&out)[KH]) {
+    if constexpr (RB) {
+      const bool emb_here = (net.emb_mask >> layer) & 1, emb_next = layer + 1 < D && ((net.emb_mask >> (layer + 1)) & 1);
+      if (!emb_here && emb_next) load_raybias(rb, rbp, el);
+      trunk_layer<KH, NGE, SPLIT, RBT>(net, layer, true, in, out, xhi, xlo, st, carry, id, next_of(layer), rb);
+      if (emb_here && emb_next) load_raybias(rb, rbp, el);
+      if (emb_next) ++el;
+    } else {
+      trunk_layer<KH, NGE, SPLIT, RBT>(net, layer, true, in, out, xhi, xlo, st, carry, id, next_of(layer), rb);
+    }
+  };
   for (; l + 1 < D; l += 2) {
-    trunk_layer<KH, NGE, SPLIT>(net, l, true, a, b, xhi, xlo, st, carry, id, next_of(l));
+    one(l, a, b);
     st.tl.stamp(10 + l, id);
-    trunk_layer<KH, NGE, SPLIT>(net, l + 1, true, b, a, xhi, xlo, st, carry, id, next_of(l + 1));
+    one(l + 1, b, a);
     st.tl.stamp(11 + l, id);
   }
   if (l < D) {
-    trunk_layer<KH, NGE, SPLIT>(net, l, true, a, b, xhi, xlo, st, carry, id, next_of(l));
+    one(l, a, b);
 #pragma unroll
     for (int t = 0; t < KH; ++t) a[t] = b[t];
   }
@@ -540,7 +589,8 @@ MF_D void extra_layer(const Net& net, const u32x4 (&act)[16], const u32x4* ex, u
               t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id);
     };
     auto piece = [&](int k) { st.piece(k, id); };
-    out_tile<NGX, 16, false, false>(carry, act, ex, ex, p, pn, bias_off + 32 * t * 4, id.h, hook, piece, 0u, out[2 * t], out[2 * t + 1]);
+    const f32x16 none = {};
+    out_tile<NGX, 16, false, false, false>(carry, act, ex, ex, p, pn, bias_off + 32 * t * 4, none, id.h, hook, piece, 0u, out[2 * t], out[2 * t + 1]);
     st.advance();
   }
 }
@@ -558,9 +608,10 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
 #pragma unroll
     for (int i = 0; i < 4; ++i) act[t][i] = 0;
   const int D = net.D;
+  NoRayBias norb;
   trunk<16, kKsNerfXyz, false>(net, D, act, xe, xe, st, carry, id, [&](int l) {
     return (sigma_only && l == D - 1) ? follow : next_trunk_bf<16, kKsNerfXyz, false>(net, l + 1);
-  });
+  }, norb, nullptr);
   // resident block: [bias_trunk (D+1) 256 | bias_extra 128 | sigma_w 256 | sigma_b 4 | rgb_w 384 | rgb_b 4]
   const uint32_t r_sigma_w = net.res_lds + ((D + 1) * 256 + 128) * 4;
   float sg[1];
@@ -571,7 +622,7 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
   const int xg = 16 + net.aux;
   const Next ex{xg, nullptr, xg, nullptr};
   u32x4 fin[16];
-  trunk_layer_m<16, kKsNerfXyz, 2, false>(net, D, false, act, fin, xe, xe, st, carry, id, ex);   // xyz_encoding_final (no ReLU, hidden input only)
+  trunk_layer_m<16, kKsNerfXyz, 2, false>(net, D, false, act, fin, xe, xe, st, carry, id, ex, norb);   // xyz_encoding_final (no ReLU, hidden input only)
   st.tl.stamp(31, id);
   u32x4 e[8], eo[kKsExtraMax];
   make_extra(eo);
@@ -586,9 +637,11 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
   for (int c = 0; c < 3; ++c) rgb[c] = 1.f / (1.f + expf(-o[c]));   // nn.Sigmoid, nerf.py:57-59
 }
 
-// Neural motion flow (W = 128) on this wave's 32 samples; xhi/xlo = split operands of [xyz block ; ind block].
-MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofIn], const u32x4 (&xlo)[kKsNofIn], const float (&xyz)[3],
-                   Stream& st, Carry& carry, const Lane& id, const Next& follow, float (&out)[3]) {
+// Neural motion flow (W = 128) on this wave's 32 samples; xhi/xlo = split operands of the xyz block; `rb` = the per-ray
+// bias (image-index block + layer bias) of layer 0, already in flight, `rbp` = where the later embedded layers' sets are.
+MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&xlo)[kKsNofXyz], const float (&xyz)[3],
+                   Stream& st, Carry& carry, const Lane& id, const Next& follow, float (&out)[3], RayBias& rb,
+                   const float* rbp) {
   u32x4 act[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t)
@@ -597,7 +650,8 @@ MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofIn], const u32x4 (&x
   const int D = net.D;
   // the head panel (16 groups) follows the last trunk layer contiguously; behind it comes `follow`'s first panel
   const Next hd{16, nullptr, follow.groups, follow.jump};
-  trunk<8, kKsNofIn, true>(net, D, act, xhi, xlo, st, carry, id, [&](int l) { return l == D - 1 ? hd : next_trunk_bf<8, kKsNofIn, true>(net, l + 1); });
+  trunk<8, kKsNofXyz, true>(net, D, act, xhi, xlo, st, carry, id,
+                            [&](int l) { return l == D - 1 ? hd : next_trunk_bf<8, kKsNofXyz, true>(net, l + 1); }, rb, rbp);
   // head on the matrix pipe (16 MFMAs instead of 9 x 64 dependent FMAs + 144 LDS reads per lane); T[0..3] come
   // out in half 0's registers 0-3, T[4..7] in half 1's registers 0-3, T[8] in half 0's register 4
   f32x16 acc;
@@ -625,14 +679,11 @@ MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofIn], const u32x4 (&x
   }
 }
 
-// NoF input operands from a point and an image index (rendering.py:70-75)
-MF_D void nof_embed(u32x4 (&xhi)[kKsNofIn], u32x4 (&xlo)[kKsNofIn], const float (&xyz)[3], float ind, uint32_t par_xyz,
-                    uint32_t par_ind, int h, bool pow2_xyz, bool pow2_ind) {
-  float emb[B2Xyz5::SLOTS + B2Ind16::SLOTS];
+// NoF matrix operands from a point: its xyz block (rendering.py:70-72); the image-index block (:73-75) is the per-ray bias
+MF_D void nof_embed(u32x4 (&xhi)[kKsNofXyz], u32x4 (&xlo)[kKsNofXyz], const float (&xyz)[3], uint32_t par_xyz, int h, bool pow2_xyz) {
+  float emb[B2Xyz5::SLOTS];
   emb_eval<3, 5, true>(emb, xyz, par_xyz, h, pow2_xyz);
-  const float iv[1] = {ind};
-  emb_eval<1, 16>(emb + B2Xyz5::SLOTS, iv, par_ind, h, pow2_ind);
-  split_operands<kKsNofIn>(emb, B2Xyz5::SLOTS + B2Ind16::SLOTS, xhi, xlo);
+  split_operands<kKsNofXyz>(emb, B2Xyz5::SLOTS, xhi, xlo);
 }
 
 }  // namespace bf

@@ -130,11 +130,16 @@ struct EmbBlock2 {
 };
 using B2Xyz10 = EmbBlock2<3, 10>;   // 32 slots per half -> 4 k-steps
 using B2Xyz5 = EmbBlock2<3, 5>;     // 18
-using B2Ind16 = EmbBlock2<1, 16>;   // 18   (NoF input: 36 -> 5 k-steps)
 using B2Dir4 = EmbBlock2<3, 4>;     // 14  -> 2 k-steps
 using B2Ind2 = EmbBlock2<1, 2>;     // 4   -> 1 k-step
 constexpr int kKsNerfXyz = (B2Xyz10::SLOTS + 7) / 8;                       // 4
-constexpr int kKsNofIn = (B2Xyz5::SLOTS + B2Ind16::SLOTS + 7) / 8;         // 5
+// The bf16 NoF's matrix input is its xyz block only (3 k-steps): the image-index block (33 of the 66 input columns,
+// models/rendering.py:73-75, models/nof.py:69-73) is constant along a ray, so  W[:, 33:66] * emb(ind) + b  of every
+// layer that consumes the embedded input is a per-ray fp32 vector -- computed once per (ray, network, index value) by
+// nof_raybias_kernel (mf_render_bf16.hip) from the fp32 columns kept behind the panels (kNofIndCols per row) and used
+// as the accumulators' initial value.
+constexpr int kKsNofXyz = (B2Xyz5::SLOTS + 7) / 8;                          // 3
+constexpr int kNofIndCols = 36;                                             // 33 image-index columns + pad
 constexpr int kKsDir = (B2Dir4::SLOTS + 7) / 8;                            // 2
 constexpr int kKsInd = (B2Ind2::SLOTS + 7) / 8;                            // 1
 constexpr int kKsExtraMax = kKsDir;
@@ -144,13 +149,8 @@ MF_HD int emb_feature2(int kind, int h, int e, int xyz_cols) {
   switch (kind) {
     case kEmbNerfXyz:
       return e < B2Xyz10::SLOTS ? B2Xyz10::feature(h, e) : -1;
-    case kEmbNofIn:
-      if (e < B2Xyz5::SLOTS) return B2Xyz5::feature(h, e);
-      if (e < B2Xyz5::SLOTS + B2Ind16::SLOTS) {
-        const int f = B2Ind16::feature(h, e - B2Xyz5::SLOTS);
-        return f < 0 ? -1 : xyz_cols + f;
-      }
-      return -1;
+    case kEmbNofIn:      // xyz block only: the image-index block is a per-ray bias (kKsNofXyz)
+      return e < B2Xyz5::SLOTS ? B2Xyz5::feature(h, e) : -1;
     case kEmbDir:
       return e < B2Dir4::SLOTS ? B2Dir4::feature(h, e) : -1;
     case kEmbInd:
@@ -186,6 +186,8 @@ struct NetLayout {
   int extra_steps;         // NeRF extra_encoding: k-steps of the extra block (0, 4, 8); -1 = no extra layer
   int64_t res_bytes;       // resident block size (multiple of 1 KiB)
   int64_t panel_bytes;     // all panels
+  int64_t ind_bytes;       // bf16 NoF: fp32 image-index columns [embedded layer][row][kNofIndCols] behind the panels
+  int n_emb_layers;        // layers that consume the embedded input (popcount of emb_mask)
   int max_groups;          // largest panel, in groups
   // resident block float offsets
   int off_bias_trunk;      // n_trunk * W

@@ -303,7 +303,13 @@ static void emb_to_params(const mf_embedding& e, EmbParams& o) {
 namespace mf {
 int points_sigma_bf16(const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz, const mf_nof_desc* nof,
                       const void* nof_packed, const mf_embedding* nof_emb_xyz, const mf_embedding* nof_emb_ind, const float* xyz,
-                      const float* ind, float ind_scalar, int64_t B, float* sigma, float* canon, hipStream_t st);   // mf_render_bf16.hip
+                      const float* ind, float ind_scalar, int64_t B, float* sigma, float* canon, void* workspace,
+                      int64_t workspace_bytes, hipStream_t st);   // mf_render_bf16.hip
+int64_t points_workspace_bytes_bf16(const mf_nof_desc* nof, int per_point_ind, int64_t B);
+}
+
+extern "C" int64_t mf_points_sigma_workspace_bytes(int32_t precision, const mf_nof_desc* nof, int32_t per_point_ind, int64_t B) {
+  return precision == MF_PREC_BF16 ? points_workspace_bytes_bf16(nof, per_point_ind, B) : 0;
 }
 
 extern "C" int32_t mf_points_sigma(const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz,
@@ -311,13 +317,14 @@ extern "C" int32_t mf_points_sigma(const mf_nerf_desc* nerf, const void* nerf_pa
                                    const mf_embedding* nof_emb_ind, const float* xyz, const float* ind,
                                    float ind_scalar, int64_t B, float* sigma, float* canon, void* stream) {
   return mf_points_sigma_p(MF_PREC_F32, nerf, nerf_packed, emb_xyz, nof, nof_packed, nof_emb_xyz, nof_emb_ind, xyz, ind, ind_scalar, B,
-                           sigma, canon, stream);
+                           sigma, canon, nullptr, 0, stream);
 }
 
 extern "C" int32_t mf_points_sigma_p(int32_t precision, const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz,
                                      const mf_nof_desc* nof, const void* nof_packed, const mf_embedding* nof_emb_xyz,
                                      const mf_embedding* nof_emb_ind, const float* xyz, const float* ind,
-                                     float ind_scalar, int64_t B, float* sigma, float* canon, void* stream) {
+                                     float ind_scalar, int64_t B, float* sigma, float* canon, void* workspace,
+                                     int64_t workspace_bytes, void* stream) {
   if (!nerf || !nerf_packed || !emb_xyz || (B > 0 && (!xyz || !sigma)))
     return fail(MF_E_INVALID, "mf_points_sigma: null argument");
   if (precision != MF_PREC_F32 && precision != MF_PREC_BF16) return fail(MF_E_INVALID, "mf_points_sigma: precision %d", precision);
@@ -331,7 +338,7 @@ extern "C" int32_t mf_points_sigma_p(int32_t precision, const mf_nerf_desc* nerf
     }
     if (B == 0) return MF_OK;
     return points_sigma_bf16(nerf, nerf_packed, emb_xyz, nof, nof_packed, nof_emb_xyz, nof_emb_ind, xyz, ind, ind_scalar, B, sigma, canon,
-                             static_cast<hipStream_t>(stream));
+                             workspace, workspace_bytes, static_cast<hipStream_t>(stream));
   }
   PointsParams p{};
   if (!nerf_layout(*nerf, p.nerf.L) || p.nerf.L.NK != 16)

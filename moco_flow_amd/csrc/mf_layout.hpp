@@ -65,7 +65,7 @@ inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0) {
   L.NK = d.W / 16;
   L.NP = d.W / 32;
   L.n_trunk = d.D;
-  L.emb_steps = bf16 ? kKsNofIn : kStepsNofIn;
+  L.emb_steps = bf16 ? kKsNofXyz : kStepsNofIn;         // bf16: xyz block only, the image-index block is a per-ray bias
   L.emb_split = bf16 ? 1 : 0;                          // bf16: the NoF's embedded input keeps 16 mantissa bits
   L.emb_mask = 1u | d.skip_mask;
   L.relu_mask = (1u << d.D) - 1u;
@@ -88,6 +88,8 @@ inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0) {
     if (head_groups(L) > L.max_groups) L.max_groups = head_groups(L);
   }
   L.panel_bytes = groups * kGroupBytes;
+  L.n_emb_layers = __builtin_popcount(L.emb_mask);
+  L.ind_bytes = bf16 ? round_up((int64_t)L.n_emb_layers * L.W * kNofIndCols * 4, kGroupBytes) : 0;
   return true;
 }
 

@@ -125,6 +125,18 @@ __global__ void pack_resident_kernel(ResJob job) {
   job.res[idx] = v;
 }
 
+// bf16 NoF: the fp32 image-index columns of the layers that consume the embedded input, [embedded layer][row][kNofIndCols]
+// (what nof_raybias_kernel contracts with emb(ind) once per ray)
+struct IndJob { const float* W[MF_MAX_LAYERS]; int n_in[MF_MAX_LAYERS]; int n_layers, rows, col0, cols; float* dst; };
+
+__global__ void pack_ind_kernel(IndJob job) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  const int per_layer = job.rows * kNofIndCols;
+  if (idx >= job.n_layers * per_layer) return;
+  const int e = idx / per_layer, r = (idx % per_layer) / kNofIndCols, c = idx % kNofIndCols;
+  job.dst[idx] = c < job.cols ? job.W[e][(long long)r * job.n_in[e] + job.col0 + c] : 0.f;
+}
+
 static int launch_pack(const PackJob& job, const ResJob& rj, hipStream_t st) {
   const int rb = (rj.total + 255) / 256;
   hipLaunchKernelGGL(pack_resident_kernel, dim3(rb), dim3(256), 0, st, rj);
@@ -147,7 +159,7 @@ extern "C" int64_t mf_nerf_packed_bytes_p(const mf_nerf_desc* d, int32_t precisi
 extern "C" int64_t mf_nof_packed_bytes_p(const mf_nof_desc* d, int32_t precision) {
   NetLayout L;
   if (!d || (precision != MF_PREC_F32 && precision != MF_PREC_BF16) || !nof_layout(*d, L, precision)) { fail(MF_E_UNSUPPORTED, "mf_nof_packed_bytes: unsupported NoF configuration"); return 0; }
-  return L.res_bytes + L.panel_bytes;
+  return L.res_bytes + L.panel_bytes + L.ind_bytes;
 }
 
 extern "C" int32_t mf_nerf_pack_p(const mf_nerf_desc* d, int32_t precision, void* packed, void* stream) {
@@ -281,6 +293,19 @@ extern "C" int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* 
   rj.res = static_cast<float*>(packed);
   rj.total = (int)(L.res_bytes / 4);
   if (g0 * kGroupBytes != L.panel_bytes) return fail(MF_E_INVALID, "mf_nof_pack: layout mismatch");
+  if (L.bf16) {
+    IndJob ij{};
+    for (int l = 0; l < L.n_trunk; ++l)
+      if ((L.emb_mask >> l) & 1) {
+        ij.W[ij.n_layers] = d->trunk_w[l];
+        ij.n_in[ij.n_layers] = cin + (l > 0 ? L.W : 0);
+        ++ij.n_layers;
+      }
+    ij.rows = L.W; ij.col0 = d->in_channels_xyz; ij.cols = d->extra_feat_dim;
+    ij.dst = reinterpret_cast<float*>(static_cast<char*>(packed) + L.res_bytes + L.panel_bytes);
+    const int total = ij.n_layers * ij.rows * kNofIndCols;
+    hipLaunchKernelGGL(pack_ind_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), ij);
+  }
   return launch_pack(job, rj, static_cast<hipStream_t>(stream));
 }
 

@@ -287,10 +287,16 @@ static void to_table(const mf_embedding& e, float* o) {
 
 int device_cus();   // mf_forward.hip
 int render_pass_bf16(const mf_render_args* a, hipStream_t st);   // mf_render_bf16.hip
+int64_t render_workspace_bytes_bf16(const mf_render_args* a);
 
 }  // namespace mf
 
 using namespace mf;
+
+extern "C" int64_t mf_render_workspace_bytes(const mf_render_args* a) {
+  if (!a || a->precision != MF_PREC_BF16 || a->n_rays <= 0) return 0;
+  return render_workspace_bytes_bf16(a);
+}
 
 extern "C" int32_t mf_nof_emb_slot_features(int32_t* features80) {
   if (!features80) return fail(MF_E_INVALID, "mf_nof_emb_slot_features: null argument");

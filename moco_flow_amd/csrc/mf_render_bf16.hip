@@ -12,6 +12,8 @@
 namespace mf {
 namespace bf {
 
+typedef const __attribute__((address_space(4))) char* typedef_kptr;
+
 struct Params {
   const float* rays; long long ray_stride; long long n_rays;
   const float* bg;
@@ -27,8 +29,71 @@ struct Params {
   long long n_groups;
   uint32_t par_off, ring_off, buf_bytes, sbuf_off, zbuf_off;
   int pow2;                        // bit t: table t's frequencies are exactly 2^k (the logscale default)
+  const float* raybias;            // MOCO: (n_rays, rb_combos, rb_layers, 128) per-ray NoF biases (nof_raybias_kernel)
+  int rb_combos, rb_layers;
 };
 
+// ---- per-ray bias of the NoF's embedded-input layers (models/rendering.py:73-75 + models/nof.py:69-73) ----
+// The NoF's input is [emb(xyz) 33 | emb(ind) 33] and the image index is one number per ray, so in every layer l that
+// consumes the embedded input  b_l + W_l[:, 33:66] emb(ind)  is constant along the ray.  One workgroup per (entry,
+// combination) evaluates it once in exact fp32 -- emb(ind) with OCML sincosf on the fp32-rounded argument 2^k ind, as
+// embedding.py:45 does, 33 FMAs per row -- and the render kernel starts those layers' accumulators from it: the image
+// index never enters the matrix pipe (2 of the 5 split k-steps of layer 0 and of the skip layer, 48 of 232 MFMAs per
+// evaluation, and the 18 sin / cos of 2^15-sized arguments per lane are gone).
+// Combination = (network, index column): render passes use bw(i), fw(i), fw(j), bw(j) (rendering.py:270-282).
+struct RayBiasParams {
+  const float* ind;                // entry e reads ind[e * ind_stride + col[c]]; null -> ind_scalar
+  long long ind_stride;
+  float ind_scalar;
+  long long n_entries;
+  int n_combos;
+  const float* bias[4];            // per combination: the network's [layer][128] trunk biases (its resident block)
+  const float* wind[4];            //                  its [embedded layer][128][kNofIndCols] index columns
+  uint32_t emb_mask[4];
+  int col[4];
+  int n_layers;                    // embedded layers per network
+  float freq[16], weight[16];      // the image-index embedding
+  float* out;                      // (n_entries, n_combos, n_layers, 128)
+};
+
+__global__ __launch_bounds__(256) void nof_raybias_kernel(const RayBiasParams p) {
+  __shared__ float e[kNofIndCols];
+  const long long entry = blockIdx.x / p.n_combos;
+  const int c = blockIdx.x % p.n_combos;
+  const int tid = threadIdx.x;
+  // the by-value argument is indexed with constants only (a runtime index would put a private copy in scratch)
+  const float* s_bias = c == 0 ? p.bias[0] : (c == 1 ? p.bias[1] : (c == 2 ? p.bias[2] : p.bias[3]));
+  const float* s_wind = c == 0 ? p.wind[0] : (c == 1 ? p.wind[1] : (c == 2 ? p.wind[2] : p.wind[3]));
+  const uint32_t s_mask = c == 0 ? p.emb_mask[0] : (c == 1 ? p.emb_mask[1] : (c == 2 ? p.emb_mask[2] : p.emb_mask[3]));
+  const int col = c == 0 ? p.col[0] : (c == 1 ? p.col[1] : (c == 2 ? p.col[2] : p.col[3]));
+  const float ind = p.ind ? p.ind[entry * p.ind_stride + col] : p.ind_scalar;
+  if (tid < kNofIndCols) e[tid] = 0.f;
+  __syncthreads();
+  if (tid == 0) e[0] = ind;
+  if (tid >= 32 && tid < 48) {                              // column order of embedding.py:42-46 with C = 1
+    const int k = tid - 32;
+    const typedef_kptr ka = (typedef_kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    const float fr = ((const __attribute__((address_space(4))) float*)(ka + offsetof(RayBiasParams, freq)))[k];
+    const float w = ((const __attribute__((address_space(4))) float*)(ka + offsetof(RayBiasParams, weight)))[k];
+    float sn, cs;
+    sincosf(fr * ind, &sn, &cs);
+    e[1 + 2 * k] = w * sn;
+    e[2 + 2 * k] = w * cs;
+  }
+  __syncthreads();
+  const int total = p.n_layers * 128;
+  for (int o = tid; o < total; o += 256) {
+    const int el = o >> 7, row = o & 127;
+    int layer = 0, seen = 0;                                // the el-th set bit of emb_mask
+    for (uint32_t m = s_mask; m; m >>= 1, ++layer)
+      if (m & 1u) { if (seen == el) break; ++seen; }
+    float acc = s_bias[layer * 128 + row];
+    const float* w = s_wind + (size_t)(el * 128 + row) * kNofIndCols;
+#pragma unroll
+    for (int k = 0; k < 33; ++k) acc = __builtin_fmaf(w[k], e[k], acc);
+    p.out[((size_t)(entry * p.n_combos + c) * p.n_layers + el) * 128 + row] = acc;
+  }
+}
 
 template <bool MOCO>
 __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p) {
@@ -45,13 +110,12 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
     const kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(Params, emb_par);
     *(float*)(smem + p.par_off + threadIdx.x * 4) = ((const __attribute__((address_space(4))) float*)ka)[threadIdx.x];
   }
-  const uint32_t par_nerf_xyz = p.par_off, par_nerf_ext = p.par_off + 128, par_nof_xyz = p.par_off + 256,
-                 par_nof_ind = p.par_off + 384;
+  const uint32_t par_nerf_xyz = p.par_off, par_nerf_ext = p.par_off + 128, par_nof_xyz = p.par_off + 256;
   Stream st;
   st.tl.start(p.alphas, id);
   Carry carry;
-  const Next prog_first = MOCO ? first_of<8, kKsNofIn, true>(p.bw) : first_of<16, kKsNerfXyz, false>(p.nerf);
-  if (MOCO) start_program<8, kKsNofIn, true>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);   // (its wait + barrier also publish the resident blocks / tables)
+  const Next prog_first = MOCO ? first_of<8, kKsNofXyz, true>(p.bw) : first_of<16, kKsNerfXyz, false>(p.nerf);
+  if (MOCO) start_program<8, kKsNofXyz, true>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);   // (its wait + barrier also publish the resident blocks / tables)
   else start_program<16, kKsNerfXyz, false>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
 
   const int S = p.S;
@@ -96,8 +160,6 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
       if (MOCO) {
         // chain program (rendering.py:270-282): step 0 bw(x,i) -> canon; local: fw(canon,i) -> recon;
         // global: fw(canon,j) -> a; bw(a,j) -> b; fw(b,i) -> chained recon.
-        const float ind_i = rp[8];
-        const float ind_j = (p.flags & MF_F_CHAIN_GLOBAL) ? rp[9] : 0.f;
         const bool loc = p.flags & MF_F_CHAIN_LOCAL, glob = p.flags & MF_F_CHAIN_GLOBAL;
         const int nsteps = 1 + (loc ? 1 : 0) + (glob ? 3 : 0);
         float canon[3] = {0.f, 0.f, 0.f}, cur[3] = {x[0], x[1], x[2]};
@@ -107,15 +169,18 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
           const int role = step;
           const bool use_fw = (role == 1 || role == 2 || role == 4);
           const Net net = use_fw ? p.fw : p.bw;
-          const float ind = (role == 2 || role == 3) ? ind_j : ind_i;
+          // per-ray bias of this (network, image index): table rows bw(i), fw(i), fw(j), bw(j); the final fw(i) is row 1
+          const float* rbp = p.raybias + ((size_t)ray * p.rb_combos + (role == 4 ? 1 : role)) * (size_t)(p.rb_layers * 128) + 4 * id.h;
+          RayBias rb;
+          load_raybias(rb, rbp, 0);                    // in flight across the encoding
           if (role == 1 || role == 2) { cur[0] = canon[0]; cur[1] = canon[1]; cur[2] = canon[2]; }
           const bool last = step == nsteps - 1;
           const bool next_fw = (role + 1 == 1 || role + 1 == 2 || role + 1 == 4);
-          const Next follow = last ? first_of<16, kKsNerfXyz, false>(p.nerf) : first_of<8, kKsNofIn, true>(next_fw ? p.fw : p.bw);
-          u32x4 nhi[kKsNofIn], nlo[kKsNofIn];
+          const Next follow = last ? first_of<16, kKsNerfXyz, false>(p.nerf) : first_of<8, kKsNofXyz, true>(next_fw ? p.fw : p.bw);
+          u32x4 nhi[kKsNofXyz], nlo[kKsNofXyz];
           float out[3];
-          nof_embed(nhi, nlo, cur, ind, par_nof_xyz, par_nof_ind, id.h, p.pow2 & 4, p.pow2 & 8);
-          nof_eval(net, nhi, nlo, cur, st, carry, id, follow, out);
+          nof_embed(nhi, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
+          nof_eval(net, nhi, nlo, cur, st, carry, id, follow, out, rb, rbp);
           if (role == 0) { canon[0] = out[0]; canon[1] = out[1]; canon[2] = out[2]; }
           if (role == 1) dl = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
           if (role == 4) dg = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
@@ -242,6 +307,8 @@ struct PointsParamsBf {
   float* canon;                    // (B,3) or null
   uint32_t par_off, ring_off, buf_bytes;
   int pow2;
+  const float* raybias;            // NOF: (B | 1, rb_layers, 128) per-point (ind given) or single (ind_scalar) NoF biases
+  int rb_layers;
 };
 
 template <bool NOF>
@@ -254,12 +321,12 @@ __global__ __launch_bounds__(kThreads, 2) void points_kernel_bf16(const PointsPa
     const kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(PointsParamsBf, emb_par);
     *(float*)(smem + p.par_off + threadIdx.x * 4) = ((const __attribute__((address_space(4))) float*)ka)[threadIdx.x];
   }
-  const uint32_t par_nerf_xyz = p.par_off, par_nof_xyz = p.par_off + 256, par_nof_ind = p.par_off + 384;
+  const uint32_t par_nerf_xyz = p.par_off, par_nof_xyz = p.par_off + 256;
   Stream st;
   st.tl.start(nullptr, id);
   Carry carry;
-  const Next prog_first = NOF ? first_of<8, kKsNofIn, true>(p.bw) : first_of<16, kKsNerfXyz, false>(p.nerf);
-  if (NOF) start_program<8, kKsNofIn, true>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);
+  const Next prog_first = NOF ? first_of<8, kKsNofXyz, true>(p.bw) : first_of<16, kKsNerfXyz, false>(p.nerf);
+  if (NOF) start_program<8, kKsNofXyz, true>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);
   else start_program<16, kKsNerfXyz, false>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
   const long long ntiles = (p.B + bf::kTile - 1) / bf::kTile;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -268,11 +335,13 @@ __global__ __launch_bounds__(kThreads, 2) void points_kernel_bf16(const PointsPa
     const long long bb = valid ? b : p.B - 1;
     float x[3] = {p.xyz[bb * 3 + 0], p.xyz[bb * 3 + 1], p.xyz[bb * 3 + 2]};
     if (NOF) {
-      const float ind = p.ind ? p.ind[bb] : p.ind_scalar;
-      u32x4 nhi[kKsNofIn], nlo[kKsNofIn];
+      const float* rbp = p.raybias + (p.ind ? (size_t)bb : (size_t)0) * (size_t)(p.rb_layers * 128) + 4 * id.h;
+      RayBias rb;
+      load_raybias(rb, rbp, 0);
+      u32x4 nhi[kKsNofXyz], nlo[kKsNofXyz];
       float out[3];
-      nof_embed(nhi, nlo, x, ind, par_nof_xyz, par_nof_ind, id.h, p.pow2 & 4, p.pow2 & 8);
-      nof_eval(p.bw, nhi, nlo, x, st, carry, id, first_of<16, kKsNerfXyz, false>(p.nerf), out);
+      nof_embed(nhi, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
+      nof_eval(p.bw, nhi, nlo, x, st, carry, id, first_of<16, kKsNerfXyz, false>(p.nerf), out, rb, rbp);
       x[0] = out[0]; x[1] = out[1]; x[2] = out[2];
       if (valid && id.h == 0 && p.canon) {
         p.canon[b * 3 + 0] = x[0]; p.canon[b * 3 + 1] = x[1]; p.canon[b * 3 + 2] = x[2];
@@ -305,9 +374,32 @@ static bool emb_table(const mf_embedding& e, float* dst) {      // returns: freq
   return pow2;
 }
 
+// combination c of a ray-bias table: network (packed buffer + layout) and the index column it reads
+static void raybias_combo(RayBiasParams& r, int c, const void* packed, const NetLayout& L, int col) {
+  const char* base = static_cast<const char*>(packed);
+  r.bias[c] = reinterpret_cast<const float*>(base) + L.off_bias_trunk;
+  r.wind[c] = reinterpret_cast<const float*>(base + L.res_bytes + L.panel_bytes);
+  r.emb_mask[c] = L.emb_mask;
+  r.col[c] = col;
+}
+
 }  // namespace bf
 
 int device_cus();   // mf_forward.hip
+
+// combinations (network, index value) and embedded layers per network of a bf16 pass with NoF; 0 combos = no table
+static void raybias_shape(const mf_render_args* a, int& combos, int& layers) {
+  combos = layers = 0;
+  if (!a->nof_bw) return;
+  combos = (a->flags & MF_F_CHAIN_GLOBAL) ? 4 : ((a->flags & MF_F_CHAIN_LOCAL) ? 2 : 1);
+  layers = __builtin_popcount(1u | a->nof_bw->skip_mask);
+}
+
+int64_t render_workspace_bytes_bf16(const mf_render_args* a) {
+  int combos, layers;
+  raybias_shape(a, combos, layers);
+  return (int64_t)a->n_rays * combos * layers * 128 * 4;
+}
 
 // called by mf_render_pass (mf_render.hip) after argument validation, precision == MF_PREC_BF16
 int render_pass_bf16(const mf_render_args* a, hipStream_t st) {
@@ -349,6 +441,31 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st) {
       if (Lf.max_groups > max_groups) max_groups = Lf.max_groups;
     }
     p.pow2 |= (emb_table(a->nof_emb_xyz, p.emb_par[2]) ? 4 : 0) | (emb_table(a->nof_emb_ind, p.emb_par[3]) ? 8 : 0);
+    // the per-ray bias table (image-index block of the NoFs' embedded-input layers), one small launch in front
+    int combos, layers;
+    raybias_shape(a, combos, layers);
+    if (chains && __builtin_popcount(1u | a->nof_fw->skip_mask) != layers)
+      return fail(MF_E_UNSUPPORTED, "mf_render_pass(bf16): backward and forward NoF must have the same number of skip layers");
+    const int64_t need = render_workspace_bytes_bf16(a);
+    if (need > 0 && (!a->workspace || a->workspace_bytes < need))
+      return fail(MF_E_INVALID, "mf_render_pass(bf16): workspace of %lld bytes needed (mf_render_workspace_bytes), got %lld",
+                  (long long)need, (long long)(a->workspace ? a->workspace_bytes : 0));
+    if (a->n_rays * (int64_t)combos > 0x7fffffffLL) return fail(MF_E_UNSUPPORTED, "mf_render_pass(bf16): too many rays for one launch");
+    p.raybias = static_cast<const float*>(a->workspace);
+    p.rb_combos = combos; p.rb_layers = layers;
+    if (a->n_rays > 0) {
+      RayBiasParams r{};
+      r.ind = a->rays; r.ind_stride = a->ray_stride; r.n_entries = a->n_rays; r.n_combos = combos; r.n_layers = layers;
+      raybias_combo(r, 0, a->nof_bw_packed, Lb, 8);
+      if (chains) {
+        raybias_combo(r, 1, a->nof_fw_packed, Lf, 8);
+        raybias_combo(r, 2, a->nof_fw_packed, Lf, 9);
+        raybias_combo(r, 3, a->nof_bw_packed, Lb, 9);
+      }
+      for (int k = 0; k < 16; ++k) { r.freq[k] = p.emb_par[3][k]; r.weight[k] = p.emb_par[3][16 + k]; }
+      r.out = static_cast<float*>(a->workspace);
+      hipLaunchKernelGGL(nof_raybias_kernel, dim3((unsigned)(a->n_rays * combos)), dim3(256), 0, st, r);
+    }
   }
   p.par_off = lds; lds += 512;
   p.ring_off = lds;
@@ -386,9 +503,15 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st) {
 }
 
 // called by mf_points_sigma_p (mf_forward.hip) after argument validation, precision == MF_PREC_BF16
+int64_t points_workspace_bytes_bf16(const mf_nof_desc* nof, int per_point_ind, int64_t B) {
+  if (!nof) return 0;
+  return (per_point_ind ? B : 1) * (int64_t)__builtin_popcount(1u | nof->skip_mask) * 128 * 4;
+}
+
 int points_sigma_bf16(const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz, const mf_nof_desc* nof,
                       const void* nof_packed, const mf_embedding* nof_emb_xyz, const mf_embedding* nof_emb_ind, const float* xyz,
-                      const float* ind, float ind_scalar, int64_t B, float* sigma, float* canon, hipStream_t st) {
+                      const float* ind, float ind_scalar, int64_t B, float* sigma, float* canon, void* workspace,
+                      int64_t workspace_bytes, hipStream_t st) {
   using namespace bf;
   PointsParamsBf p{};
   NetLayout Ln, Lb;
@@ -413,6 +536,23 @@ int points_sigma_bf16(const mf_nerf_desc* nerf, const void* nerf_packed, const m
     p.bw = net_of(Lb, nof_packed, Lb.n_trunk, Lb.n_head);
     if (Lb.max_groups > max_groups) max_groups = Lb.max_groups;
     p.pow2 |= (emb_table(*nof_emb_xyz, p.emb_par[2]) ? 4 : 0) | (emb_table(*nof_emb_ind, p.emb_par[3]) ? 8 : 0);
+    // per-point (ind given) or single (ind_scalar) bias of the NoF's embedded-input layers, see nof_raybias_kernel
+    const int64_t need = points_workspace_bytes_bf16(nof, ind != nullptr, B);
+    if (!workspace || workspace_bytes < need)
+      return fail(MF_E_INVALID, "mf_points_sigma(bf16): workspace of %lld bytes needed (mf_points_sigma_workspace_bytes), got %lld",
+                  (long long)need, (long long)(workspace ? workspace_bytes : 0));
+    const int64_t entries = ind ? B : 1;
+    if (entries > 0x7fffffffLL) return fail(MF_E_UNSUPPORTED, "mf_points_sigma(bf16): too many points for one launch");
+    p.raybias = static_cast<const float*>(workspace);
+    p.rb_layers = Lb.n_emb_layers;
+    if (B > 0) {
+      RayBiasParams r{};
+      r.ind = ind; r.ind_stride = 1; r.ind_scalar = ind_scalar; r.n_entries = entries; r.n_combos = 1; r.n_layers = Lb.n_emb_layers;
+      raybias_combo(r, 0, nof_packed, Lb, 0);
+      for (int k = 0; k < 16; ++k) { r.freq[k] = p.emb_par[3][k]; r.weight[k] = p.emb_par[3][16 + k]; }
+      r.out = static_cast<float*>(workspace);
+      hipLaunchKernelGGL(nof_raybias_kernel, dim3((unsigned)entries), dim3(256), 0, st, r);
+    }
   }
   p.par_off = lds; lds += 512;
   p.ring_off = lds;

@@ -40,9 +40,11 @@ def query_sigma(xyz, nerf, nerf_embedding_xyz, bw_nof=None, nof_embeddings=None,
                 raise RuntimeError(f"query_sigma: ind must have 1 or {B} elements")
         else:
             ind_s = float(ind)
+    need = int(L.lib().mf_points_sigma_workspace_bytes(prec, fd, 1 if ind_t is not None else 0, B)) if fd is not None else 0
+    ws = torch.empty(need, dtype=torch.uint8, device=dev) if need > 0 else None     # bf16 + NoF: per-point index bias
     with torch.cuda.device(dev):
         L.check(L.lib().mf_points_sigma_p(prec, nd, nb.data_ptr(), C.byref(ex), fd, L.ptr(fb),
                                           C.byref(fx) if fx is not None else None,
                                           C.byref(fi) if fi is not None else None, L.ptr(x), L.ptr(ind_t), ind_s, B,
-                                          L.ptr(sigma), L.ptr(canon), L.current_stream(dev)), "mf_points_sigma")
+                                          L.ptr(sigma), L.ptr(canon), L.ptr(ws), need, L.current_stream(dev)), "mf_points_sigma")
     return (sigma, canon) if return_canonical else sigma

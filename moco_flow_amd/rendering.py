@@ -128,6 +128,11 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
             a.dump_nof_stride = nstride
             a.dump_nof_emb = alloc("nof_emb", (steps, N * S, 80))
             a.dump_nof_out = alloc("nof_out", (steps, N * S, 3))
+    need = int(L.lib().mf_render_workspace_bytes(C.byref(a)))      # bf16 + NoF: the per-ray bias table (ABI v12)
+    if need > 0:
+        ws = torch.empty(need, dtype=torch.uint8, device=dev)
+        a.workspace, a.workspace_bytes = ws.data_ptr(), need
+        keep.append(ws)
     with torch.cuda.device(dev):
         L.check(L.lib().mf_render_pass(C.byref(a), L.current_stream(dev)), "mf_render_pass")
     del keep

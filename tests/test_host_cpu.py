@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
         assert n in L.SYMBOLS, f"{n} has no ctypes prototype"
-    assert lib.mf_version() == L.MF_ABI_VERSION == 11
+    assert lib.mf_version() == L.MF_ABI_VERSION == 12
     # argument validation is host-side and must not need a GPU
     d = L.mf_nerf_desc()
     d.D, d.W, d.in_channels_xyz, d.skip_mask = 8, 256, 63, 1 << 4
@@ -97,9 +97,11 @@ def test_packed_layout_sizes():
     groups = (10 + 16 + 26 + 16) * 4
     assert lib.mf_nof_packed_bytes(ctypes.byref(n)) == 7 * 1024 + groups * 1024
     # MF_PREC_BF16 (mf_bf16.hpp): a panel is ONE 32-row tile, a group one A fragment of v_mfma_f32_32x32x16_bf16;
-    # the NoF's embedded k-steps are (hi, lo) group pairs and its head is one more 16-group panel; the NeRF's encodings
-    # are single groups (plain bf16 operands: 4 k-steps of the xyz block, 2 of the direction block)
-    assert lib.mf_nof_packed_bytes_p(ctypes.byref(n), L.MF_PREC_BF16) == 7 * 1024 + ((10 + 8 + 18 + 8) * 4 + 16) * 1024
+    # the NoF's matrix input is its xyz block only -- 3 embedded k-steps as (hi, lo) group pairs -- its head is one more
+    # 16-group panel, and the fp32 image-index columns of its two embedded layers (2 x 128 rows x 36 floats = 36 KiB: the
+    # per-ray bias is made from them) follow the panels; the NeRF's encodings are single groups (plain bf16 operands:
+    # 4 k-steps of the xyz block, 2 of the direction block)
+    assert lib.mf_nof_packed_bytes_p(ctypes.byref(n), L.MF_PREC_BF16) == 7 * 1024 + ((6 + 8 + 14 + 8) * 4 + 16) * 1024 + 36 * 1024
     d.extra_feat_type, d.extra_feat_dim = L.MF_EXTRA_DIR, 27
     groups = (4 + 3 * 16 + 20 + 3 * 16 + 16) * 8 + (16 + 2) * 4
     assert lib.mf_nerf_packed_bytes_p(ctypes.byref(d), L.MF_PREC_BF16) == 13 * 1024 + groups * 1024
