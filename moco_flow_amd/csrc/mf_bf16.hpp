@@ -287,15 +287,21 @@ MF_D f32x16 head_tile(Carry& carry, const u32x4* hid, uint32_t p, uint32_t pn, u
 struct RayBias { f32x16 t[4]; };    // per tile of a 128-wide layer: the accumulators' initial value (whole vectors: a
                                     // f32x4[16] read back as f32x16 defeats SROA and lands in scratch)
 struct NoRayBias {};
+// The same vectors staged in LDS (the render pass: the rows of the tile's rays arrive by LDS-DMA one chain step ahead,
+// stage_raybias in mf_render_bf16.hip): `lane_off` = LDS byte offset of this lane's ray's [embedded layer][128] block.
+// The accumulators then start with four ds_reads exactly like the static bias, only from a per-lane address.
+struct LdsRayBias { uint32_t lane_off; };
 template <int KH, int NGE, int MODE, bool SPLIT, class RBT = NoRayBias>
 MF_D void trunk_layer_m(const Net& net, int layer, bool relu, const u32x4 (&act)[KH], u32x4 (&out)[KH], const u32x4 (&xhi)[NGE],
                         const u32x4 (&xlo)[NGE], Stream& st, Carry& carry, const Lane& id, const Next& nxt, const RBT& rb) {
-  constexpr bool RB = !__is_same(RBT, NoRayBias);
+  constexpr bool RB = __is_same(RBT, RayBias);
   static_assert(!RB || KH == 8, "per-ray bias: 128-wide layers (4 tiles)");
   constexpr int NT = KH / 2;
   const int groups = tgroups<KH, NGE, SPLIT>(net, layer);
   const unsigned lo = relu ? 0u : 0x80008000u;      // ReLU / pass-through floor
-  const uint32_t bias_off = net.res_lds + layer * (16 * KH) * 4;
+  uint32_t bias_off = net.res_lds + layer * (16 * KH) * 4;
+  if constexpr (__is_same(RBT, LdsRayBias) && (MODE & 1))      // embedded layer number popcount(mask below `layer`)
+    bias_off = rb.lane_off + (uint32_t)__builtin_popcount(net.emb_mask & ((1u << layer) - 1u)) * (16 * KH) * 4;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const uint32_t p = st.slot_off(0) + id.lane * 16;
@@ -334,6 +340,11 @@ MF_D void trunk_layer(const Net& net, int layer, bool relu, const u32x4 (&act)[K
 MF_D void load_raybias(RayBias& rb, const float* rbp, int el) {
   const float* src = rbp + el * 128;
   typedef float f32x8 __attribute__((ext_vector_type(8)));
+#ifdef MF_BF_ABL_NORB                                       // (timing ablation, tools/ab_lib.sh: no table loads)
+  for (int t = 0; t < 4; ++t)
+    for (int i = 0; i < 16; ++i) rb.t[t][i] = 0.f;
+  return;
+#endif
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(src + 32 * t), b = *reinterpret_cast<const f32x4*>(src + 32 * t + 8);
@@ -343,15 +354,18 @@ MF_D void load_raybias(RayBias& rb, const float* rbp, int el) {
   }
 }
 MF_D void load_raybias(NoRayBias&, const float*, int) {}
+MF_D void load_raybias(LdsRayBias&, const float*, int) {}
 
 // the D trunk layers of a network, in pairs a -> b -> a; returns with the last layer's output in `a`
 // RB: `rb` arrives loaded for layer 0; the set of the next embedded layer is fetched at the START of the layer in front of
 // it (a whole layer of MFMAs to land) -- or, when that layer consumes the current set itself (adjacent embedded layers),
 // right behind it.  One set is live at a time.
-template <int KH, int NGE, bool SPLIT, class NextOf, class RBT>
+// `after_first()` runs once behind layer 0 (the render pass stages the NEXT chain step's per-ray bias rows there: this
+// wave is past the step's first panel barrier, and every later barrier of the step publishes them).
+template <int KH, int NGE, bool SPLIT, class NextOf, class RBT, class AfterFirst>
 MF_D void trunk(const Net& net, int D, u32x4 (&a)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE], Stream& st, Carry& carry,
-                const Lane& id, NextOf&& next_of, RBT& rb, const float* rbp) {
-  constexpr bool RB = !__is_same(RBT, NoRayBias);
+                const Lane& id, NextOf&& next_of, RBT& rb, const float* rbp, AfterFirst&& after_first) {
+  constexpr bool RB = __is_same(RBT, RayBias);
   u32x4 b[KH];
   int l = 0;
   int el = 1;                                               // ordinal of the next embedded layer behind layer 0
@@ -368,12 +382,14 @@ MF_D void trunk(const Net& net, int D, u32x4 (&a)[KH], const u32x4 (&xhi)[NGE], 
   };
   for (; l + 1 < D; l += 2) {
     one(l, a, b);
+    if (l == 0) after_first();
     st.tl.stamp(10 + l, id);
     one(l + 1, b, a);
     st.tl.stamp(11 + l, id);
   }
   if (l < D) {
     one(l, a, b);
+    if (l == 0) after_first();
 #pragma unroll
     for (int t = 0; t < KH; ++t) a[t] = b[t];
   }
@@ -611,7 +627,7 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
   NoRayBias norb;
   trunk<16, kKsNerfXyz, false>(net, D, act, xe, xe, st, carry, id, [&](int l) {
     return (sigma_only && l == D - 1) ? follow : next_trunk_bf<16, kKsNerfXyz, false>(net, l + 1);
-  }, norb, nullptr);
+  }, norb, nullptr, [] {});
   // resident block: [bias_trunk (D+1) 256 | bias_extra 128 | sigma_w 256 | sigma_b 4 | rgb_w 384 | rgb_b 4]
   const uint32_t r_sigma_w = net.res_lds + ((D + 1) * 256 + 128) * 4;
   float sg[1];
@@ -639,9 +655,11 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
 
 // Neural motion flow (W = 128) on this wave's 32 samples; xhi/xlo = split operands of the xyz block; `rb` = the per-ray
 // bias (image-index block + layer bias) of layer 0, already in flight, `rbp` = where the later embedded layers' sets are.
+// (RBT = RayBias: register sets fetched from the global table, the per-point query; LdsRayBias: staged in LDS, the render pass)
+template <class RBT, class AfterFirst>
 MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&xlo)[kKsNofXyz], const float (&xyz)[3],
-                   Stream& st, Carry& carry, const Lane& id, const Next& follow, float (&out)[3], RayBias& rb,
-                   const float* rbp) {
+                   Stream& st, Carry& carry, const Lane& id, const Next& follow, float (&out)[3], RBT& rb,
+                   const float* rbp, AfterFirst&& after_first) {
   u32x4 act[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t)
@@ -651,7 +669,7 @@ MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&
   // the head panel (16 groups) follows the last trunk layer contiguously; behind it comes `follow`'s first panel
   const Next hd{16, nullptr, follow.groups, follow.jump};
   trunk<8, kKsNofXyz, true>(net, D, act, xhi, xlo, st, carry, id,
-                            [&](int l) { return l == D - 1 ? hd : next_trunk_bf<8, kKsNofXyz, true>(net, l + 1); }, rb, rbp);
+                            [&](int l) { return l == D - 1 ? hd : next_trunk_bf<8, kKsNofXyz, true>(net, l + 1); }, rb, rbp, after_first);
   // head on the matrix pipe (16 MFMAs instead of 9 x 64 dependent FMAs + 144 LDS reads per lane); T[0..3] come
   // out in half 0's registers 0-3, T[4..7] in half 1's registers 0-3, T[8] in half 0's register 4
   f32x16 acc;

@@ -186,7 +186,7 @@ struct NetLayout {
   int extra_steps;         // NeRF extra_encoding: k-steps of the extra block (0, 4, 8); -1 = no extra layer
   int64_t res_bytes;       // resident block size (multiple of 1 KiB)
   int64_t panel_bytes;     // all panels
-  int64_t ind_bytes;       // bf16 NoF: fp32 image-index columns [embedded layer][row][kNofIndCols] behind the panels
+  int64_t ind_bytes;       // bf16 NoF: fp32 image-index columns [embedded layer][kNofIndCols][row] behind the panels
   int n_emb_layers;        // layers that consume the embedded input (popcount of emb_mask)
   int max_groups;          // largest panel, in groups
   // resident block float offsets

@@ -125,8 +125,9 @@ __global__ void pack_resident_kernel(ResJob job) {
   job.res[idx] = v;
 }
 
-// bf16 NoF: the fp32 image-index columns of the layers that consume the embedded input, [embedded layer][row][kNofIndCols]
-// (what nof_raybias_kernel contracts with emb(ind) once per ray)
+// bf16 NoF: the fp32 image-index columns of the layers that consume the embedded input, TRANSPOSED:
+// [embedded layer][column (kNofIndCols)][row] -- what nof_raybias_kernel contracts with emb(ind) once per ray, one thread
+// per row reading its column entries coalesced
 struct IndJob { const float* W[MF_MAX_LAYERS]; int n_in[MF_MAX_LAYERS]; int n_layers, rows, col0, cols; float* dst; };
 
 __global__ void pack_ind_kernel(IndJob job) {
@@ -134,7 +135,7 @@ __global__ void pack_ind_kernel(IndJob job) {
   const int per_layer = job.rows * kNofIndCols;
   if (idx >= job.n_layers * per_layer) return;
   const int e = idx / per_layer, r = (idx % per_layer) / kNofIndCols, c = idx % kNofIndCols;
-  job.dst[idx] = c < job.cols ? job.W[e][(long long)r * job.n_in[e] + job.col0 + c] : 0.f;
+  job.dst[(e * kNofIndCols + c) * job.rows + r] = c < job.cols ? job.W[e][(long long)r * job.n_in[e] + job.col0 + c] : 0.f;
 }
 
 static int launch_pack(const PackJob& job, const ResJob& rj, hipStream_t st) {

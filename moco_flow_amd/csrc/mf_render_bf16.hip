@@ -31,12 +31,13 @@ struct Params {
   int pow2;                        // bit t: table t's frequencies are exactly 2^k (the logscale default)
   const float* raybias;            // MOCO: (n_rays, rb_combos, rb_layers, 128) per-ray NoF biases (nof_raybias_kernel)
   int rb_combos, rb_layers;
+  uint32_t rb_off, rb_buf_bytes;   // LDS: two buffers of the current / next chain step's rows of the tile's rays
 };
 
 // ---- per-ray bias of the NoF's embedded-input layers (models/rendering.py:73-75 + models/nof.py:69-73) ----
 // The NoF's input is [emb(xyz) 33 | emb(ind) 33] and the image index is one number per ray, so in every layer l that
-// consumes the embedded input  b_l + W_l[:, 33:66] emb(ind)  is constant along the ray.  One workgroup per (entry,
-// combination) evaluates it once in exact fp32 -- emb(ind) with OCML sincosf on the fp32-rounded argument 2^k ind, as
+// consumes the embedded input  b_l + W_l[:, 33:66] emb(ind)  is constant along the ray.  nof_raybias_kernel evaluates it
+// once per (entry, combination) in exact fp32 -- emb(ind) with OCML sincosf on the fp32-rounded argument 2^k ind, as
 // embedding.py:45 does, 33 FMAs per row -- and the render kernel starts those layers' accumulators from it: the image
 // index never enters the matrix pipe (2 of the 5 split k-steps of layer 0 and of the skip layer, 48 of 232 MFMAs per
 // evaluation, and the 18 sin / cos of 2^15-sized arguments per lane are gone).
@@ -48,7 +49,7 @@ struct RayBiasParams {
   long long n_entries;
   int n_combos;
   const float* bias[4];            // per combination: the network's [layer][128] trunk biases (its resident block)
-  const float* wind[4];            //                  its [embedded layer][128][kNofIndCols] index columns
+  const float* wind[4];            //                  its [embedded layer][kNofIndCols][128] index columns
   uint32_t emb_mask[4];
   int col[4];
   int n_layers;                    // embedded layers per network
@@ -56,29 +57,35 @@ struct RayBiasParams {
   float* out;                      // (n_entries, n_combos, n_layers, 128)
 };
 
+constexpr int kRbEntries = 16;      // entries (rays) per workgroup of nof_raybias_kernel
+
+// grid (ceil(n_entries / 16), n_combos), 256 threads.  Phase 1: thread (entry e, frequency k) -> one exact sincosf into
+// the LDS copy of emb(ind) of the block's 16 entries.  Phase 2: thread (embedded layer, row) keeps its 33 index-column
+// weights + bias in registers (coalesced: the packed block is [layer][column][row]) and contracts them with the 16
+// embeddings (LDS broadcasts); the 128-float rows go out coalesced.
 __global__ __launch_bounds__(256) void nof_raybias_kernel(const RayBiasParams p) {
-  __shared__ float e[kNofIndCols];
-  const long long entry = blockIdx.x / p.n_combos;
-  const int c = blockIdx.x % p.n_combos;
+  __shared__ float e[kRbEntries][kNofIndCols];
+  const int c = blockIdx.y;
+  const long long entry0 = (long long)blockIdx.x * kRbEntries;
   const int tid = threadIdx.x;
   // the by-value argument is indexed with constants only (a runtime index would put a private copy in scratch)
   const float* s_bias = c == 0 ? p.bias[0] : (c == 1 ? p.bias[1] : (c == 2 ? p.bias[2] : p.bias[3]));
   const float* s_wind = c == 0 ? p.wind[0] : (c == 1 ? p.wind[1] : (c == 2 ? p.wind[2] : p.wind[3]));
   const uint32_t s_mask = c == 0 ? p.emb_mask[0] : (c == 1 ? p.emb_mask[1] : (c == 2 ? p.emb_mask[2] : p.emb_mask[3]));
   const int col = c == 0 ? p.col[0] : (c == 1 ? p.col[1] : (c == 2 ? p.col[2] : p.col[3]));
-  const float ind = p.ind ? p.ind[entry * p.ind_stride + col] : p.ind_scalar;
-  if (tid < kNofIndCols) e[tid] = 0.f;
-  __syncthreads();
-  if (tid == 0) e[0] = ind;
-  if (tid >= 32 && tid < 48) {                              // column order of embedding.py:42-46 with C = 1
-    const int k = tid - 32;
+  {
+    const int le = tid >> 4, k = tid & 15;                  // column order of embedding.py:42-46 with C = 1
+    const long long entry = entry0 + le < p.n_entries ? entry0 + le : p.n_entries - 1;
+    const float ind = p.ind ? p.ind[entry * p.ind_stride + col] : p.ind_scalar;
     const typedef_kptr ka = (typedef_kptr)__builtin_amdgcn_kernarg_segment_ptr();
     const float fr = ((const __attribute__((address_space(4))) float*)(ka + offsetof(RayBiasParams, freq)))[k];
     const float w = ((const __attribute__((address_space(4))) float*)(ka + offsetof(RayBiasParams, weight)))[k];
     float sn, cs;
     sincosf(fr * ind, &sn, &cs);
-    e[1 + 2 * k] = w * sn;
-    e[2 + 2 * k] = w * cs;
+    e[le][1 + 2 * k] = w * sn;
+    e[le][2 + 2 * k] = w * cs;
+    if (k == 0) e[le][0] = ind;
+    if (k < 3) e[le][33 + k] = 0.f;
   }
   __syncthreads();
   const int total = p.n_layers * 128;
@@ -87,12 +94,43 @@ __global__ __launch_bounds__(256) void nof_raybias_kernel(const RayBiasParams p)
     int layer = 0, seen = 0;                                // the el-th set bit of emb_mask
     for (uint32_t m = s_mask; m; m >>= 1, ++layer)
       if (m & 1u) { if (seen == el) break; ++seen; }
-    float acc = s_bias[layer * 128 + row];
-    const float* w = s_wind + (size_t)(el * 128 + row) * kNofIndCols;
+    const float bias = s_bias[layer * 128 + row];
+    float w[33];
 #pragma unroll
-    for (int k = 0; k < 33; ++k) acc = __builtin_fmaf(w[k], e[k], acc);
-    p.out[((size_t)(entry * p.n_combos + c) * p.n_layers + el) * 128 + row] = acc;
+    for (int k = 0; k < 33; ++k) w[k] = s_wind[(size_t)(el * kNofIndCols + k) * 128 + row];
+    for (int le = 0; le < kRbEntries && entry0 + le < p.n_entries; ++le) {
+      float acc = bias;
+#pragma unroll
+      for (int k = 0; k < 33; ++k) acc = __builtin_fmaf(w[k], e[le][k], acc);
+      p.out[((size_t)((entry0 + le) * p.n_combos + c) * p.n_layers + el) * 128 + row] = acc;
+    }
   }
+}
+
+// LDS-DMA of the per-ray bias rows one chain step of one tile needs: rays [ray_first, ray_first + n) of combination
+// `combo`, entry = [embedded layer][128] floats, to `dst` (ray-major).  Pieces of 1 KiB round-robin over the waves; every
+// panel barrier behind the issue publishes them (Stream::sync waits vmcnt(0) first), so the issue sits at least one panel
+// in front of the first read and behind the last read of the buffer's previous content (see the call sites).
+MF_D void stage_raybias(const float* table, int combos, int layers, long long ray_first, int n, int combo, uint32_t dst,
+                        const Lane& id) {
+  const uint32_t entry = (uint32_t)layers * 512u, chunk = (uint32_t)n * entry;
+  const char* base = reinterpret_cast<const char*>(table) + ((size_t)ray_first * combos + combo) * entry;
+  for (uint32_t q = id.wave; q * 1024u < chunk; q += kWaves) {
+    uint32_t b = q * 1024u + id.lane * 16u;
+    b = b < chunk ? b : chunk - 16u;                       // (tail lanes re-fetch the last 16 bytes into the padding)
+    const uint32_t r = b / entry;
+    blds16(base, r * (uint32_t)combos * entry + (b - r * entry), 0, dst + q * 1024u);
+  }
+}
+template <class P>
+MF_D void stage_raybias(const P& p, long long ray_first, int n, int combo, uint32_t dst, const Lane& id) {
+  stage_raybias(p.raybias, p.rb_combos, p.rb_layers, ray_first, n, combo, dst, id);
+}
+// rays [first, first + n) touched by tile `tile` of a group of `nr` rays
+MF_D void tile_rays(int tile, int nr, int S, int& first, int& n) {
+  const int s0 = tile * bf::kTile, s1 = (s0 + bf::kTile < nr * S ? s0 + bf::kTile : nr * S) - 1;
+  first = s0 / S;
+  n = s1 / S - first + 1;
 }
 
 template <bool MOCO>
@@ -115,6 +153,14 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
   st.tl.start(p.alphas, id);
   Carry carry;
   const Next prog_first = MOCO ? first_of<8, kKsNofXyz, true>(p.bw) : first_of<16, kKsNerfXyz, false>(p.nerf);
+  int seq = 0;                       // NoF evaluations done by this workgroup: evaluation number `seq` reads buffer seq & 1
+  if (MOCO) {                        // rows of the first evaluation (first group, tile 0, bw at index i)
+    const long long g0 = blockIdx.x;
+    const int nr0 = (int)((p.n_rays - g0 * p.G) < p.G ? (p.n_rays - g0 * p.G) : p.G);
+    int f0, n0;
+    tile_rays(0, nr0, p.S, f0, n0);
+    stage_raybias(p, g0 * p.G + f0, n0, 0, p.rb_off, id);
+  }
   if (MOCO) start_program<8, kKsNofXyz, true>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);   // (its wait + barrier also publish the resident blocks / tables)
   else start_program<16, kKsNerfXyz, false>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
 
@@ -169,10 +215,12 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
           const int role = step;
           const bool use_fw = (role == 1 || role == 2 || role == 4);
           const Net net = use_fw ? p.fw : p.bw;
-          // per-ray bias of this (network, image index): table rows bw(i), fw(i), fw(j), bw(j); the final fw(i) is row 1
-          const float* rbp = p.raybias + ((size_t)ray * p.rb_combos + (role == 4 ? 1 : role)) * (size_t)(p.rb_layers * 128) + 4 * id.h;
-          RayBias rb;
-          load_raybias(rb, rbp, 0);                    // in flight across the encoding
+          // per-ray bias of this (network, image index): rows bw(i), fw(i), fw(j), bw(j) of the table (the final fw(i) is
+          // row 1), staged in LDS one evaluation ahead
+          int tf, tn;
+          tile_rays(tile, nr, S, tf, tn);
+          LdsRayBias rb{p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes + (uint32_t)(rr - tf) * (uint32_t)(p.rb_layers * 512)};
+          ++seq;
           if (role == 1 || role == 2) { cur[0] = canon[0]; cur[1] = canon[1]; cur[2] = canon[2]; }
           const bool last = step == nsteps - 1;
           const bool next_fw = (role + 1 == 1 || role + 1 == 2 || role + 1 == 4);
@@ -180,7 +228,9 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
           u32x4 nhi[kKsNofXyz], nlo[kKsNofXyz];
           float out[3];
           nof_embed(nhi, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
-          nof_eval(net, nhi, nlo, cur, st, carry, id, follow, out, rb, rbp);
+          nof_eval(net, nhi, nlo, cur, st, carry, id, follow, out, rb, nullptr, [&] {
+            if (!last) stage_raybias(p, ray0 + tf, tn, role + 1 == 4 ? 1 : role + 1, p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes, id);
+          });
           if (role == 0) { canon[0] = out[0]; canon[1] = out[1]; canon[2] = out[2]; }
           if (role == 1) dl = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
           if (role == 4) dg = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
@@ -193,6 +243,19 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
         }
       }
 
+      if (MOCO) {
+        // rows of the NEXT tile's first evaluation (next tile of this group, or tile 0 of this workgroup's next group) into
+        // the buffer the evaluation before the last one read: every wave is past that one (it has arrived at the last
+        // evaluation's barriers), and the whole NeRF lies between this issue and the first read
+        const bool more = tile + 1 < ntiles;
+        const long long ng = more ? group : group + gridDim.x;
+        if (ng < p.n_groups) {
+          const int nnr = (int)((p.n_rays - ng * p.G) < p.G ? (p.n_rays - ng * p.G) : p.G);
+          int nf, nn;
+          tile_rays(more ? tile + 1 : 0, nnr, S, nf, nn);
+          stage_raybias(p, ng * p.G + nf, nn, 0, p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes, id);
+        }
+      }
       st.tl.stamp(3, id);
       u32x4 xe[kKsNerfXyz];
       {
@@ -309,13 +372,17 @@ struct PointsParamsBf {
   int pow2;
   const float* raybias;            // NOF: (B | 1, rb_layers, 128) per-point (ind given) or single (ind_scalar) NoF biases
   int rb_layers;
+  uint32_t rb_off;                 // LDS: the single entry (ind_scalar)
 };
 
-template <bool NOF>
+// PERPT: an image index per point -- each lane fetches its own bias rows from the global table (register sets, RayBias);
+// otherwise the one entry of ind_scalar sits in LDS for the whole launch.
+template <bool NOF, bool PERPT = false>
 __global__ __launch_bounds__(kThreads, 2) void points_kernel_bf16(const PointsParamsBf p) {
   const Lane id;
   load_resident(p.nerf, id);
   if (NOF) load_resident(p.bw, id);
+  if (NOF && !PERPT) stage_raybias(p.raybias, 1, p.rb_layers, 0, 1, 0, p.rb_off, id);
   if (threadIdx.x < 128) {
     typedef const __attribute__((address_space(4))) char* kptr;
     const kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(PointsParamsBf, emb_par);
@@ -335,13 +402,19 @@ __global__ __launch_bounds__(kThreads, 2) void points_kernel_bf16(const PointsPa
     const long long bb = valid ? b : p.B - 1;
     float x[3] = {p.xyz[bb * 3 + 0], p.xyz[bb * 3 + 1], p.xyz[bb * 3 + 2]};
     if (NOF) {
-      const float* rbp = p.raybias + (p.ind ? (size_t)bb : (size_t)0) * (size_t)(p.rb_layers * 128) + 4 * id.h;
-      RayBias rb;
-      load_raybias(rb, rbp, 0);
       u32x4 nhi[kKsNofXyz], nlo[kKsNofXyz];
       float out[3];
-      nof_embed(nhi, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
-      nof_eval(p.bw, nhi, nlo, x, st, carry, id, first_of<16, kKsNerfXyz, false>(p.nerf), out, rb, rbp);
+      if constexpr (PERPT) {
+        const float* rbp = p.raybias + (size_t)bb * (size_t)(p.rb_layers * 128) + 4 * id.h;
+        RayBias rb;
+        load_raybias(rb, rbp, 0);                      // in flight across the encoding
+        nof_embed(nhi, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
+        nof_eval(p.bw, nhi, nlo, x, st, carry, id, first_of<16, kKsNerfXyz, false>(p.nerf), out, rb, rbp, [] {});
+      } else {
+        LdsRayBias rb{p.rb_off};
+        nof_embed(nhi, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
+        nof_eval(p.bw, nhi, nlo, x, st, carry, id, first_of<16, kKsNerfXyz, false>(p.nerf), out, rb, nullptr, [] {});
+      }
       x[0] = out[0]; x[1] = out[1]; x[2] = out[2];
       if (valid && id.h == 0 && p.canon) {
         p.canon[b * 3 + 0] = x[0]; p.canon[b * 3 + 1] = x[1]; p.canon[b * 3 + 2] = x[2];
@@ -450,7 +523,7 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st) {
     if (need > 0 && (!a->workspace || a->workspace_bytes < need))
       return fail(MF_E_INVALID, "mf_render_pass(bf16): workspace of %lld bytes needed (mf_render_workspace_bytes), got %lld",
                   (long long)need, (long long)(a->workspace ? a->workspace_bytes : 0));
-    if (a->n_rays * (int64_t)combos > 0x7fffffffLL) return fail(MF_E_UNSUPPORTED, "mf_render_pass(bf16): too many rays for one launch");
+    if (a->n_rays > 0x7fffffffLL) return fail(MF_E_UNSUPPORTED, "mf_render_pass(bf16): too many rays for one launch");
     p.raybias = static_cast<const float*>(a->workspace);
     p.rb_combos = combos; p.rb_layers = layers;
     if (a->n_rays > 0) {
@@ -464,13 +537,22 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st) {
       }
       for (int k = 0; k < 16; ++k) { r.freq[k] = p.emb_par[3][k]; r.weight[k] = p.emb_par[3][16 + k]; }
       r.out = static_cast<float*>(a->workspace);
-      hipLaunchKernelGGL(nof_raybias_kernel, dim3((unsigned)(a->n_rays * combos)), dim3(256), 0, st, r);
+      hipLaunchKernelGGL(nof_raybias_kernel, dim3((unsigned)((a->n_rays + kRbEntries - 1) / kRbEntries), combos), dim3(256), 0, st, r);
     }
   }
   p.par_off = lds; lds += 512;
   p.ring_off = lds;
   p.buf_bytes = (uint32_t)max_groups * kGroupBytes;
   lds += 3 * p.buf_bytes;
+  if (moco) {
+    // two buffers of per-ray bias rows: a 256-sample tile touches at most (255 / S) + 2 rays
+    const int r_max = (bf::kTile - 1) / a->n_samples + 2;
+    p.rb_buf_bytes = (uint32_t)round_up((int64_t)r_max * p.rb_layers * 512, 1024);
+    p.rb_off = lds; lds += 2 * p.rb_buf_bytes;
+    if (lds + 20u * (uint32_t)a->n_samples > 160u * 1024u)
+      return fail(MF_E_UNSUPPORTED, "mf_render_pass(bf16): n_samples=%d leaves no room for the per-ray NoF bias rows of a tile "
+                  "(%d rays); use MF_PREC_F32 for such short rays", a->n_samples, r_max);
+  }
 
   // rays per group: smallest G with G*S a multiple of the 256-sample tile, capped by the LDS left
   const uint32_t lds_cap = 160 * 1024;
@@ -551,17 +633,19 @@ int points_sigma_bf16(const mf_nerf_desc* nerf, const void* nerf_packed, const m
       raybias_combo(r, 0, nof_packed, Lb, 0);
       for (int k = 0; k < 16; ++k) { r.freq[k] = p.emb_par[3][k]; r.weight[k] = p.emb_par[3][16 + k]; }
       r.out = static_cast<float*>(workspace);
-      hipLaunchKernelGGL(nof_raybias_kernel, dim3((unsigned)entries), dim3(256), 0, st, r);
+      hipLaunchKernelGGL(nof_raybias_kernel, dim3((unsigned)((entries + kRbEntries - 1) / kRbEntries), 1), dim3(256), 0, st, r);
     }
   }
   p.par_off = lds; lds += 512;
   p.ring_off = lds;
   p.buf_bytes = (uint32_t)max_groups * kGroupBytes;
   lds += 3 * p.buf_bytes;
+  if (nof) { p.rb_off = lds; lds += (uint32_t)round_up((int64_t)Lb.n_emb_layers * 512, 1024); }
   p.xyz = xyz; p.ind = ind; p.ind_scalar = ind_scalar; p.B = B; p.sigma = sigma; p.canon = canon;
   const long long ntiles = (B + bf::kTile - 1) / bf::kTile;
   const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
-  void (*kern)(const PointsParamsBf) = nof ? points_kernel_bf16<true> : points_kernel_bf16<false>;
+  void (*kern)(const PointsParamsBf) = nof ? (ind ? points_kernel_bf16<true, true> : points_kernel_bf16<true, false>)
+                                           : points_kernel_bf16<false>;
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(MF_E_LAUNCH, "mf_points_sigma: cannot reserve %u bytes of LDS", lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, p);
