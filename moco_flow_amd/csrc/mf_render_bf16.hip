@@ -98,6 +98,9 @@ __global__ __launch_bounds__(256) void nof_raybias_kernel(const RayBiasParams p)
     float w[33];
 #pragma unroll
     for (int k = 0; k < 33; ++k) w[k] = s_wind[(size_t)(el * kNofIndCols + k) * 128 + row];
+    // (no loop vectorisation: it pairs two entries into v_pk_fma_f32, and this unit is kept free of packed-fp32 ops,
+    //  csrc/Makefile)
+#pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
     for (int le = 0; le < kRbEntries && entry0 + le < p.n_entries; ++le) {
       float acc = bias;
 #pragma unroll
