@@ -33,7 +33,7 @@ extern "C" {
  * 10: mf_nerf_forward_dump, mf_render_args.dump_nof_* (+ mf_nof_emb_slot_features), mf_smpl_lbs,
  *     mf_smpl_frame_transforms, mf_apply_vertex_transforms
  * 12: MF_PREC_BF16 NoF takes its image-index block as a per-ray fp32 bias: mf_render_args.workspace(+_bytes),
- *     mf_render_workspace_bytes, mf_points_sigma_workspace_bytes, workspace arguments of mf_points_sigma_p */
+ *     mf_render_workspace_bytes, mf_render_prepare, mf_points_sigma_workspace_bytes, workspace arguments of mf_points_sigma_p */
 #define MF_ABI_VERSION 12
 
 enum {
@@ -307,14 +307,18 @@ typedef struct mf_render_args {
   float* dump_nof_emb;
   float* dump_nof_out;
   int32_t dump_nof_plane[5];
-  /* MF_PREC_BF16 with NoF (ABI v12): caller-allocated device scratch of mf_render_workspace_bytes(a) bytes.  It receives,
+  /* MF_PREC_BF16 with NoF (ABI v12): caller-allocated device scratch of mf_render_workspace_bytes(a) bytes holding,
    * per ray and (network, image index) combination of the chain program, the fp32 vectors  b_l + W_l[:, 33:66] emb(ind)
    * of the NoF layers that consume the embedded input (models/rendering.py:73-75, models/nof.py:69-73: the index block
-   * is constant along a ray), written by a small launch in front of the fused one and read by it as the accumulators'
-   * initial values.  Ignored (may be NULL) otherwise. */
+   * is constant along a ray).  mf_render_prepare fills it (one small launch); mf_render_pass reads it as those layers'
+   * initial accumulator values.  Ignored (may be NULL) otherwise. */
   void* workspace; int64_t workspace_bytes;
 } mf_render_args;
 
+/* mf_render_prepare(a) must have run on the same stream with the same rays / NoFs / nof_emb_ind / chain flags whenever
+ * mf_render_workspace_bytes(a) > 0; the coarse and the fine pass of one render_rays call share one prepared workspace
+ * (same rays, same NoFs).  A no-op (MF_OK) when no workspace is needed. */
+int32_t mf_render_prepare(const mf_render_args* a, void* stream);
 int32_t mf_render_pass(const mf_render_args* a, void* stream);
 int64_t mf_render_workspace_bytes(const mf_render_args* a);
 

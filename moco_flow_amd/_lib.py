@@ -112,6 +112,7 @@ SYMBOLS = {
     "mf_nerf_backward": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, C.c_int64, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp]),
     "mf_render_pass": (C.c_int32, [C.POINTER(mf_render_args), _fp]),
     "mf_render_workspace_bytes": (C.c_int64, [C.POINTER(mf_render_args)]),
+    "mf_render_prepare": (C.c_int32, [C.POINTER(mf_render_args), _fp]),
     "mf_points_sigma_workspace_bytes": (C.c_int64, [C.c_int32, C.POINTER(mf_nof_desc), C.c_int32, C.c_int64]),
     "mf_points_sigma": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, C.POINTER(mf_embedding), C.POINTER(mf_nof_desc), _fp,
                                     C.POINTER(mf_embedding), C.POINTER(mf_embedding), _fp, _fp, C.c_float, C.c_int64,

@@ -286,7 +286,7 @@ static void to_table(const mf_embedding& e, float* o) {
 }
 
 int device_cus();   // mf_forward.hip
-int render_pass_bf16(const mf_render_args* a, hipStream_t st);   // mf_render_bf16.hip
+int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only);   // mf_render_bf16.hip
 int64_t render_workspace_bytes_bf16(const mf_render_args* a);
 
 }  // namespace mf
@@ -305,7 +305,11 @@ extern "C" int32_t mf_nof_emb_slot_features(int32_t* features80) {
   return MF_OK;
 }
 
-extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
+static int32_t render_entry(const mf_render_args* a, void* stream, bool prepare_only);
+extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) { return render_entry(a, stream, false); }
+extern "C" int32_t mf_render_prepare(const mf_render_args* a, void* stream) { return render_entry(a, stream, true); }
+
+static int32_t render_entry(const mf_render_args* a, void* stream, bool prepare_only) {
   if (!a || !a->nerf || !a->nerf_packed) return fail(MF_E_INVALID, "mf_render_pass: null argument");
   if (a->n_rays < 0 || a->n_samples < 1) return fail(MF_E_INVALID, "mf_render_pass: n_rays=%lld n_samples=%d",
                                                     (long long)a->n_rays, a->n_samples);
@@ -374,7 +378,8 @@ extern "C" int32_t mf_render_pass(const mf_render_args* a, void* stream) {
     to_table(a->nof_emb_xyz, p.emb_par[2]);
     to_table(a->nof_emb_ind, p.emb_par[3]);
   }
-  if (bf16) return render_pass_bf16(a, static_cast<hipStream_t>(stream));     // validated above; own layout / launch
+  if (bf16) return render_pass_bf16(a, static_cast<hipStream_t>(stream), prepare_only);     // validated above; own layout / launch
+  if (prepare_only) return MF_OK;
   p.par_off = lds; lds += 512;
   p.ring_off = lds;
   p.buf_bytes = (uint32_t)max_groups * kGroupBytes;

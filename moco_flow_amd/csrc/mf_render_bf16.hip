@@ -57,12 +57,13 @@ struct RayBiasParams {
   float* out;                      // (n_entries, n_combos, n_layers, 128)
 };
 
-constexpr int kRbEntries = 16;      // entries (rays) per workgroup of nof_raybias_kernel
+constexpr int kRbEntries = 8;       // entries (rays) per workgroup of nof_raybias_kernel
 
-// grid (ceil(n_entries / 16), n_combos), 256 threads.  Phase 1: thread (entry e, frequency k) -> one exact sincosf into
-// the LDS copy of emb(ind) of the block's 16 entries.  Phase 2: thread (embedded layer, row) keeps its 33 index-column
-// weights + bias in registers (coalesced: the packed block is [layer][column][row]) and contracts them with the 16
-// embeddings (LDS broadcasts); the 128-float rows go out coalesced.
+// grid (ceil(n_entries / 8), n_combos), 256 threads.  Thread (embedded layer, row) first requests its 33 index-column
+// weights + bias (coalesced: the packed block is [layer][column][row]); while they travel, threads (entry e, frequency k)
+// do one exact sincosf each into the LDS copy of emb(ind) of the block's 8 entries; then every thread contracts its
+// weights with the 8 embeddings (LDS broadcasts) and the 128-float rows go out coalesced.  (A latency chain of two
+// dependent memory round trips and ~300 FMAs: short blocks, many of them.)
 __global__ __launch_bounds__(256) void nof_raybias_kernel(const RayBiasParams p) {
   __shared__ float e[kRbEntries][kNofIndCols];
   const int c = blockIdx.y;
@@ -73,31 +74,42 @@ __global__ __launch_bounds__(256) void nof_raybias_kernel(const RayBiasParams p)
   const float* s_wind = c == 0 ? p.wind[0] : (c == 1 ? p.wind[1] : (c == 2 ? p.wind[2] : p.wind[3]));
   const uint32_t s_mask = c == 0 ? p.emb_mask[0] : (c == 1 ? p.emb_mask[1] : (c == 2 ? p.emb_mask[2] : p.emb_mask[3]));
   const int col = c == 0 ? p.col[0] : (c == 1 ? p.col[1] : (c == 2 ? p.col[2] : p.col[3]));
-  {
+  const int n_out = p.n_layers * 128;
+  const int o = tid < n_out ? tid : n_out - 1;              // (layers beyond the first two: the loop below)
+  const int el0 = o >> 7, row0 = o & 127;
+  auto layer_of = [&](int el) {                             // the el-th set bit of emb_mask
+    int layer = 0, seen = 0;
+    for (uint32_t m = s_mask; m; m >>= 1, ++layer)
+      if (m & 1u) { if (seen == el) break; ++seen; }
+    return layer;
+  };
+  float w[33];
+  float bias = s_bias[layer_of(el0) * 128 + row0];
+#pragma unroll
+  for (int k = 0; k < 33; ++k) w[k] = s_wind[(size_t)(el0 * kNofIndCols + k) * 128 + row0];
+  if (tid < kRbEntries * 16) {
     const int le = tid >> 4, k = tid & 15;                  // column order of embedding.py:42-46 with C = 1
     const long long entry = entry0 + le < p.n_entries ? entry0 + le : p.n_entries - 1;
     const float ind = p.ind ? p.ind[entry * p.ind_stride + col] : p.ind_scalar;
     const typedef_kptr ka = (typedef_kptr)__builtin_amdgcn_kernarg_segment_ptr();
     const float fr = ((const __attribute__((address_space(4))) float*)(ka + offsetof(RayBiasParams, freq)))[k];
-    const float w = ((const __attribute__((address_space(4))) float*)(ka + offsetof(RayBiasParams, weight)))[k];
+    const float wk = ((const __attribute__((address_space(4))) float*)(ka + offsetof(RayBiasParams, weight)))[k];
     float sn, cs;
     sincosf(fr * ind, &sn, &cs);
-    e[le][1 + 2 * k] = w * sn;
-    e[le][2 + 2 * k] = w * cs;
+    e[le][1 + 2 * k] = wk * sn;
+    e[le][2 + 2 * k] = wk * cs;
     if (k == 0) e[le][0] = ind;
     if (k < 3) e[le][33 + k] = 0.f;
   }
   __syncthreads();
-  const int total = p.n_layers * 128;
-  for (int o = tid; o < total; o += 256) {
-    const int el = o >> 7, row = o & 127;
-    int layer = 0, seen = 0;                                // the el-th set bit of emb_mask
-    for (uint32_t m = s_mask; m; m >>= 1, ++layer)
-      if (m & 1u) { if (seen == el) break; ++seen; }
-    const float bias = s_bias[layer * 128 + row];
-    float w[33];
+  for (int ob = 0; ob < n_out; ob += 256) {
+    const int oo = ob + tid;
+    if (ob > 0 && oo < n_out) {                             // (more than two embedded layers: reload this thread's row)
+      bias = s_bias[layer_of(oo >> 7) * 128 + (oo & 127)];
 #pragma unroll
-    for (int k = 0; k < 33; ++k) w[k] = s_wind[(size_t)(el * kNofIndCols + k) * 128 + row];
+      for (int k = 0; k < 33; ++k) w[k] = s_wind[(size_t)((oo >> 7) * kNofIndCols + k) * 128 + (oo & 127)];
+    }
+    if (oo >= n_out) break;
     // (no loop vectorisation: it pairs two entries into v_pk_fma_f32, and this unit is kept free of packed-fp32 ops,
     //  csrc/Makefile)
 #pragma clang loop vectorize(disable) interleave(disable) unroll(disable)
@@ -105,7 +117,7 @@ __global__ __launch_bounds__(256) void nof_raybias_kernel(const RayBiasParams p)
       float acc = bias;
 #pragma unroll
       for (int k = 0; k < 33; ++k) acc = __builtin_fmaf(w[k], e[le][k], acc);
-      p.out[((size_t)((entry0 + le) * p.n_combos + c) * p.n_layers + el) * 128 + row] = acc;
+      p.out[((size_t)((entry0 + le) * p.n_combos + c) * p.n_layers + (oo >> 7)) * 128 + (oo & 127)] = acc;
     }
   }
 }
@@ -477,8 +489,9 @@ int64_t render_workspace_bytes_bf16(const mf_render_args* a) {
   return (int64_t)a->n_rays * combos * layers * 128 * 4;
 }
 
-// called by mf_render_pass (mf_render.hip) after argument validation, precision == MF_PREC_BF16
-int render_pass_bf16(const mf_render_args* a, hipStream_t st) {
+// called by mf_render_pass / mf_render_prepare (mf_render.hip) after argument validation, precision == MF_PREC_BF16.
+// prepare_only: fill the workspace (the per-ray NoF bias table) and return; else: the fused launch, which reads it.
+int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only) {
   using namespace bf;
   Params p{};
   NetLayout Ln, Lb, Lf;
@@ -529,7 +542,7 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st) {
     if (a->n_rays > 0x7fffffffLL) return fail(MF_E_UNSUPPORTED, "mf_render_pass(bf16): too many rays for one launch");
     p.raybias = static_cast<const float*>(a->workspace);
     p.rb_combos = combos; p.rb_layers = layers;
-    if (a->n_rays > 0) {
+    if (a->n_rays > 0 && prepare_only) {
       RayBiasParams r{};
       r.ind = a->rays; r.ind_stride = a->ray_stride; r.n_entries = a->n_rays; r.n_combos = combos; r.n_layers = layers;
       raybias_combo(r, 0, a->nof_bw_packed, Lb, 8);
@@ -543,6 +556,7 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st) {
       hipLaunchKernelGGL(nof_raybias_kernel, dim3((unsigned)((a->n_rays + kRbEntries - 1) / kRbEntries), combos), dim3(256), 0, st, r);
     }
   }
+  if (prepare_only) return moco ? check_launch("mf_render_prepare") : MF_OK;
   p.par_off = lds; lds += 512;
   p.ring_off = lds;
   p.buf_bytes = (uint32_t)max_groups * kGroupBytes;

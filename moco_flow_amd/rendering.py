@@ -54,8 +54,12 @@ def _emb_desc(e):
 
 
 def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation, nerf, nerf_embs,
-                 nof_models, nof_embs, chain_local, chain_global, sigma_only, want_planes, dump=False, precision=None):
-    """One mf_render_pass call. Returns dict of fresh tensors.  ``precision``: None = the module setting."""
+                 nof_models, nof_embs, chain_local, chain_global, sigma_only, want_planes, dump=False, precision=None,
+                 workspace=None):
+    """One mf_render_pass call. Returns dict of fresh tensors.  ``precision``: None = the module setting.
+    ``workspace``: a one-element list shared by the passes of one render_rays call -- the first pass that needs the bf16
+    NoF's per-ray bias table allocates and fills it (mf_render_prepare), the next pass (same rays, same NoFs, same chain
+    flags) reuses it; None: prepare for this pass alone."""
     dev = rays.device
     N = rays.shape[0]
     S = z_vals.shape[1] if z_vals is not None else z_steps.shape[0]
@@ -129,11 +133,16 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
             a.dump_nof_emb = alloc("nof_emb", (steps, N * S, 80))
             a.dump_nof_out = alloc("nof_out", (steps, N * S, 3))
     need = int(L.lib().mf_render_workspace_bytes(C.byref(a)))      # bf16 + NoF: the per-ray bias table (ABI v12)
-    if need > 0:
-        ws = torch.empty(need, dtype=torch.uint8, device=dev)
-        a.workspace, a.workspace_bytes = ws.data_ptr(), need
-        keep.append(ws)
     with torch.cuda.device(dev):
+        if need > 0:
+            shared = workspace if workspace is not None else [None]
+            fresh = shared[0] is None or shared[0].numel() < need
+            if fresh:
+                shared[0] = torch.empty(need, dtype=torch.uint8, device=dev)
+            a.workspace, a.workspace_bytes = shared[0].data_ptr(), need
+            keep.append(shared[0])
+            if fresh:
+                L.check(L.lib().mf_render_prepare(C.byref(a), L.current_stream(dev)), "mf_render_prepare")
         L.check(L.lib().mf_render_pass(C.byref(a), L.current_stream(dev)), "mf_render_pass")
     del keep
     return out
@@ -332,10 +341,11 @@ def render_rays(rays,
                                       nof_models if use_nof else None, loc, glob, nerf_activate_type,
                                       coarse_sigma_only, z_vals, noise_c, N_importance, perturb == 0,
                                       lambda: draw_noise((N, S + N_importance), "noise_fine"), _rng.get("u"))
+    ws = [None]                     # bf16 + NoF: the per-ray bias table, filled by the first pass, shared with the second
     c = _render_pass(rays, background, z_vals, None if z_vals is not None else z_steps, use_disp,
                      noise_c, act, nerf_models[0], nerf_embeddings,
                      nof_models if use_nof else None, nof_embeddings, loc, glob, coarse_sigma_only, want_planes,
-                     dump=grad and not coarse_sigma_only, precision=pass_prec)
+                     dump=grad and not coarse_sigma_only, precision=pass_prec, workspace=ws)
     if coarse_sigma_only:
         result = {'opacity_coarse': c["opacity"]}
     else:
