@@ -41,7 +41,8 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOPS = {"nerf_dir": 1186816, "nerf_ind": 1181184, "nof_quat": 134400}   # per sample, SURVEY.md §8d
-PEAK = {"f32": 157.3, "bf16": 2516.0}     # TFLOP/s, MI355X_MICROARCH.md: fp32-input MFMA / dense bf16 MFMA
+PEAK = {"f32": 157.3, "bf16": 2516.0, "bf16x3": 2516.0}     # TFLOP/s, MI355X_MICROARCH.md: fp32-input MFMA / dense bf16 MFMA
+# (bf16x3 is priced on ALGORITHMIC flops against the bf16 peak like bf16: its extra products are its own overhead)
 
 CONFIGS = {
     "C2": dict(net="dir", precision="f32", rays=4096, S=64, M=0, nof=None,
@@ -52,6 +53,9 @@ CONFIGS = {
                 what="C3 chain in fp32 (bw NoF -> NeRF(ind) -> fw NoF, exact-fp32 MFMA; a kernel-tuning leg, not a BASELINE config)"),
     "C3": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="local",
                what="C3: bw NoF -> NeRF(ind) -> fw NoF local consensus chain, bf16 hidden GEMMs"),
+    "C3x": dict(net="ind", precision="bf16x3", rays=4096, S=64, M=0, nof="local",
+                what="C3 in the accuracy mode of the bf16 pipe (bf16x3: NoF hidden GEMMs + head as three-product splits, NeRF "
+                     "encodings split, last trunk layer with split weights, fp32 sigma head)"),
     "C3g": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="global",
                 what="C3 + global chain (5 NoF evaluations per sample), bf16 hidden GEMMs"),
     "C4": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="local", loss=True,
@@ -478,7 +482,7 @@ def worker(a):
         if k in res:
             line[k] = res[k]
     if not a.no_extra_legs and a.config == "C2":
-        legs = ["C3", "C3g", "C5"] if world == 1 else ["C4", "C5"]
+        legs = ["C3", "C3x", "C3g", "C5"] if world == 1 else ["C4", "C5"]
         line["configs"] = {}
         for name in legs:
             r = run_config(name, a, ctx, min(a.steps, 20), min(a.warmup, 3), main=False)

@@ -49,8 +49,12 @@ enum { MF_MAX_FREQS = 16, MF_MAX_LAYERS = 16 };
  * (the reference's arithmetic; BASELINE configs C1-C2).  BF16: hidden-layer weights and
  * activations rounded to bf16 (RNE), fp32 accumulate (v_mfma_f32_32x32x16_bf16, 32 samples per wave); the
  * embedded-input k-ranges and the NoF head use a two-term bf16 split (16 mantissa bits); biases, the NeRF
- * heads and the composite stay fp32 (BASELINE configs C3-C5). */
-enum { MF_PREC_F32 = 0, MF_PREC_BF16 = 1 };
+ * heads and the composite stay fp32 (BASELINE configs C3-C5).
+ * BF16X3 (ABI v12): the accuracy mode of the bf16 pipe for the MoCo chain, whose canonical point feeds sin(512 x): the
+ * NoF's hidden GEMMs and head as three bf16 products per term (activations AND weights split hi + lo, 16 mantissa
+ * bits), the NeRF's encodings split like the NoF's, its last trunk layer with split weights and the sigma head on that
+ * layer's fp32 accumulators; everything else as BF16.  ~1.4x the matrix work of BF16, still ~4x faster than F32. */
+enum { MF_PREC_F32 = 0, MF_PREC_BF16 = 1, MF_PREC_BF16X3 = 2 };
 
 /* ---- Embedding: models/embedding.py:4-47 ------------------------------------
  * out = [x, w0*sin(f0 x), w0*cos(f0 x), w1*sin(f1 x), ...]; freq[] are the module's

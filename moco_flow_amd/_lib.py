@@ -15,7 +15,8 @@ MF_MAX_LAYERS = 16
 MF_EXTRA_NONE, MF_EXTRA_IND, MF_EXTRA_DIR = 0, 1, 2
 MF_ACT_RELU, MF_ACT_SOFTPLUS = 0, 1
 MF_F_SIGMA_ONLY, MF_F_CHAIN_LOCAL, MF_F_CHAIN_GLOBAL = 1, 2, 4
-MF_PREC_F32, MF_PREC_BF16 = 0, 1
+MF_PREC_F32, MF_PREC_BF16, MF_PREC_BF16X3 = 0, 1, 2
+PRECISIONS = {"f32": MF_PREC_F32, "bf16": MF_PREC_BF16, "bf16x3": MF_PREC_BF16X3}
 MF_ABI_VERSION = 12
 
 LIB_PATH = os.environ.get("MOCOFLOW_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmocoflow_hip.so")   # (override: A/B builds)

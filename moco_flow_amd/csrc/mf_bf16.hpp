@@ -116,8 +116,13 @@ struct Net {
   uint32_t emb_mask;       // trunk layers that consume the embedded input (layer 0 + skips)
   int aux;                 // NeRF: k-steps of the extra block (0, 1, 2); NoF: head rows (3 | 9)
 };
-template <int KH, int EKS, bool SPLIT>
-MF_D int tgroups(const Net& n, int layer) { return (((n.emb_mask >> layer) & 1) ? (SPLIT ? 2 : 1) * EKS : 0) + (layer > 0 ? KH : 0); }
+// HS (MF_PREC_BF16X3): which layers' HIDDEN k-steps are (hi, lo) group pairs -- 0: none, 1: every layer (the NoF),
+// 2: the last trunk layer, n.D - 1 (the NeRF: the layer under the sigma head)
+template <int KH, int EKS, bool SPLIT, int HS = 0>
+MF_D int tgroups(const Net& n, int layer) {
+  const bool hs = HS == 1 || (HS == 2 && layer == n.D - 1);
+  return (((n.emb_mask >> layer) & 1) ? (SPLIT ? 2 : 1) * EKS : 0) + (layer > 0 ? (hs ? 2 : 1) * KH : 0);
+}
 
 // What follows the layer being computed in the panel program: its first panel (`groups`, at `jump` if the program
 // leaves the contiguous order there) and its second one (`groups2` / `jump2`: differ from the first when that layer
@@ -130,9 +135,9 @@ template <int KH, int EKS, bool SPLIT>
 MF_D Next first_of(const Net& n) {       // layer 0: embedded input only
   return Next{(SPLIT ? 2 : 1) * EKS, n.packed + n.res_bytes, (SPLIT ? 2 : 1) * EKS, nullptr};
 }
-template <int KH, int EKS, bool SPLIT>
+template <int KH, int EKS, bool SPLIT, int HS = 0>
 MF_D Next next_trunk_bf(const Net& n, int layer) {
-  return Next{tgroups<KH, EKS, SPLIT>(n, layer), nullptr, tgroups<KH, EKS, SPLIT>(n, layer), nullptr};
+  return Next{tgroups<KH, EKS, SPLIT, HS>(n, layer), nullptr, tgroups<KH, EKS, SPLIT, HS>(n, layer), nullptr};
 }
 
 struct Carry {            // the first PD fragments of the panel that follows, pre-read during the current one's tail
@@ -265,6 +270,9 @@ MF_D f32x16 head_tile(Carry& carry, const u32x4* hid, uint32_t p, uint32_t pn, u
 #pragma unroll
   for (int gi = 0; gi < NG; ++gi) {
     const int s = gi % (PD + 1);
+#ifdef MF_BF_HEAD_HI                                         // (experiment: head weights hi-only -- the lo groups are skipped)
+    if (!(gi & 1))
+#endif
     acc = MF_MFMA32(r[s], hid[gi >> 1], acc);
     __builtin_amdgcn_sched_barrier(0);
     const int sp = (gi + PD) % (PD + 1), nb = gi + PD;
@@ -297,7 +305,7 @@ MF_D void trunk_layer_m(const Net& net, int layer, bool relu, const u32x4 (&act)
   constexpr bool RB = __is_same(RBT, RayBias);
   static_assert(!RB || KH == 8, "per-ray bias: 128-wide layers (4 tiles)");
   constexpr int NT = KH / 2;
-  const int groups = tgroups<KH, NGE, SPLIT>(net, layer);
+  const int groups = ((MODE & 1) ? (SPLIT ? 2 : 1) * NGE : 0) + ((MODE & 2) ? KH : 0);
   const unsigned lo = relu ? 0u : 0x80008000u;      // ReLU / pass-through floor
   uint32_t bias_off = net.res_lds + layer * (16 * KH) * 4;
   if constexpr (__is_same(RBT, LdsRayBias) && (MODE & 1))      // embedded layer number popcount(mask below `layer`)
@@ -590,11 +598,11 @@ MF_D void load_resident(const Net& n, const Lane& id) {
 }
 
 // extra_encoding (nerf.py:98): W/2 outputs from [final (W) ; extra block], ReLU.  NGX = extra k-steps (0, 1, 2).
-template <int NGX>
-MF_D void extra_layer(const Net& net, const u32x4 (&act)[16], const u32x4* ex, u32x4 (&out)[8],
+template <int NGX, bool SPLIT = false>
+MF_D void extra_layer(const Net& net, const u32x4 (&act)[16], const u32x4* ex, const u32x4* exlo, u32x4 (&out)[8],
                       Stream& st, Carry& carry, const Lane& id, const Next& nxt) {
   constexpr int NT = 4;
-  const int groups = 16 + NGX;
+  const int groups = 16 + (SPLIT ? 2 : 1) * NGX;
   const uint32_t bias_off = net.res_lds + (net.D + 1) * 256 * 4;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -606,7 +614,7 @@ MF_D void extra_layer(const Net& net, const u32x4 (&act)[16], const u32x4* ex, u
     };
     auto piece = [&](int k) { st.piece(k, id); };
     const f32x16 none = {};
-    out_tile<NGX, 16, false, false, false>(carry, act, ex, ex, p, pn, bias_off + 32 * t * 4, none, id.h, hook, piece, 0u, out[2 * t], out[2 * t + 1]);
+    out_tile<NGX, 16, false, SPLIT, false>(carry, act, ex, exlo, p, pn, bias_off + 32 * t * 4, none, id.h, hook, piece, 0u, out[2 * t], out[2 * t + 1]);
     st.advance();
   }
 }
@@ -643,9 +651,9 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
   u32x4 e[8], eo[kKsExtraMax];
   make_extra(eo);
   st.tl.stamp(32, id);
-  if (net.aux == 2) extra_layer<2>(net, fin, eo, e, st, carry, id, follow);
-  else if (net.aux == 1) extra_layer<1>(net, fin, eo, e, st, carry, id, follow);
-  else extra_layer<0>(net, fin, eo, e, st, carry, id, follow);
+  if (net.aux == 2) extra_layer<2>(net, fin, eo, eo, e, st, carry, id, follow);
+  else if (net.aux == 1) extra_layer<1>(net, fin, eo, eo, e, st, carry, id, follow);
+  else extra_layer<0>(net, fin, eo, eo, e, st, carry, id, follow);
   st.tl.stamp(33, id);
   float o[3];
   valu_head(e, r_sigma_w + (256 + 4) * 4, r_sigma_w + (256 + 4 + 384) * 4, id.h, o);
@@ -702,6 +710,259 @@ MF_D void nof_embed(u32x4 (&xhi)[kKsNofXyz], u32x4 (&xlo)[kKsNofXyz], const floa
   float emb[B2Xyz5::SLOTS];
   emb_eval<3, 5, true>(emb, xyz, par_xyz, h, pow2_xyz);
   split_operands<kKsNofXyz>(emb, B2Xyz5::SLOTS, xhi, xlo);
+}
+
+
+// ================================================================== MF_PREC_BF16X3 (the accuracy mode of the bf16 pipe)
+// The MoCo chain feeds the canonical point into sin(512 x): what the fast mode's plain bf16 hidden GEMMs of the NoF cost
+// there is 6-15 dB (tools/bf16_emulate.py: with the NoF evaluated like this the chain is as accurate as the NeRF alone).
+//   NoF   hidden layers and head: activations AND weights as (hi, lo) pairs, three products per k-step
+//         (Whi ahi + Whi alo + Wlo ahi: 16 mantissa bits), like its embedded input; the image index stays the fp32
+//         per-ray bias;
+//   NeRF  encodings split like the NoF's (layer 0, the skip layer, extra_encoding); the LAST trunk layer with split
+//         WEIGHTS (two products: a weight rounding is the same error in every sample of a ray, an activation rounding
+//         averages out along it -- measured, the activation half buys nothing here) and the sigma head as fp32 dot
+//         product on that layer's fp32 accumulators, inside its epilogue ("keep the sigma head and
+//         its input layer" out of bf16).
+// One output tile with split operands.  Embedded block in front (NGE k-steps, always split), then KHID hidden k-steps:
+// HMODE 0 plain, 1 weights split (groups hi, lo; one MFMA each), 2 weights and activations split (hi: two MFMAs, lo:
+// one).  ReLU always.  OUT2: also the lo halves of the outputs.  SIG: sig += sigma_w[rows] . relu(acc) (fp32).
+template <int NGE, int KHID, int HMODE, bool OUT2, bool SIG, class Hook, class Piece>
+MF_D void out_tile_x(Carry& carry, const u32x4* hid, const u32x4* hidlo, const u32x4* xhi, const u32x4* xlo, uint32_t p,
+                     uint32_t pn, uint32_t bias_off, int h, Hook&& hook, Piece&& piece, u32x4& out0, u32x4& out1, u32x4& lo0,
+                     u32x4& lo1, uint32_t sigw_off, float& sig) {
+  constexpr int NEG = 2 * NGE;
+  constexpr int NHG = (HMODE ? 2 : 1) * KHID;
+  constexpr int NG = NEG + NHG;
+  static_assert(NG > PD, "panel shorter than the fragment pipeline");
+  static_assert(NG >= 4, "panel too short for the DMA pieces");
+  f32x16 acc;
+  {
+    const f32x4 b0 = lds_f4(bias_off + (0 + 4 * h) * 4), b1 = lds_f4(bias_off + (8 + 4 * h) * 4);
+    const f32x4 b2 = lds_f4(bias_off + (16 + 4 * h) * 4), b3 = lds_f4(bias_off + (24 + 4 * h) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; acc[8 + i] = b2[i]; acc[12 + i] = b3[i]; }
+  }
+  u32x4 r[PD + 1];
+#pragma unroll
+  for (int i = 0; i < PD; ++i) r[i] = carry.w[i];
+#pragma unroll
+  for (int gi = 0; gi < NG; ++gi) {
+    const int s = gi % (PD + 1);
+    const bool emb = gi < NEG;
+    const int gh = gi - NEG;
+    if (emb) acc = MF_MFMA32(r[s], xhi[gi >> 1], acc);                      // even: Whi xhi ; odd: Wlo xhi
+    else acc = MF_MFMA32(r[s], hid[HMODE ? gh >> 1 : gh], acc);             // even: Whi ahi ; odd: Wlo ahi
+    __builtin_amdgcn_sched_barrier(0);
+    const int sp = (gi + PD) % (PD + 1), nb = gi + PD;
+    if (nb < NG) r[sp] = lds_u4(p + nb * kGroupBytes);
+    if (gi == 0) hook();
+    if (gi >= 1 && gi <= 4) piece(gi - 1);                                   // (32-group panels: four pieces per wave)
+    if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
+    __builtin_amdgcn_sched_barrier(0);
+    if (emb && !(gi & 1)) {
+      acc = MF_MFMA32(r[s], xlo[gi >> 1], acc);                             // Whi xlo
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (!emb && HMODE == 2 && !(gh & 1)) {
+      acc = MF_MFMA32(r[s], hidlo[gh >> 1], acc);                           // Whi alo
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PD; ++i) carry.w[i] = r[(NG + i) % (PD + 1)];
+  float v[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[i], 0.f);
+  if constexpr (SIG) {                                       // rows 8q + 4h + i of this tile
+    const uint32_t so = sigw_off + 16 * h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const f32x4 w = lds_f4(so + 32 * q);
+#pragma unroll
+      for (int i = 0; i < 4; ++i) sig = __builtin_fmaf(w[i], v[4 * q + i], sig);
+    }
+    // (like the packed outputs below: left alone, hipcc sinks this pure chain to sig's first use behind the layer and
+    //  keeps all eight tiles' accumulators alive until then -- ~340 spilled registers)
+    asm volatile("" : "+v"(sig));
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    out0[w] = pack_bf16x2(v[2 * w], v[2 * w + 1]);
+    out1[w] = pack_bf16x2(v[8 + 2 * w], v[8 + 2 * w + 1]);
+    if constexpr (OUT2) {
+      lo0[w] = pack_bf16x2(v[2 * w] - bflo(out0[w]), v[2 * w + 1] - bfhi(out0[w]));
+      lo1[w] = pack_bf16x2(v[8 + 2 * w] - bflo(out1[w]), v[8 + 2 * w + 1] - bfhi(out1[w]));
+    }
+  }
+#pragma unroll
+  for (int w = 0; w < 4; ++w) {
+    asm volatile("" : "+v"(out0[w]), "+v"(out1[w]));
+    if constexpr (OUT2) asm volatile("" : "+v"(lo0[w]), "+v"(lo1[w]));
+  }
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+// One trunk layer with split operands: (out, outlo) <- relu(W_l [emb ; (in, inlo)] + b_l).  MODE as trunk_layer_m.
+template <int KH, int NGE, int MODE, int HMODE, bool OUT2, bool SIG, class RBT>
+MF_D void trunk_layer_x(const Net& net, int layer, const u32x4 (&in)[KH], const u32x4 (&inlo)[KH], u32x4 (&out)[KH],
+                        u32x4 (&outlo)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE], Stream& st, Carry& carry,
+                        const Lane& id, const Next& nxt, const RBT& rb, uint32_t sigw_off, float& sig) {
+  constexpr int NT = KH / 2;
+  const int groups = ((MODE & 1) ? 2 * NGE : 0) + ((MODE & 2) ? (HMODE ? 2 : 1) * KH : 0);
+  uint32_t bias_off = net.res_lds + layer * (16 * KH) * 4;
+  if constexpr (__is_same(RBT, LdsRayBias) && (MODE & 1))
+    bias_off = rb.lane_off + (uint32_t)__builtin_popcount(net.emb_mask & ((1u << layer) - 1u)) * (16 * KH) * 4;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const uint32_t p = st.slot_off(0) + id.lane * 16;
+    const uint32_t pn = st.slot_off(1) + id.lane * 16;
+    auto hook = [&]() {
+      st.sync(t + 2 < NT ? groups : (t == NT - 2 ? nxt.groups : nxt.groups2),
+              t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id);
+    };
+    auto piece = [&](int k) { st.piece(k, id); };
+    out_tile_x<(MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, HMODE, OUT2, SIG>(
+        carry, in, inlo, xhi, xlo, p, pn, bias_off + 32 * t * 4, id.h, hook, piece, out[2 * t], out[2 * t + 1],
+        outlo[OUT2 ? 2 * t : 0], outlo[OUT2 ? 2 * t + 1 : 1], sigw_off + 32 * t * 4, sig);
+    st.advance();
+  }
+}
+
+// NoF head with split activations and weights: groups (Whi, Wlo) per k-step, three products.
+template <int KHID, class Hook, class Piece>
+MF_D f32x16 head_tile_x3(Carry& carry, const u32x4* hid, const u32x4* hidlo, uint32_t p, uint32_t pn, uint32_t bias_off, int h,
+                         Hook&& hook, Piece&& piece) {
+  constexpr int NG = 2 * KHID;
+  f32x16 acc;
+  {
+    const f32x4 b0 = lds_f4(bias_off + (0 + 4 * h) * 4), b1 = lds_f4(bias_off + (8 + 4 * h) * 4);
+    const f32x4 b2 = lds_f4(bias_off + (16 + 4 * h) * 4), b3 = lds_f4(bias_off + (24 + 4 * h) * 4);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; acc[8 + i] = b2[i]; acc[12 + i] = b3[i]; }
+  }
+  u32x4 r[PD + 1];
+#pragma unroll
+  for (int i = 0; i < PD; ++i) r[i] = carry.w[i];
+#pragma unroll
+  for (int gi = 0; gi < NG; ++gi) {
+    const int s = gi % (PD + 1);
+    acc = MF_MFMA32(r[s], hid[gi >> 1], acc);
+    __builtin_amdgcn_sched_barrier(0);
+    const int sp = (gi + PD) % (PD + 1), nb = gi + PD;
+    if (nb < NG) r[sp] = lds_u4(p + nb * kGroupBytes);
+    if (gi == 0) hook();
+    if (gi >= 1 && gi <= 3) piece(gi - 1);
+    if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(gi & 1)) {
+      acc = MF_MFMA32(r[s], hidlo[gi >> 1], acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < PD; ++i) carry.w[i] = r[(NG + i) % (PD + 1)];
+  return acc;
+}
+
+template <class RBT, class AfterFirst>
+MF_D void nof_eval_x3(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&xlo)[kKsNofXyz], const float (&xyz)[3],
+                      Stream& st, Carry& carry, const Lane& id, const Next& follow, float (&out)[3], const RBT& rb,
+                      AfterFirst&& after_first) {
+  u32x4 ah[8], al[8], bh[8], bl[8];
+#pragma unroll
+  for (int t = 0; t < 8; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { ah[t][i] = 0; al[t][i] = 0; }
+  const int D = net.D;
+  const Next hd{16, nullptr, follow.groups, follow.jump};
+  float nosig = 0.f;
+  auto one = [&](int layer, const u32x4 (&ih)[8], const u32x4 (&il)[8], u32x4 (&oh)[8], u32x4 (&ol)[8]) {
+    const Next nxt = layer == D - 1 ? hd : next_trunk_bf<8, kKsNofXyz, true, 1>(net, layer + 1);
+    const int has_emb = (net.emb_mask >> layer) & 1;
+    if (layer == 0) trunk_layer_x<8, kKsNofXyz, 1, 2, true, false>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nosig);
+    else if (has_emb) trunk_layer_x<8, kKsNofXyz, 3, 2, true, false>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nosig);
+    else trunk_layer_x<8, kKsNofXyz, 2, 2, true, false>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nosig);
+  };
+  int l = 0;
+  for (; l + 1 < D; l += 2) {
+    one(l, ah, al, bh, bl);
+    if (l == 0) after_first();
+    one(l + 1, bh, bl, ah, al);
+  }
+  if (l < D) {
+    one(l, ah, al, bh, bl);
+    if (l == 0) after_first();
+#pragma unroll
+    for (int t = 0; t < 8; ++t) { ah[t] = bh[t]; al[t] = bl[t]; }
+  }
+  f32x16 acc;
+  {
+    const uint32_t p = st.slot_off(0) + id.lane * 16, pn = st.slot_off(1) + id.lane * 16;
+    auto hook = [&]() { st.sync(follow.groups2, follow.jump2, id); };
+    auto piece = [&](int k) { st.piece(k, id); };
+    acc = head_tile_x3<8>(carry, ah, al, p, pn, net.res_lds + (D + net.aux) * 128 * 4, id.h, hook, piece);
+    st.advance();
+  }
+  float own[5], oth[5];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) { own[i] = acc[i]; oth[i] = __shfl_xor(acc[i], 32, 64); }
+  if (net.aux == 9) {
+    float T[9];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) { T[i] = id.h ? oth[i] : own[i]; T[4 + i] = id.h ? own[i] : oth[i]; }
+    T[8] = id.h ? oth[4] : own[4];
+    quat_transform(T, xyz, out);
+  } else {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] = (id.h ? oth[c] : own[c]) + xyz[c];
+  }
+}
+
+// Canonical NeRF, x3: split encodings; layers 0 .. D-2 as in the fast mode; layer D-1 with split weights and the sigma
+// head in its epilogue; xyz_encoding_final, extra_encoding (split extra block) and the rgb head as in the fast mode.
+template <class MakeExtra>
+MF_D void nerf_eval_x3(const Net& net, const u32x4 (&xh)[kKsNerfXyz], const u32x4 (&xl)[kKsNerfXyz], MakeExtra&& make_extra,
+                       bool sigma_only, Stream& st, Carry& carry, const Lane& id, const Next& follow, float& sigma,
+                       float (&rgb)[3]) {
+  u32x4 act[16];
+#pragma unroll
+  for (int t = 0; t < 16; ++t)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) act[t][i] = 0;
+  const int D = net.D;
+  NoRayBias norb;
+  trunk<16, kKsNerfXyz, true>(net, D - 1, act, xh, xl, st, carry, id,
+                              [&](int l) { return next_trunk_bf<16, kKsNerfXyz, true, 2>(net, l + 1); }, norb, nullptr, [] {});
+  const uint32_t r_sigma_w = net.res_lds + ((D + 1) * 256 + 128) * 4;
+  u32x4 h7[16];
+  float sig = 0.f;
+  {
+    const Next nx = sigma_only ? follow : next_trunk_bf<16, kKsNerfXyz, true, 2>(net, D);      // xyz_encoding_final: 16 groups
+#ifndef MF_X3_SIG
+#define MF_X3_SIG true
+#endif
+    if ((net.emb_mask >> (D - 1)) & 1)
+      trunk_layer_x<16, kKsNerfXyz, 3, 1, false, MF_X3_SIG>(net, D - 1, act, act, h7, h7, xh, xl, st, carry, id, nx, norb, r_sigma_w, sig);
+    else
+      trunk_layer_x<16, kKsNerfXyz, 2, 1, false, MF_X3_SIG>(net, D - 1, act, act, h7, h7, xh, xl, st, carry, id, nx, norb, r_sigma_w, sig);
+  }
+  sigma = sig + __shfl_xor(sig, 32, 64) + lds_f(r_sigma_w + 256 * 4);
+  st.tl.stamp(30, id);
+  if (sigma_only) return;
+  const int xg = 16 + 2 * net.aux;
+  const Next ex{xg, nullptr, xg, nullptr};
+  u32x4 fin[16];
+  trunk_layer_m<16, kKsNerfXyz, 2, false>(net, D, false, h7, fin, xh, xl, st, carry, id, ex, norb);
+  u32x4 e[8], eh[kKsExtraMax], el[kKsExtraMax];
+  make_extra(eh, el);
+  if (net.aux == 2) extra_layer<2, true>(net, fin, eh, el, e, st, carry, id, follow);
+  else if (net.aux == 1) extra_layer<1, true>(net, fin, eh, el, e, st, carry, id, follow);
+  else extra_layer<0, true>(net, fin, eh, el, e, st, carry, id, follow);
+  float o[3];
+  valu_head(e, r_sigma_w + (256 + 4) * 4, r_sigma_w + (256 + 4 + 384) * 4, id.h, o);
+#pragma unroll
+  for (int c = 0; c < 3; ++c) rgb[c] = 1.f / (1.f + expf(-o[c]));   // nn.Sigmoid, nerf.py:57-59
 }
 
 }  // namespace bf

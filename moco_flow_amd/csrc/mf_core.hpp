@@ -188,6 +188,9 @@ struct NetLayout {
   int64_t panel_bytes;     // all panels
   int64_t ind_bytes;       // bf16 NoF: fp32 image-index columns [embedded layer][kNofIndCols][row] behind the panels
   int n_emb_layers;        // layers that consume the embedded input (popcount of emb_mask)
+  uint32_t hsplit_mask;    // MF_PREC_BF16X3: trunk layers whose HIDDEN k-steps are (hi, lo) group pairs too -- every NoF
+                           // layer (three products: activations and weights split), the NeRF's last trunk layer (two
+                           // products: weights split; it feeds the sigma head)
   int max_groups;          // largest panel, in groups
   // resident block float offsets
   int off_bias_trunk;      // n_trunk * W
@@ -209,7 +212,8 @@ MF_HD int trunk_batches(const NetLayout& L, int layer) {
   return (((L.emb_mask >> layer) & 1) ? L.emb_steps / 4 : 0) + (layer > 0 ? hidden_batches(L) : 0);
 }
 MF_HD int trunk_groups(const NetLayout& L, int layer) {
-  if (L.bf16) return (((L.emb_mask >> layer) & 1) ? (L.emb_split ? 2 : 1) * L.emb_steps : 0) + (layer > 0 ? L.NK : 0);
+  if (L.bf16) return (((L.emb_mask >> layer) & 1) ? (L.emb_split ? 2 : 1) * L.emb_steps : 0) +
+                     (layer > 0 ? (((L.hsplit_mask >> layer) & 1) ? 2 : 1) * L.NK : 0);
   return 2 * trunk_batches(L, layer);
 }
 // bf16 NoF: the 3|9-row head (nof.py:75-82) as one more panel behind the trunk: a 32-row tile (rows >= n_head zero)

@@ -8,8 +8,10 @@ namespace mf {
 inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 
 // returns false (layout zeroed) for configurations the kernels do not implement
+// `bf16` = the MF_PREC_* value: 0 fp32, 1 bf16, 2 bf16x3 (bf16 layout with more (hi, lo) split ranges, mf_bf16.hpp)
 inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L, int bf16 = 0) {
   L = NetLayout{};
+  const bool x3 = bf16 == MF_PREC_BF16X3;
   L.bf16 = bf16 ? 1 : 0;
   if (d.W != 256 && d.W != 128) return false;
   if (d.D < 2 || d.D + 1 > MF_MAX_LAYERS) return false;
@@ -22,7 +24,8 @@ inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L, int bf16 = 0) {
   L.n_trunk = d.D + 1;                                // + xyz_encoding_final (no ReLU)
   if (bf16 && d.W != 256) return false;
   L.emb_steps = bf16 ? kKsNerfXyz : kStepsNerfXyz;     // bf16: 16-slot k-steps (mf_bf16.hpp); fp32: 4-k MFMA steps
-  L.emb_split = 0;                                     // bf16: the NeRF's encodings are plain bf16 operands (mf_bf16.hpp)
+  L.emb_split = x3 ? 1 : 0;                            // bf16: the NeRF's encodings are plain bf16 operands (mf_bf16.hpp); x3: split
+  L.hsplit_mask = x3 ? 1u << (d.D - 1) : 0u;           // x3: the last trunk layer (-> sigma head) with split weights
   L.emb_mask = 1u | d.skip_mask;
   L.relu_mask = (1u << d.D) - 1u;
   switch (d.extra_feat_type) {
@@ -56,6 +59,7 @@ inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L, int bf16 = 0) {
 
 inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0) {
   L = NetLayout{};
+  const bool x3 = bf16 == MF_PREC_BF16X3;
   L.bf16 = bf16 ? 1 : 0;
   if (d.W != 128) return false;
   if (d.D < 2 || d.D > MF_MAX_LAYERS) return false;
@@ -67,6 +71,7 @@ inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0) {
   L.n_trunk = d.D;
   L.emb_steps = bf16 ? kKsNofXyz : kStepsNofIn;         // bf16: xyz block only, the image-index block is a per-ray bias
   L.emb_split = bf16 ? 1 : 0;                          // bf16: the NoF's embedded input keeps 16 mantissa bits
+  L.hsplit_mask = x3 ? ((1u << d.D) - 1u) & ~1u : 0u;  // x3: every hidden range as (hi, lo) pairs, three products
   L.emb_mask = 1u | d.skip_mask;
   L.relu_mask = (1u << d.D) - 1u;
   L.extra_steps = -1;

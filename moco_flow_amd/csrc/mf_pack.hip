@@ -65,18 +65,12 @@ __global__ void pack_panels_kernel(PackJob job) {
     const int i = lane & 31, h = lane >> 5;
     const float* row = R.W + (long long)(32 * P + i) * R.n_in;
     const int eg = (R.emb_split ? 2 : 1) * R.emb_steps;      // groups of the embedded block
-    const int ge = R.emb_first ? gi : gi - R.hid_batches;
+    const int hg = (R.hid_split ? 2 : 1) * R.hid_batches;    // groups of the hidden block
+    const int ge = R.emb_first ? gi : gi - hg;
     const int gh = R.emb_first ? gi - eg : gi;
     unsigned short h8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (R.n_rows && 32 * P + i >= R.n_rows) {
       // zero row of a partial tile
-    } else if (R.hid_split) {
-      const int ks = gi >> 1, lo = gi & 1;
-      for (int e = 0; e < 8; ++e) {
-        const float w = row[R.hid_col0 + 16 * ks + hid_perm2(h, e)];
-        const unsigned short hi = bf16_rne(w);
-        h8[e] = lo ? bf16_rne(w - __uint_as_float((unsigned)hi << 16)) : hi;
-      }
     } else if (ge >= 0 && ge < eg) {
       const int ks = R.emb_split ? ge >> 1 : ge, lo = R.emb_split ? ge & 1 : 0;
       for (int e = 0; e < 8; ++e) {
@@ -85,8 +79,13 @@ __global__ void pack_panels_kernel(PackJob job) {
         const unsigned short hi = bf16_rne(w);
         h8[e] = lo ? bf16_rne(w - __uint_as_float((unsigned)hi << 16)) : hi;
       }
-    } else if (gh >= 0 && gh < R.hid_batches) {
-      for (int e = 0; e < 8; ++e) h8[e] = bf16_rne(row[R.hid_col0 + 16 * gh + hid_perm2(h, e)]);
+    } else if (gh >= 0 && gh < hg) {
+      const int ks = R.hid_split ? gh >> 1 : gh, lo = R.hid_split ? gh & 1 : 0;
+      for (int e = 0; e < 8; ++e) {
+        const float w = row[R.hid_col0 + 16 * ks + hid_perm2(h, e)];
+        const unsigned short hi = bf16_rne(w);
+        h8[e] = lo ? bf16_rne(w - __uint_as_float((unsigned)hi << 16)) : hi;
+      }
     }
     unsigned* pu = reinterpret_cast<unsigned*>(&v.x);
     for (int w = 0; w < 4; ++w) pu[w] = (unsigned)h8[2 * w] | ((unsigned)h8[2 * w + 1] << 16);
@@ -153,20 +152,20 @@ using namespace mf;
 
 extern "C" int64_t mf_nerf_packed_bytes_p(const mf_nerf_desc* d, int32_t precision) {
   NetLayout L;
-  if (!d || (precision != MF_PREC_F32 && precision != MF_PREC_BF16) || !nerf_layout(*d, L, precision)) { fail(MF_E_UNSUPPORTED, "mf_nerf_packed_bytes: unsupported NeRF configuration"); return 0; }
+  if (!d || (precision < MF_PREC_F32 || precision > MF_PREC_BF16X3) || !nerf_layout(*d, L, precision)) { fail(MF_E_UNSUPPORTED, "mf_nerf_packed_bytes: unsupported NeRF configuration"); return 0; }
   return L.res_bytes + L.panel_bytes;
 }
 
 extern "C" int64_t mf_nof_packed_bytes_p(const mf_nof_desc* d, int32_t precision) {
   NetLayout L;
-  if (!d || (precision != MF_PREC_F32 && precision != MF_PREC_BF16) || !nof_layout(*d, L, precision)) { fail(MF_E_UNSUPPORTED, "mf_nof_packed_bytes: unsupported NoF configuration"); return 0; }
+  if (!d || (precision < MF_PREC_F32 || precision > MF_PREC_BF16X3) || !nof_layout(*d, L, precision)) { fail(MF_E_UNSUPPORTED, "mf_nof_packed_bytes: unsupported NoF configuration"); return 0; }
   return L.res_bytes + L.panel_bytes + L.ind_bytes;
 }
 
 extern "C" int32_t mf_nerf_pack_p(const mf_nerf_desc* d, int32_t precision, void* packed, void* stream) {
   NetLayout L;
   if (!d || !packed) return fail(MF_E_INVALID, "mf_nerf_pack: null argument");
-  if (precision != MF_PREC_F32 && precision != MF_PREC_BF16) return fail(MF_E_INVALID, "mf_nerf_pack: precision %d", precision);
+  if (precision < MF_PREC_F32 || precision > MF_PREC_BF16X3) return fail(MF_E_INVALID, "mf_nerf_pack: precision %d", precision);
   if (!nerf_layout(*d, L, precision)) return fail(MF_E_UNSUPPORTED, "mf_nerf_pack: unsupported NeRF configuration "
                                        "(W=%d D=%d in_channels_xyz=%d)", d->W, d->D, d->in_channels_xyz);
   PackJob job{};
@@ -190,6 +189,7 @@ extern "C" int32_t mf_nerf_pack_p(const mf_nerf_desc* d, int32_t precision, void
     R.hid_batches = l > 0 ? hidden_batches(L) : 0;
     R.bf16 = L.bf16;
     R.emb_split = L.emb_split;
+    R.hid_split = (L.hsplit_mask >> l) & 1;
     R.hid_col0 = has_emb ? d->in_channels_xyz : 0;
     R.xyz_cols = d->in_channels_xyz;
     R.dst_group0 = g0;
@@ -238,7 +238,7 @@ extern "C" int32_t mf_nerf_pack_p(const mf_nerf_desc* d, int32_t precision, void
 extern "C" int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* packed, void* stream) {
   NetLayout L;
   if (!d || !packed) return fail(MF_E_INVALID, "mf_nof_pack: null argument");
-  if (precision != MF_PREC_F32 && precision != MF_PREC_BF16) return fail(MF_E_INVALID, "mf_nof_pack: precision %d", precision);
+  if (precision < MF_PREC_F32 || precision > MF_PREC_BF16X3) return fail(MF_E_INVALID, "mf_nof_pack: precision %d", precision);
   if (!nof_layout(*d, L, precision)) return fail(MF_E_UNSUPPORTED, "mf_nof_pack: unsupported NoF configuration "
                                       "(W=%d D=%d in_channels_xyz=%d extra_feat_dim=%d)", d->W, d->D,
                                       d->in_channels_xyz, d->extra_feat_dim);
@@ -264,6 +264,7 @@ extern "C" int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* 
     R.hid_batches = l > 0 ? hidden_batches(L) : 0;
     R.bf16 = L.bf16;
     R.emb_split = L.emb_split;
+    R.hid_split = (L.hsplit_mask >> l) & 1;
     R.hid_col0 = has_emb ? cin : 0;
     R.xyz_cols = d->in_channels_xyz;
     R.dst_group0 = g0;

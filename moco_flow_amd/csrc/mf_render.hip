@@ -294,7 +294,7 @@ int64_t render_workspace_bytes_bf16(const mf_render_args* a);
 using namespace mf;
 
 extern "C" int64_t mf_render_workspace_bytes(const mf_render_args* a) {
-  if (!a || a->precision != MF_PREC_BF16 || a->n_rays <= 0) return 0;
+  if (!a || (a->precision != MF_PREC_BF16 && a->precision != MF_PREC_BF16X3) || a->n_rays <= 0) return 0;
   return render_workspace_bytes_bf16(a);
 }
 
@@ -318,9 +318,9 @@ static int32_t render_entry(const mf_render_args* a, void* stream, bool prepare_
   if (!a->z_vals && !a->z_steps) return fail(MF_E_INVALID, "mf_render_pass: need z_vals or z_steps");
   if (a->activation != MF_ACT_RELU && a->activation != MF_ACT_SOFTPLUS)
     return fail(MF_E_INVALID, "mf_render_pass: activation %d not supported", a->activation);
-  if (a->precision != MF_PREC_F32 && a->precision != MF_PREC_BF16)
+  if (a->precision < MF_PREC_F32 || a->precision > MF_PREC_BF16X3)
     return fail(MF_E_INVALID, "mf_render_pass: precision %d", a->precision);
-  const int bf16 = a->precision == MF_PREC_BF16;
+  const int bf16 = a->precision != MF_PREC_F32;
   RenderParams p{};
   if (!nerf_layout(*a->nerf, p.nerf.L, 0)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported NeRF configuration");
   if (p.nerf.L.NK != 16) return fail(MF_E_UNSUPPORTED, "mf_render_pass: only W=256 NeRF is built");

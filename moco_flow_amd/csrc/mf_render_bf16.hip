@@ -148,7 +148,9 @@ MF_D void tile_rays(int tile, int nr, int S, int& first, int& n) {
   n = s1 / S - first + 1;
 }
 
-template <bool MOCO>
+// X3: MF_PREC_BF16X3 (mf_bf16.hpp: NoF hidden GEMMs and head as three-product splits, NeRF encodings split, last trunk
+// layer with split weights, sigma head on fp32 accumulators)
+template <bool MOCO, bool X3 = false>
 __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p) {
   const Lane id;
   load_resident(p.nerf, id);
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
   Stream st;
   st.tl.start(p.alphas, id);
   Carry carry;
-  const Next prog_first = MOCO ? first_of<8, kKsNofXyz, true>(p.bw) : first_of<16, kKsNerfXyz, false>(p.nerf);
+  const Next prog_first = MOCO ? first_of<8, kKsNofXyz, true>(p.bw) : first_of<16, kKsNerfXyz, X3>(p.nerf);
   int seq = 0;                       // NoF evaluations done by this workgroup: evaluation number `seq` reads buffer seq & 1
   if (MOCO) {                        // rows of the first evaluation (first group, tile 0, bw at index i)
     const long long g0 = blockIdx.x;
@@ -177,7 +179,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
     stage_raybias(p, g0 * p.G + f0, n0, 0, p.rb_off, id);
   }
   if (MOCO) start_program<8, kKsNofXyz, true>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);   // (its wait + barrier also publish the resident blocks / tables)
-  else start_program<16, kKsNerfXyz, false>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
+  else start_program<16, kKsNerfXyz, X3>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
 
   const int S = p.S;
   const bool sigma_only = p.flags & MF_F_SIGMA_ONLY;
@@ -239,13 +241,15 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
           if (role == 1 || role == 2) { cur[0] = canon[0]; cur[1] = canon[1]; cur[2] = canon[2]; }
           const bool last = step == nsteps - 1;
           const bool next_fw = (role + 1 == 1 || role + 1 == 2 || role + 1 == 4);
-          const Next follow = last ? first_of<16, kKsNerfXyz, false>(p.nerf) : first_of<8, kKsNofXyz, true>(next_fw ? p.fw : p.bw);
+          const Next follow = last ? first_of<16, kKsNerfXyz, X3>(p.nerf) : first_of<8, kKsNofXyz, true>(next_fw ? p.fw : p.bw);
           u32x4 nhi[kKsNofXyz], nlo[kKsNofXyz];
           float out[3];
           nof_embed(nhi, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
-          nof_eval(net, nhi, nlo, cur, st, carry, id, follow, out, rb, nullptr, [&] {
+          auto stage_next = [&] {
             if (!last) stage_raybias(p, ray0 + tf, tn, role + 1 == 4 ? 1 : role + 1, p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes, id);
-          });
+          };
+          if constexpr (X3) nof_eval_x3(net, nhi, nlo, cur, st, carry, id, follow, out, rb, stage_next);
+          else nof_eval(net, nhi, nlo, cur, st, carry, id, follow, out, rb, nullptr, stage_next);
           if (role == 0) { canon[0] = out[0]; canon[1] = out[1]; canon[2] = out[2]; }
           if (role == 1) dl = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
           if (role == 4) dg = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
@@ -272,15 +276,8 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
         }
       }
       st.tl.stamp(3, id);
-      u32x4 xe[kKsNerfXyz];
-      {
-        float embx[B2Xyz10::SLOTS];
-        jitter();
-        emb_eval<3, 10, true>(embx, xin, par_nerf_xyz, id.h, p.pow2 & 1);
-        pack_operands<kKsNerfXyz>(embx, B2Xyz10::SLOTS, xe);
-      }
-      auto make_extra = [&](u32x4 (&eo)[kKsExtraMax]) {
-        float ext[8 * kKsExtraMax];
+      float sigma, rgb[3] = {0.f, 0.f, 0.f};
+      auto extra_slots = [&](float (&ext)[8 * kKsExtraMax]) {
 #pragma unroll
         for (int e = 0; e < 8 * kKsExtraMax; ++e) ext[e] = 0.f;
         if (p.extra_type == MF_EXTRA_DIR) {
@@ -290,11 +287,40 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
           const float iv[1] = {rp[8]};
           emb_eval<1, 2, true>(ext, iv, par_nerf_ext, id.h, p.pow2 & 2);                         // rendering.py:133-137
         }
-        pack_operands<kKsExtraMax>(ext, 8 * kKsExtraMax, eo);
       };
-      st.tl.stamp(4, id);
-      float sigma, rgb[3] = {0.f, 0.f, 0.f};
-      nerf_eval(p.nerf, xe, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb);
+      if constexpr (X3) {
+        u32x4 xh[kKsNerfXyz], xl[kKsNerfXyz];
+        {
+          float embx[B2Xyz10::SLOTS];
+          jitter();
+          // exact seeds + doubling chains (<= 2e-6): the transcendental unit's 2e-4 rad at 512 x would sit above the
+          // 2^-16 of the split operands
+          emb_eval<3, 10, false>(embx, xin, par_nerf_xyz, id.h, p.pow2 & 1);
+          split_operands<kKsNerfXyz>(embx, B2Xyz10::SLOTS, xh, xl);
+        }
+        auto make_extra = [&](u32x4 (&eh)[kKsExtraMax], u32x4 (&el)[kKsExtraMax]) {
+          float ext[8 * kKsExtraMax];
+          extra_slots(ext);
+          split_operands<kKsExtraMax>(ext, 8 * kKsExtraMax, eh, el);
+        };
+        st.tl.stamp(4, id);
+        nerf_eval_x3(p.nerf, xh, xl, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb);
+      } else {
+        u32x4 xe[kKsNerfXyz];
+        {
+          float embx[B2Xyz10::SLOTS];
+          jitter();
+          emb_eval<3, 10, true>(embx, xin, par_nerf_xyz, id.h, p.pow2 & 1);
+          pack_operands<kKsNerfXyz>(embx, B2Xyz10::SLOTS, xe);
+        }
+        auto make_extra = [&](u32x4 (&eo)[kKsExtraMax]) {
+          float ext[8 * kKsExtraMax];
+          extra_slots(ext);
+          pack_operands<kKsExtraMax>(ext, 8 * kKsExtraMax, eo);
+        };
+        st.tl.stamp(4, id);
+        nerf_eval(p.nerf, xe, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb);
+      }
       if (valid && id.h == 0) {
         sbuf[srel] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
         zbuf[srel] = z;
@@ -495,7 +521,9 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
   using namespace bf;
   Params p{};
   NetLayout Ln, Lb, Lf;
-  if (!nerf_layout(*a->nerf, Ln, 1)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported NeRF configuration (bf16: W = 256)");
+  const int prec = a->precision;                // MF_PREC_BF16 | MF_PREC_BF16X3
+  const bool x3 = prec == MF_PREC_BF16X3;
+  if (!nerf_layout(*a->nerf, Ln, prec)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported NeRF configuration (bf16: W = 256)");
   const bool moco = a->nof_bw != nullptr;
   const bool chains = a->flags & (MF_F_CHAIN_LOCAL | MF_F_CHAIN_GLOBAL);
   p.rays = a->rays; p.ray_stride = a->ray_stride; p.n_rays = a->n_rays; p.bg = a->background;
@@ -521,11 +549,11 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
   p.nerf = net_of(Ln, a->nerf_packed, Ln.n_trunk - 1, Ln.extra_steps);
   int max_groups = Ln.max_groups;
   if (moco) {
-    if (!nof_layout(*a->nof_bw, Lb, 1)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported backward NoF configuration");
+    if (!nof_layout(*a->nof_bw, Lb, prec)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported backward NoF configuration");
     p.bw = net_of(Lb, a->nof_bw_packed, Lb.n_trunk, Lb.n_head);
     if (Lb.max_groups > max_groups) max_groups = Lb.max_groups;
     if (chains) {
-      if (!nof_layout(*a->nof_fw, Lf, 1)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported forward NoF configuration");
+      if (!nof_layout(*a->nof_fw, Lf, prec)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported forward NoF configuration");
       p.fw = net_of(Lf, a->nof_fw_packed, Lf.n_trunk, Lf.n_head);
       if (Lf.max_groups > max_groups) max_groups = Lf.max_groups;
     }
@@ -594,7 +622,8 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
   lds = (lds + 15u) & ~15u;
 
   const int grid = (int)(p.n_groups < device_cus() ? p.n_groups : device_cus());
-  void (*kern)(const Params) = moco ? render_kernel_bf16<true> : render_kernel_bf16<false>;
+  void (*kern)(const Params) = x3 ? (moco ? render_kernel_bf16<true, true> : render_kernel_bf16<false, true>)
+                                  : (moco ? render_kernel_bf16<true, false> : render_kernel_bf16<false, false>);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, p);

@@ -40,6 +40,7 @@ class NeRF(nn.Module):
         self.rgb = nn.Sequential(nn.Linear(W // 2, 3), nn.Sigmoid())
         self._packed = PackedWeights()
         self._packed_bf16 = PackedWeights()
+        self._packed_x3 = PackedWeights()
         self._packed_bwd = PackedWeights()
 
     # ---- HIP plumbing -----------------------------------------------------
@@ -76,12 +77,12 @@ class NeRF(nn.Module):
     def packed(self, precision=L.MF_PREC_F32):
         """(descriptor, packed device buffer), re-packed when the parameters (or the precision) changed."""
         lib = L.lib()
-        cache = self._packed if precision == L.MF_PREC_F32 else self._packed_bf16
+        cache = {L.MF_PREC_F32: self._packed, L.MF_PREC_BF16: self._packed_bf16, L.MF_PREC_BF16X3: self._packed_x3}[precision]
         return cache.get(self, self._build_desc, lib.mf_nerf_packed_bytes_p, lib.mf_nerf_pack_p, "NeRF", precision)
 
     def invalidate_packed(self):
         """Drop the packed-weight caches (needed only after in-place edits through ``param.data``)."""
-        for c in (self._packed, self._packed_bf16, self._packed_bwd):
+        for c in (self._packed, self._packed_bf16, self._packed_x3, self._packed_bwd):
             c.invalidate()
 
     def packed_bwd(self):

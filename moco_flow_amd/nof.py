@@ -36,6 +36,7 @@ class NoF(nn.Module):
         self.nof_encoding_final = nn.Linear(W, 9 if use_quat else 3)
         self._packed = PackedWeights()
         self._packed_bf16 = PackedWeights()
+        self._packed_x3 = PackedWeights()
         self._packed_bwd = PackedWeights()
 
     def _build_desc(self):
@@ -66,7 +67,7 @@ class NoF(nn.Module):
 
     def invalidate_packed(self):
         """Drop the packed-weight caches (needed only after in-place edits through ``param.data``)."""
-        for c in (self._packed, self._packed_bf16, self._packed_bwd):
+        for c in (self._packed, self._packed_bf16, self._packed_x3, self._packed_bwd):
             c.invalidate()
 
     def packed_bwd(self):
@@ -77,7 +78,7 @@ class NoF(nn.Module):
 
     def packed(self, precision=L.MF_PREC_F32):
         lib = L.lib()
-        cache = self._packed if precision == L.MF_PREC_F32 else self._packed_bf16
+        cache = {L.MF_PREC_F32: self._packed, L.MF_PREC_BF16: self._packed_bf16, L.MF_PREC_BF16X3: self._packed_x3}[precision]
         return cache.get(self, self._build_desc, lib.mf_nof_packed_bytes_p, lib.mf_nof_pack_p, "NoF", precision)
 
     def forward(self, inputs, xyz, img_ind=None):

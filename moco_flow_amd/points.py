@@ -18,7 +18,7 @@ def query_sigma(xyz, nerf, nerf_embedding_xyz, bw_nof=None, nof_embeddings=None,
     ``precision``: "f32" | "bf16" (None = the module setting of ``rendering.set_precision``); bf16 = hidden GEMMs on the
     bf16 matrix pipe as in render_rays' gradient-free passes (the mesh-extraction lattice ~8x faster)."""
     from . import rendering
-    prec = L.MF_PREC_BF16 if (precision or rendering.PRECISION) == "bf16" else L.MF_PREC_F32
+    prec = L.MF_PREC_F32 if (precision or rendering.PRECISION) == "f32" else L.MF_PREC_BF16     # (bf16x3 is a render-pass mode)
     L.require_gpu(xyz, "query_sigma")
     x = xyz.detach().float().contiguous()
     B = x.shape[0]

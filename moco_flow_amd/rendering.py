@@ -17,17 +17,20 @@ from . import _lib as L
 from . import autograd as A
 
 # Arithmetic of the hidden (256-/128-wide) GEMMs of the fused pass: "f32" = exact-fp32 MFMA (the
-# reference's arithmetic, BASELINE configs C1-C2; default) or "bf16" = bf16 operands with fp32
-# accumulate (BASELINE configs C3-C5); embedded-input k-ranges as a two-term bf16 split (16 mantissa
-# bits); heads and composite stay fp32.
+# reference's arithmetic, BASELINE configs C1-C2; default); "bf16" = bf16 operands with fp32
+# accumulate (BASELINE configs C3-C5), the NoF's xyz block as a two-term bf16 split (16 mantissa
+# bits), its image-index block as an exact fp32 per-ray bias, heads and composite in fp32;
+# "bf16x3" = the accuracy mode of the bf16 pipe for the MoCo chain (include/mocoflow_hip.h, MF_PREC_BF16X3: the NoF's
+# hidden GEMMs and head as three bf16 products per term, NeRF encodings split, its last trunk layer with split
+# weights, sigma head on fp32 accumulators: the chain then costs no accuracy beyond the NeRF's own bf16 hidden layers).
 # The reference's render_rays signature has no such knob, so it is a module setting.
 PRECISION = "f32"
 
 
 def set_precision(p: str):
     global PRECISION
-    if p not in ("f32", "bf16"):
-        raise ValueError(f"precision must be 'f32' or 'bf16', got {p!r}")
+    if p not in L.PRECISIONS:
+        raise ValueError(f"precision must be one of {sorted(L.PRECISIONS)}, got {p!r}")
     PRECISION = p
 
 
@@ -78,7 +81,7 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
     if chain_global:
         flags |= L.MF_F_CHAIN_GLOBAL
     a.flags = flags
-    prec = L.MF_PREC_BF16 if (precision or PRECISION) == "bf16" else L.MF_PREC_F32
+    prec = L.PRECISIONS[precision or PRECISION]
     a.precision = prec
     desc, buf = nerf.packed(prec)
     a.nerf, a.nerf_packed = C.pointer(desc), buf.data_ptr()
@@ -366,7 +369,7 @@ def render_rays(rays,
         f = _render_pass(rays, background, z_all, None, use_disp, noise_f, act,
                          nerf_models[1], nerf_embeddings, nof_models if use_nof else None, nof_embeddings,
                          loc, glob, False, loc or glob or grad or _capture is not None,
-                         dump=grad, precision=pass_prec)
+                         dump=grad, precision=pass_prec, workspace=ws)
         if _capture is not None:
             _capture.update(z_fine=z_all, weights_fine=f.get("weights"), alphas_fine=f.get("alphas"))
         result['rgb_fine'] = f["rgb"]

@@ -42,13 +42,18 @@ def test_inference_kernels_have_no_spills_and_stream_weights_by_buffer_dma():
         b16 = ex.submit(_compile, "mf_render_bf16", ["-fno-slp-vectorize"])      # csrc/Makefile builds this unit so
         (u32, a32), (u16, a16) = f32.result(), b16.result()
     # render_kernel<MOCO, DUMP>: the two inference instantiations (DUMP = false) and every bf16 kernel
+    x3 = [k for k in u16 if re.search(r"render_kernel_bf16ILb[01]ELb1EE", k)]          # <MOCO, X3 = true>
     want = [k for k in u32 if re.search(r"render_kernelILb[01]ELb0EE", k)] + \
-           [k for k in u16 if "render_kernel_bf16" in k or "points_kernel_bf16" in k]
-    assert len(want) == 2 + 5, sorted(list(u32) + list(u16))     # fp32 NeRF / MoCo; bf16 render x 2, point query x 3
+           [k for k in u16 if ("render_kernel_bf16" in k or "points_kernel_bf16" in k) and k not in x3]
+    assert len(want) == 2 + 5 and len(x3) == 2, sorted(list(u32) + list(u16))   # fp32 NeRF / MoCo; bf16 render x 2, point query x 3
     for k in want:
         u = {**u32, **u16}[k]
         assert u["VGPRs Spill"] == 0 and u["ScratchSize"] == 0, (k, u)
         assert u["VGPRs"] <= 256, (k, u)
+    # the bf16x3 accuracy mode keeps (hi, lo) pairs of the NoF's activations: at the 256-register limit; hipcc spills one
+    # 64-bit value in the kernel prologue (outside every loop)
+    for k in x3:
+        assert u16[k]["VGPRs Spill"] <= 2 and u16[k]["ScratchSize"] <= 16, (k, u16[k])
     for asm in (a32, a16):
         assert "global_load_lds" not in asm                       # FLAT-encoded LDS-DMA: forces lgkmcnt(0) waits
         assert len(re.findall(r"buffer_load_dwordx4 .* lds", asm)) > 50

@@ -68,7 +68,13 @@ class NoFEmu(R.NoF):
             acc = b.unsqueeze(0)
             if i == 0 or i in self.skips:
                 We = W[:, :inputs.shape[1]]
-                if o["ind_exact"]:
+                if o["ind_exact"] and o.get("xyz") == "in_split":      # input split, weights hi-only: two products
+                    xh, xl = split(inputs[:, :cx])
+                    acc = acc + F.linear(xh, bf(We[:, :cx])) + F.linear(xl, bf(We[:, :cx])) + F.linear(inputs[:, cx:], We[:, cx:])
+                elif o["ind_exact"] and o.get("xyz") == "w_split":     # weights split, input hi-only
+                    Wa, Wb = split(We[:, :cx])
+                    acc = acc + F.linear(bf(inputs[:, :cx]), Wa) + F.linear(bf(inputs[:, :cx]), Wb) + F.linear(inputs[:, cx:], We[:, cx:])
+                elif o["ind_exact"]:
                     acc = acc + lin_split(inputs[:, :cx], We[:, :cx]) + F.linear(inputs[:, cx:], We[:, cx:])
                 else:
                     acc = acc + lin_split(inputs, We)
@@ -170,6 +176,8 @@ VARIANTS = {
     "x3_l2p":   (dict(ind_exact=True, head="split", hidden="split", act_plain_layers=(2,)), dict(last="plain", emb="plain")),
     "x3_l12p":  (dict(ind_exact=True, head="split", hidden="split", act_plain_layers=(1, 2)), dict(last="plain", emb="plain")),
     "x3_l1p":   (dict(ind_exact=True, head="split", hidden="split", act_plain_layers=(1,)), dict(last="plain", emb="plain")),
+    "bias_in2":  (dict(ind_exact=True, head="split_w", hidden="plain", xyz="in_split"), dict(last="plain", emb="plain")),
+    "bias_w2":   (dict(ind_exact=True, head="split_w", hidden="plain", xyz="w_split"), dict(last="plain", emb="plain")),
     "x3sn":    (dict(ind_exact=True, head="split", hidden="split"), dict(last="split", emb="split")),
 }
 
