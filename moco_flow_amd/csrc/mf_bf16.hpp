@@ -61,7 +61,7 @@ struct Stream {
 
   MF_D uint32_t slot_off(uint32_t k) const { return k == 0 ? off0 : (k == 1 ? off1 : off2); }
   // The panel hook, in two parts.  sync(): barrier of the panel, then the DMA source / destination of the panel two
-  // ahead are latched.  piece(k): this wave's k-th 1 KiB piece of that panel (k = 0..2: a panel is at most 24 groups
+  // ahead are latched.  piece(k): this wave's k-th 1 KiB piece of that panel (k = 0..3: a panel is at most 32 groups
   // over 8 waves); the pieces are issued one per MFMA gap behind the barrier instead of as a burst.
   const char* dsrc; uint32_t ddst; uint32_t pmask;
   MF_D void sync(int groups, const char* jump, const Lane& id) {
@@ -223,7 +223,7 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
     r[sp] = r[s];
 #endif
     if (gi == 0) hook();
-    if (gi >= 1 && gi <= 3) piece(gi - 1);
+    if (gi >= 1 && gi <= 4) piece(gi - 1);     // (the 4th piece: only the 32-group panels of MF_PREC_BF16X3 have one)
 #ifndef MF_BF_ABL_NOFRAG
     if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
 #endif
