@@ -92,9 +92,14 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_forward_kernel(NerfFwdParams
       if (valid) dump_row = p.dump + b * p.dump_stride;
     }
     nerf_eval<16, DUMP>(net, embx, ext, p.sigma_only != 0, st, carry, id, follow_of(net), sigma, rgb, dump_row);
-    if (valid && id.g == 0) {
-      if (p.sigma_only) p.out[b] = sigma;
-      else *reinterpret_cast<float4*>(p.out + b * 4) = make_float4(rgb[0], rgb[1], rgb[2], sigma);
+    // (the sample index is rebuilt from an opaque lane index: the 64-bit output address is then formed here instead of
+    //  being carried -- with DUMP: spilled -- across the MFMA section)
+    int jo = id.j;
+    asm volatile("" : "+v"(jo));
+    const long long bo = tile * kTile + id.wave * kWaveSamples + jo;
+    if (bo < p.B && id.g == 0) {
+      if (p.sigma_only) p.out[bo] = sigma;
+      else *reinterpret_cast<float4*>(p.out + bo * 4) = make_float4(rgb[0], rgb[1], rgb[2], sigma);
     }
   }
   wait_vm0();   // the stream runs two panels ahead: drain the LDS-DMA before the workgroup retires

@@ -91,48 +91,65 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
 
     for (int tile = 0; tile < ntiles; ++tile) {
       st.tl.stamp(1, id);
-      const int srel = tile * kTile + id.wave * kWaveSamples + id.j;
-      const bool valid = srel < nsamp;
-      const int sl = valid ? srel : nsamp - 1;
-      const int rr = sl / S;
-      const int si = sl - rr * S;
-      const long long ray = ray0 + rr;
-      const float* rp = p.rays + ray * p.ray_stride;
-      const float o[3] = {rp[0], rp[1], rp[2]};
-      const float d[3] = {rp[3], rp[4], rp[5]};
-      float z;
-      if (p.z_vals) {
-        z = p.z_vals[ray * S + si];
-      } else {
-        const float nearv = rp[6], farv = rp[7], t = p.z_steps[si];
-        if (!p.use_disp) z = nearv * (1.f - t) + farv * t;                    // rendering.py:247
-        else z = 1.f / (1.f / nearv * (1.f - t) + 1.f / farv * t);            // rendering.py:249
-      }
-      float x[3];
+      // Per-sample bookkeeping (sample / ray indices, the ray's row pointer, the index columns) is NOT carried through the
+      // tile: everything follows from the lane's column j and tile-uniform scalars, so each use site rebuilds what it
+      // needs from an opaque copy of j (`where()`).  Held in registers from here, those values -- and the 64-bit
+      // addresses hipcc derives from them ahead of time -- were what the MoCo training forward spilled (12 registers, 116
+      // bytes of scratch per lane in round 2's build).  z and the observation-space point wait in the group's LDS
+      // sample buffers (their slots are free until the tile's results are written).
+      struct Where { int srel, sl, si; bool valid; long long ray; const float* rp; };
+      auto where = [&]() {
+        int jo = id.j;
+        asm volatile("" : "+v"(jo));
+        Where w;
+        w.srel = tile * kTile + id.wave * kWaveSamples + jo;
+        w.valid = w.srel < nsamp;
+        w.sl = w.valid ? w.srel : nsamp - 1;
+        const int rr = w.sl / S;
+        w.si = w.sl - rr * S;
+        w.ray = ray0 + rr;
+        w.rp = p.rays + w.ray * p.ray_stride;
+        return w;
+      };
+      float xin[3];                            // what the canonical NeRF sees
+      {
+        const Where w = where();
+        const float* rp = w.rp;
+        const float o[3] = {rp[0], rp[1], rp[2]};
+        const float d[3] = {rp[3], rp[4], rp[5]};
+        float z;
+        if (p.z_vals) {
+          z = p.z_vals[w.ray * S + w.si];
+        } else {
+          const float nearv = rp[6], farv = rp[7], t = p.z_steps[w.si];
+          if (!p.use_disp) z = nearv * (1.f - t) + farv * t;                    // rendering.py:247
+          else z = 1.f / (1.f / nearv * (1.f - t) + 1.f / farv * t);            // rendering.py:249
+        }
 #pragma unroll
-      for (int c = 0; c < 3; ++c) x[c] = o[c] + d[c] * z;                      // rendering.py:262-263
-
+        for (int c = 0; c < 3; ++c) xin[c] = o[c] + d[c] * z;                    // rendering.py:262-263
+        if (w.valid && id.g == 0) {
+          zbuf[w.srel] = z;
+          if (MOCO) sbuf[w.srel] = make_float4(xin[0], xin[1], xin[2], 0.f);
+        }
+      }
 #ifdef MF_TIMELINE
-      asm volatile("s_waitcnt vmcnt(0)" : "+v"(x[0]), "+v"(x[1]), "+v"(x[2]));
+      asm volatile("s_waitcnt vmcnt(0)" : "+v"(xin[0]), "+v"(xin[1]), "+v"(xin[2]));
 #endif
       st.tl.stamp(2, id);
-      float xin[3] = {x[0], x[1], x[2]};      // what the canonical NeRF sees
       if (MOCO) {
         // chain program (rendering.py:270-282): step 0 bw(x,i) -> canon; local: fw(canon,i) -> recon;
         // global: fw(canon,j) -> a; bw(a,j) -> b; fw(b,i) -> chained recon.
-        const float ind_i = rp[8];
-        const float ind_j = (p.flags & MF_F_CHAIN_GLOBAL) ? rp[9] : 0.f;
         const bool loc = p.flags & MF_F_CHAIN_LOCAL, glob = p.flags & MF_F_CHAIN_GLOBAL;
         const int nsteps = 1 + (loc ? 1 : 0) + (glob ? 3 : 0);
-        float canon[3] = {0.f, 0.f, 0.f}, cur[3] = {x[0], x[1], x[2]};
-        float dl = 0.f, dg = 0.f;
+        float canon[3] = {0.f, 0.f, 0.f}, cur[3] = {xin[0], xin[1], xin[2]};
         for (int step = 0; step < nsteps; ++step) {
           // role of this step: 0 = bw_i, 1 = local fw_i, 2 = fw_j, 3 = bw_j, 4 = final fw_i
           // (chain_global implies chain_local -- checked on the host -- so role == step)
           const int role = step;
           const bool use_fw = (role == 1 || role == 2 || role == 4);
           const NetDev net = use_fw ? p.fw : p.bw;
-          const float ind = (role == 2 || role == 3) ? ind_j : ind_i;
+          const Where w = where();
+          const float ind = w.rp[(role == 2 || role == 3) ? 9 : 8];
           if (role == 1 || role == 2) { cur[0] = canon[0]; cur[1] = canon[1]; cur[2] = canon[2]; }
           // what follows this evaluation in the panel program
           const bool last = step == nsteps - 1;
@@ -141,11 +158,10 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
           float emb[kStepsNofIn], out[3];
           nof_embed_lds(emb, cur, ind, par_nof_xyz, par_nof_ind, id.g);
           float* nof_row = nullptr;
-          long long nof_idx = 0;
           if constexpr (DUMP) {
-            if (valid && p.dump_nof_acts) {
+            if (w.valid && p.dump_nof_acts) {
               // training forward: what autograd.NofPoints' backward reads, per chain step (step-major planes)
-              nof_idx = (long long)((p.nof_plane_pack >> (3 * step)) & 7u) * p.n_rays * S + (ray * S + si);
+              const long long nof_idx = (long long)((p.nof_plane_pack >> (3 * step)) & 7u) * p.n_rays * S + (w.ray * S + w.si);
               nof_row = p.dump_nof_acts + nof_idx * p.dump_nof_stride;
               // embedded input in the kernel's own slot order (column 20 g + e = slot e of lane group g: five 16-byte
               // stores per lane instead of twenty scattered dwords; mf_nof_emb_slot_features gives the column map)
@@ -157,21 +173,25 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
           }
           nof_eval<DUMP>(net, emb, cur, st, carry, id, follow, out, nof_row);
           if constexpr (DUMP) {
-            if (nof_row && id.g == 0) {
+            const Where v = where();
+            if (v.valid && p.dump_nof_acts && id.g == 0) {
+              const long long nof_idx = (long long)((p.nof_plane_pack >> (3 * step)) & 7u) * p.n_rays * S + (v.ray * S + v.si);
               float* q = p.dump_nof_out + nof_idx * 3;
               q[0] = out[0]; q[1] = out[1]; q[2] = out[2];
             }
           }
           if (role == 0) { canon[0] = out[0]; canon[1] = out[1]; canon[2] = out[2]; }
-          if (role == 1) dl = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
-          if (role == 4) dg = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
+          if (role == 1 || role == 4) {
+            const Where v = where();
+            const float4 x4 = sbuf[v.sl];          // the observation-space point (own wave's write, or -- lanes past the
+                                                   // group's last sample -- anything: their distances are never stored)
+            const float dd = (fabsf(x4.x - out[0]) + fabsf(x4.y - out[1]) + fabsf(x4.z - out[2])) / 3.f;
+            float* plane = role == 1 ? p.disp_local : p.disp_global;       // rendering.py:310-314, stored right away
+            if (v.valid && id.g == 0 && plane) plane[v.ray * S + v.si] = dd;
+          }
           cur[0] = out[0]; cur[1] = out[1]; cur[2] = out[2];
         }
         xin[0] = canon[0]; xin[1] = canon[1]; xin[2] = canon[2];
-        if (valid && id.g == 0) {
-          if (loc && p.disp_local) p.disp_local[ray * S + si] = dl;
-          if (glob && p.disp_global) p.disp_global[ray * S + si] = dg;
-        }
       }
 
       st.tl.stamp(3, id);
@@ -182,28 +202,35 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
       for (int e = BlkXyz10::SLOTS; e < kStepsNerfXyz; ++e) embx[e] = 0.f;
 #pragma unroll
       for (int e = 0; e < kStepsExtraMax; ++e) ext[e] = 0.f;
-      if (!sigma_only) {
-        if (p.extra_type == MF_EXTRA_DIR) {
-          emb_eval_lds<3, 4>(ext, d, par_nerf_ext, id.g);                                // rendering.py:138-142
-        } else if (p.extra_type == MF_EXTRA_IND) {
-          const float iv[1] = {rp[8]};
-          emb_eval_lds<1, 2>(ext, iv, par_nerf_ext, id.g);                               // rendering.py:133-137
+      float* dump_row = nullptr;
+      {
+        const Where w = where();
+        if (!sigma_only) {
+          if (p.extra_type == MF_EXTRA_DIR) {
+            const float dd[3] = {w.rp[3], w.rp[4], w.rp[5]};
+            emb_eval_lds<3, 4>(ext, dd, par_nerf_ext, id.g);                             // rendering.py:138-142
+          } else if (p.extra_type == MF_EXTRA_IND) {
+            const float iv[1] = {w.rp[8]};
+            emb_eval_lds<1, 2>(ext, iv, par_nerf_ext, id.g);                             // rendering.py:133-137
+          }
+        }
+        if constexpr (DUMP) {
+          if (w.valid && p.dump_acts) dump_row = p.dump_acts + (w.ray * S + w.si) * p.dump_stride;
         }
       }
       st.tl.stamp(4, id);
       float sigma, rgb[3] = {0.f, 0.f, 0.f};
-      float* dump_row = nullptr;
-      if constexpr (DUMP) {
-        if (valid && p.dump_acts) dump_row = p.dump_acts + (ray * S + si) * p.dump_stride;
-      }
       st.keep2 = false;      // the first panel's barrier drains everything (see Stream::sync_and_dma)
       nerf_eval<16, DUMP>(nerf, embx, ext, sigma_only, st, carry, id, prog_first, sigma, rgb, dump_row);
-      if (valid && id.g == 0) {
-        sbuf[srel] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
-        zbuf[srel] = z;
-        if constexpr (DUMP) {
-          if (p.dump_rgbsigma) *reinterpret_cast<float4*>(p.dump_rgbsigma + (ray * S + si) * 4) = make_float4(rgb[0], rgb[1], rgb[2], sigma);
-          if (p.dump_xyz) { float* q = p.dump_xyz + (ray * S + si) * 3; q[0] = xin[0]; q[1] = xin[1]; q[2] = xin[2]; }
+      {
+        const Where w = where();
+        if (w.valid && id.g == 0) {
+          sbuf[w.srel] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
+          if constexpr (DUMP) {
+            const long long row = w.ray * S + w.si;
+            if (p.dump_rgbsigma) *reinterpret_cast<float4*>(p.dump_rgbsigma + row * 4) = make_float4(rgb[0], rgb[1], rgb[2], sigma);
+            if (p.dump_xyz) { float* q = p.dump_xyz + row * 3; q[0] = xin[0]; q[1] = xin[1]; q[2] = xin[2]; }
+          }
         }
       }
       st.tl.stamp(5, id);

@@ -16,6 +16,7 @@
 //   * db falls out of the G tile already in LDS (one column per thread).
 #include "mf_host.hpp"
 #include "mf_core.hpp"
+#include <cstddef>
 #include <cstdlib>
 
 namespace mf {
@@ -272,15 +273,30 @@ MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, 
   }
 }
 
+// The item table is read through the kernarg segment pointer (scalar loads of one item at a time): indexing the by-value
+// `p.it[i]` with the runtime i made hipcc keep a private copy of all of WgParams in scratch (460 bytes per lane, 114
+// VGPR + 136 SGPR spills in round 2's build).
+MF_D WgItem wg_item(int i) {
+  typedef const __attribute__((address_space(4))) char* kptr;
+  const kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WgParams, it) + (size_t)i * sizeof(WgItem);
+  return *reinterpret_cast<const __attribute__((address_space(4))) WgItem*>(ka);
+}
+
 __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WgParams p) {
-  const LaneId id;
+  const LaneId id0;
   const int w = blockIdx.x;
   for (int i = 0; i < p.n_items; ++i) {
-    const WgItem& it = p.it[i];
+    const WgItem it = wg_item(i);
     long long b, e;
     wg_range(p.total_cost, p.grid, w, it.cost0, wg_stage_cost(it.shape), p.stages, b, e);
     if (b >= e) continue;
     float* part = p.scratch + it.part_off + (long long)(w - it.slot0) * wg_out_floats(it.shape);
+    // The lane / wave indices are made opaque per item: everything the eight shape bodies derive from them (fragment
+    // offsets, tile origins, bias columns) is invariant in this loop, and hipcc hoists all of it in front of the loop
+    // -- ~80 registers live across the 256x256 body with its 128 accumulators: 114 VGPR spills, 460 bytes of scratch per
+    // lane in round 2's build.
+    LaneId id = id0;
+    asm volatile("" : "+v"(id.lane), "+v"(id.j), "+v"(id.g), "+s"(id.wave));
     switch (it.shape) {
       case 0: wg_segment<ShapeA>(it, b, e, p.P, part, id, p.dbg); break;
       case 1: wg_segment<ShapeB>(it, b, e, p.P, part, id, p.dbg); break;
@@ -298,12 +314,15 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WgParams p) {
 __global__ void wgrad_reduce_kernel(WgParams p) {
   const int i = blockIdx.y;
   if (i >= p.n_items) return;
-  const WgItem& it = p.it[i];
+  const WgItem it = wg_item(i);
   const int nf = wg_out_floats(it.shape);
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= nf) return;
   const float* src = p.scratch + it.part_off + e;
-  float s = 0.f;
+  // fixed order, summed in double: up to 256 partials of mixed sign -- a weight gradient is a heavily cancelling sum
+  // over 1e5..1e6 samples, and a 256-long fp32 chain cost 4x the reference's own fp32 error on layer-0 gradients
+  // (tests/test_gpu_shapes.py::test_stage1_training_shape_vs_oracle)
+  double s = 0.0;
   if (it.dense) {
     for (int k = 0; k < it.n_slots; ++k) s += src[(long long)k * nf];
   } else {
@@ -324,8 +343,8 @@ __global__ void wgrad_reduce_kernel(WgParams p) {
     case 6: nout = ShapeG::NOUT; nin = ShapeG::NIN; break;
     default: nout = ShapeH::NOUT; nin = ShapeH::NIN; break;
   }
-  if (e < nout * nin) it.dW[e] = s;
-  else if (it.db) it.db[e - nout * nin] = s;
+  if (e < nout * nin) it.dW[e] = (float)s;
+  else if (it.db) it.db[e - nout * nin] = (float)s;
 }
 
 static int shape_of(const mf_wgrad_item& a) {
