@@ -277,9 +277,13 @@ MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, 
 // `p.it[i]` with the runtime i made hipcc keep a private copy of all of WgParams in scratch (460 bytes per lane, 114
 // VGPR + 136 SGPR spills in round 2's build).
 MF_D WgItem wg_item(int i) {
+  WgItem it;
+#if defined(__HIP_DEVICE_COMPILE__)
   typedef const __attribute__((address_space(4))) char* kptr;
   const kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(WgParams, it) + (size_t)i * sizeof(WgItem);
-  return *reinterpret_cast<const __attribute__((address_space(4))) WgItem*>(ka);
+  __builtin_memcpy(&it, (const __attribute__((address_space(4))) void*)ka, sizeof(WgItem));
+#endif
+  return it;
 }
 
 __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WgParams p) {
