@@ -33,7 +33,7 @@ extern "C" {
  * 10: mf_nerf_forward_dump, mf_render_args.dump_nof_* (+ mf_nof_emb_slot_features), mf_smpl_lbs,
  *     mf_smpl_frame_transforms, mf_apply_vertex_transforms
  * 12: MF_PREC_BF16 NoF takes its image-index block as a per-ray fp32 bias: mf_render_args.workspace(+_bytes),
- *     mf_render_workspace_bytes, mf_render_prepare, mf_points_sigma_workspace_bytes, workspace arguments of mf_points_sigma_p */
+ *     mf_render_workspace_bytes, mf_render_prepare, mf_loss_partials_backward, perturb arguments of mf_z_vals, mf_points_sigma_workspace_bytes, workspace arguments of mf_points_sigma_p */
 #define MF_ABI_VERSION 12
 
 enum {
@@ -378,13 +378,33 @@ int64_t mf_loss_partials_scratch_bytes(void);
 int32_t mf_loss_partials(const mf_loss_pass* coarse, const mf_loss_pass* fine, const float* target, int64_t n_rays,
                          double* out12, void* scratch, void* stream);
 
+/* Backward of mf_loss_partials (ABI v12): the training-mode loss epilogue.  g12 (device, 12 doubles) = dL/d out12 (only the
+ * six sums carry a gradient; out12 = the forward's result, its counts tell whether the consensus mask fell back to
+ * all-true).  Writes the gradient seeds the backward nodes of the pass consume, each buffer whole:
+ *   g_rgb (N,3)              = g12[2q] * 2 (rgb - target)                               models/losses.py:4-14
+ *   g_recon_local  (N*S,3)   = g12[4+2q] * mask * (-sign(x - recon_local)) / 3           models/rendering.py:310-311
+ *   g_recon_global (N*S,3)   = g12[8+2q] * mask * (-sign(x - recon_global)) / 3          models/rendering.py:313-314
+ * x = o + d z (rays columns 0-5, z_vals (N,S)); recon_* = the output points of the chain's last forward-flow evaluation
+ * (mf_render_args.dump_nof_out planes of steps 1 / 4).  Any output pointer may be NULL. */
+typedef struct mf_loss_grad_pass {
+  const float* rgb; float* g_rgb;
+  const float* alphas; int32_t n_samples;
+  const float* rays; int64_t ray_stride; const float* z_vals;
+  const float* recon_local; float* g_recon_local;
+  const float* recon_global; float* g_recon_global;
+} mf_loss_grad_pass;
+int32_t mf_loss_partials_backward(const mf_loss_grad_pass* coarse, const mf_loss_grad_pass* fine, const float* target,
+                                  int64_t n_rays, const double* out12, const double* g12, void* stream);
+
 /* The sample depths of a pass as render_rays materialises them when something outside the fused kernel needs them
  * (the resample, stratified jitter, the backward): z_out (N, S) = near*(1-t) + far*t, or 1/(1/near*(1-t) + 1/far*t)
  * with use_disp (models/rendering.py:245-251; near / far = columns 6 / 7 of the ray rows, t = z_steps (S) = linspace(0,1,S));
  * every product and sum separately rounded, bit-identical to the torch expression and to the fused pass's own z.
- * (ABI v11) */
+ * perturb_rand (N, S) uniform draws, or NULL (ABI v12): the stratified jitter of rendering.py:253-260 in the same launch,
+ * z = lower + (upper - lower) * (perturb * rand) with lower / upper the neighbouring mid-points (the ray's ends at the
+ * ends), again bit-identical to the torch expression. */
 int32_t mf_z_vals(const float* rays, int64_t ray_stride, int64_t n_rays, const float* z_steps, int32_t n_samples,
-                  int32_t use_disp, float* z_out, void* stream);
+                  int32_t use_disp, const float* perturb_rand, float perturb, float* z_out, void* stream);
 
 /* ---- producers either side of the path -----------------------------
  * Camera.make_rays (utils/camera.py:134-148 with gen_ray_directions :29-50 and gen_rays :52-81):

@@ -62,6 +62,12 @@ class mf_loss_pass(C.Structure):
     _fields_ = [("rgb", _fp), ("alphas", _fp), ("disp_local", _fp), ("disp_global", _fp), ("n_samples", C.c_int32)]
 
 
+class mf_loss_grad_pass(C.Structure):
+    _fields_ = [("rgb", _fp), ("g_rgb", _fp), ("alphas", _fp), ("n_samples", C.c_int32),
+                ("rays", _fp), ("ray_stride", C.c_int64), ("z_vals", _fp),
+                ("recon_local", _fp), ("g_recon_local", _fp), ("recon_global", _fp), ("g_recon_global", _fp)]
+
+
 class mf_render_args(C.Structure):
     _fields_ = [("rays", _fp), ("ray_stride", C.c_int64), ("n_rays", C.c_int64),
                 ("background", _fp), ("n_samples", C.c_int32),
@@ -124,7 +130,7 @@ SYMBOLS = {
     "mf_sample_pdf_merge": (C.c_int32, [_fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
     "mf_sample_pdf": (C.c_int32, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_int64,
                                   _fp, _fp, _fp, _fp, _fp]),
-    "mf_z_vals": (C.c_int32, [_fp, C.c_int64, C.c_int64, _fp, C.c_int32, C.c_int32, _fp, _fp]),
+    "mf_z_vals": (C.c_int32, [_fp, C.c_int64, C.c_int64, _fp, C.c_int32, C.c_int32, _fp, C.c_float, _fp, _fp]),
     "mf_make_rays": (C.c_int32, [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float),
                                  C.c_float, C.c_float, C.c_float, _fp, _fp]),
     "mf_knn1": (C.c_int32, [_fp, C.c_int64, _fp, C.c_int64, _fp, _fp, _fp]),
@@ -138,6 +144,7 @@ SYMBOLS = {
     "mf_valid_rays_mask": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _fp, _fp]),
     "mf_loss_partials_scratch_bytes": (C.c_int64, []),
     "mf_loss_partials": (C.c_int32, [C.POINTER(mf_loss_pass), C.POINTER(mf_loss_pass), _fp, C.c_int64, _fp, _fp, _fp]),
+    "mf_loss_partials_backward": (C.c_int32, [C.POINTER(mf_loss_grad_pass), C.POINTER(mf_loss_grad_pass), _fp, C.c_int64, _fp, _fp, _fp]),
     "mf_compact_scratch_bytes": (C.c_int64, [C.c_int64]),
     "mf_compact_mask": (C.c_int32, [_fp, _fp, _fp, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
 }

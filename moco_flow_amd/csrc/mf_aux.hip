@@ -159,17 +159,26 @@ __global__ __launch_bounds__(256) void knn1_kernel(KnnParams p) {
 
 // rendering.py:245-251: z_vals (N, S) from the rays' near / far and the S linspace steps, separately rounded
 // multiplies and adds exactly as the torch expression (and as the fused pass computes them in registers)
+// With perturb_rand (N, S): the stratified jitter of rendering.py:253-260 in the same launch --
+//   mid = 0.5 (z[:, :-1] + z[:, 1:]); upper = [mid, z_last]; lower = [z_0, mid]; z = lower + (upper - lower) * (perturb * rand)
+// -- every operation separately rounded in the torch expression's order (this unit is built with -ffp-contract=off).
 __global__ void z_vals_kernel(const float* rays, long long ray_stride, long long n_rays, const float* z_steps, int S,
-                              int use_disp, float* out) {
+                              int use_disp, const float* perturb_rand, float perturb, float* out) {
   const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n_rays * S) return;
   const long long ray = i / S;
   const int si = (int)(i - ray * S);
-  const float nearv = rays[ray * ray_stride + 6], farv = rays[ray * ray_stride + 7], t = z_steps[si];
-  float z;
-  if (!use_disp) z = nearv * (1.f - t) + farv * t;
-  else z = 1.f / (1.f / nearv * (1.f - t) + 1.f / farv * t);
-  out[i] = z;
+  const float nearv = rays[ray * ray_stride + 6], farv = rays[ray * ray_stride + 7];
+  auto zat = [&](int k) {
+    const float t = z_steps[k];
+    if (!use_disp) return nearv * (1.f - t) + farv * t;
+    return 1.f / (1.f / nearv * (1.f - t) + 1.f / farv * t);
+  };
+  const float z = zat(si);
+  if (!perturb_rand) { out[i] = z; return; }
+  const float lower = si > 0 ? 0.5f * (zat(si - 1) + z) : z;
+  const float upper = si + 1 < S ? 0.5f * (z + zat(si + 1)) : z;
+  out[i] = lower + (upper - lower) * (perturb * perturb_rand[i]);
 }
 
 }  // namespace mf
@@ -177,14 +186,14 @@ __global__ void z_vals_kernel(const float* rays, long long ray_stride, long long
 using namespace mf;
 
 extern "C" int32_t mf_z_vals(const float* rays, int64_t ray_stride, int64_t n_rays, const float* z_steps, int32_t n_samples,
-                             int32_t use_disp, float* z_out, void* stream) {
+                             int32_t use_disp, const float* perturb_rand, float perturb, float* z_out, void* stream) {
   if (n_rays < 0 || n_samples < 1 || ray_stride < 8) return fail(MF_E_INVALID, "mf_z_vals: n_rays=%lld n_samples=%d ray_stride=%lld",
                                                                   (long long)n_rays, n_samples, (long long)ray_stride);
   if (n_rays == 0) return MF_OK;
   if (!rays || !z_steps || !z_out) return fail(MF_E_INVALID, "mf_z_vals: null argument");
   const long long n = n_rays * n_samples;
   hipLaunchKernelGGL(z_vals_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), rays,
-                     (long long)ray_stride, (long long)n_rays, z_steps, n_samples, use_disp, z_out);
+                     (long long)ray_stride, (long long)n_rays, z_steps, n_samples, use_disp, perturb_rand, perturb, z_out);
   return check_launch("mf_z_vals");
 }
 

@@ -108,9 +108,94 @@ __global__ __launch_bounds__(kLossBlocks) void loss_finish_kernel(LossParams p, 
   }
 }
 
+// ---- backward of the partial sums (the training-mode loss epilogue) ----
+// g12 = dL / d out12 (only the six sums carry a gradient).  Seeds, written whole (zeros where the mask is off) into the
+// buffers the composite / NoF backward nodes consume:
+//   g_rgb[i]        = g12[2q]     * 2 (rgb[i] - target[i])                              MSELoss, models/losses.py:4-14
+//   g_recon[p][c]   = g12[4+2q] * m_p * (-sign(x_p[c] - recon_p[c])) / 3                 mean_c |x - recon|, rendering.py:310-314
+// with x = o + d z the observation-space point (rendering.py:262-263) and m the consensus mask alpha >= 0.01, all-true
+// when empty (:306-308) -- known from the forward's count (count == N S means every point was counted).
+struct LossGradPass {
+  const float* rgb; float* g_rgb;
+  const float* alphas; const float* rays; long long ray_stride; const float* z;
+  const float* rl; float* g_rl; const float* rg; float* g_rg;
+  long long n_pix, n_samp; int S;
+};
+struct LossGradParams {
+  LossGradPass pass[2];
+  const float* target; const double* out12; const double* g12;
+};
+
+__global__ __launch_bounds__(kLossThreads) void loss_partials_backward_kernel(LossGradParams p) {
+  const long long tid = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long nth = (long long)gridDim.x * blockDim.x;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const LossGradPass& P = p.pass[q];
+    if (P.g_rgb) {
+      const float g = (float)p.g12[2 * q];
+      for (long long i = tid; i < P.n_pix; i += nth) P.g_rgb[i] = g * (2.f * (P.rgb[i] - p.target[i]));
+    }
+    if (P.g_rl || P.g_rg) {
+      const float gl = (float)(p.g12[4 + 2 * q] / 3.0), gg = (float)(p.g12[8 + 2 * q] / 3.0);
+      const double cnt = P.g_rl ? p.out12[4 + 2 * q + 1] : p.out12[8 + 2 * q + 1];
+      const bool all = cnt == (double)P.n_samp;
+      for (long long i = tid; i < P.n_samp; i += nth) {
+        const long long ray = i / P.S;
+        const float* rp = P.rays + ray * P.ray_stride;
+        const float z = P.z[i];
+        const bool m = all || P.alphas[i] >= 0.01f;
+#pragma unroll
+        for (int c = 0; c < 3; ++c) {
+          const float x = rp[c] + rp[3 + c] * z;
+          if (P.g_rl) {
+            const float d = x - P.rl[i * 3 + c];
+            P.g_rl[i * 3 + c] = m ? (d > 0.f ? -gl : (d < 0.f ? gl : 0.f)) : 0.f;
+          }
+          if (P.g_rg) {
+            const float d = x - P.rg[i * 3 + c];
+            P.g_rg[i * 3 + c] = m ? (d > 0.f ? -gg : (d < 0.f ? gg : 0.f)) : 0.f;
+          }
+        }
+      }
+    }
+  }
+}
+
 }  // namespace mf
 
 using namespace mf;
+
+extern "C" int32_t mf_loss_partials_backward(const mf_loss_grad_pass* coarse, const mf_loss_grad_pass* fine, const float* target,
+                                             int64_t n_rays, const double* out12, const double* g12, void* stream) {
+  if (!coarse || !out12 || !g12 || n_rays < 0) return fail(MF_E_INVALID, "mf_loss_partials_backward: null argument");
+  if (n_rays == 0) return MF_OK;
+  LossGradParams p{};
+  const mf_loss_grad_pass* src[2] = {coarse, fine};
+  long long work = 0;
+  for (int q = 0; q < 2; ++q) {
+    if (!src[q]) continue;
+    const mf_loss_grad_pass& s = *src[q];
+    if (s.g_rgb && (!s.rgb || !target)) return fail(MF_E_INVALID, "mf_loss_partials_backward: g_rgb without rgb / target");
+    const bool cons = s.g_recon_local || s.g_recon_global;
+    if (cons && (!s.alphas || !s.rays || !s.z_vals || s.n_samples < 1 || s.ray_stride < 6 || (s.g_recon_local && !s.recon_local) ||
+                 (s.g_recon_global && !s.recon_global)))
+      return fail(MF_E_INVALID, "mf_loss_partials_backward: consensus seeds need alphas, rays, z_vals, n_samples and the reconstructed points");
+    LossGradPass& P = p.pass[q];
+    P.rgb = s.rgb; P.g_rgb = s.g_rgb; P.alphas = s.alphas; P.rays = s.rays; P.ray_stride = s.ray_stride; P.z = s.z_vals;
+    P.rl = s.recon_local; P.g_rl = s.g_recon_local; P.rg = s.recon_global; P.g_rg = s.g_recon_global;
+    P.n_pix = s.g_rgb ? n_rays * 3 : 0;
+    P.S = s.n_samples;
+    P.n_samp = cons ? n_rays * (long long)s.n_samples : 0;
+    work += P.n_pix + P.n_samp;
+  }
+  p.target = target; p.out12 = out12; p.g12 = g12;
+  if (work == 0) return MF_OK;
+  int blocks = (int)((work + kLossThreads * 4 - 1) / (kLossThreads * 4));
+  blocks = blocks < 1 ? 1 : (blocks > 2048 ? 2048 : blocks);
+  hipLaunchKernelGGL(loss_partials_backward_kernel, dim3(blocks), dim3(kLossThreads), 0, static_cast<hipStream_t>(stream), p);
+  return check_launch("mf_loss_partials_backward");
+}
 
 extern "C" int64_t mf_loss_partials_scratch_bytes(void) { return (int64_t)kLossBlocks * kLossSlots * sizeof(double); }
 

@@ -314,17 +314,16 @@ def render_rays(rays,
     z_steps = torch.linspace(0, 1, S, device=dev)                     # rendering.py:245
     z_vals = None
     if perturb > 0 or need_fine or grad:
-        z_vals = torch.empty((N, S), device=dev, dtype=torch.float32)   # rendering.py:245-251, one launch (mf_z_vals)
+        # rendering.py:245-251 and, with perturb > 0, the stratified jitter of :253-260: one launch (mf_z_vals), the
+        # uniform draws made here with torch in the reference's order
+        pr = None
+        if perturb > 0:
+            pr = _rng["perturb_rand"] if "perturb_rand" in _rng else torch.rand((N, S), device=dev)
+            pr = pr.contiguous().float()
+        z_vals = torch.empty((N, S), device=dev, dtype=torch.float32)
         with torch.cuda.device(dev):
             L.check(L.lib().mf_z_vals(L.ptr(rays), rays.stride(0), N, L.ptr(z_steps), S, 1 if use_disp else 0,
-                                      L.ptr(z_vals), L.current_stream(dev)), "mf_z_vals")
-        if perturb > 0:                                                # rendering.py:253-260
-            z_mid = 0.5 * (z_vals[:, :-1] + z_vals[:, 1:])
-            upper = torch.cat([z_mid, z_vals[:, -1:]], -1)
-            lower = torch.cat([z_vals[:, :1], z_mid], -1)
-            pr = _rng["perturb_rand"] if "perturb_rand" in _rng else torch.rand(z_vals.shape, device=dev)
-            z_vals = lower + (upper - lower) * (perturb * pr)
-        z_vals = z_vals.contiguous()
+                                      L.ptr(pr), float(perturb), L.ptr(z_vals), L.current_stream(dev)), "mf_z_vals")
 
     def draw_noise(shape, key=None):
         if key in _rng:
@@ -353,7 +352,11 @@ def render_rays(rays,
         result = {'opacity_coarse': c["opacity"]}
     else:
         result = {'rgb_coarse': c["rgb"], 'depth_coarse': c["depth"], 'opacity_coarse': c["opacity"]}
-    fused_loss = _loss_target is not None
+    # the 12 loss partials replace the compacted consensus vectors -- unless gradients are wanted on a pass the explicit
+    # HIP backward does not cover (the sigma-only coarse pass of test_time): there the partials are assembled from the
+    # attached result below, consensus vectors included
+    explicit = grad and N > 0 and not coarse_sigma_only
+    fused_loss = _loss_target is not None and (explicit or not (grad and N > 0))
     if (loc or glob) and not fused_loss:
         la, ga = _compact(c["alphas"], c.get("disp_local"), c.get("disp_global"))
         if loc:
@@ -393,6 +396,9 @@ def render_rays(rays,
                                   nof_embeddings, nof_models if use_nof else None, loc, glob, nerf_activate_type,
                                   coarse_sigma_only, z_vals, noise_c, c["alphas"],
                                   (z_all, noise_f, f["alphas"]) if need_fine else None)
+        if _loss_target is not None:
+            from . import dist as _dist
+            result['loss_partials'] = _dist.loss_partials(result, _loss_target.detach().float())
     return result
 
 
@@ -436,15 +442,15 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
       * autograd.NofPoints -- one HIP forward-with-dump / backward node per NoF evaluation of the chains.
     Each returned tensor is  hip_value + (torch_value - torch_value.detach())."""
     rays_o, rays_d, ind = rays[:, 0:3], rays[:, 3:6], rays[:, 8:9]
-    out, cons = {}, {}
+    out, recons, kernel_vals = {}, {}, set()
 
     def one(tag, nerf, pack):
         p, z, noise = pack
         N, S = z.shape
         xyz = rays_o.unsqueeze(1) + rays_d.unsqueeze(1) * z.unsqueeze(2)
         mask = None
-        if loc or glob:
-            mask = _mask_of(p["alphas"]) if loss_target is None else _mask_nosync(p["alphas"])
+        if (loc or glob) and loss_target is None:
+            mask = _mask_of(p["alphas"])
         xin = p["xyz_in"]
         if nof_models is not None:
             bw = nof_models[0]
@@ -454,12 +460,15 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
                 n_bw = sum(1 for k in range(len(plane)) if k in (0, 3))
                 # per network: its planes are adjacent; with whole 128-row blocks per plane the nodes leave their
                 # pre-activation gradients in one buffer and ONE mf_weight_grads launch per network follows them
-                batched = (N * S) % 128 == 0
+                # (the sinks are keyed by module: not when one NoF object plays both roles; and a frozen network has no
+                #  weight gradients to batch -- its gate's backward would never run and flush the buffer)
+                batched = (N * S) % 128 == 0 and (len(nof_models) < 2 or nof_models[0] is not nof_models[1])
+                trains = lambda m: any(q.requires_grad for q in m.parameters())
                 sinks = {}
-                if batched:
+                if batched and trains(bw):
                     sinks[id(bw)] = (A.NofGradSink(bw, p["nof_acts"][:n_bw], p["nof_emb"][:n_bw]), 0)
-                    if len(plane) > n_bw:
-                        sinks[id(nof_models[1])] = (A.NofGradSink(nof_models[1], p["nof_acts"][n_bw:], p["nof_emb"][n_bw:]), n_bw)
+                if batched and len(plane) > n_bw and trains(nof_models[1]):
+                    sinks[id(nof_models[1])] = (A.NofGradSink(nof_models[1], p["nof_acts"][n_bw:], p["nof_emb"][n_bw:]), n_bw)
                 gated = {key: A.NofParamGate.apply(sk, *sk.m.parameters()) for key, (sk, _) in sinks.items()}
 
                 def nof_points(pts, ray_ind, embs_, m):
@@ -477,16 +486,16 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
                 if loss_target is None:
                     out[f"nof_local_disp_{tag}"] = _masked_point_means(torch.abs(xyz - recon), mask)
                 else:
-                    cons[f"local_{tag}"] = _masked_sum(torch.abs(xyz - recon), mask)
+                    recons[f"local_{tag}"] = recon           # the loss node differentiates |x - recon| itself
             if glob:
                 cind = rays[:, 9:10]
                 a_ = nof_points(canon, cind, nof_embs, fw)
                 b_ = nof_points(a_, cind, nof_embs, bw)
-                gd = torch.abs(xyz - nof_points(b_, ind, nof_embs, fw))
+                chained = nof_points(b_, ind, nof_embs, fw)
                 if loss_target is None:
-                    out[f"nof_global_disp_{tag}"] = _masked_point_means(gd, mask)
+                    out[f"nof_global_disp_{tag}"] = _masked_point_means(torch.abs(xyz - chained), mask)
                 else:
-                    cons[f"global_{tag}"] = _masked_sum(gd, mask)
+                    recons[f"global_{tag}"] = chained
             xin = canon.reshape(-1, 3)
         with torch.no_grad():
             # (mf_embedding_forward: one launch each instead of ~60 elementwise ones)
@@ -502,6 +511,7 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
             out[f"rgb_{tag}"], out[f"depth_{tag}"], out[f"opacity_{tag}"] = A.CompositeSamples.apply(
                 rgbsig, rays, z, noise, activation, background, result[f"rgb_{tag}"], result[f"depth_{tag}"],
                 result[f"opacity_{tag}"])
+            kernel_vals.update((f"rgb_{tag}", f"depth_{tag}", f"opacity_{tag}"))
         else:
             comp = A.composite_from_samples(rgbsig, z, rays_d, noise, activation, background, False)
             out[f"rgb_{tag}"], out[f"depth_{tag}"], out[f"opacity_{tag}"] = comp["rgb"], comp["depth"], comp["opacity"]
@@ -512,22 +522,19 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
     final = {}
     for k, v in result.items():
         t = out[k]
-        final[k] = v.detach() + (t - t.detach())
+        # CompositeSamples hands back the kernel's own values (detached clones): nothing to re-base
+        final[k] = t if k in kernel_vals else v.detach() + (t - t.detach())
     if loss_target is not None:
-        # differentiable (sum, count) pairs in the layout of dist.loss_partials / mf_loss_partials
-        tgt = loss_target.detach().float()
-        zero = torch.zeros((), dtype=torch.float64, device=tgt.device)
-        parts = []
-        for tag in ("coarse", "fine"):
-            if f"rgb_{tag}" in final:
-                d = (final[f"rgb_{tag}"] - tgt).double()
-                parts += [(d * d).sum(), torch.full((), float(d.numel()), dtype=torch.float64, device=tgt.device)]
-            else:
-                parts += [zero, zero]
-        for key in ("local", "global"):
-            for tag in ("coarse", "fine"):
-                parts += list(cons.get(f"{key}_{tag}", (zero, zero)))
-        final["loss_partials"] = torch.stack(parts)
+        # the 12 (sum, count) partials (layout of dist.loss_partials / mf_loss_partials) as one autograd node: forward =
+        # the kernel on the planes the passes wrote, backward = one launch writing the seeds (autograd.LossPartials)
+        tgt = loss_target.detach().float().contiguous()
+        passes = [dict(planes=coarse[0], z=coarse[1])] + ([dict(planes=fine[0], z=fine[1])] if fine is not None else [])
+        tensors = []
+        for tag in ("coarse", "fine")[:len(passes)]:
+            tensors += [out[f"rgb_{tag}"], recons.get(f"local_{tag}"), recons.get(f"global_{tag}")]
+        N = rays.shape[0]
+        final["loss_partials"] = A.LossPartials.apply(
+            lambda: _loss_partials_hip(coarse[0], fine[0] if fine is not None else None, tgt, N), rays, tgt, passes, *tensors)
     return final
 
 
@@ -535,18 +542,6 @@ def _masked_point_means(dist3, mask):
     """torch.mean(dist3[mask], dim=1) of rendering.py:310-314 as mean-then-select: the same numbers, but the backward
     is a masked scatter instead of the sort + accumulate of boolean-index backward."""
     return torch.masked_select(dist3.mean(-1), mask)
-
-
-def _mask_nosync(alphas):
-    """rendering.py:306-308 without the host round trip of ``if not torch.any(mask)``."""
-    mask = alphas.ge(0.01)
-    return torch.where(mask.any(), mask, torch.ones_like(mask))
-
-
-def _masked_sum(dist3, mask):
-    """(sum over masked points of the per-point mean distance, number of masked points), float64 scalars."""
-    m = mask.to(dist3.dtype)
-    return (dist3.mean(-1) * m).sum().double(), m.sum().double()
 
 
 def _mask_of(alphas):

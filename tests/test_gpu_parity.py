@@ -205,9 +205,20 @@ def test_z_vals_bit_identical_to_the_torch_expression(M):
         for use_disp in (0, 1):
             want = (near * (1 - t) + far * t) if not use_disp else 1 / (1 / near * (1 - t) + 1 / far * t)
             got = torch.empty(N, S, device="cuda")
-            L.check(L.lib().mf_z_vals(L.ptr(rays), rays.stride(0), N, L.ptr(t), S, use_disp, L.ptr(got),
+            L.check(L.lib().mf_z_vals(L.ptr(rays), rays.stride(0), N, L.ptr(t), S, use_disp, None, 0.0, L.ptr(got),
                                       L.current_stream(rays.device)), "mf_z_vals")
             assert torch.equal(got, want.expand(N, S)), (N, S, use_disp, float((got - want).abs().max()) if N else 0)
+            # the stratified jitter of rendering.py:253-260 in the same launch: the reference's own expression, bit for bit
+            for perturb in (1.0, 0.37):
+                z_vals = want.expand(N, S).contiguous()
+                pr = torch.rand(N, S, device="cuda")
+                z_mid = 0.5 * (z_vals[:, :-1] + z_vals[:, 1:])
+                upper = torch.cat([z_mid, z_vals[:, -1:]], -1)
+                lower = torch.cat([z_vals[:, :1], z_mid], -1)
+                want_p = lower + (upper - lower) * (perturb * pr)
+                L.check(L.lib().mf_z_vals(L.ptr(rays), rays.stride(0), N, L.ptr(t), S, use_disp, L.ptr(pr), perturb, L.ptr(got),
+                                          L.current_stream(rays.device)), "mf_z_vals")
+                assert torch.equal(got, want_p), (N, S, use_disp, perturb, float((got - want_p).abs().max()) if N else 0)
 
 
 def test_sample_pdf_indices_bit_exact(M):

@@ -155,12 +155,14 @@ def test_stage1_training_shape_vs_oracle(M, R):
     """Stage 1 shape (init_nerf.yaml: 128 + 128 samples, NeRF(dir/27) with the xyz encoding at N_freqs = 0 zero-padded
     to 63 columns, softplus densities, perturb = 1.0) on 128 of its 5120 rays: training-mode forward 1e-4 against the
     oracle, and the END-TO-END gradients of the reference's loss (MSE coarse + fine, models/losses.py:4-14).
-    Gradient bar: a weight gradient here is a sum over 49 152 samples of mixed-sign products, and the REFERENCE's own
-    fp32 arithmetic is only good to a few 1e-4 on it (oracle fp32 vs fp64 autograd: up to 5.7e-4 on xyz_encoding_3 at
-    this shape, measured in the build container).  So the truth is the oracle in float64, and each HIP tensor must be
-    within max(1e-4, 3 x the fp32 oracle's own distance to it) -- i.e. as good as the reference's arithmetic, not
-    better than it can be.  (What pins each backward kernel at 1e-4 is test_*_backward_vs_oracle*: same function,
-    same points.)"""
+    Gradient bars.  A weight gradient here is a heavily cancelling sum over 49 152 samples behind eight ReLUs, and the
+    REFERENCE's own fp32 arithmetic is only good to ~1e-4 on it: oracle fp32 vs float64 autograd differ by up to 4.3e-4
+    max-rel / 1.3e-4 l2-rel per tensor at this shape (measured in the build container) -- single borderline samples
+    whose ReLU mask flips between two fp32 evaluation orders move a row of dW by their whole contribution, so the
+    max-rel figure is a discrete event, not rounding noise.  The truth is therefore the oracle in float64, and every
+    HIP tensor must be within 3x the fp32 oracle's own l2 distance to it (floor 1e-4), with max-rel <= 2e-3 as the
+    guard against a wrong element.  (What pins each backward kernel at 1e-4 is test_*_backward_vs_oracle*: the same
+    function at the same points, masks included.)"""
     from moco_flow_amd import synth
     c = dict(STAGE1)
     n, S, Mi = 128, c["S"], c["M"]
@@ -181,20 +183,26 @@ def test_stage1_training_shape_vs_oracle(M, R):
         e = relerr(res[k].detach(), v.detach())
         print(f"stage-1 shape (training forward) {k}: max-rel {e:.2e}")
         assert e <= TOL, (k, e)
-    checked, worst, floor = 0, (0.0, ""), (0.0, "")
+    def l2rel(a, b):
+        a, b = a.detach().cpu().double(), b.detach().double()
+        return float((a - b).norm() / b.norm().clamp_min(1e-30))
+
+    checked, worst, floor, worst_max = 0, (0.0, ""), (0.0, ""), (0.0, "")
     for key, g in g64.items():
         i, k = key
         p = dict(nerfs[i].named_parameters())[k]
         if g is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
             continue
-        noise = relerr(g32[key], g)                     # the reference arithmetic's own error on this tensor
-        e = relerr(p.grad, g)
+        noise = l2rel(g32[key], g)                      # the reference arithmetic's own error on this tensor
+        e, emax = l2rel(p.grad, g), relerr(p.grad, g)
         worst, floor = max(worst, (e, f"{i}.{k}")), max(floor, (noise, f"{i}.{k}"))
+        worst_max = max(worst_max, (emax, f"{i}.{k}"))
         assert e <= max(TOL, 3 * noise), (i, k, e, noise)
+        assert emax <= 2e-3, (i, k, emax)
         checked += 1
-    print(f"stage-1 shape: end-to-end gradients vs the float64 oracle, worst max-rel {worst[0]:.2e} at {worst[1]} "
-          f"(fp32 oracle's own worst {floor[0]:.2e} at {floor[1]}; {checked} tensors)")
+    print(f"stage-1 shape: end-to-end gradients vs the float64 oracle, worst l2-rel {worst[0]:.2e} at {worst[1]}, worst max-rel "
+          f"{worst_max[0]:.2e} at {worst_max[1]} (fp32 oracle's own worst l2-rel {floor[0]:.2e} at {floor[1]}; {checked} tensors)")
     assert checked == 2 * 24
 
 
