@@ -1,30 +1,23 @@
 """Backward pass of the drop-in modules.
 
-Forward values always come from the fused HIP kernels.  When gradients are requested:
-
-* fp32 render passes (the training path): the fused forward additionally DUMPS what the backward
-  needs (per-sample post-activation layer outputs, rgb/sigma, NeRF input points; mf_render_args
-  dump_*) and the backward is HIP too, as a handful of autograd nodes whose backward methods are
-  single launches:
+Forward values always come from the fused HIP kernels.  When gradients are requested the fp32 forward additionally
+DUMPS what the backward needs (per-sample post-activation layer outputs, rgb / sigma, NeRF input points, every NoF
+evaluation of the chains; mf_render_args.dump_*) and the backward is HIP too, as a handful of autograd nodes whose
+backward methods are single launches:
+    ``LossPartials``      mf_loss_partials / mf_loss_partials_backward   the 12 (sum, count) loss partials of the step
     ``CompositeSamples``  mf_composite_backward   dL/d(rgb, depth, opacity) -> dL/d(rgb, sigma) per sample
-    ``NerfSamples``       mf_nerf_backward + mf_weight_grads   the 12-layer NeRF: input-gradient chain on the
-                          transposed weights over the dump, then every dW / db in one persistent launch
-    ``NofPoints``         mf_nof_points_dump (forward) / mf_nof_backward + mf_weight_grads   one NoF
-                          evaluation on points; the consensus chains are compositions of this node
-  No forward recompute of the NeRF, no autograd graph over any MLP, no library GEMM.  Measured (MI355X):
-  stage-1 step (5120 rays x (128 + 256) samples) 59 ms vs 154 ms for the reference's own op sequence
-  under PyTorch-ROCm autograd on the same GPU; joint MoCo stage (1024 rays x 384 samples, local + global
-  chains) 29 ms vs 138 ms.  (_NERF_BACKWARD / _NOF_BACKWARD / _COMPOSITE_BACKWARD are timing-comparison hooks for
-  tools/ab_switches.py -- library-GEMM / torch-recompute variants -- not part of the drop-in surface.)
-* ``NeRF(x[, sigma_only])`` / ``NoF(x, xyz)`` called directly (the joint stage's point losses): ``NerfModule`` /
-  ``NofModule`` -- a dumping forward launch, then the same backward launches.
-* everything else (shapes the fused backward is not built for, the sigma-only coarse pass): ``RecomputeBackward`` re-runs the
-  pass with differentiable device ops (the reference's op sequence: models/nerf.py:78-102,
-  models/nof.py:69-82, models/embedding.py:42-46, models/rendering.py:49-192) on exactly the depths /
-  noise / masks the kernels used.
+    ``NerfSamples``       mf_nerf_backward_x + mf_weight_grads   the 12-layer NeRF: input-gradient chain on the transposed
+                          weights over the dump, then every dW / db in one persistent launch
+    ``NofPointsDumped``   mf_nof_backward (+ one mf_weight_grads per network, NofGradSink)   one NoF evaluation of a chain
+    ``NofPoints``         the same node with its own dumping forward (mf_nof_points_dump)
+``NeRF(x[, sigma_only])`` / ``NoF(x, xyz)`` / ``Embedding(x)`` called directly (the joint stage's point losses):
+``NerfModule`` / ``NofModule`` / ``EmbeddingModule`` -- a dumping forward launch, then the same backward launches.
+No forward recompute, no autograd graph over any MLP, no eager restatement of the reference anywhere in the package: a
+shape the HIP backward is not built for raises NotImplementedError under grad (require_nerf_hip / require_nof_hip; the
+reference's three YAML configurations are inside the envelope).  The eager op sequence the tools time against lives in
+tools/eager_ref.py.
 
-All of this runs on the GPU and shares no code with the test-side checker.  Gradients reach every
-parameter that requires grad (frozen sub-modules are honoured, trainer_moco_flow.py:391-404) and do
+Gradients reach every parameter that requires grad (frozen sub-modules are honoured, trainer_moco_flow.py:391-404) and do
 not flow through the resampled depths (rendering.py:323).
 """
 from __future__ import annotations
@@ -38,16 +31,6 @@ import torch.nn.functional as F
 from . import _lib as L
 
 
-# ------------------------------------------------------------------ differentiable restatement
-def embed(emb, x):
-    """embedding.py:42-46 with torch ops on x's device."""
-    out = [x]
-    for w, f in zip(emb.weights, emb.freq_bands):
-        f = float(f)
-        out += [w * torch.sin(f * x), w * torch.cos(f * x)]
-    return torch.cat(out, -1)
-
-
 def _pad_to(t, width):
     if t.shape[1] == width:
         return t
@@ -56,179 +39,12 @@ def _pad_to(t, width):
     return out
 
 
-def nerf_forward(m, inputs, sigma_only=False):
-    """nerf.py:78-102 on the module's own parameters."""
-    if not sigma_only:
-        xyz, extra = torch.split(inputs, [m.in_channels_xyz, m.extra_feat_dim], dim=-1)
-    else:
-        xyz = inputs
-    h = xyz
-    for i in range(m.D):
-        if i in m.skips:
-            h = torch.cat([xyz, h], -1)
-        lin = getattr(m, f"xyz_encoding_{i+1}")[0]
-        h = F.relu(F.linear(h, lin.weight, lin.bias))
-    sigma = F.linear(h, m.sigma.weight, m.sigma.bias)
-    if sigma_only:
-        return sigma
-    feat = F.linear(h, m.xyz_encoding_final.weight, m.xyz_encoding_final.bias)
-    e = F.relu(F.linear(torch.cat([feat, extra], -1), m.extra_encoding[0].weight, m.extra_encoding[0].bias))
-    rgb = torch.sigmoid(F.linear(e, m.rgb[0].weight, m.rgb[0].bias))
-    return torch.cat([rgb, sigma], -1)
-
-
-def _quat_rotate(T, xyz):
-    """kornia 0.6.5 quaternion_log_to_exp + quaternion_to_rotation_matrix (restated),
-    then nof.py:80."""
-    v, s, t = T[:, :3], T[:, 3:6], T[:, 6:9]
-    n = torch.norm(v, p=2, dim=-1, keepdim=True).clamp(min=1e-8)
-    q = torch.cat([v * torch.sin(n) / n, torch.cos(n)], -1)
-    q = F.normalize(q, p=2.0, dim=-1, eps=1e-12)
-    x, y, z, w = torch.chunk(q, 4, dim=-1)
-    tx, ty, tz = 2.0 * x, 2.0 * y, 2.0 * z
-    twx, twy, twz = tx * w, ty * w, tz * w
-    txx, txy, txz = tx * x, ty * x, tz * x
-    tyy, tyz, tzz = ty * y, tz * y, tz * z
-    R = torch.stack((1.0 - (tyy + tzz), txy - twz, txz + twy, txy + twz, 1.0 - (txx + tzz), tyz - twx,
-                     txz - twy, tyz + twx, 1.0 - (txx + tyy)), dim=-1).view(-1, 3, 3)
-    return torch.bmm((xyz - s).unsqueeze(1), R).squeeze(1) + s + t
-
-
-def nof_forward(m, inputs, xyz):
-    """nof.py:69-82."""
-    u = inputs
-    for i in range(m.D):
-        if i in m.skips:
-            u = torch.cat([inputs, u], -1)
-        lin = getattr(m, f"nof_encoding_{i+1}")[0]
-        u = F.relu(F.linear(u, lin.weight, lin.bias))
-    head = F.linear(u, m.nof_encoding_final.weight, m.nof_encoding_final.bias)
-    return _quat_rotate(head, xyz) if m.use_quat else head + xyz
-
-
-def _nof_points(xyz, ind, nof_embs, m):
-    """rendering.py:49-83 for (N,S,3) points and (N,1) indices."""
-    N, S = xyz.shape[0], xyz.shape[1]
-    flat = xyz.reshape(-1, 3)
-    xe = _pad_to(embed(nof_embs[0], flat), m.in_channels_xyz)
-    ie = torch.repeat_interleave(embed(nof_embs[1], ind), repeats=S, dim=0)
-    return nof_forward(m, torch.cat([xe, ie], -1), flat).view(N, S, 3)
-
-
-def render_pass(rays, background, z_vals, noise, activation, nerf, nerf_embs, nof_models, nof_embs,
-                chain_local, chain_global, sigma_only, masks: Optional[Dict[str, torch.Tensor]]):
-    """One pass of render_rays (rendering.py:262-314 / 329-373) as differentiable torch ops on given
-    depths. Returns the same dict the fused kernel fills (rgb, depth, opacity, weights, alphas and the
-    mask-compacted consensus vectors when ``masks`` carries the kernel's mask)."""
-    N, S = z_vals.shape
-    o, d = rays[:, 0:3], rays[:, 3:6]
-    ind = rays[:, 8:9]
-    xyz = o.unsqueeze(1) + d.unsqueeze(1) * z_vals.unsqueeze(2)
-    out = {}
-    pts = xyz
-    if nof_models is not None:
-        bw = nof_models[0]
-        canon = _nof_points(xyz, ind, nof_embs, bw)
-        if chain_local:
-            fw = nof_models[1]
-            recon = _nof_points(canon, ind, nof_embs, fw)
-            out["disp_local_full"] = torch.abs(xyz - recon)
-        if chain_global:
-            cind = rays[:, 9:10]
-            a = _nof_points(canon, cind, nof_embs, fw)
-            b = _nof_points(a, cind, nof_embs, bw)
-            out["disp_global_full"] = torch.abs(xyz - _nof_points(b, ind, nof_embs, fw))
-        pts = canon
-    flat = pts.reshape(-1, 3)
-    inp = _pad_to(embed(nerf_embs[0], flat), nerf.in_channels_xyz)
-    if not sigma_only:
-        if nerf.extra_feat_type == "ind":
-            e = torch.repeat_interleave(embed(nerf_embs[1], ind), repeats=S, dim=0)
-            inp = torch.cat([inp, _pad_to(e, nerf.extra_feat_dim)], 1)
-        elif nerf.extra_feat_type == "dir":
-            e = torch.repeat_interleave(embed(nerf_embs[2], d), repeats=S, dim=0)
-            inp = torch.cat([inp, _pad_to(e, nerf.extra_feat_dim)], 1)
-    net = nerf_forward(nerf, inp, sigma_only=sigma_only)
-    if sigma_only:
-        sigmas, rgbs = net.view(N, S), None
-    else:
-        net = net.view(N, S, 4)
-        rgbs, sigmas = net[..., :3], net[..., 3]
-    deltas = z_vals[:, 1:] - z_vals[:, :-1]
-    deltas = torch.cat([deltas, 1e10 * torch.ones_like(deltas[:, :1])], -1) * torch.norm(d.unsqueeze(1), dim=-1)
-    sg = sigmas if noise is None else sigmas + noise
-    act = torch.relu(sg) if activation == "relu" else F.softplus(sg)
-    alphas = 1 - torch.exp(-deltas * act)
-    shifted = torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas + 1e-10], -1)
-    weights = alphas * torch.cumprod(shifted, -1)[:, :-1]
-    out["opacity"] = weights.sum(1)
-    out["weights"], out["alphas"] = weights, alphas
-    if not sigma_only:
-        rgb = torch.sum(weights.unsqueeze(-1) * rgbs, -2)
-        if background is not None:
-            rgb = rgb + background * (1 - out["opacity"].unsqueeze(-1))
-        out["rgb"] = rgb
-        out["depth"] = torch.sum(weights * z_vals, -1)
-    return out
-
-
 # ------------------------------------------------------------------ autograd glue
 def needs_grad(modules) -> bool:
     return torch.is_grad_enabled() and any(p.requires_grad for m in modules if m is not None for p in m.parameters())
 
 
-class RecomputeBackward(torch.autograd.Function):
-    """forward: hand back tensors already computed by the HIP kernels; backward: rebuild them with
-    ``recompute()`` (differentiable torch ops) and pull the incoming gradients through."""
-
-    @staticmethod
-    def forward(ctx, recompute, n_out, *tensors):
-        outs, params = tensors[:n_out], tensors[n_out:]
-        ctx.recompute = recompute
-        ctx.params = params
-        return tuple(o.detach() for o in outs)
-
-    @staticmethod
-    def backward(ctx, *grads):
-        params = ctx.params
-        with torch.enable_grad():
-            outs = ctx.recompute()
-        pairs = [(o, g) for o, g in zip(outs, grads) if g is not None and o.requires_grad]
-        need = [i for i, p in enumerate(params) if p.requires_grad]
-        result: List[Optional[torch.Tensor]] = [None] * len(params)
-        if pairs and need:
-            got = torch.autograd.grad([o for o, _ in pairs], [params[i] for i in need],
-                                      [g.to(o.dtype) for o, g in pairs], allow_unused=True)
-            for i, g in zip(need, got):
-                result[i] = g
-        return (None, None) + tuple([None] * len(grads)) + tuple(result)
-
-
-def attach(outputs: List[torch.Tensor], params: List[torch.Tensor], recompute) -> List[torch.Tensor]:
-    """Make the HIP-computed ``outputs`` differentiable w.r.t. ``params`` through ``recompute``."""
-    res = RecomputeBackward.apply(recompute, len(outputs), *outputs, *params)
-    return list(res)
-
-
 # ------------------------------------------------------------------ explicit NeRF backward on the kernel's dump
-def embed_backward(emb, x, g_emb):
-    """Gradient of embedding.py:42-46 w.r.t. x: out = [x, w_k sin(f_k x), w_k cos(f_k x), ...]."""
-    C = x.shape[1]
-    g = g_emb[:, :C].clone()
-    for k, (w, f) in enumerate(zip(emb.weights, emb.freq_bands)):
-        f = float(f)
-        w = float(w)
-        if w == 0.0:
-            continue
-        gs = g_emb[:, C + 2 * C * k: C + 2 * C * k + C]
-        gc = g_emb[:, C + 2 * C * k + C: C + 2 * C * k + 2 * C]
-        g += (w * f) * (torch.cos(f * x) * gs - torch.sin(f * x) * gc)
-    return g
-
-
-_NERF_BACKWARD = "hip"     # "hip": fused dX chain + mf_weight_grads; "gemm" (tools/ab_switches.py): library GEMMs only
-
-
 def nerf_backward_hip(m, g_out, acts, rgbsig, want_emb=False):
     """mf_nerf_backward_x: (gpre (P,stride) in the dump's layout, ghead (P,4), g_emb (P,64) | None) from
     dL/d[rgb, sigma]; g_emb = the gradient of the embedded input, produced by the same launch."""
@@ -318,9 +134,6 @@ def weight_grads(jobs, P, dev):
 
 
 # ------------------------------------------------------------------ NoF evaluation on points, HIP forward + backward
-_NOF_BACKWARD = "hip"      # "hip": mf_nof_points_dump / mf_nof_backward / mf_weight_grads; "torch" (tools/ab_switches.py)
-
-
 def nof_hip_supported(m, nof_embs) -> bool:
     """nof_embs = None: module-level call on pre-embedded inputs (no embedding constraints)."""
     skips = [s for s in m.skips if 0 < s < m.D]
@@ -589,11 +402,17 @@ def nof_points_dumped(xyz, nof_embs, m, acts, emb, out, sink=None, sink_plane=0,
 
 
 def nof_points(xyz, ray_ind, nof_embs, m):
-    """_nof_points with the HIP forward/backward node when the configuration is built (else torch ops)."""
+    """One NoF evaluation of a chain on (N,S,3) points with per-ray indices as a HIP forward / backward node."""
     N, S = xyz.shape[0], xyz.shape[1]
-    if _NOF_BACKWARD == "hip" and nof_hip_supported(m, nof_embs) and N * S > 0:
-        return NofPoints.apply(m, nof_embs, ray_ind, S, xyz.reshape(-1, 3), *m.parameters()).view(N, S, 3)
-    return _nof_points(xyz, ray_ind, nof_embs, m)
+    require_nof_hip(m, nof_embs)
+    return NofPoints.apply(m, nof_embs, ray_ind, S, xyz.reshape(-1, 3), *m.parameters()).view(N, S, 3)
+
+
+def require_nof_hip(m, nof_embs):
+    if not nof_hip_supported(m, nof_embs):
+        raise NotImplementedError(f"render_rays with gradients: the NoF backward is built for W = 128, in_channels_xyz = 33, "
+                                  f"extra_feat_dim = 33, at most one skip layer, xyz embedding <= 5 and index embedding = 16 "
+                                  f"frequencies (got W={m.W}, D={m.D}, skips={m.skips}); there is no eager fallback")
 
 
 def nerf_fused_eligible(m, P):
@@ -720,18 +539,11 @@ class NerfModule(torch.autograd.Function):
                 g_out = g.contiguous().float()
             emb = x[:, :cin]
             extra = x[:, cin:cin + ext_dim] if (ext_dim > 0 and not sigma_only) else None
-            n_skip = len([s_ for s_ in m.skips if 0 < s_ < D])
-            emb_hip = ctx.in_grad and n_skip <= 1
-            grads, gpre, g_emb, _ = nerf_fused_grads(m, g_out, acts, rgbsig, emb, extra, emb_hip, sigma_path_only=sigma_only)
+            grads, gpre, g_emb, _ = nerf_fused_grads(m, g_out, acts, rgbsig, emb, extra, ctx.in_grad, sigma_path_only=sigma_only)
             g_in = None
             if ctx.in_grad:
                 g_in = torch.zeros((x.shape[0], ctx.in_width), device=x.device, dtype=torch.float32)
-                if emb_hip:
-                    g_in[:, :cin] = g_emb[:, :cin]
-                else:                                         # several skip layers: small library GEMMs
-                    for l in range(D):
-                        if l == 0 or l in m.skips:
-                            g_in[:, :cin] += gpre[:, l * W:(l + 1) * W] @ getattr(m, f"xyz_encoding_{l+1}")[0].weight[:, :cin]
+                g_in[:, :cin] = g_emb[:, :cin]
                 if extra is not None:                         # (B,128) x (128, extra_dim): the one library GEMM of this node
                     g_in[:, cin:] = gpre[:, (D + 1) * W:(D + 1) * W + W // 2] @ m.extra_encoding[0].weight[:, W:W + ext_dim]
         return (None, g_in, None) + tuple(grads[n] for n in names)
@@ -767,118 +579,20 @@ class NerfSamples(torch.autograd.Function):
         need_in = ctx.xin_grad
 
         with torch.no_grad():
-            h = lambda l: acts[:, l * W:(l + 1) * W]
-            f = acts[:, D * W:(D + 1) * W]
-            e2 = acts[:, (D + 1) * W:(D + 1) * W + W // 2]
-            fused = _NERF_BACKWARD == "hip" and nerf_fused_eligible(m, acts.shape[0])
-            if fused:
-                n_skip = len([s_ for s_ in m.skips if 0 < s_ < D])
-                emb_hip = need_in and n_skip <= 1 and cin == ctx.emb_xyz.out_channels and cin <= 64
-                grads, gpre, g_emb_hip, emb64 = nerf_fused_grads(m, g_out, acts, rgbsig, emb, extra, emb_hip)
-                gslot = lambda l: gpre[:, l * W:(l + 1) * W]
-                g_emb = None
-                if emb_hip:      # produced by the chain launch itself; the sin / cos chain rule is one more small launch
-                    g_xin = embed_backward_hip(ctx.emb_xyz, emb64, g_emb_hip)
-                    return (None, None, None, None, None, None, g_xin) + tuple(grads[n] for n in names)
-                if need_in:      # (several skip layers / a narrower embedding: library GEMMs)
-                    for l in range(D):
-                        if l == 0 or l in m.skips:
-                            lin = getattr(m, f"xyz_encoding_{l+1}")[0]
-                            t = gslot(l) @ lin.weight[:, :cin]
-                            g_emb = t if g_emb is None else g_emb + t
-            else:
-                def lin_grads(prefix, g_pre, x_in):
-                    if req[prefix + ".weight"]:
-                        grads[prefix + ".weight"] = g_pre.t() @ x_in
-                    if req[prefix + ".bias"]:
-                        grads[prefix + ".bias"] = g_pre.sum(0)
-
-                rgb = rgbsig[:, :3]
-                g_pre_rgb = g_out[:, :3] * rgb * (1 - rgb)
-                g_sigma = g_out[:, 3:4].contiguous()
-                lin_grads("rgb.0", g_pre_rgb, e2)
-                g_e2 = (g_pre_rgb @ m.rgb[0].weight) * (e2 > 0)
-                in_extra = f if extra is None else torch.cat([f, extra], -1)
-                lin_grads("extra_encoding.0", g_e2, in_extra)
-                g_f = g_e2 @ m.extra_encoding[0].weight[:, :W]
-                lin_grads("xyz_encoding_final", g_f, h(D - 1))
-                lin_grads("sigma", g_sigma, h(D - 1))
-                g_h = g_f @ m.xyz_encoding_final.weight + g_sigma @ m.sigma.weight
-                g_emb = torch.zeros_like(emb) if need_in else None
-                for l in range(D - 1, -1, -1):
-                    g_pre = g_h * (h(l) > 0)
-                    lin = getattr(m, f"xyz_encoding_{l+1}")[0]
-                    if l == 0:
-                        x_in = emb
-                    elif l in m.skips:
-                        x_in = torch.cat([emb, h(l - 1)], -1)
-                    else:
-                        x_in = h(l - 1)
-                    lin_grads(f"xyz_encoding_{l+1}.0", g_pre, x_in)
-                    if l == 0:
-                        if need_in:
-                            g_emb += g_pre @ lin.weight
-                    elif l in m.skips:
-                        if need_in:
-                            g_emb += g_pre @ lin.weight[:, :cin]
-                        g_h = g_pre @ lin.weight[:, cin:]
-                    else:
-                        g_h = g_pre @ lin.weight
-            g_xin = embed_backward(ctx.emb_xyz, xin, g_emb[:, :ctx.emb_xyz.out_channels]) if need_in else None
+            grads, gpre, g_emb_hip, emb64 = nerf_fused_grads(m, g_out, acts, rgbsig, emb, extra, need_in)
+            # the embedded input's gradient comes out of the chain launch itself; the sin / cos chain rule is one more
+            # small launch (an embedding narrower than in_channels_xyz -- fewer frequencies -- reads its own columns only)
+            g_xin = embed_backward_hip(ctx.emb_xyz, emb64, g_emb_hip) if need_in else None
         return (None, None, None, None, None, None, g_xin) + tuple(grads[n] for n in names)
 
 
-class LossPartials(torch.autograd.Function):
-    """The 12 (sum, count) loss partials of a training step as ONE node (the losses "fused
-    into the epilogue"; models/losses.py:4-14, trainer/trainer_moco_flow.py:317-328).  Forward: mf_loss_partials on the
-    arrays the fused passes already wrote (rgb, alphas, the per-sample consensus distances) -- the values of the
-    gradient-free fast path, bit for bit.  Backward: mf_loss_partials_backward, one launch that writes the seeds
-    2 g (rgb - gt) and  -g mask sign(x - recon) / 3  straight into the buffers CompositeSamples / NofPointsDumped
-    consume.  No torch arithmetic, no mask tensor, no host sync.
-    ``passes``: per pass a dict(planes = the kernel's output dict, z = depths (N,S)); differentiable inputs per pass:
-    rgb (N,3), recon_local (N,S,3) | None, recon_global (N,S,3) | None."""
-
-    @staticmethod
-    def forward(ctx, partials_fn, rays, target, passes, *tensors):
-        ctx.rays, ctx.target, ctx.passes = rays, target, passes
-        ctx.shapes = [None if t is None else t.shape for t in tensors]
-        out12 = partials_fn()
-        ctx.save_for_backward(out12, *[t.detach() if t is not None else rays.new_empty(0) for t in tensors])
-        return out12
-
-    @staticmethod
-    def backward(ctx, g12):
-        out12, *tensors = ctx.saved_tensors
-        rays, target, passes = ctx.rays, ctx.target, ctx.passes
-        dev, N = rays.device, rays.shape[0]
-        g12 = g12.detach().contiguous().double()
-        descs, grads = [], []
-        for q, ps in enumerate(passes):
-            rgb, rl, rg = (tensors[3 * q + k] if ctx.shapes[3 * q + k] is not None else None for k in range(3))
-            d = L.mf_loss_grad_pass()
-            pl, z = ps["planes"], ps["z"]
-            need = [ctx.needs_input_grad[4 + 3 * q + k] and ctx.shapes[3 * q + k] is not None for k in range(3)]
-            g_rgb = torch.empty_like(rgb) if need[0] else None
-            g_rl = torch.empty_like(rl) if need[1] else None
-            g_rg = torch.empty_like(rg) if need[2] else None
-            d.rgb, d.g_rgb = L.ptr(rgb.contiguous() if rgb is not None else None), L.ptr(g_rgb)
-            if g_rl is not None or g_rg is not None:
-                d.alphas, d.n_samples = L.ptr(pl["alphas"]), z.shape[1]
-                d.rays, d.ray_stride, d.z_vals = L.ptr(rays), rays.stride(0), L.ptr(z)
-                d.recon_local, d.g_recon_local = L.ptr(rl.contiguous() if g_rl is not None else None), L.ptr(g_rl)
-                d.recon_global, d.g_recon_global = L.ptr(rg.contiguous() if g_rg is not None else None), L.ptr(g_rg)
-            descs.append(d)
-            grads += [g_rgb, g_rl, g_rg]
-        while len(grads) < len(ctx.shapes):
-            grads.append(None)
-        with torch.cuda.device(dev):
-            L.check(L.lib().mf_loss_partials_backward(C.byref(descs[0]), C.byref(descs[1]) if len(descs) > 1 else None,
-                                                      L.ptr(target), N, out12.data_ptr(), g12.data_ptr(),
-                                                      L.current_stream(dev)), "mf_loss_partials_backward")
-        return (None, None, None, None) + tuple(grads)
-
-
-_COMPOSITE_BACKWARD = "hip"   # "hip": mf_composite_backward; "torch" (tools/ab_switches.py): composite_from_samples under autograd
+def require_nerf_hip(m, P, under_nof):
+    """The shapes the explicit NeRF backward is built for; anything else raises (there is no eager fallback)."""
+    n_skip = len([s_ for s_ in m.skips if 0 < s_ < m.D])
+    if not nerf_fused_eligible(m, P) or (under_nof and n_skip > 1):
+        raise NotImplementedError(f"render_rays with gradients: the HIP backward is built for NeRFs with W = 256, in_channels_xyz <= "
+                                  f"64, extra_feat_dim <= 32 (and at most one skip layer under NoF); got W={m.W}, D={m.D}, "
+                                  f"skips={m.skips}, in_channels_xyz={m.in_channels_xyz}, extra_feat_dim={m.extra_feat_dim}")
 
 
 class CompositeSamples(torch.autograd.Function):
@@ -912,25 +626,3 @@ class CompositeSamples(torch.autograd.Function):
                                                   ptr(g_depth), ptr(g_opacity), g.data_ptr(), L.current_stream(dev)),
                     "mf_composite_backward")
         return g, None, None, None, None, None, None, None, None
-
-
-def composite_from_samples(rgbsig, z_vals, rays_d, noise, activation, background, sigma_only):
-    """rendering.py:157-192 on per-sample (rgb, sigma) planes -- differentiable, (N,S) elementwise only."""
-    N, S = z_vals.shape
-    rs = rgbsig.view(N, S, 4)
-    rgbs, sigmas = rs[..., :3], rs[..., 3]
-    deltas = z_vals[:, 1:] - z_vals[:, :-1]
-    deltas = torch.cat([deltas, 1e10 * torch.ones_like(deltas[:, :1])], -1) * torch.norm(rays_d.unsqueeze(1), dim=-1)
-    sg = sigmas if noise is None else sigmas + noise
-    act = torch.relu(sg) if activation == "relu" else F.softplus(sg)
-    alphas = 1 - torch.exp(-deltas * act)
-    shifted = torch.cat([torch.ones_like(alphas[:, :1]), 1 - alphas + 1e-10], -1)
-    weights = alphas * torch.cumprod(shifted, -1)[:, :-1]
-    out = {"opacity": weights.sum(1), "alphas": alphas, "weights": weights}
-    if not sigma_only:
-        rgb = torch.sum(weights.unsqueeze(-1) * rgbs, -2)
-        if background is not None:
-            rgb = rgb + background * (1 - out["opacity"].unsqueeze(-1))
-        out["rgb"] = rgb
-        out["depth"] = torch.sum(weights * z_vals, -1)
-    return out

@@ -104,7 +104,11 @@ class NeRF(nn.Module):
                                f"got {tuple(inputs.shape)}")
         from . import autograd as A
         want_grad = A.needs_grad([self]) or (torch.is_grad_enabled() and inputs.requires_grad)
-        if want_grad and A._NERF_BACKWARD == "hip" and A.nerf_fused_eligible(self, inputs.shape[0]):
+        if want_grad and inputs.shape[0] > 0:
+            if not A.nerf_fused_eligible(self, inputs.shape[0]):
+                raise NotImplementedError(f"NeRF.forward with gradients: the HIP backward is built for W = 256, one xyz block of <= 64 "
+                                          f"columns and an extra block of <= 32 (got W={self.W}, in_channels_xyz={self.in_channels_xyz}, "
+                                          f"extra_feat_dim={self.extra_feat_dim}, skips={self.skips}); there is no eager fallback")
             return A.NerfModule.apply(self, inputs, bool(sigma_only), *self.parameters())
         desc, buf = self.packed()
         x = inputs.detach().float()
@@ -116,7 +120,4 @@ class NeRF(nn.Module):
             L.check(L.lib().mf_nerf_forward(desc, buf.data_ptr(), L.ptr(x), x.stride(0) if B else width, B,
                                             1 if sigma_only else 0, L.ptr(out), L.current_stream(x.device)),
                     "mf_nerf_forward")
-        if want_grad:       # shapes the fused backward is not built for (W != 256, many skips): differentiable recompute
-            params = [p for p in self.parameters()] + ([inputs] if inputs.requires_grad else [])
-            out, = A.attach([out], params, lambda: [A.nerf_forward(self, inputs, sigma_only)])
         return out

@@ -92,9 +92,16 @@ class NoF(nn.Module):
         from . import autograd as A
         wrt = [t for t in (inputs, xyz) if torch.is_grad_enabled() and t.requires_grad]
         B = inputs.shape[0]
-        if (A.needs_grad([self]) and not wrt and B > 0 and A._NOF_BACKWARD == "hip"
-                and A.nof_hip_supported(self, None)):
-            # training call on data points (stage 2, SMPL-point losses): HIP forward-with-dump + HIP backward
+        if (A.needs_grad([self]) or wrt) and B > 0:
+            # training call on data points (stage 2, SMPL-point losses: trainer_nof.py:85-112, trainer_moco_flow.py:159-187,
+            # 337-362 -- the points are data, only the parameters learn): HIP forward-with-dump + HIP backward
+            if wrt:
+                raise NotImplementedError("NoF.forward: gradients w.r.t. `inputs` / `xyz` of a module-level call are not built (the "
+                                          "reference's trainers call it on data points; render_rays differentiates its chains "
+                                          "through the points itself); there is no eager fallback")
+            if not A.nof_hip_supported(self, None):
+                raise NotImplementedError(f"NoF.forward with gradients: the HIP backward is built for W = 128, in_channels_xyz = 33, "
+                                          f"extra_feat_dim = 33, at most one skip layer (got W={self.W}, D={self.D}, skips={self.skips})")
             return A.NofModule.apply(self, inputs, xyz, *self.parameters())
         desc, buf = self.packed()
         x = inputs.detach().float()
@@ -105,6 +112,4 @@ class NoF(nn.Module):
         with torch.cuda.device(x.device):
             L.check(L.lib().mf_nof_forward(desc, buf.data_ptr(), L.ptr(x), x.stride(0) if B else width, L.ptr(p), B,
                                            L.ptr(out), L.current_stream(x.device)), "mf_nof_forward")
-        if A.needs_grad([self]) or wrt:
-            out, = A.attach([out], [p for p in self.parameters()] + wrt, lambda: [A.nof_forward(self, inputs, xyz)])
         return out

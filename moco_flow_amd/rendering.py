@@ -34,17 +34,13 @@ def set_precision(p: str):
     PRECISION = p
 
 
-# Training (gradients requested): forward values ALWAYS come from the fused HIP kernels.  The backward is
-#   * hand-written HIP for every fp32 render_rays pass that evaluates the full NeRF: mf_composite_backward,
-#     mf_nerf_backward_x (+ mf_embedding_backward under NoF), mf_weight_grads, mf_nof_points_dump / mf_nof_backward
-#     (autograd.py); torch evaluates only the loss;
-#     -- also when the module setting is "bf16": a pass that records gradients runs the fp32 kernels (the reference
-#     trains in fp32; bf16 is the throughput mode of gradient-free passes);
-#   * a differentiable recompute with PyTorch-ROCm device ops (autograd.RecomputeBackward) for what is not built in
-#     HIP: the sigma-only coarse pass of test_time under grad, network shapes outside the fused envelope.
-# _TRAIN_FORWARD is a timing-comparison hook for tools/ab_switches.py ("torch": the whole pass as eager device ops,
-# i.e. what the reference itself would run on this GPU); it is not part of the drop-in surface.
-_TRAIN_FORWARD = "hip"
+# Training (gradients requested): forward values come from the fused HIP kernels, which also dump what the backward needs;
+# the backward is hand-written HIP (autograd.py): mf_loss_partials_backward, mf_composite_backward, mf_nerf_backward_x
+# (+ mf_embedding_backward under NoF), mf_nof_backward, mf_weight_grads.  A pass that records gradients runs the fp32
+# kernels whatever the module setting (the reference trains in fp32; bf16 / bf16x3 are modes of gradient-free passes).
+# What the HIP backward is not built for raises NotImplementedError under grad -- network shapes outside the envelope
+# (autograd.require_nerf_hip / require_nof_hip) and test_time passes (their coarse pass evaluates sigma only; the
+# reference renders those under no_grad).  There is no eager fallback in the package.
 
 
 # Draw torch.randn(N,S) in every pass even when noise_std == 0, as the reference does
@@ -121,8 +117,7 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
         a.dump_stride = stride
         a.dump_rgbsigma = alloc("rgbsig", (N * S, 4))
         a.dump_xyz = alloc("xyz_in", (N * S, 3))
-        if nof_models is not None and all(A.nof_hip_supported(m, nof_embs) for m in nof_models) \
-                and len({(m.D, m.W) for m in nof_models}) == 1 and A._NOF_BACKWARD == "hip":
+        if nof_models is not None and len({(m.D, m.W) for m in nof_models}) == 1:
             # the chain's NoF evaluations dump too (one plane per step): no re-evaluation in the backward graph
             steps = 1 + (1 if chain_local else 0) + (3 if chain_global else 0)
             # planes grouped by network (bw: steps 0, 3; fw: steps 1, 2, 4): one weight-gradient contraction per network
@@ -338,11 +333,15 @@ def render_rays(rays,
     pass_prec = "f32" if grad else None       # a pass that records gradients runs the reference's fp32 arithmetic
     want_planes = need_fine or loc or glob or grad or _capture is not None
     noise_c = draw_noise((N, S), "noise_coarse")
-    if grad and N > 0 and _TRAIN_FORWARD == "torch":
-        return _torch_training_render(rays, background, nerf_embeddings, nerf_models, nof_embeddings,
-                                      nof_models if use_nof else None, loc, glob, nerf_activate_type,
-                                      coarse_sigma_only, z_vals, noise_c, N_importance, perturb == 0,
-                                      lambda: draw_noise((N, S + N_importance), "noise_fine"), _rng.get("u"))
+    if grad and N > 0:
+        if coarse_sigma_only:
+            raise NotImplementedError("render_rays(test_time=True, N_importance > 0) with gradients: the sigma-only coarse pass "
+                                      "has no HIP backward (the reference renders test_time passes under torch.no_grad())")
+        for m in nerf_models[:2 if need_fine else 1]:
+            A.require_nerf_hip(m, N * S, use_nof)
+        if use_nof:
+            for m in nof_models:
+                A.require_nof_hip(m, nof_embeddings)
     ws = [None]                     # bf16 + NoF: the per-ray bias table, filled by the first pass, shared with the second
     c = _render_pass(rays, background, z_vals, None if z_vals is not None else z_steps, use_disp,
                      noise_c, act, nerf_models[0], nerf_embeddings,
@@ -352,11 +351,7 @@ def render_rays(rays,
         result = {'opacity_coarse': c["opacity"]}
     else:
         result = {'rgb_coarse': c["rgb"], 'depth_coarse': c["depth"], 'opacity_coarse': c["opacity"]}
-    # the 12 loss partials replace the compacted consensus vectors -- unless gradients are wanted on a pass the explicit
-    # HIP backward does not cover (the sigma-only coarse pass of test_time): there the partials are assembled from the
-    # attached result below, consensus vectors included
-    explicit = grad and N > 0 and not coarse_sigma_only
-    fused_loss = _loss_target is not None and (explicit or not (grad and N > 0))
+    fused_loss = _loss_target is not None     # the 12 loss partials replace the compacted consensus vectors
     if (loc or glob) and not fused_loss:
         la, ga = _compact(c["alphas"], c.get("disp_local"), c.get("disp_global"))
         if loc:
@@ -386,50 +381,12 @@ def render_rays(rays,
                 result['nof_global_disp_fine'] = ga
     if fused_loss and not (grad and N > 0):
         result['loss_partials'] = _loss_partials_hip(c, f if need_fine else None, _loss_target, N)
-    if grad and N > 0 and "acts" in c and (not need_fine or "acts" in f):
+    if grad and N > 0:
         result = _attach_explicit(result, rays, background, nerf_embeddings, nerf_models, nof_embeddings,
                                   nof_models if use_nof else None, loc, glob, nerf_activate_type,
                                   (c, z_vals, noise_c), (f, z_all, noise_f) if need_fine else None,
                                   loss_target=_loss_target)
-    elif grad and N > 0:
-        result = _attach_backward(result, rays, background, all_models, nerf_embeddings, nerf_models,
-                                  nof_embeddings, nof_models if use_nof else None, loc, glob, nerf_activate_type,
-                                  coarse_sigma_only, z_vals, noise_c, c["alphas"],
-                                  (z_all, noise_f, f["alphas"]) if need_fine else None)
-        if _loss_target is not None:
-            from . import dist as _dist
-            result['loss_partials'] = _dist.loss_partials(result, _loss_target.detach().float())
     return result
-
-
-def _torch_training_render(rays, background, nerf_embs, nerf_models, nof_embs, nof_models, loc, glob, activation,
-                           coarse_sigma_only, z_c, noise_c, n_importance, det, draw_noise_f, u):
-    """_TRAIN_FORWARD == "torch": both passes with differentiable device ops (autograd.render_pass);
-    only the (detached) hierarchical resample runs in the HIP kernel."""
-    result = {}
-
-    def one(tag, nerf, z, noise, sigma_only):
-        r = A.render_pass(rays, background, z, noise, activation, nerf, nerf_embs, nof_models, nof_embs,
-                          loc, glob, sigma_only, None)
-        if not sigma_only:
-            result[f"rgb_{tag}"], result[f"depth_{tag}"] = r["rgb"], r["depth"]
-        result[f"opacity_{tag}"] = r["opacity"]
-        if loc or glob:
-            mask = _mask_of(r["alphas"].detach())
-            if loc:
-                result[f"nof_local_disp_{tag}"] = torch.mean(r["disp_local_full"][mask], dim=1)
-            if glob:
-                result[f"nof_global_disp_{tag}"] = torch.mean(r["disp_global_full"][mask], dim=1)
-        return r
-
-    c = one("coarse", nerf_models[0], z_c, noise_c, coarse_sigma_only)
-    if n_importance > 0:
-        z_all = resample_merge(z_c, c["weights"].detach(), n_importance, det=det, u=u)
-        one("fine", nerf_models[1], z_all, draw_noise_f(), False)
-    # key order of the reference: coarse rgb/depth/opacity, coarse consensus, fine ..., fine consensus
-    order = ["rgb_coarse", "depth_coarse", "opacity_coarse", "nof_local_disp_coarse", "nof_global_disp_coarse",
-             "rgb_fine", "depth_fine", "opacity_fine", "nof_local_disp_fine", "nof_global_disp_fine"]
-    return {k: result[k] for k in order if k in result}
 
 
 def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs, nof_models, loc, glob,
@@ -507,14 +464,12 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
                 extra_in = A._pad_to(torch.repeat_interleave(nerf_embs[2](rays_d.contiguous()), S, dim=0), nerf.extra_feat_dim)
         rgbsig = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, nerf_embs[0], xin,
                                      *nerf.parameters())
-        if A._COMPOSITE_BACKWARD == "hip" and activation in ("relu", "softplus") and S <= 2048:
-            out[f"rgb_{tag}"], out[f"depth_{tag}"], out[f"opacity_{tag}"] = A.CompositeSamples.apply(
-                rgbsig, rays, z, noise, activation, background, result[f"rgb_{tag}"], result[f"depth_{tag}"],
-                result[f"opacity_{tag}"])
-            kernel_vals.update((f"rgb_{tag}", f"depth_{tag}", f"opacity_{tag}"))
-        else:
-            comp = A.composite_from_samples(rgbsig, z, rays_d, noise, activation, background, False)
-            out[f"rgb_{tag}"], out[f"depth_{tag}"], out[f"opacity_{tag}"] = comp["rgb"], comp["depth"], comp["opacity"]
+        if S > 2048:
+            raise NotImplementedError(f"render_rays with gradients: mf_composite_backward is built for <= 2048 samples per ray, got {S}")
+        out[f"rgb_{tag}"], out[f"depth_{tag}"], out[f"opacity_{tag}"] = A.CompositeSamples.apply(
+            rgbsig, rays, z, noise, activation, background, result[f"rgb_{tag}"], result[f"depth_{tag}"],
+            result[f"opacity_{tag}"])
+        kernel_vals.update((f"rgb_{tag}", f"depth_{tag}", f"opacity_{tag}"))
 
     one("coarse", nerf_models[0], coarse)
     if fine is not None:
@@ -549,35 +504,3 @@ def _mask_of(alphas):
     if not torch.any(mask):
         mask = torch.ones_like(mask).bool()
     return mask
-
-
-def _attach_backward(result, rays, background, all_models, nerf_embs, nerf_models, nof_embs, nof_models,
-                     loc, glob, activation, coarse_sigma_only, z_c, noise_c, alphas_c, fine):
-    """Make the HIP-computed result differentiable: the backward re-runs both passes with torch ops
-    (autograd.render_pass) on the same depths, noise and consensus masks."""
-    keys = list(result.keys())
-    mask_c = _mask_of(alphas_c) if (loc or glob) else None
-    mask_f = _mask_of(fine[2]) if (fine is not None and (loc or glob)) else None
-
-    def recompute():
-        outs = {}
-
-        def one(tag, nerf, z, noise, sigma_only, mask):
-            r = A.render_pass(rays, background, z, noise, activation, nerf, nerf_embs, nof_models, nof_embs,
-                              loc, glob, sigma_only, None)
-            if not sigma_only:
-                outs[f"rgb_{tag}"], outs[f"depth_{tag}"] = r["rgb"], r["depth"]
-            outs[f"opacity_{tag}"] = r["opacity"]
-            if loc:
-                outs[f"nof_local_disp_{tag}"] = torch.mean(r["disp_local_full"][mask], dim=1)
-            if glob:
-                outs[f"nof_global_disp_{tag}"] = torch.mean(r["disp_global_full"][mask], dim=1)
-
-        one("coarse", nerf_models[0], z_c, noise_c, coarse_sigma_only, mask_c)
-        if fine is not None:
-            one("fine", nerf_models[1], fine[0], fine[1], False, mask_f)
-        return [outs[k] for k in keys]
-
-    params = [p for m in all_models for p in m.parameters()]
-    attached = A.attach([result[k] for k in keys], params, recompute)
-    return {k: v for k, v in zip(keys, attached)}

@@ -75,3 +75,64 @@ def case_inputs(c, seed, n=None, device="cpu"):
     rays = torch.from_numpy(rays).to(device)
     bg = torch.from_numpy(bg).to(device) if c.get("bg", True) else None
     return rays, bg
+
+
+class OracleOps:
+    """CPU stand-ins, backed by oracle.cpu_ref, for the building blocks the backward unit tests differentiate: the same
+    weights as a product module in an oracle container whose tensors are autograd leaves (``twin``), and the oracle's
+    embedding / network / chain / composite functions on CPU copies of the inputs.  (Round 2 compared the HIP nodes with
+    an eager restatement that lived inside the package; the checker is the oracle.)"""
+
+    def __init__(self, R):
+        self.R = R
+        self.twins = {}
+
+    def twin(self, m):
+        if id(m) not in self.twins:
+            sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+            if hasattr(m, "use_quat"):
+                t = self.R.NoF(m.D, m.W, m.in_channels_xyz, list(m.skips), m.extra_feat_type, m.extra_feat_dim, m.use_quat, state=sd)
+            else:
+                t = self.R.NeRF(m.D, m.W, m.in_channels_xyz, list(m.skips), m.extra_feat_type, m.extra_feat_dim, state=sd)
+            for k in t.p:
+                t.p[k] = t.p[k].clone().requires_grad_(True)
+            self.twins[id(m)] = t
+        return self.twins[id(m)]
+
+    def grads(self, m):
+        return {k: v.grad for k, v in self.twin(m).p.items()}
+
+    def emb(self, e):
+        o = self.R.Embedding(e.in_channels, e.N_freqs)
+        o.freq_bands = torch.as_tensor(e.freq_bands).detach().clone().cpu().float()
+        o.weights = [float(w) for w in e.weights]
+        return o
+
+    @staticmethod
+    def _c(t):
+        return t if (t is None or not torch.is_tensor(t) or not t.is_cuda) else t.detach().cpu()
+
+    def embed(self, e, x):
+        return self.emb(e)(x if not x.is_cuda else self._c(x))
+
+    def pad_to(self, t, width):
+        out = torch.zeros((t.shape[0], width))
+        out[:, :t.shape[1]] = t
+        return out
+
+    def nerf_forward(self, m, inputs, sigma_only=False):
+        return self.twin(m)(inputs, sigma_only=sigma_only)
+
+    def nof_forward(self, m, inputs, xyz):
+        return self.twin(m)(inputs, xyz)
+
+    def nof_points(self, xyz, ind, embs, m):
+        return self.R.nof_inference(xyz, self._c(ind), [self.emb(embs[0]), self.emb(embs[1])], self.twin(m))
+
+    def composite(self, rgbsig, z_vals, rays_d, noise, activation, background):
+        N, S = z_vals.shape
+        rs = rgbsig.view(N, S, 4)
+        nz = torch.zeros(N, S) if noise is None else self._c(noise)
+        rgb, depth, weights, alphas = self.R.composite(rs[..., 3], rs[..., :3], self._c(z_vals), self._c(rays_d), nz, activation,
+                                                       self._c(background))
+        return dict(rgb=rgb, depth=depth, opacity=weights.sum(1), weights=weights, alphas=alphas)

@@ -7,14 +7,9 @@ import pytest
 import torch
 
 from cases import RENDER_CASES
-from helpers import build_case, case_inputs, load_golden, relerr
+from helpers import OracleOps, build_case, case_inputs, load_golden, relerr
 
 pytestmark = pytest.mark.gpu
-
-import os as _os
-import sys as _sys
-_sys.path.insert(0, _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "tools"))
-import ab_switches as AB   # noqa: E402  (tools/ab_switches.py: timing-comparison switches, not package surface)
 
 TOL = 1e-4
 
@@ -410,28 +405,30 @@ def test_gradients_vs_oracle(M, R, name):
     assert checked >= 10
 
 
-def test_module_gradients(M):
-    """NeRF / NoF / Embedding called directly with grad (trainer_nof.py:111, trainer_moco_flow.py:153,185)."""
-    from moco_flow_amd import autograd as A, synth
+def test_module_gradients(M, R):
+    """NoF / Embedding called directly with grad (trainer_nof.py:111, trainer_moco_flow.py:153,185) against the oracle's
+    CPU autograd; gradients w.r.t. the points of a module-level NoF call are not built and say so."""
+    O = OracleOps(R)
     torch.manual_seed(0)
     nof = M.NoF(4, 128, 33, [2], "ind", 33, True).cuda()
     inp = torch.randn(40, 66, device="cuda")
-    xyz = torch.randn(40, 3, device="cuda", requires_grad=True)
+    xyz = torch.randn(40, 3, device="cuda")
     out = nof(inp, xyz)
     out.square().sum().backward()
-    g_hip = [p.grad.clone() for p in nof.parameters()] + [xyz.grad.clone()]
-    for p in nof.parameters():
-        p.grad = None
-    xyz.grad = None
-    A.nof_forward(nof, inp, xyz).square().sum().backward()        # plain torch ops on the same device
-    g_ref = [p.grad for p in nof.parameters()] + [xyz.grad]
-    for a, b in zip(g_hip, g_ref):
-        assert relerr(a, b) <= 1e-4
+    ref = O.nof_forward(nof, inp.cpu(), xyz.cpu())
+    assert relerr(out, ref) <= 1e-5
+    ref.square().sum().backward()
+    want = O.grads(nof)
+    for n, q in nof.named_parameters():
+        assert relerr(q.grad, want[n]) <= 1e-4, n
+    with pytest.raises(NotImplementedError):
+        nof(inp, xyz.clone().requires_grad_(True))
     x = torch.randn(16, 3, device="cuda", requires_grad=True)
     e = M.Embedding(3, 4)
     e(x).sum().backward()
-    want = torch.autograd.grad(A.embed(e, x).sum(), x)[0]
-    assert relerr(x.grad, want) <= 1e-5
+    xc = x.detach().cpu().requires_grad_(True)
+    want_x = torch.autograd.grad(O.embed(e, xc).sum(), xc)[0]
+    assert relerr(x.grad, want_x) <= 1e-5
 
 
 def _psnr(a, b):
@@ -947,39 +944,6 @@ def test_training_loop_converges(M):
     assert float(crit(res, target)) < losses[0]
 
 
-def test_train_forward_torch_mode_matches_hip_mode(M):
-    """The eager-torch comparison path of the timing tools (tools/ab_switches.py) returns the same values and
-    gradients as the shipped path (HIP forward + HIP backward nodes), with the same keys in the same order."""
-    from moco_flow_amd import rendering
-    c = dict(RENDER_CASES["r_moco_global_fine"])
-    seed = int(load_golden("r_moco_global_fine")["meta_seed"])
-    embs, nerfs, kw = build_case(M, c, seed, device="cuda")
-    rays, bg = case_inputs(c, seed, n=40)
-    rays, bg = rays.cuda(), bg.cuda()
-    nets = list(nerfs) + list(kw["nof_models"])
-
-    def run():
-        for m in nets:
-            m.zero_grad(set_to_none=True)
-        res = M.render_rays(rays, bg, embs, nerfs, **kw)
-        loss = sum(v.mean() for v in res.values())
-        loss.backward()
-        return res, [p.grad.clone() for m in nets for p in m.parameters()]
-
-    a, ga = run()
-    try:
-        AB.set_train_forward("torch")
-        b, gb = run()
-    finally:
-        AB.set_train_forward("hip")
-    assert list(a.keys()) == list(b.keys())
-    for k in a:
-        if a[k].shape == b[k].shape:
-            assert relerr(a[k], b[k]) <= (2e-3 if "fine" in k else TOL), k     # fine: resample conditioning
-    for x, y in zip(ga, gb):
-        assert relerr(x, y) <= 5e-2           # kink flips at points 1e-6 apart, see test_gradients_vs_oracle
-
-
 def _oracle_param_grads(model, out, gout, extra_inputs=()):
     """d <out, gout> / d (every parameter of the oracle model, extra inputs) by CPU autograd."""
     names = list(model.p)
@@ -1016,8 +980,8 @@ def test_nerf_backward_vs_oracle_on_dumped_points(M, R):
     xin = p["xyz_in"].clone().requires_grad_(True)
     ind = rays_g[:, 8:9]
     with torch.no_grad():
-        emb_in = A._pad_to(A.embed(embs[0], p["xyz_in"]), 63)
-        extra_in = A._pad_to(torch.repeat_interleave(A.embed(embs[1], ind), S, dim=0), 5)
+        emb_in = A._pad_to(embs[0](p["xyz_in"]), 63)
+        extra_in = A._pad_to(torch.repeat_interleave(embs[1](ind.contiguous()), S, dim=0), 5)
     gout = torch.randn(n_rays * S, 4, device="cuda")
     out = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, embs[0], xin, *nerf.parameters())
     out.backward(gout)
@@ -1171,16 +1135,14 @@ def test_composite_backward_vs_oracle(M, R, act, use_noise, use_bg):
     assert e <= 1e-4
 
 
-@pytest.mark.parametrize("kind,n_rays", [("hip", 40), ("hip", 37), ("hip", 1), ("gemm", 40)])
-def test_explicit_nerf_backward_unit(M, kind, n_rays):
-    """autograd.NerfSamples (fused HIP dX chain mf_nerf_backward + library dW GEMMs over the kernel's
-    activation dump; "gemm": library GEMMs only) against plain torch autograd of the same network on the
-    SAME points: parameter and input-point gradients to 1e-4, frozen sub-module honoured, ragged
-    sample counts (not a multiple of the 128-sample tile)."""
-    from moco_flow_amd import autograd as A, rendering, synth
-    import ctypes as C
+@pytest.mark.parametrize("n_rays", [40, 37, 1])
+def test_explicit_nerf_backward_unit(M, R, n_rays):
+    """autograd.NerfSamples (fused HIP dX chain mf_nerf_backward_x + mf_weight_grads over the kernel's activation dump)
+    against the oracle's CPU autograd of the same network on the SAME points: parameter and input-point gradients to
+    1e-4, frozen sub-module honoured, ragged sample counts (not a multiple of the 128-sample tile)."""
+    from moco_flow_amd import autograd as A, rendering
+    O = OracleOps(R)
     torch.manual_seed(0)
-    AB.set_nerf_backward(kind)
     c = dict(RENDER_CASES["r_nerf_ind_dense"])
     embs, nerfs, kw = build_case(M, c, 21, device="cuda")
     nerf = nerfs[0]
@@ -1191,39 +1153,35 @@ def test_explicit_nerf_backward_unit(M, kind, n_rays):
     with torch.no_grad():
         p = rendering._render_pass(rays, bg, z, None, False, None, 0, nerf, embs, None, None, False, False, False,
                                    True, dump=True)
+        emb_in = A._pad_to(embs[0](p["xyz_in"]), 63)
+        extra_in = A._pad_to(torch.repeat_interleave(embs[1](rays[:, 8:9].contiguous()), S, dim=0), 5)
     xin = p["xyz_in"].clone().requires_grad_(True)
-    ind = rays[:, 8:9]
-    emb_in = A._pad_to(A.embed(embs[0], p["xyz_in"]), 63)
-    extra_in = A._pad_to(torch.repeat_interleave(A.embed(embs[1], ind), S, dim=0), 5)
     for q in nerf.rgb.parameters():
         q.requires_grad_(False)
     gout = torch.randn(n_rays * S, 4, device="cuda")
     out = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, embs[0], xin, *nerf.parameters())
-    try:
-        out.backward(gout)
-    finally:
-        AB.set_nerf_backward("hip")
-    got = {n: (q.grad.clone() if q.grad is not None else None) for n, q in nerf.named_parameters()}
-    got_x = xin.grad.clone()
-    nerf.zero_grad(set_to_none=True)
-    x2 = p["xyz_in"].clone().requires_grad_(True)
-    ref = A.nerf_forward(nerf, torch.cat([A._pad_to(A.embed(embs[0], x2), 63), extra_in], -1))
+    out.backward(gout)
+    x2 = p["xyz_in"].cpu().clone().requires_grad_(True)
+    e_ind = O.pad_to(torch.repeat_interleave(O.embed(embs[1], rays[:, 8:9].cpu()), S, dim=0), 5)
+    ref = O.nerf_forward(nerf, torch.cat([O.pad_to(O.embed(embs[0], x2), 63), e_ind], -1))
     assert relerr(out, ref) <= 1e-5                                  # the dump IS the forward
-    ref.backward(gout)
+    ref.backward(gout.cpu())
+    want = O.grads(nerf)
     for n, q in nerf.named_parameters():
         if n.startswith("rgb."):
-            assert got[n] is None and q.grad is None
+            assert q.grad is None
         else:
-            assert relerr(got[n], q.grad) <= 1e-4, (n, relerr(got[n], q.grad))
-    assert relerr(got_x, x2.grad) <= 1e-4
+            assert relerr(q.grad, want[n]) <= 1e-4, (n, relerr(q.grad, want[n]))
+    assert relerr(xin.grad, x2.grad) <= 1e-4
 
 
 @pytest.mark.parametrize("quat,n_rays,S", [(True, 40, 64), (False, 40, 64), (True, 3, 37), (True, 1, 1)])
-def test_nof_points_backward_unit(M, quat, n_rays, S):
-    """autograd.NofPoints (mf_nof_points_dump + mf_nof_backward + mf_weight_grads) against plain torch
-    autograd of the same evaluation (rendering.py:49-83 + nof.py:69-82 restated with torch ops) on the
-    same points: output to 1e-5, parameter and point gradients to 1e-4; ragged sample counts."""
+def test_nof_points_backward_unit(M, R, quat, n_rays, S):
+    """autograd.NofPoints (mf_nof_points_dump + mf_nof_backward + mf_weight_grads) against the oracle's CPU autograd of
+    the same evaluation (nof_inference: rendering.py:49-83 + nof.py:69-82) on the same points: output to 1e-5,
+    parameter and point gradients to 1e-4; ragged sample counts."""
     from moco_flow_amd import autograd as A, synth
+    O = OracleOps(R)
     torch.manual_seed(1)
     nof = M.NoF(4, 128, 33, [2], "ind", 33, quat)
     nof.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nof_state(5, use_quat=quat, tag="bw", head_scale=0.25).items()})
@@ -1238,16 +1196,14 @@ def test_nof_points_backward_unit(M, quat, n_rays, S):
     out = A.nof_points(pts, ind, embs, nof)
     assert "NofPoints" in type(out.grad_fn.next_functions[0][0]).__name__          # the HIP node, not the torch recompute
     out.backward(gout)
-    got = {n: q.grad.clone() for n, q in nof.named_parameters()}
-    got_x = pts.grad.clone()
-    nof.zero_grad(set_to_none=True)
-    p2 = pts.detach().clone().requires_grad_(True)
-    ref = A._nof_points(p2, ind, embs, nof)
+    p2 = pts.detach().cpu().clone().requires_grad_(True)
+    ref = O.nof_points(p2, ind, embs, nof)
     assert relerr(out, ref) <= 1e-5
-    ref.backward(gout)
+    ref.backward(gout.cpu())
+    want = O.grads(nof)
     for n, q in nof.named_parameters():
-        assert relerr(got[n], q.grad) <= 1e-4, (n, relerr(got[n], q.grad))
-    assert relerr(got_x, p2.grad) <= 1e-4, relerr(got_x, p2.grad)
+        assert relerr(q.grad, want[n]) <= 1e-4, (n, relerr(q.grad, want[n]))
+    assert relerr(pts.grad, p2.grad) <= 1e-4, relerr(pts.grad, p2.grad)
 
 
 def test_render_image_vs_golden(M):
@@ -1284,12 +1240,13 @@ def test_render_image_vs_golden(M):
 
 @pytest.mark.parametrize("act,use_noise,use_bg,N,S", [("relu", False, True, 33, 64), ("softplus", True, True, 9, 200),
                                                      ("relu", True, False, 5, 2), ("softplus", False, False, 3, 700)])
-def test_composite_backward_unit(M, act, use_noise, use_bg, N, S):
-    """autograd.CompositeSamples (mf_composite_backward) against torch autograd of the composite restated
-    with torch ops (rendering.py:157-192) on the same planes: dL/d[rgb, sigma] per sample to 1e-4,
+def test_composite_backward_unit(M, R, act, use_noise, use_bg, N, S):
+    """autograd.CompositeSamples (mf_composite_backward) against the oracle's CPU autograd of the composite
+    (cpu_ref.composite: rendering.py:157-192) on the same planes: dL/d[rgb, sigma] per sample to 1e-4,
     including the 1e10 last interval, multi-chunk rays (S > 64) and S = 2 (S = 1 is degenerate in the
     reference itself: `ones_like(deltas[:, :1])` of an empty tensor drops the only interval, rendering.py:158-160)."""
     from moco_flow_amd import autograd as A
+    O = OracleOps(R)
     torch.manual_seed(3)
     dev = "cuda"
     rays = torch.randn(N, 9, device=dev)
@@ -1300,22 +1257,24 @@ def test_composite_backward_unit(M, act, use_noise, use_bg, N, S):
     noise = torch.randn(N, S, device=dev) * 0.3 if use_noise else None
     bg = torch.rand(N, 3, device=dev) if use_bg else None
     g = [torch.randn(N, 3, device=dev), torch.randn(N, device=dev), torch.randn(N, device=dev)]
-    a = rgbsig.clone().requires_grad_(True)
-    comp = A.composite_from_samples(a, z, rays[:, 3:6], noise, act, bg, False)
-    torch.autograd.backward([comp["rgb"], comp["depth"], comp["opacity"]], g)
+    a = rgbsig.cpu().clone().requires_grad_(True)
+    comp = O.composite(a, z, rays[:, 3:6], noise, act, bg)
+    torch.autograd.backward([comp["rgb"], comp["depth"], comp["opacity"]], [t.cpu() for t in g])
     b = rgbsig.clone().requires_grad_(True)
-    outs = A.CompositeSamples.apply(b, rays, z, noise, act, bg, comp["rgb"].detach(), comp["depth"].detach(), comp["opacity"].detach())
+    outs = A.CompositeSamples.apply(b, rays, z, noise, act, bg, comp["rgb"].detach().cuda(), comp["depth"].detach().cuda(),
+                                    comp["opacity"].detach().cuda())
     torch.autograd.backward(list(outs), g)
     assert relerr(b.grad[:, :3], a.grad[:, :3]) <= 1e-5
     assert relerr(b.grad[:, 3], a.grad[:, 3]) <= 1e-4, relerr(b.grad[:, 3], a.grad[:, 3])
 
 
 @pytest.mark.parametrize("D,skips,extra,extra_dim", [(6, [2], "none", 0), (4, [], "dir", 27), (10, [3], "ind", 5), (8, [7], "dir", 27)])
-def test_nerf_backward_other_shapes(M, D, skips, extra, extra_dim):
-    """The fused backward (mf_nerf_backward + mf_weight_grads) on network shapes other than the configs'
-    8x256 / skip 4: depth, skip position (none / last layer) and extra input type; against torch autograd of
-    the same network on the same points, 1e-4."""
+def test_nerf_backward_other_shapes(M, R, D, skips, extra, extra_dim):
+    """The fused backward (mf_nerf_backward_x + mf_weight_grads) on network shapes other than the configs'
+    8x256 / skip 4: depth, skip position (none / last layer) and extra input type; against the oracle's CPU autograd
+    of the same network on the same points, 1e-4."""
     from moco_flow_amd import autograd as A, rendering
+    O = OracleOps(R)
     torch.manual_seed(11)
     nerf = M.NeRF(D, 256, 63, skips, extra, extra_dim).cuda()
     with torch.no_grad():
@@ -1329,32 +1288,35 @@ def test_nerf_backward_other_shapes(M, D, skips, extra, extra_dim):
     with torch.no_grad():
         p = rendering._render_pass(rays, bg, z, None, False, None, 0, nerf, embs, None, None, False, False, False, True, dump=True)
     xin = p["xyz_in"].clone().requires_grad_(True)
-    emb_in = A._pad_to(A.embed(embs[0], p["xyz_in"]), 63)
-    extra_in = None
-    if extra == "ind":
-        extra_in = A._pad_to(torch.repeat_interleave(A.embed(embs[1], rays[:, 8:9]), S, dim=0), extra_dim)
-    elif extra == "dir":
-        extra_in = A._pad_to(torch.repeat_interleave(A.embed(embs[2], rays[:, 3:6]), S, dim=0), extra_dim)
+    with torch.no_grad():
+        emb_in = A._pad_to(embs[0](p["xyz_in"]), 63)
+        extra_in, extra_o = None, None
+        if extra == "ind":
+            extra_in = A._pad_to(torch.repeat_interleave(embs[1](rays[:, 8:9].contiguous()), S, dim=0), extra_dim)
+            extra_o = O.pad_to(torch.repeat_interleave(O.embed(embs[1], rays[:, 8:9].cpu()), S, dim=0), extra_dim)
+        elif extra == "dir":
+            extra_in = A._pad_to(torch.repeat_interleave(embs[2](rays[:, 3:6].contiguous()), S, dim=0), extra_dim)
+            extra_o = O.pad_to(torch.repeat_interleave(O.embed(embs[2], rays[:, 3:6].cpu()), S, dim=0), extra_dim)
     gout = torch.randn(n_rays * S, 4, device="cuda")
     out = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, embs[0], xin, *nerf.parameters())
     out.backward(gout)
-    got = {n: q.grad.clone() for n, q in nerf.named_parameters()}
-    got_x = xin.grad.clone()
-    nerf.zero_grad(set_to_none=True)
-    x2 = p["xyz_in"].clone().requires_grad_(True)
-    full = A._pad_to(A.embed(embs[0], x2), 63)
-    ref = A.nerf_forward(nerf, full if extra_in is None else torch.cat([full, extra_in], -1))
+    x2 = p["xyz_in"].cpu().clone().requires_grad_(True)
+    full = O.pad_to(O.embed(embs[0], x2), 63)
+    ref = O.nerf_forward(nerf, full if extra_o is None else torch.cat([full, extra_o], -1))
     assert relerr(out, ref) <= 1e-5
-    ref.backward(gout)
+    ref.backward(gout.cpu())
+    want = O.grads(nerf)
     for n, q in nerf.named_parameters():
-        assert relerr(got[n], q.grad) <= 1e-4, (n, relerr(got[n], q.grad))
-    assert relerr(got_x, x2.grad) <= 1e-4
+        assert relerr(q.grad, want[n]) <= 1e-4, (n, relerr(q.grad, want[n]))
+    assert relerr(xin.grad, x2.grad) <= 1e-4
 
 
 @pytest.mark.parametrize("D,skips,quat", [(3, [1], True), (5, [], False), (6, [5], True), (2, [], True)])
-def test_nof_backward_other_shapes(M, D, skips, quat):
-    """NofPoints on depths / skip positions other than the configs' 4x128 / skip 2 (default nn.Linear init)."""
+def test_nof_backward_other_shapes(M, R, D, skips, quat):
+    """NofPoints on depths / skip positions other than the configs' 4x128 / skip 2 (default nn.Linear init), against the
+    oracle's CPU autograd."""
     from moco_flow_amd import autograd as A
+    O = OracleOps(R)
     torch.manual_seed(5)
     nof = M.NoF(D, 128, 33, skips, "ind", 33, quat).cuda()
     embs = [M.Embedding(3, 5), M.Embedding(1, 16)]
@@ -1366,16 +1328,14 @@ def test_nof_backward_other_shapes(M, D, skips, quat):
     assert A.nof_hip_supported(nof, embs)
     out = A.nof_points(pts, rays[:, 8:9], embs, nof)
     out.backward(gout)
-    got = {n: q.grad.clone() for n, q in nof.named_parameters()}
-    got_x = pts.grad.clone()
-    nof.zero_grad(set_to_none=True)
-    p2 = pts.detach().clone().requires_grad_(True)
-    ref = A._nof_points(p2, rays[:, 8:9], embs, nof)
+    p2 = pts.detach().cpu().clone().requires_grad_(True)
+    ref = O.nof_points(p2, rays[:, 8:9], embs, nof)
     assert relerr(out, ref) <= 1e-5
-    ref.backward(gout)
+    ref.backward(gout.cpu())
+    want = O.grads(nof)
     for n, q in nof.named_parameters():
-        assert relerr(got[n], q.grad) <= 1e-4, (n, relerr(got[n], q.grad))
-    assert relerr(got_x, p2.grad) <= 1e-4
+        assert relerr(q.grad, want[n]) <= 1e-4, (n, relerr(q.grad, want[n]))
+    assert relerr(pts.grad, p2.grad) <= 1e-4
 
 
 @pytest.mark.parametrize("name", ["r_nerf_dir_fine_train", "r_moco_global_fine"])
@@ -1411,11 +1371,12 @@ def test_training_gradients_are_reproducible(M, name):
 
 
 @pytest.mark.parametrize("quat,B", [(True, 1000), (False, 333)])
-def test_nof_module_training_call(M, quat, B):
+def test_nof_module_training_call(M, R, quat, B):
     """NoF(inputs, xyz) on data points with only the parameters requiring grad (trainer_nof.py:85-125, the
     stage-2 step; trainer_moco_flow.py:159-187): autograd.NofModule (mf_nof_forward_dump + mf_nof_backward
-    + mf_weight_grads) against torch autograd of the same call, values 1e-5, gradients 1e-4."""
-    from moco_flow_amd import autograd as A, synth
+    + mf_weight_grads) against the oracle's CPU autograd of the same call, values 1e-5, gradients 1e-4."""
+    from moco_flow_amd import synth
+    O = OracleOps(R)
     torch.manual_seed(2)
     nof = M.NoF(4, 128, 33, [2], "ind", 33, quat)
     nof.load_state_dict({k: torch.from_numpy(v) for k, v in synth.nof_state(9, use_quat=quat, tag="fw", head_scale=0.25).items()})
@@ -1428,20 +1389,20 @@ def test_nof_module_training_call(M, quat, B):
     out = nof(inputs, xyz)
     assert "NofModule" in type(out.grad_fn).__name__
     torch.nn.functional.mse_loss(out, target).backward()
-    got = {n: q.grad.clone() for n, q in nof.named_parameters()}
-    nof.zero_grad(set_to_none=True)
-    ref = A.nof_forward(nof, inputs, xyz)
+    ref = O.nof_forward(nof, inputs.detach().cpu(), xyz.cpu())
     assert relerr(out, ref) <= 1e-5
-    torch.nn.functional.mse_loss(ref, target).backward()
+    torch.nn.functional.mse_loss(ref, target.cpu()).backward()
+    want = O.grads(nof)
     for n, q in nof.named_parameters():
-        assert relerr(got[n], q.grad) <= 1e-4, (n, relerr(got[n], q.grad))
+        assert relerr(q.grad, want[n]) <= 1e-4, (n, relerr(q.grad, want[n]))
 
 
-def test_aux_point_losses_train(M):
+def test_aux_point_losses_train(M, R):
     """The joint stage's point losses (trainer_moco_flow.py:330-363): outside points -> bw NoF (module call,
     HIP NofModule) -> xyz embedding -> NeRF(sigma_only) -> alphas -> mask loss.  Gradients reach the NoF through
-    the NeRF's input; compared with the same chain in plain torch ops."""
-    from moco_flow_amd import autograd as A, synth
+    the NeRF's input; compared with the same chain through the oracle on the CPU."""
+    from moco_flow_amd import synth
+    O = OracleOps(R)
     torch.manual_seed(4)
     B = 1000
     load = lambda m, sd: (m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}), m.cuda())[1]
@@ -1451,27 +1412,27 @@ def test_aux_point_losses_train(M):
     pts = torch.randn(B, 3, device="cuda") * 0.5
     ind = torch.full((B, 1), 0.1, device="cuda")
 
-    def chain(nof_call, emb_call, nerf_call):
+    def chain(nof_call, emb_call, nerf_call, pts, ind):
         inp = torch.cat([emb_call(exyz, pts), emb_call(eind, ind)], -1)
         canon = nof_call(inp, pts)
         sig = nerf_call(emb_call(nxyz, canon))
         alphas = 1 - torch.exp(-(1.0 / 128) * torch.nn.functional.softplus(sig))
         return canon, (alphas ** 2).mean()
 
-    canon, loss = chain(lambda i, x: nof(i, x), lambda e, x: e(x), lambda z: nerf(z, sigma_only=True))
+    canon, loss = chain(lambda i, x: nof(i, x), lambda e, x: e(x), lambda z: nerf(z, sigma_only=True), pts, ind)
     loss.backward()
-    got = {("nof", n): q.grad.clone() for n, q in nof.named_parameters()}
-    got.update({("nerf", n): q.grad.clone() for n, q in nerf.named_parameters() if q.grad is not None})
-    nof.zero_grad(set_to_none=True); nerf.zero_grad(set_to_none=True)
-    canon_t, loss_t = chain(lambda i, x: A.nof_forward(nof, i, x), lambda e, x: A.embed(e, x),
-                            lambda z: A.nerf_forward(nerf, z, sigma_only=True))
+    canon_t, loss_t = chain(lambda i, x: O.nof_forward(nof, i, x), lambda e, x: O.embed(e, x),
+                            lambda z: O.nerf_forward(nerf, z, sigma_only=True), pts.cpu(), ind.cpu())
     loss_t.backward()
     assert relerr(canon, canon_t) <= 1e-5 and relerr(loss, loss_t) <= 1e-4
+    want_nof, want_nerf = O.grads(nof), O.grads(nerf)
     for n, q in nof.named_parameters():
-        assert relerr(got[("nof", n)], q.grad) <= 2e-3, (n, relerr(got[("nof", n)], q.grad))
+        assert relerr(q.grad, want_nof[n]) <= 2e-3, (n, relerr(q.grad, want_nof[n]))
     for n, q in nerf.named_parameters():
-        if q.grad is not None:
-            assert relerr(got[("nerf", n)], q.grad) <= 2e-3, (n, relerr(got[("nerf", n)], q.grad))
+        if want_nerf[n] is None:
+            assert q.grad is None or float(q.grad.abs().max()) == 0.0, n
+        else:
+            assert relerr(q.grad, want_nerf[n]) <= 2e-3, (n, relerr(q.grad, want_nerf[n]))
 
 
 @pytest.mark.parametrize("name", ["r_moco_global_fine", "r_moco_local", "r_nerf_dir_fine_train", "r_nerf_dir_dense"])

@@ -1,14 +1,14 @@
 #!/usr/bin/env python3
 """Time one training step of the joint MoCo-Flow stage (c2f.yaml shape: N_rand = 1024 rays x (128 coarse
 + 256 fine) samples, backward NoF -> NeRF(ind) with local + global consensus chains, trainer_moco_flow.py
-:200-216, 317-328) through the drop-in (HIP forward + HIP/torch backward) and with everything in
-PyTorch-ROCm eager ops (TRAIN_FORWARD=torch: what the reference itself would run on this GPU)."""
+:200-216, 317-328) through the drop-in (HIP forward + HIP backward) and with everything in
+PyTorch-ROCm eager ops (tools/eager_ref.py: what the reference itself would run on this GPU)."""
 import sys, os, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import moco_flow_amd as M
-import ab_switches as AB   # tools/ab_switches.py
+import eager_ref as E      # tools/eager_ref.py
 from moco_flow_amd import synth, rendering
 rendering.STRICT_RNG = False
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
@@ -79,6 +79,15 @@ print(f"N_rand={N} rays x ({S} + {S+Mi}) samples = {N*(2*S+Mi)/1e6:.2f} M sample
 print(f"  HIP forward (no_grad)            : {timeit(fwd_only):8.2f} ms")
 print(f"  HIP forward + backward (shipped) : {timeit(fwd_bwd):8.2f} ms")
 print(f"  same, loss from the fused partials : {timeit(fwd_bwd_fast):8.2f} ms")
+def eager_fwd_bwd():
+    for m in mods:
+        m.zero_grad(set_to_none=True)
+    res = E.render_rays_eager(rays, bg, embs, nerfs, nof_embs, nofs, True, True, N_samples=S, N_importance=Mi, perturb=1.0)
+    loss = crit(res, gt)
+    for k in ("nof_local_disp_coarse", "nof_global_disp_coarse", "nof_local_disp_fine", "nof_global_disp_fine"):
+        loss = loss + 0.1 * res[k].mean()
+    loss.backward()
+
+
 if os.environ.get("MF_ONLY") != "hipbwd":
-    AB.set_train_forward("torch")
-    print(f"  TRAIN_FORWARD=torch fwd+bwd      : {timeit(fwd_bwd):8.2f} ms")
+    print(f"  PyTorch-ROCm eager fwd+bwd       : {timeit(eager_fwd_bwd, n=5):8.2f} ms")

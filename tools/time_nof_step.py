@@ -7,8 +7,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import moco_flow_amd as M
-import ab_switches as AB   # tools/ab_switches.py
-from moco_flow_amd import autograd as A, synth
+import eager_ref as E   # tools/ab_switches.py
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 dev = torch.device("cuda")
 load = lambda m, sd: (m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}), m.to(dev))[1]
@@ -38,7 +37,4 @@ def timeit(f, n=5):
 
 print(f"{B} correspondence points, bw + fw NoF, forward + backward")
 print(f"  HIP forward + HIP backward (shipped)      : {timeit(lambda: step(lambda m, i, x: m(i, x))):7.2f} ms")
-AB.set_nof_backward("torch")
-print(f"  HIP forward + torch-recompute backward   : {timeit(lambda: step(lambda m, i, x: m(i, x))):7.2f} ms")
-AB.set_nof_backward("hip")
-print(f"  PyTorch-ROCm eager (reference op sequence): {timeit(lambda: step(lambda m, i, x: A.nof_forward(m, i, x))):7.2f} ms")
+print(f"  PyTorch-ROCm eager (reference op sequence): {timeit(lambda: step(lambda m, i, x: E.nof_forward(m, i, x))):7.2f} ms")

@@ -7,8 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import moco_flow_amd as M
-import ab_switches as AB   # tools/ab_switches.py
-from moco_flow_amd import synth, autograd as A, rendering
+import eager_ref as E   # tools/eager_ref.py
+from moco_flow_amd import synth, rendering
 rendering.STRICT_RNG = False
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 S, Mi = 128, 128
@@ -34,9 +34,9 @@ def fwd_bwd():
 def eager_fwd():
     with torch.no_grad():
         z = (rays[:, 6:7] * (1 - torch.linspace(0, 1, S, device=dev)) + rays[:, 7:8] * torch.linspace(0, 1, S, device=dev)).contiguous()
-        c = A.render_pass(rays, bg, z, None, "relu", nerfs[0], embs, None, None, False, False, False, None)
+        c = E.render_pass(rays, bg, z, None, "relu", nerfs[0], embs, None, None, False, False, False, None)
         z2 = rendering.resample_merge(z, c["weights"], Mi)
-        A.render_pass(rays, bg, z2, None, "relu", nerfs[1], embs, None, None, False, False, False, None)
+        E.render_pass(rays, bg, z2, None, "relu", nerfs[1], embs, None, None, False, False, False, None)
 if os.environ.get("MF_ONLY") in ("hipbwd", "step"):      # profiling: only the shipped training path
     print(f"  HIP forward + HIP dX chain + dW GEMMs : {timeit(fwd_bwd):8.2f} ms")
     sys.exit(0)
@@ -44,8 +44,7 @@ print(f"N_rand={N} rays x ({S} + {S+Mi}) samples = {N*(2*S+Mi)/1e6:.2f} M sample
 print(f"  HIP forward (no_grad)            : {timeit(fwd_only):8.2f} ms")
 print(f"  PyTorch-ROCm eager forward        : {timeit(eager_fwd):8.2f} ms")
 print(f"  HIP forward + HIP dX chain + dW GEMMs : {timeit(fwd_bwd):8.2f} ms")
-AB.set_nerf_backward("gemm")
-print(f"  HIP forward + library-GEMM backward   : {timeit(fwd_bwd):8.2f} ms")
-AB.set_nerf_backward("hip")
-AB.set_train_forward("torch")
-print(f"  TRAIN_FORWARD=torch fwd+bwd       : {timeit(fwd_bwd):8.2f} ms")
+def eager_fwd_bwd():
+    for m in nerfs: m.zero_grad(set_to_none=True)
+    crit(E.render_rays_eager(rays, bg, embs, nerfs, N_samples=S, N_importance=Mi), gt).backward()
+print(f"  PyTorch-ROCm eager fwd+bwd (tools/eager_ref.py) : {timeit(eager_fwd_bwd):8.2f} ms")
