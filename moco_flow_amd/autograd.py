@@ -595,6 +595,56 @@ def require_nerf_hip(m, P, under_nof):
                                   f"skips={m.skips}, in_channels_xyz={m.in_channels_xyz}, extra_feat_dim={m.extra_feat_dim}")
 
 
+class LossPartials(torch.autograd.Function):
+    """The 12 (sum, count) loss partials of a training step as ONE node (the losses "fused
+    into the epilogue"; models/losses.py:4-14, trainer/trainer_moco_flow.py:317-328).  Forward: mf_loss_partials on the
+    arrays the fused passes already wrote (rgb, alphas, the per-sample consensus distances) -- the values of the
+    gradient-free fast path, bit for bit.  Backward: mf_loss_partials_backward, one launch that writes the seeds
+    2 g (rgb - gt) and  -g mask sign(x - recon) / 3  straight into the buffers CompositeSamples / NofPointsDumped
+    consume.  No torch arithmetic, no mask tensor, no host sync.
+    ``passes``: per pass a dict(planes = the kernel's output dict, z = depths (N,S)); differentiable inputs per pass:
+    rgb (N,3), recon_local (N,S,3) | None, recon_global (N,S,3) | None."""
+
+    @staticmethod
+    def forward(ctx, partials_fn, rays, target, passes, *tensors):
+        ctx.rays, ctx.target, ctx.passes = rays, target, passes
+        ctx.shapes = [None if t is None else t.shape for t in tensors]
+        out12 = partials_fn()
+        ctx.save_for_backward(out12, *[t.detach() if t is not None else rays.new_empty(0) for t in tensors])
+        return out12
+
+    @staticmethod
+    def backward(ctx, g12):
+        out12, *tensors = ctx.saved_tensors
+        rays, target, passes = ctx.rays, ctx.target, ctx.passes
+        dev, N = rays.device, rays.shape[0]
+        g12 = g12.detach().contiguous().double()
+        descs, grads = [], []
+        for q, ps in enumerate(passes):
+            rgb, rl, rg = (tensors[3 * q + k] if ctx.shapes[3 * q + k] is not None else None for k in range(3))
+            d = L.mf_loss_grad_pass()
+            pl, z = ps["planes"], ps["z"]
+            need = [ctx.needs_input_grad[4 + 3 * q + k] and ctx.shapes[3 * q + k] is not None for k in range(3)]
+            g_rgb = torch.empty_like(rgb) if need[0] else None
+            g_rl = torch.empty_like(rl) if need[1] else None
+            g_rg = torch.empty_like(rg) if need[2] else None
+            d.rgb, d.g_rgb = L.ptr(rgb.contiguous() if rgb is not None else None), L.ptr(g_rgb)
+            if g_rl is not None or g_rg is not None:
+                d.alphas, d.n_samples = L.ptr(pl["alphas"]), z.shape[1]
+                d.rays, d.ray_stride, d.z_vals = L.ptr(rays), rays.stride(0), L.ptr(z)
+                d.recon_local, d.g_recon_local = L.ptr(rl.contiguous() if g_rl is not None else None), L.ptr(g_rl)
+                d.recon_global, d.g_recon_global = L.ptr(rg.contiguous() if g_rg is not None else None), L.ptr(g_rg)
+            descs.append(d)
+            grads += [g_rgb, g_rl, g_rg]
+        while len(grads) < len(ctx.shapes):
+            grads.append(None)
+        with torch.cuda.device(dev):
+            L.check(L.lib().mf_loss_partials_backward(C.byref(descs[0]), C.byref(descs[1]) if len(descs) > 1 else None,
+                                                      L.ptr(target), N, out12.data_ptr(), g12.data_ptr(),
+                                                      L.current_stream(dev)), "mf_loss_partials_backward")
+        return (None, None, None, None) + tuple(grads)
+
+
 class CompositeSamples(torch.autograd.Function):
     """(rgb, depth, opacity) of a pass as a function of the per-sample (rgb, sigma) plane.  Forward: the
     values the fused HIP pass already produced; backward: mf_composite_backward (rendering.py:157-192

@@ -7,7 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import moco_flow_amd as M
-import eager_ref as E   # tools/ab_switches.py
+import eager_ref as E   # tools/eager_ref.py
+from moco_flow_amd import synth
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 200000
 dev = torch.device("cuda")
 load = lambda m, sd: (m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()}), m.to(dev))[1]
