@@ -303,7 +303,7 @@ def kernel_probe(M, rendering, torch, cfg, models, rays, bg, kw, iters=20):
             e.record()
         torch.cuda.synchronize()
     ms = sorted(s.elapsed_time(e) for s, e in ev)
-    return float(sum(ms) / len(ms)), n * S
+    return float(ms[len(ms) // 2]), n * S          # median
 
 
 def run_config(name, a, ctx, steps, warmup, main):
@@ -334,6 +334,9 @@ def run_config(name, a, ctx, steps, warmup, main):
         # with a loss: the fast path of the mean-only caller -- mf_loss_partials instead of mask compaction +
         # host sync; the 12 partials (96 B) go to the asynchronous all-reduce (RCCL over xGMI when world > 1)
         out = M.render_rays(rays, bg, models["embs"], models["nerfs"], _loss_target=gt if reducer is not None else None, **kw)
+        # what the unchanged trainer does with the consensus vectors right away (trainer_moco_flow.py:317-328): their means
+        # (lazy.MaskedVector: masked sums on the device, no compaction, no host sync)
+        cons = [torch.mean(v) for k, v in out.items() if k.startswith("nof_")]
         if i is not None:
             ev[i][1].record()
         if reducer is not None:
@@ -360,7 +363,7 @@ def run_config(name, a, ctx, steps, warmup, main):
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    kernel_ms = float(np.mean([s.elapsed_time(e) for s, e in ev]))
+    kernel_ms = float(np.median([s.elapsed_time(e) for s, e in ev]))        # median of the timed calls
 
     spr = samples_per_ray(cfg)
     value = n * spr * world * steps / elapsed
@@ -379,7 +382,11 @@ def run_config(name, a, ctx, steps, warmup, main):
                    "loss_allreduce": bool(reducer is not None and world > 1)},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
                      "frac": achieved / peak, "traffic": traffic, "traffic_unit": "B/launch",
-                     "traffic_source": traffic_src, "kernel": "mf_render_pass" + (" (fine pass)" if cfg["M"] else ""),
+                     "traffic_source": traffic_src,
+                     "traffic_note": "HBM bytes per launch: the weight stream is read once per XCD L2 (8 x the packed weights) + "
+                                     "rays / requested (N,S) planes" + (" + the per-ray NoF bias table" if cfg["nof"] and cfg["precision"] != "f32" else "")
+                                     + "; algorithmic I/O is 68 B/ray (+ 8 B/sample per requested plane): MFMA-bound, not HBM-bound",
+                     "kernel": "mf_render_pass" + (" (fine pass)" if cfg["M"] else ""),
                      "kernel_ms": kernel_ms, "flops_per_launch": flops_launch, "samples_per_launch": launch_samples,
                      "step_span_ms": step_span_ms, "launches_per_step": 2 if cfg["M"] else 1,
                      "flops_per_step": flops_step},
@@ -406,13 +413,31 @@ def run_config(name, a, ctx, steps, warmup, main):
             base, ref = cpu_baseline(cfg, models["states"], rays_np[:n], bg_np[:n])
             res["cpu_baseline"] = base
             res["speedup_vs_cpu"] = value / base["value"]
+            if name == "C2":
+                # BASELINE config C1: the same canonical NeRF at 1024 rays x 64 samples on the host cores
+                ts = []
+                for _ in range(3):
+                    t0 = time.perf_counter()
+                    oracle_render(cfg, models["states"], torch.from_numpy(rays_np[:1024]), torch.from_numpy(bg_np[:1024]))
+                    ts.append(time.perf_counter() - t0)
+                med = float(np.median(ts))
+                res["c1_cpu"] = dict(value=1024 * spr / med, unit="ray-samples/s", cores=base["cores"], kind="port",
+                                     sample=f"BASELINE config C1: canonical NeRF, 1024 rays x {spr} samples, CPU oracle, median of 3 "
+                                            f"({med:.3f} s), {base['cores']} threads on {cpu_model()}")
         k = n if (main and not cfg["M"]) else min(512, n)
         if not (main and not cfg["M"]):             # accuracy on a bounded 512-ray sample; with a fine pass the
             cap = {}                                # oracle evaluates it on the HIP path's own fine depths
             with torch.no_grad():
                 out = M.render_rays(rays[:k], bg[:k], models["embs"], models["nerfs"], _capture=cap, **kw)
+            t0 = time.perf_counter()
             ref = oracle_render(cfg, models["states"], torch.from_numpy(rays_np[:k]), torch.from_numpy(bg_np[:k]),
                                 z_fine=cap["z_fine"].cpu() if cfg["M"] else None)
+            dt = time.perf_counter() - t0
+            if not main:      # every leg carries its own baseline: the oracle on this bounded sample of the leg's workload
+                res["cpu_baseline"] = dict(value=k * spr / dt, unit="ray-samples/s", cores=torch.get_num_threads(), kind="port",
+                                           sample=f"one oracle pass over the first {k} rays x {spr} samples of the batch ({dt:.2f} s), "
+                                                  f"{torch.get_num_threads()} threads on {cpu_model()}")
+                res["speedup_vs_cpu"] = value / res["cpu_baseline"]["value"]
         res["error_vs_cpu"] = errors_vs(ref, out)
         res["error_vs_cpu"]["sample"] = f"first {k} rays of the batch vs the CPU oracle" + (
             " (fine pass on the HIP path's own resampled depths)" if cfg["M"] else "")
@@ -478,7 +503,7 @@ def worker(a):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic",
         "config": res["config"], "roofline": res["roofline"],
     }
-    for k in ("fwd_bwd", "cpu_baseline", "error_vs_cpu", "speedup_vs_cpu", "loss_path"):
+    for k in ("fwd_bwd", "cpu_baseline", "c1_cpu", "error_vs_cpu", "speedup_vs_cpu", "loss_path"):
         if k in res:
             line[k] = res[k]
     if not a.no_extra_legs and a.config == "C2":
@@ -486,7 +511,8 @@ def worker(a):
         line["configs"] = {}
         for name in legs:
             r = run_config(name, a, ctx, min(a.steps, 20), min(a.warmup, 3), main=False)
-            line["configs"][name] = {k: r[k] for k in ("value", "ms_per_step", "dtype", "config", "roofline", "error_vs_cpu", "loss_path") if k in r}
+            line["configs"][name] = {k: r[k] for k in ("value", "ms_per_step", "dtype", "config", "roofline", "error_vs_cpu", "loss_path",
+                                                       "cpu_baseline", "speedup_vs_cpu") if k in r}
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

@@ -1,0 +1,131 @@
+"""The consensus vectors of a pass without the compaction when nobody looks at their length.
+
+``render_rays`` returns, per pass, ``nof_local_disp_*`` / ``nof_global_disp_*`` = ``mean_c |x - recon|`` at the samples
+with ``alpha >= 0.01`` (all samples when none qualifies) -- 1-D tensors whose LENGTH depends on the data
+(models/rendering.py:306-314).  Building them means a mask, a count, a scatter and a host round trip for the size; the
+reference's only caller takes ``torch.mean`` of each right away (trainer/trainer_moco_flow.py:317-328).
+
+``MaskedVector`` stands for such a vector.  ``v.mean()`` / ``torch.mean(v)`` / ``v.sum()`` / ``torch.sum(v)`` come from
+masked sums on the device -- no compaction, no ``.item()``, so consecutive steps pipeline (gradient-free passes: the two
+launches of mf_loss_partials, shared by the pass's vectors; with gradients: differentiable device reductions on the
+per-sample distances).  Anything else -- ``.shape``, ``len()``, indexing, arithmetic, any other torch function --
+materialises the real tensor first (mf_compact_mask: count -> scan -> scatter in row-major (ray, sample) order, one host
+sync; ``torch.masked_select`` under autograd), after which the object simply forwards to it.  It is not a
+``torch.Tensor`` subclass (a tensor needs its size up front); ``rendering.LAZY_CONSENSUS = False`` restores eager tensors.
+"""
+from __future__ import annotations
+
+import torch
+
+
+class ConsensusPass:
+    """What the vectors of one pass share: the (N,S) alphas, the per-sample distance planes, the cached masked sums and
+    the cached compacted tensors (one compaction serves both vectors)."""
+
+    def __init__(self, alphas, planes, stats_fn, compact_fn, differentiable):
+        self.alphas, self.planes = alphas, planes            # planes: {"local": (N,S), "global": (N,S)}
+        self._stats_fn, self._compact_fn = stats_fn, compact_fn
+        self.differentiable = differentiable
+        self._stats, self._vectors, self._mask = None, None, None
+
+    def stats(self):
+        """{"local": (sum, count), "global": (sum, count)} as device scalars (float64), no host sync."""
+        if self._stats is None:
+            self._stats = self._stats_fn()
+        return self._stats
+
+    def mask(self):
+        """alpha >= 0.01, all-true when empty (rendering.py:306-308), without the host round trip."""
+        if self._mask is None:
+            m = self.alphas.ge(0.01)
+            self._mask = torch.where(m.any(), m, torch.ones_like(m))
+        return self._mask
+
+    def vectors(self):
+        if self._vectors is None:
+            self._vectors = self._compact_fn()
+        return self._vectors
+
+
+class MaskedVector:
+    def __init__(self, group: ConsensusPass, key: str):
+        self._g, self._k = group, key
+
+    # ---- the reductions that need no length
+    def _sum_count(self):
+        g = self._g
+        if g.differentiable:
+            m = g.mask().to(g.planes[self._k].dtype)
+            return (g.planes[self._k] * m).sum(), m.sum()
+        return g.stats()[self._k]
+
+    def mean(self, *args, **kwargs):
+        if args or kwargs:
+            return self.materialize().mean(*args, **kwargs)
+        s, c = self._sum_count()
+        return (s / c).to(torch.float32)
+
+    def sum(self, *args, **kwargs):
+        if args or kwargs:
+            return self.materialize().sum(*args, **kwargs)
+        return self._sum_count()[0].to(torch.float32)
+
+    # ---- everything else: the real tensor
+    def materialize(self) -> torch.Tensor:
+        return self._g.vectors()[self._k]
+
+    @classmethod
+    def __torch_function__(cls, func, types, args=(), kwargs=None):
+        kwargs = kwargs or {}
+        if func in (torch.mean, torch.Tensor.mean, torch.sum, torch.Tensor.sum) and len(args) == 1 and not kwargs \
+                and isinstance(args[0], MaskedVector):
+            return args[0].mean() if func in (torch.mean, torch.Tensor.mean) else args[0].sum()
+
+        def real(a):
+            if isinstance(a, MaskedVector):
+                return a.materialize()
+            if isinstance(a, (list, tuple)):
+                return type(a)(real(x) for x in a)
+            return a
+
+        return func(*real(args), **{k: real(v) for k, v in kwargs.items()})
+
+    def __getattr__(self, name):           # .shape, .dtype, .is_cuda, .cpu(), .numel(), .detach(), ...
+        if name.startswith("_"):
+            raise AttributeError(name)
+        return getattr(self.materialize(), name)
+
+    def __len__(self):
+        return len(self.materialize())
+
+    def __getitem__(self, i):
+        return self.materialize()[i]
+
+    def __iter__(self):
+        return iter(self.materialize())
+
+    def __array__(self, dtype=None):
+        a = self.materialize().detach().cpu().numpy()
+        return a if dtype is None else a.astype(dtype)
+
+    def __repr__(self):
+        return f"MaskedVector({self._k}, materialised={self._g._vectors is not None})"
+
+    def __float__(self):
+        return float(self.materialize())
+
+
+def _binary(name):
+    def op(self, other):
+        other = other.materialize() if isinstance(other, MaskedVector) else other
+        return getattr(self.materialize(), name)(other)
+    op.__name__ = name
+    return op
+
+
+for _n in ("__add__", "__radd__", "__sub__", "__rsub__", "__mul__", "__rmul__", "__truediv__", "__rtruediv__", "__pow__",
+           "__lt__", "__le__", "__gt__", "__ge__", "__eq__", "__ne__", "__matmul__"):
+    setattr(MaskedVector, _n, _binary(_n))
+MaskedVector.__neg__ = lambda self: -self.materialize()
+MaskedVector.__abs__ = lambda self: abs(self.materialize())
+MaskedVector.__hash__ = lambda self: id(self)

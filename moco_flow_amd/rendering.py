@@ -43,6 +43,11 @@ def set_precision(p: str):
 # reference renders those under no_grad).  There is no eager fallback in the package.
 
 
+# The consensus vectors nof_*_disp_* as lazy.MaskedVector (default): .mean() / .sum() from masked sums on the device, the
+# data-dependent-length tensor only when something asks for it.  False: eager tensors (compaction + host sync per pass).
+LAZY_CONSENSUS = True
+
+
 # Draw torch.randn(N,S) in every pass even when noise_std == 0, as the reference does
 # (rendering.py:166), so that the device RNG stream advances identically.
 STRICT_RNG = True
@@ -187,6 +192,37 @@ def _compact(alphas, vals_a, vals_b):
                                     count.data_ptr(), scratch.data_ptr(), L.current_stream(dev)), "mf_compact_mask")
     n = int(count.item())   # data-dependent length, as in the reference's boolean indexing
     return (oa[:n] if oa is not None else None), (ob[:n] if ob is not None else None)
+
+
+def _pass_stats(p, N):
+    """(sum, count) of the masked consensus distances of ONE pass as device scalars: mf_loss_partials on its planes."""
+    dev = p["alphas"].device
+    lib = L.lib()
+    d = L.mf_loss_pass()
+    d.alphas, d.disp_local, d.disp_global = L.ptr(p["alphas"]), L.ptr(p.get("disp_local")), L.ptr(p.get("disp_global"))
+    d.n_samples = p["alphas"].shape[1]
+    out = torch.empty(12, dtype=torch.float64, device=dev)
+    scratch = torch.empty(int(lib.mf_loss_partials_scratch_bytes()), dtype=torch.uint8, device=dev)
+    with torch.cuda.device(dev):
+        L.check(lib.mf_loss_partials(C.byref(d), None, None, N, out.data_ptr(), scratch.data_ptr(), L.current_stream(dev)),
+                "mf_loss_partials")
+    return {"local": (out[4], out[5]), "global": (out[8], out[9])}
+
+
+def _consensus_vectors(p, N, loc, glob):
+    """nof_local_disp / nof_global_disp of a gradient-free pass: lazy.MaskedVector over the kernel's planes (or, with
+    LAZY_CONSENSUS off, the compacted tensors right away)."""
+    if not LAZY_CONSENSUS:
+        return _compact(p["alphas"], p.get("disp_local"), p.get("disp_global"))
+    from .lazy import ConsensusPass, MaskedVector
+
+    def compact():
+        la, ga = _compact(p["alphas"], p.get("disp_local"), p.get("disp_global"))
+        return {"local": la, "global": ga}
+
+    g = ConsensusPass(p["alphas"], {"local": p.get("disp_local"), "global": p.get("disp_global")}, lambda: _pass_stats(p, N), compact,
+                      differentiable=False)
+    return (MaskedVector(g, "local") if loc else None), (MaskedVector(g, "global") if glob else None)
 
 
 def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
@@ -352,8 +388,9 @@ def render_rays(rays,
     else:
         result = {'rgb_coarse': c["rgb"], 'depth_coarse': c["depth"], 'opacity_coarse': c["opacity"]}
     fused_loss = _loss_target is not None     # the 12 loss partials replace the compacted consensus vectors
+    training = grad and N > 0            # the consensus vectors then come from _attach_explicit, differentiable
     if (loc or glob) and not fused_loss:
-        la, ga = _compact(c["alphas"], c.get("disp_local"), c.get("disp_global"))
+        la, ga = (None, None) if training else _consensus_vectors(c, N, loc, glob)
         if loc:
             result['nof_local_disp_coarse'] = la
         if glob:
@@ -374,7 +411,7 @@ def render_rays(rays,
         result['depth_fine'] = f["depth"]
         result['opacity_fine'] = f["opacity"]
         if (loc or glob) and not fused_loss:
-            la, ga = _compact(f["alphas"], f.get("disp_local"), f.get("disp_global"))
+            la, ga = (None, None) if training else _consensus_vectors(f, N, loc, glob)
             if loc:
                 result['nof_local_disp_fine'] = la
             if glob:
@@ -405,9 +442,19 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
         p, z, noise = pack
         N, S = z.shape
         xyz = rays_o.unsqueeze(1) + rays_d.unsqueeze(1) * z.unsqueeze(2)
-        mask = None
+        group = None
         if (loc or glob) and loss_target is None:
-            mask = _mask_of(p["alphas"])
+            from .lazy import ConsensusPass, MaskedVector
+            planes = {}
+            group = ConsensusPass(p["alphas"], planes, None,
+                                  lambda: {k: torch.masked_select(v, _mask_of(p["alphas"])) for k, v in planes.items()}, True)
+
+            def vector(key, dist3):
+                # torch.mean(dist3[mask], dim=1) of rendering.py:310-314 as mean-then-select (same numbers; the backward is a
+                # masked scatter instead of the sort + accumulate of boolean-index backward), lazily (lazy.MaskedVector)
+                planes[key] = dist3.mean(-1)
+                v = MaskedVector(group, key)
+                return v if LAZY_CONSENSUS else v.materialize()
         xin = p["xyz_in"]
         if nof_models is not None:
             bw = nof_models[0]
@@ -441,7 +488,7 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
                 fw = nof_models[1]
                 recon = nof_points(canon, ind, nof_embs, fw)
                 if loss_target is None:
-                    out[f"nof_local_disp_{tag}"] = _masked_point_means(torch.abs(xyz - recon), mask)
+                    out[f"nof_local_disp_{tag}"] = vector("local", torch.abs(xyz - recon))
                 else:
                     recons[f"local_{tag}"] = recon           # the loss node differentiates |x - recon| itself
             if glob:
@@ -450,7 +497,7 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
                 b_ = nof_points(a_, cind, nof_embs, bw)
                 chained = nof_points(b_, ind, nof_embs, fw)
                 if loss_target is None:
-                    out[f"nof_global_disp_{tag}"] = _masked_point_means(torch.abs(xyz - chained), mask)
+                    out[f"nof_global_disp_{tag}"] = vector("global", torch.abs(xyz - chained))
                 else:
                     recons[f"global_{tag}"] = chained
             xin = canon.reshape(-1, 3)
@@ -477,8 +524,8 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
     final = {}
     for k, v in result.items():
         t = out[k]
-        # CompositeSamples hands back the kernel's own values (detached clones): nothing to re-base
-        final[k] = t if k in kernel_vals else v.detach() + (t - t.detach())
+        # CompositeSamples hands back the kernel's own values (detached clones), the consensus vectors are built here
+        final[k] = t if (k in kernel_vals or v is None) else v.detach() + (t - t.detach())
     if loss_target is not None:
         # the 12 (sum, count) partials (layout of dist.loss_partials / mf_loss_partials) as one autograd node: forward =
         # the kernel on the planes the passes wrote, backward = one launch writing the seeds (autograd.LossPartials)
@@ -491,12 +538,6 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
         final["loss_partials"] = A.LossPartials.apply(
             lambda: _loss_partials_hip(coarse[0], fine[0] if fine is not None else None, tgt, N), rays, tgt, passes, *tensors)
     return final
-
-
-def _masked_point_means(dist3, mask):
-    """torch.mean(dist3[mask], dim=1) of rendering.py:310-314 as mean-then-select: the same numbers, but the backward
-    is a masked scatter instead of the sort + accumulate of boolean-index backward."""
-    return torch.masked_select(dist3.mean(-1), mask)
 
 
 def _mask_of(alphas):

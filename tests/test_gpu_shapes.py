@@ -225,3 +225,68 @@ def test_rccl_one_rank_child(rccl_child):
     assert out["ok"] and out["backend"] == "nccl" and out["world"] == 1
     assert out["steps"] == 50 and out["mismatching_steps"] == 0
     assert all("Done" not in t for t in out["work_types"]), out["work_types"]
+
+
+def test_lazy_consensus_vectors(M):
+    """The consensus vectors as lazy.MaskedVector (moco_flow_amd/lazy.py): what the unchanged trainer does with them --
+    torch.mean(res["nof_local_disp_coarse"]) (trainer_moco_flow.py:317-328) -- involves no compaction and NO host
+    synchronisation (torch's sync-debug mode set to "error" around render + means); the means equal those of the
+    materialised tensors; materialising gives exactly the eager path's tensors; and in training both routes
+    back-propagate the same gradients."""
+    from moco_flow_amd import rendering, synth
+    from moco_flow_amd.lazy import MaskedVector
+    c = dict(RENDER_CASES["r_moco_global_fine"])
+    embs, nerfs, kw = build_case(M, c, 5, device="cuda")
+    rays_np, bg_np = synth.rays(5, 192, chained=True)
+    rays, bg = torch.from_numpy(rays_np).cuda(), torch.from_numpy(bg_np).cuda()
+    keys = [f"nof_{a}_disp_{b}" for b in ("coarse", "fine") for a in ("local", "global")]
+    strict = rendering.STRICT_RNG
+    try:
+        rendering.STRICT_RNG = False
+        for prec in ("f32", "bf16"):
+            rendering.set_precision(prec)
+            with torch.no_grad():
+                M.render_rays(rays, bg, embs, nerfs, **kw)                    # warm-up: packing, module load, allocator
+                torch.cuda.synchronize()
+                torch.cuda.set_sync_debug_mode("error")
+                try:
+                    res = M.render_rays(rays, bg, embs, nerfs, **kw)
+                    means = {k: torch.mean(res[k]) for k in keys}
+                    sums = {k: res[k].sum() for k in keys}
+                finally:
+                    torch.cuda.set_sync_debug_mode("default")
+                assert all(isinstance(res[k], MaskedVector) for k in keys)
+                rendering.LAZY_CONSENSUS = False
+                eager = M.render_rays(rays, bg, embs, nerfs, **kw)
+                rendering.LAZY_CONSENSUS = True
+            for k in keys:
+                assert torch.is_tensor(eager[k]) and torch.equal(res[k].materialize(), eager[k]), k
+                assert res[k].shape == eager[k].shape and len(res[k]) == eager[k].shape[0]
+                assert abs(float(means[k]) - float(eager[k].mean())) <= 1e-5 * abs(float(eager[k].mean())), k
+                assert abs(float(sums[k]) - float(eager[k].sum())) <= 1e-5 * abs(float(eager[k].sum())), k
+            for k in res:                                                    # the per-ray outputs are untouched
+                if k not in keys:
+                    assert torch.equal(res[k], eager[k]), k
+    finally:
+        rendering.set_precision("f32")
+        rendering.STRICT_RNG, rendering.LAZY_CONSENSUS = strict, True
+    # training: loss through the lazy means vs through the materialised vectors
+    nets = list(nerfs) + list(kw["nof_models"])
+    gt = torch.rand(192, 3, device="cuda")
+
+    def grads(materialise):
+        for m in nets:
+            m.zero_grad(set_to_none=True)
+        res = M.render_rays(rays, bg, embs, nerfs, **kw)
+        loss = M.get_loss(dict(type="MSE"))(res, gt)
+        for k in keys:
+            v = res[k].materialize() if materialise else res[k]
+            loss = loss + 0.2 * torch.mean(v)
+        loss.backward()
+        return float(loss), [p.grad.clone() for m in nets for p in m.parameters()]
+
+    la, ga = grads(False)
+    lb, gb = grads(True)
+    assert la == pytest.approx(lb, rel=1e-6)
+    for x, y in zip(ga, gb):
+        assert relerr(x, y) <= 1e-5
