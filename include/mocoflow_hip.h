@@ -375,8 +375,10 @@ typedef struct mf_loss_pass {
   int32_t n_samples;         /* S of the pass                                         */
 } mf_loss_pass;
 int64_t mf_loss_partials_scratch_bytes(void);
+/* means6 (device, 6 floats, optional; ABI v12): sum / count of each pair in fp32 -- what torch.mean of the corresponding
+ * vector returns (nan for an empty one) -- so that a mean-only caller launches nothing else. */
 int32_t mf_loss_partials(const mf_loss_pass* coarse, const mf_loss_pass* fine, const float* target, int64_t n_rays,
-                         double* out12, void* scratch, void* stream);
+                         double* out12, float* means6, void* scratch, void* stream);
 
 /* Backward of mf_loss_partials (ABI v12): the training-mode loss epilogue.  g12 (device, 12 doubles) = dL/d out12 (only the
  * six sums carry a gradient; out12 = the forward's result, its counts tell whether the consensus mask fell back to

@@ -143,7 +143,7 @@ SYMBOLS = {
     "mf_embedding_backward": (C.c_int32, [C.POINTER(mf_embedding), _fp, C.c_int64, _fp, C.c_int64, C.c_int64, _fp, _fp]),
     "mf_valid_rays_mask": (C.c_int32, [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.c_int32, _fp, _fp]),
     "mf_loss_partials_scratch_bytes": (C.c_int64, []),
-    "mf_loss_partials": (C.c_int32, [C.POINTER(mf_loss_pass), C.POINTER(mf_loss_pass), _fp, C.c_int64, _fp, _fp, _fp]),
+    "mf_loss_partials": (C.c_int32, [C.POINTER(mf_loss_pass), C.POINTER(mf_loss_pass), _fp, C.c_int64, _fp, _fp, _fp, _fp]),
     "mf_loss_partials_backward": (C.c_int32, [C.POINTER(mf_loss_grad_pass), C.POINTER(mf_loss_grad_pass), _fp, C.c_int64, _fp, _fp, _fp]),
     "mf_compact_scratch_bytes": (C.c_int64, [C.c_int64]),
     "mf_compact_mask": (C.c_int32, [_fp, _fp, _fp, C.c_int64, C.c_int32, _fp, _fp, _fp, _fp, _fp]),

@@ -24,6 +24,7 @@ struct LossParams {
   const float* target;
   double* scratch;    // (kLossBlocks, kLossSlots)
   double* out;        // (12)
+  float* means;       // (6) sum / count of each pair as fp32 (0 / 0 = nan, like torch.mean of an empty vector), or null
 };
 
 __device__ inline double wave_sum_d(double v) {
@@ -105,6 +106,8 @@ __global__ __launch_bounds__(kLossBlocks) void loss_finish_kernel(LossParams p, 
       p.out[8 + 2 * q] = P.dg ? (none ? tot[6 * q + 5] : tot[6 * q + 3]) : 0.0;
       p.out[8 + 2 * q + 1] = P.dg ? cnt : 0.0;
     }
+    if (p.means)
+      for (int k = 0; k < 6; ++k) p.means[k] = (float)(p.out[2 * k] / p.out[2 * k + 1]);
   }
 }
 
@@ -200,7 +203,7 @@ extern "C" int32_t mf_loss_partials_backward(const mf_loss_grad_pass* coarse, co
 extern "C" int64_t mf_loss_partials_scratch_bytes(void) { return (int64_t)kLossBlocks * kLossSlots * sizeof(double); }
 
 extern "C" int32_t mf_loss_partials(const mf_loss_pass* coarse, const mf_loss_pass* fine, const float* target, int64_t n_rays,
-                                    double* out12, void* scratch, void* stream) {
+                                    double* out12, float* means6, void* scratch, void* stream) {
   if (!coarse || !out12 || !scratch || n_rays < 0) return fail(MF_E_INVALID, "mf_loss_partials: null argument");
   LossParams p{};
   const mf_loss_pass* src[2] = {coarse, fine};
@@ -219,6 +222,7 @@ extern "C" int32_t mf_loss_partials(const mf_loss_pass* coarse, const mf_loss_pa
   p.target = target;
   p.scratch = static_cast<double*>(scratch);
   p.out = out12;
+  p.means = means6;
   int blocks = (int)((work + kLossThreads * 8 - 1) / (kLossThreads * 8));
   blocks = blocks < 1 ? 1 : (blocks > kLossBlocks ? kLossBlocks : blocks);
   hipStream_t st = static_cast<hipStream_t>(stream);

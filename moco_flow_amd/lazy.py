@@ -57,11 +57,13 @@ class MaskedVector:
         if g.differentiable:
             m = g.mask().to(g.planes[self._k].dtype)
             return (g.planes[self._k] * m).sum(), m.sum()
-        return g.stats()[self._k]
+        return g.stats()[self._k][:2]
 
     def mean(self, *args, **kwargs):
         if args or kwargs:
             return self.materialize().mean(*args, **kwargs)
+        if not self._g.differentiable:
+            return self._g.stats()[self._k][2]          # the kernel's own fp32 mean: no further launch
         s, c = self._sum_count()
         return (s / c).to(torch.float32)
 

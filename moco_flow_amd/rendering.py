@@ -174,7 +174,7 @@ def _loss_partials_hip(c, f, target, N):
     scratch = torch.empty(int(lib.mf_loss_partials_scratch_bytes()), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
         L.check(lib.mf_loss_partials(C.byref(dc), C.byref(df) if df is not None else None, tgt.data_ptr(), N,
-                                     out.data_ptr(), scratch.data_ptr(), L.current_stream(dev)), "mf_loss_partials")
+                                     out.data_ptr(), None, scratch.data_ptr(), L.current_stream(dev)), "mf_loss_partials")
     return out
 
 
@@ -202,11 +202,13 @@ def _pass_stats(p, N):
     d.alphas, d.disp_local, d.disp_global = L.ptr(p["alphas"]), L.ptr(p.get("disp_local")), L.ptr(p.get("disp_global"))
     d.n_samples = p["alphas"].shape[1]
     out = torch.empty(12, dtype=torch.float64, device=dev)
+    means = torch.empty(6, dtype=torch.float32, device=dev)
     scratch = torch.empty(int(lib.mf_loss_partials_scratch_bytes()), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        L.check(lib.mf_loss_partials(C.byref(d), None, None, N, out.data_ptr(), scratch.data_ptr(), L.current_stream(dev)),
-                "mf_loss_partials")
-    return {"local": (out[4], out[5]), "global": (out[8], out[9])}
+        L.check(lib.mf_loss_partials(C.byref(d), None, None, N, out.data_ptr(), means.data_ptr(), scratch.data_ptr(),
+                                     L.current_stream(dev)), "mf_loss_partials")
+    # (sum, count, mean): the mean is a view of the kernel's own fp32 output -- torch.mean(vector) launches nothing
+    return {"local": (out[4], out[5], means[2]), "global": (out[8], out[9], means[4])}
 
 
 def _consensus_vectors(p, N, loc, glob):

@@ -106,7 +106,7 @@ def test_packed_layout_sizes():
     groups = (4 + 3 * 16 + 20 + 3 * 16 + 16) * 8 + (16 + 2) * 4
     assert lib.mf_nerf_packed_bytes_p(ctypes.byref(d), L.MF_PREC_BF16) == 13 * 1024 + groups * 1024
     assert lib.mf_loss_partials_scratch_bytes() == 256 * 12 * 8
-    assert lib.mf_loss_partials(None, None, None, 0, None, None, None) == -1
+    assert lib.mf_loss_partials(None, None, None, 0, None, None, None, None) == -1
 
 
 def test_modules_keep_reference_contract():
