@@ -82,46 +82,118 @@ __global__ void image_compose_kernel(ComposeParams p) {
 struct MaskParams {
   int H, W, n;
   int hx[8], hy[8];            // convex hull vertices (x = column, y = row), any orientation
-  int ymin, ymax;
+  int ymin, ymax, imin;        // rows of the hull; first vertex with the smallest row
+  // the hull's edges as cv2's Line() rasterises them: clipped to the image (clipLine, on the host), traversed left to right
+  int lx1[8], ly1[8], lx2[8], ly2[8], lvalid[8];
   unsigned char* out;
 };
 
-__device__ inline long long floor_div(long long a, long long b) {      // b > 0
-  const long long q = a / b;
-  return (a % b != 0 && a < 0) ? q - 1 : q;
+// Camera.get_valid_rays_mask (utils/camera.py:119-132) = cv2.fillConvexPoly(mask, cv2.convexHull(pts), 255), one thread per
+// pixel, restating OpenCV's algorithm (modules/imgproc/src/drawing.cpp, FillConvexPoly with line_type 8, shift 0) in
+// closed form.  PARITY UNPINNED vs cv2 itself (absent from the image); oracle/cpu_ref.py::valid_rays_mask restates the same
+// algorithm as the sequential loops OpenCV runs, and the two must agree bit for bit.  A pixel is set iff it lies on
+//  (a) the OUTLINE: every hull edge drawn by Line() -- clipLine, then the 8-connected Bresenham walk of LineIterator from
+//      the leftmost endpoint: after k steps along the major axis the minor coordinate has advanced
+//      m_k = floor((2 dmin k + dmaj - 1) / (2 dmaj))   (err starts at dmaj - 2 dmin; a step is diagonal iff err < 0); or
+//  (b) a SPAN: rows ymin .. min(ymax - 1, H - 1) -- the scan-line loop runs out of edges at the hull's last row, which is
+//      covered by the outline only -- between the two edge chains that descend from the top vertex, each stepped in
+//      16.16 fixed point: x(y) = (xa << 16) + dx (y - ya), dx = (((xb - xa) << 17) + (yb - ya)) / (2 (yb - ya)) (C
+//      division, truncating), pixels (x_left + 0.5) >> 16 .. (x_right + 0.5) >> 16.
+// (Round 2's rule -- exact intersections, no outline -- dropped the outline's runs along shallow edges.)
+__device__ inline bool on_cv_line(int x, int y, int x1, int y1, int x2, int y2) {
+  long long dx = (long long)x2 - x1, dy = (long long)y2 - y1;
+  if (dx < 0) { dx = -dx; dy = -dy; const int tx = x1, ty = y1; x1 = x2; y1 = y2; x2 = tx; y2 = ty; }   // leftToRight
+  const int sy = dy < 0 ? -1 : 1;
+  if (dy < 0) dy = -dy;
+  if (dy > dx) {                                 // the walk is along y, x advances by +1 on the diagonal steps
+    const long long k = (long long)(y - y1) * sy;
+    if (k < 0 || k > dy) return false;
+    return x == x1 + (int)((2 * dx * k + dy - 1) / (2 * dy));
+  }
+  const long long k = (long long)x - x1;
+  if (k < 0 || k > dx) return false;
+  if (dx == 0) return y == y1;                   // a single point
+  return y == y1 + sy * (int)((2 * dy * k + dx - 1) / (2 * dx));
 }
 
-// Camera.get_valid_rays_mask (utils/camera.py:119-132): one thread per pixel.  Rule (cv2.fillConvexPoly's scan-line
-// fill, line_type 8, with exact intersections; PARITY UNPINNED vs cv2 itself, see oracle/cpu_ref.py::valid_rays_mask):
-// pixel (x, y) is set iff ymin <= y <= ymax and round_half_up(XL(y)) <= x <= round_half_up(XR(y)), [XL, XR] = the
-// intersection of row y with the closed hull.  Integer arithmetic throughout.
 __global__ void valid_mask_kernel(MaskParams p) {
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (long long)p.H * p.W) return;
   const int y = (int)(idx / p.W), x = (int)(idx - (long long)y * p.W);
   bool in = false;
-  if (y >= p.ymin && y <= p.ymax) {
-    // min / max of the rational intersections num/den (den > 0), compared by cross-multiplication
-    long long ln = 0, ld = 0, rn = 0, rd = 0;
-    auto take = [&](long long num, long long den) {
-      if (ld == 0 || num * ld < ln * den) { ln = num; ld = den; }
-      if (rd == 0 || num * rd > rn * den) { rn = num; rd = den; }
-    };
-    const int n = p.n;
-    for (int e = 0; e < (n > 1 ? n : 1); ++e) {
-      const int ax = p.hx[e], ay = p.hy[e], bx = p.hx[(e + 1) % n], by = p.hy[(e + 1) % n];
-      if ((long long)(y - ay) * (y - by) > 0) continue;
-      if (ay == by) { take(ax, 1); take(bx, 1); continue; }
-      long long den = by - ay, num = (long long)ax * den + (long long)(y - ay) * (bx - ax);
-      if (den < 0) { den = -den; num = -num; }
-      take(num, den);
+  const int n = p.n;
+#pragma unroll
+  for (int e = 0; e < 8; ++e)
+    if (e < (n > 1 ? n : 1) && p.lvalid[e] && on_cv_line(x, y, p.lx1[e], p.ly1[e], p.lx2[e], p.ly2[e])) in = true;
+  const int last = p.ymax - 1 < p.H - 1 ? p.ymax - 1 : p.H - 1;
+  if (!in && n >= 3 && y >= p.ymin && y <= last) {
+    long long xe[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {                // the two chains from vertex imin: +1 and -1 through the hull
+      int i0 = p.imin;
+      long long xf = 0;
+      for (int s = 0; s < n; ++s) {
+        int i1 = c == 0 ? i0 + 1 : i0 - 1;
+        i1 = i1 >= n ? i1 - n : (i1 < 0 ? i1 + n : i1);
+        // (runtime indices into the by-value argument would put a private copy of it in scratch: select instead)
+        int ax = 0, ay = 0, bx = 0, by = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          if (q == i0) { ax = p.hx[q]; ay = p.hy[q]; }
+          if (q == i1) { bx = p.hx[q]; by = p.hy[q]; }
+        }
+        if (by > y) {                            // the edge that is active in row y (horizontal edges are passed over)
+          const long long num = (((long long)(bx - ax)) << 17) + (by - ay);
+          xf = (((long long)ax) << 16) + (num / (2LL * (by - ay))) * (y - ay);
+          break;
+        }
+        i0 = i1;
+      }
+      xe[c] = xf;
     }
-    if (ld != 0) {
-      const long long lo = floor_div(2 * ln + ld, 2 * ld), hi = floor_div(2 * rn + rd, 2 * rd);   // floor(v + 1/2)
-      in = x >= lo && x <= hi;
-    }
+    const long long xl = xe[0] < xe[1] ? xe[0] : xe[1], xr = xe[0] < xe[1] ? xe[1] : xe[0];
+    const long long x1 = (xl + 32768) >> 16, x2 = (xr + 32768) >> 16;
+    in = x2 >= 0 && x1 < p.W && x >= x1 && x <= x2;
   }
   p.out[idx] = in ? 1 : 0;
+}
+
+// cv::clipLine (drawing.cpp) on the image rectangle [0, W-1] x [0, H-1]; false = nothing of the segment is inside
+static bool cv_clip_line(long long W, long long H, long long& x1, long long& y1, long long& x2, long long& y2) {
+  const long long right = W - 1, bottom = H - 1;
+  if (W <= 0 || H <= 0) return false;
+  int c1 = (x1 < 0) + (x1 > right) * 2 + (y1 < 0) * 4 + (y1 > bottom) * 8;
+  int c2 = (x2 < 0) + (x2 > right) * 2 + (y2 < 0) * 4 + (y2 > bottom) * 8;
+  if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+    long long a;
+    if (c1 & 12) {
+      a = c1 < 8 ? 0 : bottom;
+      x1 += (long long)((double)(a - y1) * (x2 - x1) / (y2 - y1));
+      y1 = a;
+      c1 = (x1 < 0) + (x1 > right) * 2;
+    }
+    if (c2 & 12) {
+      a = c2 < 8 ? 0 : bottom;
+      x2 += (long long)((double)(a - y2) * (x2 - x1) / (y2 - y1));
+      y2 = a;
+      c2 = (x2 < 0) + (x2 > right) * 2;
+    }
+    if ((c1 & c2) == 0 && (c1 | c2) != 0) {
+      if (c1) {
+        a = c1 == 1 ? 0 : right;
+        y1 += (long long)((double)(a - x1) * (y2 - y1) / (x2 - x1));
+        x1 = a;
+        c1 = 0;
+      }
+      if (c2) {
+        a = c2 == 1 ? 0 : right;
+        y2 += (long long)((double)(a - x2) * (y2 - y1) / (x2 - x1));
+        x2 = a;
+        c2 = 0;
+      }
+    }
+  }
+  return (c1 | c2) == 0;
 }
 
 struct KnnParams {
@@ -261,8 +333,14 @@ extern "C" int32_t mf_valid_rays_mask(int32_t H, int32_t W, const int32_t* pts_x
   p.ymin = 1; p.ymax = 0;
   for (int i = 0; i < k; ++i) {
     p.hx[i] = (int)hx[i]; p.hy[i] = (int)hy[i];
-    if (i == 0 || p.hy[i] < p.ymin) p.ymin = p.hy[i];
+    if (i == 0 || p.hy[i] < p.ymin) { p.ymin = p.hy[i]; p.imin = i; }
     if (i == 0 || p.hy[i] > p.ymax) p.ymax = p.hy[i];
+  }
+  for (int i = 0; i < (k > 1 ? k : (k == 1 ? 1 : 0)); ++i) {      // edge i: vertex i-1 -> vertex i (FillConvexPoly's Line() calls)
+    const int j = (i + k - 1) % k;
+    long long x1 = hx[j], y1 = hy[j], x2 = hx[i], y2 = hy[i];
+    p.lvalid[i] = cv_clip_line(W, H, x1, y1, x2, y2) ? 1 : 0;
+    p.lx1[i] = (int)x1; p.ly1[i] = (int)y1; p.lx2[i] = (int)x2; p.ly2[i] = (int)y2;
   }
   const long long n = (long long)H * W;
   hipLaunchKernelGGL(valid_mask_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);

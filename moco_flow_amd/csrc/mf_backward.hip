@@ -341,6 +341,12 @@ extern "C" int32_t mf_embedding_backward(const mf_embedding* e, const float* g_e
   p.g_x = g_x;
   const int ncols = p.C * (2 * p.F + 1);
   const size_t lds = (size_t)2 * kEmbBwdSamples * (ncols | 1) * sizeof(float);
+  // wide embeddings (in_channels (2 N_freqs + 1) > 127, e.g. Embedding(4, 16)) need more than the 64 KiB a launch gets by
+  // default: raise the kernel's limit up to the CU's 160 KiB, refuse beyond
+  if (lds > 160 * 1024) return fail(MF_E_UNSUPPORTED, "mf_embedding_backward: %d embedded columns exceed the staged width (312)", ncols);
+  if (lds > 48 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void*>(embed_backward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return fail(MF_E_LAUNCH, "mf_embedding_backward: cannot reserve %zu bytes of LDS", lds);
   hipLaunchKernelGGL(embed_backward_kernel, dim3((unsigned)((P + kEmbBwdSamples - 1) / kEmbBwdSamples)), dim3(256), lds,
                      static_cast<hipStream_t>(stream), p);
   return check_launch("mf_embedding_backward");

@@ -48,6 +48,10 @@ class SMPL(nn.Module):
             self.register_buffer("faces", torch.as_tensor(np.array(m["f"]).astype(np.int64)))
         if "parent" in m:
             parent = [int(p) for p in np.array(m["parent"]).tolist()]
+            if len(parent) == 24:        # some exports keep the root's (meaningless) entry in front: joints 1..23 have parents
+                parent = parent[1:]
+            if len(parent) != 23:
+                raise ValueError(f"SMPL model: 'parent' must list the parents of joints 1..23 (23 entries), got {len(parent)}")
         else:                                                                                # :83-85
             kt = np.array(m["kintree_table"]).astype(np.int64)
             id_to_col = {int(kt[1, i]): i for i in range(kt.shape[1])}

@@ -477,35 +477,138 @@ def convex_hull_int(points):
     return lower[:-1] + upper[:-1]
 
 
+def _cv_clip_line(W, H, x1, y1, x2, y2):
+    """cv::clipLine (OpenCV modules/imgproc/src/drawing.cpp) on [0, W-1] x [0, H-1]; None when nothing is inside."""
+    right, bottom = W - 1, H - 1
+    if W <= 0 or H <= 0:
+        return None
+    code = lambda x, y: (x < 0) + (x > right) * 2 + (y < 0) * 4 + (y > bottom) * 8
+    c1, c2 = code(x1, y1), code(x2, y2)
+    if (c1 & c2) == 0 and (c1 | c2) != 0:
+        if c1 & 12:
+            a = 0 if c1 < 8 else bottom
+            x1 += int(float(a - y1) * (x2 - x1) / (y2 - y1))       # (int64)((double)(a - y1) * (x2 - x1) / (y2 - y1))
+            y1 = a
+            c1 = (x1 < 0) + (x1 > right) * 2
+        if c2 & 12:
+            a = 0 if c2 < 8 else bottom
+            x2 += int(float(a - y2) * (x2 - x1) / (y2 - y1))
+            y2 = a
+            c2 = (x2 < 0) + (x2 > right) * 2
+        if (c1 & c2) == 0 and (c1 | c2) != 0:
+            if c1:
+                a = 0 if c1 == 1 else right
+                y1 += int(float(a - x1) * (y2 - y1) / (x2 - x1))
+                x1 = a
+                c1 = 0
+            if c2:
+                a = 0 if c2 == 1 else right
+                y2 += int(float(a - x2) * (y2 - y1) / (x2 - x1))
+                x2 = a
+                c2 = 0
+    return (x1, y1, x2, y2) if (c1 | c2) == 0 else None
+
+
+def _cv_line(mask, p1, p2):
+    """cv::Line(img, p1, p2, color, 8): clipLine, then LineIterator(connectivity 8, leftToRight = true) -- the
+    error-term walk as OpenCV runs it, one pixel per step."""
+    H, W = mask.shape
+    c = _cv_clip_line(W, H, p1[0], p1[1], p2[0], p2[1])
+    if c is None:
+        return
+    x1, y1, x2, y2 = c
+    dx, dy = x2 - x1, y2 - y1
+    if dx < 0:                       # leftToRight: start from the leftmost endpoint
+        dx, dy, x1, y1 = -dx, -dy, x2, y2
+    step_x, step_y = 1, 1
+    if dy < 0:
+        dy, step_y = -dy, -1
+    vert = dy > dx
+    if vert:
+        dx, dy = dy, dx
+    err, plus_delta, minus_delta = dx - (dy + dy), dx + dx, -(dy + dy)
+    x, y = x1, y1
+    for _ in range(dx + 1):
+        mask[y, x] = True
+        diag = err < 0
+        err += minus_delta + (plus_delta if diag else 0)
+        if vert:
+            y += step_y
+            x += step_x if diag else 0
+        else:
+            x += step_x
+            y += step_y if diag else 0
+
+
 def valid_rays_mask(projected_pixels, H, W):
-    """Camera.get_valid_rays_mask (utils/camera.py:119-132) by brute force with exact rational arithmetic.
-    PARITY UNPINNED vs cv2.fillConvexPoly (cv2 is absent from this image): the rasterisation rule restated here is
-    cv2's scan-line fill for line_type 8 -- for every row y in [ymin, ymax] of the hull the pixels
-    round_half_up(XL(y)) .. round_half_up(XR(y)) are set, [XL, XR] = the row's intersection with the closed hull --
-    evaluated with exact intersections (cv2 steps the edges in 16.16 fixed point, which can move a boundary pixel
-    when an intersection is within 2^-16 of a half)."""
-    from fractions import Fraction
-    import math
+    """Camera.get_valid_rays_mask (utils/camera.py:119-132): cv2.fillConvexPoly(zeros, cv2.convexHull(pts), 255) > 0.
+    PARITY UNPINNED vs cv2 (absent from this image).  This restates OpenCV's FillConvexPoly (modules/imgproc/src/
+    drawing.cpp; line_type 8, shift 0) the way OpenCV runs it -- sequential loops -- where the kernel uses closed forms:
+    first every hull edge is drawn with Line() (clipLine + the 8-connected LineIterator), then the scan-line loop fills
+    hlines between two edge chains stepped in 16.16 fixed point with rounded slopes, and stops when it runs out of edges
+    -- i.e. BEFORE the hull's last row, which only the outline covers."""
     hull = convex_hull_int(projected_pixels)
     mask = np.zeros((H, W), dtype=bool)
-    if not hull:
-        return mask.reshape(-1)
-    ys = [q[1] for q in hull]
     n = len(hull)
-    edges = [(hull[i], hull[(i + 1) % n]) for i in range(n)] if n > 1 else [(hull[0], hull[0])]
-    for y in range(max(min(ys), 0), min(max(ys), H - 1) + 1):
-        xs = []
-        for (ax, ay), (bx, by) in edges:
-            if (y - ay) * (y - by) > 0:
-                continue
-            if ay == by:
-                xs += [Fraction(ax), Fraction(bx)]
-            else:
-                xs.append(Fraction(ax) + Fraction((y - ay) * (bx - ax), by - ay))
-        lo = math.floor(min(xs) + Fraction(1, 2))
-        hi = math.floor(max(xs) + Fraction(1, 2))
-        for x in range(max(lo, 0), min(hi, W - 1) + 1):
-            mask[y, x] = True
+    if n == 0:
+        return mask.reshape(-1)
+    XY_SHIFT, XY_ONE = 16, 1 << 16
+    v = [(int(x), int(y)) for x, y in hull]
+    ymin, ymax, imin = v[0][1], v[0][1], 0
+    p0 = v[n - 1]
+    for i, p in enumerate(v):
+        if p[1] < ymin:
+            ymin, imin = p[1], i
+        ymax = max(ymax, p[1])
+        _cv_line(mask, p0, p)
+        p0 = p
+    xs_all = [q[0] for q in v]
+    if n < 3 or max(xs_all) < 0 or ymax < 0 or min(xs_all) >= W or ymin >= H:
+        return mask.reshape(-1)
+    ymax = min(ymax, H - 1)
+    edge = [dict(idx=imin, ye=ymin, di=1, x=-XY_ONE, dx=0), dict(idx=imin, ye=ymin, di=n - 1, x=-XY_ONE, dx=0)]
+    edges, y = n, ymin
+
+    def trunc_div(a, b):             # C integer division (truncates toward zero)
+        q = abs(a) // abs(b)
+        return q if (a < 0) == (b < 0) else -q
+
+    while True:
+        for e in edge:
+            if y >= e["ye"]:
+                idx0, di = e["idx"], e["di"]
+                idx = idx0 + di
+                if idx >= n:
+                    idx -= n
+                while True:
+                    edges -= 1
+                    if edges < 0:
+                        break
+                    ty = v[idx][1]
+                    if ty > y:
+                        xs, xe = v[idx0][0] << XY_SHIFT, v[idx][0] << XY_SHIFT
+                        e["ye"] = ty
+                        e["dx"] = trunc_div((xe - xs) * 2 + (ty - y), 2 * (ty - y))
+                        e["x"] = xs
+                        e["idx"] = idx
+                        break
+                    idx0 = idx
+                    idx += di
+                    if idx >= n:
+                        idx -= n
+        if edges < 0:
+            break
+        if y >= 0:
+            left, right = (0, 1) if edge[0]["x"] <= edge[1]["x"] else (1, 0)
+            xx1 = (edge[left]["x"] + (XY_ONE >> 1)) >> XY_SHIFT
+            xx2 = (edge[right]["x"] + (XY_ONE >> 1)) >> XY_SHIFT
+            if xx2 >= 0 and xx1 < W:
+                mask[y, max(xx1, 0):min(xx2, W - 1) + 1] = True
+        edge[0]["x"] += edge[0]["dx"]
+        edge[1]["x"] += edge[1]["dx"]
+        y += 1
+        if y > ymax:
+            break
     return mask.reshape(-1)
 
 

@@ -127,13 +127,14 @@ def test_camera_vectors():
 def test_valid_rays_mask_oracle():
     """Camera.get_valid_rays_mask (utils/camera.py:119-132).  The projection (calculate_2d_projections, :83-103) is
     pinned to the reference's own output; the hull + fill half is cv2 (absent): PARITY UNPINNED, the oracle restates
-    cv2.fillConvexPoly's scan-line rule with exact intersections -- checked here on hand-countable polygons."""
+    OpenCV's FillConvexPoly -- outline by Line() (clipLine + 8-connected LineIterator), then 16.16 fixed-point scan-line
+    spans up to, not including, the hull's last row -- checked here on hand-countable polygons."""
     g = load_golden("u_camera")
     pix = R.project_aabb(g["in_aabb_verts"], g["in_c2w"], g["in_K"])
     assert pix.dtype == np.int32 and np.array_equal(pix, g["out_projected_pixels"])
     H, W = [int(v) for v in g["in_HW"]]
     m = R.valid_rays_mask(pix, H, W).reshape(H, W)
-    assert m.sum() == 115 and m[0, 34] and not m[0, 33] and m[:, -1].all()
+    assert m.sum() == 120 and m[0, 34] and not m[0, 33] and m[:, -1].all()      # (115 without the clipped outline, round 2)
     # axis-aligned rectangle: closed on all four sides
     sq = R.valid_rays_mask(np.array([[2, 1], [5, 1], [5, 3], [2, 3], [3, 2]]), 6, 8).reshape(6, 8)
     assert sq.sum() == 12 and sq[1:4, 2:6].all()
@@ -143,6 +144,10 @@ def test_valid_rays_mask_oracle():
     # slanted edge with half-pixel intersections: (0,0) (3,0) (0,2): row 1 ends at x = 1.5 -> rounds up to 2
     t2 = R.valid_rays_mask(np.array([[0, 0], [3, 0], [0, 2]]), 3, 4).reshape(3, 4)
     assert [int(r.sum()) for r in t2] == [4, 3, 1]
+    # shallow top edge (0,0)-(9,1): the scan-line span of row 0 is the single pixel x = 0, the OUTLINE's Bresenham run adds
+    # x = 1 .. 4 (m_k = (2k + 8) // 18 turns 1 at k = 5); the last row is the outline of the bottom edge alone
+    sh = R.valid_rays_mask(np.array([[0, 0], [9, 1], [9, 3], [0, 3]]), 4, 10).reshape(4, 10)
+    assert [int(r.sum()) for r in sh] == [5, 10, 10, 10] and sh[0, :5].all() and not sh[0, 5:].any()
     # degenerate inputs: a single point, a segment, everything off-screen
     assert R.valid_rays_mask(np.array([[1, 1]] * 8), 3, 3).sum() == 1
     assert R.valid_rays_mask(np.array([[0, 0], [3, 3]]), 4, 4).reshape(4, 4).diagonal().all()
