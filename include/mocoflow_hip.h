@@ -79,8 +79,8 @@ enum { MF_EXTRA_NONE = 0, MF_EXTRA_IND = 1, MF_EXTRA_DIR = 2 };
 
 typedef struct mf_nerf_desc {
   int32_t D;                       /* trunk layers, 2..MF_MAX_LAYERS-1       */
-  int32_t W;                       /* hidden width: 256 (or 128)             */
-  int32_t in_channels_xyz;         /* 63 (= 3*(2*10+1)) or 33               */
+  int32_t W;                       /* hidden width: 256 (bf16 modes, backward); the fp32 forward also takes 128 */
+  int32_t in_channels_xyz;         /* 63 (= 3*(2*10+1)); narrower embeddings are zero-padded to it by the caller */
   uint32_t skip_mask;              /* bit i set <=> i in skips (nerf.py:84-86) */
   int32_t extra_feat_type;         /* MF_EXTRA_*                             */
   int32_t extra_feat_dim;          /* columns of extra_encoding beyond W     */

@@ -3,9 +3,9 @@
 Drop-in surface (same names / signatures as the reference's ``models`` package):
     Embedding, NeRF, NoF, get_model, get_loss, render_rays, sample_pdf
 Every forward value comes from hand-written HIP kernels reached through the C ABI in include/mocoflow_hip.h
-(libmocoflow_hip.so); CPU tensors and a missing library raise.  Backward: HIP for fp32 render_rays passes and the
-NoF module call; a recompute with PyTorch-ROCm device ops for bf16 passes, the sigma-only coarse pass of test_time
-and module-level NeRF / Embedding calls under grad (rendering.py header).
+(libmocoflow_hip.so); CPU tensors and a missing library raise.  The backward is HIP as well -- of render_rays passes
+(which record gradients in fp32 whatever set_precision says) and of module-level NeRF / NoF / Embedding calls; shapes it
+is not built for raise NotImplementedError under grad.  There is no eager fallback (autograd.py).
 """
 from .embedding import Embedding
 from .factory import get_loss, get_model
