@@ -296,14 +296,47 @@ def kernel_probe(M, rendering, torch, cfg, models, rays, bg, kw, iters=20):
         ws = [None]
         for _ in range(3):
             rendering._render_pass(*args, workspace=ws)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
-        for s, e in ev:
-            s.record()
-            rendering._render_pass(*args, workspace=ws)
-            e.record()
-        torch.cuda.synchronize()
-    ms = sorted(s.elapsed_time(e) for s, e in ev)
-    return float(ms[len(ms) // 2]), n * S          # median
+        # Preferred: R launches captured in ONE HIP graph and replayed -- the launches then follow each other on the device
+        # without waiting for the host, so a loaded host (slow Python between two launches) cannot leak into the kernel's
+        # duration; (events around the replay) / R = the kernel + the device-side launch gap.  Fallback: events around single
+        # eager launches (valid as long as the host keeps the queue full).
+        ms, how = None, "hip events around each eager launch (median of %d)" % iters
+        try:
+            R = 10
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                rendering._render_pass(*args, workspace=ws)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for _ in range(R):
+                    rendering._render_pass(*args, workspace=ws)
+            g.replay()
+            torch.cuda.synchronize()
+            spans = []
+            for _ in range(max(3, iters // R + 1)):
+                s0, e0 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s0.record()
+                g.replay()
+                e0.record()
+                torch.cuda.synchronize()
+                spans.append(s0.elapsed_time(e0) / R)
+            ms = float(sorted(spans)[len(spans) // 2])
+            how = f"hip events around a HIP-graph replay of {R} back-to-back launches, / {R} (median of {len(spans)} replays)"
+            del g
+        except Exception as exc:  # noqa: BLE001  (graph capture unavailable: time eager launches)
+            how += f" [graph probe unavailable: {type(exc).__name__}]"
+        if ms is None:
+            ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(iters)]
+            for s, e in ev:
+                s.record()
+                rendering._render_pass(*args, workspace=ws)
+                e.record()
+            torch.cuda.synchronize()
+            t = sorted(s.elapsed_time(e) for s, e in ev)
+            ms = float(t[len(t) // 2])
+    return ms, n * S, how
 
 
 def run_config(name, a, ctx, steps, warmup, main):
@@ -369,7 +402,7 @@ def run_config(name, a, ctx, steps, warmup, main):
     value = n * spr * world * steps / elapsed
     flops_step = n * spr * flops_per_sample(cfg)
     step_span_ms = kernel_ms
-    kernel_ms, launch_samples = kernel_probe(M, rendering, torch, cfg, models, rays, bg, kw)
+    kernel_ms, launch_samples, probe_how = kernel_probe(M, rendering, torch, cfg, models, rays, bg, kw)
     flops_launch = launch_samples * flops_per_sample(cfg)
     achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
     peak = PEAK[cfg["precision"]]
@@ -387,7 +420,7 @@ def run_config(name, a, ctx, steps, warmup, main):
                                      "rays / requested (N,S) planes" + (" + the per-ray NoF bias table" if cfg["nof"] and cfg["precision"] != "f32" else "")
                                      + "; algorithmic I/O is 68 B/ray (+ 8 B/sample per requested plane): MFMA-bound, not HBM-bound",
                      "kernel": "mf_render_pass" + (" (fine pass)" if cfg["M"] else ""),
-                     "kernel_ms": kernel_ms, "flops_per_launch": flops_launch, "samples_per_launch": launch_samples,
+                     "kernel_ms": kernel_ms, "kernel_ms_how": probe_how, "flops_per_launch": flops_launch, "samples_per_launch": launch_samples,
                      "step_span_ms": step_span_ms, "launches_per_step": 2 if cfg["M"] else 1,
                      "flops_per_step": flops_step},
     }

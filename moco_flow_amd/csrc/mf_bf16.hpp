@@ -698,7 +698,7 @@ MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&
 #pragma unroll
     for (int i = 0; i < 4; ++i) { T[i] = id.h ? oth[i] : own[i]; T[4 + i] = id.h ? own[i] : oth[i]; }
     T[8] = id.h ? oth[4] : own[4];
-    quat_transform(T, xyz, out);
+    quat_transform<true>(T, xyz, out);
   } else {
 #pragma unroll
     for (int c = 0; c < 3; ++c) out[c] = (id.h ? oth[c] : own[c]) + xyz[c];

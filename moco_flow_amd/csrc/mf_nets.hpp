@@ -133,15 +133,30 @@ MF_D void nerf_eval(const NetDev& net, const float (&embx)[kStepsNerfXyz], const
 // kornia 0.6.5 quaternion_log_to_exp + quaternion_to_rotation_matrix as restated in
 // oracle/kornia_restated.py (PARITY UNPINNED), then nof.py:80:
 //   out = (xyz - s) R + s + t      ((xyz - s) as a ROW vector)
+// FAST (the bf16 fast mode only): the same formulas on the hardware's approximate units -- v_sqrt_f32 / v_rcp_f32 (1 ulp) and
+// v_sin_f32 / v_cos_f32 on the angle in revolutions (abs error ~1e-6: the angle is the norm of a head output, well
+// under a revolution) instead of OCML's exact sincosf (~110 instructions), sqrtf and seven IEEE divisions; the point
+// moves by ~1e-6 relative, under what the bf16 operands around it cost.  ~2 % of a C3 tile, ~4 % of C3g's.
+template <bool FAST = false>
 MF_D void quat_transform(const float (&T)[9], const float (&xyz)[3], float (&out)[3]) {
   const float vx = T[0], vy = T[1], vz = T[2];
-  float n = sqrtf(vx * vx + vy * vy + vz * vz);
-  n = fmaxf(n, 1e-8f);
-  float sn, cn;
-  sincosf(n, &sn, &cn);
-  float qx = vx * sn / n, qy = vy * sn / n, qz = vz * sn / n, qw = cn;
-  const float qn = fmaxf(sqrtf(qx * qx + qy * qy + qz * qz + qw * qw), 1e-12f);
-  qx /= qn; qy /= qn; qz /= qn; qw /= qn;
+  float qx, qy, qz, qw;
+  if constexpr (FAST) {
+    const float n = fmaxf(__builtin_amdgcn_sqrtf(vx * vx + vy * vy + vz * vz), 1e-8f);
+    const float rev = n * 0.15915494309189535f;
+    const float s_n = __builtin_amdgcn_sinf(rev) * __builtin_amdgcn_rcpf(n);
+    qx = vx * s_n; qy = vy * s_n; qz = vz * s_n; qw = __builtin_amdgcn_cosf(rev);
+    const float rq = __builtin_amdgcn_rcpf(fmaxf(__builtin_amdgcn_sqrtf(qx * qx + qy * qy + qz * qz + qw * qw), 1e-12f));
+    qx *= rq; qy *= rq; qz *= rq; qw *= rq;
+  } else {
+    float n = sqrtf(vx * vx + vy * vy + vz * vz);
+    n = fmaxf(n, 1e-8f);
+    float sn, cn;
+    sincosf(n, &sn, &cn);
+    qx = vx * sn / n; qy = vy * sn / n; qz = vz * sn / n; qw = cn;
+    const float qn = fmaxf(sqrtf(qx * qx + qy * qy + qz * qz + qw * qw), 1e-12f);
+    qx /= qn; qy /= qn; qz /= qn; qw /= qn;
+  }
   const float tx = 2.f * qx, ty = 2.f * qy, tz = 2.f * qz;
   const float twx = tx * qw, twy = ty * qw, twz = tz * qw;
   const float txx = tx * qx, txy = ty * qx, txz = tz * qx;

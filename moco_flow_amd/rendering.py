@@ -2,10 +2,12 @@
 ``sample_pdf`` (:5-46) with the reference's signatures, running on the HIP path.
 
 Each pass (coarse, fine) is ONE fused kernel launch (mf_render_pass): ray -> depths ->
-points -> [NoF chains] -> encoding -> NeRF -> composite. The hierarchical resample is one
-launch (mf_sample_pdf_merge) and the consensus-mask compaction three tiny ones
-(mf_compact_mask). Random draws (perturb / noise / stochastic resampling) are made here
-with torch, in the reference's order, and handed to the kernels, which stay deterministic.
+points -> [NoF chains] -> encoding -> NeRF -> composite (bf16 modes with NoF: + one small
+launch per render_rays call for the per-ray index bias, mf_render_prepare). The hierarchical
+resample is one launch (mf_sample_pdf), the consensus vectors are lazy (lazy.MaskedVector: their
+means come from the two launches of mf_loss_partials; the compaction, mf_compact_mask, runs only
+when a vector's length is asked for). Random draws (perturb / noise / stochastic resampling) are made
+here with torch, in the reference's order, and handed to the kernels, which stay deterministic.
 """
 from __future__ import annotations
 
@@ -51,6 +53,18 @@ LAZY_CONSENSUS = True
 # Draw torch.randn(N,S) in every pass even when noise_std == 0, as the reference does
 # (rendering.py:166), so that the device RNG stream advances identically.
 STRICT_RNG = True
+
+
+_LINSPACE = {}
+
+
+def _linspace01(S, dev):
+    """torch.linspace(0, 1, S) on the device, built once per (S, device): a launch per render_rays call otherwise."""
+    key = (S, str(dev))
+    t = _LINSPACE.get(key)
+    if t is None:
+        t = _LINSPACE[key] = torch.linspace(0, 1, S, device=dev)
+    return t
 
 
 def _emb_desc(e):
@@ -239,7 +253,7 @@ def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
         raise RuntimeError(f"sample_pdf: weights must be (N, {nb - 1}), got {tuple(weights.shape)}")
     M = N_importance
     if det:
-        u, u_stride = torch.linspace(0, 1, M, device=dev), 0
+        u, u_stride = _linspace01(M, dev), 0
     else:
         u, u_stride = torch.rand(N, M, device=dev), M
     b = bins.detach().contiguous().float()
@@ -260,7 +274,7 @@ def resample_merge(z_vals, weights, N_importance, det=True, u=None, return_aux=F
     M = N_importance
     if u is None:
         if det:
-            u = torch.linspace(0, 1, M, device=dev)
+            u = _linspace01(M, dev)
             u_stride = 0
         else:
             u = torch.rand(N, M, device=dev)
@@ -344,7 +358,7 @@ def render_rays(rays,
     glob = bool(use_nof and chain_global and not test_time)
     need_fine = N_importance > 0
 
-    z_steps = torch.linspace(0, 1, S, device=dev)                     # rendering.py:245
+    z_steps = _linspace01(S, dev)                                     # rendering.py:245
     z_vals = None
     if perturb > 0 or need_fine or grad:
         # rendering.py:245-251 and, with perturb > 0, the stratified jitter of :253-260: one launch (mf_z_vals), the
