@@ -53,9 +53,14 @@ CONFIGS = {
                 what="C3 chain in fp32 (bw NoF -> NeRF(ind) -> fw NoF, exact-fp32 MFMA; a kernel-tuning leg, not a BASELINE config)"),
     "C3": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="local",
                what="C3: bw NoF -> NeRF(ind) -> fw NoF local consensus chain, bf16 hidden GEMMs"),
+    "C2x": dict(net="dir", precision="bf16x3", rays=4096, S=64, M=0, nof=None,
+                what="C2 in the accuracy mode of the bf16 pipe (bf16x3: every matrix product as three bf16 products of (hi, lo) "
+                     "operand pairs, fp32 accumulation and heads)"),
     "C3x": dict(net="ind", precision="bf16x3", rays=4096, S=64, M=0, nof="local",
-                what="C3 in the accuracy mode of the bf16 pipe (bf16x3: NoF hidden GEMMs + head as three-product splits, NeRF "
-                     "encodings split, last trunk layer with split weights, fp32 sigma head)"),
+                what="C3 in the accuracy mode of the bf16 pipe (bf16x3: every matrix product of both networks as three bf16 "
+                     "products of (hi, lo) operand pairs, fp32 accumulation, heads and per-ray image-index bias)"),
+    "C5x": dict(net="ind", precision="bf16x3", rays=1024, S=64, M=128, nof="global", loss=True,
+                what="C5 in the accuracy mode of the bf16 pipe (bf16x3)"),
     "C3g": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="global",
                 what="C3 + global chain (5 NoF evaluations per sample), bf16 hidden GEMMs"),
     "C4": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="local", loss=True,

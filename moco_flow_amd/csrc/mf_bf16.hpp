@@ -52,8 +52,12 @@ struct Lane {
 MF_D u32x4 lds_u4(uint32_t byte_off) { return *(const u32x4*)(smem + byte_off); }
 
 // Weight-panel stream (see mf_core.hpp Stream): 3-slot LDS ring fed by LDS-DMA, two panels ahead of the MFMAs,
-// one workgroup barrier per panel.
-struct Stream {
+// one workgroup barrier per panel.  NW = waves of the workgroup (8: the fast mode, two per SIMD; 4: MF_PREC_BF16X3, one
+// per SIMD with the whole register file).
+template <int NW>
+struct StreamT {
+  static constexpr int kNW = NW;
+  static constexpr int kPieces = 32 / NW;      // 1 KiB pieces per wave of the largest panel (32 groups)
   Timeline tl;
   const char* gnext;      // global address of the panel two ahead of the one being computed
   uint32_t off0, off1, off2;   // LDS byte offsets of the slots holding the current panel, the next one, the one after
@@ -61,8 +65,8 @@ struct Stream {
 
   MF_D uint32_t slot_off(uint32_t k) const { return k == 0 ? off0 : (k == 1 ? off1 : off2); }
   // The panel hook, in two parts.  sync(): barrier of the panel, then the DMA source / destination of the panel two
-  // ahead are latched.  piece(k): this wave's k-th 1 KiB piece of that panel (k = 0..3: a panel is at most 32 groups
-  // over 8 waves); the pieces are issued one per MFMA gap behind the barrier instead of as a burst.
+  // ahead are latched.  piece(k): this wave's k-th 1 KiB piece of that panel (k = 0..kPieces-1: a panel is at most 32
+  // groups); the pieces are issued one per MFMA gap behind the barrier instead of as a burst.
   const char* dsrc; uint32_t ddst; uint32_t pmask;
   MF_D void sync(int groups, const char* jump, const Lane& id) {
     // (MF_BF_ABL_*: timing-ablation builds only, tools/ab_lib.sh; results are garbage there)
@@ -75,15 +79,27 @@ struct Stream {
 #endif
     asm volatile("" ::: "memory");
     if (jump) gnext = jump;
-    dsrc = gnext + id.wave * kGroupBytes;    // this wave's first piece
-    ddst = off2 + id.wave * kGroupBytes;
-    const int mine = (groups - id.wave + kWaves - 1) / kWaves;      // pieces of this wave: groups wave, wave + 8, ...
+    // this wave's pieces: a BLOCK of consecutive groups (wave w: groups w per .. w per + per - 1), so that they share one
+    // base / M0 and differ in the instruction offset only
+    const int per = (groups + NW - 1) / NW;
+    const int first = id.wave * per;
+    dsrc = gnext + first * kGroupBytes;
+    ddst = off2 + first * kGroupBytes;
+    const int mine = groups - first < per ? groups - first : per;
     pmask = (1u << (mine < 0 ? 0 : mine)) - 1u;
     gnext += (size_t)groups * kGroupBytes;
   }
   MF_D void piece(int k, const Lane& id) {
 #ifndef MF_BF_ABL_NODMA
-    if ((pmask >> k) & 1u) blds16(dsrc, id.lane * 16, k * (kWaves * kGroupBytes), ddst + k * (kWaves * kGroupBytes));
+    if ((pmask >> k) & 1u) {
+      const uint32_t hi = (uint32_t)(k >> 2) * (4 * kGroupBytes);
+      switch (k & 3) {
+        case 0: blds16_imm<0>(dsrc, id.lane * 16, hi, ddst + hi); break;
+        case 1: blds16_imm<1024>(dsrc, id.lane * 16, hi, ddst + hi); break;
+        case 2: blds16_imm<2048>(dsrc, id.lane * 16, hi, ddst + hi); break;
+        default: blds16_imm<3072>(dsrc, id.lane * 16, hi, ddst + hi); break;
+      }
+    }
 #endif
   }
   MF_D void advance() {
@@ -92,7 +108,7 @@ struct Stream {
   }
   MF_D void start(const char* first, int groups, uint32_t ring, uint32_t buf_bytes, const Lane& id) {
     off0 = ring; off1 = ring + buf_bytes; off2 = ring + 2 * buf_bytes;
-    for (int grp = id.wave; grp < groups; grp += kWaves) {
+    for (int grp = id.wave; grp < groups; grp += NW) {
       blds16(first, id.lane * 16, grp * kGroupBytes, off0 + grp * kGroupBytes);
       blds16(first, id.lane * 16, (groups + grp) * kGroupBytes, off1 + grp * kGroupBytes);
     }
@@ -101,6 +117,8 @@ struct Stream {
     __syncthreads();
   }
 };
+using Stream = StreamT<kWaves>;
+using Stream4 = StreamT<4>;
 
 // Uniform per-network state of the bf16 kernels: SIX scalars.  (The fp32 kernels hand a whole NetLayout -- ~25 derived
 // offsets per network -- through SGPRs; with three networks that alone overflowed the scalar file here and every
@@ -116,11 +134,10 @@ struct Net {
   uint32_t emb_mask;       // trunk layers that consume the embedded input (layer 0 + skips)
   int aux;                 // NeRF: k-steps of the extra block (0, 1, 2); NoF: head rows (3 | 9)
 };
-// HS (MF_PREC_BF16X3): which layers' HIDDEN k-steps are (hi, lo) group pairs -- 0: none, 1: every layer (the NoF),
-// 2: the last trunk layer, n.D - 1 (the NeRF: the layer under the sigma head)
+// HS (MF_PREC_BF16X3): the layers' HIDDEN k-steps are (hi, lo) group pairs -- 0: none, 1: every layer
 template <int KH, int EKS, bool SPLIT, int HS = 0>
 MF_D int tgroups(const Net& n, int layer) {
-  const bool hs = HS == 1 || (HS == 2 && layer == n.D - 1);
+  const bool hs = HS == 1;
   return (((n.emb_mask >> layer) & 1) ? (SPLIT ? 2 : 1) * EKS : 0) + (layer > 0 ? (hs ? 2 : 1) * KH : 0);
 }
 
@@ -140,13 +157,20 @@ MF_D Next next_trunk_bf(const Net& n, int layer) {
   return Next{tgroups<KH, EKS, SPLIT, HS>(n, layer), nullptr, tgroups<KH, EKS, SPLIT, HS>(n, layer), nullptr};
 }
 
-struct Carry {            // the first PD fragments of the panel that follows, pre-read during the current one's tail
-  u32x4 w[PD];
+template <int N>
+struct CarryT {           // the first N fragments of the panel that follows, pre-read during the current one's tail
+  static constexpr int kPD = N;
+  u32x4 w[N];
   MF_D void load(uint32_t panel_lane_off) {
 #pragma unroll
-    for (int i = 0; i < PD; ++i) w[i] = lds_u4(panel_lane_off + i * kGroupBytes);
+    for (int i = 0; i < N; ++i) w[i] = lds_u4(panel_lane_off + i * kGroupBytes);
   }
 };
+using Carry = CarryT<PD>;
+#ifndef MF_BF_PDX
+#define MF_BF_PDX 3                  // the same distance in the MF_PREC_BF16X3 kernels (one wave per SIMD)
+#endif
+using CarryX = CarryT<MF_BF_PDX>;
 
 MF_D float bflo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 MF_D float bfhi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
@@ -586,15 +610,16 @@ MF_D void pack_operands(const float* emb, int n_slots, u32x4 (&x)[KS]) {
 }
 
 // ------------------------------------------------------------------ the two networks
-template <int KH, int EKS, bool SPLIT>
-MF_D void start_program(const Net& n, Stream& st, Carry& carry, uint32_t ring, uint32_t buf_bytes, const Lane& id) {
+template <int KH, int EKS, bool SPLIT, class ST, class CR>
+MF_D void start_program(const Net& n, ST& st, CR& carry, uint32_t ring, uint32_t buf_bytes, const Lane& id) {
   st.start(n.packed + n.res_bytes, (SPLIT ? 2 : 1) * EKS, ring, buf_bytes, id);
   carry.load(st.slot_off(0) + id.lane * 16);
 }
 
+template <int NW = kWaves>
 MF_D void load_resident(const Net& n, const Lane& id) {
   const int groups = (int)(n.res_bytes / kGroupBytes);
-  for (int g = id.wave; g < groups; g += kWaves) blds16(n.packed, id.lane * 16, g * kGroupBytes, n.res_lds + g * kGroupBytes);
+  for (int g = id.wave; g < groups; g += NW) blds16(n.packed, id.lane * 16, g * kGroupBytes, n.res_lds + g * kGroupBytes);
 }
 
 // extra_encoding (nerf.py:98): W/2 outputs from [final (W) ; extra block], ReLU.  NGX = extra k-steps (0, 1, 2).
@@ -714,126 +739,219 @@ MF_D void nof_embed(u32x4 (&xhi)[kKsNofXyz], u32x4 (&xlo)[kKsNofXyz], const floa
 
 
 // ================================================================== MF_PREC_BF16X3 (the accuracy mode of the bf16 pipe)
-// The MoCo chain feeds the canonical point into sin(512 x): what the fast mode's plain bf16 hidden GEMMs of the NoF cost
-// there is 6-15 dB (tools/bf16_emulate.py: with the NoF evaluated like this the chain is as accurate as the NeRF alone).
-//   NoF   hidden layers and head: activations AND weights as (hi, lo) pairs, three products per k-step
-//         (Whi ahi + Whi alo + Wlo ahi: 16 mantissa bits), like its embedded input; the image index stays the fp32
-//         per-ray bias;
-//   NeRF  encodings split like the NoF's (layer 0, the skip layer, extra_encoding); the LAST trunk layer with split
-//         WEIGHTS (two products: a weight rounding is the same error in every sample of a ray, an activation rounding
-//         averages out along it -- measured, the activation half buys nothing here) and the sigma head as fp32 dot
-//         product on that layer's fp32 accumulators, inside its epilogue ("keep the sigma head and
-//         its input layer" out of bf16).
-// One output tile with split operands.  Embedded block in front (NGE k-steps, always split), then KHID hidden k-steps:
-// HMODE 0 plain, 1 weights split (groups hi, lo; one MFMA each), 2 weights and activations split (hi: two MFMAs, lo:
-// one).  ReLU always.  OUT2: also the lo halves of the outputs.  SIG: sig += sigma_w[rows] . relu(acc) (fp32).
-template <int NGE, int KHID, int HMODE, bool OUT2, bool SIG, class Hook, class Piece>
-MF_D void out_tile_x(Carry& carry, const u32x4* hid, const u32x4* hidlo, const u32x4* xhi, const u32x4* xlo, uint32_t p,
-                     uint32_t pn, uint32_t bias_off, int h, Hook&& hook, Piece&& piece, u32x4& out0, u32x4& out1, u32x4& lo0,
-                     u32x4& lo1, uint32_t sigw_off, float& sig) {
+// EVERY matrix product of both networks as a two-term bf16 split of activations AND weights, x = hi + lo, three products
+// hi*hi + hi*lo + lo*hi with fp32 accumulation (16 mantissa bits per operand: the dropped lo*lo term is 2^-16 relative),
+// the sigma / rgb heads as fp32 dot products on the fp32 accumulators inside the epilogue of the layer in front of them,
+// the NoF's image index as the exact fp32 per-ray bias.  tools/bf16_emulate.py ("x3full"): 98-108 dB and l2 <= 4e-5
+// against the fp32 oracle through the MoCo chains where the fast mode gives 38-51 dB -- fp32-class results at three
+// bf16 matrix instructions per fp32 one (the fp32 pipe costs sixteen).  Splitting only parts does not get there: the NoF
+// alone 47-60 dB, + the NeRF's trunk 63-72 dB (round 3's first bf16x3 was the former).
+//
+// Registers: the (hi, lo) activations of a 256-wide layer are 128 registers per lane, its output as many: more than the
+// 256 of a wave at two waves per SIMD.  The x3 kernels therefore run ONE wave per SIMD (workgroup = 4 waves = 128
+// samples per pass over the weight stream) with the whole file: 256 VGPRs + 256 AGPRs, hipcc parks the finished output
+// tiles in AGPRs (one v_accvgpr_write / _read per register and layer).
+// LDS: a tile's groups stream as one panel up to 32 groups and as two half panels beyond (panel_cap, mf_core.hpp: the
+// skip layer has 40, extra_encoding 36), so the ring's three slots stay 32 KiB.
+//
+// One output tile.  Embedded block (NGE k-steps, always split) in front of (EMB_FIRST) or behind the KHID hidden k-steps;
+// HMODE 0: hidden plain (one group, one MFMA per k-step), 2: hidden split (groups hi, lo; hi: two MFMAs, lo: one).
+// OUTS: 0 no operand output, 1 hi, 2 (hi, lo).  NHEAD: head[o] += w_o[rows of this tile] . act(acc) in fp32, rows
+// HSTRIDE bytes apart.  `two` = the panels two ahead of this tile's first / second panel.
+constexpr int PDX = MF_BF_PDX;
+
+struct Ahead { int g0; const char* j0; int g1; const char* j1; };
+
+MF_D f32x2 lds_f2(uint32_t byte_off) { return *(const f32x2*)(smem + byte_off); }
+
+// Epilogue of one tile in 16 steps of ~5 instructions (a wave alone on its SIMD hides about five issues behind each
+// MFMA, MI355X_MICROARCH.md): step 2u (u = 0..7) turns accumulator pair u into the hi dword (+ its share of the head dot
+// products), step 2u + 1 into the lo dword.  Pair u < 4: registers 2u, 2u+1 -> out0[u]; u >= 4: registers 8 + 2(u-4), +1
+// -> out1[u-4]  (C/D order: register 4q + i = row 8q + 4h + i of the tile).
+template <bool RELU, int OUTS, int NHEAD, int HSTRIDE>
+MF_D void epi_step(const f32x16& acc, int step, int h, u32x4& out0, u32x4& out1, u32x4& lo0, u32x4& lo1, uint32_t headw_off,
+                   float (&head)[NHEAD ? NHEAD : 1]) {
+  const int u = step >> 1, w = u & 3, r = u < 4 ? 2 * u : 8 + 2 * (u - 4);
+#ifdef MF_BF_ABL_NOEPI                                        // (timing ablation, tools/ab_lib.sh: results are garbage)
+  if (OUTS > 0 && !(step & 1)) { if (u < 4) out0[w] = __builtin_bit_cast(unsigned, acc[r]); else out1[w] = __builtin_bit_cast(unsigned, acc[r]); }
+  if (OUTS == 2 && (step & 1)) { if (u < 4) lo0[w] = __builtin_bit_cast(unsigned, acc[r + 1]); else lo1[w] = __builtin_bit_cast(unsigned, acc[r + 1]); }
+  if (NHEAD > 0 && step == 0) for (int o = 0; o < NHEAD; ++o) head[o] += acc[o];
+  return;
+#endif
+  // ReLU as a signed-integer max: every negative float (and -0) is a negative int32 -- one v_max_i32 where fmaxf's IEEE
+  // canonicalisation costs two v_max_f32
+  auto relu = [](float x) { const int b = __builtin_bit_cast(int, x); return __builtin_bit_cast(float, b > 0 ? b : 0); };
+  const float v0 = RELU ? relu(acc[r]) : acc[r], v1 = RELU ? relu(acc[r + 1]) : acc[r + 1];
+  u32x4& hv = u < 4 ? out0 : out1;
+  if (!(step & 1)) {
+    if constexpr (NHEAD > 0) {                               // rows 8q + 4h + i: q = r / 4, i = r % 4
+      const uint32_t so = headw_off + 16 * h + 32 * (r >> 2) + 4 * (r & 3);
+#pragma unroll
+      for (int o = 0; o < NHEAD; ++o) {
+        const f32x2 wv = lds_f2(so + o * HSTRIDE);
+        head[o] = __builtin_fmaf(wv[1], v1, __builtin_fmaf(wv[0], v0, head[o]));
+        asm volatile("" : "+v"(head[o]));
+      }
+    }
+    if constexpr (OUTS > 0) {
+      unsigned hi = pack_bf16x2(v0, v1);
+      // (the register file is full: each packed dword must exist HERE -- left alone, hipcc sinks the pure convert chain to
+      //  the outputs' first use in the next layer and keeps every tile's accumulators alive until then)
+      asm volatile("" : "+v"(hi));
+      hv[w] = hi;
+    }
+  } else if constexpr (OUTS == 2) {
+    const unsigned hi = hv[w];
+    unsigned lo = pack_bf16x2(v0 - bflo(hi), v1 - bfhi(hi));
+    asm volatile("" : "+v"(lo));
+    (u < 4 ? lo0 : lo1)[w] = lo;
+  }
+}
+
+// The matrix part of one output tile: acc = bias + W_tile [emb ; (hid, hidlo)] in three products per k-step.  `gap(m)`
+// runs behind the m-th MFMA (m = 0 .. NM-1): the caller's deferred work (the previous tile's epilogue steps).
+template <int NGE, int KHID, int HMODE, bool EMB_FIRST, class ST, class Gap>
+MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, const u32x4* hidlo, const u32x4* xhi, const u32x4* xlo,
+                     uint32_t bias_off, const Ahead& two, f32x16& acc, Gap&& gap) {
   constexpr int NEG = 2 * NGE;
   constexpr int NHG = (HMODE ? 2 : 1) * KHID;
   constexpr int NG = NEG + NHG;
-  static_assert(NG > PD, "panel shorter than the fragment pipeline");
-  static_assert(NG >= 4, "panel too short for the DMA pieces");
-  f32x16 acc;
+  constexpr int NSEG = NG > 32 ? 2 : 1;
+  constexpr int NG1 = NSEG == 2 ? (NG + 1) / 2 : NG;         // groups of the first panel (panel_cap)
+  static_assert(NG > PDX && NG - NG1 != 1 && (NSEG == 1 || NG - NG1 > PDX), "panel shorter than the fragment pipeline");
+  static_assert(NG <= 64, "tile longer than two panels");
+  const int h = id.h;
+  const uint32_t b0 = st.off0 + id.lane * 16, b1 = st.off1 + id.lane * 16, b2 = st.off2 + id.lane * 16;
+  auto frag = [&](int g) {                                   // group g of this tile; g >= NG: of the tile behind it
+#ifdef MF_BF_ABL_NOFRAG
+    return carry.w[0];
+#endif
+    if (g < NG1) return lds_u4(b0 + g * kGroupBytes);
+    if (g < NG) return lds_u4(b1 + (g - NG1) * kGroupBytes);
+    return lds_u4((NSEG == 2 ? b2 : b1) + (g - NG) * kGroupBytes);
+  };
   {
-    const f32x4 b0 = lds_f4(bias_off + (0 + 4 * h) * 4), b1 = lds_f4(bias_off + (8 + 4 * h) * 4);
-    const f32x4 b2 = lds_f4(bias_off + (16 + 4 * h) * 4), b3 = lds_f4(bias_off + (24 + 4 * h) * 4);
+    const f32x4 c0 = lds_f4(bias_off + (0 + 4 * h) * 4), c1 = lds_f4(bias_off + (8 + 4 * h) * 4);
+    const f32x4 c2 = lds_f4(bias_off + (16 + 4 * h) * 4), c3 = lds_f4(bias_off + (24 + 4 * h) * 4);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; acc[8 + i] = b2[i]; acc[12 + i] = b3[i]; }
+    for (int i = 0; i < 4; ++i) { acc[i] = c0[i]; acc[4 + i] = c1[i]; acc[8 + i] = c2[i]; acc[12 + i] = c3[i]; }
   }
-  u32x4 r[PD + 1];
+  u32x4 r[PDX + 1];
 #pragma unroll
-  for (int i = 0; i < PD; ++i) r[i] = carry.w[i];
+  for (int i = 0; i < PDX; ++i) r[i] = carry.w[i];
+  int m = 0;                                                 // MFMAs issued (compile time after unrolling)
 #pragma unroll
   for (int gi = 0; gi < NG; ++gi) {
-    const int s = gi % (PD + 1);
-    const bool emb = gi < NEG;
-    const int gh = gi - NEG;
-    if (emb) acc = MF_MFMA32(r[s], xhi[gi >> 1], acc);                      // even: Whi xhi ; odd: Wlo xhi
+    const int s = gi % (PDX + 1);
+    const int ge = EMB_FIRST ? gi : gi - NHG, gh = EMB_FIRST ? gi - NEG : gi;
+    const bool emb = ge >= 0 && ge < NEG;
+    if (gi == NG1) st.advance();                             // second panel of the tile
+    if (emb) acc = MF_MFMA32(r[s], xhi[ge >> 1], acc);                      // even: Whi xhi ; odd: Wlo xhi
     else acc = MF_MFMA32(r[s], hid[HMODE ? gh >> 1 : gh], acc);             // even: Whi ahi ; odd: Wlo ahi
     __builtin_amdgcn_sched_barrier(0);
-    const int sp = (gi + PD) % (PD + 1), nb = gi + PD;
-    if (nb < NG) r[sp] = lds_u4(p + nb * kGroupBytes);
-    if (gi == 0) hook();
-    if (gi >= 1 && gi <= 4) piece(gi - 1);                                   // (32-group panels: four pieces per wave)
-    if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
+    const int sp = (gi + PDX) % (PDX + 1), nb = gi + PDX;
+    if (nb < NG) r[sp] = frag(nb);
+    // the panel's barrier + the DMA of the panel two ahead, behind its first group; that panel's pieces go into the MFMA
+    // gaps that follow (several per gap where the panel is short)
+    const int base = gi >= NG1 ? NG1 : 0, len = gi >= NG1 ? NG - NG1 : NG1, q = gi - base;
+    if (q == 0) st.sync(base ? two.g1 : two.g0, base ? two.j1 : two.j0, id);
+    if (nb >= NG) r[sp] = frag(nb);
+    gap(m++);
     __builtin_amdgcn_sched_barrier(0);
-    if (emb && !(gi & 1)) {
-      acc = MF_MFMA32(r[s], xlo[gi >> 1], acc);                             // Whi xlo
+    if ((emb && !(ge & 1)) || (!emb && HMODE == 2 && !(gh & 1))) {         // (the even groups: both blocks start at an even gi)
+      acc = MF_MFMA32(r[s], emb ? xlo[ge >> 1] : hidlo[gh >> 1], acc);       // Whi xlo / Whi alo
+      __builtin_amdgcn_sched_barrier(0);
+      // the pieces of the panel two ahead go behind these second MFMAs -- gaps that carry no fragment read (an LDS-DMA
+      // issued next to a ds_read_b128 costs the wave ~50 cycles, alone ~10) -- spread evenly over the panel
+      const int e0 = base + (base & 1), nslots = (base + len - e0 + 1) / 2, j = (gi - e0) / 2;
+#pragma unroll
+      for (int k = j * ST::kPieces / nslots; k < (j + 1) * ST::kPieces / nslots; ++k) st.piece(k, id);
+      gap(m++);
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!emb && HMODE == 2 && !(gh & 1)) {
-      acc = MF_MFMA32(r[s], hidlo[gh >> 1], acc);                           // Whi alo
-      __builtin_amdgcn_sched_barrier(0);
-    }
   }
 #pragma unroll
-  for (int i = 0; i < PD; ++i) carry.w[i] = r[(NG + i) % (PD + 1)];
-  float v[16];
-#pragma unroll
-  for (int i = 0; i < 16; ++i) v[i] = fmaxf(acc[i], 0.f);
-  if constexpr (SIG) {                                       // rows 8q + 4h + i of this tile
-    const uint32_t so = sigw_off + 16 * h;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const f32x4 w = lds_f4(so + 32 * q);
-#pragma unroll
-      for (int i = 0; i < 4; ++i) sig = __builtin_fmaf(w[i], v[4 * q + i], sig);
-    }
-    // (like the packed outputs below: left alone, hipcc sinks this pure chain to sig's first use behind the layer and
-    //  keeps all eight tiles' accumulators alive until then -- ~340 spilled registers)
-    asm volatile("" : "+v"(sig));
-  }
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    out0[w] = pack_bf16x2(v[2 * w], v[2 * w + 1]);
-    out1[w] = pack_bf16x2(v[8 + 2 * w], v[8 + 2 * w + 1]);
-    if constexpr (OUT2) {
-      lo0[w] = pack_bf16x2(v[2 * w] - bflo(out0[w]), v[2 * w + 1] - bfhi(out0[w]));
-      lo1[w] = pack_bf16x2(v[8 + 2 * w] - bflo(out1[w]), v[8 + 2 * w + 1] - bfhi(out1[w]));
-    }
-  }
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    asm volatile("" : "+v"(out0[w]), "+v"(out1[w]));
-    if constexpr (OUT2) asm volatile("" : "+v"(lo0[w]), "+v"(lo1[w]));
-  }
-  __builtin_amdgcn_sched_barrier(0);
+  for (int i = 0; i < PDX; ++i) carry.w[i] = r[(NG + i) % (PDX + 1)];
 }
 
-// One trunk layer with split operands: (out, outlo) <- relu(W_l [emb ; (in, inlo)] + b_l).  MODE as trunk_layer_m.
-template <int KH, int NGE, int MODE, int HMODE, bool OUT2, bool SIG, class RBT>
+// the first two panels of a layer whose tiles are `g` groups long
+MF_D Next next_of_groups(int g) { return g > 32 ? Next{(g + 1) / 2, nullptr, g / 2, nullptr} : Next{g, nullptr, g, nullptr}; }
+template <int KH, int EKS>
+MF_D Next next_x(const Net& n, int layer) { return next_of_groups(tgroups<KH, EKS, true, 1>(n, layer)); }
+
+// One layer of NT tiles with split operands: (out, outlo) <- act(W [emb ; (in, inlo)] + b), `nxt` = what follows it.
+// The epilogue of tile t runs in the MFMA gaps of tile t + 1 (a wave alone on its SIMD has nobody to cover it); only the
+// last tile's stands alone.
+template <int NT, int NGE, int KHID, int HMODE, bool EMB_FIRST, bool RELU, int OUTS, int NHEAD, int HSTRIDE, class ST, int KI, int KO>
+MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], const u32x4 (&inlo)[KI], u32x4 (&out)[KO],
+                  u32x4 (&outlo)[KO], const u32x4* xhi, const u32x4* xlo, uint32_t bias_off, const Next& nxt, uint32_t headw_off,
+                  float (&head)[NHEAD ? NHEAD : 1]) {
+  constexpr int NG = 2 * NGE + (HMODE ? 2 : 1) * KHID;
+  constexpr int NSEG = NG > 32 ? 2 : 1;
+  constexpr int NG1 = NSEG == 2 ? (NG + 1) / 2 : NG;
+  constexpr int NM = 3 * NGE + (HMODE == 2 ? 3 : 2) * KHID / (HMODE ? 1 : 2);      // MFMAs of a tile
+  constexpr int kSteps = 16;
+  f32x16 pend = {};
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    Ahead two;
+    if constexpr (NSEG == 1) {        // panel t + 2 of this layer, else panel t + 2 - NT of what follows
+      two = Ahead{t + 2 < NT ? NG : (t == NT - 2 ? nxt.groups : nxt.groups2),
+                  t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), 0, nullptr};
+    } else {                          // the same half of the next tile, else of the first tile of what follows
+      two = t + 1 < NT ? Ahead{NG1, nullptr, NG - NG1, nullptr} : Ahead{nxt.groups, nxt.jump, nxt.groups2, nxt.jump2};
+    }
+    const int tp = t > 0 ? t - 1 : 0;                        // the tile whose epilogue is pending
+    auto gap = [&](int m) __attribute__((always_inline)) {
+#ifndef MF_BF_X3_NODEFER
+      if (t == 0) return;
+#pragma unroll
+      for (int sidx = kSteps * m / NM; sidx < kSteps * (m + 1) / NM; ++sidx)
+        epi_step<RELU, OUTS, NHEAD, HSTRIDE>(pend, sidx, id.h, out[OUTS ? 2 * tp : 0], out[OUTS ? 2 * tp + 1 : 1], outlo[OUTS == 2 ? 2 * tp : 0],
+                                             outlo[OUTS == 2 ? 2 * tp + 1 : 1], headw_off + 32 * tp * 4, head);
+#endif
+    };
+    f32x16 acc;
+    mma_tile_x<NGE, KHID, HMODE, EMB_FIRST>(st, id, carry, in, inlo, xhi, xlo, bias_off + 32 * t * 4, two, acc, gap);
+    st.advance();
+#ifdef MF_BF_X3_NODEFER
+#pragma unroll
+    for (int sidx = 0; sidx < kSteps; ++sidx)
+      epi_step<RELU, OUTS, NHEAD, HSTRIDE>(acc, sidx, id.h, out[OUTS ? 2 * t : 0], out[OUTS ? 2 * t + 1 : 1], outlo[OUTS == 2 ? 2 * t : 0],
+                                           outlo[OUTS == 2 ? 2 * t + 1 : 1], headw_off + 32 * t * 4, head);
+    __builtin_amdgcn_sched_barrier(0);
+#endif
+    pend = acc;
+  }
+#ifndef MF_BF_X3_NODEFER
+#pragma unroll
+  for (int sidx = 0; sidx < kSteps; ++sidx)
+    epi_step<RELU, OUTS, NHEAD, HSTRIDE>(pend, sidx, id.h, out[OUTS ? 2 * (NT - 1) : 0], out[OUTS ? 2 * (NT - 1) + 1 : 1],
+                                         outlo[OUTS == 2 ? 2 * (NT - 1) : 0], outlo[OUTS == 2 ? 2 * (NT - 1) + 1 : 1],
+                                         headw_off + 32 * (NT - 1) * 4, head);
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+}
+
+// One trunk layer: MODE as trunk_layer_m (1 embedded input only, 2 hidden only, 3 both, embedded input first).
+template <int KH, int NGE, int MODE, bool RELU, int NHEAD, class RBT, class ST>
 MF_D void trunk_layer_x(const Net& net, int layer, const u32x4 (&in)[KH], const u32x4 (&inlo)[KH], u32x4 (&out)[KH],
-                        u32x4 (&outlo)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE], Stream& st, Carry& carry,
-                        const Lane& id, const Next& nxt, const RBT& rb, uint32_t sigw_off, float& sig) {
-  constexpr int NT = KH / 2;
-  const int groups = ((MODE & 1) ? 2 * NGE : 0) + ((MODE & 2) ? (HMODE ? 2 : 1) * KH : 0);
+                        u32x4 (&outlo)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE], ST& st, CarryX& carry,
+                        const Lane& id, const Next& nxt, const RBT& rb, uint32_t headw_off, float (&head)[NHEAD ? NHEAD : 1]) {
   uint32_t bias_off = net.res_lds + layer * (16 * KH) * 4;
   if constexpr (__is_same(RBT, LdsRayBias) && (MODE & 1))
     bias_off = rb.lane_off + (uint32_t)__builtin_popcount(net.emb_mask & ((1u << layer) - 1u)) * (16 * KH) * 4;
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
-    const uint32_t p = st.slot_off(0) + id.lane * 16;
-    const uint32_t pn = st.slot_off(1) + id.lane * 16;
-    auto hook = [&]() {
-      st.sync(t + 2 < NT ? groups : (t == NT - 2 ? nxt.groups : nxt.groups2),
-              t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id);
-    };
-    auto piece = [&](int k) { st.piece(k, id); };
-    out_tile_x<(MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, HMODE, OUT2, SIG>(
-        carry, in, inlo, xhi, xlo, p, pn, bias_off + 32 * t * 4, id.h, hook, piece, out[2 * t], out[2 * t + 1],
-        outlo[OUT2 ? 2 * t : 0], outlo[OUT2 ? 2 * t + 1 : 1], sigw_off + 32 * t * 4, sig);
-    st.advance();
-  }
+  layer_x<KH / 2, (MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, 2, true, RELU, 2, NHEAD, 0>(
+      st, id, carry, in, inlo, out, outlo, xhi, xlo, bias_off, nxt, headw_off, head);
 }
 
 // NoF head with split activations and weights: groups (Whi, Wlo) per k-step, three products.
-template <int KHID, class Hook, class Piece>
-MF_D f32x16 head_tile_x3(Carry& carry, const u32x4* hid, const u32x4* hidlo, uint32_t p, uint32_t pn, uint32_t bias_off, int h,
-                         Hook&& hook, Piece&& piece) {
+template <int KHID, class ST>
+MF_D f32x16 head_tile_x3(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, const u32x4* hidlo, uint32_t bias_off, int g2,
+                         const char* j2) {
   constexpr int NG = 2 * KHID;
+  const int h = id.h;
+  const uint32_t p = st.off0 + id.lane * 16, pn = st.off1 + id.lane * 16;
   f32x16 acc;
   {
     const f32x4 b0 = lds_f4(bias_off + (0 + 4 * h) * 4), b1 = lds_f4(bias_off + (8 + 4 * h) * 4);
@@ -841,18 +959,18 @@ MF_D f32x16 head_tile_x3(Carry& carry, const u32x4* hid, const u32x4* hidlo, uin
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; acc[8 + i] = b2[i]; acc[12 + i] = b3[i]; }
   }
-  u32x4 r[PD + 1];
+  u32x4 r[PDX + 1];
 #pragma unroll
-  for (int i = 0; i < PD; ++i) r[i] = carry.w[i];
+  for (int i = 0; i < PDX; ++i) r[i] = carry.w[i];
 #pragma unroll
   for (int gi = 0; gi < NG; ++gi) {
-    const int s = gi % (PD + 1);
+    const int s = gi % (PDX + 1);
     acc = MF_MFMA32(r[s], hid[gi >> 1], acc);
     __builtin_amdgcn_sched_barrier(0);
-    const int sp = (gi + PD) % (PD + 1), nb = gi + PD;
+    const int sp = (gi + PDX) % (PDX + 1), nb = gi + PDX;
     if (nb < NG) r[sp] = lds_u4(p + nb * kGroupBytes);
-    if (gi == 0) hook();
-    if (gi >= 1 && gi <= 3) piece(gi - 1);
+    if (gi == 0) st.sync(g2, j2, id);
+    if (gi >= 1 && gi <= ST::kPieces) st.piece(gi - 1, id);
     if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
     __builtin_amdgcn_sched_barrier(0);
     if (!(gi & 1)) {
@@ -861,13 +979,13 @@ MF_D f32x16 head_tile_x3(Carry& carry, const u32x4* hid, const u32x4* hidlo, uin
     }
   }
 #pragma unroll
-  for (int i = 0; i < PD; ++i) carry.w[i] = r[(NG + i) % (PD + 1)];
+  for (int i = 0; i < PDX; ++i) carry.w[i] = r[(NG + i) % (PDX + 1)];
   return acc;
 }
 
-template <class RBT, class AfterFirst>
+template <class RBT, class AfterFirst, class ST>
 MF_D void nof_eval_x3(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&xlo)[kKsNofXyz], const float (&xyz)[3],
-                      Stream& st, Carry& carry, const Lane& id, const Next& follow, float (&out)[3], const RBT& rb,
+                      ST& st, CarryX& carry, const Lane& id, const Next& follow, float (&out)[3], const RBT& rb,
                       AfterFirst&& after_first) {
   u32x4 ah[8], al[8], bh[8], bl[8];
 #pragma unroll
@@ -876,13 +994,13 @@ MF_D void nof_eval_x3(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4
     for (int i = 0; i < 4; ++i) { ah[t][i] = 0; al[t][i] = 0; }
   const int D = net.D;
   const Next hd{16, nullptr, follow.groups, follow.jump};
-  float nosig = 0.f;
-  auto one = [&](int layer, const u32x4 (&ih)[8], const u32x4 (&il)[8], u32x4 (&oh)[8], u32x4 (&ol)[8]) {
-    const Next nxt = layer == D - 1 ? hd : next_trunk_bf<8, kKsNofXyz, true, 1>(net, layer + 1);
+  float nohead[1] = {0.f};
+  auto one = [&](int layer, const u32x4 (&ih)[8], const u32x4 (&il)[8], u32x4 (&oh)[8], u32x4 (&ol)[8]) __attribute__((always_inline)) {
+    const Next nxt = layer == D - 1 ? hd : next_x<8, kKsNofXyz>(net, layer + 1);
     const int has_emb = (net.emb_mask >> layer) & 1;
-    if (layer == 0) trunk_layer_x<8, kKsNofXyz, 1, 2, true, false>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nosig);
-    else if (has_emb) trunk_layer_x<8, kKsNofXyz, 3, 2, true, false>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nosig);
-    else trunk_layer_x<8, kKsNofXyz, 2, 2, true, false>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nosig);
+    if (layer == 0) trunk_layer_x<8, kKsNofXyz, 1, true, 0>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead);
+    else if (has_emb) trunk_layer_x<8, kKsNofXyz, 3, true, 0>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead);
+    else trunk_layer_x<8, kKsNofXyz, 2, true, 0>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead);
   };
   int l = 0;
   for (; l + 1 < D; l += 2) {
@@ -896,14 +1014,9 @@ MF_D void nof_eval_x3(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4
 #pragma unroll
     for (int t = 0; t < 8; ++t) { ah[t] = bh[t]; al[t] = bl[t]; }
   }
-  f32x16 acc;
-  {
-    const uint32_t p = st.slot_off(0) + id.lane * 16, pn = st.slot_off(1) + id.lane * 16;
-    auto hook = [&]() { st.sync(follow.groups2, follow.jump2, id); };
-    auto piece = [&](int k) { st.piece(k, id); };
-    acc = head_tile_x3<8>(carry, ah, al, p, pn, net.res_lds + (D + net.aux) * 128 * 4, id.h, hook, piece);
-    st.advance();
-  }
+  // the head panel; the panel two ahead of it = the SECOND panel of whatever follows
+  f32x16 acc = head_tile_x3<8>(st, id, carry, ah, al, net.res_lds + (D + net.aux) * 128 * 4, follow.groups2, follow.jump2);
+  st.advance();
   float own[5], oth[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) { own[i] = acc[i]; oth[i] = __shfl_xor(acc[i], 32, 64); }
@@ -919,50 +1032,72 @@ MF_D void nof_eval_x3(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4
   }
 }
 
-// Canonical NeRF, x3: split encodings; layers 0 .. D-2 as in the fast mode; layer D-1 with split weights and the sigma
-// head in its epilogue; xyz_encoding_final, extra_encoding (split extra block) and the rgb head as in the fast mode.
-template <class MakeExtra>
+// Canonical NeRF, x3: every layer in three products; the sigma head inside the epilogue of the last trunk layer, the rgb
+// head inside extra_encoding's (whose outputs never become operands).  `make_extra(eh, el)` builds the extra block's split
+// operands right before extra_encoding.
+template <class MakeExtra, class ST>
 MF_D void nerf_eval_x3(const Net& net, const u32x4 (&xh)[kKsNerfXyz], const u32x4 (&xl)[kKsNerfXyz], MakeExtra&& make_extra,
-                       bool sigma_only, Stream& st, Carry& carry, const Lane& id, const Next& follow, float& sigma,
+                       bool sigma_only, ST& st, CarryX& carry, const Lane& id, const Next& follow, float& sigma,
                        float (&rgb)[3]) {
-  u32x4 act[16];
+  u32x4 ah[16], al[16], bh[16], bl[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) act[t][i] = 0;
+    for (int i = 0; i < 4; ++i) { ah[t][i] = 0; al[t][i] = 0; }
   const int D = net.D;
   NoRayBias norb;
-  trunk<16, kKsNerfXyz, true>(net, D - 1, act, xh, xl, st, carry, id,
-                              [&](int l) { return next_trunk_bf<16, kKsNerfXyz, true, 2>(net, l + 1); }, norb, nullptr, [] {});
-  const uint32_t r_sigma_w = net.res_lds + ((D + 1) * 256 + 128) * 4;
-  u32x4 h7[16];
-  float sig = 0.f;
-  {
-    const Next nx = sigma_only ? follow : next_trunk_bf<16, kKsNerfXyz, true, 2>(net, D);      // xyz_encoding_final: 16 groups
-#ifndef MF_X3_SIG
-#define MF_X3_SIG true
-#endif
-    if ((net.emb_mask >> (D - 1)) & 1)
-      trunk_layer_x<16, kKsNerfXyz, 3, 1, false, MF_X3_SIG>(net, D - 1, act, act, h7, h7, xh, xl, st, carry, id, nx, norb, r_sigma_w, sig);
-    else
-      trunk_layer_x<16, kKsNerfXyz, 2, 1, false, MF_X3_SIG>(net, D - 1, act, act, h7, h7, xh, xl, st, carry, id, nx, norb, r_sigma_w, sig);
+  float nohead[1] = {0.f};
+  // (always_inline: called three times; as a real function its array arguments would live in scratch)
+  auto one = [&](int layer, const u32x4 (&ih)[16], const u32x4 (&il)[16], u32x4 (&oh)[16], u32x4 (&ol)[16]) __attribute__((always_inline)) {
+    const Next nxt = next_x<16, kKsNerfXyz>(net, layer + 1);
+    const int has_emb = (net.emb_mask >> layer) & 1;
+    if (layer == 0) trunk_layer_x<16, kKsNerfXyz, 1, true, 0>(net, layer, ih, il, oh, ol, xh, xl, st, carry, id, nxt, norb, 0u, nohead);
+    else if (has_emb) trunk_layer_x<16, kKsNerfXyz, 3, true, 0>(net, layer, ih, il, oh, ol, xh, xl, st, carry, id, nxt, norb, 0u, nohead);
+    else trunk_layer_x<16, kKsNerfXyz, 2, true, 0>(net, layer, ih, il, oh, ol, xh, xl, st, carry, id, nxt, norb, 0u, nohead);
+  };
+  int l = 0;                                                  // layers 0 .. D-2, in pairs a -> b -> a
+  for (; l + 1 < D - 1; l += 2) {
+    one(l, ah, al, bh, bl);
+    st.tl.stamp(10 + l, id);
+    one(l + 1, bh, bl, ah, al);
+    st.tl.stamp(11 + l, id);
   }
-  sigma = sig + __shfl_xor(sig, 32, 64) + lds_f(r_sigma_w + 256 * 4);
+  if (l < D - 1) {
+    one(l, ah, al, bh, bl);
+#pragma unroll
+    for (int t = 0; t < 16; ++t) { ah[t] = bh[t]; al[t] = bl[t]; }
+  }
+  // resident block: [bias_trunk (D+1) 256 | bias_extra 128 | sigma_w 256 | sigma_b 4 | rgb_w 384 | rgb_b 4]
+  const uint32_t r_sigma_w = net.res_lds + ((D + 1) * 256 + 128) * 4;
+  float sig[1] = {0.f};
+  {                                                           // layer D-1 (a -> b), the sigma head in its epilogue
+    const Next nx = sigma_only ? follow : next_x<16, kKsNerfXyz>(net, D);      // xyz_encoding_final: 32 groups
+    if ((net.emb_mask >> (D - 1)) & 1)
+      trunk_layer_x<16, kKsNerfXyz, 3, true, 1>(net, D - 1, ah, al, bh, bl, xh, xl, st, carry, id, nx, norb, r_sigma_w, sig);
+    else
+      trunk_layer_x<16, kKsNerfXyz, 2, true, 1>(net, D - 1, ah, al, bh, bl, xh, xl, st, carry, id, nx, norb, r_sigma_w, sig);
+  }
+  sigma = sig[0] + __shfl_xor(sig[0], 32, 64) + lds_f(r_sigma_w + 256 * 4);
   st.tl.stamp(30, id);
   if (sigma_only) return;
-  const int xg = 16 + 2 * net.aux;
-  const Next ex{xg, nullptr, xg, nullptr};
-  u32x4 fin[16];
-  trunk_layer_m<16, kKsNerfXyz, 2, false>(net, D, false, h7, fin, xh, xl, st, carry, id, ex, norb);
-  u32x4 e[8], eh[kKsExtraMax], el[kKsExtraMax];
+  const Next ex = next_of_groups(32 + 2 * net.aux);
+  trunk_layer_x<16, kKsNerfXyz, 2, false, 0>(net, D, bh, bl, ah, al, xh, xl, st, carry, id, ex, norb, 0u, nohead);   // xyz_encoding_final (b -> a, no ReLU)
+  st.tl.stamp(31, id);
+  u32x4 eh[kKsExtraMax], el[kKsExtraMax];
   make_extra(eh, el);
-  if (net.aux == 2) extra_layer<2, true>(net, fin, eh, el, e, st, carry, id, follow);
-  else if (net.aux == 1) extra_layer<1, true>(net, fin, eh, el, e, st, carry, id, follow);
-  else extra_layer<0, true>(net, fin, eh, el, e, st, carry, id, follow);
-  float o[3];
-  valu_head(e, r_sigma_w + (256 + 4) * 4, r_sigma_w + (256 + 4 + 384) * 4, id.h, o);
+  st.tl.stamp(32, id);
+  // extra_encoding (nerf.py:98): W/2 outputs from [final (W) ; extra block], ReLU; rgb (nerf.py:57-59) in its epilogue
+  float o[3] = {0.f, 0.f, 0.f};
+  const uint32_t bias_extra = net.res_lds + (D + 1) * 256 * 4, r_rgb_w = r_sigma_w + (256 + 4) * 4;
+  if (net.aux == 2) layer_x<4, 2, 16, 2, false, true, 0, 3, 512>(st, id, carry, ah, al, bh, bl, eh, el, bias_extra, follow, r_rgb_w, o);
+  else if (net.aux == 1) layer_x<4, 1, 16, 2, false, true, 0, 3, 512>(st, id, carry, ah, al, bh, bl, eh, el, bias_extra, follow, r_rgb_w, o);
+  else layer_x<4, 0, 16, 2, false, true, 0, 3, 512>(st, id, carry, ah, al, bh, bl, eh, el, bias_extra, follow, r_rgb_w, o);
+  st.tl.stamp(33, id);
 #pragma unroll
-  for (int c = 0; c < 3; ++c) rgb[c] = 1.f / (1.f + expf(-o[c]));   // nn.Sigmoid, nerf.py:57-59
+  for (int c = 0; c < 3; ++c) {
+    const float t = o[c] + __shfl_xor(o[c], 32, 64) + lds_f(r_rgb_w + (384 + c) * 4);
+    rgb[c] = 1.f / (1.f + expf(-t));                          // nn.Sigmoid, nerf.py:57-59
+  }
 }
 
 }  // namespace bf

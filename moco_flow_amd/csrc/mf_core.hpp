@@ -188,10 +188,10 @@ struct NetLayout {
   int64_t panel_bytes;     // all panels
   int64_t ind_bytes;       // bf16 NoF: fp32 image-index columns [embedded layer][kNofIndCols][row] behind the panels
   int n_emb_layers;        // layers that consume the embedded input (popcount of emb_mask)
-  uint32_t hsplit_mask;    // MF_PREC_BF16X3: trunk layers whose HIDDEN k-steps are (hi, lo) group pairs too -- every NoF
-                           // layer (three products: activations and weights split), the NeRF's last trunk layer (two
-                           // products: weights split; it feeds the sigma head)
-  int max_groups;          // largest panel, in groups
+  uint32_t hsplit_mask;    // MF_PREC_BF16X3: layers whose HIDDEN k-steps are (hi, lo) group pairs too (three products:
+                           // activations and weights split) -- every layer of both networks; bit n_trunk = the NeRF's
+                           // extra_encoding
+  int max_groups;          // largest panel, in groups (x3: tiles of more than 32 groups stream as two panels, panel_cap)
   // resident block float offsets
   int off_bias_trunk;      // n_trunk * W
   int off_bias_extra;      // W/2
@@ -220,9 +220,13 @@ MF_HD int trunk_groups(const NetLayout& L, int layer) {
 // whose hidden k-steps are split (hi, lo) group pairs -- the head's weights keep 16 mantissa bits.
 MF_HD int head_groups(const NetLayout& L) { return 2 * L.NK; }
 MF_HD int extra_groups(const NetLayout& L) {
-  if (L.bf16) return L.NK + (L.emb_split ? 2 : 1) * L.extra_steps;
+  if (L.bf16) return (((L.hsplit_mask >> L.n_trunk) & 1) ? 2 : 1) * L.NK + (L.emb_split ? 2 : 1) * L.extra_steps;
   return 2 * (hidden_batches(L) + L.extra_steps / 4);
 }
+
+// MF_PREC_BF16X3: a tile's groups stream as ONE panel up to 32 groups, as two halves beyond (the 3-slot LDS ring holds
+// 32 KiB slots; the groups of a tile are contiguous in the packed buffer, so a panel boundary is only a barrier position)
+MF_HD int panel_cap(int groups) { return groups > 32 ? (groups + 1) / 2 : groups; }
 
 // ------------------------------------------------------------------ device helpers
 extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -238,6 +242,13 @@ extern __shared__ __attribute__((aligned(16))) char smem[];
 MF_D void blds16(const char* base, uint32_t lane16, uint32_t soff, uint32_t lds_off) {
   const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, -1, 0x00020000);
   __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + lds_off), 16, (int)lane16, (int)soff, 0, 0);
+}
+// the same with an instruction offset IMM (<= 4095; added to the global AND the LDS address): consecutive 1 KiB pieces of
+// one wave share base, scalar offset and M0
+template <int IMM>
+MF_D void blds16_imm(const char* base, uint32_t lane16, uint32_t soff, uint32_t lds_off) {
+  const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, -1, 0x00020000);
+  __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)(smem + lds_off), 16, (int)lane16, (int)soff, IMM, 0);
 }
 MF_D void wait_vm0() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 

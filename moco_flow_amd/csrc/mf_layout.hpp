@@ -25,7 +25,7 @@ inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L, int bf16 = 0) {
   if (bf16 && d.W != 256) return false;
   L.emb_steps = bf16 ? kKsNerfXyz : kStepsNerfXyz;     // bf16: 16-slot k-steps (mf_bf16.hpp); fp32: 4-k MFMA steps
   L.emb_split = x3 ? 1 : 0;                            // bf16: the NeRF's encodings are plain bf16 operands (mf_bf16.hpp); x3: split
-  L.hsplit_mask = x3 ? 1u << (d.D - 1) : 0u;           // x3: the last trunk layer (-> sigma head) with split weights
+  L.hsplit_mask = x3 ? ((1u << (d.D + 2)) - 1u) & ~1u : 0u;   // x3: every hidden range (trunk, final, extra_encoding) as (hi, lo) pairs
   L.emb_mask = 1u | d.skip_mask;
   L.relu_mask = (1u << d.D) - 1u;
   switch (d.extra_feat_type) {
@@ -48,11 +48,11 @@ inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L, int bf16 = 0) {
   for (int l = 0; l < L.n_trunk; ++l) {
     const int g = trunk_groups(L, l);
     groups += (int64_t)g * L.NP;
-    if (g > L.max_groups) L.max_groups = g;
+    if ((x3 ? panel_cap(g) : g) > L.max_groups) L.max_groups = x3 ? panel_cap(g) : g;
   }
   const int ge = extra_groups(L);
   groups += (int64_t)ge * (L.NP / 2);      // (W/2)-wide layer: NP/2 panels in either layout
-  if (ge > L.max_groups) L.max_groups = ge;
+  if ((x3 ? panel_cap(ge) : ge) > L.max_groups) L.max_groups = x3 ? panel_cap(ge) : ge;
   L.panel_bytes = groups * kGroupBytes;
   return true;
 }

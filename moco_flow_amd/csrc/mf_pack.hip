@@ -214,6 +214,7 @@ extern "C" int32_t mf_nerf_pack_p(const mf_nerf_desc* d, int32_t precision, void
     R.hid_batches = hidden_batches(L);
     R.bf16 = L.bf16;
     R.emb_split = L.emb_split;
+    R.hid_split = (L.hsplit_mask >> L.n_trunk) & 1;
     R.hid_col0 = 0;
     R.xyz_cols = 0;
     R.dst_group0 = g0;

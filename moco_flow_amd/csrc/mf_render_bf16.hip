@@ -4,6 +4,7 @@
 // written to HBM -- on the 32x32x16 bf16 core of mf_bf16.hpp: a wave owns 32 samples, a workgroup tile is 256
 // samples, a weight panel is one 32-row tile of a layer.
 #include <cstddef>
+#include <type_traits>
 
 #include "mf_bf16.hpp"
 #include "mf_host.hpp"
@@ -126,37 +127,41 @@ __global__ __launch_bounds__(256) void nof_raybias_kernel(const RayBiasParams p)
 // `combo`, entry = [embedded layer][128] floats, to `dst` (ray-major).  Pieces of 1 KiB round-robin over the waves; every
 // panel barrier behind the issue publishes them (Stream::sync waits vmcnt(0) first), so the issue sits at least one panel
 // in front of the first read and behind the last read of the buffer's previous content (see the call sites).
+template <int NW = kWaves>
 MF_D void stage_raybias(const float* table, int combos, int layers, long long ray_first, int n, int combo, uint32_t dst,
                         const Lane& id) {
   const uint32_t entry = (uint32_t)layers * 512u, chunk = (uint32_t)n * entry;
   const char* base = reinterpret_cast<const char*>(table) + ((size_t)ray_first * combos + combo) * entry;
-  for (uint32_t q = id.wave; q * 1024u < chunk; q += kWaves) {
+  for (uint32_t q = id.wave; q * 1024u < chunk; q += NW) {
     uint32_t b = q * 1024u + id.lane * 16u;
     b = b < chunk ? b : chunk - 16u;                       // (tail lanes re-fetch the last 16 bytes into the padding)
     const uint32_t r = b / entry;
     blds16(base, r * (uint32_t)combos * entry + (b - r * entry), 0, dst + q * 1024u);
   }
 }
-template <class P>
+template <int NW, class P>
 MF_D void stage_raybias(const P& p, long long ray_first, int n, int combo, uint32_t dst, const Lane& id) {
-  stage_raybias(p.raybias, p.rb_combos, p.rb_layers, ray_first, n, combo, dst, id);
+  stage_raybias<NW>(p.raybias, p.rb_combos, p.rb_layers, ray_first, n, combo, dst, id);
 }
-// rays [first, first + n) touched by tile `tile` of a group of `nr` rays
+// rays [first, first + n) touched by tile `tile` (TILE samples) of a group of `nr` rays
+template <int TILE>
 MF_D void tile_rays(int tile, int nr, int S, int& first, int& n) {
-  const int s0 = tile * bf::kTile, s1 = (s0 + bf::kTile < nr * S ? s0 + bf::kTile : nr * S) - 1;
+  const int s0 = tile * TILE, s1 = (s0 + TILE < nr * S ? s0 + TILE : nr * S) - 1;
   first = s0 / S;
   n = s1 / S - first + 1;
 }
 
-// X3: MF_PREC_BF16X3 (mf_bf16.hpp: NoF hidden GEMMs and head as three-product splits, NeRF encodings split, last trunk
-// layer with split weights, sigma head on fp32 accumulators)
+// X3: MF_PREC_BF16X3 (mf_bf16.hpp: every matrix product as a three-product split, heads on fp32 accumulators): 4 waves,
+// one per SIMD, 128-sample tiles; else 8 waves, two per SIMD, 256-sample tiles
 template <bool MOCO, bool X3 = false>
-__global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p) {
+__global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel_bf16(const Params p) {
+  constexpr int NW = X3 ? 4 : kWaves;
+  constexpr int TILE = NW * kWaveSamples;
   const Lane id;
-  load_resident(p.nerf, id);
+  load_resident<NW>(p.nerf, id);
   if (MOCO) {
-    load_resident(p.bw, id);
-    if (p.flags & (MF_F_CHAIN_LOCAL | MF_F_CHAIN_GLOBAL)) load_resident(p.fw, id);
+    load_resident<NW>(p.bw, id);
+    if (p.flags & (MF_F_CHAIN_LOCAL | MF_F_CHAIN_GLOBAL)) load_resident<NW>(p.fw, id);
   }
   if (threadIdx.x < 128) {
     // the embedding tables go kernarg -> LDS through the kernarg segment pointer: indexing the by-value struct with
@@ -166,17 +171,17 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
     *(float*)(smem + p.par_off + threadIdx.x * 4) = ((const __attribute__((address_space(4))) float*)ka)[threadIdx.x];
   }
   const uint32_t par_nerf_xyz = p.par_off, par_nerf_ext = p.par_off + 128, par_nof_xyz = p.par_off + 256;
-  Stream st;
+  StreamT<NW> st;
   st.tl.start(p.alphas, id);
-  Carry carry;
+  typename std::conditional<X3, CarryX, Carry>::type carry;
   const Next prog_first = MOCO ? first_of<8, kKsNofXyz, true>(p.bw) : first_of<16, kKsNerfXyz, X3>(p.nerf);
   int seq = 0;                       // NoF evaluations done by this workgroup: evaluation number `seq` reads buffer seq & 1
   if (MOCO) {                        // rows of the first evaluation (first group, tile 0, bw at index i)
     const long long g0 = blockIdx.x;
     const int nr0 = (int)((p.n_rays - g0 * p.G) < p.G ? (p.n_rays - g0 * p.G) : p.G);
     int f0, n0;
-    tile_rays(0, nr0, p.S, f0, n0);
-    stage_raybias(p, g0 * p.G + f0, n0, 0, p.rb_off, id);
+    tile_rays<TILE>(0, nr0, p.S, f0, n0);
+    stage_raybias<NW>(p, g0 * p.G + f0, n0, 0, p.rb_off, id);
   }
   if (MOCO) start_program<8, kKsNofXyz, true>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);   // (its wait + barrier also publish the resident blocks / tables)
   else start_program<16, kKsNerfXyz, X3>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
@@ -190,11 +195,11 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
     const long long ray0 = group * p.G;
     const int nr = (int)((p.n_rays - ray0) < p.G ? (p.n_rays - ray0) : p.G);
     const int nsamp = nr * S;
-    const int ntiles = (nsamp + bf::kTile - 1) / bf::kTile;
+    const int ntiles = (nsamp + TILE - 1) / TILE;
 
     for (int tile = 0; tile < ntiles; ++tile) {
       st.tl.stamp(1, id);
-      const int srel = tile * bf::kTile + id.wave * kWaveSamples + id.j;
+      const int srel = tile * TILE + id.wave * kWaveSamples + id.j;
       const bool valid = srel < nsamp;
       const int sl = valid ? srel : nsamp - 1;
       const int rr = sl / S;
@@ -235,7 +240,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
           // per-ray bias of this (network, image index): rows bw(i), fw(i), fw(j), bw(j) of the table (the final fw(i) is
           // row 1), staged in LDS one evaluation ahead
           int tf, tn;
-          tile_rays(tile, nr, S, tf, tn);
+          tile_rays<TILE>(tile, nr, S, tf, tn);
           LdsRayBias rb{p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes + (uint32_t)(rr - tf) * (uint32_t)(p.rb_layers * 512)};
           ++seq;
           if (role == 1 || role == 2) { cur[0] = canon[0]; cur[1] = canon[1]; cur[2] = canon[2]; }
@@ -246,7 +251,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
           float out[3];
           nof_embed(nhi, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
           auto stage_next = [&] {
-            if (!last) stage_raybias(p, ray0 + tf, tn, role + 1 == 4 ? 1 : role + 1, p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes, id);
+            if (!last) stage_raybias<NW>(p, ray0 + tf, tn, role + 1 == 4 ? 1 : role + 1, p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes, id);
           };
           if constexpr (X3) nof_eval_x3(net, nhi, nlo, cur, st, carry, id, follow, out, rb, stage_next);
           else nof_eval(net, nhi, nlo, cur, st, carry, id, follow, out, rb, nullptr, stage_next);
@@ -271,8 +276,8 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
         if (ng < p.n_groups) {
           const int nnr = (int)((p.n_rays - ng * p.G) < p.G ? (p.n_rays - ng * p.G) : p.G);
           int nf, nn;
-          tile_rays(more ? tile + 1 : 0, nnr, S, nf, nn);
-          stage_raybias(p, ng * p.G + nf, nn, 0, p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes, id);
+          tile_rays<TILE>(more ? tile + 1 : 0, nnr, S, nf, nn);
+          stage_raybias<NW>(p, ng * p.G + nf, nn, 0, p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes, id);
         }
       }
       st.tl.stamp(3, id);
@@ -331,7 +336,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel_bf16(const Params p
     st.tl.stamp(6, id);
 
     // ---- composite (rendering.py:157-192): one wave per ray, lanes over samples
-    for (int rr = id.wave; rr < nr; rr += kWaves) {
+    for (int rr = id.wave; rr < nr; rr += NW) {
       const long long ray = ray0 + rr;
       const float* rp = p.rays + ray * p.ray_stride;
       const float dnorm = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);  // rendering.py:164
@@ -534,6 +539,7 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
   p.rgb = a->rgb; p.depth = a->depth; p.opacity = a->opacity; p.weights = a->weights; p.alphas = a->alphas;
   p.disp_local = a->disp_local; p.disp_global = a->disp_global;
 
+  const int tile_samples = x3 ? 4 * bf::kWaveSamples : bf::kTile;      // x3: 4 waves per workgroup
   uint32_t lds = 0;
   auto net_of = [&](const NetLayout& L, const void* packed, int D, int aux) {
     Net n;
@@ -590,8 +596,8 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
   p.buf_bytes = (uint32_t)max_groups * kGroupBytes;
   lds += 3 * p.buf_bytes;
   if (moco) {
-    // two buffers of per-ray bias rows: a 256-sample tile touches at most (255 / S) + 2 rays
-    const int r_max = (bf::kTile - 1) / a->n_samples + 2;
+    // two buffers of per-ray bias rows: a tile of T samples touches at most ((T - 1) / S) + 2 rays
+    const int r_max = (tile_samples - 1) / a->n_samples + 2;
     p.rb_buf_bytes = (uint32_t)round_up((int64_t)r_max * p.rb_layers * 512, 1024);
     p.rb_off = lds; lds += 2 * p.rb_buf_bytes;
     if (lds + 20u * (uint32_t)a->n_samples > 160u * 1024u)
@@ -599,18 +605,18 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
                   "(%d rays); use MF_PREC_F32 for such short rays", a->n_samples, r_max);
   }
 
-  // rays per group: smallest G with G*S a multiple of the 256-sample tile, capped by the LDS left
+  // rays per group: smallest G with G*S a multiple of the tile (256 samples; x3: 128), capped by the LDS left
   const uint32_t lds_cap = 160 * 1024;
   const int max_samples = (int)((lds_cap - lds) / 20);
   const int S = a->n_samples;
   if (S > max_samples) return fail(MF_E_UNSUPPORTED, "mf_render_pass: n_samples=%d exceeds the %d samples a workgroup can stage", S, max_samples);
   int G = 1;
-  while ((G * S) % bf::kTile != 0 && (G + 1) * S <= max_samples && G < 64) ++G;
-  if ((G * S) % bf::kTile != 0) {           // no exact fit: take as many rays as reduce the padding waste
+  while ((G * S) % tile_samples != 0 && (G + 1) * S <= max_samples && G < 64) ++G;
+  if ((G * S) % tile_samples != 0) {        // no exact fit: take as many rays as reduce the padding waste
     int best = 1; double best_eff = 0;
     for (int g = 1; g * S <= max_samples && g <= 64; ++g) {
-      const int tiles = (g * S + bf::kTile - 1) / bf::kTile;
-      const double eff = (double)(g * S) / (tiles * bf::kTile);
+      const int tiles = (g * S + tile_samples - 1) / tile_samples;
+      const double eff = (double)(g * S) / (tiles * tile_samples);
       if (eff > best_eff + 1e-9) { best_eff = eff; best = g; }
     }
     G = best;
@@ -626,7 +632,7 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
                                   : (moco ? render_kernel_bf16<true, false> : render_kernel_bf16<false, false>);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(x3 ? 256 : kThreads), lds, st, p);
   return check_launch("mf_render_pass(bf16)");
 }
 

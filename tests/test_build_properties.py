@@ -39,7 +39,7 @@ def _compile(unit, extra):
 def test_inference_kernels_have_no_spills_and_stream_weights_by_buffer_dma():
     with ThreadPoolExecutor(2) as ex:
         f32 = ex.submit(_compile, "mf_render", [])
-        b16 = ex.submit(_compile, "mf_render_bf16", ["-fno-slp-vectorize"])      # csrc/Makefile builds this unit so
+        b16 = ex.submit(_compile, "mf_render_bf16", ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"])      # csrc/Makefile builds this unit so
         (u32, a32), (u16, a16) = f32.result(), b16.result()
     # render_kernel<MOCO, DUMP>: the two inference instantiations (DUMP = false) and every bf16 kernel
     x3 = [k for k in u16 if re.search(r"render_kernel_bf16ILb[01]ELb1EE", k)]          # <MOCO, X3 = true>

@@ -134,6 +134,8 @@ class NeRFEmu(R.NeRF):
                 elif last and o["last"] == "wsplit":          # weights split, activations plain: two products
                     Wa, Wb = split(Wh)
                     acc = acc + F.linear(bf(h), Wa) + F.linear(bf(h), Wb)
+                elif o.get("hidden") == "split":             # every hidden layer in three products
+                    acc = acc + lin_split(h, Wh)
                 elif o.get("hidden") == "wsplit":
                     Wa, Wb = split(Wh)
                     acc = acc + F.linear(bf(h), Wa) + F.linear(bf(h), Wb)
@@ -149,9 +151,10 @@ class NeRFEmu(R.NeRF):
             sigma = F.linear(bf(h), p["sigma.weight"], p["sigma.bias"])        # fp32 weights x bf16 activations
         if sigma_only:
             return sigma
-        feat = lin_plain(h, p["xyz_encoding_final.weight"]) + p["xyz_encoding_final.bias"]
-        e = F.relu(lin_plain(torch.cat([feat, extra], -1), p["extra_encoding.0.weight"]) + p["extra_encoding.0.bias"])
-        rgb = torch.sigmoid(F.linear(bf(e), p["rgb.0.weight"], p["rgb.0.bias"]))
+        tail = lin_split if o.get("tail") == "split" else lin_plain
+        feat = tail(h, p["xyz_encoding_final.weight"]) + p["xyz_encoding_final.bias"]
+        e = F.relu(tail(torch.cat([feat, extra], -1), p["extra_encoding.0.weight"]) + p["extra_encoding.0.bias"])
+        rgb = torch.sigmoid(F.linear(e if o.get("tail") == "split" else bf(e), p["rgb.0.weight"], p["rgb.0.bias"]))
         return torch.cat([rgb, sigma], -1)
 
 
@@ -178,6 +181,8 @@ VARIANTS = {
     "x3_l1p":   (dict(ind_exact=True, head="split", hidden="split", act_plain_layers=(1,)), dict(last="plain", emb="plain")),
     "bias_in2":  (dict(ind_exact=True, head="split_w", hidden="plain", xyz="in_split"), dict(last="plain", emb="plain")),
     "bias_w2":   (dict(ind_exact=True, head="split_w", hidden="plain", xyz="w_split"), dict(last="plain", emb="plain")),
+    "x3full":  (dict(ind_exact=True, head="split", hidden="split"), dict(last="split", emb="split", hidden="split", tail="split")),
+    "x3hid":   (dict(ind_exact=True, head="split", hidden="split"), dict(last="split", emb="split", hidden="split")),
     "x3sn":    (dict(ind_exact=True, head="split", hidden="split"), dict(last="split", emb="split")),
 }
 
