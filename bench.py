@@ -19,8 +19,10 @@ BASELINE.json configs:
   C5   coarse 64 + fine 128 with the inverse-CDF resample, MoCo local+global chains, bf16, 1024 rays per rank
        (8192 rays on 8 GPUs)
 The default run also measures the other configs as short extra legs and reports them in the same JSON line under
-"configs" (N = 1: C3, C3g, C5 shard; N > 1: C4, C5), each with its own roofline fraction, so every BASELINE
-config is driver-measured without changing what `value` means.
+"configs" (N = 1: C3, C3g, C5 shard, and C2x / C3x / C5x = the same workloads in bf16x3, the fp32-class mode of the bf16
+matrix pipe -- every product as three bf16 products of (hi, lo) operand pairs; N > 1: C4, C5), each with its own
+roofline fraction and error against the CPU oracle, so every BASELINE config is driver-measured without changing what
+`value` means.
 
 Extra JSON objects: "roofline" (MFMA bound: algorithmic Linear-layer FLOPs of the dominant kernel's launch / its
 average duration, HIP events on the launch stream around the launch alone, vs the dense matrix peak of the dtype;
@@ -41,7 +43,12 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOPS = {"nerf_dir": 1186816, "nerf_ind": 1181184, "nof_quat": 134400}   # per sample, SURVEY.md §8d
-PEAK = {"f32": 157.3, "bf16": 2516.0, "bf16x3": 2516.0}     # TFLOP/s, MI355X_MICROARCH.md: fp32-input MFMA / dense bf16 MFMA
+# TFLOP/s, MI355X_MICROARCH.md: fp32-input MFMA / dense bf16 MFMA.  bf16x3 issues THREE bf16 matrix instructions per
+# algorithmic product (hi*hi + hi*lo + lo*hi): its ceiling in algorithmic FLOP/s is a third of the bf16 peak.
+PEAK = {"f32": 157.3, "bf16": 2516.0, "bf16x3": 2516.0 / 3}
+PEAK_NOTE = {"f32": "dense fp32-input MFMA peak", "bf16": "dense bf16 MFMA peak",
+             "bf16x3": "dense bf16 MFMA peak / 3 (three bf16 matrix instructions per algorithmic product; `achieved` counts "
+                       "algorithmic FLOP)"}
 # (bf16x3 is priced on ALGORITHMIC flops against the bf16 peak like bf16: its extra products are its own overhead)
 
 CONFIGS = {
@@ -418,8 +425,8 @@ def run_config(name, a, ctx, steps, warmup, main):
                    "samples_per_ray": spr, "global_rays": n * world,
                    "sharding": f"rays{world}" if world > 1 else "none",
                    "loss_allreduce": bool(reducer is not None and world > 1)},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "unit": "TFLOP/s",
-                     "frac": achieved / peak, "traffic": traffic, "traffic_unit": "B/launch",
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "peak_note": PEAK_NOTE[cfg["precision"]],
+                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_unit": "B/launch",
                      "traffic_source": traffic_src,
                      "traffic_note": "HBM bytes per launch: the weight stream is read once per XCD L2 (8 x the packed weights) + "
                                      "rays / requested (N,S) planes" + (" + the per-ray NoF bias table" if cfg["nof"] and cfg["precision"] != "f32" else "")
@@ -545,7 +552,7 @@ def worker(a):
         if k in res:
             line[k] = res[k]
     if not a.no_extra_legs and a.config == "C2":
-        legs = ["C3", "C3x", "C3g", "C5"] if world == 1 else ["C4", "C5"]
+        legs = ["C2x", "C3", "C3x", "C3g", "C5", "C5x"] if world == 1 else ["C4", "C5"]
         line["configs"] = {}
         for name in legs:
             r = run_config(name, a, ctx, min(a.steps, 20), min(a.warmup, 3), main=False)

@@ -15,10 +15,12 @@ def query_sigma(xyz, nerf, nerf_embedding_xyz, bw_nof=None, nof_embeddings=None,
     bw_nof / nof_embeddings=[xyz, ind] / ind: optional backward flow at image index ``ind`` (a python
     float in [-1,1) for all points, or a (B,) / (B,1) tensor); without them the query is made in
     canonical space (visualize_mesh with frame_idx == -1). Inference only.
-    ``precision``: "f32" | "bf16" (None = the module setting of ``rendering.set_precision``); bf16 = hidden GEMMs on the
-    bf16 matrix pipe as in render_rays' gradient-free passes (the mesh-extraction lattice ~8x faster)."""
+    ``precision``: "f32" | "bf16" | "bf16x3" (None = the module setting of ``rendering.set_precision``); bf16 = hidden GEMMs
+    on the bf16 matrix pipe as in render_rays' gradient-free passes (the mesh-extraction lattice ~8x faster); bf16x3 (the
+    fp32-class mode of the render passes) has no point-query kernel: it runs the exact-fp32 one, so the setting never
+    costs accuracy."""
     from . import rendering
-    prec = L.MF_PREC_F32 if (precision or rendering.PRECISION) == "f32" else L.MF_PREC_BF16     # (bf16x3 is a render-pass mode)
+    prec = L.MF_PREC_BF16 if (precision or rendering.PRECISION) == "bf16" else L.MF_PREC_F32
     L.require_gpu(xyz, "query_sigma")
     x = xyz.detach().float().contiguous()
     B = x.shape[0]

@@ -456,8 +456,18 @@ BF16_BARS = {"r_nerf_dir_dense":      (58.0,                3e-3,        2e-3),
              "r_moco_global_fine":    (48.0,                8e-3,        2e-3)}
 
 
+# the same fixtures in bf16x3: PSNR-equiv / l2-rel / max-rel bars (1e-4 max-rel = the fp32 contract, except where the
+# fixture's own fp32 conditioning is worse: see the per-case note)
+X3_BARS = {"r_nerf_dir_dense":      (100.0, 3e-5, 3e-5, 1e-4),
+           "r_nerf_dir_fine_train": (100.0, 3e-5, 3e-5, 1e-4),
+           "r_nerf_dir_default":    (110.0, 1e-5, 1e-5, 1e-4),
+           "r_moco_global":         (95.0,  5e-5, 5e-5, 1e-4),
+           "r_moco_global_fine":    (95.0,  5e-5, 5e-5, 1e-4)}
+
+
+@pytest.mark.parametrize("precision", ["bf16", "bf16x3"])
 @pytest.mark.parametrize("name", sorted(BF16_BARS))
-def test_bf16_hidden_gemms(M, R, name):
+def test_bf16_hidden_gemms(M, R, name, precision):
     """BASELINE configs C3-C5: bf16 hidden GEMMs (fp32 accumulate; the NoF's embedded-input k-ranges and head as a
     16-bit two-term bf16 split, the NeRF's encodings as plain bf16 operands -- measured 90.4 dB at default init (95.0
     with the split), 61.8 dB dense (unchanged); heads and composite in fp32).  Not the 1e-4 contract -- north_star allows a PSNR-equivalent
@@ -473,7 +483,7 @@ def test_bf16_hidden_gemms(M, R, name):
     bg = torch.from_numpy(g["in_background"]).cuda() if c.get("bg", True) else None
     cap = {}
     try:
-        rendering.set_precision("bf16")
+        rendering.set_precision(precision)
         with torch.no_grad():
             res = M.render_rays(rays, bg, embs, nerfs, _capture=cap, **kw)
     finally:
@@ -485,12 +495,14 @@ def test_bf16_hidden_gemms(M, R, name):
             w2 = R.render_rays(rays.cpu(), bg.cpu() if bg is not None else None, embs_o, nerfs_o,
                                _z_fine_override=cap["z_fine"].cpu(), **kw_o)
         want.update({k: v for k, v in w2.items() if "fine" in k})
-    bar_db, bar_rgb, bar_other = BF16_BARS[name]
+    bar_db, bar_rgb, bar_other = BF16_BARS[name] if precision == "bf16" else X3_BARS[name][:3]
     for k, v in want.items():
         if k.startswith("nof_"):
             continue
         ps, l2 = _psnr(res[k], v), _l2rel(res[k], v)
-        print(f"{name} {k}: bf16 PSNR-equiv {ps:.1f} dB, l2-rel {l2:.2e}, max-rel {relerr(res[k], v):.2e}")
+        print(f"{name} {k}: {precision} PSNR-equiv {ps:.1f} dB, l2-rel {l2:.2e}, max-rel {relerr(res[k], v):.2e}")
+        if precision == "bf16x3":
+            assert relerr(res[k], v) <= X3_BARS[name][3], (k, relerr(res[k], v))
         if k.startswith("rgb"):
             assert ps >= bar_db, (k, ps)
             assert l2 <= bar_rgb, (k, l2)
@@ -505,7 +517,9 @@ def test_bf16_every_case_shape(M, R, name, precision):
     disparity sampling, no background, none / ind / dir extra blocks, muted and absent frequencies, flow head, bw-only
     and local chains, the test-time sigma-only coarse pass, N = 0): same keys and shapes as the reference, per-ray
     outputs within the generic bf16 band (rgb >= 36 dB, l2-rel <= 6e-2) -- a wrong sample-to-lane map or head is
-    orders of magnitude outside it.  The tight per-case bars are test_bf16_hidden_gemms'."""
+    orders of magnitude outside it.  The tight per-case bars are test_bf16_hidden_gemms'.
+    bf16x3 (three bf16 products per matrix product, fp32 accumulation and heads): held to the fp32 contract, 1e-4 max-rel
+    on every per-ray output."""
     from moco_flow_amd import rendering
     c = dict(RENDER_CASES[name])
     g = load_golden(name)
@@ -548,6 +562,12 @@ def test_bf16_every_case_shape(M, R, name, precision):
         if v.numel() == 0 or (flip_prone and k.endswith("_fine")):
             continue
         ps, l2 = _psnr(res[k], v), _l2rel(res[k], v)
+        print(f"{name} [{precision}] {k}: PSNR-equiv {ps:.1f} dB, l2-rel {l2:.2e}, max-rel {relerr(res[k], v):.2e}")
+        if precision == "bf16x3":
+            # every matrix product as three bf16 products of (hi, lo) pairs: the fp32 contract itself (north_star: 1e-4
+            # max-rel; measured <= 4.6e-5 over all fixtures, fp32 kernels <= 2e-5)
+            assert relerr(res[k], v) <= TOL, (k, relerr(res[k], v))
+            continue
         if k.startswith("rgb"):
             assert ps >= 36.0, (k, ps)
         assert l2 <= 6e-2, (k, l2)
@@ -641,20 +661,21 @@ def test_c3_full_size_bf16_vs_oracle(M, R, name, draw):
             assert abs(res[k].shape[0] - want[k].shape[0]) <= 0.02 * want[k].shape[0], k
 
 
-# bf16x3 (MF_PREC_BF16X3): the chain must cost no accuracy beyond the NeRF's own bf16 hidden layers.  tools/bf16_emulate.py
-# (CPU emulation of the arithmetic) predicts, at 4096 rays: bench draw 60.1 dB (fast mode 51.4; exact-fp32 NoF with the
-# same NeRF arithmetic 59.5), golden-case draw 47.7 dB (38.1; 47.9) -- the 48 dB of the case draw is the NeRF's plain bf16
-# hidden layers on that weight draw, not the chain.  Bars a couple of dB under the measured values.
+# bf16x3 (MF_PREC_BF16X3): every matrix product of both networks as three bf16 products of (hi, lo) operand pairs, fp32
+# accumulation, heads and per-ray image-index bias.  tools/bf16_emulate.py ("x3full") predicts 98-108 dB; measured at 4096
+# rays: bench draw 104.4 dB, l2 1.1e-5 / 8.2e-6 / 1.7e-6 (the fp32 kernels: 123 dB, 1.3e-6); golden-case draw 88.6 dB, l2
+# 9.0e-5 / 2.4e-4 / 1.3e-4 (fp32 kernels: 118.7 dB -- that draw's dense NoF amplifies the 2^-17 of the split ~30x more).
+# Round 3's first bf16x3 (NoF and the NeRF's last layer only) gave 60.4 / 47.0 dB, the fast mode 51.4 / 38.1.
 #                 draw     tags         PSNR   l2 rgb   l2 depth  l2 opacity
-C3_X3_BARS = {"bench": (BENCH_TAGS, 57.0, 2.6e-3, 5e-3, 2.5e-3), "case": (None, 45.0, 1.4e-2, 2.6e-2, 1.4e-2)}
+C3_X3_BARS = {"bench": (BENCH_TAGS, 100.0, 3e-5, 3e-5, 1e-5), "case": (None, 84.0, 2e-4, 5e-4, 3e-4)}
 
 
 @pytest.mark.parametrize("draw", sorted(C3_X3_BARS))
 @pytest.mark.parametrize("name", ["r_moco_local", "r_moco_global"])
 def test_c3_full_size_bf16x3_vs_oracle(M, R, name, draw):
-    """BASELINE config C3 in the accuracy mode of the bf16 pipe (set_precision("bf16x3")): NoF hidden GEMMs and head as
-    three bf16 products per term, NeRF encodings split, last trunk layer with split weights, sigma head on fp32
-    accumulators -- against the fp32 oracle, and against the fast bf16 mode on the same batch (must be >= 5 dB better)."""
+    """BASELINE config C3 in the accuracy mode of the bf16 pipe (set_precision("bf16x3")): every matrix product as
+    three bf16 products, heads on fp32 accumulators -- against the fp32 oracle, and against the fast bf16 mode on the same
+    batch (must be >= 40 dB better)."""
     tags, bar_db, bar_rgb, bar_depth, bar_op = C3_X3_BARS[draw]
     c, res, want = _full_size_case(M, R, name, 4096, "bf16x3", tags=tags)
     _, fast, _ = _full_size_case(M, R, name, 4096, "bf16", tags=tags)
@@ -662,26 +683,28 @@ def test_c3_full_size_bf16x3_vs_oracle(M, R, name, draw):
     l2 = {k: _l2rel(res[k], want[k]) for k in ("rgb_coarse", "depth_coarse", "opacity_coarse")}
     print(f"C3 {name} bf16x3 [{draw} draw]: PSNR-equiv {ps:.1f} dB (fast bf16: {ps_fast:.1f}); l2-rel rgb {l2['rgb_coarse']:.2e} "
           f"depth {l2['depth_coarse']:.2e} opacity {l2['opacity_coarse']:.2e}")
-    assert ps >= bar_db and ps >= ps_fast + 5.0
+    assert ps >= bar_db and ps >= ps_fast + 40.0
     assert l2["rgb_coarse"] <= bar_rgb and l2["depth_coarse"] <= bar_depth and l2["opacity_coarse"] <= bar_op
     for k in want:
         if k.startswith("nof_"):
-            assert abs(float(res[k].mean()) - float(want[k].mean())) <= 2e-3 * abs(float(want[k].mean())), k
-            assert abs(res[k].shape[0] - want[k].shape[0]) <= 0.01 * want[k].shape[0], k
+            assert abs(float(res[k].mean()) - float(want[k].mean())) <= 5e-4 * abs(float(want[k].mean())), k
+            assert abs(res[k].shape[0] - want[k].shape[0]) <= 0.002 * want[k].shape[0] + 2, k
 
 
 def test_c5_shard_shape_bf16x3_vs_oracle(M, R):
     """BASELINE config C5's shard (1024 rays x (64 + 128), two NeRFs, local + global chains) in bf16x3, both passes
-    against the oracle on identical samples; emulation: rgb_fine 57.1 dB (fast mode 52.7), rgb_coarse 48.5 (39.9)."""
+    against the oracle on identical samples.  Measured: rgb_fine 108.5 dB / l2 5.3e-6 (fast mode 52.7 dB), rgb_coarse 82.9
+    dB / 1.8e-4 (39.9; the coarse NeRF of this fixture is the dense golden-case draw)."""
     c, res, want = _full_size_case(M, R, "r_moco_global_fine", 1024, "bf16x3")
     for k in ("rgb_coarse", "rgb_fine", "depth_coarse", "depth_fine", "opacity_coarse", "opacity_fine"):
-        print(f"C5 shard bf16x3 {k}: PSNR-equiv {_psnr(res[k], want[k]):.1f} dB, l2-rel {_l2rel(res[k], want[k]):.2e}")
-    assert _psnr(res["rgb_fine"], want["rgb_fine"]) >= 54.0 and _l2rel(res["rgb_fine"], want["rgb_fine"]) <= 3e-3
-    assert _psnr(res["rgb_coarse"], want["rgb_coarse"]) >= 45.0 and _l2rel(res["rgb_coarse"], want["rgb_coarse"]) <= 1.4e-2
+        print(f"C5 shard bf16x3 {k}: PSNR-equiv {_psnr(res[k], want[k]):.1f} dB, l2-rel {_l2rel(res[k], want[k]):.2e}, "
+              f"max-rel {relerr(res[k], want[k]):.2e}")
+    assert _psnr(res["rgb_fine"], want["rgb_fine"]) >= 100.0 and _l2rel(res["rgb_fine"], want["rgb_fine"]) <= 2e-5
+    assert _psnr(res["rgb_coarse"], want["rgb_coarse"]) >= 78.0 and _l2rel(res["rgb_coarse"], want["rgb_coarse"]) <= 4e-4
     for k in ("depth_coarse", "opacity_coarse"):
-        assert _l2rel(res[k], want[k]) <= 3e-2, k
-    for k in ("depth_fine", "opacity_fine"):
-        assert _l2rel(res[k], want[k]) <= 2e-3, k
+        assert _l2rel(res[k], want[k]) <= 1e-3, k
+    for k in ("rgb_fine", "depth_fine", "opacity_fine"):
+        assert relerr(res[k], want[k]) <= TOL, k          # the fine pass: the fp32 contract
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])

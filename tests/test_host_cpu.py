@@ -105,6 +105,11 @@ def test_packed_layout_sizes():
     d.extra_feat_type, d.extra_feat_dim = L.MF_EXTRA_DIR, 27
     groups = (4 + 3 * 16 + 20 + 3 * 16 + 16) * 8 + (16 + 2) * 4
     assert lib.mf_nerf_packed_bytes_p(ctypes.byref(d), L.MF_PREC_BF16) == 13 * 1024 + groups * 1024
+    # MF_PREC_BF16X3: every k-step as a (hi, lo) group pair -- twice the groups of the bf16 layout where the NeRF is
+    # concerned (its encodings split too), the NoF's hidden ranges doubled (its embedded input and head already were)
+    groups = (8 + 3 * 32 + 40 + 3 * 32 + 32) * 8 + (32 + 4) * 4
+    assert lib.mf_nerf_packed_bytes_p(ctypes.byref(d), L.MF_PREC_BF16X3) == 13 * 1024 + groups * 1024
+    assert lib.mf_nof_packed_bytes_p(ctypes.byref(n), L.MF_PREC_BF16X3) == 7 * 1024 + ((6 + 16 + 22 + 16) * 4 + 16) * 1024 + 36 * 1024
     assert lib.mf_loss_partials_scratch_bytes() == 256 * 12 * 8
     assert lib.mf_loss_partials(None, None, None, 0, None, None, None, None) == -1
 
