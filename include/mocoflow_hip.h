@@ -50,10 +50,12 @@ enum { MF_MAX_FREQS = 16, MF_MAX_LAYERS = 16 };
  * activations rounded to bf16 (RNE), fp32 accumulate (v_mfma_f32_32x32x16_bf16, 32 samples per wave); the
  * embedded-input k-ranges and the NoF head use a two-term bf16 split (16 mantissa bits); biases, the NeRF
  * heads and the composite stay fp32 (BASELINE configs C3-C5).
- * BF16X3 (ABI v12): the accuracy mode of the bf16 pipe for the MoCo chain, whose canonical point feeds sin(512 x): the
- * NoF's hidden GEMMs and head as three bf16 products per term (activations AND weights split hi + lo, 16 mantissa
- * bits), the NeRF's encodings split like the NoF's, its last trunk layer with split weights and the sigma head on that
- * layer's fp32 accumulators; everything else as BF16.  ~1.4x the matrix work of BF16, still ~4x faster than F32. */
+ * BF16X3 (ABI v12): fp32-class results on the bf16 pipe -- EVERY matrix product of the NeRF and the NoFs as a two-term
+ * bf16 split of activations AND weights (hi + lo, 16 mantissa bits each), three products hi*hi + hi*lo + lo*hi with fp32
+ * accumulation; sigma / rgb heads as fp32 dot products on the fp32 accumulators; the NoF's image index an exact fp32
+ * per-ray bias.  Three bf16 matrix instructions per product where F32 costs sixteen: ~1/3 of F32's time at <= 5e-5
+ * max-rel on the reference's golden vectors.  Own packed layout (every k-step a (hi, lo) group pair); render passes only
+ * (mf_points_sigma_p takes F32 | BF16). */
 enum { MF_PREC_F32 = 0, MF_PREC_BF16 = 1, MF_PREC_BF16X3 = 2 };
 
 /* ---- Embedding: models/embedding.py:4-47 ------------------------------------

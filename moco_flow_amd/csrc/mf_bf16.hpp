@@ -81,6 +81,14 @@ struct StreamT {
     if (jump) gnext = jump;
     // this wave's pieces: a BLOCK of consecutive groups (wave w: groups w per .. w per + per - 1), so that they share one
     // base / M0 and differ in the instruction offset only
+#ifdef MF_BF_DMA_RR                           // (A/B: round 2's round-robin assignment, groups wave, wave + NW, ...)
+    dsrc = gnext + id.wave * kGroupBytes;
+    ddst = off2 + id.wave * kGroupBytes;
+    const int mine_rr = (groups - id.wave + NW - 1) / NW;
+    pmask = (1u << (mine_rr < 0 ? 0 : mine_rr)) - 1u;
+    gnext += (size_t)groups * kGroupBytes;
+    return;
+#endif
     const int per = (groups + NW - 1) / NW;
     const int first = id.wave * per;
     dsrc = gnext + first * kGroupBytes;
@@ -90,6 +98,10 @@ struct StreamT {
     gnext += (size_t)groups * kGroupBytes;
   }
   MF_D void piece(int k, const Lane& id) {
+#ifdef MF_BF_DMA_RR
+    if ((pmask >> k) & 1u) blds16(dsrc, id.lane * 16, k * (NW * kGroupBytes), ddst + k * (NW * kGroupBytes));
+    return;
+#endif
 #ifndef MF_BF_ABL_NODMA
     if ((pmask >> k) & 1u) {
       const uint32_t hi = (uint32_t)(k >> 2) * (4 * kGroupBytes);

@@ -22,9 +22,9 @@ from . import autograd as A
 # reference's arithmetic, BASELINE configs C1-C2; default); "bf16" = bf16 operands with fp32
 # accumulate (BASELINE configs C3-C5), the NoF's xyz block as a two-term bf16 split (16 mantissa
 # bits), its image-index block as an exact fp32 per-ray bias, heads and composite in fp32;
-# "bf16x3" = the accuracy mode of the bf16 pipe for the MoCo chain (include/mocoflow_hip.h, MF_PREC_BF16X3: the NoF's
-# hidden GEMMs and head as three bf16 products per term, NeRF encodings split, its last trunk layer with split
-# weights, sigma head on fp32 accumulators: the chain then costs no accuracy beyond the NeRF's own bf16 hidden layers).
+# "bf16x3" = fp32-class results on the bf16 pipe (include/mocoflow_hip.h, MF_PREC_BF16X3: every matrix product of both
+# networks as three bf16 products of (hi, lo) operand pairs, fp32 accumulation, heads on the fp32 accumulators: <= 5e-5
+# max-rel on the golden vectors at about a third of the fp32 kernels' time).
 # The reference's render_rays signature has no such knob, so it is a module setting.
 PRECISION = "f32"
 
