@@ -33,8 +33,9 @@ extern "C" {
  * 10: mf_nerf_forward_dump, mf_render_args.dump_nof_* (+ mf_nof_emb_slot_features), mf_smpl_lbs,
  *     mf_smpl_frame_transforms, mf_apply_vertex_transforms
  * 12: MF_PREC_BF16 NoF takes its image-index block as a per-ray fp32 bias: mf_render_args.workspace(+_bytes),
- *     mf_render_workspace_bytes, mf_render_prepare, mf_loss_partials_backward, perturb arguments of mf_z_vals, mf_points_sigma_workspace_bytes, workspace arguments of mf_points_sigma_p */
-#define MF_ABI_VERSION 12
+ *     mf_render_workspace_bytes, mf_render_prepare, mf_loss_partials_backward, perturb arguments of mf_z_vals, mf_points_sigma_workspace_bytes, workspace arguments of mf_points_sigma_p
+ * 13: MF_PREC_BF16X3 is the full three-product mode (own packed layout); mf_weight_grads_p, mf_weight_grads_scratch_bytes_p */
+#define MF_ABI_VERSION 13
 
 enum {
   MF_OK = 0,
@@ -205,6 +206,13 @@ typedef struct mf_wgrad_item {
 } mf_wgrad_item;
 int64_t mf_weight_grads_scratch_bytes(const mf_wgrad_item* items, int32_t n_items, int64_t P);
 int32_t mf_weight_grads(const mf_wgrad_item* items, int32_t n_items, int64_t P, void* scratch, void* stream);
+/* The same with the arithmetic of the contraction chosen (ABI v13).  MF_PREC_F32: exact-fp32 MFMA (the two calls above).
+ * MF_PREC_BF16X3: the large NeRF blocks (256x256, 128x256) contract G and X as two-term bf16 splits, three bf16
+ * products per 16-sample step with fp32 accumulation (16 mantissa bits per operand; a fifth of the fp32 pipe's matrix
+ * time, the launch then runs against the HBM reads of its operands); the other blocks stay fp32.  The scratch size
+ * depends on the precision. */
+int64_t mf_weight_grads_scratch_bytes_p(int32_t precision, const mf_wgrad_item* items, int32_t n_items, int64_t P);
+int32_t mf_weight_grads_p(int32_t precision, const mf_wgrad_item* items, int32_t n_items, int64_t P, void* scratch, void* stream);
 
 /* ---- backward of one NoF evaluation on points (rendering.py:49-83 + nof.py:69-82; ABI v5) ---------
  * mf_nof_points_dump: pts (P,3), per-ray image index ind[ray * ind_stride] with ray = sample / S ->

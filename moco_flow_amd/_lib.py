@@ -17,7 +17,7 @@ MF_ACT_RELU, MF_ACT_SOFTPLUS = 0, 1
 MF_F_SIGMA_ONLY, MF_F_CHAIN_LOCAL, MF_F_CHAIN_GLOBAL = 1, 2, 4
 MF_PREC_F32, MF_PREC_BF16, MF_PREC_BF16X3 = 0, 1, 2
 PRECISIONS = {"f32": MF_PREC_F32, "bf16": MF_PREC_BF16, "bf16x3": MF_PREC_BF16X3}
-MF_ABI_VERSION = 12
+MF_ABI_VERSION = 13
 
 LIB_PATH = os.environ.get("MOCOFLOW_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmocoflow_hip.so")   # (override: A/B builds)
 
@@ -116,6 +116,8 @@ SYMBOLS = {
     "mf_image_compose": (C.c_int32, [_fp, _fp, C.c_int64, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "mf_weight_grads_scratch_bytes": (C.c_int64, [C.POINTER(mf_wgrad_item), C.c_int32, C.c_int64]),
     "mf_weight_grads": (C.c_int32, [C.POINTER(mf_wgrad_item), C.c_int32, C.c_int64, _fp, _fp]),
+    "mf_weight_grads_scratch_bytes_p": (C.c_int64, [C.c_int32, C.POINTER(mf_wgrad_item), C.c_int32, C.c_int64]),
+    "mf_weight_grads_p": (C.c_int32, [C.c_int32, C.POINTER(mf_wgrad_item), C.c_int32, C.c_int64, _fp, _fp]),
     "mf_nerf_backward": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, C.c_int64, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp]),
     "mf_render_pass": (C.c_int32, [C.POINTER(mf_render_args), _fp]),
     "mf_render_workspace_bytes": (C.c_int64, [C.POINTER(mf_render_args)]),

@@ -103,9 +103,26 @@ _WG_BLOCK = {(256, 256): (256, 256), (256, 64): (256, 64), (128, 256): (128, 256
              (128, 128): (128, 128), (128, 80): (128, 80), (12, 128): (16, 128)}
 
 
+# Arithmetic of the weight-gradient contractions dW = G^T X (mf_weight_grads_p): "f32" = exact-fp32 MFMA; "bf16x3" = the
+# NeRF's large blocks (256x256, 128x256) as three bf16 products of (hi, lo) operand pairs with fp32 accumulation
+# (include/mocoflow_hip.h): 16 mantissa bits per operand, a sum over ~1e6 samples -- 7e-6 l2-rel against a float64 GEMM
+# where the fp32 MFMA measures 4e-6 (tools/bench_wgrad.py), every gradient test holds its bar in both (tests/conftest.py
+# `wgrad`) -- at 0.70x the time of the launch (it then runs against the HBM reads of its operands).  The default;
+# set_wgrad_precision("f32") restores the exact-fp32 contraction.
+WGRAD_PRECISION = "bf16x3"
+
+
+def set_wgrad_precision(p: str):
+    global WGRAD_PRECISION
+    if p not in ("f32", "bf16x3"):
+        raise ValueError(f"wgrad precision must be 'f32' or 'bf16x3', got {p!r}")
+    WGRAD_PRECISION = p
+
+
 def weight_grads(jobs, P, dev):
-    """mf_weight_grads: jobs = [(G, X, n_out, n_in, want_bias)] with G / X fp32 device matrices (column
-    slices allowed) -> [(dW (rows, n_in), db (rows,) | None)] in ONE persistent HIP launch."""
+    """mf_weight_grads_p: jobs = [(G, X, n_out, n_in, want_bias)] with G / X fp32 device matrices (column
+    slices allowed) -> [(dW (rows, n_in), db (rows,) | None)] in ONE persistent HIP launch (two when WGRAD_PRECISION is
+    "bf16x3": the blocks with a three-product variant and the rest)."""
     n = len(jobs)
     if n == 0:
         return []
@@ -124,12 +141,13 @@ def weight_grads(jobs, P, dev):
         it.dW, it.db = dW.data_ptr(), (db.data_ptr() if bias else None)
         outs.append((dW, db))
     lib = L.lib()
-    nbytes = lib.mf_weight_grads_scratch_bytes(items, n, P)
+    prec = L.PRECISIONS[WGRAD_PRECISION]
+    nbytes = lib.mf_weight_grads_scratch_bytes_p(prec, items, n, P)
     if nbytes < 0:
         L.check(-3, "mf_weight_grads")
     scratch = torch.empty(max(int(nbytes), 16), dtype=torch.uint8, device=dev)
     with torch.cuda.device(dev):
-        L.check(lib.mf_weight_grads(items, n, P, scratch.data_ptr(), L.current_stream(dev)), "mf_weight_grads")
+        L.check(lib.mf_weight_grads_p(prec, items, n, P, scratch.data_ptr(), L.current_stream(dev)), "mf_weight_grads")
     return outs
 
 

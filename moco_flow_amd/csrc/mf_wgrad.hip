@@ -45,6 +45,23 @@ using ShapeF = WgShape<128, 128, 2, 4, 2, 128>;   // NoF hidden x hidden
 using ShapeG = WgShape<128, 80, 1, 5, 1, 128>;    // NoF hidden x embedded input (66 -> 80)
 using ShapeH = WgShape<16, 128, 1, 1, 8, 12>;     // NoF head: d T (9 | 3, padded 12) x h_D
 
+// MF_PREC_BF16X3 variants of the large blocks (shape ids 8..): the contraction on v_mfma_f32_32x32x16_bf16 with G and X as
+// (hi, lo) bf16 pairs, three products per 16-sample k-step (wg_segment_x3).  8 waves as (8 / WAVES_C) x WAVES_C, each wave
+// WR x WC tiles of 32 x 32.
+template <int NOUT_, int NIN_, int WR_, int WC_, int WAVES_C_>
+struct WgShapeX {
+  static constexpr int NOUT = NOUT_, NIN = NIN_, WR = WR_, WC = WC_, WAVES_C = WAVES_C_;
+  static constexpr int PART_BYTES = (NOUT + NIN) * 2 * 16;          // one of (hi | lo): both sample octets of every feature
+  static constexpr int BUF_BYTES = 2 * PART_BYTES;                  // a stage's fragments: hi + lo
+  static constexpr int OUT_FLOATS = NOUT * NIN + NOUT;
+  static_assert((8 / WAVES_C) * WR * 32 == NOUT && WAVES_C * WC * 32 == NIN, "wave tiling must cover the block");
+  static_assert(NOUT + NIN <= kThreads && NOUT % 64 == 0 && NIN % 64 == 0, "one conversion unit per thread");
+};
+using ShapeAX = WgShapeX<256, 256, 4, 2, 4>;      // hidden x hidden
+using ShapeCX = WgShapeX<128, 256, 2, 2, 4>;      // extra_encoding x final
+// (a 128 x 128 variant for the NoF's hidden blocks measured no gain: those items already run against HBM in fp32)
+constexpr int kWgShapeX0 = 8;                     // first x3 shape id
+
 // cost of one stage of each block shape in CU cycles, MEASURED (tools/bench_wgrad.py: each shape alone at 1.3 M samples,
 // launch overhead subtracted).  Only the ratios matter: they decide where the linearised (item, stage) space is cut, and
 // a shape that is under-priced by 20 % makes its workgroups -- and the launch -- 20 % late (the first-principles model
@@ -59,7 +76,9 @@ MF_HD int wg_stage_cost(int shape) {
     case 4: return 4790;
     case 5: return 3440;
     case 6: return 2690;
-    default: return 2560;
+    case 7: return 2560;
+    case 8: return 5660;      // x3 variants (MF_WGRAD=bf16x3 tools/bench_wgrad.py; planned apart from the fp32 shapes)
+    default: return 4300;
   }
 }
 MF_HD int wg_out_floats(int shape) {
@@ -71,7 +90,9 @@ MF_HD int wg_out_floats(int shape) {
     case 4: return ShapeE::OUT_FLOATS;
     case 5: return ShapeF::OUT_FLOATS;
     case 6: return ShapeG::OUT_FLOATS;
-    default: return ShapeH::OUT_FLOATS;
+    case 7: return ShapeH::OUT_FLOATS;
+    case 8: return ShapeAX::OUT_FLOATS;
+    default: return ShapeCX::OUT_FLOATS;
   }
 }
 
@@ -273,6 +294,146 @@ MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, 
   }
 }
 
+// ---- MF_PREC_BF16X3: dW = G^T X with G and X as two-term bf16 splits, three products per k-step ----
+// The fp32 matrix pipe does 16 samples x 256 x 256 in 9 640 cycles per CU; three bf16 products of (hi, lo) pairs carry 16
+// mantissa bits per operand (the dropped lo*lo term is 2^-16 relative, the sum over samples accumulates in fp32 like the
+// fp32 MFMA's) at a fifth of the matrix time -- the launch then runs against the HBM reads of its two operands.
+// Stage = 16 samples = one k-step.  Thread t owns one conversion unit per stage -- two adjacent features x one sample
+// octet of G (t < NOUT) or of X (t - NOUT < NIN): eight 8-byte loads straight from HBM, issued two stages ahead into a
+// register pair set, (hi, lo) split in registers, four 16-byte LDS writes in the MFMA operand layout
+// [hi | lo][octet][feature][8 bf16] (A = G^T: 32 out-features x 16 samples, B = X: 16 samples x 32 in-features -- both
+// "one feature, eight consecutive samples" per lane).  No raw staging in LDS, no LDS-DMA; two fragment buffers, one
+// barrier per stage.  db: the G units' column sums (fp32) as a by-product of the conversion.
+typedef float wg_f2 __attribute__((ext_vector_type(2)));
+typedef __bf16 wg_bf2 __attribute__((ext_vector_type(2)));
+MF_D unsigned wg_pack(float a, float b) {
+  wg_f2 v; v[0] = a; v[1] = b;
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, wg_bf2));
+}
+typedef float f32x16w __attribute__((ext_vector_type(16)));
+
+template <class S>
+MF_D void wg_segment_x3(const WgItem& it, long long sb, long long se, long long P, float* part, const LaneId& id) {
+  constexpr int WR = S::WR, WC = S::WC;
+  const int tid = threadIdx.x;
+  const int lane = id.lane, li = lane & 31, lh = lane >> 5;
+  const int wr = id.wave / S::WAVES_C, wc = id.wave % S::WAVES_C;
+  const int row0 = wr * WR * 32, col0 = wc * WC * 32;
+  // conversion role of this thread
+  const bool is_g = tid < S::NOUT, is_x = !is_g && tid - S::NOUT < S::NIN;
+  const int ut = is_g ? tid : tid - S::NOUT, nf = is_g ? S::NOUT : S::NIN;
+  const int up = ut % (nf / 2), uh = ut / (nf / 2);                  // feature pair, sample octet
+  const float* src = is_g ? it.G : it.X;
+  const long long stride = is_g ? it.g_stride : it.x_stride;
+  const uint32_t reg0 = is_g ? 0u : (uint32_t)(2 * S::NOUT * 16);    // byte offset of this operand's region inside a part
+  const uint32_t wdst = reg0 + (uint32_t)((uh * nf + 2 * up) * 16);  // [octet][feature] x 16 bytes
+  __syncthreads();                                   // previous segment's readers are done with the buffers
+  f32x16w acc[WR][WC];
+#pragma unroll
+  for (int a = 0; a < WR; ++a)
+#pragma unroll
+    for (int b = 0; b < WC; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float bs0 = 0.f, bs1 = 0.f;
+  wg_f2 raw[2][8];
+  // Loads through a buffer descriptor: wave-uniform 64-bit base (this wave's octet of the stage: `uh` is the same for a
+  // whole wave, NOUT / 2 and NIN / 2 being multiples of 64) + ONE per-lane 32-bit offset + a scalar row offset -- no
+  // 64-bit address per lane and row -- and `num_records` = the bytes up to sample P, so rows past the last sample read 0.
+  const int voff = up * 8;
+  const long long row_bytes = stride * 4;
+  auto load = [&](wg_f2 (&r)[8], long long st) {
+    const long long s0 = st * kWgStage + 8 * uh;
+    const long long left = (st < se && (is_g || is_x)) ? (P - s0) * row_bytes : 0;
+    const unsigned recs = left <= 0 ? 0u : (left > 0xffffffffLL ? 0xffffffffu : (unsigned)left);
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + s0 * stride), 0, (int)recs, 0x00020000);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      typedef unsigned wg_u2 __attribute__((ext_vector_type(2)));
+      const wg_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (int)(e * row_bytes), 0);
+      r[e] = __builtin_bit_cast(wg_f2, v);
+    }
+  };
+  auto convert = [&](const wg_f2 (&r)[8], uint32_t buf) {
+    if (!(is_g || is_x)) return;
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {                    // the unit's two features, one after the other (8 live registers)
+      u32x4 hv, lv;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float a0 = r[2 * w][c], a1 = r[2 * w + 1][c];
+        const unsigned ha = wg_pack(a0, a1);
+        hv[w] = ha;
+        lv[w] = wg_pack(a0 - __builtin_bit_cast(float, ha << 16), a1 - __builtin_bit_cast(float, ha & 0xffff0000u));
+        if (c == 0) bs0 += a0 + a1; else bs1 += a0 + a1;
+      }
+      *reinterpret_cast<u32x4*>(smem + buf + wdst + 16 * c) = hv;
+      *reinterpret_cast<u32x4*>(smem + buf + S::PART_BYTES + wdst + 16 * c) = lv;
+    }
+  };
+  load(raw[0], sb);
+  load(raw[1], sb + 1);
+  convert(raw[0], 0);
+  load(raw[0], sb + 2);
+  // fragment addresses of this lane: A rows row0 + 32 ti + li, B columns col0 + 32 tj + li, octet lh
+  const uint32_t aoff = (uint32_t)((lh * S::NOUT + row0 + li) * 16);
+  const uint32_t boff = (uint32_t)(2 * S::NOUT * 16 + (lh * S::NIN + col0 + li) * 16);
+  int par = 0;
+  for (long long st = sb; st < se; ++st) {
+    const uint32_t buf = par ? S::BUF_BYTES : 0u, nbuf = par ? 0u : S::BUF_BYTES;
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this thread's fragment writes of stage st
+    __builtin_amdgcn_s_barrier();                               // everybody's; and everybody left buffer nbuf (stage st - 1)
+    asm volatile("" ::: "memory");
+    u32x4 bh[WC], bl[WC];
+#pragma unroll
+    for (int t = 0; t < WC; ++t) {
+      bh[t] = *reinterpret_cast<const u32x4*>(smem + buf + boff + t * 512);
+      bl[t] = *reinterpret_cast<const u32x4*>(smem + buf + S::PART_BYTES + boff + t * 512);
+    }
+    u32x4 ah = *reinterpret_cast<const u32x4*>(smem + buf + aoff), al = *reinterpret_cast<const u32x4*>(smem + buf + S::PART_BYTES + aoff);
+    // the next stage's fragments, then the loads two stages further into the registers just freed
+    if (par) { convert(raw[0], nbuf); load(raw[0], st + 3); }
+    else { convert(raw[1], nbuf); load(raw[1], st + 3); }
+#pragma unroll
+    for (int ti = 0; ti < WR; ++ti) {
+      u32x4 nh = ah, nl = al;
+      if (ti + 1 < WR) {                                        // the next row tile's fragments while this one multiplies
+        nh = *reinterpret_cast<const u32x4*>(smem + buf + aoff + (ti + 1) * 512);
+        nl = *reinterpret_cast<const u32x4*>(smem + buf + S::PART_BYTES + aoff + (ti + 1) * 512);
+      }
+#pragma unroll
+      for (int tj = 0; tj < WC; ++tj) {
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[tj]), acc[ti][tj], 0, 0, 0);
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl[tj]), acc[ti][tj], 0, 0, 0);
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh[tj]), acc[ti][tj], 0, 0, 0);
+      }
+      ah = nh; al = nl;
+    }
+    par ^= 1;
+  }
+  // partial result: C/D layout row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31
+  // (the lane index is made opaque: hipcc otherwise computes the store addresses in front of the stage loop and carries
+  //  them through it next to the 128 accumulators)
+  int lo_ = lane;
+  asm volatile("" : "+v"(lo_));
+  float* pl = part + (long long)(row0 + 4 * (lo_ >> 5)) * S::NIN + col0 + (lo_ & 31);
+#pragma unroll
+  for (int ti = 0; ti < WR; ++ti)
+#pragma unroll
+    for (int tj = 0; tj < WC; ++tj)
+#pragma unroll
+      for (int r = 0; r < 16; ++r)
+        pl[(32 * ti + (r & 3) + 8 * (r >> 2)) * S::NIN + 32 * tj] = acc[ti][tj][r];
+  // db: the two octets' column sums meet in LDS (the fragment buffers are idle now)
+  __syncthreads();
+  if (is_g) {
+    *reinterpret_cast<float*>(smem + (uh * S::NOUT + 2 * up) * 4) = bs0;
+    *reinterpret_cast<float*>(smem + (uh * S::NOUT + 2 * up + 1) * 4) = bs1;
+  }
+  __syncthreads();
+  if (tid < S::NOUT) part[(long long)S::NOUT * S::NIN + tid] = lds_f(tid * 4) + lds_f((S::NOUT + tid) * 4);
+}
+
 // The item table is read through the kernarg segment pointer (scalar loads of one item at a time): indexing the by-value
 // `p.it[i]` with the runtime i made hipcc keep a private copy of all of WgParams in scratch (460 bytes per lane, 114
 // VGPR + 136 SGPR spills in round 2's build).
@@ -286,6 +447,9 @@ MF_D WgItem wg_item(int i) {
   return it;
 }
 
+// X3 = false: the fp32 block shapes (ids 0-7); true: the three-product shapes (ids 8-10).  Two kernels, because one
+// kernel holding both families spills (hipcc hoists lane-derived values of every body in front of the item loop).
+template <bool X3>
 __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WgParams p) {
   const LaneId id0;
   const int w = blockIdx.x;
@@ -295,21 +459,28 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WgParams p) {
     wg_range(p.total_cost, p.grid, w, it.cost0, wg_stage_cost(it.shape), p.stages, b, e);
     if (b >= e) continue;
     float* part = p.scratch + it.part_off + (long long)(w - it.slot0) * wg_out_floats(it.shape);
-    // The lane / wave indices are made opaque per item: everything the eight shape bodies derive from them (fragment
+    // The lane / wave indices are made opaque per item: everything the shape bodies derive from them (fragment
     // offsets, tile origins, bias columns) is invariant in this loop, and hipcc hoists all of it in front of the loop
     // -- ~80 registers live across the 256x256 body with its 128 accumulators: 114 VGPR spills, 460 bytes of scratch per
     // lane in round 2's build.
     LaneId id = id0;
     asm volatile("" : "+v"(id.lane), "+v"(id.j), "+v"(id.g), "+s"(id.wave));
-    switch (it.shape) {
-      case 0: wg_segment<ShapeA>(it, b, e, p.P, part, id, p.dbg); break;
-      case 1: wg_segment<ShapeB>(it, b, e, p.P, part, id, p.dbg); break;
-      case 2: wg_segment<ShapeC>(it, b, e, p.P, part, id, p.dbg); break;
-      case 3: wg_segment<ShapeD>(it, b, e, p.P, part, id, p.dbg); break;
-      case 4: wg_segment<ShapeE>(it, b, e, p.P, part, id, p.dbg); break;
-      case 5: wg_segment<ShapeF>(it, b, e, p.P, part, id, p.dbg); break;
-      case 6: wg_segment<ShapeG>(it, b, e, p.P, part, id, p.dbg); break;
-      default: wg_segment<ShapeH>(it, b, e, p.P, part, id, p.dbg); break;
+    if constexpr (!X3) {
+      switch (it.shape) {
+        case 0: wg_segment<ShapeA>(it, b, e, p.P, part, id, p.dbg); break;
+        case 1: wg_segment<ShapeB>(it, b, e, p.P, part, id, p.dbg); break;
+        case 2: wg_segment<ShapeC>(it, b, e, p.P, part, id, p.dbg); break;
+        case 3: wg_segment<ShapeD>(it, b, e, p.P, part, id, p.dbg); break;
+        case 4: wg_segment<ShapeE>(it, b, e, p.P, part, id, p.dbg); break;
+        case 5: wg_segment<ShapeF>(it, b, e, p.P, part, id, p.dbg); break;
+        case 6: wg_segment<ShapeG>(it, b, e, p.P, part, id, p.dbg); break;
+        default: wg_segment<ShapeH>(it, b, e, p.P, part, id, p.dbg); break;
+      }
+    } else {
+      switch (it.shape) {
+        case kWgShapeX0: wg_segment_x3<ShapeAX>(it, b, e, p.P, part, id); break;
+        default: wg_segment_x3<ShapeCX>(it, b, e, p.P, part, id); break;
+      }
     }
   }
 }
@@ -345,13 +516,19 @@ __global__ void wgrad_reduce_kernel(WgParams p) {
     case 4: nout = ShapeE::NOUT; nin = ShapeE::NIN; break;
     case 5: nout = ShapeF::NOUT; nin = ShapeF::NIN; break;
     case 6: nout = ShapeG::NOUT; nin = ShapeG::NIN; break;
-    default: nout = ShapeH::NOUT; nin = ShapeH::NIN; break;
+    case 7: nout = ShapeH::NOUT; nin = ShapeH::NIN; break;
+    case 8: nout = ShapeAX::NOUT; nin = ShapeAX::NIN; break;
+    default: nout = ShapeCX::NOUT; nin = ShapeCX::NIN; break;
   }
   if (e < nout * nin) it.dW[e] = (float)s;
   else if (it.db) it.db[e - nout * nin] = (float)s;
 }
 
-static int shape_of(const mf_wgrad_item& a) {
+static int shape_of(const mf_wgrad_item& a, int precision) {
+  if (precision == MF_PREC_BF16X3) {                 // the large blocks have a three-product variant
+    if (a.n_out == 256 && a.n_in == 256) return kWgShapeX0;
+    if (a.n_out == 128 && a.n_in == 256) return kWgShapeX0 + 1;
+  }
   if (a.n_out == 256 && a.n_in == 256) return 0;
   if (a.n_out == 256 && a.n_in == 64) return 1;
   if (a.n_out == 128 && a.n_in == 256) return 2;
@@ -363,7 +540,7 @@ static int shape_of(const mf_wgrad_item& a) {
   return -1;
 }
 
-static int wg_plan(const mf_wgrad_item* items, int n, long long P, WgParams& p, long long& scratch_floats) {
+static int wg_plan(const mf_wgrad_item* items, int n, long long P, int precision, WgParams& p, long long& scratch_floats) {
   if (n < 0 || n > kWgMaxItems) return fail(MF_E_INVALID, "mf_weight_grads: %d items (max %d)", n, kWgMaxItems);
   p = WgParams{};
   p.n_items = n;
@@ -373,9 +550,10 @@ static int wg_plan(const mf_wgrad_item* items, int n, long long P, WgParams& p, 
   long long cost = 0;
   for (int i = 0; i < n; ++i) {
     const mf_wgrad_item& a = items[i];
-    const int sh = shape_of(a);
-    if (sh < 0) return fail(MF_E_UNSUPPORTED, "mf_weight_grads: item %d has unsupported block %d x %d", i, a.n_out, a.n_in);
+    const int sh = shape_of(a, precision);
     if (!a.G || !a.X || !a.dW) return fail(MF_E_INVALID, "mf_weight_grads: item %d has a null pointer", i);
+    if (sh >= kWgShapeX0 && ((a.g_stride & 1) || (a.x_stride & 1)))
+      return fail(MF_E_INVALID, "mf_weight_grads: item %d strides must be even", i);
     if ((a.g_stride & 3) || (a.x_stride & 3) || (reinterpret_cast<uintptr_t>(a.G) & 15) || (reinterpret_cast<uintptr_t>(a.X) & 15))
       return fail(MF_E_INVALID, "mf_weight_grads: item %d operands must be 16-byte aligned with strides that are multiples of 4 floats", i);
     WgItem& it = p.it[i];
@@ -407,40 +585,79 @@ static int wg_plan(const mf_wgrad_item* items, int n, long long P, WgParams& p, 
 
 using namespace mf;
 
+static int wg_precision_ok(int precision) { return precision == MF_PREC_F32 || precision == MF_PREC_BF16X3; }
+
+// The items of a call as (at most) two launches: those whose block has a three-product variant (precision BF16X3) and the
+// rest (fp32).  Each subset is planned on its own (own cost space, own partials behind the other's in the scratch buffer).
+struct WgSplit {
+  mf_wgrad_item items[2][kWgMaxItems];
+  int n[2];
+  WgParams p[2];
+  long long fl[2];
+};
+static int wg_split_plan(const mf_wgrad_item* items, int n, long long P, int precision, WgSplit& sp) {
+  if (n < 0 || n > kWgMaxItems) return fail(MF_E_INVALID, "mf_weight_grads: %d items (max %d)", n, kWgMaxItems);
+  sp.n[0] = sp.n[1] = 0;
+  for (int i = 0; i < n; ++i) {
+    const int sh = shape_of(items[i], precision);
+    if (sh < 0) return fail(MF_E_UNSUPPORTED, "mf_weight_grads: item %d has unsupported block %d x %d", i, items[i].n_out, items[i].n_in);
+    const int k = sh >= kWgShapeX0 ? 1 : 0;
+    sp.items[k][sp.n[k]++] = items[i];
+  }
+  for (int k = 0; k < 2; ++k) {
+    sp.fl[k] = 0;
+    const int rc = wg_plan(sp.items[k], sp.n[k], P, k ? MF_PREC_BF16X3 : MF_PREC_F32, sp.p[k], sp.fl[k]);
+    if (rc != MF_OK) return rc;
+  }
+  return MF_OK;
+}
+
+extern "C" int64_t mf_weight_grads_scratch_bytes_p(int32_t precision, const mf_wgrad_item* items, int32_t n_items, int64_t P) {
+  static thread_local WgSplit sp;
+  if (!items || P < 0 || !wg_precision_ok(precision) || wg_split_plan(items, n_items, P, precision, sp) != MF_OK) return -1;
+  return (sp.fl[0] + sp.fl[1]) * 4 + 16;
+}
 extern "C" int64_t mf_weight_grads_scratch_bytes(const mf_wgrad_item* items, int32_t n_items, int64_t P) {
-  WgParams p;
-  long long fl = 0;
-  if (!items || P < 0 || wg_plan(items, n_items, P, p, fl) != MF_OK) return -1;
-  return fl * 4 + 16;
+  return mf_weight_grads_scratch_bytes_p(MF_PREC_F32, items, n_items, P);
+}
+
+extern "C" int32_t mf_weight_grads_p(int32_t precision, const mf_wgrad_item* items, int32_t n_items, int64_t P, void* scratch, void* stream) {
+  if (!items || P < 0) return fail(MF_E_INVALID, "mf_weight_grads: null argument");
+  if (!wg_precision_ok(precision)) return fail(MF_E_INVALID, "mf_weight_grads: precision %d (MF_PREC_F32 | MF_PREC_BF16X3)", precision);
+  if (n_items == 0) return MF_OK;
+  static thread_local WgSplit sp;
+  const int rc = wg_split_plan(items, n_items, P, precision, sp);
+  if (rc != MF_OK) return rc;
+  if (sp.fl[0] + sp.fl[1] > 0 && !scratch) return fail(MF_E_INVALID, "mf_weight_grads: scratch buffer missing");
+  hipStream_t st = static_cast<hipStream_t>(stream);
+  int lds = ShapeA::SLOT_BYTES;
+  if (ShapeB::SLOT_BYTES > lds) lds = ShapeB::SLOT_BYTES;
+  if (ShapeC::SLOT_BYTES > lds) lds = ShapeC::SLOT_BYTES;
+  if (ShapeD::SLOT_BYTES > lds) lds = ShapeD::SLOT_BYTES;
+  if (ShapeE::SLOT_BYTES > lds) lds = ShapeE::SLOT_BYTES;
+  if (ShapeF::SLOT_BYTES > lds) lds = ShapeF::SLOT_BYTES;
+  if (ShapeG::SLOT_BYTES > lds) lds = ShapeG::SLOT_BYTES;
+  if (ShapeH::SLOT_BYTES > lds) lds = ShapeH::SLOT_BYTES;
+  lds *= 3;
+  const int lds_k[2] = {lds, 2 * ShapeAX::BUF_BYTES};
+  for (int k = 0; k < 2; ++k) {
+    if (sp.n[k] == 0) continue;
+    WgParams& p = sp.p[k];
+    p.scratch = static_cast<float*>(scratch) + (k ? sp.fl[0] : 0);
+    if (const char* e = getenv("MF_DEBUG_FLAGS")) p.dbg = atoi(e);
+    if (P > 0) {
+      void (*kern)(WgParams) = k ? wgrad_kernel<true> : wgrad_kernel<false>;
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_k[k]) != hipSuccess)
+        return fail(MF_E_LAUNCH, "mf_weight_grads: cannot reserve %d bytes of LDS", lds_k[k]);
+      hipLaunchKernelGGL(kern, dim3(p.grid), dim3(kThreads), lds_k[k], st, p);
+    }
+    int maxf = 0;
+    for (int i = 0; i < sp.n[k]; ++i) if (wg_out_floats(p.it[i].shape) > maxf) maxf = wg_out_floats(p.it[i].shape);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((maxf + 255) / 256, sp.n[k]), dim3(256), 0, st, p);
+  }
+  return check_launch("mf_weight_grads");
 }
 
 extern "C" int32_t mf_weight_grads(const mf_wgrad_item* items, int32_t n_items, int64_t P, void* scratch, void* stream) {
-  if (!items || P < 0) return fail(MF_E_INVALID, "mf_weight_grads: null argument");
-  if (n_items == 0) return MF_OK;
-  WgParams p;
-  long long fl = 0;
-  const int rc = wg_plan(items, n_items, P, p, fl);
-  if (rc != MF_OK) return rc;
-  if (fl > 0 && !scratch) return fail(MF_E_INVALID, "mf_weight_grads: scratch buffer missing");
-  p.scratch = static_cast<float*>(scratch);
-  if (const char* e = getenv("MF_DEBUG_FLAGS")) p.dbg = atoi(e);
-  hipStream_t st = static_cast<hipStream_t>(stream);
-  if (P > 0) {
-    int lds = ShapeA::SLOT_BYTES;
-    if (ShapeB::SLOT_BYTES > lds) lds = ShapeB::SLOT_BYTES;
-    if (ShapeC::SLOT_BYTES > lds) lds = ShapeC::SLOT_BYTES;
-    if (ShapeD::SLOT_BYTES > lds) lds = ShapeD::SLOT_BYTES;
-    if (ShapeE::SLOT_BYTES > lds) lds = ShapeE::SLOT_BYTES;
-    if (ShapeF::SLOT_BYTES > lds) lds = ShapeF::SLOT_BYTES;
-    if (ShapeG::SLOT_BYTES > lds) lds = ShapeG::SLOT_BYTES;
-    if (ShapeH::SLOT_BYTES > lds) lds = ShapeH::SLOT_BYTES;
-    lds *= 3;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(wgrad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-      return fail(MF_E_LAUNCH, "mf_weight_grads: cannot reserve %d bytes of LDS", lds);
-    hipLaunchKernelGGL(wgrad_kernel, dim3(p.grid), dim3(kThreads), lds, st, p);
-  }
-  int maxf = 0;
-  for (int i = 0; i < n_items; ++i) if (wg_out_floats(p.it[i].shape) > maxf) maxf = wg_out_floats(p.it[i].shape);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((maxf + 255) / 256, n_items), dim3(256), 0, st, p);
-  return check_launch("mf_weight_grads");
+  return mf_weight_grads_p(MF_PREC_F32, items, n_items, P, scratch, stream);
 }

@@ -30,6 +30,11 @@ def _gpu_run_selected(config):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # MF_TEST_WGRAD=f32|bf16x3: run the whole session with that arithmetic of the weight-gradient contractions (the
+    # gradient bars must hold in both; the package default is what a plain run tests)
+    if os.environ.get("MF_TEST_WGRAD"):
+        from moco_flow_amd import autograd as _A
+        _A.set_wgrad_precision(os.environ["MF_TEST_WGRAD"])
     # Start the RCCL child NOW, while this process has not touched the GPU: a process that has initialised the GPU
     # must not exec another program on the GPU pool, and every later point of a -m gpu session is behind such a call.
     if _gpu_run_selected(config) and not os.environ.get("MF_NO_RCCL_CHILD") and not hasattr(config, "workerinput"):
@@ -67,3 +72,14 @@ def pytest_collection_modifyitems(config, items):
 @pytest.fixture(scope="session")
 def rccl_child():
     return RCCL_CHILD
+
+
+@pytest.fixture(params=["f32", "bf16x3"])
+def wgrad(request):
+    """Arithmetic of the weight-gradient contractions (autograd.set_wgrad_precision) for the duration of one test: the
+    exact-fp32 MFMA and the three-product bf16 split must both hold the gradient bars."""
+    from moco_flow_amd import autograd as A
+    old = A.WGRAD_PRECISION
+    A.set_wgrad_precision(request.param)
+    yield request.param
+    A.set_wgrad_precision(old)

@@ -360,7 +360,7 @@ GRAD_BARS = {"r_nerf_dir_dense": 1e-4, "r_nerf_ind_dense": 1e-4, "r_moco_global"
 
 
 @pytest.mark.parametrize("name", sorted(GRAD_BARS))
-def test_gradients_vs_oracle(M, R, name):
+def test_gradients_vs_oracle(M, R, name, wgrad):
     """Training contract (moco_flow_amd/autograd.py): forward values from the HIP kernels, gradients from
     the HIP backward nodes (composite, NeRF dX chain + weight gradients, NoF evaluations); against the CPU oracle's autograd
     for the reference's loss shape (MSE on rgb + consensus means, trainer_moco_flow.py:317-328)."""
@@ -1159,7 +1159,7 @@ def test_composite_backward_vs_oracle(M, R, act, use_noise, use_bg):
 
 
 @pytest.mark.parametrize("n_rays", [40, 37, 1])
-def test_explicit_nerf_backward_unit(M, R, n_rays):
+def test_explicit_nerf_backward_unit(M, R, n_rays, wgrad):
     """autograd.NerfSamples (fused HIP dX chain mf_nerf_backward_x + mf_weight_grads over the kernel's activation dump)
     against the oracle's CPU autograd of the same network on the SAME points: parameter and input-point gradients to
     1e-4, frozen sub-module honoured, ragged sample counts (not a multiple of the 128-sample tile)."""

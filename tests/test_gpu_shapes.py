@@ -77,7 +77,7 @@ C2F = dict(n=256, S=128, M=128, extra="ind", regime="dense", nof="global")
 STAGE1 = dict(n=256, S=128, M=128, extra="dir", regime="dense", act="softplus", xyz_freqs=0)
 
 
-def test_c2f_training_shape_vs_oracle(M, R):
+def test_c2f_training_shape_vs_oracle(M, R, wgrad):
     """Joint MoCo stage shape (c2f.yaml: 128 coarse + 128 importance samples, two NeRF(ind), bw / fw quaternion NoFs,
     local + global chains, perturb = 1.0) on 256 of its 1024 rays, in training mode: the values come from the DUMPING
     forward (`render_kernel<true, true>`), both passes.  The stratified jitter and the stochastic resample take
@@ -151,7 +151,7 @@ def _oracle_stage1(R, c, seed, rays, bg, rng, gt, z_fine, dtype):
     return want, dict(zip(flat, grads))
 
 
-def test_stage1_training_shape_vs_oracle(M, R):
+def test_stage1_training_shape_vs_oracle(M, R, wgrad):
     """Stage 1 shape (init_nerf.yaml: 128 + 128 samples, NeRF(dir/27) with the xyz encoding at N_freqs = 0 zero-padded
     to 63 columns, softplus densities, perturb = 1.0) on 128 of its 5120 rays: training-mode forward 1e-4 against the
     oracle, and the END-TO-END gradients of the reference's loss (MSE coarse + fine, models/losses.py:4-14).

@@ -48,7 +48,9 @@ sets["NoF all 6"] = sets["F x3 (128x128)"] + sets["G x2 (128x80)"] + sets["H x1 
 sets["all 13"] = sum((sets[k] for k in ("A x9 (256x256)", "B x2 (256x64)", "C x1 (128x256)", "D x1 (128x32)", "E x1 (4x640)")), [])
 flops = lambda jobs: sum(2.0 * P * a[2] * a[3] for a in jobs)
 byts = lambda jobs: sum(4.0 * P * (a[2] + a[3]) for a in jobs)
-print(f"P = {P} samples")
+prec = os.environ.get("MF_WGRAD", "f32")          # MF_WGRAD=bf16x3: the three-product variants of the large blocks
+A.set_wgrad_precision(prec)
+print(f"P = {P} samples, wgrad precision {prec}")
 for k, jobs in sets.items():
     ms = timeit(lambda: A.weight_grads(jobs, P, dev))
     print(f"  {k:18s}: {ms:7.3f} ms  {flops(jobs)/ms/1e9:7.1f} TFLOP/s  {byts(jobs)/ms/1e9:6.2f} TB/s"
@@ -58,8 +60,10 @@ jobs = sets["all 13"] + sets["NoF all 6"]
 res = A.weight_grads(jobs[:13], P, dev) + A.weight_grads(jobs[13:], P, dev)
 worst = 0.0
 for (G, X, no, ni, b), (dW, db) in zip(jobs, res):
-    ref = G.t() @ X
-    worst = max(worst, float((dW[:no] - ref).abs().max() / ref.abs().max()))
+    ref = (G.t().double() @ X.double())
+    err = float((dW[:no].double() - ref).abs().max() / ref.abs().max())
+    print(f"    {no}x{ni}: max-rel {err:.2e}  l2-rel {float((dW[:no].double() - ref).norm() / ref.norm()):.2e}")
+    worst = max(worst, err)
     if b:
         rb = G.sum(0)
         worst = max(worst, float((db[:no] - rb).abs().max() / rb.abs().max()))

@@ -9,6 +9,9 @@ sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 import moco_flow_amd as M
 import eager_ref as E   # tools/eager_ref.py
 from moco_flow_amd import synth, rendering
+from moco_flow_amd import autograd as _A
+if os.environ.get("MF_WGRAD"):
+    _A.set_wgrad_precision(os.environ["MF_WGRAD"])      # f32 | bf16x3
 rendering.STRICT_RNG = False
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 S, Mi = 128, 128
