@@ -280,8 +280,14 @@ def train_leg(M, torch, models, rays, bg, gt, kw, cfg, steps=10):
     if cfg["nof"] is None and cfg["net"] == "dir":
         # Linear-layer MACs x 2: forward + weight gradients (593 408 each) + input-gradient chain (557 696)
         flops = 2 * (593408 * 2 + 557696)
+        from moco_flow_amd import autograd as A
         out["flops_per_sample"] = flops
+        out["wgrad_precision"] = A.WGRAD_PRECISION
+        # against the fp32 matrix peak: the forward and the dX chain run there; with wgrad_precision "bf16x3" the large
+        # weight-gradient blocks run on the bf16 pipe (three products) and against HBM, so this is a throughput in units of
+        # the fp32 peak, not a utilisation of one pipe
         out["mfma_frac"] = n * flops / (ms * 1e-3) / 1e12 / PEAK["f32"]
+        out["mfma_frac_note"] = "algorithmic FLOP/s of fwd + dX + dW over the fp32 matrix peak (dW blocks in " + A.WGRAD_PRECISION + ")"
     return out
 
 

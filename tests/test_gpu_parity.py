@@ -1697,3 +1697,46 @@ def test_pass_and_training_step_replay_in_a_hip_graph(M, mode):
         rendering.set_precision("f32")
         rendering.STRICT_RNG = strict
         clear()
+
+
+@pytest.mark.parametrize("P", [1, 37, 5000, 70001])
+def test_weight_grads_three_products_vs_float64(M, P):
+    """mf_weight_grads_p(MF_PREC_BF16X3) alone: the NeRF's block shapes on column slices of strided dumps, ragged sample
+    counts (not a multiple of the 16-sample stage, fewer samples than workgroups), against a float64 GEMM: the
+    three-product blocks (256x256, 128x256) to 3e-5 l2-rel / 1e-4 max-rel (measured 7e-6; the fp32 MFMA 4e-6), the
+    blocks that stay fp32 (256x64, 128x32, 4x640) to 2e-5; db = column sums to 1e-5; bit-identical between runs."""
+    from moco_flow_amd import autograd as A
+    dev = torch.device("cuda")
+    g = torch.Generator(device="cpu").manual_seed(7 + P)
+    W, stride = 256, 9 * 256 + 128
+    acts = torch.randn(P, stride, generator=g).to(dev)
+    gpre = torch.randn(P, stride, generator=g).to(dev)
+    emb = torch.randn(P, 64, generator=g).to(dev)
+    ext = torch.randn(P, 32, generator=g).to(dev)
+    ghead = torch.randn(P, 4, generator=g).to(dev)
+    sl = lambda t, l, w=W: t[:, l * W:l * W + w]
+    jobs = [(sl(gpre, 1), sl(acts, 0), 256, 256, True), (sl(gpre, 5), sl(acts, 4), 256, 256, False),
+            (sl(gpre, 9, 128), sl(acts, 8), 128, 256, True), (sl(gpre, 0), emb, 256, 64, True),
+            (sl(gpre, 9, 128), ext, 128, 32, False), (ghead, acts[:, 7 * W:7 * W + 640], 4, 640, True)]
+    old = A.WGRAD_PRECISION
+    try:
+        A.set_wgrad_precision("bf16x3")
+        res = A.weight_grads(jobs, P, dev)
+        res2 = A.weight_grads(jobs, P, dev)
+        A.set_wgrad_precision("f32")
+        ref32 = A.weight_grads(jobs, P, dev)
+    finally:
+        A.set_wgrad_precision(old)
+    for (G, X, no, ni, b), (dW, db), (dW2, db2), (dWf, dbf) in zip(jobs, res, res2, ref32):
+        assert torch.equal(dW, dW2)                                   # deterministic (fixed-order partial sums)
+        want = G.double().t() @ X.double()
+        x3 = (no, ni) in ((256, 256), (128, 256))
+        l2 = float((dW[:no].double() - want).norm() / want.norm().clamp_min(1e-30))
+        mr = float((dW[:no].double() - want).abs().max() / want.abs().max().clamp_min(1e-30))
+        print(f"P={P} {no}x{ni} {'x3' if x3 else 'f32'}: l2-rel {l2:.2e} max-rel {mr:.2e}")
+        assert l2 <= (3e-5 if x3 else 2e-5) and mr <= 1e-4, (no, ni, l2, mr)
+        if not x3:       # same arithmetic under either setting (only the split of the sample range over workgroups moves)
+            assert float((dW - dWf).abs().max()) <= 2e-6 * float(dWf.abs().max().clamp_min(1e-30))
+        if b:
+            wb = G.double().sum(0)
+            assert float((db[:no].double() - wb).abs().max() / wb.abs().max().clamp_min(1e-30)) <= 1e-5
