@@ -22,6 +22,7 @@
 // one more layer's worth of activation rounding) for 10 % more matrix instructions, and the pass is throttled by its own activity
 // (DESIGN.md).  Accumulation, biases, the sigma / rgb / NoF heads and the composite stay fp32.
 #pragma once
+#include <type_traits>
 #include "mf_nets.hpp"
 
 namespace mf {
@@ -68,11 +69,16 @@ struct StreamT {
   // ahead are latched.  piece(k): this wave's k-th 1 KiB piece of that panel (k = 0..kPieces-1: a panel is at most 32
   // groups); the pieces are issued one per MFMA gap behind the barrier instead of as a burst.
   const char* dsrc; uint32_t ddst; uint32_t pmask;
+  // KEEP: VM operations this wave has issued behind its last piece of the panel that must have landed (dump stores of
+  // the training forward: the VM counter retires in order, so "all but the KEEP youngest" still covers every piece
+  // without waiting for those stores' round trip).  A LOWER bound is safe; 0 waits for everything.
+  template <int KEEP = 0>
   MF_D void sync(int groups, const char* jump, const Lane& id) {
     // (MF_BF_ABL_*: timing-ablation builds only, tools/ab_lib.sh; results are garbage there)
     jitter();
 #ifndef MF_BF_ABL_NOWAIT
-    wait_vm0();                              // this wave's pieces of the NEXT panel have landed
+    if constexpr (KEEP == 0) wait_vm0();     // this wave's pieces of the NEXT panel have landed
+    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
 #endif
 #ifndef MF_BF_ABL_NOBAR
     __builtin_amdgcn_s_barrier();            // RAW: everybody's have; WAR: everybody left the previous panel
@@ -774,6 +780,26 @@ constexpr int PDX = MF_BF_PDX;
 
 struct Ahead { int g0; const char* j0; int g1; const char* j1; };
 
+// Activation dump of the training forward (mf_render_args.dump_acts): `row` = this lane's sample row + the layer's first
+// column + 4 (lane >> 5); a tile's 16 accumulators are rows 8 q + 4 h + i, i.e. four 16-byte stores at row[32 t + 8 q].
+struct NoDump {};
+struct RowDump { float* row; bool on; };
+template <bool RELU>
+MF_D void dump_store(const RowDump& d, const f32x16& acc, int t, int q) {
+  if (!d.on) return;
+  auto act = [](float x) {
+    if (!RELU) return x;
+    const int b = __builtin_bit_cast(int, x);
+    return __builtin_bit_cast(float, b > 0 ? b : 0);
+  };
+  f32x4 v;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) v[i] = act(acc[4 * q + i]);
+  *reinterpret_cast<f32x4*>(d.row + 32 * t + 8 * q) = v;
+}
+template <bool RELU>
+MF_D void dump_store(const NoDump&, const f32x16&, int, int) {}
+
 MF_D f32x2 lds_f2(uint32_t byte_off) { return *(const f32x2*)(smem + byte_off); }
 
 // Epilogue of one tile in 16 steps of ~5 instructions (a wave alone on its SIMD hides about five issues behind each
@@ -822,7 +848,9 @@ MF_D void epi_step(const f32x16& acc, int step, int h, u32x4& out0, u32x4& out1,
 
 // The matrix part of one output tile: acc = bias + W_tile [emb ; (hid, hidlo)] in three products per k-step.  `gap(m)`
 // runs behind the m-th MFMA (m = 0 .. NM-1): the caller's deferred work (the previous tile's epilogue steps).
-template <int NGE, int KHID, int HMODE, bool EMB_FIRST, class ST, class Gap>
+// KEEP: see StreamT::sync (the tile's FIRST panel barrier only).  LATE_FREE: no LDS-DMA pieces behind the last two (hi, lo)
+// group pairs of the tile's last panel -- the caller's dump stores go there, behind every piece of the panel.
+template <int NGE, int KHID, int HMODE, bool EMB_FIRST, int KEEP = 0, bool LATE_FREE = false, class ST, class Gap>
 MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, const u32x4* hidlo, const u32x4* xhi, const u32x4* xlo,
                      uint32_t bias_off, const Ahead& two, f32x16& acc, Gap&& gap) {
   constexpr int NEG = 2 * NGE;
@@ -866,7 +894,10 @@ MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, co
     // the panel's barrier + the DMA of the panel two ahead, behind its first group; that panel's pieces go into the MFMA
     // gaps that follow (several per gap where the panel is short)
     const int base = gi >= NG1 ? NG1 : 0, len = gi >= NG1 ? NG - NG1 : NG1, q = gi - base;
-    if (q == 0) st.sync(base ? two.g1 : two.g0, base ? two.j1 : two.j0, id);
+    if (q == 0) {
+      if (base) st.sync(two.g1, two.j1, id);
+      else st.template sync<KEEP>(two.g0, two.j0, id);
+    }
     if (nb >= NG) r[sp] = frag(nb);
     gap(m++);
     __builtin_amdgcn_sched_barrier(0);
@@ -875,9 +906,13 @@ MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, co
       __builtin_amdgcn_sched_barrier(0);
       // the pieces of the panel two ahead go behind these second MFMAs -- gaps that carry no fragment read (an LDS-DMA
       // issued next to a ds_read_b128 costs the wave ~50 cycles, alone ~10) -- spread evenly over the panel
-      const int e0 = base + (base & 1), nslots = (base + len - e0 + 1) / 2, j = (gi - e0) / 2;
+      const int e0 = base + (base & 1), nall = (base + len - e0 + 1) / 2, j = (gi - e0) / 2;
+      const bool last_panel = base + len == NG;
+      const int nslots = (LATE_FREE && last_panel && nall > 2) ? nall - 2 : nall;
+      if (j < nslots) {
 #pragma unroll
-      for (int k = j * ST::kPieces / nslots; k < (j + 1) * ST::kPieces / nslots; ++k) st.piece(k, id);
+        for (int k = j * ST::kPieces / nslots; k < (j + 1) * ST::kPieces / nslots; ++k) st.piece(k, id);
+      }
       gap(m++);
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -894,18 +929,25 @@ MF_D Next next_x(const Net& n, int layer) { return next_of_groups(tgroups<KH, EK
 // One layer of NT tiles with split operands: (out, outlo) <- act(W [emb ; (in, inlo)] + b), `nxt` = what follows it.
 // The epilogue of tile t runs in the MFMA gaps of tile t + 1 (a wave alone on its SIMD has nobody to cover it); only the
 // last tile's stands alone.
-template <int NT, int NGE, int KHID, int HMODE, bool EMB_FIRST, bool RELU, int OUTS, int NHEAD, int HSTRIDE, class ST, int KI, int KO>
+template <int NT, int NGE, int KHID, int HMODE, bool EMB_FIRST, bool RELU, int OUTS, int NHEAD, int HSTRIDE, class DT, class ST, int KI, int KO>
 MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], const u32x4 (&inlo)[KI], u32x4 (&out)[KO],
                   u32x4 (&outlo)[KO], const u32x4* xhi, const u32x4* xlo, uint32_t bias_off, const Next& nxt, uint32_t headw_off,
-                  float (&head)[NHEAD ? NHEAD : 1]) {
+                  float (&head)[NHEAD ? NHEAD : 1], const DT& dump) {
+  constexpr bool DUMP = __is_same(DT, RowDump);
   constexpr int NG = 2 * NGE + (HMODE ? 2 : 1) * KHID;
   constexpr int NSEG = NG > 32 ? 2 : 1;
   constexpr int NG1 = NSEG == 2 ? (NG + 1) / 2 : NG;
   constexpr int NM = 3 * NGE + (HMODE == 2 ? 3 : 2) * KHID / (HMODE ? 1 : 2);      // MFMAs of a tile
   constexpr int kSteps = 16;
+  static_assert(!DUMP || NM >= 8, "dump stores need four piece-free MFMA gaps");
   f32x16 pend = {};
-#pragma unroll
-  for (int t = 0; t < NT; ++t) {
+  // DUMP: the pending tile's four row stores go into the LAST four MFMA gaps of the next tile, behind that tile's last
+  // LDS-DMA piece (LATE_FREE), so the panel barrier that follows may leave exactly them in flight (KEEP = 4).  Which
+  // barriers: the first of tile t >= 2 (tile t - 1 carried tile t - 2's stores) and the first of tile 0 (the layer in
+  // front ended with its last tile's stores; a lower bound where other VM traffic sits in between).  Tile 1's waits for
+  // everything: tile 0 carries no stores.
+  auto run = [&](auto tc) __attribute__((always_inline)) {
+    constexpr int t = decltype(tc)::value;
     Ahead two;
     if constexpr (NSEG == 1) {        // panel t + 2 of this layer, else panel t + 2 - NT of what follows
       two = Ahead{t + 2 < NT ? NG : (t == NT - 2 ? nxt.groups : nxt.groups2),
@@ -913,7 +955,7 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
     } else {                          // the same half of the next tile, else of the first tile of what follows
       two = t + 1 < NT ? Ahead{NG1, nullptr, NG - NG1, nullptr} : Ahead{nxt.groups, nxt.jump, nxt.groups2, nxt.jump2};
     }
-    const int tp = t > 0 ? t - 1 : 0;                        // the tile whose epilogue is pending
+    constexpr int tp = t > 0 ? t - 1 : 0;                    // the tile whose epilogue is pending
     auto gap = [&](int m) __attribute__((always_inline)) {
 #ifndef MF_BF_X3_NODEFER
       if (t == 0) return;
@@ -921,10 +963,12 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
       for (int sidx = kSteps * m / NM; sidx < kSteps * (m + 1) / NM; ++sidx)
         epi_step<RELU, OUTS, NHEAD, HSTRIDE>(pend, sidx, id.h, out[OUTS ? 2 * tp : 0], out[OUTS ? 2 * tp + 1 : 1], outlo[OUTS == 2 ? 2 * tp : 0],
                                              outlo[OUTS == 2 ? 2 * tp + 1 : 1], headw_off + 32 * tp * 4, head);
+      if (DUMP && m >= NM - 4) dump_store<RELU>(dump, pend, tp, m - (NM - 4));
 #endif
     };
     f32x16 acc;
-    mma_tile_x<NGE, KHID, HMODE, EMB_FIRST>(st, id, carry, in, inlo, xhi, xlo, bias_off + 32 * t * 4, two, acc, gap);
+    constexpr int KEEP = (DUMP && t != 1) ? 4 : 0;
+    mma_tile_x<NGE, KHID, HMODE, EMB_FIRST, KEEP, DUMP>(st, id, carry, in, inlo, xhi, xlo, bias_off + 32 * t * 4, two, acc, gap);
     st.advance();
 #ifdef MF_BF_X3_NODEFER
 #pragma unroll
@@ -934,6 +978,13 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
     __builtin_amdgcn_sched_barrier(0);
 #endif
     pend = acc;
+  };
+  static_assert(NT == 4 || NT == 8, "tiles per layer");
+  run(std::integral_constant<int, 0>{}); run(std::integral_constant<int, 1>{});
+  run(std::integral_constant<int, 2>{}); run(std::integral_constant<int, 3>{});
+  if constexpr (NT == 8) {
+    run(std::integral_constant<int, 4>{}); run(std::integral_constant<int, 5>{});
+    run(std::integral_constant<int, 6>{}); run(std::integral_constant<int, 7>{});
   }
 #ifndef MF_BF_X3_NODEFER
 #pragma unroll
@@ -941,20 +992,25 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
     epi_step<RELU, OUTS, NHEAD, HSTRIDE>(pend, sidx, id.h, out[OUTS ? 2 * (NT - 1) : 0], out[OUTS ? 2 * (NT - 1) + 1 : 1],
                                          outlo[OUTS == 2 ? 2 * (NT - 1) : 0], outlo[OUTS == 2 ? 2 * (NT - 1) + 1 : 1],
                                          headw_off + 32 * (NT - 1) * 4, head);
+  if constexpr (DUMP) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) dump_store<RELU>(dump, pend, NT - 1, q);
+  }
   __builtin_amdgcn_sched_barrier(0);
 #endif
 }
 
 // One trunk layer: MODE as trunk_layer_m (1 embedded input only, 2 hidden only, 3 both, embedded input first).
-template <int KH, int NGE, int MODE, bool RELU, int NHEAD, class RBT, class ST>
+template <int KH, int NGE, int MODE, bool RELU, int NHEAD, class RBT, class ST, class DT = NoDump>
 MF_D void trunk_layer_x(const Net& net, int layer, const u32x4 (&in)[KH], const u32x4 (&inlo)[KH], u32x4 (&out)[KH],
                         u32x4 (&outlo)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE], ST& st, CarryX& carry,
-                        const Lane& id, const Next& nxt, const RBT& rb, uint32_t headw_off, float (&head)[NHEAD ? NHEAD : 1]) {
+                        const Lane& id, const Next& nxt, const RBT& rb, uint32_t headw_off, float (&head)[NHEAD ? NHEAD : 1],
+                        const DT& dump = DT{}) {
   uint32_t bias_off = net.res_lds + layer * (16 * KH) * 4;
   if constexpr (__is_same(RBT, LdsRayBias) && (MODE & 1))
     bias_off = rb.lane_off + (uint32_t)__builtin_popcount(net.emb_mask & ((1u << layer) - 1u)) * (16 * KH) * 4;
   layer_x<KH / 2, (MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, 2, true, RELU, 2, NHEAD, 0>(
-      st, id, carry, in, inlo, out, outlo, xhi, xlo, bias_off, nxt, headw_off, head);
+      st, id, carry, in, inlo, out, outlo, xhi, xlo, bias_off, nxt, headw_off, head, dump);
 }
 
 // NoF head with split activations and weights: groups (Whi, Wlo) per k-step, three products.
@@ -1047,10 +1103,16 @@ MF_D void nof_eval_x3(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4
 // Canonical NeRF, x3: every layer in three products; the sigma head inside the epilogue of the last trunk layer, the rgb
 // head inside extra_encoding's (whose outputs never become operands).  `make_extra(eh, el)` builds the extra block's split
 // operands right before extra_encoding.
-template <class MakeExtra, class ST>
+// DT = RowDump (training forward): every layer's activations [h_0 .. h_{D-1} | xyz_encoding_final | extra_encoding] go to the
+// sample's dump row as they leave the accumulators (dump.row = row start + 4 (lane >> 5)).
+template <class MakeExtra, class ST, class DT = NoDump>
 MF_D void nerf_eval_x3(const Net& net, const u32x4 (&xh)[kKsNerfXyz], const u32x4 (&xl)[kKsNerfXyz], MakeExtra&& make_extra,
                        bool sigma_only, ST& st, CarryX& carry, const Lane& id, const Next& follow, float& sigma,
-                       float (&rgb)[3]) {
+                       float (&rgb)[3], const DT& dump = DT{}) {
+  auto dump_at = [&](int col) {                               // the dump of a layer whose first column is `col`
+    if constexpr (__is_same(DT, RowDump)) return RowDump{dump.row + col, dump.on};
+    else return NoDump{};
+  };
   u32x4 ah[16], al[16], bh[16], bl[16];
 #pragma unroll
   for (int t = 0; t < 16; ++t)
@@ -1063,9 +1125,10 @@ MF_D void nerf_eval_x3(const Net& net, const u32x4 (&xh)[kKsNerfXyz], const u32x
   auto one = [&](int layer, const u32x4 (&ih)[16], const u32x4 (&il)[16], u32x4 (&oh)[16], u32x4 (&ol)[16]) __attribute__((always_inline)) {
     const Next nxt = next_x<16, kKsNerfXyz>(net, layer + 1);
     const int has_emb = (net.emb_mask >> layer) & 1;
-    if (layer == 0) trunk_layer_x<16, kKsNerfXyz, 1, true, 0>(net, layer, ih, il, oh, ol, xh, xl, st, carry, id, nxt, norb, 0u, nohead);
-    else if (has_emb) trunk_layer_x<16, kKsNerfXyz, 3, true, 0>(net, layer, ih, il, oh, ol, xh, xl, st, carry, id, nxt, norb, 0u, nohead);
-    else trunk_layer_x<16, kKsNerfXyz, 2, true, 0>(net, layer, ih, il, oh, ol, xh, xl, st, carry, id, nxt, norb, 0u, nohead);
+    const auto dl = dump_at(layer * 256);
+    if (layer == 0) trunk_layer_x<16, kKsNerfXyz, 1, true, 0>(net, layer, ih, il, oh, ol, xh, xl, st, carry, id, nxt, norb, 0u, nohead, dl);
+    else if (has_emb) trunk_layer_x<16, kKsNerfXyz, 3, true, 0>(net, layer, ih, il, oh, ol, xh, xl, st, carry, id, nxt, norb, 0u, nohead, dl);
+    else trunk_layer_x<16, kKsNerfXyz, 2, true, 0>(net, layer, ih, il, oh, ol, xh, xl, st, carry, id, nxt, norb, 0u, nohead, dl);
   };
   int l = 0;                                                  // layers 0 .. D-2, in pairs a -> b -> a
   for (; l + 1 < D - 1; l += 2) {
@@ -1084,16 +1147,17 @@ MF_D void nerf_eval_x3(const Net& net, const u32x4 (&xh)[kKsNerfXyz], const u32x
   float sig[1] = {0.f};
   {                                                           // layer D-1 (a -> b), the sigma head in its epilogue
     const Next nx = sigma_only ? follow : next_x<16, kKsNerfXyz>(net, D);      // xyz_encoding_final: 32 groups
+    const auto dl = dump_at((D - 1) * 256);
     if ((net.emb_mask >> (D - 1)) & 1)
-      trunk_layer_x<16, kKsNerfXyz, 3, true, 1>(net, D - 1, ah, al, bh, bl, xh, xl, st, carry, id, nx, norb, r_sigma_w, sig);
+      trunk_layer_x<16, kKsNerfXyz, 3, true, 1>(net, D - 1, ah, al, bh, bl, xh, xl, st, carry, id, nx, norb, r_sigma_w, sig, dl);
     else
-      trunk_layer_x<16, kKsNerfXyz, 2, true, 1>(net, D - 1, ah, al, bh, bl, xh, xl, st, carry, id, nx, norb, r_sigma_w, sig);
+      trunk_layer_x<16, kKsNerfXyz, 2, true, 1>(net, D - 1, ah, al, bh, bl, xh, xl, st, carry, id, nx, norb, r_sigma_w, sig, dl);
   }
   sigma = sig[0] + __shfl_xor(sig[0], 32, 64) + lds_f(r_sigma_w + 256 * 4);
   st.tl.stamp(30, id);
   if (sigma_only) return;
   const Next ex = next_of_groups(32 + 2 * net.aux);
-  trunk_layer_x<16, kKsNerfXyz, 2, false, 0>(net, D, bh, bl, ah, al, xh, xl, st, carry, id, ex, norb, 0u, nohead);   // xyz_encoding_final (b -> a, no ReLU)
+  trunk_layer_x<16, kKsNerfXyz, 2, false, 0>(net, D, bh, bl, ah, al, xh, xl, st, carry, id, ex, norb, 0u, nohead, dump_at(D * 256));   // xyz_encoding_final (b -> a, no ReLU)
   st.tl.stamp(31, id);
   u32x4 eh[kKsExtraMax], el[kKsExtraMax];
   make_extra(eh, el);
@@ -1101,9 +1165,10 @@ MF_D void nerf_eval_x3(const Net& net, const u32x4 (&xh)[kKsNerfXyz], const u32x
   // extra_encoding (nerf.py:98): W/2 outputs from [final (W) ; extra block], ReLU; rgb (nerf.py:57-59) in its epilogue
   float o[3] = {0.f, 0.f, 0.f};
   const uint32_t bias_extra = net.res_lds + (D + 1) * 256 * 4, r_rgb_w = r_sigma_w + (256 + 4) * 4;
-  if (net.aux == 2) layer_x<4, 2, 16, 2, false, true, 0, 3, 512>(st, id, carry, ah, al, bh, bl, eh, el, bias_extra, follow, r_rgb_w, o);
-  else if (net.aux == 1) layer_x<4, 1, 16, 2, false, true, 0, 3, 512>(st, id, carry, ah, al, bh, bl, eh, el, bias_extra, follow, r_rgb_w, o);
-  else layer_x<4, 0, 16, 2, false, true, 0, 3, 512>(st, id, carry, ah, al, bh, bl, eh, el, bias_extra, follow, r_rgb_w, o);
+  const auto de = dump_at((D + 1) * 256);
+  if (net.aux == 2) layer_x<4, 2, 16, 2, false, true, 0, 3, 512>(st, id, carry, ah, al, bh, bl, eh, el, bias_extra, follow, r_rgb_w, o, de);
+  else if (net.aux == 1) layer_x<4, 1, 16, 2, false, true, 0, 3, 512>(st, id, carry, ah, al, bh, bl, eh, el, bias_extra, follow, r_rgb_w, o, de);
+  else layer_x<4, 0, 16, 2, false, true, 0, 3, 512>(st, id, carry, ah, al, bh, bl, eh, el, bias_extra, follow, r_rgb_w, o, de);
   st.tl.stamp(33, id);
 #pragma unroll
   for (int c = 0; c < 3; ++c) {

@@ -33,6 +33,7 @@ struct Params {
   const float* raybias;            // MOCO: (n_rays, rb_combos, rb_layers, 128) per-ray NoF biases (nof_raybias_kernel)
   int rb_combos, rb_layers;
   uint32_t rb_off, rb_buf_bytes;   // LDS: two buffers of the current / next chain step's rows of the tile's rays
+  float* dump_acts; long long dump_stride; float* dump_rgbsigma; float* dump_xyz;   // training forward (X3, no NoF)
 };
 
 // ---- per-ray bias of the NoF's embedded-input layers (models/rendering.py:73-75 + models/nof.py:69-73) ----
@@ -153,8 +154,11 @@ MF_D void tile_rays(int tile, int nr, int S, int& first, int& n) {
 
 // X3: MF_PREC_BF16X3 (mf_bf16.hpp: every matrix product as a three-product split, heads on fp32 accumulators): 4 waves,
 // one per SIMD, 128-sample tiles; else 8 waves, two per SIMD, 256-sample tiles
-template <bool MOCO, bool X3 = false>
+// DUMP (X3 && !MOCO): the training forward -- every sample's layer activations, (rgb, sigma) and input point are stored
+// for the backward (mf_render_args.dump_*), as mf_render.hip's render_kernel<*, true> does in fp32.
+template <bool MOCO, bool X3 = false, bool DUMP = false>
 __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel_bf16(const Params p) {
+  static_assert(!DUMP || (X3 && !MOCO), "the dump variant exists for the three-product canonical pass");
   constexpr int NW = X3 ? 4 : kWaves;
   constexpr int TILE = NW * kWaveSamples;
   const Lane id;
@@ -309,7 +313,17 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
           split_operands<kKsExtraMax>(ext, 8 * kKsExtraMax, eh, el);
         };
         st.tl.stamp(4, id);
-        nerf_eval_x3(p.nerf, xh, xl, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb);
+        if constexpr (DUMP) {
+          const long long row = ray * S + si;
+          const RowDump dump{p.dump_acts + row * p.dump_stride + 4 * id.h, valid && p.dump_acts != nullptr};
+          nerf_eval_x3(p.nerf, xh, xl, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb, dump);
+          if (valid && id.h == 0) {
+            if (p.dump_rgbsigma) *reinterpret_cast<float4*>(p.dump_rgbsigma + row * 4) = make_float4(rgb[0], rgb[1], rgb[2], sigma);
+            if (p.dump_xyz) { float* q = p.dump_xyz + row * 3; q[0] = xin[0]; q[1] = xin[1]; q[2] = xin[2]; }
+          }
+        } else {
+          nerf_eval_x3(p.nerf, xh, xl, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb);
+        }
       } else {
         u32x4 xe[kKsNerfXyz];
         {
@@ -628,7 +642,15 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
   lds = (lds + 15u) & ~15u;
 
   const int grid = (int)(p.n_groups < device_cus() ? p.n_groups : device_cus());
-  void (*kern)(const Params) = x3 ? (moco ? render_kernel_bf16<true, true> : render_kernel_bf16<false, true>)
+  const bool dump = a->dump_acts || a->dump_rgbsigma || a->dump_xyz;
+  if (dump) {      // (validated by the caller: bf16x3, no NoF)
+    if (a->dump_acts && a->dump_stride < (int64_t)Ln.n_trunk * Ln.W + Ln.W / 2)
+      return fail(MF_E_INVALID, "mf_render_pass: dump_stride %lld too small", (long long)a->dump_stride);
+    if (a->dump_acts && ((a->dump_stride & 3) || (reinterpret_cast<uintptr_t>(a->dump_acts) & 15)))
+      return fail(MF_E_INVALID, "mf_render_pass(bf16x3): dump_acts must be 16-byte aligned with a stride that is a multiple of 4 floats");
+    p.dump_acts = a->dump_acts; p.dump_stride = a->dump_stride; p.dump_rgbsigma = a->dump_rgbsigma; p.dump_xyz = a->dump_xyz;
+  }
+  void (*kern)(const Params) = x3 ? (moco ? render_kernel_bf16<true, true> : (dump ? render_kernel_bf16<false, true, true> : render_kernel_bf16<false, true>))
                                   : (moco ? render_kernel_bf16<true, false> : render_kernel_bf16<false, false>);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);

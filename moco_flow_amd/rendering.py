@@ -27,6 +27,17 @@ from . import autograd as A
 # max-rel on the golden vectors at about a third of the fp32 kernels' time).
 # The reference's render_rays signature has no such knob, so it is a module setting.
 PRECISION = "f32"
+# Arithmetic of the TRAINING forward (a pass that records gradients) when no NoF is involved (stage 1: the canonical
+# NeRF alone): "f32" = the reference's; "bf16x3" = the three-product kernels writing the same activation dump (forward
+# values and dumped activations to ~1e-5; the dX chain on them stays fp32, the weight gradients follow set_wgrad_precision).
+TRAIN_FORWARD_PRECISION = "f32"
+
+
+def set_train_forward_precision(p: str):
+    global TRAIN_FORWARD_PRECISION
+    if p not in ("f32", "bf16x3"):
+        raise ValueError(f"training-forward precision must be 'f32' or 'bf16x3', got {p!r}")
+    TRAIN_FORWARD_PRECISION = p
 
 
 def set_precision(p: str):
@@ -382,7 +393,9 @@ def render_rays(rays,
         return None
 
     coarse_sigma_only = bool(need_fine and test_time)                  # rendering.py:290-294
-    pass_prec = "f32" if grad else None       # a pass that records gradients runs the reference's fp32 arithmetic
+    # a pass that records gradients runs the reference's fp32 arithmetic (or, NeRF-only passes, the three-product kernels:
+    # set_train_forward_precision)
+    pass_prec = (TRAIN_FORWARD_PRECISION if not use_nof else "f32") if grad else None
     want_planes = need_fine or loc or glob or grad or _capture is not None
     noise_c = draw_noise((N, S), "noise_coarse")
     if grad and N > 0:

@@ -32,6 +32,9 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # MF_TEST_WGRAD=f32|bf16x3: run the whole session with that arithmetic of the weight-gradient contractions (the
     # gradient bars must hold in both; the package default is what a plain run tests)
+    if os.environ.get("MF_TEST_TRAIN_FWD"):
+        from moco_flow_amd import rendering as _Rn
+        _Rn.set_train_forward_precision(os.environ["MF_TEST_TRAIN_FWD"])
     if os.environ.get("MF_TEST_WGRAD"):
         from moco_flow_amd import autograd as _A
         _A.set_wgrad_precision(os.environ["MF_TEST_WGRAD"])

@@ -359,6 +359,61 @@ def _oracle_grads(R, c, seed, rays, bg, loss_fn):
 GRAD_BARS = {"r_nerf_dir_dense": 1e-4, "r_nerf_ind_dense": 1e-4, "r_moco_global": 5e-2, "r_moco_global_default": 3e-3}
 
 
+@pytest.mark.parametrize("name", ["r_nerf_dir_dense", "r_nerf_ind_dense"])
+def test_train_forward_bf16x3(M, R, name):
+    """rendering.set_train_forward_precision("bf16x3") (opt-in; NeRF-only passes): the training forward on the three-product
+    kernels, writing the same activation dump; dX chain in fp32 on that dump.  Forward values hold the fp32 contract (1e-4
+    max-rel, measured ~1e-5).  Gradients do NOT: a ReLU network's gradient is discontinuous where a pre-activation crosses
+    zero, and the forward's 1e-5 moves ~100x more units across than fp32 rounding does -- the same effect separates the
+    oracle's own fp32 and fp64 gradients, here at 2e-3 max-rel / 3e-4 l2-rel per parameter tensor.
+    That is why the mode is opt-in and "f32" the default; the bars document the measured level."""
+    from moco_flow_amd import rendering
+    c = dict(RENDER_CASES[name])
+    seed = int(load_golden(name)["meta_seed"])
+    n = 48
+    rays, bg = case_inputs(c, seed, n=n)
+    gt = torch.rand(n, 3, generator=torch.Generator().manual_seed(0))
+
+    def loss_fn(res, gt=gt):
+        return ((res["rgb_coarse"] - gt.to(res["rgb_coarse"].device)) ** 2).mean() + 0.1 * res["depth_coarse"].mean()
+
+    want_res, want = _oracle_grads(R, c, seed, rays, bg, loss_fn)
+    embs, nerfs, kw = build_case(M, c, seed, device="cuda")
+    try:
+        rendering.set_train_forward_precision("bf16x3")
+        res = M.render_rays(rays.cuda(), bg.cuda(), embs, nerfs, **kw)
+        loss_fn(res).backward()
+    finally:
+        rendering.set_train_forward_precision("f32")
+    for k in ("rgb_coarse", "depth_coarse", "opacity_coarse"):
+        assert relerr(res[k], want_res[k]) <= TOL, (k, relerr(res[k], want_res[k]))
+    worst_mr, worst_l2 = 0.0, 0.0
+    for k, p in nerfs[0].named_parameters():
+        w = want[f"0.{k}"]
+        if w is None:
+            continue
+        mr, l2 = relerr(p.grad, w), _l2rel(p.grad, w)
+        worst_mr, worst_l2 = max(worst_mr, mr), max(worst_l2, l2)
+    print(f"{name}: bf16x3 training forward: gradients vs oracle autograd worst max-rel {worst_mr:.2e}, l2-rel {worst_l2:.2e}")
+    assert worst_mr <= 1e-2 and worst_l2 <= 2e-3
+    # bit-identical between runs at a size that keeps every workgroup busy for several tiles (the dump stores stay in flight
+    # across the panel barriers: a piece of the weight stream that had not landed would show up here)
+    rays2, bg2 = case_inputs(c, seed, n=1500)
+    grads = []
+    try:
+        rendering.set_train_forward_precision("bf16x3")
+        for _ in range(3):
+            for p in nerfs[0].parameters():
+                p.grad = None
+            r2 = M.render_rays(rays2.cuda(), bg2.cuda(), embs, nerfs, **kw)
+            (r2["rgb_coarse"].square().mean() + r2["depth_coarse"].mean()).backward()
+            grads.append([p.grad.clone() for p in nerfs[0].parameters()] + [r2["rgb_coarse"].detach().clone()])
+    finally:
+        rendering.set_train_forward_precision("f32")
+    for g in grads[1:]:
+        assert all(torch.equal(a, b) for a, b in zip(grads[0], g))
+
+
 @pytest.mark.parametrize("name", sorted(GRAD_BARS))
 def test_gradients_vs_oracle(M, R, name, wgrad):
     """Training contract (moco_flow_amd/autograd.py): forward values from the HIP kernels, gradients from
