@@ -55,8 +55,9 @@ enum { MF_MAX_FREQS = 16, MF_MAX_LAYERS = 16 };
  * bf16 split of activations AND weights (hi + lo, 16 mantissa bits each), three products hi*hi + hi*lo + lo*hi with fp32
  * accumulation; sigma / rgb heads as fp32 dot products on the fp32 accumulators; the NoF's image index an exact fp32
  * per-ray bias.  Three bf16 matrix instructions per product where F32 costs sixteen: ~1/3 of F32's time at <= 5e-5
- * max-rel on the reference's golden vectors.  Own packed layout (every k-step a (hi, lo) group pair); render passes only
- * (mf_points_sigma_p takes F32 | BF16). */
+ * max-rel on the reference's golden vectors.  Own packed layout (every k-step a (hi, lo) group pair).  Render passes
+ * (with the NeRF activation dump of the training forward when no NoF is involved) and mf_points_sigma_p (scalar
+ * image index or no NoF). */
 enum { MF_PREC_F32 = 0, MF_PREC_BF16 = 1, MF_PREC_BF16X3 = 2 };
 
 /* ---- Embedding: models/embedding.py:4-47 ------------------------------------

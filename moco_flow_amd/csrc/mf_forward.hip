@@ -306,7 +306,7 @@ static void emb_to_params(const mf_embedding& e, EmbParams& o) {
 }
 
 namespace mf {
-int points_sigma_bf16(const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz, const mf_nof_desc* nof,
+int points_sigma_bf16(int prec, const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz, const mf_nof_desc* nof,
                       const void* nof_packed, const mf_embedding* nof_emb_xyz, const mf_embedding* nof_emb_ind, const float* xyz,
                       const float* ind, float ind_scalar, int64_t B, float* sigma, float* canon, void* workspace,
                       int64_t workspace_bytes, hipStream_t st);   // mf_render_bf16.hip
@@ -314,7 +314,7 @@ int64_t points_workspace_bytes_bf16(const mf_nof_desc* nof, int per_point_ind, i
 }
 
 extern "C" int64_t mf_points_sigma_workspace_bytes(int32_t precision, const mf_nof_desc* nof, int32_t per_point_ind, int64_t B) {
-  return precision == MF_PREC_BF16 ? points_workspace_bytes_bf16(nof, per_point_ind, B) : 0;
+  return precision != MF_PREC_F32 ? points_workspace_bytes_bf16(nof, per_point_ind, B) : 0;
 }
 
 extern "C" int32_t mf_points_sigma(const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz,
@@ -332,8 +332,8 @@ extern "C" int32_t mf_points_sigma_p(int32_t precision, const mf_nerf_desc* nerf
                                      int64_t workspace_bytes, void* stream) {
   if (!nerf || !nerf_packed || !emb_xyz || (B > 0 && (!xyz || !sigma)))
     return fail(MF_E_INVALID, "mf_points_sigma: null argument");
-  if (precision != MF_PREC_F32 && precision != MF_PREC_BF16) return fail(MF_E_INVALID, "mf_points_sigma: precision %d", precision);
-  if (precision == MF_PREC_BF16) {
+  if (precision < MF_PREC_F32 || precision > MF_PREC_BF16X3) return fail(MF_E_INVALID, "mf_points_sigma: precision %d", precision);
+  if (precision != MF_PREC_F32) {
     if (emb_xyz->in_channels != 3 || emb_xyz->n_freqs > 10)
       return fail(MF_E_UNSUPPORTED, "mf_points_sigma: xyz embedding must have 3 channels and <= 10 frequencies");
     if (nof) {
@@ -342,7 +342,7 @@ extern "C" int32_t mf_points_sigma_p(int32_t precision, const mf_nerf_desc* nerf
         return fail(MF_E_UNSUPPORTED, "mf_points_sigma: NoF embeddings must be xyz(3, <=5 freqs) and ind(1, 16 freqs)");
     }
     if (B == 0) return MF_OK;
-    return points_sigma_bf16(nerf, nerf_packed, emb_xyz, nof, nof_packed, nof_emb_xyz, nof_emb_ind, xyz, ind, ind_scalar, B, sigma, canon,
+    return points_sigma_bf16(precision, nerf, nerf_packed, emb_xyz, nof, nof_packed, nof_emb_xyz, nof_emb_ind, xyz, ind, ind_scalar, B, sigma, canon,
                              workspace, workspace_bytes, static_cast<hipStream_t>(stream));
   }
   PointsParams p{};

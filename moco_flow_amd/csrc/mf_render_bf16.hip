@@ -437,27 +437,32 @@ struct PointsParamsBf {
 
 // PERPT: an image index per point -- each lane fetches its own bias rows from the global table (register sets, RayBias);
 // otherwise the one entry of ind_scalar sits in LDS for the whole launch.
-template <bool NOF, bool PERPT = false>
-__global__ __launch_bounds__(kThreads, 2) void points_kernel_bf16(const PointsParamsBf p) {
+// X3 (MF_PREC_BF16X3; not with PERPT): the three-product networks, 4 waves, 128 points per tile.
+template <bool NOF, bool PERPT = false, bool X3 = false>
+__global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void points_kernel_bf16(const PointsParamsBf p) {
+  static_assert(!(X3 && PERPT), "per-point image indices: fast mode only");
+  constexpr int NW = X3 ? 4 : kWaves;
+  constexpr int TILE = NW * kWaveSamples;
   const Lane id;
-  load_resident(p.nerf, id);
-  if (NOF) load_resident(p.bw, id);
-  if (NOF && !PERPT) stage_raybias(p.raybias, 1, p.rb_layers, 0, 1, 0, p.rb_off, id);
+  load_resident<NW>(p.nerf, id);
+  if (NOF) load_resident<NW>(p.bw, id);
+  if (NOF && !PERPT) stage_raybias<NW>(p.raybias, 1, p.rb_layers, 0, 1, 0, p.rb_off, id);
   if (threadIdx.x < 128) {
     typedef const __attribute__((address_space(4))) char* kptr;
     const kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(PointsParamsBf, emb_par);
     *(float*)(smem + p.par_off + threadIdx.x * 4) = ((const __attribute__((address_space(4))) float*)ka)[threadIdx.x];
   }
   const uint32_t par_nerf_xyz = p.par_off, par_nof_xyz = p.par_off + 256;
-  Stream st;
+  StreamT<NW> st;
   st.tl.start(nullptr, id);
-  Carry carry;
-  const Next prog_first = NOF ? first_of<8, kKsNofXyz, true>(p.bw) : first_of<16, kKsNerfXyz, false>(p.nerf);
+  typename std::conditional<X3, CarryX, Carry>::type carry;
+  const Next nerf_first = first_of<16, kKsNerfXyz, X3>(p.nerf);
+  const Next prog_first = NOF ? first_of<8, kKsNofXyz, true>(p.bw) : nerf_first;
   if (NOF) start_program<8, kKsNofXyz, true>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);
-  else start_program<16, kKsNerfXyz, false>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
-  const long long ntiles = (p.B + bf::kTile - 1) / bf::kTile;
+  else start_program<16, kKsNerfXyz, X3>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
+  const long long ntiles = (p.B + TILE - 1) / TILE;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-    const long long b = tile * bf::kTile + id.wave * kWaveSamples + id.j;
+    const long long b = tile * TILE + id.wave * kWaveSamples + id.j;
     const bool valid = b < p.B;
     const long long bb = valid ? b : p.B - 1;
     float x[3] = {p.xyz[bb * 3 + 0], p.xyz[bb * 3 + 1], p.xyz[bb * 3 + 2]};
@@ -469,29 +474,44 @@ __global__ __launch_bounds__(kThreads, 2) void points_kernel_bf16(const PointsPa
         RayBias rb;
         load_raybias(rb, rbp, 0);                      // in flight across the encoding
         nof_embed(nhi, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
-        nof_eval(p.bw, nhi, nlo, x, st, carry, id, first_of<16, kKsNerfXyz, false>(p.nerf), out, rb, rbp, [] {});
+        nof_eval(p.bw, nhi, nlo, x, st, carry, id, nerf_first, out, rb, rbp, [] {});
       } else {
         LdsRayBias rb{p.rb_off};
         nof_embed(nhi, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
-        nof_eval(p.bw, nhi, nlo, x, st, carry, id, first_of<16, kKsNerfXyz, false>(p.nerf), out, rb, nullptr, [] {});
+        if constexpr (X3) nof_eval_x3(p.bw, nhi, nlo, x, st, carry, id, nerf_first, out, rb, [] {});
+        else nof_eval(p.bw, nhi, nlo, x, st, carry, id, nerf_first, out, rb, nullptr, [] {});
       }
       x[0] = out[0]; x[1] = out[1]; x[2] = out[2];
       if (valid && id.h == 0 && p.canon) {
         p.canon[b * 3 + 0] = x[0]; p.canon[b * 3 + 1] = x[1]; p.canon[b * 3 + 2] = x[2];
       }
     }
-    u32x4 xe[kKsNerfXyz];
-    {
-      float embx[B2Xyz10::SLOTS];
-      emb_eval<3, 10, true>(embx, x, par_nerf_xyz, id.h, p.pow2 & 1);
-      pack_operands<kKsNerfXyz>(embx, B2Xyz10::SLOTS, xe);
-    }
-    auto make_extra = [&](u32x4 (&eo)[kKsExtraMax]) {          // (sigma only: the extra block is never reached)
-#pragma unroll
-      for (int k = 0; k < kKsExtraMax; ++k) eo[k] = u32x4{0u, 0u, 0u, 0u};
-    };
     float sigma, rgb[3] = {0.f, 0.f, 0.f};
-    nerf_eval(p.nerf, xe, make_extra, true, st, carry, id, prog_first, sigma, rgb);
+    if constexpr (X3) {
+      u32x4 xh[kKsNerfXyz], xl[kKsNerfXyz];
+      {
+        float embx[B2Xyz10::SLOTS];
+        emb_eval<3, 10, false>(embx, x, par_nerf_xyz, id.h, p.pow2 & 1);
+        split_operands<kKsNerfXyz>(embx, B2Xyz10::SLOTS, xh, xl);
+      }
+      auto make_extra = [&](u32x4 (&eh)[kKsExtraMax], u32x4 (&el)[kKsExtraMax]) {   // (sigma only: never reached)
+#pragma unroll
+        for (int k = 0; k < kKsExtraMax; ++k) { eh[k] = u32x4{0u, 0u, 0u, 0u}; el[k] = u32x4{0u, 0u, 0u, 0u}; }
+      };
+      nerf_eval_x3(p.nerf, xh, xl, make_extra, true, st, carry, id, prog_first, sigma, rgb);
+    } else {
+      u32x4 xe[kKsNerfXyz];
+      {
+        float embx[B2Xyz10::SLOTS];
+        emb_eval<3, 10, true>(embx, x, par_nerf_xyz, id.h, p.pow2 & 1);
+        pack_operands<kKsNerfXyz>(embx, B2Xyz10::SLOTS, xe);
+      }
+      auto make_extra = [&](u32x4 (&eo)[kKsExtraMax]) {          // (sigma only: the extra block is never reached)
+#pragma unroll
+        for (int k = 0; k < kKsExtraMax; ++k) eo[k] = u32x4{0u, 0u, 0u, 0u};
+      };
+      nerf_eval(p.nerf, xe, make_extra, true, st, carry, id, prog_first, sigma, rgb);
+    }
     if (valid && id.h == 0) p.sigma[b] = sigma;
   }
   wait_vm0();
@@ -664,14 +684,16 @@ int64_t points_workspace_bytes_bf16(const mf_nof_desc* nof, int per_point_ind, i
   return (per_point_ind ? B : 1) * (int64_t)__builtin_popcount(1u | nof->skip_mask) * 128 * 4;
 }
 
-int points_sigma_bf16(const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz, const mf_nof_desc* nof,
+int points_sigma_bf16(int prec, const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz, const mf_nof_desc* nof,
                       const void* nof_packed, const mf_embedding* nof_emb_xyz, const mf_embedding* nof_emb_ind, const float* xyz,
                       const float* ind, float ind_scalar, int64_t B, float* sigma, float* canon, void* workspace,
                       int64_t workspace_bytes, hipStream_t st) {
   using namespace bf;
   PointsParamsBf p{};
   NetLayout Ln, Lb;
-  if (!nerf_layout(*nerf, Ln, 1)) return fail(MF_E_UNSUPPORTED, "mf_points_sigma: unsupported NeRF configuration (bf16: W = 256)");
+  const bool x3 = prec == MF_PREC_BF16X3;
+  if (x3 && nof && ind) return fail(MF_E_UNSUPPORTED, "mf_points_sigma(bf16x3): per-point image indices are not built (use MF_PREC_F32 or MF_PREC_BF16)");
+  if (!nerf_layout(*nerf, Ln, prec)) return fail(MF_E_UNSUPPORTED, "mf_points_sigma: unsupported NeRF configuration (bf16: W = 256)");
   uint32_t lds = 0;
   auto net_of = [&](const NetLayout& L, const void* packed, int D, int aux) {
     Net n;
@@ -688,7 +710,7 @@ int points_sigma_bf16(const mf_nerf_desc* nerf, const void* nerf_packed, const m
   int max_groups = Ln.max_groups;
   p.pow2 = emb_table(*emb_xyz, p.emb_par[0]) ? 1 : 0;
   if (nof) {
-    if (!nof_layout(*nof, Lb, 1)) return fail(MF_E_UNSUPPORTED, "mf_points_sigma: unsupported NoF configuration");
+    if (!nof_layout(*nof, Lb, prec)) return fail(MF_E_UNSUPPORTED, "mf_points_sigma: unsupported NoF configuration");
     p.bw = net_of(Lb, nof_packed, Lb.n_trunk, Lb.n_head);
     if (Lb.max_groups > max_groups) max_groups = Lb.max_groups;
     p.pow2 |= (emb_table(*nof_emb_xyz, p.emb_par[2]) ? 4 : 0) | (emb_table(*nof_emb_ind, p.emb_par[3]) ? 8 : 0);
@@ -716,13 +738,15 @@ int points_sigma_bf16(const mf_nerf_desc* nerf, const void* nerf_packed, const m
   lds += 3 * p.buf_bytes;
   if (nof) { p.rb_off = lds; lds += (uint32_t)round_up((int64_t)Lb.n_emb_layers * 512, 1024); }
   p.xyz = xyz; p.ind = ind; p.ind_scalar = ind_scalar; p.B = B; p.sigma = sigma; p.canon = canon;
-  const long long ntiles = (B + bf::kTile - 1) / bf::kTile;
+  const int tile = x3 ? 4 * bf::kWaveSamples : bf::kTile;
+  const long long ntiles = (B + tile - 1) / tile;
   const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
-  void (*kern)(const PointsParamsBf) = nof ? (ind ? points_kernel_bf16<true, true> : points_kernel_bf16<true, false>)
-                                           : points_kernel_bf16<false>;
+  void (*kern)(const PointsParamsBf) = x3 ? (nof ? points_kernel_bf16<true, false, true> : points_kernel_bf16<false, false, true>)
+                                          : (nof ? (ind ? points_kernel_bf16<true, true> : points_kernel_bf16<true, false>)
+                                                 : points_kernel_bf16<false>);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(MF_E_LAUNCH, "mf_points_sigma: cannot reserve %u bytes of LDS", lds);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(x3 ? 256 : kThreads), lds, st, p);
   return check_launch("mf_points_sigma(bf16)");
 }
 

@@ -16,11 +16,13 @@ def query_sigma(xyz, nerf, nerf_embedding_xyz, bw_nof=None, nof_embeddings=None,
     float in [-1,1) for all points, or a (B,) / (B,1) tensor); without them the query is made in
     canonical space (visualize_mesh with frame_idx == -1). Inference only.
     ``precision``: "f32" | "bf16" | "bf16x3" (None = the module setting of ``rendering.set_precision``); bf16 = hidden GEMMs
-    on the bf16 matrix pipe as in render_rays' gradient-free passes (the mesh-extraction lattice ~8x faster); bf16x3 (the
-    fp32-class mode of the render passes) has no point-query kernel: it runs the exact-fp32 one, so the setting never
-    costs accuracy."""
+    on the bf16 matrix pipe as in render_rays' gradient-free passes (the mesh-extraction lattice ~8x faster); bf16x3 = the
+    fp32-class three-product kernels (scalar ``ind`` or no NoF; with a per-point ``ind`` tensor the exact-fp32 kernel runs
+    instead, so the setting never costs accuracy)."""
     from . import rendering
-    prec = L.MF_PREC_BF16 if (precision or rendering.PRECISION) == "bf16" else L.MF_PREC_F32
+    prec = L.PRECISIONS[precision or rendering.PRECISION]
+    if prec == L.MF_PREC_BF16X3 and bw_nof is not None and torch.is_tensor(ind) and ind.numel() > 1:
+        prec = L.MF_PREC_F32
     L.require_gpu(xyz, "query_sigma")
     x = xyz.detach().float().contiguous()
     B = x.shape[0]

@@ -26,7 +26,7 @@ def timeit(f, n=3):
 
 
 print(f"{N}^3 = {xyz.shape[0] / 1e6:.1f} M lattice points")
-for prec in ("f32", "bf16"):
+for prec in ("f32", "bf16", "bf16x3"):
     ms = timeit(lambda: M.query_sigma(xyz, nerf, emb, precision=prec))
     print(f"  {prec:4s} canonical space (NeRF sigma)        : {ms:8.1f} ms  {xyz.shape[0] / (ms * 1e-3):.3e} points/s")
     ms = timeit(lambda: M.query_sigma(xyz, nerf, emb, nof, nof_embs, 0.25, precision=prec))
