@@ -246,9 +246,11 @@ int32_t mf_points_sigma(const mf_nerf_desc* nerf, const void* nerf_packed, const
                         const mf_nof_desc* nof, const void* nof_packed, const mf_embedding* nof_emb_xyz,
                         const mf_embedding* nof_emb_ind, const float* xyz, const float* ind,
                         float ind_scalar, int64_t B, float* sigma, float* canon, void* stream);
-/* The same query with the arithmetic of `precision` (MF_PREC_F32 | MF_PREC_BF16; the packed buffers must have been
- * packed for it): bf16 runs the hidden GEMMs of both networks on the bf16 matrix pipe like mf_render_pass does
- * (inference only; the 512^3 mesh-extraction lattice of test.py in ~0.15 s instead of ~0.9 s).  (ABI v11) */
+/* The same query with the arithmetic of `precision` (MF_PREC_F32 | MF_PREC_BF16 | MF_PREC_BF16X3; the packed buffers must
+ * have been packed for it): bf16 runs the hidden GEMMs of both networks on the bf16 matrix pipe like mf_render_pass does
+ * (inference only; the 512^3 mesh-extraction lattice of test.py in ~0.15 s instead of ~0.9 s); bf16x3 (ABI v13) the
+ * three-product kernels (fp32-class, ~0.3 s), with `ind` == NULL only (scalar image index, or no NoF): a per-point index
+ * tensor returns MF_E_UNSUPPORTED.  (ABI v11) */
 int32_t mf_points_sigma_p(int32_t precision, const mf_nerf_desc* nerf, const void* nerf_packed, const mf_embedding* emb_xyz,
                           const mf_nof_desc* nof, const void* nof_packed, const mf_embedding* nof_emb_xyz,
                           const mf_embedding* nof_emb_ind, const float* xyz, const float* ind,
