@@ -34,7 +34,8 @@ extern "C" {
  *     mf_smpl_frame_transforms, mf_apply_vertex_transforms
  * 12: MF_PREC_BF16 NoF takes its image-index block as a per-ray fp32 bias: mf_render_args.workspace(+_bytes),
  *     mf_render_workspace_bytes, mf_render_prepare, mf_loss_partials_backward, perturb arguments of mf_z_vals, mf_points_sigma_workspace_bytes, workspace arguments of mf_points_sigma_p
- * 13: MF_PREC_BF16X3 is the full three-product mode (own packed layout); mf_weight_grads_p, mf_weight_grads_scratch_bytes_p */
+ * 13: MF_PREC_BF16X3 is the full three-product mode (own packed layout); mf_weight_grads_p, mf_weight_grads_scratch_bytes_p,
+ *     mf_nerf_backward3 (+ mf_nerf_bwd3_packed_bytes, mf_nerf_pack_bwd3), MF_PREC_BF16X3 in mf_points_sigma_p and with the NeRF dump */
 #define MF_ABI_VERSION 13
 
 enum {
@@ -173,6 +174,16 @@ int32_t mf_nerf_backward(const mf_nerf_desc* d, const void* packed_bwd, int64_t 
 int32_t mf_nerf_backward_x(const mf_nerf_desc* d, const void* packed_bwd, int64_t P, const float* g_out,
                            const float* acts, int64_t stride, const float* rgbsigma, float* gpre,
                            float* ghead, float* g_emb, void* stream);
+/* The chain of mf_nerf_backward in three bf16 products (ABI v13; csrc/mf_backward_bf16.hip): gradients and transposed
+ * weights as (hi, lo) bf16 pairs, fp32 accumulation, ReLU masks from the dump as in the fp32 chain (no unit changes side:
+ * the result differs by the 2^-16 of the split operands).  Own packed stream (mf_nerf_bwd3_packed_bytes /
+ * mf_nerf_pack_bwd3); same arguments and outputs as mf_nerf_backward; no g_emb (callers that need the gradient of the
+ * embedded input use mf_nerf_backward_x).  W = 256, D >= 2. */
+int64_t mf_nerf_bwd3_packed_bytes(const mf_nerf_desc* d);
+int32_t mf_nerf_pack_bwd3(const mf_nerf_desc* d, void* packed, void* stream);
+int32_t mf_nerf_backward3(const mf_nerf_desc* d, const void* packed_bwd3, int64_t P, const float* g_out,
+                          const float* acts, int64_t stride, const float* rgbsigma, float* gpre,
+                          float* ghead, void* stream);
 /* Backward of Embedding.forward (models/embedding.py:42-46) through the embedded values themselves:
  * g_x[c] = g_emb[c] + sum_k f_k (emb[cos_kc] g_emb[sin_kc] - emb[sin_kc] g_emb[cos_kc]);  g_emb (P, >= C(2F+1))
  * with row stride g_stride, emb = the forward's output rows (stride e_stride), g_x (P, C). */

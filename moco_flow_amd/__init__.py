@@ -13,8 +13,8 @@ from .losses import MSELoss
 from .nerf import NeRF
 from .nof import NoF
 from .points import query_sigma
-from .autograd import set_wgrad_precision
+from .autograd import set_dx_precision, set_wgrad_precision
 from .rendering import render_rays, resample_merge, sample_pdf, set_precision, set_train_forward_precision
 
 __all__ = ["Embedding", "NeRF", "NoF", "get_model", "get_loss", "render_rays", "sample_pdf",
-           "resample_merge", "set_precision", "set_wgrad_precision", "set_train_forward_precision", "query_sigma", "MSELoss"]
+           "resample_merge", "set_precision", "set_wgrad_precision", "set_dx_precision", "set_train_forward_precision", "query_sigma", "MSELoss"]

@@ -41,6 +41,7 @@ class NeRF(nn.Module):
         self._packed = PackedWeights()
         self._packed_bf16 = PackedWeights()
         self._packed_x3 = PackedWeights()
+        self._packed_bwd3 = PackedWeights()
         self._packed_bwd = PackedWeights()
 
     # ---- HIP plumbing -----------------------------------------------------
@@ -82,7 +83,7 @@ class NeRF(nn.Module):
 
     def invalidate_packed(self):
         """Drop the packed-weight caches (needed only after in-place edits through ``param.data``)."""
-        for c in (self._packed, self._packed_bf16, self._packed_x3, self._packed_bwd):
+        for c in (self._packed, self._packed_bf16, self._packed_x3, self._packed_bwd, self._packed_bwd3):
             c.invalidate()
 
     def packed_bwd(self):
@@ -90,6 +91,12 @@ class NeRF(nn.Module):
         lib = L.lib()
         return self._packed_bwd.get(self, self._build_desc, lambda d, _p: lib.mf_nerf_bwd_packed_bytes(d),
                                     lambda d, _p, buf, st: lib.mf_nerf_pack_bwd(d, buf, st), "NeRF backward", "bwd")
+
+    def packed_bwd3(self):
+        """(descriptor, transposed (hi, lo) fragment stream) for mf_nerf_backward3."""
+        lib = L.lib()
+        return self._packed_bwd3.get(self, self._build_desc, lambda d, _p: lib.mf_nerf_bwd3_packed_bytes(d),
+                                     lambda d, _p, buf, st: lib.mf_nerf_pack_bwd3(d, buf, st), "NeRF backward (bf16x3)", "bwd3")
 
     def forward(self, inputs, sigma_only=False, img_ind=None):
         """inputs (B, in_channels_xyz [+ extra_feat_dim]) -> (B,4) rgb+sigma, or (B,1) sigma."""

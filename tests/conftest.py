@@ -35,6 +35,9 @@ def pytest_configure(config):
     if os.environ.get("MF_TEST_TRAIN_FWD"):
         from moco_flow_amd import rendering as _Rn
         _Rn.set_train_forward_precision(os.environ["MF_TEST_TRAIN_FWD"])
+    if os.environ.get("MF_TEST_DX"):
+        from moco_flow_amd import autograd as _A2
+        _A2.set_dx_precision(os.environ["MF_TEST_DX"])
     if os.environ.get("MF_TEST_WGRAD"):
         from moco_flow_amd import autograd as _A
         _A.set_wgrad_precision(os.environ["MF_TEST_WGRAD"])
@@ -79,10 +82,13 @@ def rccl_child():
 
 @pytest.fixture(params=["f32", "bf16x3"])
 def wgrad(request):
-    """Arithmetic of the weight-gradient contractions (autograd.set_wgrad_precision) for the duration of one test: the
-    exact-fp32 MFMA and the three-product bf16 split must both hold the gradient bars."""
+    """Arithmetic of the backward's matrix work -- the weight-gradient contractions (autograd.set_wgrad_precision) and the
+    NeRF's input-gradient chain (set_dx_precision) -- for the duration of one test: the exact-fp32 MFMA kernels and the
+    three-product bf16 ones must both hold the gradient bars."""
     from moco_flow_amd import autograd as A
-    old = A.WGRAD_PRECISION
+    old = (A.WGRAD_PRECISION, A.DX_PRECISION)
     A.set_wgrad_precision(request.param)
+    A.set_dx_precision(request.param)
     yield request.param
-    A.set_wgrad_precision(old)
+    A.set_wgrad_precision(old[0])
+    A.set_dx_precision(old[1])

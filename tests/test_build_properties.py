@@ -37,16 +37,19 @@ def _compile(unit, extra):
 
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_inference_kernels_have_no_spills_and_stream_weights_by_buffer_dma():
-    with ThreadPoolExecutor(2) as ex:
+    with ThreadPoolExecutor(3) as ex:
         f32 = ex.submit(_compile, "mf_render", [])
         b16 = ex.submit(_compile, "mf_render_bf16", ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"])      # csrc/Makefile builds this unit so
-        (u32, a32), (u16, a16) = f32.result(), b16.result()
+        bw3 = ex.submit(_compile, "mf_backward_bf16", ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"])
+        (u32, a32), (u16, a16), (ub3, _) = f32.result(), b16.result(), bw3.result()
+    u16 = {**u16, **{k: v for k, v in ub3.items() if "nerf_backward_kernel_x3" in k}}
     # render_kernel<MOCO, DUMP>: the two inference instantiations (DUMP = false) and every bf16 kernel
     x3 = [k for k in u16 if re.search(r"render_kernel_bf16ILb[01]ELb1ELb[01]E", k) or      # <MOCO, X3 = true, DUMP>
-          re.search(r"points_kernel_bf16ILb[01]ELb0ELb1E", k)]                            # <NOF, PERPT = false, X3 = true>
+          re.search(r"points_kernel_bf16ILb[01]ELb0ELb1E", k) or                           # <NOF, PERPT = false, X3 = true>
+          "nerf_backward_kernel_x3" in k]                                                 # the three-product dX chain
     want = [k for k in u32 if re.search(r"render_kernelILb[01]ELb0EE", k)] + \
            [k for k in u16 if ("render_kernel_bf16" in k or "points_kernel_bf16" in k) and k not in x3]
-    assert len(want) == 2 + 5 and len(x3) == 5, sorted(list(u32) + list(u16))   # fp32 NeRF / MoCo; bf16 render x 2, point query x 3; x3: NeRF, MoCo, NeRF + dump, point query x 2
+    assert len(want) == 2 + 5 and len(x3) == 6, sorted(list(u32) + list(u16))   # fp32 NeRF / MoCo; bf16 render x 2, point query x 3; x3: NeRF, MoCo, NeRF + dump, point query x 2
     for k in want:
         u = {**u32, **u16}[k]
         assert u["VGPRs Spill"] == 0 and u["ScratchSize"] == 0, (k, u)

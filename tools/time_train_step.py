@@ -12,6 +12,8 @@ from moco_flow_amd import synth, rendering
 from moco_flow_amd import autograd as _A
 if os.environ.get("MF_TRAIN_FWD"):
     rendering.set_train_forward_precision(os.environ["MF_TRAIN_FWD"])      # f32 | bf16x3
+if os.environ.get("MF_DX"):
+    _A.set_dx_precision(os.environ["MF_DX"])      # f32 | bf16x3
 if os.environ.get("MF_WGRAD"):
     _A.set_wgrad_precision(os.environ["MF_WGRAD"])      # f32 | bf16x3
 rendering.STRICT_RNG = False
