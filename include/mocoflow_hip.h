@@ -177,13 +177,12 @@ int32_t mf_nerf_backward_x(const mf_nerf_desc* d, const void* packed_bwd, int64_
 /* The chain of mf_nerf_backward in three bf16 products (ABI v13; csrc/mf_backward_bf16.hip): gradients and transposed
  * weights as (hi, lo) bf16 pairs, fp32 accumulation, ReLU masks from the dump as in the fp32 chain (no unit changes side:
  * the result differs by the 2^-16 of the split operands).  Own packed stream (mf_nerf_bwd3_packed_bytes /
- * mf_nerf_pack_bwd3); same arguments and outputs as mf_nerf_backward; no g_emb (callers that need the gradient of the
- * embedded input use mf_nerf_backward_x).  W = 256, D >= 2. */
+ * mf_nerf_pack_bwd3); same arguments and outputs as mf_nerf_backward_x (g_emb may be NULL).  W = 256, D >= 2. */
 int64_t mf_nerf_bwd3_packed_bytes(const mf_nerf_desc* d);
 int32_t mf_nerf_pack_bwd3(const mf_nerf_desc* d, void* packed, void* stream);
 int32_t mf_nerf_backward3(const mf_nerf_desc* d, const void* packed_bwd3, int64_t P, const float* g_out,
                           const float* acts, int64_t stride, const float* rgbsigma, float* gpre,
-                          float* ghead, void* stream);
+                          float* ghead, float* g_emb, void* stream);
 /* Backward of Embedding.forward (models/embedding.py:42-46) through the embedded values themselves:
  * g_x[c] = g_emb[c] + sum_k f_k (emb[cos_kc] g_emb[sin_kc] - emb[sin_kc] g_emb[cos_kc]);  g_emb (P, >= C(2F+1))
  * with row stride g_stride, emb = the forward's output rows (stride e_stride), g_x (P, C). */

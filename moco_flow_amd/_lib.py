@@ -120,7 +120,7 @@ SYMBOLS = {
     "mf_weight_grads_p": (C.c_int32, [C.c_int32, C.POINTER(mf_wgrad_item), C.c_int32, C.c_int64, _fp, _fp]),
     "mf_nerf_bwd3_packed_bytes": (C.c_int64, [C.POINTER(mf_nerf_desc)]),
     "mf_nerf_pack_bwd3": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, _fp]),
-    "mf_nerf_backward3": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, C.c_int64, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp]),
+    "mf_nerf_backward3": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, C.c_int64, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp, _fp]),
     "mf_nerf_backward": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, C.c_int64, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp]),
     "mf_render_pass": (C.c_int32, [C.POINTER(mf_render_args), _fp]),
     "mf_render_workspace_bytes": (C.c_int64, [C.POINTER(mf_render_args)]),

@@ -46,8 +46,8 @@ def needs_grad(modules) -> bool:
 
 # ------------------------------------------------------------------ explicit NeRF backward on the kernel's dump
 # Arithmetic of the NeRF's input-gradient chain (the D + 1 W-wide contractions on the transposed weights): "f32" =
-# mf_nerf_backward_x; "bf16x3" = mf_nerf_backward3 (three bf16 products of (hi, lo) pairs, masks from the dump as in fp32;
-# used where the gradient of the embedded input is not needed, i.e. without NoF in front of the NeRF).  End-to-end
+# mf_nerf_backward_x; "bf16x3" = mf_nerf_backward3 (three bf16 products of (hi, lo) pairs, masks from the dump as in fp32,
+# incl. the gradient of the embedded input the joint stage's NoFs need).  End-to-end
 # gradients against the oracle's autograd: 8e-6 max-rel (fp32 chain: 2e-6; bar 1e-4); stage-1 step 47.4 -> 41.6 ms.  The
 # default; set_dx_precision("f32") restores the exact-fp32 chain.
 DX_PRECISION = "bf16x3"
@@ -68,13 +68,14 @@ def nerf_backward_hip(m, g_out, acts, rgbsig, want_emb=False):
     g_out = g_out.contiguous().float()
     gpre = torch.empty(((P + 127) // 128 * 128, stride), device=dev, dtype=torch.float32)
     ghead = torch.empty((P, 4), device=dev, dtype=torch.float32)
-    if DX_PRECISION == "bf16x3" and not want_emb and m.W == 256 and m.D >= 2 and stride % 4 == 0:
+    if DX_PRECISION == "bf16x3" and m.W == 256 and m.D >= 2 and stride % 4 == 0 and (not want_emb or len(m.skips) <= 1):
         desc, buf = m.packed_bwd3()
+        g_emb = torch.empty((P, 64), device=dev, dtype=torch.float32) if want_emb else None
         with torch.cuda.device(dev):
             L.check(L.lib().mf_nerf_backward3(C.byref(desc), buf.data_ptr(), P, g_out.data_ptr(), acts.data_ptr(), stride,
-                                              rgbsig.data_ptr(), gpre.data_ptr(), ghead.data_ptr(), L.current_stream(dev)),
-                    "mf_nerf_backward3")
-        return gpre[:P], ghead, None
+                                              rgbsig.data_ptr(), gpre.data_ptr(), ghead.data_ptr(), L.ptr(g_emb),
+                                              L.current_stream(dev)), "mf_nerf_backward3")
+        return gpre[:P], ghead, g_emb
     desc, buf = m.packed_bwd()
     g_emb = torch.empty((P, 64), device=dev, dtype=torch.float32) if want_emb else None
     with torch.cuda.device(dev):

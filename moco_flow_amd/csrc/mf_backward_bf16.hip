@@ -11,8 +11,9 @@
 // A tile's epilogue (sigma term, mask, (hi, lo) split of the next layer's operand) runs in the MFMA gaps of the next tile;
 // its four 16-byte row stores sit behind that tile's last LDS-DMA piece so that the panel barrier leaves exactly them (and
 // the next tile's four mask loads) in flight (StreamT::sync<KEEP>).
-// Not built here: the gradient of the embedded input (mf_nerf_backward_x's g_emb: the joint stage's NoF training) -- callers
-// that need it use the fp32 chain.
+// The gradient of the embedded input (g_emb, ABI v9: the joint stage's NoF training) = W_0[:, :63]^T d_z_0 (+ one skip
+// layer: W_skip[:, :63]^T d_z_skip) follows as one or two 64-row layers behind the chain, d_z_skip re-read from the rows
+// this lane stored several layers earlier.
 #include "mf_bf16.hpp"
 #include "mf_host.hpp"
 #include "mf_layout.hpp"
@@ -29,12 +30,22 @@ namespace bf {
 // group (hi | lo of k-step ks): lane (i = lane & 31, h = lane >> 5) holds Wt[32 P + i][16 ks + hid_perm2(h, e)], e = 0..7.
 constexpr int kB3Zero = 0, kB3Rgb = 32, kB3Sig = 32 + 384, kB3ResFloats = 32 + 384 + 256;
 constexpr int kB3ResBytes = ((kB3ResFloats * 4 + kGroupBytes - 1) / kGroupBytes) * kGroupBytes;
-inline long long bwd3_groups_total(int D) { return 8LL * 16 + (long long)D * 8 * 32; }
+//                 [then, for g_emb: W_0[:, :63]^T and (one skip layer) W_skip[:, :63]^T: 2 tiles x 32 groups each, rows >= 63 zero]
+inline long long bwd3_groups_total(int D, int n_emb) { return 8LL * 16 + (long long)D * 8 * 32 + (long long)n_emb * 2 * 32; }
+inline int bwd3_skip_layer(const mf_nerf_desc& d) {      // the single skip layer, 0 = none, -1 = several
+  int s = 0;
+  for (int l = 1; l < d.D; ++l)
+    if ((d.skip_mask >> l) & 1u) { if (s) return -1; s = l; }
+  return s;
+}
 
 struct Bwd3PackJob {
-  const float* W[MF_MAX_LAYERS + 2];   // forward weight feeding backward layer i
-  int ld[MF_MAX_LAYERS + 2];           // its row length
-  int col0[MF_MAX_LAYERS + 2];         // first hidden column
+  const float* W[MF_MAX_LAYERS + 4];   // forward weight feeding backward layer i
+  int ld[MF_MAX_LAYERS + 4];           // its row length
+  int col0[MF_MAX_LAYERS + 4];         // first column read
+  int ncols[MF_MAX_LAYERS + 4];        // output rows present (rows beyond are zero): the embedded-input layers
+  int gpt[MF_MAX_LAYERS + 4];          // groups per tile
+  long long g0[MF_MAX_LAYERS + 5];     // first group of layer i
   int n_layers;
   const float* sigma_w; const float* rgb_w;
   float* res; unsigned* panels;
@@ -59,16 +70,16 @@ __global__ void pack_bwd3_kernel(Bwd3PackJob job) {
   const long long grp = gidx >> 6;
   if (grp >= job.total_groups) return;
   const int lane = (int)(gidx & 63), i = lane & 31, h = lane >> 5;
-  int li; long long local;
-  if (grp < 8 * 16) { li = 0; local = grp; }
-  else { li = 1 + (int)((grp - 8 * 16) / (8 * 32)); local = (grp - 8 * 16) % (8 * 32); }
-  const int gpt = li == 0 ? 16 : 32;                      // groups per tile
+  int li = 0;
+  while (li + 1 < job.n_layers && grp >= job.g0[li + 1]) ++li;
+  const long long local = grp - job.g0[li];
+  const int gpt = job.gpt[li];
   const int P = (int)(local / gpt), gi = (int)(local % gpt), ks = gi >> 1, lo = gi & 1;
   const int n = 32 * P + i;                               // output feature of the backward layer = forward input column
   unsigned short h8[8];
   for (int e = 0; e < 8; ++e) {
     const int k = 16 * ks + hid_perm2(h, e);              // forward output row
-    const float w = job.W[li][(long long)k * job.ld[li] + job.col0[li] + n];
+    const float w = n < job.ncols[li] ? job.W[li][(long long)k * job.ld[li] + job.col0[li] + n] : 0.f;
     const unsigned short hi = b3_rne(w);
     h8[e] = lo ? b3_rne(w - __uint_as_float((unsigned)hi << 16)) : hi;
   }
@@ -81,6 +92,8 @@ struct Bwd3Params {
   long long P, stride;
   const float* g_out; const float* acts; const float* rgbsigma;
   float* gpre; float* ghead;
+  float* g_emb;            // (P,64) dL/d embedded input (natural column order, column 63 = 0), or null
+  int skip;                // the skip layer (0 = none)
   uint32_t ring_off, buf_bytes;
 };
 
@@ -160,6 +173,18 @@ MF_D void bwd_layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[1
   __builtin_amdgcn_sched_barrier(0);
 }
 
+// A 64-row layer behind the chain (the embedded-input gradient): res[t] = Wt_tile (in, inlo), t = 0, 1; nothing stored.
+template <class ST>
+MF_D void bwd_emb_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[16], const u32x4 (&inlo)[16], uint32_t zero_off,
+                    const Next& nxt, f32x16 (&res)[2]) {
+  const Ahead t0{nxt.groups, nxt.jump, 0, nullptr}, t1{nxt.groups2, nxt.jump2, 0, nullptr};
+  auto nogap = [](int) {};
+  mma_tile_x<0, 16, 2, true>(st, id, carry, in, inlo, in, inlo, zero_off, t0, res[0], nogap);
+  st.advance();
+  mma_tile_x<0, 16, 2, true>(st, id, carry, in, inlo, in, inlo, zero_off, t1, res[1], nogap);
+  st.advance();
+}
+
 __global__ __launch_bounds__(256, 1) void nerf_backward_kernel_x3(const Bwd3Params p) {
   constexpr int NW = 4, TILE = NW * kWaveSamples;
   const Lane id;
@@ -230,8 +255,47 @@ __global__ __launch_bounds__(256, 1) void nerf_backward_kernel_x3(const Bwd3Para
 #pragma unroll
       for (int t = 0; t < 16; ++t) { ah[t] = bh[t]; al[t] = bl[t]; }
     }
-    if (D >= 2)
+    if (!p.g_emb) {
       bwd_layer_x<16, true, false, false>(st, id, carry, ah, al, bh, bl, zero_off, nfirst, arow, grow, 0u, 0.f);
+    } else {
+      // d emb = W_0[:, :63]^T d_z_0 (+ W_skip[:, :63]^T d_z_skip): two 32-row tiles each, K = W
+      bwd_layer_x<16, true, false, true>(st, id, carry, ah, al, bh, bl, zero_off, n32, arow, grow, 0u, 0.f);     // d_z_0 as an operand too
+      f32x16 ge[2];
+      bwd_emb_x(st, id, carry, bh, bl, zero_off, p.skip > 0 ? n32 : nfirst, ge);
+      if (p.skip > 0) {
+        // d_z_skip was stored by this very lane several layers ago (the panel barriers' vmcnt waits retired the stores)
+        const float* zrow = grow + (long long)p.skip * 256;
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) {
+          const f32x4 v0 = *reinterpret_cast<const f32x4*>(zrow + 16 * ks), v1 = *reinterpret_cast<const f32x4*>(zrow + 16 * ks + 8);
+          const float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+#pragma unroll
+          for (int w = 0; w < 4; ++w) {
+            const unsigned hi = pack_bf16x2(v[2 * w], v[2 * w + 1]);
+            ah[ks][w] = hi;
+            al[ks][w] = pack_bf16x2(v[2 * w] - bflo(hi), v[2 * w + 1] - bfhi(hi));
+          }
+        }
+        f32x16 g2[2];
+        bwd_emb_x(st, id, carry, ah, al, zero_off, nfirst, g2);
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) ge[t][r] += g2[t][r];
+      }
+      if (valid) {
+        float* er = p.g_emb + s * 64 + 4 * id.h;
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            f32x4 v;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = ge[t][4 * q + i];
+            *reinterpret_cast<f32x4*>(er + 32 * t + 8 * q) = v;
+          }
+      }
+    }
   }
   wait_vm0();
 }
@@ -245,10 +309,14 @@ static bool bwd3_supported(const mf_nerf_desc* d) {
   NetLayout F;
   return d && nerf_layout(*d, F, MF_PREC_BF16X3) && F.W == 256 && d->D >= 2;
 }
+static int bwd3_n_emb(const mf_nerf_desc* d) {           // embedded-input layers behind the chain (0 = g_emb unsupported)
+  const int sk = bf::bwd3_skip_layer(*d);
+  return sk < 0 ? 0 : (sk > 0 ? 2 : 1);
+}
 
 extern "C" int64_t mf_nerf_bwd3_packed_bytes(const mf_nerf_desc* d) {
   if (!bwd3_supported(d)) { fail(MF_E_UNSUPPORTED, "mf_nerf_bwd3_packed_bytes: unsupported NeRF configuration"); return 0; }
-  return bf::kB3ResBytes + bf::bwd3_groups_total(d->D) * kGroupBytes;
+  return bf::kB3ResBytes + bf::bwd3_groups_total(d->D, bwd3_n_emb(d)) * kGroupBytes;
 }
 
 extern "C" int32_t mf_nerf_pack_bwd3(const mf_nerf_desc* d, void* packed, void* stream) {
@@ -256,23 +324,34 @@ extern "C" int32_t mf_nerf_pack_bwd3(const mf_nerf_desc* d, void* packed, void* 
   if (!bwd3_supported(d)) return fail(MF_E_UNSUPPORTED, "mf_nerf_pack_bwd3: unsupported NeRF configuration (W=%d D=%d)", d->W, d->D);
   bf::Bwd3PackJob job{};
   const int ext = d->extra_feat_type == MF_EXTRA_NONE ? 0 : d->extra_feat_dim;
-  job.W[0] = d->extra_w; job.ld[0] = 256 + ext; job.col0[0] = 0;
-  job.W[1] = d->final_w; job.ld[1] = 256; job.col0[1] = 0;
+  long long g0 = 0;
+  job.W[0] = d->extra_w; job.ld[0] = 256 + ext; job.col0[0] = 0; job.ncols[0] = 256; job.gpt[0] = 16; job.g0[0] = g0; g0 += 8 * 16;
+  job.W[1] = d->final_w; job.ld[1] = 256; job.col0[1] = 0; job.ncols[1] = 256; job.gpt[1] = 32; job.g0[1] = g0; g0 += 8 * 32;
   for (int i = 2; i <= d->D; ++i) {
     const int l = d->D + 1 - i;
     const bool emb = ((1u | d->skip_mask) >> l) & 1u;
     job.W[i] = d->trunk_w[l];
     job.ld[i] = (emb ? d->in_channels_xyz : 0) + 256;
     job.col0[i] = emb ? d->in_channels_xyz : 0;
+    job.ncols[i] = 256; job.gpt[i] = 32; job.g0[i] = g0; g0 += 8 * 32;
   }
   job.n_layers = d->D + 1;
+  const int n_emb = bwd3_n_emb(d), sk = bf::bwd3_skip_layer(*d);
+  for (int e = 0; e < n_emb; ++e) {
+    const int i = job.n_layers++, l = e == 0 ? 0 : sk;
+    job.W[i] = d->trunk_w[l];
+    job.ld[i] = (l == 0 ? 0 : 256) + d->in_channels_xyz;
+    job.col0[i] = 0; job.ncols[i] = d->in_channels_xyz; job.gpt[i] = 32; job.g0[i] = g0; g0 += 2 * 32;
+  }
+  job.g0[job.n_layers] = g0;
   for (int i = 0; i < job.n_layers; ++i)
     if (!job.W[i]) return fail(MF_E_INVALID, "mf_nerf_pack_bwd3: missing weight pointer (backward layer %d)", i);
   if (!d->sigma_w || !d->rgb_w) return fail(MF_E_INVALID, "mf_nerf_pack_bwd3: missing sigma / rgb weight");
   job.sigma_w = d->sigma_w; job.rgb_w = d->rgb_w;
   job.res = static_cast<float*>(packed);
   job.panels = reinterpret_cast<unsigned*>(static_cast<char*>(packed) + bf::kB3ResBytes);
-  job.total_groups = bf::bwd3_groups_total(d->D);
+  job.total_groups = bf::bwd3_groups_total(d->D, n_emb);
+  if (g0 != job.total_groups) return fail(MF_E_INVALID, "mf_nerf_pack_bwd3: layout mismatch");
   const long long slots = job.total_groups * 64;
   hipLaunchKernelGGL(bf::pack_bwd3_kernel, dim3((unsigned)((slots + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), job);
   return check_launch("mf_nerf_pack_bwd3");
@@ -280,14 +359,17 @@ extern "C" int32_t mf_nerf_pack_bwd3(const mf_nerf_desc* d, void* packed, void* 
 
 extern "C" int32_t mf_nerf_backward3(const mf_nerf_desc* d, const void* packed_bwd3, int64_t P, const float* g_out,
                                      const float* acts, int64_t stride, const float* rgbsigma, float* gpre, float* ghead,
-                                     void* stream) {
+                                     float* g_emb, void* stream) {
   if (!d || !packed_bwd3 || (P > 0 && (!g_out || !acts || !rgbsigma || !gpre || !ghead)))
     return fail(MF_E_INVALID, "mf_nerf_backward3: null argument");
   if (!bwd3_supported(d)) return fail(MF_E_UNSUPPORTED, "mf_nerf_backward3: unsupported NeRF configuration (W=%d D=%d)", d->W, d->D);
   if (stride < (int64_t)(d->D + 1) * 256 + 128 || (stride & 3) || (reinterpret_cast<uintptr_t>(acts) & 15) || (reinterpret_cast<uintptr_t>(gpre) & 15))
     return fail(MF_E_INVALID, "mf_nerf_backward3: dump rows must be 16-byte aligned, stride >= (D + 1) W + W / 2 and a multiple of 4 floats");
+  if (g_emb && bwd3_n_emb(d) == 0)
+    return fail(MF_E_UNSUPPORTED, "mf_nerf_backward3: the embedded-input gradient is built for at most one skip layer");
   if (P == 0) return MF_OK;
   bf::Bwd3Params p{};
+  p.g_emb = g_emb; p.skip = bf::bwd3_skip_layer(*d) > 0 ? bf::bwd3_skip_layer(*d) : 0;
   p.net.packed = static_cast<const char*>(packed_bwd3);
   p.net.res_lds = 0; p.net.res_bytes = bf::kB3ResBytes; p.net.D = d->D; p.net.emb_mask = 0; p.net.aux = 0;
   p.P = P; p.stride = stride; p.g_out = g_out; p.acts = acts; p.rgbsigma = rgbsigma; p.gpre = gpre; p.ghead = ghead;

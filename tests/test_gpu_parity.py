@@ -1842,8 +1842,8 @@ def test_weight_grads_three_products_vs_float64(M, P):
 def test_nerf_backward_three_products_vs_fp32_chain(M, P):
     """mf_nerf_backward3 alone: on the SAME activation dump and output gradients as the fp32 chain (mf_nerf_backward_x),
     every pre-activation gradient [d z_0 .. d z_{D-1} | d final | d extra] agrees to 1e-4 max-rel per layer block (measured
-    ~1e-5: 16-bit operands, identical ReLU masks), ghead bit for bit (same VALU arithmetic), ragged sample counts, both
-    head types of the extra block, run-to-run bit-identical."""
+    ~1e-5: 16-bit operands, identical ReLU masks), ghead bit for bit (same VALU arithmetic), the embedded-input gradient
+    to 1e-4, ragged sample counts, both head types of the extra block, run-to-run bit-identical."""
     from moco_flow_amd import autograd as A, synth
     dev = torch.device("cuda")
     for ext_type, ext_dim in (("dir", 27), ("ind", 5)):
@@ -1865,13 +1865,15 @@ def test_nerf_backward_three_products_vs_fp32_chain(M, P):
         old = A.DX_PRECISION
         try:
             A.set_dx_precision("f32")
-            gp32, gh32, _ = A.nerf_backward_hip(nerf, g_out, acts, out)
+            gp32, gh32, ge32 = A.nerf_backward_hip(nerf, g_out, acts, out, want_emb=True)
             A.set_dx_precision("bf16x3")
             gp3, gh3, _ = A.nerf_backward_hip(nerf, g_out, acts, out)
-            gp3b, _, _ = A.nerf_backward_hip(nerf, g_out, acts, out)
+            gp3b, _, ge3 = A.nerf_backward_hip(nerf, g_out, acts, out, want_emb=True)
         finally:
             A.set_dx_precision(old)
         assert torch.equal(gp3, gp3b) and torch.equal(gh32, gh3)
+        # the gradient of the embedded input (two more 64-row layers: W_0^T d_z_0 + W_skip^T d_z_skip), column 63 = 0
+        assert relerr(ge3, ge32) <= TOL and float(ge3[:, 63].abs().max()) == 0.0, relerr(ge3, ge32)
         worst = 0.0
         for l in range(10):
             w = 128 if l == 9 else 256
