@@ -283,11 +283,13 @@ def train_leg(M, torch, models, rays, bg, gt, kw, cfg, steps=10):
         from moco_flow_amd import autograd as A
         out["flops_per_sample"] = flops
         out["wgrad_precision"] = A.WGRAD_PRECISION
-        # against the fp32 matrix peak: the forward and the dX chain run there; with wgrad_precision "bf16x3" the large
-        # weight-gradient blocks run on the bf16 pipe (three products) and against HBM, so this is a throughput in units of
-        # the fp32 peak, not a utilisation of one pipe
+        out["dx_precision"] = A.DX_PRECISION
+        # against the fp32 matrix peak: the forward runs there; with "bf16x3" the dX chain and the large weight-gradient
+        # blocks run on the bf16 pipe (three products) and against HBM, so this is a throughput in units of the fp32 peak,
+        # not a utilisation of one pipe
         out["mfma_frac"] = n * flops / (ms * 1e-3) / 1e12 / PEAK["f32"]
-        out["mfma_frac_note"] = "algorithmic FLOP/s of fwd + dX + dW over the fp32 matrix peak (dW blocks in " + A.WGRAD_PRECISION + ")"
+        out["mfma_frac_note"] = ("algorithmic FLOP/s of fwd + dX + dW over the fp32 matrix peak (dX chain in " + A.DX_PRECISION +
+                                 ", dW blocks in " + A.WGRAD_PRECISION + ")")
     return out
 
 
