@@ -177,12 +177,13 @@ int32_t mf_nerf_backward_x(const mf_nerf_desc* d, const void* packed_bwd, int64_
 /* The chain of mf_nerf_backward in three bf16 products (ABI v13; csrc/mf_backward_bf16.hip): gradients and transposed
  * weights as (hi, lo) bf16 pairs, fp32 accumulation, ReLU masks from the dump as in the fp32 chain (no unit changes side:
  * the result differs by the 2^-16 of the split operands).  Own packed stream (mf_nerf_bwd3_packed_bytes /
- * mf_nerf_pack_bwd3); same arguments and outputs as mf_nerf_backward_x (g_emb may be NULL).  W = 256, D >= 2. */
+ * mf_nerf_pack_bwd3); same arguments and outputs as mf_nerf_backward_x (g_emb may be NULL).  `mask` (nullable): the
+ * forward's mf_render_args.dump_mask rows -- the chain then reads no activation at all (`acts` may be NULL).  W = 256, D >= 2. */
 int64_t mf_nerf_bwd3_packed_bytes(const mf_nerf_desc* d);
 int32_t mf_nerf_pack_bwd3(const mf_nerf_desc* d, void* packed, void* stream);
 int32_t mf_nerf_backward3(const mf_nerf_desc* d, const void* packed_bwd3, int64_t P, const float* g_out,
                           const float* acts, int64_t stride, const float* rgbsigma, float* gpre,
-                          float* ghead, float* g_emb, void* stream);
+                          float* ghead, float* g_emb, const uint32_t* mask, int64_t mask_stride, void* stream);
 /* Backward of Embedding.forward (models/embedding.py:42-46) through the embedded values themselves:
  * g_x[c] = g_emb[c] + sum_k f_k (emb[cos_kc] g_emb[sin_kc] - emb[sin_kc] g_emb[cos_kc]);  g_emb (P, >= C(2F+1))
  * with row stride g_stride, emb = the forward's output rows (stride e_stride), g_x (P, C). */
@@ -340,6 +341,12 @@ typedef struct mf_render_args {
    * is constant along a ray).  mf_render_prepare fills it (one small launch); mf_render_pass reads it as those layers'
    * initial accumulator values.  Ignored (may be NULL) otherwise. */
   void* workspace; int64_t workspace_bytes;
+  /* ReLU bit mask of the NeRF's dumped activations (ABI v13; with dump_acts; NULL = none): dump_mask (N*S, dump_mask_stride
+   * >= 8 (D + 2) words): word 8 l + t covers outputs 32 t .. 32 t + 31 of layer l, output 32 t + f at bit
+   * (f < 16 ? 8 (f / 4) + f % 4 : 8 ((f - 16) / 4) + 4 + f % 4) -- the forward kernels' lane order -- for the trunk layers
+   * l = 0 .. D-1 and extra_encoding (l = D + 1, 4 words; l = D, xyz_encoding_final, is not written: no activation) -- what
+   * mf_nerf_backward3 needs of the activations: 32 bytes instead of 1 KiB per layer and sample. */
+  uint32_t* dump_mask; int64_t dump_mask_stride;
 } mf_render_args;
 
 /* mf_render_prepare(a) must have run on the same stream with the same rays / NoFs / nof_emb_ind / chain flags whenever

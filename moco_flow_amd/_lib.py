@@ -83,7 +83,8 @@ class mf_render_args(C.Structure):
                 ("dump_acts", _fp), ("dump_stride", C.c_int64), ("dump_rgbsigma", _fp), ("dump_xyz", _fp),
                 ("dump_nof_acts", _fp), ("dump_nof_stride", C.c_int64), ("dump_nof_emb", _fp), ("dump_nof_out", _fp),
                 ("dump_nof_plane", C.c_int32 * 5),
-                ("workspace", _fp), ("workspace_bytes", C.c_int64)]
+                ("workspace", _fp), ("workspace_bytes", C.c_int64),
+                ("dump_mask", _fp), ("dump_mask_stride", C.c_int64)]
 
 
 # every symbol include/mocoflow_hip.h declares: (restype, argtypes)
@@ -120,7 +121,7 @@ SYMBOLS = {
     "mf_weight_grads_p": (C.c_int32, [C.c_int32, C.POINTER(mf_wgrad_item), C.c_int32, C.c_int64, _fp, _fp]),
     "mf_nerf_bwd3_packed_bytes": (C.c_int64, [C.POINTER(mf_nerf_desc)]),
     "mf_nerf_pack_bwd3": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, _fp]),
-    "mf_nerf_backward3": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, C.c_int64, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp, _fp]),
+    "mf_nerf_backward3": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, C.c_int64, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp, _fp, C.c_int64, _fp]),
     "mf_nerf_backward": (C.c_int32, [C.POINTER(mf_nerf_desc), _fp, C.c_int64, _fp, _fp, C.c_int64, _fp, _fp, _fp, _fp]),
     "mf_render_pass": (C.c_int32, [C.POINTER(mf_render_args), _fp]),
     "mf_render_workspace_bytes": (C.c_int64, [C.POINTER(mf_render_args)]),

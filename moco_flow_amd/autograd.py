@@ -71,9 +71,13 @@ def nerf_backward_hip(m, g_out, acts, rgbsig, want_emb=False):
     if DX_PRECISION == "bf16x3" and m.W == 256 and m.D >= 2 and stride % 4 == 0 and (not want_emb or len(m.skips) <= 1):
         desc, buf = m.packed_bwd3()
         g_emb = torch.empty((P, 64), device=dev, dtype=torch.float32) if want_emb else None
+        mask = getattr(acts, "_mf_mask", None)          # the forward's ReLU bit-mask rows, when it wrote them (rendering.py)
+        if mask is not None and (mask.shape[0] != P or mask.shape[1] < (m.D + 2) * 8):
+            mask = None
         with torch.cuda.device(dev):
             L.check(L.lib().mf_nerf_backward3(C.byref(desc), buf.data_ptr(), P, g_out.data_ptr(), acts.data_ptr(), stride,
                                               rgbsig.data_ptr(), gpre.data_ptr(), ghead.data_ptr(), L.ptr(g_emb),
+                                              L.ptr(mask), mask.shape[1] if mask is not None else 0,
                                               L.current_stream(dev)), "mf_nerf_backward3")
         return gpre[:P], ghead, g_emb
     desc, buf = m.packed_bwd()

@@ -133,7 +133,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_backward_kernel(BwdParams p)
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = MF_TIMING_FLAGS ? p.dbg : 0;
-  st.keep2 = false;
+  st.keep2 = 0;
   const uint32_t zero_bias = net.res_lds + net.L.off_bias_trunk * 4;
   const char* first = net.packed + net.L.res_bytes;
   st.start(first, bwd_groups(net.L, 0), id);

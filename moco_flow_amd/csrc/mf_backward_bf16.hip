@@ -94,21 +94,28 @@ struct Bwd3Params {
   float* gpre; float* ghead;
   float* g_emb;            // (P,64) dL/d embedded input (natural column order, column 63 = 0), or null
   int skip;                // the skip layer (0 = none)
+  const unsigned* mask; long long mask_stride;   // the forward's ReLU bit-mask rows (BITS instantiation), else acts is read
   uint32_t ring_off, buf_bytes;
 };
 
 // value of accumulator register r of tile t: + the sigma term, masked by the forward activation
-template <bool MASK, bool SIG>
+// (BITS: m[0][0] carries the tile's mask word shifted by 8 h: row 8 q + 4 h + i = feature f of the tile sits at bit
+//  relu_mask_bit(f) = 8 h + {0, 16, 4, 20}[q] + i, mf_core.hpp)
+template <bool MASK, bool SIG, bool BITS>
 MF_D float b3_val(const f32x16& acc, const f32x4 (&m)[4], int r, uint32_t sigw_off, int t, int h, float dsig) {
   float v = acc[r];
   if (SIG) v = __builtin_fmaf(lds_f(sigw_off + (32 * t + 8 * (r >> 2) + 4 * h + (r & 3)) * 4), dsig, v);
-  if (MASK) v = m[r >> 2][r & 3] > 0.f ? v : 0.f;
+  if (MASK) {
+    if (BITS) v = ((__builtin_bit_cast(unsigned, m[0][0]) >> (((r >> 2) & 1) * 16 + ((r >> 2) >> 1) * 4 + (r & 3))) & 1u) ? v : 0.f;
+    else v = m[r >> 2][r & 3] > 0.f ? v : 0.f;
+  }
   return v;
 }
 
 // One backward layer: (out, outlo) <- split(mask * (Wt (in, inlo) [+ w_sigma d_sigma])), the fp32 values to grow[32 t + ...].
 // KHID = k-steps of the input (8 | 16).  mrow / grow: this lane's dump row / gradient row of the layer + 4 (lane >> 5).
-template <int KHID, bool MASK, bool SIG, bool OUT, class ST>
+// BITS: `mrow` points at the layer's 8 mask words of this lane's sample instead (one 4-byte load per tile).
+template <int KHID, bool MASK, bool SIG, bool OUT, bool BITS, class ST>
 MF_D void bwd_layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[16], const u32x4 (&inlo)[16], u32x4 (&out)[16],
                       u32x4 (&outlo)[16], uint32_t zero_off, const Next& nxt, const float* mrow, float* grow, uint32_t sigw_off,
                       float dsig) {
@@ -118,7 +125,7 @@ MF_D void bwd_layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[1
   auto step = [&](const f32x16& acc, const f32x4 (&m)[4], int sidx, int t) __attribute__((always_inline)) {
     const int u = sidx >> 1, w = u & 3, r = u < 4 ? 2 * u : 8 + 2 * (u - 4);
     if (!OUT) return;
-    const float v0 = b3_val<MASK, SIG>(acc, m, r, sigw_off, t, id.h, dsig), v1 = b3_val<MASK, SIG>(acc, m, r + 1, sigw_off, t, id.h, dsig);
+    const float v0 = b3_val<MASK, SIG, BITS>(acc, m, r, sigw_off, t, id.h, dsig), v1 = b3_val<MASK, SIG, BITS>(acc, m, r + 1, sigw_off, t, id.h, dsig);
     u32x4& hv = u < 4 ? out[2 * t] : out[2 * t + 1];
     if (!(sidx & 1)) {
       unsigned hi = pack_bf16x2(v0, v1);
@@ -134,14 +141,16 @@ MF_D void bwd_layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[1
   auto store = [&](const f32x16& acc, const f32x4 (&m)[4], int t, int q) __attribute__((always_inline)) {
     f32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = b3_val<MASK, SIG>(acc, m, 4 * q + i, sigw_off, t, id.h, dsig);
+    for (int i = 0; i < 4; ++i) v[i] = b3_val<MASK, SIG, BITS>(acc, m, 4 * q + i, sigw_off, t, id.h, dsig);
     *reinterpret_cast<f32x4*>(grow + 32 * t + 8 * q) = v;
   };
   auto run = [&](auto tc) __attribute__((always_inline)) {
     constexpr int t = decltype(tc)::value;
     const Ahead two{t + 2 < NT ? NG : (t == NT - 2 ? nxt.groups : nxt.groups2),
                     t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), 0, nullptr};
-    if constexpr (MASK) {                                     // this tile's mask: in flight across its MFMAs
+    if constexpr (MASK && BITS) {                             // this tile's mask word: in flight across its MFMAs
+      hm[0][0] = __builtin_bit_cast(float, reinterpret_cast<const unsigned*>(mrow)[t] >> (8 * id.h));
+    } else if constexpr (MASK) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) hm[q] = *reinterpret_cast<const f32x4*>(mrow + 32 * t + 8 * q);
     }
@@ -155,7 +164,7 @@ MF_D void bwd_layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[1
     f32x16 acc;
     // VM operations younger than the previous panel's last piece at this tile's first barrier: the four row stores that
     // closed the previous tile (tile 0: the layer in front; none behind tile 0) + this tile's four mask loads
-    constexpr int KEEP = (t == 1 ? 0 : 4) + (MASK ? 4 : 0);
+    constexpr int KEEP = (t == 1 ? 0 : 4) + (MASK ? (BITS ? 1 : 4) : 0);
     mma_tile_x<0, KHID, 2, true, KEEP, true>(st, id, carry, in, inlo, in, inlo, zero_off, two, acc, gap);
     st.advance();
     pend = acc;
@@ -185,6 +194,7 @@ MF_D void bwd_emb_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[16]
   st.advance();
 }
 
+template <bool BITS>
 __global__ __launch_bounds__(256, 1) void nerf_backward_kernel_x3(const Bwd3Params p) {
   constexpr int NW = 4, TILE = NW * kWaveSamples;
   const Lane id;
@@ -207,12 +217,14 @@ __global__ __launch_bounds__(256, 1) void nerf_backward_kernel_x3(const Bwd3Para
     const float4 rs = *reinterpret_cast<const float4*>(p.rgbsigma + ss * 4);
     const float d0 = go.x * rs.x * (1.f - rs.x), d1 = go.y * rs.y * (1.f - rs.y), d2 = go.z * rs.z * (1.f - rs.z);
     if (valid && id.h == 0) *reinterpret_cast<float4*>(p.ghead + s * 4) = make_float4(d0, d1, d2, go.w);
-    const float* arow = p.acts + ss * p.stride + 4 * id.h;
+    // BITS: "activation rows" are the sample's mask words (8 per layer); else the dump rows + 4 h
+    const float* arow = BITS ? reinterpret_cast<const float*>(p.mask + ss * p.mask_stride) : p.acts + ss * p.stride + 4 * id.h;
+    constexpr int LW = BITS ? 8 : 256;                           // row elements per layer
     float* grow = p.gpre + s * p.stride + 4 * id.h;             // rows up to round_up(P, 128) exist
     // d_e = (W_rgb^T d_o) [e > 0] as the (hi, lo) operands of 8 k-steps: slot e of step ks = feature 16 ks + hid_perm2(h, e)
     u32x4 ah[16], al[16], bh[16], bl[16];
     {
-      const float* erow = arow + (long long)(D + 1) * 256;
+      const float* erow = arow + (long long)(D + 1) * LW;
       float* gerow = grow + (long long)(D + 1) * 256;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
@@ -222,7 +234,14 @@ __global__ __launch_bounds__(256, 1) void nerf_backward_kernel_x3(const Bwd3Para
           const int f = 16 * ks + 8 * c;
           const f32x4 w0 = lds_f4(rgbw + (0 * 128 + f + 4 * id.h) * 4), w1 = lds_f4(rgbw + (1 * 128 + f + 4 * id.h) * 4);
           const f32x4 w2 = lds_f4(rgbw + (2 * 128 + f + 4 * id.h) * 4);
-          const f32x4 e4 = *reinterpret_cast<const f32x4*>(erow + f);
+          f32x4 e4;
+          if constexpr (BITS) {                                  // features (f & 31) + 4 h + r of word f / 32
+            const unsigned wv = reinterpret_cast<const unsigned*>(erow)[f >> 5];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) e4[r] = ((wv >> relu_mask_bit((f & 31) + 4 * id.h + r)) & 1u) ? 1.f : 0.f;
+          } else {
+            e4 = *reinterpret_cast<const f32x4*>(erow + f);
+          }
           f32x4 g;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -243,23 +262,23 @@ __global__ __launch_bounds__(256, 1) void nerf_backward_kernel_x3(const Bwd3Para
       for (int ks = 8; ks < 16; ++ks) { ah[ks] = u32x4{0u, 0u, 0u, 0u}; al[ks] = u32x4{0u, 0u, 0u, 0u}; }
     }
     // layer 0: d_g = W_e[:, :W]^T d_e (a -> b; xyz_encoding_final has no activation)
-    bwd_layer_x<8, false, false, true>(st, id, carry, ah, al, bh, bl, zero_off, n32, nullptr, grow + (long long)D * 256, 0u, 0.f);
+    bwd_layer_x<8, false, false, true, BITS>(st, id, carry, ah, al, bh, bl, zero_off, n32, nullptr, grow + (long long)D * 256, 0u, 0.f);
     // layer 1: d_z_{D-1} = (W_f^T d_g + w_sigma d_sigma) [h_{D-1} > 0] (b -> a)
-    bwd_layer_x<16, true, true, true>(st, id, carry, bh, bl, ah, al, zero_off, D >= 2 ? n32 : nfirst, arow + (long long)(D - 1) * 256,
+    bwd_layer_x<16, true, true, true, BITS>(st, id, carry, bh, bl, ah, al, zero_off, D >= 2 ? n32 : nfirst, arow + (long long)(D - 1) * LW,
                                       grow + (long long)(D - 1) * 256, sigw, go.w);
     // layers 2 .. D: d_z_{l-1} = (W_l^T d_z_l) [h_{l-1} > 0], l = D-1 .. 1 (a -> b, copied back); the last one only stores
     for (int i = 2; i < D; ++i) {
       const int l = D + 1 - i;
-      bwd_layer_x<16, true, false, true>(st, id, carry, ah, al, bh, bl, zero_off, n32, arow + (long long)(l - 1) * 256,
+      bwd_layer_x<16, true, false, true, BITS>(st, id, carry, ah, al, bh, bl, zero_off, n32, arow + (long long)(l - 1) * LW,
                                          grow + (long long)(l - 1) * 256, 0u, 0.f);
 #pragma unroll
       for (int t = 0; t < 16; ++t) { ah[t] = bh[t]; al[t] = bl[t]; }
     }
     if (!p.g_emb) {
-      bwd_layer_x<16, true, false, false>(st, id, carry, ah, al, bh, bl, zero_off, nfirst, arow, grow, 0u, 0.f);
+      bwd_layer_x<16, true, false, false, BITS>(st, id, carry, ah, al, bh, bl, zero_off, nfirst, arow, grow, 0u, 0.f);
     } else {
       // d emb = W_0[:, :63]^T d_z_0 (+ W_skip[:, :63]^T d_z_skip): two 32-row tiles each, K = W
-      bwd_layer_x<16, true, false, true>(st, id, carry, ah, al, bh, bl, zero_off, n32, arow, grow, 0u, 0.f);     // d_z_0 as an operand too
+      bwd_layer_x<16, true, false, true, BITS>(st, id, carry, ah, al, bh, bl, zero_off, n32, arow, grow, 0u, 0.f);     // d_z_0 as an operand too
       f32x16 ge[2];
       bwd_emb_x(st, id, carry, bh, bl, zero_off, p.skip > 0 ? n32 : nfirst, ge);
       if (p.skip > 0) {
@@ -359,10 +378,11 @@ extern "C" int32_t mf_nerf_pack_bwd3(const mf_nerf_desc* d, void* packed, void* 
 
 extern "C" int32_t mf_nerf_backward3(const mf_nerf_desc* d, const void* packed_bwd3, int64_t P, const float* g_out,
                                      const float* acts, int64_t stride, const float* rgbsigma, float* gpre, float* ghead,
-                                     float* g_emb, void* stream) {
-  if (!d || !packed_bwd3 || (P > 0 && (!g_out || !acts || !rgbsigma || !gpre || !ghead)))
+                                     float* g_emb, const uint32_t* mask, int64_t mask_stride, void* stream) {
+  if (!d || !packed_bwd3 || (P > 0 && (!g_out || (!acts && !mask) || !rgbsigma || !gpre || !ghead)))
     return fail(MF_E_INVALID, "mf_nerf_backward3: null argument");
   if (!bwd3_supported(d)) return fail(MF_E_UNSUPPORTED, "mf_nerf_backward3: unsupported NeRF configuration (W=%d D=%d)", d->W, d->D);
+  if (mask && mask_stride < (int64_t)(d->D + 2) * 8) return fail(MF_E_INVALID, "mf_nerf_backward3: mask_stride %lld < 8 (D + 2)", (long long)mask_stride);
   if (stride < (int64_t)(d->D + 1) * 256 + 128 || (stride & 3) || (reinterpret_cast<uintptr_t>(acts) & 15) || (reinterpret_cast<uintptr_t>(gpre) & 15))
     return fail(MF_E_INVALID, "mf_nerf_backward3: dump rows must be 16-byte aligned, stride >= (D + 1) W + W / 2 and a multiple of 4 floats");
   if (g_emb && bwd3_n_emb(d) == 0)
@@ -370,6 +390,7 @@ extern "C" int32_t mf_nerf_backward3(const mf_nerf_desc* d, const void* packed_b
   if (P == 0) return MF_OK;
   bf::Bwd3Params p{};
   p.g_emb = g_emb; p.skip = bf::bwd3_skip_layer(*d) > 0 ? bf::bwd3_skip_layer(*d) : 0;
+  p.mask = mask; p.mask_stride = mask_stride;
   p.net.packed = static_cast<const char*>(packed_bwd3);
   p.net.res_lds = 0; p.net.res_bytes = bf::kB3ResBytes; p.net.D = d->D; p.net.emb_mask = 0; p.net.aux = 0;
   p.P = P; p.stride = stride; p.g_out = g_out; p.acts = acts; p.rgbsigma = rgbsigma; p.gpre = gpre; p.ghead = ghead;
@@ -377,8 +398,9 @@ extern "C" int32_t mf_nerf_backward3(const mf_nerf_desc* d, const void* packed_b
   p.ring_off = lds; p.buf_bytes = 32 * kGroupBytes; lds += 3 * p.buf_bytes;
   const long long ntiles = (P + 127) / 128;
   const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(bf::nerf_backward_kernel_x3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  void (*kern)(const bf::Bwd3Params) = mask ? bf::nerf_backward_kernel_x3<true> : bf::nerf_backward_kernel_x3<false>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(MF_E_LAUNCH, "mf_nerf_backward3: cannot reserve %u bytes of LDS", lds);
-  hipLaunchKernelGGL(bf::nerf_backward_kernel_x3, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), p);
   return check_launch("mf_nerf_backward3");
 }

@@ -42,7 +42,7 @@ MF_D void bwd_layer(const f32x4 (&in)[NKI], const float (&sig)[kBwdSigSteps], f3
       *reinterpret_cast<f32x4*>(store_row + 32 * t + 4 * id.g) = E;
       *reinterpret_cast<f32x4*>(store_row + 32 * t + 16 + 4 * id.g) = O;
     }
-    st.keep2 = STORE && !(st.dbg & 4);   // the two youngest VM operations are this panel's row stores
+    st.keep2 = (STORE && !(st.dbg & 4)) ? 2 : 0;   // the two youngest VM operations are this panel's row stores
     out[2 * t] = E;
     out[2 * t + 1] = O;
     st.advance();

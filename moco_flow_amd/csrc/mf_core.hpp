@@ -359,7 +359,7 @@ struct Stream {
   uint32_t buf_bytes;     // bytes per slot
   uint32_t cur;           // slot (0..2) of the panel being computed
   int dbg;                // timing-ablation switches (MF_DEBUG_FLAGS; 0 in production)
-  bool keep2;             // KEEP2 instantiations only: this wave stores two dump rows per panel
+  int keep2;              // KEEP2 instantiations only: VM stores this wave issued at the end of the panel (0, 2: the dump rows, 3: + the mask word)
 
   MF_D uint32_t slot_off(uint32_t k) const {
     uint32_t s = cur + k;
@@ -392,7 +392,8 @@ struct Stream {
   MF_D void sync_and_dma(int groups, const char* jump, const LaneId& id, int ph = 2) {
     if (ph != 1) {
       jitter();
-      if (KEEP2 && keep2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      if (KEEP2 && keep2 == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+      else if (KEEP2 && keep2 == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
       else if (!(dbg & 16)) wait_vm0();
       if (!(dbg & 1)) __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -548,10 +549,21 @@ struct NextLayer {
 // `dump_row` (training forward only, DUMP instantiations): this lane's sample row of the activation
 // dump, already offset to this layer; the layer's post-activation outputs are stored there in
 // natural feature order (the dW GEMMs of the backward read them).  nullptr: nothing stored.
+// `mask_row` (ABI v13): this lane's sample row of the ReLU bit mask, offset to this layer (8 words = 32 bytes): byte
+// 4 t + g of the row = this lane's eight outputs of panel t -- bit r = [output 32 t + 4 g + r > 0], bit 4 + r = [output
+// 32 t + 16 + 4 g + r > 0] -- one byte store per lane and panel (no cross-lane traffic in the forward); what the
+// three-product dX chain reads instead of the 1 KiB of activations.  relu_mask_bit(f): bit of feature f (0..31) in word t.
+MF_D unsigned relu_mask_byte(const f32x4& E, const f32x4& O) {
+  unsigned w = 0;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) w |= (E[r] > 0.f ? 1u : 0u) << r | (O[r] > 0.f ? 0x10u : 0u) << r;
+  return w;
+}
+MF_HD int relu_mask_bit(int f) { return f < 16 ? 8 * (f >> 2) + (f & 3) : 8 * ((f - 16) >> 2) + 4 + (f & 3); }
 template <int NK, int EMB, bool DUMP = false>
 MF_D void trunk_layer(const NetDev& net, int layer, f32x4 (&act)[NK],
                       const float (&emb)[EMB], Stream& st, CarryT<kPD>& carry, const LaneId& id,
-                      const NextLayer& nxt, float* dump_row = nullptr) {
+                      const NextLayer& nxt, float* dump_row = nullptr, unsigned* mask_row = nullptr) {
   constexpr int NP = NK / 2;
   const int has_emb = (net.L.emb_mask >> layer) & 1;
   const int mode = (has_emb ? 1 : 0) | (layer > 0 ? 2 : 0);
@@ -579,7 +591,9 @@ MF_D void trunk_layer(const NetDev& net, int layer, f32x4 (&act)[NK],
         *reinterpret_cast<f32x4*>(dump_row + 32 * t + 4 * id.g) = E;
         *reinterpret_cast<f32x4*>(dump_row + 32 * t + 16 + 4 * id.g) = O;
       }
-      st.keep2 = __ballot(dump_row != nullptr) != 0ull;   // the wave issued the two stores
+      const bool wm = __ballot(mask_row != nullptr) != 0ull;
+      if (wm && dump_row && mask_row) reinterpret_cast<unsigned char*>(mask_row)[4 * t + id.g] = (unsigned char)relu_mask_byte(E, O);
+      st.keep2 = __ballot(dump_row != nullptr) != 0ull ? (wm ? 3 : 2) : 0;   // the wave issued the stores
     }
     st.advance();
   }

@@ -61,7 +61,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_forward_kernel(NerfFwdParams
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = 0;
-  st.keep2 = false;
+  st.keep2 = 0;
   start_program(net, st, carry, id);                    // also drains the resident-block DMA
   const long long ntiles = (p.B + kTile - 1) / kTile;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -124,7 +124,7 @@ __global__ __launch_bounds__(kThreads, 2) void nof_forward_kernel(NofFwdParams p
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = 0;
-  st.keep2 = false;
+  st.keep2 = 0;
   start_program(net, st, carry, id);
   const long long ntiles = (p.B + kTile - 1) / kTile;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -178,7 +178,7 @@ __global__ __launch_bounds__(kThreads, 2) void points_kernel(PointsParams p) {
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = 0;
-  st.keep2 = false;
+  st.keep2 = 0;
   const NextLayer prog_first = NOF ? follow_of(p.nof) : follow_of(p.nerf);
   if (NOF) start_program(p.nof, st, carry, id);
   else start_program(p.nerf, st, carry, id);

@@ -43,7 +43,7 @@ template <int NK, bool DUMP = false>
 MF_D void extra_layer(const NetDev& net, const f32x4 (&act)[NK],
                       const float (&ext)[kStepsExtraMax], f32x4 (&out)[NK / 2],
                       Stream& st, CarryT<kPD>& carry, const LaneId& id, const NextLayer& nxt,
-                      float* dump_row = nullptr) {
+                      float* dump_row = nullptr, unsigned* mask_row = nullptr) {
   constexpr int NPO = NK / 4;                      // panels of the (W/2)-wide layer
   constexpr int QH = NK;                           // hidden batches in front of the extra block
   const int groups = extra_groups(net.L);
@@ -84,7 +84,9 @@ MF_D void extra_layer(const NetDev& net, const f32x4 (&act)[NK],
         *reinterpret_cast<f32x4*>(dump_row + 32 * t + 4 * id.g) = E;
         *reinterpret_cast<f32x4*>(dump_row + 32 * t + 16 + 4 * id.g) = O;
       }
-      st.keep2 = __ballot(dump_row != nullptr) != 0ull;   // the wave issued the two stores
+      const bool wm = __ballot(mask_row != nullptr) != 0ull;
+      if (wm && dump_row && mask_row) reinterpret_cast<unsigned char*>(mask_row)[4 * t + id.g] = (unsigned char)relu_mask_byte(E, O);
+      st.keep2 = __ballot(dump_row != nullptr) != 0ull ? (wm ? 3 : 2) : 0;   // the wave issued the stores
     }
     st.advance();
   }
@@ -96,7 +98,8 @@ MF_D void extra_layer(const NetDev& net, const f32x4 (&act)[NK],
 template <int NK, bool DUMP = false>
 MF_D void nerf_eval(const NetDev& net, const float (&embx)[kStepsNerfXyz], const float (&ext)[kStepsExtraMax],
                     bool sigma_only, Stream& st, CarryT<kPD>& carry, const LaneId& id,
-                    const NextLayer& follow, float& sigma, float (&rgb)[3], float* dump_row = nullptr) {
+                    const NextLayer& follow, float& sigma, float (&rgb)[3], float* dump_row = nullptr,
+                    unsigned* mask_row = nullptr) {
   f32x4 act[NK];
 #pragma unroll
   for (int t = 0; t < NK; ++t)
@@ -106,7 +109,7 @@ MF_D void nerf_eval(const NetDev& net, const float (&embx)[kStepsNerfXyz], const
   for (int l = 0; l < D; ++l) {
     const bool last = sigma_only && l == D - 1;
     trunk_layer<NK, kStepsNerfXyz, DUMP>(net, l, act, embx, st, carry, id, last ? follow : next_trunk(net, l + 1),
-                                               dump_row ? dump_row + l * net.L.W : nullptr);
+                                               dump_row ? dump_row + l * net.L.W : nullptr, mask_row ? mask_row + l * 8 : nullptr);
     st.tl.stamp(10 + l, id);
   }
   float sg[1];
@@ -122,7 +125,8 @@ MF_D void nerf_eval(const NetDev& net, const float (&embx)[kStepsNerfXyz], const
                                              dump_row ? dump_row + D * net.L.W : nullptr);
   st.tl.stamp(31, id);
   f32x4 e[NK / 2];
-  extra_layer<NK, DUMP>(net, act, ext, e, st, carry, id, follow, dump_row ? dump_row + (D + 1) * net.L.W : nullptr);
+  extra_layer<NK, DUMP>(net, act, ext, e, st, carry, id, follow, dump_row ? dump_row + (D + 1) * net.L.W : nullptr,
+                        mask_row ? mask_row + (D + 1) * 8 : nullptr);
   st.tl.stamp(33, id);
   float o[3];
   valu_head(e, net.res_lds + net.L.off_rgb_w * 4, net.L.W / 2, net.res_lds + net.L.off_rgb_b * 4, id.g, o);

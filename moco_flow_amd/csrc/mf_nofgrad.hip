@@ -53,7 +53,7 @@ __global__ __launch_bounds__(kThreads, 2) void nof_points_dump_kernel(NofDumpPar
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = 0;
-  st.keep2 = false;
+  st.keep2 = 0;
   start_program(net, st, carry, id);
   const int D = net.L.n_trunk;
   const long long ntiles = (p.P + kTile - 1) / kTile;
@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kThreads, 2) void nof_points_dump_kernel(NofDumpPar
     f32x4 act[8];
 #pragma unroll
     for (int t = 0; t < 8; ++t) act[t] = f32x4{0.f, 0.f, 0.f, 0.f};
-    st.keep2 = false;
+    st.keep2 = 0;
     for (int l = 0; l < D; ++l)
       trunk_layer<8, kStepsNofIn, true>(net, l, act, emb, st, carry, id,
                                                l == D - 1 ? follow_of(net) : next_trunk(net, l + 1),
@@ -289,7 +289,7 @@ __global__ __launch_bounds__(kThreads, 2) void nof_backward_kernel(NofBwdParams 
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = MF_TIMING_FLAGS ? p.dbg : 0;
-  st.keep2 = false;
+  st.keep2 = 0;
   const uint32_t zero_bias = net.res_lds + net.L.off_bias_trunk * 4;
   const uint32_t headw = net.res_lds + net.L.off_head_w * 4;
   const char* first = net.packed + net.L.res_bytes;

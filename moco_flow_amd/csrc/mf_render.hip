@@ -42,6 +42,7 @@ struct RenderParams {
   uint32_t ring_off, buf_bytes, sbuf_off, zbuf_off;
   int dbg;
   float* dump_acts; long long dump_stride; float* dump_rgbsigma; float* dump_xyz;   // training forward
+  unsigned* dump_mask; long long dump_mask_stride;                                  // ReLU bit mask rows (optional)
   float* dump_nof_acts; long long dump_nof_stride; float* dump_nof_emb; float* dump_nof_out;   // per chain step
   uint32_t nof_plane_pack;     // plane of step k = (pack >> 3k) & 7   (a packed scalar: no runtime index into the kernarg)
 };
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
   st.ring = p.ring_off;
   st.buf_bytes = p.buf_bytes;
   st.dbg = MF_TIMING_FLAGS ? p.dbg : 0;
-  st.keep2 = false;
+  st.keep2 = 0;
   st.tl.start(p.alphas, id);
   // the panel program of a tile: [bw NoF, fw NoF chains,] NeRF, then around again
   const NextLayer prog_first = MOCO ? follow_of(p.bw) : follow_of(nerf);
@@ -169,7 +170,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
 #pragma unroll
               for (int q = 0; q < kStepsNofIn / 4; ++q) e4[q] = make_float4(emb[4 * q], emb[4 * q + 1], emb[4 * q + 2], emb[4 * q + 3]);
             }
-            st.keep2 = false;
+            st.keep2 = 0;
           }
           nof_eval<DUMP>(net, emb, cur, st, carry, id, follow, out, nof_row);
           if constexpr (DUMP) {
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
 #pragma unroll
       for (int e = 0; e < kStepsExtraMax; ++e) ext[e] = 0.f;
       float* dump_row = nullptr;
+      unsigned* mask_row = nullptr;
       {
         const Where w = where();
         if (!sigma_only) {
@@ -216,12 +218,13 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
         }
         if constexpr (DUMP) {
           if (w.valid && p.dump_acts) dump_row = p.dump_acts + (w.ray * S + w.si) * p.dump_stride;
+          if (p.dump_mask) mask_row = p.dump_mask + (w.ray * S + w.si) * p.dump_mask_stride;     // (uniformly non-null when asked for)
         }
       }
       st.tl.stamp(4, id);
       float sigma, rgb[3] = {0.f, 0.f, 0.f};
-      st.keep2 = false;      // the first panel's barrier drains everything (see Stream::sync_and_dma)
-      nerf_eval<16, DUMP>(nerf, embx, ext, sigma_only, st, carry, id, prog_first, sigma, rgb, dump_row);
+      st.keep2 = 0;      // the first panel's barrier drains everything (see Stream::sync_and_dma)
+      nerf_eval<16, DUMP>(nerf, embx, ext, sigma_only, st, carry, id, prog_first, sigma, rgb, dump_row, mask_row);
       {
         const Where w = where();
         if (w.valid && id.g == 0) {
@@ -452,6 +455,11 @@ static int32_t render_entry(const mf_render_args* a, void* stream, bool prepare_
   if (a->dump_acts && a->dump_stride < (int64_t)p.nerf.L.n_trunk * p.nerf.L.W + p.nerf.L.W / 2)
     return fail(MF_E_INVALID, "mf_render_pass: dump_stride %lld too small", (long long)a->dump_stride);
   p.dump_acts = a->dump_acts; p.dump_stride = a->dump_stride; p.dump_rgbsigma = a->dump_rgbsigma; p.dump_xyz = a->dump_xyz;
+  if (a->dump_mask) {
+    if (!a->dump_acts || a->dump_mask_stride < (int64_t)(p.nerf.L.n_trunk + 1) * 8)
+      return fail(MF_E_INVALID, "mf_render_pass: dump_mask needs dump_acts and dump_mask_stride >= 8 (D + 2) words");
+    p.dump_mask = a->dump_mask; p.dump_mask_stride = a->dump_mask_stride;
+  }
   if (a->dump_nof_acts) {
     if (!moco || !a->dump_nof_emb || !a->dump_nof_out) return fail(MF_E_INVALID, "mf_render_pass: dump_nof_acts needs NoF models, dump_nof_emb and dump_nof_out");
     if (a->dump_nof_stride < (int64_t)p.bw.L.n_trunk * p.bw.L.W + 16 || (a->dump_nof_stride & 3))

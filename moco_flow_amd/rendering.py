@@ -147,6 +147,12 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
         a.dump_stride = stride
         a.dump_rgbsigma = alloc("rgbsig", (N * S, 4))
         a.dump_xyz = alloc("xyz_in", (N * S, 3))
+        if not sigma_only and prec == L.MF_PREC_F32 and A.DX_PRECISION == "bf16x3":
+            # the ReLU bit mask of the dumped activations: all the three-product dX chain needs of them (32 bytes instead
+            # of 1 KiB per layer and sample); travels with the dump tensor
+            mw = (nerf.D + 2) * 8
+            out["acts"]._mf_mask = torch.empty((N * S, mw), device=dev, dtype=torch.int32)
+            a.dump_mask, a.dump_mask_stride = out["acts"]._mf_mask.data_ptr(), mw
         if nof_models is not None and len({(m.D, m.W) for m in nof_models}) == 1:
             # the chain's NoF evaluations dump too (one plane per step): no re-evaluation in the backward graph
             steps = 1 + (1 if chain_local else 0) + (3 if chain_global else 0)
