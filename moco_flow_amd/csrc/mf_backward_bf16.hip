@@ -142,6 +142,9 @@ MF_D void bwd_layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[1
     f32x4 v;
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = b3_val<MASK, SIG, BITS>(acc, m, 4 * q + i, sigw_off, t, id.h, dsig);
+#ifdef MF_B3_ABL_NOSTORE                                        // (timing ablation, tools/ab_lib.sh: results are garbage)
+    if (v[0] == 1.2345e-30f)
+#endif
     *reinterpret_cast<f32x4*>(grow + 32 * t + 8 * q) = v;
   };
   auto run = [&](auto tc) __attribute__((always_inline)) {

@@ -15,7 +15,7 @@ if [ "$mode" = build ]; then
   others=$(ls $REPO/moco_flow_amd/csrc/*.o | grep -v "/${unit%.hip}.o")
   # (csrc/Makefile builds the bf16 unit without SLP vectorisation -- packed-fp32 ops were not bit-stable there; the A/B
   #  variants of that unit must carry the same flag or they measure it too)
-  unitflags=""; [ "$unit" = mf_render_bf16.hip ] && unitflags="-fno-slp-vectorize -mllvm -pragma-unroll-threshold=1000000"
+  unitflags=""; [ "$unit" = mf_render_bf16.hip -o "$unit" = mf_backward_bf16.hip ] && unitflags="-fno-slp-vectorize -mllvm -pragma-unroll-threshold=1000000"
   for spec in "$@"; do
     name=${spec%%=*}; flags="${spec#*=} $unitflags"
     ( cd $REPO/moco_flow_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $flags -c $unit -o $AB/${unit%.hip}_$name.o \
