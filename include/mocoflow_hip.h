@@ -341,7 +341,7 @@ typedef struct mf_render_args {
    * is constant along a ray).  mf_render_prepare fills it (one small launch); mf_render_pass reads it as those layers'
    * initial accumulator values.  Ignored (may be NULL) otherwise. */
   void* workspace; int64_t workspace_bytes;
-  /* ReLU bit mask of the NeRF's dumped activations (ABI v13; with dump_acts; NULL = none): dump_mask (N*S, dump_mask_stride
+  /* ReLU bit mask of the NeRF's dumped activations (ABI v13; with dump_acts, passes without NoF; NULL = none): dump_mask (N*S, dump_mask_stride
    * >= 8 (D + 2) words): word 8 l + t covers outputs 32 t .. 32 t + 31 of layer l, output 32 t + f at bit
    * (f < 16 ? 8 (f / 4) + f % 4 : 8 ((f - 16) / 4) + 4 + f % 4) -- the forward kernels' lane order -- for the trunk layers
    * l = 0 .. D-1 and extra_encoding (l = D + 1, 4 words; l = D, xyz_encoding_final, is not written: no activation) -- what

@@ -147,7 +147,7 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
         a.dump_stride = stride
         a.dump_rgbsigma = alloc("rgbsig", (N * S, 4))
         a.dump_xyz = alloc("xyz_in", (N * S, 3))
-        if not sigma_only and prec == L.MF_PREC_F32 and A.DX_PRECISION == "bf16x3":
+        if not sigma_only and prec == L.MF_PREC_F32 and A.DX_PRECISION == "bf16x3" and nof_models is None:
             # the ReLU bit mask of the dumped activations: all the three-product dX chain needs of them (32 bytes instead
             # of 1 KiB per layer and sample); travels with the dump tensor
             mw = (nerf.D + 2) * 8

@@ -49,7 +49,7 @@ def test_inference_kernels_have_no_spills_and_stream_weights_by_buffer_dma():
           "nerf_backward_kernel_x3" in k]                                                 # the three-product dX chain
     want = [k for k in u32 if re.search(r"render_kernelILb[01]ELb0EE", k)] + \
            [k for k in u16 if ("render_kernel_bf16" in k or "points_kernel_bf16" in k) and k not in x3]
-    assert len(want) == 2 + 5 and len(x3) == 6, sorted(list(u32) + list(u16))   # fp32 NeRF / MoCo; bf16 render x 2, point query x 3; x3: NeRF, MoCo, NeRF + dump, point query x 2
+    assert len(want) == 2 + 5 and len(x3) == 7, sorted(list(u32) + list(u16))   # fp32 NeRF / MoCo; bf16 render x 2, point query x 3; x3: NeRF, MoCo, NeRF + dump, point query x 2, dX chain x 2
     for k in want:
         u = {**u32, **u16}[k]
         assert u["VGPRs Spill"] == 0 and u["ScratchSize"] == 0, (k, u)
