@@ -72,13 +72,18 @@ struct StreamT {
   // KEEP: VM operations this wave has issued behind its last piece of the panel that must have landed (dump stores of
   // the training forward: the VM counter retires in order, so "all but the KEEP youngest" still covers every piece
   // without waiting for those stores' round trip).  A LOWER bound is safe; 0 waits for everything.
+  // `keep_ok` (wave-uniform): the KEEP operations were really issued by this wave (a wave whose lanes all sit past the last
+  // sample issues no dump stores: its youngest operations ARE pieces).
   template <int KEEP = 0>
-  MF_D void sync(int groups, const char* jump, const Lane& id) {
+  MF_D void sync(int groups, const char* jump, const Lane& id, bool keep_ok = true) {
     // (MF_BF_ABL_*: timing-ablation builds only, tools/ab_lib.sh; results are garbage there)
     jitter();
 #ifndef MF_BF_ABL_NOWAIT
     if constexpr (KEEP == 0) wait_vm0();     // this wave's pieces of the NEXT panel have landed
-    else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+    else {
+      if (keep_ok) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
+      else wait_vm0();
+    }
 #endif
 #ifndef MF_BF_ABL_NOBAR
     __builtin_amdgcn_s_barrier();            // RAW: everybody's have; WAR: everybody left the previous panel
@@ -782,8 +787,10 @@ struct Ahead { int g0; const char* j0; int g1; const char* j1; };
 
 // Activation dump of the training forward (mf_render_args.dump_acts): `row` = this lane's sample row + the layer's first
 // column + 4 (lane >> 5); a tile's 16 accumulators are rows 8 q + 4 h + i, i.e. four 16-byte stores at row[32 t + 8 q].
+struct RowDump { float* row; bool on; bool wave_on; };     // wave_on: some lane of the wave stores (uniform)
+MF_D bool dump_wave_on(const RowDump& d) { return d.wave_on; }
 struct NoDump {};
-struct RowDump { float* row; bool on; };
+MF_D bool dump_wave_on(const NoDump&) { return true; }
 template <bool RELU>
 MF_D void dump_store(const RowDump& d, const f32x16& acc, int t, int q) {
   if (!d.on) return;
@@ -852,7 +859,7 @@ MF_D void epi_step(const f32x16& acc, int step, int h, u32x4& out0, u32x4& out1,
 // group pairs of the tile's last panel -- the caller's dump stores go there, behind every piece of the panel.
 template <int NGE, int KHID, int HMODE, bool EMB_FIRST, int KEEP = 0, bool LATE_FREE = false, class ST, class Gap>
 MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, const u32x4* hidlo, const u32x4* xhi, const u32x4* xlo,
-                     uint32_t bias_off, const Ahead& two, f32x16& acc, Gap&& gap) {
+                     uint32_t bias_off, const Ahead& two, f32x16& acc, Gap&& gap, bool keep_ok = true) {
   constexpr int NEG = 2 * NGE;
   constexpr int NHG = (HMODE ? 2 : 1) * KHID;
   constexpr int NG = NEG + NHG;
@@ -896,7 +903,7 @@ MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, co
     const int base = gi >= NG1 ? NG1 : 0, len = gi >= NG1 ? NG - NG1 : NG1, q = gi - base;
     if (q == 0) {
       if (base) st.sync(two.g1, two.j1, id);
-      else st.template sync<KEEP>(two.g0, two.j0, id);
+      else st.template sync<KEEP>(two.g0, two.j0, id, keep_ok);
     }
     if (nb >= NG) r[sp] = frag(nb);
     gap(m++);
@@ -968,7 +975,7 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
     };
     f32x16 acc;
     constexpr int KEEP = (DUMP && t != 1) ? 4 : 0;
-    mma_tile_x<NGE, KHID, HMODE, EMB_FIRST, KEEP, DUMP>(st, id, carry, in, inlo, xhi, xlo, bias_off + 32 * t * 4, two, acc, gap);
+    mma_tile_x<NGE, KHID, HMODE, EMB_FIRST, KEEP, DUMP>(st, id, carry, in, inlo, xhi, xlo, bias_off + 32 * t * 4, two, acc, gap, dump_wave_on(dump));
     st.advance();
 #ifdef MF_BF_X3_NODEFER
 #pragma unroll
@@ -1110,7 +1117,7 @@ MF_D void nerf_eval_x3(const Net& net, const u32x4 (&xh)[kKsNerfXyz], const u32x
                        bool sigma_only, ST& st, CarryX& carry, const Lane& id, const Next& follow, float& sigma,
                        float (&rgb)[3], const DT& dump = DT{}) {
   auto dump_at = [&](int col) {                               // the dump of a layer whose first column is `col`
-    if constexpr (__is_same(DT, RowDump)) return RowDump{dump.row + col, dump.on};
+    if constexpr (__is_same(DT, RowDump)) return RowDump{dump.row + col, dump.on, dump.wave_on};
     else return NoDump{};
   };
   u32x4 ah[16], al[16], bh[16], bl[16];

@@ -315,7 +315,8 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
         st.tl.stamp(4, id);
         if constexpr (DUMP) {
           const long long row = ray * S + si;
-          const RowDump dump{p.dump_acts + row * p.dump_stride + 4 * id.h, valid && p.dump_acts != nullptr};
+          const bool don = valid && p.dump_acts != nullptr;
+          const RowDump dump{p.dump_acts + row * p.dump_stride + 4 * id.h, don, __ballot(don) != 0ull};
           nerf_eval_x3(p.nerf, xh, xl, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb, dump);
           if (valid && id.h == 0) {
             if (p.dump_rgbsigma) *reinterpret_cast<float4*>(p.dump_rgbsigma + row * 4) = make_float4(rgb[0], rgb[1], rgb[2], sigma);

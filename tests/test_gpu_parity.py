@@ -412,6 +412,27 @@ def test_train_forward_bf16x3(M, R, name):
         rendering.set_train_forward_precision("f32")
     for g in grads[1:]:
         assert all(torch.equal(a, b) for a, b in zip(grads[0], g))
+    # ragged ends: sample counts that leave whole waves of the last 128-sample tile without a sample (such a wave issues no
+    # dump stores, so its panel barriers must wait for everything: StreamT::sync's keep_ok)
+    c40 = dict(RENDER_CASES["r_nerf_dir_S40"])
+    embs40, nerfs40, kw40 = build_case(M, c40, seed, device="cuda")
+    for n_r in (1, 5, 7):
+        r40, b40 = case_inputs(c40, seed, n=n_r)
+        _, want40 = None, None
+        embs_o, nerfs_o, kw_o = build_case(R, c40, seed)
+        with torch.no_grad():
+            want40 = R.render_rays(r40, b40, embs_o, nerfs_o, **kw_o)
+        outs = []
+        try:
+            rendering.set_train_forward_precision("bf16x3")
+            for _ in range(3):
+                outs.append(M.render_rays(r40.cuda(), b40.cuda(), embs40, nerfs40, **kw40))
+        finally:
+            rendering.set_train_forward_precision("f32")
+        assert outs[0]["rgb_coarse"].requires_grad
+        for k in ("rgb_coarse", "depth_coarse", "opacity_coarse"):
+            assert relerr(outs[0][k], want40[k]) <= TOL, (n_r, k, relerr(outs[0][k], want40[k]))
+            assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k])
 
 
 @pytest.mark.parametrize("name", sorted(GRAD_BARS))
