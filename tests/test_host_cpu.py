@@ -79,6 +79,48 @@ def test_backward_entry_points_validate_on_the_host():
     assert lib.mf_image_compose(None, None, 0, None, None, None, None, None, None, None) == 0
 
 
+def test_three_product_entry_points_validate_on_the_host():
+    """ABI v13 (mf_weight_grads_p, mf_nerf_backward3 and its packer, MF_PREC_BF16X3 in the point query): sizes, scratch
+    plans and argument validation are host-side and must not need a GPU."""
+    import moco_flow_amd._lib as L
+    lib = L.lib()
+    d = L.mf_nerf_desc()
+    d.D, d.W, d.in_channels_xyz, d.skip_mask = 8, 256, 63, 1 << 4
+    d.extra_feat_type, d.extra_feat_dim = L.MF_EXTRA_DIR, 27
+    # transposed (hi, lo) stream: 3 KiB resident + extra^T (K = 128: 8 tiles x 16 groups) + 8 layers x (8 x 32) + the two
+    # 64-row layers of the embedded-input gradient (2 x 32 each)
+    assert lib.mf_nerf_bwd3_packed_bytes(ctypes.byref(d)) == 3 * 1024 + (8 * 16 + 8 * 8 * 32 + 2 * 2 * 32) * 1024
+    d.skip_mask = 0
+    assert lib.mf_nerf_bwd3_packed_bytes(ctypes.byref(d)) == 3 * 1024 + (8 * 16 + 8 * 8 * 32 + 1 * 2 * 32) * 1024
+    d.skip_mask = (1 << 2) | (1 << 4)          # two skip layers: the chain is built, the embedded-input gradient is not
+    assert lib.mf_nerf_bwd3_packed_bytes(ctypes.byref(d)) == 3 * 1024 + (8 * 16 + 8 * 8 * 32) * 1024
+    d.W = 128
+    assert lib.mf_nerf_bwd3_packed_bytes(ctypes.byref(d)) == 0 and b"unsupported" in lib.mf_last_error()
+    assert lib.mf_nerf_backward3(None, None, 0, None, None, 0, None, None, None, None, None, 0, None) == -1
+    assert lib.mf_nerf_pack_bwd3(None, None, None) == -1
+    # weight-gradient plan per precision: the three-product blocks are planned apart from the fp32 ones
+    items = (L.mf_wgrad_item * 3)()
+    buf = (ctypes.c_float * 4096)()
+    base = ctypes.addressof(buf) & ~15
+    for it, (no, ni) in zip(items, [(256, 256), (128, 256), (4, 640)]):
+        it.G, it.g_stride, it.n_out, it.X, it.x_stride, it.n_in, it.dW, it.db = base, 2432, no, base, 2432, ni, base, None
+    P = 100000
+    lo = (256 * 256 + 256 + 128 * 256 + 128 + 16 * 640 + 16) * 4
+    for prec in (L.MF_PREC_F32, L.MF_PREC_BF16X3):
+        nbytes = lib.mf_weight_grads_scratch_bytes_p(prec, items, 3, P)
+        assert lo <= nbytes <= 300 * lo, (prec, nbytes)
+    assert lib.mf_weight_grads_scratch_bytes_p(L.MF_PREC_F32, items, 3, P) == lib.mf_weight_grads_scratch_bytes(items, 3, P)
+    assert lib.mf_weight_grads_scratch_bytes_p(L.MF_PREC_BF16, items, 3, P) == -1          # not an arithmetic of this call
+    assert lib.mf_weight_grads_p(L.MF_PREC_BF16, items, 3, P, None, None) < 0
+    # point query: the workspace (per-point / single NoF bias) exists for both bf16 arithmetics
+    n = L.mf_nof_desc()
+    n.D, n.W, n.in_channels_xyz, n.extra_feat_dim, n.skip_mask, n.use_quat = 4, 128, 33, 33, 1 << 2, 1
+    assert lib.mf_points_sigma_workspace_bytes(L.MF_PREC_F32, ctypes.byref(n), 0, 1000) == 0
+    assert lib.mf_points_sigma_workspace_bytes(L.MF_PREC_BF16, ctypes.byref(n), 0, 1000) == 2 * 128 * 4
+    assert lib.mf_points_sigma_workspace_bytes(L.MF_PREC_BF16X3, ctypes.byref(n), 0, 1000) == 2 * 128 * 4
+    assert lib.mf_points_sigma_workspace_bytes(L.MF_PREC_BF16, ctypes.byref(n), 1, 1000) == 1000 * 2 * 128 * 4
+
+
 def test_packed_layout_sizes():
     """Packed sizes follow from the panel program: NeRF dir/27 = resident 13 KiB +
     (L0 8 + 3x32 + skip 40 + 3x32 + final 32) groups x 8 panels + extra 36 groups x 4 panels."""
