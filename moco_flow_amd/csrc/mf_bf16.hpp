@@ -171,13 +171,16 @@ struct Next {
   int groups; const char* jump;
   int groups2; const char* jump2;
 };
-template <int KH, int EKS, bool SPLIT>
-MF_D Next first_of(const Net& n) {       // layer 0: embedded input only
-  return Next{(SPLIT ? 2 : 1) * EKS, n.packed + n.res_bytes, (SPLIT ? 2 : 1) * EKS, nullptr};
+// PAIR (the fast mode's NoF, 128 wide: four tiles of 6-14 groups per layer): TWO tiles stream as one panel -- half the
+// barriers of a NoF evaluation, whose tiles are 8-14 MFMAs long.
+template <int KH, int EKS, bool SPLIT, int TPP = 1>
+MF_D Next first_of(const Net& n) {       // layer 0: embedded input only, TPP tiles per panel
+  return Next{TPP * (SPLIT ? 2 : 1) * EKS, n.packed + n.res_bytes, TPP * (SPLIT ? 2 : 1) * EKS, nullptr};
 }
-template <int KH, int EKS, bool SPLIT, int HS = 0>
+template <int KH, int EKS, bool SPLIT, int HS = 0, bool PAIR = false>
 MF_D Next next_trunk_bf(const Net& n, int layer) {
-  return Next{tgroups<KH, EKS, SPLIT, HS>(n, layer), nullptr, tgroups<KH, EKS, SPLIT, HS>(n, layer), nullptr};
+  const int g = (PAIR ? 2 : 1) * tgroups<KH, EKS, SPLIT, HS>(n, layer);
+  return Next{g, nullptr, g, nullptr};
 }
 
 template <int N>
@@ -346,27 +349,33 @@ struct NoRayBias {};
 // stage_raybias in mf_render_bf16.hip): `lane_off` = LDS byte offset of this lane's ray's [embedded layer][128] block.
 // The accumulators then start with four ds_reads exactly like the static bias, only from a per-lane address.
 struct LdsRayBias { uint32_t lane_off; };
-template <int KH, int NGE, int MODE, bool SPLIT, class RBT = NoRayBias>
+template <int KH, int NGE, int MODE, bool SPLIT, class RBT = NoRayBias, int TPP = 1>
 MF_D void trunk_layer_m(const Net& net, int layer, bool relu, const u32x4 (&act)[KH], u32x4 (&out)[KH], const u32x4 (&xhi)[NGE],
                         const u32x4 (&xlo)[NGE], Stream& st, Carry& carry, const Lane& id, const Next& nxt, const RBT& rb) {
   constexpr bool RB = __is_same(RBT, RayBias);
   static_assert(!RB || KH == 8, "per-ray bias: 128-wide layers (4 tiles)");
   constexpr int NT = KH / 2;
-  const int groups = ((MODE & 1) ? (SPLIT ? 2 : 1) * NGE : 0) + ((MODE & 2) ? KH : 0);
+  constexpr int NP = NT / TPP;                          // panels of the layer (TPP tiles each)
+  static_assert(NT % TPP == 0, "tiles per panel");
+  const int groups = ((MODE & 1) ? (SPLIT ? 2 : 1) * NGE : 0) + ((MODE & 2) ? KH : 0);      // of one tile
+  const int pgroups = TPP * groups;                                                           // of one panel
   const unsigned lo = relu ? 0u : 0x80008000u;      // ReLU / pass-through floor
   uint32_t bias_off = net.res_lds + layer * (16 * KH) * 4;
   if constexpr (__is_same(RBT, LdsRayBias) && (MODE & 1))      // embedded layer number popcount(mask below `layer`)
     bias_off = rb.lane_off + (uint32_t)__builtin_popcount(net.emb_mask & ((1u << layer) - 1u)) * (16 * KH) * 4;
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const uint32_t p = st.slot_off(0) + id.lane * 16;
-    const uint32_t pn = st.slot_off(1) + id.lane * 16;
-    // panel two ahead: same layer while t+2 < NT, else panel (t+2-NT) of the next layer
+    const int pi = t / TPP, sub = t % TPP;             // panel of this tile, position inside it
+    const bool second = sub != 0;                      // (not the tile that carries the panel's barrier and DMA)
+    const uint32_t p = st.slot_off(0) + id.lane * 16 + sub * groups * kGroupBytes;
+    const uint32_t pn = sub == TPP - 1 ? st.slot_off(1) + id.lane * 16 : p + groups * kGroupBytes;
+    // panel two ahead: same layer while pi + 2 < NP, else panel (pi + 2 - NP) of the next layer
     auto hook = [&]() {
-      st.sync(t + 2 < NT ? groups : (t == NT - 2 ? nxt.groups : nxt.groups2),
-              t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id);
+      if (second) return;
+      st.sync(pi + 2 < NP ? pgroups : (pi == NP - 2 ? nxt.groups : nxt.groups2),
+              pi == NP - 2 ? nxt.jump : (pi == NP - 1 ? nxt.jump2 : nullptr), id);
     };
-    auto piece = [&](int k) { st.piece(k, id); };
+    auto piece = [&](int k) { if (!second) st.piece(k, id); };
     if constexpr (RB && (MODE & 1)) {
       out_tile<NGE, (MODE & 2) ? KH : 0, true, SPLIT, true>(carry, act, xhi, xlo, p, pn, 0u, rb.t[t < 4 ? t : 0], id.h, hook, piece, lo,
                                                             out[2 * t], out[2 * t + 1]);
@@ -375,18 +384,18 @@ MF_D void trunk_layer_m(const Net& net, int layer, bool relu, const u32x4 (&act)
       out_tile<(MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, true, SPLIT, false>(carry, act, xhi, xlo, p, pn, bias_off + 32 * t * 4, none,
                                                                              id.h, hook, piece, lo, out[2 * t], out[2 * t + 1]);
     }
-    st.advance();
+    if (sub == TPP - 1) st.advance();
   }
 }
 
 // in -> out (two register sets: the callers alternate them from layer to layer, so no layer ends in a 64-register copy)
-template <int KH, int NGE, bool SPLIT, class RBT = NoRayBias>
+template <int KH, int NGE, bool SPLIT, class RBT = NoRayBias, bool PAIR = false, int TPP0 = (PAIR ? 2 : 1)>
 MF_D void trunk_layer(const Net& net, int layer, bool relu, const u32x4 (&act)[KH], u32x4 (&out)[KH], const u32x4 (&xhi)[NGE],
                       const u32x4 (&xlo)[NGE], Stream& st, Carry& carry, const Lane& id, const Next& nxt, const RBT& rb) {
   const int has_emb = (net.emb_mask >> layer) & 1;
-  if (layer == 0) trunk_layer_m<KH, NGE, 1, SPLIT, RBT>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt, rb);
-  else if (has_emb) trunk_layer_m<KH, NGE, 3, SPLIT, RBT>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt, rb);
-  else trunk_layer_m<KH, NGE, 2, SPLIT, RBT>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt, rb);
+  if (layer == 0) trunk_layer_m<KH, NGE, 1, SPLIT, RBT, TPP0>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt, rb);
+  else if (has_emb) trunk_layer_m<KH, NGE, 3, SPLIT, RBT, PAIR ? 2 : 1>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt, rb);
+  else trunk_layer_m<KH, NGE, 2, SPLIT, RBT, PAIR ? 2 : 1>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt, rb);
 }
 
 // This lane's rows of the per-ray bias of embedded layer number `el` (0 = layer 0, 1 = the first skip layer, ...):
@@ -417,7 +426,7 @@ MF_D void load_raybias(LdsRayBias&, const float*, int) {}
 // right behind it.  One set is live at a time.
 // `after_first()` runs once behind layer 0 (the render pass stages the NEXT chain step's per-ray bias rows there: this
 // wave is past the step's first panel barrier, and every later barrier of the step publishes them).
-template <int KH, int NGE, bool SPLIT, class NextOf, class RBT, class AfterFirst>
+template <int KH, int NGE, bool SPLIT, bool PAIR = false, int TPP0 = (PAIR ? 2 : 1), class NextOf, class RBT, class AfterFirst>
 MF_D void trunk(const Net& net, int D, u32x4 (&a)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE], Stream& st, Carry& carry,
                 const Lane& id, NextOf&& next_of, RBT& rb, const float* rbp, AfterFirst&& after_first) {
   constexpr bool RB = __is_same(RBT, RayBias);
@@ -428,11 +437,11 @@ MF_D void trunk(const Net& net, int D, u32x4 (&a)[KH], const u32x4 (&xhi)[NGE], 
     if constexpr (RB) {
       const bool emb_here = (net.emb_mask >> layer) & 1, emb_next = layer + 1 < D && ((net.emb_mask >> (layer + 1)) & 1);
       if (!emb_here && emb_next) load_raybias(rb, rbp, el);
-      trunk_layer<KH, NGE, SPLIT, RBT>(net, layer, true, in, out, xhi, xlo, st, carry, id, next_of(layer), rb);
+      trunk_layer<KH, NGE, SPLIT, RBT, PAIR, TPP0>(net, layer, true, in, out, xhi, xlo, st, carry, id, next_of(layer), rb);
       if (emb_here && emb_next) load_raybias(rb, rbp, el);
       if (emb_next) ++el;
     } else {
-      trunk_layer<KH, NGE, SPLIT, RBT>(net, layer, true, in, out, xhi, xlo, st, carry, id, next_of(layer), rb);
+      trunk_layer<KH, NGE, SPLIT, RBT, PAIR, TPP0>(net, layer, true, in, out, xhi, xlo, st, carry, id, next_of(layer), rb);
     }
   };
   for (; l + 1 < D; l += 2) {
@@ -633,9 +642,9 @@ MF_D void pack_operands(const float* emb, int n_slots, u32x4 (&x)[KS]) {
 }
 
 // ------------------------------------------------------------------ the two networks
-template <int KH, int EKS, bool SPLIT, class ST, class CR>
+template <int KH, int EKS, bool SPLIT, int TPP = 1, class ST, class CR>
 MF_D void start_program(const Net& n, ST& st, CR& carry, uint32_t ring, uint32_t buf_bytes, const Lane& id) {
-  st.start(n.packed + n.res_bytes, (SPLIT ? 2 : 1) * EKS, ring, buf_bytes, id);
+  st.start(n.packed + n.res_bytes, TPP * (SPLIT ? 2 : 1) * EKS, ring, buf_bytes, id);
   carry.load(st.slot_off(0) + id.lane * 16);
 }
 
@@ -670,6 +679,10 @@ MF_D void extra_layer(const Net& net, const u32x4 (&act)[16], const u32x4* ex, c
 // Canonical NeRF (W = 256) on this wave's 32 samples.  xe: bf16 operands of the xyz embedding (4 k-steps).
 // `make_extra(ex)` builds the extra block's operands; it is called right before extra_encoding so that those
 // registers are not held through the trunk.
+#ifndef MF_BF_NERF_TPP0
+#define MF_BF_NERF_TPP0 1            // the fast mode's NeRF layer 0 (eight tiles of 4 groups): tiles per panel (2 and 4 measured 0 %)
+#endif
+constexpr int kNerfTpp0 = MF_BF_NERF_TPP0;
 template <class MakeExtra>
 MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
                     MakeExtra&& make_extra, bool sigma_only, Stream& st,
@@ -681,7 +694,7 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
     for (int i = 0; i < 4; ++i) act[t][i] = 0;
   const int D = net.D;
   NoRayBias norb;
-  trunk<16, kKsNerfXyz, false>(net, D, act, xe, xe, st, carry, id, [&](int l) {
+  trunk<16, kKsNerfXyz, false, false, kNerfTpp0>(net, D, act, xe, xe, st, carry, id, [&](int l) {
     return (sigma_only && l == D - 1) ? follow : next_trunk_bf<16, kKsNerfXyz, false>(net, l + 1);
   }, norb, nullptr, [] {});
   // resident block: [bias_trunk (D+1) 256 | bias_extra 128 | sigma_w 256 | sigma_b 4 | rgb_w 384 | rgb_b 4]
@@ -712,6 +725,11 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
 // Neural motion flow (W = 128) on this wave's 32 samples; xhi/xlo = split operands of the xyz block; `rb` = the per-ray
 // bias (image-index block + layer bias) of layer 0, already in flight, `rbp` = where the later embedded layers' sets are.
 // (RBT = RayBias: register sets fetched from the global table, the per-point query; LdsRayBias: staged in LDS, the render pass)
+#ifndef MF_BF_NOF_PAIR
+#define MF_BF_NOF_PAIR 1             // the fast mode's NoF layers as two-tile panels (A/B: 0)
+#endif
+constexpr bool kNofPair = MF_BF_NOF_PAIR != 0;
+constexpr int kNofTpp = kNofPair ? 2 : 1;
 template <class RBT, class AfterFirst>
 MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&xlo)[kKsNofXyz], const float (&xyz)[3],
                    Stream& st, Carry& carry, const Lane& id, const Next& follow, float (&out)[3], RBT& rb,
@@ -724,8 +742,8 @@ MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&
   const int D = net.D;
   // the head panel (16 groups) follows the last trunk layer contiguously; behind it comes `follow`'s first panel
   const Next hd{16, nullptr, follow.groups, follow.jump};
-  trunk<8, kKsNofXyz, true>(net, D, act, xhi, xlo, st, carry, id,
-                            [&](int l) { return l == D - 1 ? hd : next_trunk_bf<8, kKsNofXyz, true>(net, l + 1); }, rb, rbp, after_first);
+  trunk<8, kKsNofXyz, true, kNofPair>(net, D, act, xhi, xlo, st, carry, id,
+                                      [&](int l) { return l == D - 1 ? hd : next_trunk_bf<8, kKsNofXyz, true, 0, kNofPair>(net, l + 1); }, rb, rbp, after_first);
   // head on the matrix pipe (16 MFMAs instead of 9 x 64 dependent FMAs + 144 LDS reads per lane); T[0..3] come
   // out in half 0's registers 0-3, T[4..7] in half 1's registers 0-3, T[8] in half 0's register 4
   f32x16 acc;

@@ -178,7 +178,9 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
   StreamT<NW> st;
   st.tl.start(p.alphas, id);
   typename std::conditional<X3, CarryX, Carry>::type carry;
-  const Next prog_first = MOCO ? first_of<8, kKsNofXyz, true>(p.bw) : first_of<16, kKsNerfXyz, X3>(p.nerf);
+  constexpr int NP2 = X3 ? 1 : kNofTpp;      // the fast mode's NoF layers stream two tiles per panel,
+  constexpr int NF0 = X3 ? 1 : kNerfTpp0;    // its NeRF layer 0 four
+  const Next prog_first = MOCO ? first_of<8, kKsNofXyz, true, NP2>(p.bw) : first_of<16, kKsNerfXyz, X3, NF0>(p.nerf);
   int seq = 0;                       // NoF evaluations done by this workgroup: evaluation number `seq` reads buffer seq & 1
   if (MOCO) {                        // rows of the first evaluation (first group, tile 0, bw at index i)
     const long long g0 = blockIdx.x;
@@ -187,8 +189,8 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
     tile_rays<TILE>(0, nr0, p.S, f0, n0);
     stage_raybias<NW>(p, g0 * p.G + f0, n0, 0, p.rb_off, id);
   }
-  if (MOCO) start_program<8, kKsNofXyz, true>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);   // (its wait + barrier also publish the resident blocks / tables)
-  else start_program<16, kKsNerfXyz, X3>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
+  if (MOCO) start_program<8, kKsNofXyz, true, NP2>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);   // (its wait + barrier also publish the resident blocks / tables)
+  else start_program<16, kKsNerfXyz, X3, NF0>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
 
   const int S = p.S;
   const bool sigma_only = p.flags & MF_F_SIGMA_ONLY;
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
           if (role == 1 || role == 2) { cur[0] = canon[0]; cur[1] = canon[1]; cur[2] = canon[2]; }
           const bool last = step == nsteps - 1;
           const bool next_fw = (role + 1 == 1 || role + 1 == 2 || role + 1 == 4);
-          const Next follow = last ? first_of<16, kKsNerfXyz, X3>(p.nerf) : first_of<8, kKsNofXyz, true>(next_fw ? p.fw : p.bw);
+          const Next follow = last ? first_of<16, kKsNerfXyz, X3, NF0>(p.nerf) : first_of<8, kKsNofXyz, true, NP2>(next_fw ? p.fw : p.bw);
           u32x4 nhi[kKsNofXyz], nlo[kKsNofXyz];
           float out[3];
           nof_embed(nhi, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
@@ -457,10 +459,11 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void points_kernel
   StreamT<NW> st;
   st.tl.start(nullptr, id);
   typename std::conditional<X3, CarryX, Carry>::type carry;
-  const Next nerf_first = first_of<16, kKsNerfXyz, X3>(p.nerf);
-  const Next prog_first = NOF ? first_of<8, kKsNofXyz, true>(p.bw) : nerf_first;
-  if (NOF) start_program<8, kKsNofXyz, true>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);
-  else start_program<16, kKsNerfXyz, X3>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
+  constexpr int NP2 = X3 ? 1 : kNofTpp, NF0 = X3 ? 1 : kNerfTpp0;
+  const Next nerf_first = first_of<16, kKsNerfXyz, X3, NF0>(p.nerf);
+  const Next prog_first = NOF ? first_of<8, kKsNofXyz, true, NP2>(p.bw) : nerf_first;
+  if (NOF) start_program<8, kKsNofXyz, true, NP2>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);
+  else start_program<16, kKsNerfXyz, X3, NF0>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
   const long long ntiles = (p.B + TILE - 1) / TILE;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
     const long long b = tile * TILE + id.wave * kWaveSamples + id.j;
@@ -592,11 +595,12 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
   if (moco) {
     if (!nof_layout(*a->nof_bw, Lb, prec)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported backward NoF configuration");
     p.bw = net_of(Lb, a->nof_bw_packed, Lb.n_trunk, Lb.n_head);
-    if (Lb.max_groups > max_groups) max_groups = Lb.max_groups;
+    const int nof_pair = (!x3 && bf::kNofPair) ? 2 : 1;        // fast mode: two NoF tiles per panel
+    if (nof_pair * Lb.max_groups > max_groups) max_groups = nof_pair * Lb.max_groups;
     if (chains) {
       if (!nof_layout(*a->nof_fw, Lf, prec)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported forward NoF configuration");
       p.fw = net_of(Lf, a->nof_fw_packed, Lf.n_trunk, Lf.n_head);
-      if (Lf.max_groups > max_groups) max_groups = Lf.max_groups;
+      if (nof_pair * Lf.max_groups > max_groups) max_groups = nof_pair * Lf.max_groups;
     }
     p.pow2 |= (emb_table(a->nof_emb_xyz, p.emb_par[2]) ? 4 : 0) | (emb_table(a->nof_emb_ind, p.emb_par[3]) ? 8 : 0);
     // the per-ray bias table (image-index block of the NoFs' embedded-input layers), one small launch in front
@@ -713,7 +717,8 @@ int points_sigma_bf16(int prec, const mf_nerf_desc* nerf, const void* nerf_packe
   if (nof) {
     if (!nof_layout(*nof, Lb, prec)) return fail(MF_E_UNSUPPORTED, "mf_points_sigma: unsupported NoF configuration");
     p.bw = net_of(Lb, nof_packed, Lb.n_trunk, Lb.n_head);
-    if (Lb.max_groups > max_groups) max_groups = Lb.max_groups;
+    const int nof_pair = (!x3 && bf::kNofPair) ? 2 : 1;
+    if (nof_pair * Lb.max_groups > max_groups) max_groups = nof_pair * Lb.max_groups;
     p.pow2 |= (emb_table(*nof_emb_xyz, p.emb_par[2]) ? 4 : 0) | (emb_table(*nof_emb_ind, p.emb_par[3]) ? 8 : 0);
     // per-point (ind given) or single (ind_scalar) bias of the NoF's embedded-input layers, see nof_raybias_kernel
     const int64_t need = points_workspace_bytes_bf16(nof, ind != nullptr, B);
