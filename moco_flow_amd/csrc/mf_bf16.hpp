@@ -21,6 +21,10 @@
 // C2 shape the split bought 0.1 dB (61.15 vs 61.00 dB against the fp32 oracle -- the rounding of the 63 O(1) inputs is
 // one more layer's worth of activation rounding) for 10 % more matrix instructions, and the pass is throttled by its own activity
 // (DESIGN.md).  Accumulation, biases, the sigma / rgb / NoF heads and the composite stay fp32.
+// The second half of the file is MF_PREC_BF16X3: the same tile loop with EVERY operand of both networks as such a split
+// (three products per k-step, heads on the fp32 accumulators) -- fp32-class results at three bf16 matrix instructions per
+// product -- in kernels of 4 waves, one per SIMD with the whole register file (StreamT<4>, layer_x, nerf_eval_x3, nof_eval_x3);
+// csrc/mf_backward_bf16.hip runs the backward's input-gradient chain on it.
 #pragma once
 #include <type_traits>
 #include "mf_nets.hpp"
