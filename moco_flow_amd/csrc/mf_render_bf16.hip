@@ -532,6 +532,14 @@ static bool emb_table(const mf_embedding& e, float* dst) {      // returns: freq
 }
 
 // combination c of a ray-bias table: network (packed buffer + layout) and the index column it reads
+// largest panel of a NoF in groups: its trunk tiles stream `tpp` per panel (fast mode: two), its head is one panel
+static int nof_panel_groups(const NetLayout& L, int tpp) {
+  int g = head_groups(L);
+  for (int l = 0; l < L.n_trunk; ++l)
+    if (tpp * trunk_groups(L, l) > g) g = tpp * trunk_groups(L, l);
+  return g;
+}
+
 static void raybias_combo(RayBiasParams& r, int c, const void* packed, const NetLayout& L, int col) {
   const char* base = static_cast<const char*>(packed);
   r.bias[c] = reinterpret_cast<const float*>(base) + L.off_bias_trunk;
@@ -596,11 +604,11 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
     if (!nof_layout(*a->nof_bw, Lb, prec)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported backward NoF configuration");
     p.bw = net_of(Lb, a->nof_bw_packed, Lb.n_trunk, Lb.n_head);
     const int nof_pair = (!x3 && bf::kNofPair) ? 2 : 1;        // fast mode: two NoF tiles per panel
-    if (nof_pair * Lb.max_groups > max_groups) max_groups = nof_pair * Lb.max_groups;
+    if (bf::nof_panel_groups(Lb, nof_pair) > max_groups) max_groups = bf::nof_panel_groups(Lb, nof_pair);
     if (chains) {
       if (!nof_layout(*a->nof_fw, Lf, prec)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported forward NoF configuration");
       p.fw = net_of(Lf, a->nof_fw_packed, Lf.n_trunk, Lf.n_head);
-      if (nof_pair * Lf.max_groups > max_groups) max_groups = nof_pair * Lf.max_groups;
+      if (bf::nof_panel_groups(Lf, nof_pair) > max_groups) max_groups = bf::nof_panel_groups(Lf, nof_pair);
     }
     p.pow2 |= (emb_table(a->nof_emb_xyz, p.emb_par[2]) ? 4 : 0) | (emb_table(a->nof_emb_ind, p.emb_par[3]) ? 8 : 0);
     // the per-ray bias table (image-index block of the NoFs' embedded-input layers), one small launch in front
@@ -718,7 +726,7 @@ int points_sigma_bf16(int prec, const mf_nerf_desc* nerf, const void* nerf_packe
     if (!nof_layout(*nof, Lb, prec)) return fail(MF_E_UNSUPPORTED, "mf_points_sigma: unsupported NoF configuration");
     p.bw = net_of(Lb, nof_packed, Lb.n_trunk, Lb.n_head);
     const int nof_pair = (!x3 && bf::kNofPair) ? 2 : 1;
-    if (nof_pair * Lb.max_groups > max_groups) max_groups = nof_pair * Lb.max_groups;
+    if (nof_panel_groups(Lb, nof_pair) > max_groups) max_groups = nof_panel_groups(Lb, nof_pair);
     p.pow2 |= (emb_table(*nof_emb_xyz, p.emb_par[2]) ? 4 : 0) | (emb_table(*nof_emb_ind, p.emb_par[3]) ? 8 : 0);
     // per-point (ind given) or single (ind_scalar) bias of the NoF's embedded-input layers, see nof_raybias_kernel
     const int64_t need = points_workspace_bytes_bf16(nof, ind != nullptr, B);
