@@ -293,6 +293,77 @@ def train_leg(M, torch, models, rays, bg, gt, kw, cfg, steps=10):
     return out
 
 
+def train_shape_legs(M, synth, torch, dev, steps=6):
+    """The reference's two training-step shapes (reported beside the forward metric), forward +
+    backward through the drop-in exactly as the unchanged trainer calls it, median of `steps` individually timed steps:
+      stage1: init_nerf.yaml -- N_rand 5120 rays x (128 coarse + 256 fine) samples, NeRF(dir / 27) x 2, MSE loss
+              (trainer_nerf.py:149-169);
+      joint:  c2f.yaml -- 1024 rays x (128 + 256), NeRF(ind / 5) x 2 behind the backward NoF, local + global consensus
+              chains, perturb = 1, MSE + consensus means (trainer_moco_flow.py:200-216, 317-328)."""
+    from moco_flow_amd import autograd as A, rendering
+
+    def load(m, sd):
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        return m.to(dev)
+
+    def med(f):
+        f()
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(steps):
+            t0 = time.perf_counter()
+            f()
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        return float(sorted(ts)[len(ts) // 2])
+
+    crit = M.get_loss(dict(type="MSE"))
+    out = {"dx_precision": A.DX_PRECISION, "wgrad_precision": A.WGRAD_PRECISION, "train_forward_precision": rendering.TRAIN_FORWARD_PRECISION,
+           "what": "render_rays + loss + backward (every parameter gradient), median ms per step; synthetic rays, dense random weights"}
+    # stage 1
+    N = 5120
+    nerfs = [load(M.NeRF(8, 256, 63, [4], "dir", 27), synth.nerf_state(0, regime="dense", tag=t)) for t in ("coarse", "fine")]
+    embs = [M.Embedding(3, 10), None, M.Embedding(3, 4)]
+    r, b = synth.rays(0, N)
+    rays, bg = torch.from_numpy(r).to(dev), torch.from_numpy(b).to(dev)
+    gt = torch.rand(N, 3, device=dev)
+    kw = dict(N_samples=128, N_importance=128, noise_std=0, perturb=0)
+
+    def stage1():
+        for m in nerfs:
+            m.zero_grad(set_to_none=True)
+        crit(M.render_rays(rays, bg, embs, nerfs, **kw), gt).backward()
+
+    out["stage1"] = {"ms_per_step": med(stage1), "rays": N, "samples_per_ray": 384}
+    del nerfs, rays, bg, gt
+    torch.cuda.empty_cache()
+    # joint MoCo stage
+    N = 1024
+    nerfs = [load(M.NeRF(8, 256, 63, [4], "ind", 5), synth.nerf_state(0, extra_feat_type="ind", extra_feat_dim=5, regime="dense", tag=t))
+             for t in ("coarse", "fine")]
+    nofs = [load(M.NoF(4, 128, 33, [2], "ind", 33, True), synth.nof_state(0, use_quat=True, tag=t, head_scale=0.25)) for t in ("bw", "fw")]
+    embs = [M.Embedding(3, 10), M.Embedding(1, 2), None]
+    r, b = synth.rays(0, N, chained=True)
+    rays, bg = torch.from_numpy(r).to(dev), torch.from_numpy(b).to(dev)
+    gt = torch.rand(N, 3, device=dev)
+    kw = dict(nof_embeddings=[M.Embedding(3, 5), M.Embedding(1, 16)], nof_models=nofs, chain_local=True, chain_global=True,
+              N_samples=128, N_importance=128, noise_std=0, perturb=1.0)
+
+    def joint():
+        for m in nerfs + nofs:
+            m.zero_grad(set_to_none=True)
+        res = M.render_rays(rays, bg, embs, nerfs, **kw)
+        loss = crit(res, gt)
+        for k in ("nof_local_disp_coarse", "nof_global_disp_coarse", "nof_local_disp_fine", "nof_global_disp_fine"):
+            loss = loss + 0.1 * res[k].mean()
+        loss.backward()
+
+    out["joint"] = {"ms_per_step": med(joint), "rays": N, "samples_per_ray": 384}
+    del nerfs, nofs, rays, bg, gt
+    torch.cuda.empty_cache()
+    return out
+
+
 def kernel_probe(M, rendering, torch, cfg, models, rays, bg, kw, iters=20):
     """Average duration of the DOMINANT kernel launch alone (mf_render_pass of the largest pass: the fine pass when
     there is one), HIP events on the launch stream around the C-ABI call itself -- no resample, no compaction, no
@@ -461,6 +532,8 @@ def run_config(name, a, ctx, steps, warmup, main):
                                     "vectors (no compaction, no host sync; INTEGRATION.md)"}
     if main and rank == 0 and world == 1 and not a.no_train_leg and cfg["precision"] == "f32":
         res["fwd_bwd"] = train_leg(M, torch, models, rays, bg, gt, kw, cfg)
+        if not a.no_extra_legs:
+            res["train_steps"] = train_shape_legs(M, synth, torch, rays.device)
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         if main:
             base, ref = cpu_baseline(cfg, models["states"], rays_np[:n], bg_np[:n])
@@ -556,7 +629,7 @@ def worker(a):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic",
         "config": res["config"], "roofline": res["roofline"],
     }
-    for k in ("fwd_bwd", "cpu_baseline", "c1_cpu", "error_vs_cpu", "speedup_vs_cpu", "loss_path"):
+    for k in ("fwd_bwd", "train_steps", "cpu_baseline", "c1_cpu", "error_vs_cpu", "speedup_vs_cpu", "loss_path"):
         if k in res:
             line[k] = res[k]
     if not a.no_extra_legs and a.config == "C2":
