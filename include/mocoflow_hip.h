@@ -35,8 +35,9 @@ extern "C" {
  * 12: MF_PREC_BF16 NoF takes its image-index block as a per-ray fp32 bias: mf_render_args.workspace(+_bytes),
  *     mf_render_workspace_bytes, mf_render_prepare, mf_loss_partials_backward, perturb arguments of mf_z_vals, mf_points_sigma_workspace_bytes, workspace arguments of mf_points_sigma_p
  * 13: MF_PREC_BF16X3 is the full three-product mode (own packed layout); mf_weight_grads_p, mf_weight_grads_scratch_bytes_p,
- *     mf_nerf_backward3 (+ mf_nerf_bwd3_packed_bytes, mf_nerf_pack_bwd3), MF_PREC_BF16X3 in mf_points_sigma_p and with the NeRF dump */
-#define MF_ABI_VERSION 13
+ *     mf_nerf_backward3 (+ mf_nerf_bwd3_packed_bytes, mf_nerf_pack_bwd3), MF_PREC_BF16X3 in mf_points_sigma_p and with the NeRF dump
+ * 14: mf_embedding_forward_rows */
+#define MF_ABI_VERSION 14
 
 enum {
   MF_OK = 0,
@@ -131,6 +132,13 @@ int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* packed, voi
 
 /* Embedding.forward, models/embedding.py:30-47:  x (B, in_channels) -> out (B, C*(2F+1)). */
 int32_t mf_embedding_forward(const mf_embedding* e, const float* x, int64_t B, float* out, void* stream);
+/* The same for B OUTPUT rows of `out_stride` >= C*(2F+1) floats (the columns past the embedding are written 0;
+ * out_stride <= 0: the embedding's width), output row b embedding input row b / repeat (x has ceil(B / repeat)
+ * rows): the embedded inputs as the weight-gradient launches read them (64 / 32-column operands of mf_weight_grads;
+ * the per-ray `ind` / `dir` embedding of rendering.py:133-146 repeated for the ray's samples) in ONE launch
+ * instead of embedding + repeat_interleave + zero pad. */
+int32_t mf_embedding_forward_rows(const mf_embedding* e, const float* x, int64_t B, int32_t repeat, float* out,
+                                  int64_t out_stride, void* stream);
 
 /* NeRF.forward, models/nerf.py:61-102: inputs (B, in_channels_xyz [+ extra_feat_dim]) row
  * stride `in_stride` floats -> out (B,4) = [rgb, sigma], or (B,1) sigma when sigma_only. */

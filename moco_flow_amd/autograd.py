@@ -237,15 +237,15 @@ def _nof_param_grads(m, gpre, acts, emb80, req, slot_order=False):
     for prefix, blocks, bias_from in sinks:
         if req[prefix + ".weight"]:
             parts = [res[j][0][:, cs] for j, cs in blocks]
-            grads[prefix + ".weight"] = parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, 1)
+            grads[prefix + ".weight"] = parts[0] if len(parts) == 1 else torch.cat(parts, 1)
         if req[prefix + ".bias"]:
-            grads[prefix + ".bias"] = res[bias_from][1].clone()
+            grads[prefix + ".bias"] = res[bias_from][1]
     if head_job is not None:
         nh = m.nof_encoding_final.weight.shape[0]
         if req["nof_encoding_final.weight"]:
-            grads["nof_encoding_final.weight"] = res[head_job][0][:nh].contiguous()
+            grads["nof_encoding_final.weight"] = res[head_job][0][:nh]
         if req["nof_encoding_final.bias"]:
-            grads["nof_encoding_final.bias"] = res[head_job][1][:nh].clone()
+            grads["nof_encoding_final.bias"] = res[head_job][1][:nh]
     return grads
 
 
@@ -409,7 +409,8 @@ class NofPointsDumped(torch.autograd.Function):
         ctx.m, ctx.ex, ctx.stride = m, nof_embs[0].descriptor(), acts.shape[1]
         ctx.sink, ctx.sink_plane = sink, sink_plane
         ctx.save_for_backward(pts.detach().contiguous().float(), acts, emb)
-        return out.clone()
+        ctx.set_materialize_grads(False)
+        return out.detach()                                   # the dump's own plane (nobody writes it after the pass)
 
     @staticmethod
     def backward(ctx, g_out):
@@ -419,6 +420,8 @@ class NofPointsDumped(torch.autograd.Function):
         names = [n for n, _ in m.named_parameters()]
         req = {n: p.requires_grad for n, p in m.named_parameters()}
         need_pts = ctx.needs_input_grad[7]
+        if g_out is None:
+            return (None,) * (8 + len(names))
         with torch.no_grad():
             desc, buf = m.packed_bwd()
             g_out = g_out.contiguous().float()
@@ -517,7 +520,7 @@ def nerf_fused_grads(m, g_out, acts, rgbsig, emb, extra, want_emb, sigma_path_on
         if extra is not None:
             ext32 = F.pad(extra, (0, 32 - extra.shape[1])) if extra.shape[1] < 32 else extra
             jobs.append((g_e2, ext32, 128, 32, False))
-            blocks.append((len(jobs) - 1, slice(0, W // 2), slice(0, extra.shape[1])))
+            blocks.append((len(jobs) - 1, slice(0, W // 2), slice(0, min(extra.shape[1], m.extra_feat_dim))))
         put("extra_encoding.0", blocks, blocks[0][0])
     head_job = None
     if wants("sigma") or wants("rgb.0"):
@@ -527,19 +530,19 @@ def nerf_fused_grads(m, g_out, acts, rgbsig, emb, extra, want_emb, sigma_path_on
     for prefix, blocks, bias_from in sinks:
         if req[prefix + ".weight"]:
             parts = [res[j][0][rs, cs] for j, rs, cs in blocks]
-            grads[prefix + ".weight"] = parts[0].contiguous() if len(parts) == 1 else torch.cat(parts, 1)
+            grads[prefix + ".weight"] = parts[0] if len(parts) == 1 else torch.cat(parts, 1)
         if req[prefix + ".bias"]:
-            grads[prefix + ".bias"] = res[bias_from][1][blocks[0][1]].clone()
+            grads[prefix + ".bias"] = res[bias_from][1][blocks[0][1]]
     if head_job is not None:
         hW, hb = res[head_job]
         if req["sigma.weight"]:
-            grads["sigma.weight"] = hW[3:4, 0:W].contiguous()
+            grads["sigma.weight"] = hW[3:4, 0:W]
         if req["sigma.bias"]:
-            grads["sigma.bias"] = hb[3:4].clone()
+            grads["sigma.bias"] = hb[3:4]
         if req["rgb.0.weight"]:
-            grads["rgb.0.weight"] = hW[0:3, 2 * W:2 * W + W // 2].contiguous()
+            grads["rgb.0.weight"] = hW[0:3, 2 * W:2 * W + W // 2]
         if req["rgb.0.bias"]:
-            grads["rgb.0.bias"] = hb[0:3].clone()
+            grads["rgb.0.bias"] = hb[0:3]
     return grads, gpre, g_emb_hip, emb64
 
 
@@ -610,7 +613,7 @@ class NerfSamples(torch.autograd.Function):
         ctx.save_for_backward(rgbsig, xin)
         ctx.xin_grad = xin.requires_grad
         ctx.n_params = len(params)
-        return rgbsig.detach().clone()
+        return rgbsig.detach()
 
     @staticmethod
     def backward(ctx, g_out):
@@ -700,7 +703,8 @@ class CompositeSamples(torch.autograd.Function):
         ctx.save_for_backward(rgbsig, rays, z_vals, noise if noise is not None else rgbsig.new_empty(0),
                               background if background is not None else rgbsig.new_empty(0))
         ctx.has_noise, ctx.has_bg, ctx.activation = noise is not None, background is not None, activation
-        return rgb_val.detach().clone(), depth_val.detach().clone(), opacity_val.detach().clone()
+        ctx.set_materialize_grads(False)                      # an output the loss does not use: a null seed, not zeros
+        return rgb_val.detach(), depth_val.detach(), opacity_val.detach()
 
     @staticmethod
     def backward(ctx, g_rgb, g_depth, g_opacity):

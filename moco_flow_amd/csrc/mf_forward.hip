@@ -18,23 +18,26 @@ struct EmbFwdParams {
   const float* x;
   float* out;
   long long B;
+  long long out_stride;   // floats per output row (>= the embedding's width; the columns past it are written 0)
+  int repeat;             // output row b embeds input row b / repeat
 };
 
 __global__ void embedding_forward_kernel(EmbFwdParams p) {
   const int C = p.e.in_channels, F = p.e.n_freqs;
   const int OC = C * (2 * F + 1);
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= p.B * OC) return;
-  const long long b = idx / OC;
-  const int col = (int)(idx - b * OC);
-  float v;
+  if (idx >= p.B * p.out_stride) return;
+  const long long b = idx / p.out_stride;
+  const int col = (int)(idx - b * p.out_stride);
+  const float* x = p.x + (b / p.repeat) * C;
+  float v = 0.f;
   if (col < C) {
-    v = p.x[b * C + col];
-  } else {
+    v = x[col];
+  } else if (col < OC) {
     const int k = (col - C) / C;          // 0 .. 2F-1 : (freq, sin|cos)
     const int c = (col - C) % C;
     const int f = k >> 1;
-    const float arg = p.e.freq[f] * p.x[b * C + c];
+    const float arg = p.e.freq[f] * x[c];
     v = p.e.weight[f] * ((k & 1) ? cosf(arg) : sinf(arg));
   }
   p.out[idx] = v;
@@ -226,16 +229,31 @@ int device_cus() {
 
 using namespace mf;
 
-extern "C" int32_t mf_embedding_forward(const mf_embedding* e, const float* x, int64_t B, float* out, void* stream) {
-  if (!e || (B > 0 && (!x || !out))) return fail(MF_E_INVALID, "mf_embedding_forward: null argument");
+static int32_t embedding_forward(const char* who, const mf_embedding* e, const float* x, int64_t B, int32_t repeat,
+                                 float* out, int64_t out_stride, void* stream) {
+  if (!e || (B > 0 && (!x || !out))) return fail(MF_E_INVALID, "%s: null argument", who);
   if (e->in_channels < 1 || e->n_freqs < 0 || e->n_freqs > MF_MAX_FREQS)
-    return fail(MF_E_INVALID, "mf_embedding_forward: in_channels=%d n_freqs=%d out of range", e->in_channels, e->n_freqs);
+    return fail(MF_E_INVALID, "%s: in_channels=%d n_freqs=%d out of range", who, e->in_channels, e->n_freqs);
+  const long long width = (long long)e->in_channels * (2 * e->n_freqs + 1);
+  if (out_stride <= 0) out_stride = width;
+  if (B < 0 || repeat < 1 || out_stride < width)
+    return fail(MF_E_INVALID, "%s: B=%lld repeat=%d out_stride=%lld (embedding width %lld)", who, (long long)B, repeat,
+                (long long)out_stride, width);
   if (B == 0) return MF_OK;
-  EmbFwdParams p{*e, x, out, B};
-  const long long total = B * e->in_channels * (2 * e->n_freqs + 1);
+  EmbFwdParams p{*e, x, out, B, out_stride, repeat};
+  const long long total = B * out_stride;
   hipLaunchKernelGGL(embedding_forward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p);
-  return check_launch("mf_embedding_forward");
+  return check_launch(who);
+}
+
+extern "C" int32_t mf_embedding_forward(const mf_embedding* e, const float* x, int64_t B, float* out, void* stream) {
+  return embedding_forward("mf_embedding_forward", e, x, B, 1, out, 0, stream);
+}
+
+extern "C" int32_t mf_embedding_forward_rows(const mf_embedding* e, const float* x, int64_t B, int32_t repeat, float* out,
+                                             int64_t out_stride, void* stream) {
+  return embedding_forward("mf_embedding_forward_rows", e, x, B, repeat, out, out_stride, stream);
 }
 
 static int32_t nerf_forward_launch(const char* who, const mf_nerf_desc* d, const void* packed, const float* inputs, int64_t in_stride,

@@ -50,6 +50,22 @@ class Embedding(nn.Module):
         self.__dict__["_desc_cache"] = (key, d, fb)
         return d
 
+    def rows(self, x, repeat=1, width=None):
+        """mf_embedding_forward_rows (no gradients): (B * repeat, width) -- the embedding of every row of x for
+        ``repeat`` consecutive output rows, zero-padded to ``width`` columns; the X operands of the first-layer weight
+        gradients (autograd.nerf_fused_grads) in one launch."""
+        L.require_gpu(x, "Embedding.rows")
+        if x.dim() != 2 or x.shape[1] != self.in_channels:
+            raise RuntimeError(f"Embedding expects (B, {self.in_channels}), got {tuple(x.shape)}")
+        width = self.out_channels if width is None else max(int(width), self.out_channels)
+        xc = x.detach().contiguous().float()
+        B = x.shape[0] * repeat
+        out = torch.empty((B, width), device=x.device, dtype=torch.float32)
+        with torch.cuda.device(x.device):
+            L.check(L.lib().mf_embedding_forward_rows(self.descriptor(), L.ptr(xc), B, repeat, L.ptr(out), width,
+                                                      L.current_stream(x.device)), "mf_embedding_forward_rows")
+        return out
+
     def forward(self, x):
         L.require_gpu(x, "Embedding.forward")
         if x.dim() != 2 or x.shape[1] != self.in_channels:

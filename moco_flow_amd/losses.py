@@ -35,10 +35,24 @@ def from_partials(partials: torch.Tensor):
     (mf_loss_partials; layout of dist.loss_partials), as differentiable device scalars with no host sync:
     ``img_loss`` = MSE coarse + fine (models/losses.py:4-14), ``nof_local`` / ``nof_global`` = mean over the
     masked points, coarse + fine (trainer_moco_flow.py:317-328).  A term whose count is 0 (pass / chain absent) is 0."""
-    p = partials
-    one = torch.ones((), dtype=p.dtype, device=p.device)
+    img, local, glob = _PartialMeans.apply(partials).unbind(0)
+    return {"img_loss": img, "nof_local": local, "nof_global": glob}
 
-    def mean(i):
-        return p[i] / torch.where(p[i + 1] > 0, p[i + 1], one)
 
-    return {"img_loss": mean(0) + mean(2), "nof_local": mean(4) + mean(6), "nof_global": mean(8) + mean(10)}
+class _PartialMeans(torch.autograd.Function):
+    """(12,) partials [sum, count] x 6 -> (3,) [img, local, global], each the coarse + fine mean (0 where the count is 0):
+    a handful of vectorised device ops forward and backward (d term / d sum = 1 / count; the counts carry no gradient)
+    instead of ~100 scalar ones through autograd."""
+
+    @staticmethod
+    def forward(ctx, partials):
+        p = partials.detach().view(6, 2)
+        den = torch.where(p[:, 1] > 0, p[:, 1], torch.ones_like(p[:, 1]))
+        ctx.save_for_backward(den)
+        return (p[:, 0] / den).view(3, 2).sum(1)
+
+    @staticmethod
+    def backward(ctx, g):
+        den, = ctx.saved_tensors
+        g6 = g.to(den.dtype).repeat_interleave(2) / den
+        return torch.stack((g6, torch.zeros_like(g6)), 1).view(12)

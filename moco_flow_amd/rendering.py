@@ -537,13 +537,14 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
                     recons[f"global_{tag}"] = chained
             xin = canon.reshape(-1, 3)
         with torch.no_grad():
-            # (mf_embedding_forward: one launch each instead of ~60 elementwise ones)
-            emb_in = A._pad_to(nerf_embs[0](p["xyz_in"]), nerf.in_channels_xyz)
+            # (mf_embedding_forward_rows: the 64- / 32-column operands of the first-layer weight gradients, the per-ray
+            #  block repeated for the ray's samples, zero padded -- no repeat_interleave / pad copies)
+            emb_in = nerf_embs[0].rows(p["xyz_in"], 1, max(64, nerf.in_channels_xyz))
             extra_in = None
             if nerf.extra_feat_type == "ind":
-                extra_in = A._pad_to(torch.repeat_interleave(nerf_embs[1](ind.contiguous()), S, dim=0), nerf.extra_feat_dim)
+                extra_in = nerf_embs[1].rows(ind, S, max(32, nerf.extra_feat_dim))
             elif nerf.extra_feat_type == "dir":
-                extra_in = A._pad_to(torch.repeat_interleave(nerf_embs[2](rays_d.contiguous()), S, dim=0), nerf.extra_feat_dim)
+                extra_in = nerf_embs[2].rows(rays_d, S, max(32, nerf.extra_feat_dim))
         rgbsig = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, nerf_embs[0], xin,
                                      *nerf.parameters())
         if S > 2048:

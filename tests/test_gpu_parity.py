@@ -1211,6 +1211,21 @@ def test_embedding_module_backward_vs_oracle(M, R):
     assert x.grad.shape == (0, 3)
 
 
+def test_embedding_rows_is_embed_repeat_pad(M):
+    """Embedding.rows (mf_embedding_forward_rows): every input row embedded for `repeat` output rows at a wider, zero-padded
+    row stride == Embedding.forward + repeat_interleave + pad, bit for bit (the operands the weight-gradient launches read)."""
+    torch.manual_seed(3)
+    for cin, nf, rep, width in ((3, 10, 1, 64), (1, 16, 7, 40), (3, 4, 5, 32), (3, 10, 3, None)):
+        e = M.Embedding(cin, nf)
+        x = torch.randn(131, cin + 2, device="cuda")[:, 1:1 + cin]          # a strided view, like rays[:, 8:9]
+        got = e.rows(x, rep, width)
+        want = torch.repeat_interleave(e(x.contiguous()), rep, dim=0)
+        w = want.shape[1] if width is None else width
+        assert got.shape == (131 * rep, w)
+        assert torch.equal(got[:, :want.shape[1]], want) and not got[:, want.shape[1]:].any()
+    assert M.Embedding(3, 4).rows(torch.zeros(0, 3, device="cuda"), 4, 32).shape == (0, 32)
+
+
 @pytest.mark.parametrize("quat", [True, False])
 def test_nof_backward_vs_oracle(M, R, quat):
     """One NoF evaluation on points (rendering.py:49-83 + nof.py:69-82): HIP forward-with-dump / backward node

@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
         assert n in L.SYMBOLS, f"{n} has no ctypes prototype"
-    assert lib.mf_version() == L.MF_ABI_VERSION == 13
+    assert lib.mf_version() == L.MF_ABI_VERSION == 14
     # argument validation is host-side and must not need a GPU
     d = L.mf_nerf_desc()
     d.D, d.W, d.in_channels_xyz, d.skip_mask = 8, 256, 63, 1 << 4
@@ -119,6 +119,22 @@ def test_three_product_entry_points_validate_on_the_host():
     assert lib.mf_points_sigma_workspace_bytes(L.MF_PREC_BF16, ctypes.byref(n), 0, 1000) == 2 * 128 * 4
     assert lib.mf_points_sigma_workspace_bytes(L.MF_PREC_BF16X3, ctypes.byref(n), 0, 1000) == 2 * 128 * 4
     assert lib.mf_points_sigma_workspace_bytes(L.MF_PREC_BF16, ctypes.byref(n), 1, 1000) == 1000 * 2 * 128 * 4
+
+
+def test_embedding_rows_validates_on_the_host():
+    """ABI v14 mf_embedding_forward_rows: row stride below the embedding's width, repeat < 1 and null buffers are refused
+    before any launch; zero rows is a no-op."""
+    import moco_flow_amd._lib as L
+    lib = L.lib()
+    e = L.mf_embedding()
+    e.in_channels, e.n_freqs = 3, 10                       # width 63
+    buf = (ctypes.c_float * 64)()
+    ptr = ctypes.addressof(buf)
+    assert lib.mf_embedding_forward_rows(ctypes.byref(e), None, 0, 1, None, 64, None) == 0
+    assert lib.mf_embedding_forward_rows(ctypes.byref(e), ptr, 1, 1, ptr, 62, None) == -1 and b"out_stride" in lib.mf_last_error()
+    assert lib.mf_embedding_forward_rows(ctypes.byref(e), ptr, 1, 0, ptr, 64, None) == -1
+    assert lib.mf_embedding_forward_rows(ctypes.byref(e), None, 1, 1, ptr, 64, None) == -1
+    assert lib.mf_embedding_forward_rows(None, ptr, 1, 1, ptr, 64, None) == -1
 
 
 def test_packed_layout_sizes():
