@@ -335,6 +335,16 @@ def train_shape_legs(M, synth, torch, dev, steps=6):
         crit(M.render_rays(rays, bg, embs, nerfs, **kw), gt).backward()
 
     out["stage1"] = {"ms_per_step": med(stage1), "rays": N, "samples_per_ray": 384}
+    # the same step with the opt-in three-product training forward (set_train_forward_precision("bf16x3"): forward values to
+    # 5e-6 max-rel, but gradients then differ from the fp32 oracle's by ~3e-3 max-rel through ReLU units that change side
+    # -- outside the 1e-4 bars the default is held to; reported for information)
+    prev = rendering.TRAIN_FORWARD_PRECISION
+    rendering.set_train_forward_precision("bf16x3")
+    try:
+        out["stage1_optin_bf16x3_forward"] = {"ms_per_step": med(stage1), "rays": N, "samples_per_ray": 384,
+                                             "note": "not the default: gradient parity 3e-3 instead of 1e-4 (ReLU mask flips)"}
+    finally:
+        rendering.set_train_forward_precision(prev)
     del nerfs, rays, bg, gt
     torch.cuda.empty_cache()
     # joint MoCo stage
