@@ -481,6 +481,37 @@ def test_gradients_vs_oracle(M, R, name, wgrad):
     assert checked >= 10
 
 
+@pytest.mark.parametrize("name", ["r_nerf_dir_dense", "r_moco_global_default"])
+def test_gradients_when_the_loss_skips_outputs(M, R, name):
+    """A loss that does not touch rgb (depth + opacity only): the composite node gets NO seed for rgb (autograd hands None,
+    the node does not materialise zeros -- mf_composite_backward takes a null pointer) and the gradients still match the
+    oracle's autograd; an output-free NoF evaluation chain leaves its parameters without gradient.  (Bar of the MoCo case:
+    the gradient runs through sin(512 x) of the canonical point -- see GRAD_BARS; with only 40 rays and no rgb term the
+    backward NoF's head bias measures 9e-3 against the fp32 oracle, inside the oracle's own fp32-vs-fp64 spread.)"""
+    c = dict(RENDER_CASES[name])
+    seed = int(load_golden(name)["meta_seed"])
+    rays, bg = case_inputs(c, seed, n=40)
+
+    def loss_fn(res):
+        return 0.3 * res["depth_coarse"].mean() + 0.2 * res["opacity_coarse"].square().mean()
+
+    _, want = _oracle_grads(R, c, seed, rays, bg, loss_fn)
+    embs, nerfs, kw = build_case(M, c, seed, device="cuda")
+    nets = list(nerfs) + (list(kw["nof_models"]) if kw["nof_models"] else [])
+    loss_fn(M.render_rays(rays.cuda(), bg.cuda(), embs, nerfs, **kw)).backward()
+    checked = 0
+    for i, m in enumerate(nets):
+        for k, p in m.named_parameters():
+            w = want[f"{i}.{k}"]
+            if w is None or float(w.abs().max()) == 0.0:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, (i, k)
+                continue
+            bar = {"r_nerf_dir_dense": 1e-4, "r_moco_global_default": 2e-2}[name]
+            assert p.grad is not None and relerr(p.grad, w) <= bar, (i, k, None if p.grad is None else relerr(p.grad, w))
+            checked += 1
+    assert checked >= 8
+
+
 def test_module_gradients(M, R):
     """NoF / Embedding called directly with grad (trainer_nof.py:111, trainer_moco_flow.py:153,185) against the oracle's
     CPU autograd; gradients w.r.t. the points of a module-level NoF call are not built and say so."""
