@@ -1,5 +1,5 @@
 """Consistency sweep over ragged launch shapes: N in {1 .. 5000} x S in {40, 64, 128, 192}, fp32 NeRF / fp32 MoCo chain /
-bf16 MoCo global chain -- one launch must equal the concatenation of two launches over a split of the rays BIT FOR BIT (ray
+bf16 MoCo global chain / bf16x3 NeRF, local and global chains -- one launch must equal the concatenation of two launches over a split of the rays BIT FOR BIT (ray
 groups, tiles per group and the composite phase are launch-shape dependent; per-ray results must not be)."""
 import sys, os, itertools
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
@@ -10,7 +10,7 @@ from moco_flow_amd import rendering, synth
 rendering.STRICT_RNG = False
 dev = torch.device("cuda:0")
 bad = 0
-for prec, cfgname in (("f32", "C2"), ("f32", "C3f"), ("bf16", "C3g")):
+for prec, cfgname in (("f32", "C2"), ("f32", "C3f"), ("bf16", "C3g"), ("bf16x3", "C2x"), ("bf16x3", "C3x"), ("bf16x3", "C5x")):
     cfg = dict(bench.CONFIGS[cfgname]); cfg["precision"] = prec
     rendering.set_precision(prec)
     models = bench.build_models(M, synth, dev, cfg)
