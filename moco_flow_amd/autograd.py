@@ -31,14 +31,6 @@ import torch.nn.functional as F
 from . import _lib as L
 
 
-def _pad_to(t, width):
-    if t.shape[1] == width:
-        return t
-    out = t.new_zeros((t.shape[0], width))
-    out[:, :t.shape[1]] = t
-    return out
-
-
 # ------------------------------------------------------------------ autograd glue
 def needs_grad(modules) -> bool:
     return torch.is_grad_enabled() and any(p.requires_grad for m in modules if m is not None for p in m.parameters())

@@ -136,3 +136,12 @@ class OracleOps:
         rgb, depth, weights, alphas = self.R.composite(rs[..., 3], rs[..., :3], self._c(z_vals), self._c(rays_d), nz, activation,
                                                        self._c(background))
         return dict(rgb=rgb, depth=depth, opacity=weights.sum(1), weights=weights, alphas=alphas)
+
+
+def pad_to(t, width):
+    """(P, w) -> (P, width) zero padded on the right (the narrow operands the backward nodes also accept)."""
+    if t.shape[1] == width:
+        return t
+    out = t.new_zeros((t.shape[0], width))
+    out[:, :t.shape[1]] = t
+    return out

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from cases import RENDER_CASES
-from helpers import OracleOps, build_case, case_inputs, load_golden, relerr
+from helpers import OracleOps, build_case, case_inputs, load_golden, pad_to, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -1151,8 +1151,8 @@ def test_nerf_backward_vs_oracle_on_dumped_points(M, R):
     xin = p["xyz_in"].clone().requires_grad_(True)
     ind = rays_g[:, 8:9]
     with torch.no_grad():
-        emb_in = A._pad_to(embs[0](p["xyz_in"]), 63)
-        extra_in = A._pad_to(torch.repeat_interleave(embs[1](ind.contiguous()), S, dim=0), 5)
+        emb_in = pad_to(embs[0](p["xyz_in"]), 63)
+        extra_in = pad_to(torch.repeat_interleave(embs[1](ind.contiguous()), S, dim=0), 5)
     gout = torch.randn(n_rays * S, 4, device="cuda")
     out = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, embs[0], xin, *nerf.parameters())
     out.backward(gout)
@@ -1339,8 +1339,8 @@ def test_explicit_nerf_backward_unit(M, R, n_rays, wgrad):
     with torch.no_grad():
         p = rendering._render_pass(rays, bg, z, None, False, None, 0, nerf, embs, None, None, False, False, False,
                                    True, dump=True)
-        emb_in = A._pad_to(embs[0](p["xyz_in"]), 63)
-        extra_in = A._pad_to(torch.repeat_interleave(embs[1](rays[:, 8:9].contiguous()), S, dim=0), 5)
+        emb_in = pad_to(embs[0](p["xyz_in"]), 63)
+        extra_in = pad_to(torch.repeat_interleave(embs[1](rays[:, 8:9].contiguous()), S, dim=0), 5)
     xin = p["xyz_in"].clone().requires_grad_(True)
     for q in nerf.rgb.parameters():
         q.requires_grad_(False)
@@ -1512,13 +1512,13 @@ def test_nerf_backward_other_shapes(M, R, D, skips, extra, extra_dim):
         p = rendering._render_pass(rays, bg, z, None, False, None, 0, nerf, embs, None, None, False, False, False, True, dump=True)
     xin = p["xyz_in"].clone().requires_grad_(True)
     with torch.no_grad():
-        emb_in = A._pad_to(embs[0](p["xyz_in"]), 63)
+        emb_in = pad_to(embs[0](p["xyz_in"]), 63)
         extra_in, extra_o = None, None
         if extra == "ind":
-            extra_in = A._pad_to(torch.repeat_interleave(embs[1](rays[:, 8:9].contiguous()), S, dim=0), extra_dim)
+            extra_in = pad_to(torch.repeat_interleave(embs[1](rays[:, 8:9].contiguous()), S, dim=0), extra_dim)
             extra_o = O.pad_to(torch.repeat_interleave(O.embed(embs[1], rays[:, 8:9].cpu()), S, dim=0), extra_dim)
         elif extra == "dir":
-            extra_in = A._pad_to(torch.repeat_interleave(embs[2](rays[:, 3:6].contiguous()), S, dim=0), extra_dim)
+            extra_in = pad_to(torch.repeat_interleave(embs[2](rays[:, 3:6].contiguous()), S, dim=0), extra_dim)
             extra_o = O.pad_to(torch.repeat_interleave(O.embed(embs[2], rays[:, 3:6].cpu()), S, dim=0), extra_dim)
     gout = torch.randn(n_rays * S, 4, device="cuda")
     out = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, embs[0], xin, *nerf.parameters())
