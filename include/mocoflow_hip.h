@@ -213,7 +213,8 @@ int32_t mf_composite_backward(const float* rays, int64_t ray_stride, int64_t n_r
  * G_i / X_i: fp32 row-major device matrices (column slices of the mf_nerf_backward gradient buffer, of
  * the forward's activation dump, or of the embedded inputs), 16-byte aligned, strides multiples of 4
  * floats.  Supported blocks (n_out x n_in): NeRF 256x256, 256x64, 128x256, 128x32 and 4x640 (the two heads
- * at once: G = ghead (P,4), X = dump columns [h_D | final | extra]); NoF 128x128, 128x80 (embedded input,
+ * at once: G = ghead (P,4), X = dump columns [h_D | final | extra]; no head reads `final`: its 256 columns
+ * are not fetched and columns 256..511 of this block's dW are returned as 0); NoF 128x128, 128x80 (embedded input,
  * 66 -> 80) and 12x128 (head, G = d T padded to 12 columns).  dW is written as a dense
  * (max(n_out,16), n_in) matrix, db (optional, may be NULL) as max(n_out,16) floats.  Deterministic
  * (fixed-order partial sums through `scratch`, no atomics).  Replaces the dW/db halves of torch's

@@ -40,7 +40,7 @@ using ShapeA = WgShape<256, 256, 4, 8, 2, 256>;   // hidden x hidden
 using ShapeB = WgShape<256, 64, 2, 4, 1, 256>;    // hidden x embedded xyz (63 -> 64)
 using ShapeC = WgShape<128, 256, 4, 4, 4, 128>;   // extra_encoding x final
 using ShapeD = WgShape<128, 32, 1, 2, 1, 128>;    // extra_encoding x embedded dir / ind (<= 32)
-using ShapeE = WgShape<16, 640, 1, 5, 8, 4>;      // heads: [d rgb(3), d sigma] x [h_D | final | extra]
+using ShapeE = WgShape<16, 640, 1, 5, 8, 4>;      // heads: [d rgb(3), d sigma] x [h_D | (final: not fetched, dW = 0) | extra]
 using ShapeF = WgShape<128, 128, 2, 4, 2, 128>;   // NoF hidden x hidden
 using ShapeG = WgShape<128, 80, 1, 5, 1, 128>;    // NoF hidden x embedded input (66 -> 80)
 using ShapeH = WgShape<16, 128, 1, 1, 8, 12>;     // NoF head: d T (9 | 3, padded 12) x h_D
@@ -73,7 +73,7 @@ MF_HD int wg_stage_cost(int shape) {
     case 1: return 3700;
     case 2: return 5990;
     case 3: return 2500;
-    case 4: return 4790;
+    case 4: return 3260;      // (the `final` columns not fetched: was 4790)
     case 5: return 3440;
     case 6: return 2690;
     case 7: return 2560;
@@ -150,8 +150,10 @@ MF_D void wg_load_stage(WgSource& src, long long P, uint32_t slot, const LaneId&
       // (buffer form of the LDS-DMA: wave-uniform row address + lane * 16, see blds16)
       if (id.lane < S::GW / 4) blds16(gsrc, id.lane * 16, 0, dg);
 #pragma unroll
-      for (int c0 = 0; c0 < S::NIN / 4; c0 += 64)
+      for (int c0 = 0; c0 < S::NIN / 4; c0 += 64) {
+        if (S::NIN == 640 && c0 == 64) continue;     // heads block: columns 256..511 (`final`, read by no head) are not fetched
         if (c0 + id.lane < S::NIN / 4) blds16(xsrc, id.lane * 16, c0 * 16, dx + c0 * 16);
+      }
     } else {      // past the last sample: the rows contribute nothing
       for (int c = id.lane; c < S::GW; c += 64) lds_zero(dg + c * 4);
       for (int c = id.lane; c < S::NIN; c += 64) lds_zero(dx + c * 4);
@@ -173,6 +175,12 @@ MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, 
     for (int i = tid; i < 3 * kWgStage * S::PG; i += kThreads) {
       const int sl = i / (kWgStage * S::PG), o = i % (kWgStage * S::PG);
       lds_zero(sl * S::SLOT_BYTES + o * 4);
+    }
+    if (S::NIN == 640) {                             // heads block: its unfetched X columns 256..511 stay zero (dW there = 0)
+      for (int i = tid; i < 3 * kWgStage * 256; i += kThreads) {
+        const int sl = i / (kWgStage * 256), r = (i / 256) % kWgStage, c = 256 + i % 256;
+        lds_zero(sl * S::SLOT_BYTES + kWgStage * S::PG * 4 + (r * S::PX + c) * 4);
+      }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __syncthreads();

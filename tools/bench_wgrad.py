@@ -61,6 +61,8 @@ res = A.weight_grads(jobs[:13], P, dev) + A.weight_grads(jobs[13:], P, dev)
 worst = 0.0
 for (G, X, no, ni, b), (dW, db) in zip(jobs, res):
     ref = (G.t().double() @ X.double())
+    if ni == 640:
+        ref[:, 256:512] = 0      # heads block: the `final` columns are not fetched (dW = 0 there by contract)
     err = float((dW[:no].double() - ref).abs().max() / ref.abs().max())
     print(f"    {no}x{ni}: max-rel {err:.2e}  l2-rel {float((dW[:no].double() - ref).norm() / ref.norm()):.2e}")
     worst = max(worst, err)
