@@ -22,25 +22,29 @@ struct EmbFwdParams {
   int repeat;             // output row b embeds input row b / repeat
 };
 
+// one thread per (output row, unit): unit u < C copies x_u; C <= u < C + C F evaluates ONE sincos for (frequency, channel)
+// and writes both of its columns; the remaining units write the zero padding up to out_stride
 __global__ void embedding_forward_kernel(EmbFwdParams p) {
   const int C = p.e.in_channels, F = p.e.n_freqs;
   const int OC = C * (2 * F + 1);
+  const int units = C + C * F + (int)(p.out_stride - OC);
   const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= p.B * p.out_stride) return;
-  const long long b = idx / p.out_stride;
-  const int col = (int)(idx - b * p.out_stride);
+  if (idx >= p.B * units) return;
+  const long long b = idx / units;
+  const int u = (int)(idx - b * units);
   const float* x = p.x + (b / p.repeat) * C;
-  float v = 0.f;
-  if (col < C) {
-    v = x[col];
-  } else if (col < OC) {
-    const int k = (col - C) / C;          // 0 .. 2F-1 : (freq, sin|cos)
-    const int c = (col - C) % C;
-    const int f = k >> 1;
-    const float arg = p.e.freq[f] * x[c];
-    v = p.e.weight[f] * ((k & 1) ? cosf(arg) : sinf(arg));
+  float* o = p.out + b * p.out_stride;
+  if (u < C) {
+    o[u] = x[u];
+  } else if (u < C + C * F) {
+    const int f = (u - C) / C, c = (u - C) % C;
+    float sn, cs;
+    sincosf(p.e.freq[f] * x[c], &sn, &cs);
+    o[C + (2 * f) * C + c] = p.e.weight[f] * sn;
+    o[C + (2 * f + 1) * C + c] = p.e.weight[f] * cs;
+  } else {
+    o[OC + (u - C - C * F)] = 0.f;
   }
-  p.out[idx] = v;
 }
 
 // ------------------------------------------------------------------ NeRF.forward
@@ -241,7 +245,7 @@ static int32_t embedding_forward(const char* who, const mf_embedding* e, const f
                 (long long)out_stride, width);
   if (B == 0) return MF_OK;
   EmbFwdParams p{*e, x, out, B, out_stride, repeat};
-  const long long total = B * out_stride;
+  const long long total = B * (e->in_channels * (1 + e->n_freqs) + (out_stride - width));
   hipLaunchKernelGGL(embedding_forward_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      static_cast<hipStream_t>(stream), p);
   return check_launch(who);
