@@ -162,6 +162,9 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
   constexpr int NW = X3 ? 4 : kWaves;
   constexpr int TILE = NW * kWaveSamples;
   const Lane id;
+#ifdef MF_TIMELINE
+  const unsigned long long tl_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   load_resident<NW>(p.nerf, id);
   if (MOCO) {
     load_resident<NW>(p.bw, id);
@@ -417,6 +420,14 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
     st.tl.stamp(8, id);
   }
   wait_vm0();   // the stream runs two panels ahead: drain the LDS-DMA before the workgroup retires
+#ifdef MF_TIMELINE      // (timing builds only) every workgroup's start / end on the chip-wide 100 MHz clock, in alphas[2..3] of its last group
+  if (threadIdx.x == 0 && p.alphas && blockIdx.x < p.n_groups) {
+    const long long lastg = blockIdx.x + ((p.n_groups - 1 - blockIdx.x) / gridDim.x) * gridDim.x;
+    float* o = p.alphas + lastg * p.G * p.S;
+    o[2] = (float)(tl_rt0 & 0xFFFFFFull);
+    o[3] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFFFull);
+  }
+#endif
 }
 
 // sigma (and the canonical position) of free points in bf16 mode: the lattice / SMPL-point query of mf_forward.hip's

@@ -36,3 +36,28 @@ for w, base in ((0, 0), (4, 512)):
             break
         print(f"tag {tag:3d}  t {t:10.0f}  +{t - prev:8.0f}")
         prev = t
+
+# every workgroup's start / end (chip-wide 100 MHz clock, 24 bits), written by the MF_TIMELINE build of the bf16 kernels
+if cfg["precision"] != "f32":
+    G = 1
+    tile = 128 if cfg["precision"] == "bf16x3" else 256
+    while (G * S) % tile:
+        G += 1
+    ngroups = (N + G - 1) // G
+    grid = min(ngroups, 256)
+    al = out["alphas"].cpu()
+    se = []
+    for b in range(grid):
+        lastg = b + ((ngroups - 1 - b) // grid) * grid
+        row = al.flatten()[lastg * G * S:lastg * G * S + 4]
+        se.append((float(row[2]), float(row[3])))
+    se = np.array(se)
+    t0 = se[:, 0].min()
+    st, en = (se[:, 0] - t0) / 100.0, (se[:, 1] - t0) / 100.0          # microseconds
+    print(f"workgroups: start  min {st.min():.2f} / median {np.median(st):.2f} / max {st.max():.2f} us;  end  min {en.min():.2f} / median {np.median(en):.2f} / max {en.max():.2f} us;"
+          f"  run time min {(en - st).min():.2f} / median {np.median(en - st):.2f} / max {(en - st).max():.2f} us")
+    order = np.argsort(en)
+    print("latest workgroups (id: start, end):", [(int(b), round(float(st[b]), 1), round(float(en[b]), 1)) for b in order[-8:]])
+    xcd = np.arange(grid) % 8
+    for x in range(8):
+        print(f"  XCD {x}: start median {np.median(st[xcd == x]):6.2f}  end median {np.median(en[xcd == x]):7.2f}  end max {en[xcd == x].max():7.2f}")
