@@ -53,6 +53,9 @@ template <bool MOCO, bool DUMP>
 __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
   const LaneId id;
   const NetDev nerf = p.nerf;
+#ifdef MF_TIMELINE
+  const unsigned long long tl_rt0 = __builtin_amdgcn_s_memrealtime();
+#endif
   load_resident(nerf, id);
   if (MOCO) {
     load_resident(p.bw, id);
@@ -307,6 +310,14 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
     st.tl.stamp(8, id);
   }
   wait_vm0();   // the stream runs two panels ahead: drain the LDS-DMA before the workgroup retires
+#ifdef MF_TIMELINE      // (timing builds only) every workgroup's start / end on the chip-wide 100 MHz clock, in alphas[2..3] of its last group
+  if (threadIdx.x == 0 && p.alphas && blockIdx.x < p.n_groups) {
+    const long long lastg = blockIdx.x + ((p.n_groups - 1 - blockIdx.x) / gridDim.x) * gridDim.x;
+    float* o = p.alphas + lastg * p.G * p.S;
+    o[2] = (float)(tl_rt0 & 0xFFFFFFull);
+    o[3] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFFFull);
+  }
+#endif
 }
 
 static void to_table(const mf_embedding& e, float* o) {

@@ -38,9 +38,9 @@ for w, base in ((0, 0), (4, 512)):
         prev = t
 
 # every workgroup's start / end (chip-wide 100 MHz clock, 24 bits), written by the MF_TIMELINE build of the bf16 kernels
-if cfg["precision"] != "f32":
+if True:
     G = 1
-    tile = 128 if cfg["precision"] == "bf16x3" else 256
+    tile = 256 if cfg["precision"] == "bf16" else 128
     while (G * S) % tile:
         G += 1
     ngroups = (N + G - 1) // G
