@@ -22,7 +22,9 @@ The default run also measures the other configs as short extra legs and reports 
 "configs" (N = 1: C3, C3g, C5 shard, and C2x / C3x / C5x = the same workloads in bf16x3, the fp32-class mode of the bf16
 matrix pipe -- every product as three bf16 products of (hi, lo) operand pairs; N > 1: C4, C5), each with its own
 roofline fraction and error against the CPU oracle, so every BASELINE config is driver-measured without changing what
-`value` means.
+`value` means.  The legs are sub-millisecond passes: each gets 100 warm-up and 200 timed steps of its own (a handful of
+warm-up steps leaves the clocks ramping); the main line uses exactly the --steps / --warmup it was given.  The timed region
+of every config holds the calls alone: the per-call event pairs behind "step_span_ms" are recorded in a second, untimed loop.
 
 Extra JSON objects: "roofline" (MFMA bound: algorithmic Linear-layer FLOPs of the dominant kernel's launch / its
 average duration, HIP events on the launch stream around the launch alone, vs the dense matrix peak of the dtype;
