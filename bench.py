@@ -12,8 +12,8 @@ device.  metric = ray-samples/s = network-evaluated samples of all ranks / wall 
 
 BASELINE.json configs:
   C2   canonical NeRF 8x256 (xyz F=10, dir F=4), fp32 (exact-f32 MFMA), 4096 rays x 64 samples -- THE HEADLINE:
-       the main line at every N (4096 rays per rank, weak scaling), so that the driver's 1/2/4/8-GPU curve
-       compares like with like.
+       the main line at every N (4096 rays per rank, weak scaling, NO loss path / collective: that is C4's), so that
+       the driver's 1/2/4/8-GPU curve compares like with like.
   C3   bw NoF -> NeRF(ind) -> fw NoF local chain, bf16 hidden GEMMs, 4096 x 64      (C3g: + global chain)
   C4   C3 ray-sharded, 4096 rays per rank, per-batch loss partials all-reduced over RCCL (N > 1)
   C5   coarse 64 + fine 128 with the inverse-CDF resample, MoCo local+global chains, bf16, 1024 rays per rank
@@ -30,7 +30,8 @@ Extra JSON objects: "roofline" (MFMA bound: algorithmic Linear-layer FLOPs of th
 average duration, HIP events on the launch stream around the launch alone, vs the dense matrix peak of the dtype;
 "step_span_ms" is the whole render_rays call incl. resample / consensus compaction) and "cpu_baseline" (the CPU oracle -- a PyTorch restatement of the
 reference's op sequence, pinned to the reference's golden vectors -- timed on this box's host cores with the
-best thread count of a sweep; rank 0, N = 1 only).
+best thread count of a sweep; rank 0, N = 1 only).  The line ENDS with "legs": one compact record per measured config
+(ms per step, kernel ms, roofline fraction, PSNR-equivalent dB, worst max-rel) + the training-step times.
 """
 import argparse
 import json
@@ -460,7 +461,9 @@ def run_config(name, a, ctx, steps, warmup, main):
     kw = render_kwargs(cfg, models)
 
     from moco_flow_amd.dist import N_PARTIALS, OverlappedLossReducer
-    with_loss = world > 1 or cfg.get("loss")
+    # the loss partials + their all-reduce belong to the configs that name them (C4, C5): the C2 main line is the same work
+    # at every N, so the driver's 1 -> N curve compares like with like
+    with_loss = bool(cfg.get("loss"))
     reducer = OverlappedLossReducer(N_PARTIALS, dev) if with_loss else None
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
 
@@ -472,7 +475,9 @@ def run_config(name, a, ctx, steps, warmup, main):
         out = M.render_rays(rays, bg, models["embs"], models["nerfs"], _loss_target=gt if reducer is not None else None, **kw)
         # what the unchanged trainer does with the consensus vectors right away (trainer_moco_flow.py:317-328): their means
         # (lazy.MaskedVector: masked sums on the device, no compaction, no host sync)
-        cons = [torch.mean(v) for k, v in out.items() if k.startswith("nof_")]
+        # -- behind the per-chunk concatenation of its forward() wrapper, `results[k] = torch.cat(v, 0)` (:199-223; one chunk:
+        # chunk >= N_rand in every shipped YAML), which stays lazy too
+        cons = [torch.mean(torch.cat([v], 0)) for k, v in out.items() if k.startswith("nof_")]
         if i is not None:
             ev[i][1].record()
         if reducer is not None:
@@ -662,6 +667,23 @@ def worker(a):
             line["configs"][name] = {k: r[k] for k in ("value", "ms_per_step", "dtype", "config", "roofline", "error_vs_cpu", "loss_path",
                                                        "cpu_baseline", "speedup_vs_cpu") if k in r}
             line["configs"][name].update(steps=k_leg, warmup=w_leg)
+    # LAST key: a compact summary of every measured configuration (the driver's record keeps the final 2000 characters of
+    # the line; the full objects above may fall off it).  Per config: ms per step, dominant kernel ms, roofline fraction,
+    # PSNR-equivalent (dB) and the worst max-rel of the per-ray outputs against the CPU oracle.
+    def compact(r):
+        e = r.get("error_vs_cpu") or {}
+        worst = max(e["max_rel"].values()) if e.get("max_rel") else None
+        sig = lambda x, n=4: None if x is None else float(f"{x:.{n}g}")
+        return {"ms": sig(r["ms_per_step"]), "kernel_ms": sig(r["roofline"]["kernel_ms"]), "frac": sig(r["roofline"]["frac"], 3),
+                "db": sig(e.get("psnr_equiv_db"), 4), "max_rel": sig(worst, 2)}
+    legs = {main_cfg: compact(res)}
+    for name, r in line.get("configs", {}).items():
+        legs[name] = compact(r)
+    if "train_steps" in res:
+        legs["train_ms"] = {k: float(f"{v['ms_per_step']:.4g}") for k, v in res["train_steps"].items() if isinstance(v, dict)}
+    if "fwd_bwd" in res:
+        legs["fwd_bwd_ms"] = float(f"{res['fwd_bwd']['ms_per_step']:.4g}")
+    line["legs"] = legs
     if rank == 0:
         print(json.dumps(line), flush=True)
     if dist is not None:

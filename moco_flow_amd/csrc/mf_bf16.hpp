@@ -775,10 +775,19 @@ MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&
   }
 }
 
-// NoF matrix operands from a point: its xyz block (rendering.py:70-72); the image-index block (:73-75) is the per-ray bias
+// NoF matrix operands from a point: its xyz block (rendering.py:70-72); the image-index block (:73-75) is the per-ray bias.
+// HW: sin / cos from the transcendental unit (the fast mode: the angle's fp32 rounding in revolutions, <= 6e-6 rad at
+// 16 x, is far under the hidden layers' bf16 rounding); the three-product mode takes exact seeds + doubling chains -- the
+// canonical point this network produces feeds sin(512 x), and 6e-6 rad is the size of the split operands' own 2^-17.
+#ifdef MF_X3_NOF_HW                  // (A/B: round 3's x3 kernels took the unit's values here too)
+#define MF_NOF_HW_X3 true
+#else
+#define MF_NOF_HW_X3 false
+#endif
+template <bool HW = true>
 MF_D void nof_embed(u32x4 (&xhi)[kKsNofXyz], u32x4 (&xlo)[kKsNofXyz], const float (&xyz)[3], uint32_t par_xyz, int h, bool pow2_xyz) {
   float emb[B2Xyz5::SLOTS];
-  emb_eval<3, 5, true>(emb, xyz, par_xyz, h, pow2_xyz);
+  emb_eval<3, 5, HW>(emb, xyz, par_xyz, h, pow2_xyz);
   split_operands<kKsNofXyz>(emb, B2Xyz5::SLOTS, xhi, xlo);
 }
 

@@ -258,7 +258,7 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
           const Next follow = last ? first_of<16, kKsNerfXyz, X3, NF0>(p.nerf) : first_of<8, kKsNofXyz, true, NP2>(next_fw ? p.fw : p.bw);
           u32x4 nhi[kKsNofXyz], nlo[kKsNofXyz];
           float out[3];
-          nof_embed(nhi, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
+          nof_embed<!X3 || MF_NOF_HW_X3>(nhi, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
           auto stage_next = [&] {
             if (!last) stage_raybias<NW>(p, ray0 + tf, tn, role + 1 == 4 ? 1 : role + 1, p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes, id);
           };
@@ -492,7 +492,7 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void points_kernel
         nof_eval(p.bw, nhi, nlo, x, st, carry, id, nerf_first, out, rb, rbp, [] {});
       } else {
         LdsRayBias rb{p.rb_off};
-        nof_embed(nhi, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
+        nof_embed<!X3 || MF_NOF_HW_X3>(nhi, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
         if constexpr (X3) nof_eval_x3(p.bw, nhi, nlo, x, st, carry, id, nerf_first, out, rb, [] {});
         else nof_eval(p.bw, nhi, nlo, x, st, carry, id, nerf_first, out, rb, nullptr, [] {});
       }

@@ -12,6 +12,11 @@ per-sample distances).  Anything else -- ``.shape``, ``len()``, indexing, arithm
 materialises the real tensor first (mf_compact_mask: count -> scan -> scatter in row-major (ray, sample) order, one host
 sync; ``torch.masked_select`` under autograd), after which the object simply forwards to it.  It is not a
 ``torch.Tensor`` subclass (a tensor needs its size up front); ``rendering.LAZY_CONSENSUS = False`` restores eager tensors.
+
+``torch.cat`` of such vectors along dim 0 stays lazy: the reference's trainer concatenates the result dicts of its ray
+chunks before it takes the means (``results[k] = torch.cat(v, 0)``, trainer/trainer_moco_flow.py:199-223, 236-247 -- with
+``chunk`` >= ``N_rand``, as in every shipped YAML, a list of ONE vector), and the mean of a concatenation is
+sum of the parts' sums / sum of their counts.
 """
 from __future__ import annotations
 
@@ -41,29 +46,41 @@ class ConsensusPass:
             self._mask = torch.where(m.any(), m, torch.ones_like(m))
         return self._mask
 
-    def vectors(self):
-        if self._vectors is None:
-            self._vectors = self._compact_fn()
-        return self._vectors
+    def vector(self, key):
+        """The compacted tensor of plane ``key``.  (Keyed: under autograd the planes of a pass are registered one by one, and
+        an eager caller -- LAZY_CONSENSUS off -- asks for "local" before "global" exists.)"""
+        if self._vectors is None or key not in self._vectors:
+            self._vectors = {**self._compact_fn(), **(self._vectors or {})}      # (tensors already handed out stay)
+        return self._vectors[key]
 
 
 class MaskedVector:
-    def __init__(self, group: ConsensusPass, key: str):
-        self._g, self._k = group, key
+    def __init__(self, group: ConsensusPass, key: str, parts=None):
+        self._parts = list(parts) if parts is not None else [(group, key)]     # a lazy concatenation has several
+        self._g, self._k = self._parts[0]
 
     # ---- the reductions that need no length
-    def _sum_count(self):
-        g = self._g
+    @staticmethod
+    def _part_sum_count(g, k):
         if g.differentiable:
-            m = g.mask().to(g.planes[self._k].dtype)
-            return (g.planes[self._k] * m).sum(), m.sum()
-        return g.stats()[self._k][:2]
+            m = g.mask().to(g.planes[k].dtype)
+            return (g.planes[k] * m).sum(), m.sum()
+        return g.stats()[k][:2]
+
+    def _sum_count(self):
+        s, c = self._part_sum_count(*self._parts[0])
+        for g, k in self._parts[1:]:
+            s2, c2 = self._part_sum_count(g, k)
+            s, c = s + s2, c + c2
+        return s, c
 
     def mean(self, *args, **kwargs):
         if args or kwargs:
             return self.materialize().mean(*args, **kwargs)
-        if not self._g.differentiable:
-            return self._g.stats()[self._k][2]          # the kernel's own fp32 mean: no further launch
+        if len(self._parts) == 1 and not self._g.differentiable:
+            # the kernel's own fp32 mean -- a COPY: the reference adds in place into what torch.mean returned
+            # (`nof_local = torch.mean(coarse); nof_local += torch.mean(fine)`, trainer_moco_flow.py:318-321)
+            return self._g.stats()[self._k][2].clone()
         s, c = self._sum_count()
         return (s / c).to(torch.float32)
 
@@ -74,7 +91,9 @@ class MaskedVector:
 
     # ---- everything else: the real tensor
     def materialize(self) -> torch.Tensor:
-        return self._g.vectors()[self._k]
+        if len(self._parts) == 1:
+            return self._g.vector(self._k)
+        return torch.cat([g.vector(k) for g, k in self._parts], 0)
 
     @classmethod
     def __torch_function__(cls, func, types, args=(), kwargs=None):
@@ -82,6 +101,11 @@ class MaskedVector:
         if func in (torch.mean, torch.Tensor.mean, torch.sum, torch.Tensor.sum) and len(args) == 1 and not kwargs \
                 and isinstance(args[0], MaskedVector):
             return args[0].mean() if func in (torch.mean, torch.Tensor.mean) else args[0].sum()
+        if func is torch.cat and args and isinstance(args[0], (list, tuple)) and args[0] \
+                and all(isinstance(a, MaskedVector) for a in args[0]) \
+                and (args[1] if len(args) > 1 else kwargs.get("dim", 0)) in (0, -1) and not (set(kwargs) - {"dim"}):
+            # the trainer's per-chunk concatenation (module docstring): stays lazy
+            return MaskedVector(None, None, parts=[p for a in args[0] for p in a._parts])
 
         def real(a):
             if isinstance(a, MaskedVector):
@@ -111,7 +135,8 @@ class MaskedVector:
         return a if dtype is None else a.astype(dtype)
 
     def __repr__(self):
-        return f"MaskedVector({self._k}, materialised={self._g._vectors is not None})"
+        done = all(g._vectors is not None and k in g._vectors for g, k in self._parts)
+        return f"MaskedVector({'+'.join(k for _, k in self._parts)}, materialised={done})"
 
     def __float__(self):
         return float(self.materialize())

@@ -11,8 +11,8 @@ if ROOT not in sys.path:
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
 
-# the 1-rank RCCL child (tests/rccl_child.py): {"proc": Popen, "log": path} once started
-RCCL_CHILD = {}
+# the child-process legs of a GPU session (tests/preflight.py): {"proc": Popen, "dir": path} once started
+PREFLIGHT = {}
 
 
 def _gpu_run_selected(config):
@@ -41,21 +41,18 @@ def pytest_configure(config):
     if os.environ.get("MF_TEST_WGRAD"):
         from moco_flow_amd import autograd as _A
         _A.set_wgrad_precision(os.environ["MF_TEST_WGRAD"])
-    # Start the RCCL child NOW, while this process has not touched the GPU: a process that has initialised the GPU
-    # must not exec another program on the GPU pool, and every later point of a -m gpu session is behind such a call.
-    if _gpu_run_selected(config) and not os.environ.get("MF_NO_RCCL_CHILD") and not hasattr(config, "workerinput"):
-        log = tempfile.NamedTemporaryFile(prefix="mf_rccl_child_", suffix=".log", delete=False)
-        env = dict(os.environ)
-        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        RCCL_CHILD["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "rccl_child.py")],
-                                              stdout=log, stderr=subprocess.STDOUT, env=env, cwd=ROOT)
-        RCCL_CHILD["log"] = log.name
-        log.close()
+    # Start the child-process legs NOW (tests/preflight.py: the 1-rank RCCL child, then bench.py --gpus 2), while this
+    # process has not touched the GPU: a process that has initialised the GPU must not start another GPU program on this
+    # pool, and every later point of a -m gpu session is behind such a call.
+    if _gpu_run_selected(config) and not os.environ.get("MF_NO_PREFLIGHT") and not hasattr(config, "workerinput"):
+        out = tempfile.mkdtemp(prefix="mf_preflight_")
+        PREFLIGHT["proc"] = subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "preflight.py"), out], cwd=ROOT)
+        PREFLIGHT["dir"] = out
 
 
 def pytest_unconfigure(config):
-    p = RCCL_CHILD.get("proc")
-    if p is not None and p.poll() is None:       # the exact process we started
+    p = PREFLIGHT.get("proc")
+    if p is not None and p.poll() is None:       # the exact process we started (its children carry their own timeouts)
         p.kill()
 
 
@@ -75,9 +72,25 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
-@pytest.fixture(scope="session")
-def rccl_child():
-    return RCCL_CHILD
+@pytest.fixture(scope="session", autouse=True)
+def preflight():
+    """{"status": {"rccl": rc, "bench2": rc}, "dir": logs} of tests/preflight.py, or {} when it was not started.  Autouse:
+    the session's first test waits for the children to finish, so they never share the GPU with a timing- or
+    bit-sensitive test (their own timeouts bound the wait)."""
+    p = PREFLIGHT.get("proc")
+    if p is None:
+        return {}
+    try:
+        p.wait(timeout=1800)
+    except subprocess.TimeoutExpired:
+        p.kill()
+    import json
+    try:
+        with open(os.path.join(PREFLIGHT["dir"], "status.json")) as fh:
+            status = json.load(fh)
+    except OSError:
+        status = {}
+    return {"status": status, "dir": PREFLIGHT["dir"]}
 
 
 @pytest.fixture(params=["f32", "bf16x3"])

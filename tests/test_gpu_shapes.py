@@ -4,9 +4,11 @@
   105-109: S = 128, M = 128, NeRF(ind/5), quaternion NoFs, local + global chains, perturb = 1.0) and stage 1
   (init_nerf.yaml:29-36: S = 128, M = 128, NeRF(dir/27), xyz N_freqs = 0, softplus, perturb = 1.0) -- on a ray slice
   the oracle finishes in seconds, in TRAINING mode (gradients recorded: the dumping kernels are the ones checked);
-* the 1-rank RCCL leg (tests/rccl_child.py, started by conftest.py before this process touched the GPU).
+* the child-process legs (tests/preflight.py, started by conftest.py before this process touched the GPU): the 1-rank RCCL
+  group (tests/rccl_child.py) and bench.py's real two-rank worker path.
 Bars: 1e-4 max-rel (north_star) unless a comment says why not."""
 import json
+import os
 
 import numpy as np
 import pytest
@@ -206,25 +208,46 @@ def test_stage1_training_shape_vs_oracle(M, R, wgrad):
     assert checked == 2 * 24
 
 
-def test_rccl_one_rank_child(rccl_child):
+def _preflight_log(preflight, name):
+    assert preflight, "conftest.py did not start tests/preflight.py (MF_NO_PREFLIGHT set?)"
+    log = open(os.path.join(preflight["dir"], name + ".log")).read()
+    print(log[-3000:])
+    assert preflight["status"].get(name) == 0, (preflight["status"], log[-3000:])
+    return log
+
+
+def test_rccl_one_rank_child(preflight):
     """BASELINE config C4's collective leg on one GPU (trainer/base.py:104-106): tests/rccl_child.py -- a 1-rank "nccl"
     (RCCL) process group, 50 MoCo bf16 steps whose loss partials go through OverlappedLossReducer's real all-reduce Work
-    objects under torch's sync-debug "error" mode -- was started by conftest.py before this process touched the GPU."""
-    p = rccl_child.get("proc")
-    assert p is not None, "conftest.py did not start tests/rccl_child.py (MF_NO_RCCL_CHILD set?)"
-    try:
-        rc = p.wait(timeout=600)
-    except Exception:
-        p.kill()
-        raise
-    log = open(rccl_child["log"]).read()
-    print(log[-3000:])
-    assert rc == 0, log[-3000:]
+    objects under torch's sync-debug "error" mode -- was run by tests/preflight.py before this process touched the GPU."""
+    log = _preflight_log(preflight, "rccl")
     line = [ln for ln in log.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["ok"] and out["backend"] == "nccl" and out["world"] == 1
     assert out["steps"] == 50 and out["mismatching_steps"] == 0
     assert all("Done" not in t for t in out["work_types"]), out["work_types"]
+
+
+def test_bench_two_ranks_real_worker_path(preflight):
+    """`python bench.py --gpus 2 --steps 3 --warmup 1` -- bench.py's REAL world > 1 worker path (self-spawned ranks, 127.0.0.1
+    rendezvous, C2 main line, C4 / C5 legs with the loss-partials all-reduce, MAX-over-ranks timing, one JSON line from rank
+    0) -- with both ranks on GPU 0 and gloo as the backend (MF_BENCH_SHARE_GPU / MF_BENCH_BACKEND: what one GPU can
+    execute; RCCL itself is the other child's subject).  The N > 1 main line carries no loss path (same work as N = 1)."""
+    log = _preflight_log(preflight, "bench2")
+    lines = [ln for ln in log.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["config"]["global_rays"] == 8192 and d["config"]["rays_per_gpu"] == 4096 and d["config"]["sharding"] == "rays2"
+    assert d["config"]["loss_allreduce"] is False and d["dtype"] == "f32"
+    assert np.isfinite(d["value"]) and d["value"] > 0 and np.isfinite(d["ms_per_step"])
+    assert set(d["configs"]) >= {"C4", "C5"}
+    for name in ("C4", "C5"):
+        leg = d["configs"][name]
+        assert leg["config"]["loss_allreduce"] is True and leg["config"]["sharding"] == "rays2", name
+        assert np.isfinite(leg["value"]) and leg["value"] > 0 and 0 < leg["roofline"]["frac"] < 1, name
+    assert list(d)[-1] == "legs" and set(d["legs"]) >= {"C2", "C4", "C5"}
+    assert all(np.isfinite(v["ms"]) and v["ms"] > 0 for k, v in d["legs"].items() if isinstance(v, dict) and "ms" in v)
 
 
 def test_lazy_consensus_vectors(M):
@@ -251,11 +274,28 @@ def test_lazy_consensus_vectors(M):
                 torch.cuda.set_sync_debug_mode("error")
                 try:
                     res = M.render_rays(rays, bg, embs, nerfs, **kw)
-                    means = {k: torch.mean(res[k]) for k in keys}
+                    # the unchanged trainer: forward() concatenates its ray chunks' result dicts -- `torch.cat(v, 0)`,
+                    # trainer_moco_flow.py:199-223 -- before _shared_step takes the means (:317-328), adding in place
+                    wrapped = {k: torch.cat([res[k]], 0) for k in keys}
+                    means = {k: torch.mean(wrapped[k]) for k in keys}
+                    acc = torch.mean(wrapped[keys[0]])
+                    acc += torch.mean(wrapped[keys[2]])
                     sums = {k: res[k].sum() for k in keys}
+                    again = torch.mean(wrapped[keys[0]])
                 finally:
                     torch.cuda.set_sync_debug_mode("default")
-                assert all(isinstance(res[k], MaskedVector) for k in keys)
+                assert all(isinstance(res[k], MaskedVector) and isinstance(wrapped[k], MaskedVector) for k in keys)
+                assert float(again) == float(means[keys[0]])             # the in-place += did not reach the cached mean
+                assert float(acc) == pytest.approx(float(means[keys[0]]) + float(means[keys[2]]), rel=1e-6)
+                # two ray chunks through the same wrapper: the mean of the concatenation
+                h = rays.shape[0] // 2
+                parts = [M.render_rays(rays[:h], bg[:h], embs, nerfs, **kw), M.render_rays(rays[h:], bg[h:], embs, nerfs, **kw)]
+                for k in keys:
+                    cat = torch.cat([q[k] for q in parts], 0)
+                    assert isinstance(cat, MaskedVector)
+                    whole = res[k].materialize()
+                    assert float(torch.mean(cat)) == pytest.approx(float(whole.mean()), rel=2e-6), k
+                    assert torch.equal(cat.materialize(), whole), k
                 rendering.LAZY_CONSENSUS = False
                 eager = M.render_rays(rays, bg, embs, nerfs, **kw)
                 rendering.LAZY_CONSENSUS = True
@@ -289,4 +329,13 @@ def test_lazy_consensus_vectors(M):
     lb, gb = grads(True)
     assert la == pytest.approx(lb, rel=1e-6)
     for x, y in zip(ga, gb):
+        assert relerr(x, y) <= 1e-5
+    # the eager opt-out in TRAINING with the global chain (c2f.yaml's configuration; ADVICE r3: KeyError 'global')
+    try:
+        rendering.LAZY_CONSENSUS = False
+        lc, gc = grads(False)
+    finally:
+        rendering.LAZY_CONSENSUS = True
+    assert lc == pytest.approx(lb, rel=1e-6)
+    for x, y in zip(gc, gb):
         assert relerr(x, y) <= 1e-5

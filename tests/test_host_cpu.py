@@ -503,6 +503,12 @@ def test_bench_self_spawns_its_ranks():
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["reduced"] == 3.0      # ranks contribute 1 + 2
+    # the driver's largest world: 8 ranks (1 + 2 + ... + 8 = 36)
+    r8 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
+                        env=env, capture_output=True, text=True, timeout=400)
+    assert r8.returncode == 0, r8.stderr[-2000:]
+    d8 = json.loads([l for l in r8.stdout.splitlines() if l.startswith("{")][-1])
+    assert d8["n_gpus"] == 8 and d8["reduced"] == 36.0
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "nope"],
                          env=env, capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0
@@ -516,3 +522,60 @@ def test_scripts_compile():
     for f in files:
         with open(f) as fh:
             compile(fh.read(), f, "exec")
+
+
+def test_lazy_vectors_host_logic():
+    """lazy.MaskedVector / ConsensusPass on CPU tensors (no kernel involved): (i) the eager opt-out under autograd asks for
+    "local" before the "global" plane exists -- the keyed cache must serve both (KeyError 'global' with
+    LAZY_CONSENSUS off and chain_global); (ii) torch.cat of vectors along dim 0 -- the reference trainer's per-chunk
+    concatenation, trainer/trainer_moco_flow.py:199-223 -- stays lazy, and its mean / sum are those of the concatenated
+    tensors; (iii) the mean of a gradient-free vector is a copy: the trainer's in-place `+=` (trainer_moco_flow.py:318-321)
+    must not reach the cached kernel output."""
+    from moco_flow_amd.lazy import ConsensusPass, MaskedVector
+    torch.manual_seed(0)
+
+    def diff_group(n, s):
+        alphas = torch.rand(n, s) * 0.05
+        planes = {}
+        sel = lambda: {k: torch.masked_select(v, alphas.ge(0.01)) for k, v in planes.items()}
+        return alphas, planes, ConsensusPass(alphas, planes, None, sel, True)
+
+    # (i)
+    alphas, planes, g = diff_group(5, 7)
+    planes["local"] = torch.rand(5, 7, requires_grad=True)
+    local = MaskedVector(g, "local").materialize()
+    planes["global"] = torch.rand(5, 7, requires_grad=True)
+    glob = MaskedVector(g, "global").materialize()
+    assert torch.equal(glob, planes["global"][alphas.ge(0.01)])
+    assert MaskedVector(g, "local").materialize() is local          # what was handed out stays
+    (local.sum() + glob.sum()).backward()
+    assert planes["local"].grad is not None and planes["global"].grad is not None
+
+    # (ii) differentiable parts
+    parts, eager = [], []
+    for n in (3, 4, 2):
+        a, pl, gg = diff_group(n, 6)
+        pl["local"] = torch.rand(n, 6)
+        parts.append(MaskedVector(gg, "local"))
+        eager.append(pl["local"][a.ge(0.01)])
+    one = torch.cat([parts[0]], 0)
+    assert isinstance(one, MaskedVector) and one._g._vectors is None
+    cat = torch.cat(parts, 0)
+    assert isinstance(cat, MaskedVector) and all(p._g._vectors is None for p in parts)
+    want = torch.cat(eager, 0)
+    assert torch.mean(cat).item() == pytest.approx(want.mean().item(), rel=1e-6)
+    assert cat.sum().item() == pytest.approx(want.sum().item(), rel=1e-6)
+    assert torch.equal(cat.materialize(), want) and len(cat) == want.shape[0]
+    assert torch.is_tensor(torch.cat(parts, 0) * 2)                  # anything else materialises
+    # a mixed list (tensor + vector) is an ordinary cat
+    assert torch.equal(torch.cat([parts[0], want[:2]], 0), torch.cat([eager[0], want[:2]], 0))
+
+    # (iii) gradient-free: stats() is the kernel's (sum, count, mean) triple
+    cache = {"local": (torch.tensor(6.0, dtype=torch.float64), torch.tensor(3.0, dtype=torch.float64), torch.tensor(2.0))}
+    gf = ConsensusPass(torch.rand(2, 2), {"local": torch.rand(2, 2)}, lambda: cache, lambda: {}, False)
+    v = MaskedVector(gf, "local")
+    m = torch.mean(v)
+    m += 10.0
+    assert float(torch.mean(v)) == 2.0 and float(cache["local"][2]) == 2.0
+    two = torch.cat([v, v], 0)                                       # chunks: sum of sums / sum of counts
+    assert float(torch.mean(two)) == pytest.approx(2.0)

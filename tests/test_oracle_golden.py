@@ -6,7 +6,7 @@ import pytest
 import torch
 
 from cases import RENDER_CASES
-from helpers import build_case, load_golden, relerr
+from helpers import build_case, case_inputs, load_golden, relerr
 from oracle import cpu_ref as R
 
 TOL = 1e-6
@@ -213,3 +213,49 @@ def test_smpl_oracle_vs_reference_golden():
     assert relerr(trans, g["out_trans"]) <= 1e-5
     cano = smpl_ref.apply_vertex_transforms(trans, torch.from_numpy(g["out_ind"]), torch.from_numpy(g["in_query"]))
     assert relerr(cano, g["out_cano"]) <= 1e-5
+
+
+def test_bf16_ref_hooks_off_is_cpu_ref():
+    """oracle/bf16_ref.py -- the oracle with rounding hooks at the bf16 kernels' choices -- degenerates, hooks off, to
+    the very calls of oracle/cpu_ref.py: torch.equal on whole render passes (MoCo coarse + fine with both chains, flow
+    head, NeRF alone with dir / none), so it inherits cpu_ref's pinning to the reference-generated fixtures."""
+    from oracle import bf16_ref as B
+    for name in ("r_moco_global_fine", "r_moco_global_flowhead", "r_nerf_dir_dense", "r_nerf_none_dense", "r_moco_local_test"):
+        c = RENDER_CASES[name]
+        rays, bg = case_inputs(c, 0)
+        embs, nerfs, kw = build_case(R, c, 0)
+        want = R.render_rays(rays, bg, embs, nerfs, **kw)
+        embs2, nerfs2, kw2 = build_case(B.Backend(B.F32), c, 0)
+        got = R.render_rays(rays, bg, embs2, nerfs2, **kw2)
+        assert list(got) == list(want)
+        for k in want:
+            assert torch.equal(got[k], want[k]), (name, k)
+
+
+def test_bf16_ref_modes_sit_where_their_arithmetic_puts_them():
+    """The hooks on: each mode's distance to the fp32 oracle on the MoCo fixture is the size of its operand rounding --
+    bf16 operands 35-60 dB, three bf16 products >= 95 dB, float64 accumulation of fp32 operands >= 115 dB -- and every
+    sin / cos variant of the encodings agrees with torch's to the accuracy the kernels rely on (transcendental-unit path
+    <= 7.5e-8 of the angle, doubling chains <= 5e-6: four doublings of a seed's 1e-7)."""
+    from oracle import bf16_ref as B
+    c = RENDER_CASES["r_moco_global"]
+    rays, bg = case_inputs(c, 0)
+    embs, nerfs, kw = build_case(R, c, 0)
+    want = R.render_rays(rays, bg, embs, nerfs, **kw)
+    band = {"bf16": (35.0, 60.0), "bf16x3": (95.0, 125.0), "bf16x3_r3": (90.0, 125.0)}
+    for name, (lo, hi) in band.items():
+        e2, n2, kw2 = build_case(B.Backend(B.ARITH[name]), c, 0)
+        got = R.render_rays(rays, bg, e2, n2, **kw2)
+        ps = B.psnr_equiv(got["rgb_coarse"], want["rgb_coarse"])
+        assert lo <= ps <= hi, (name, ps)
+    from dataclasses import replace
+    e2, n2, kw2 = build_case(B.Backend(replace(B.F32, acc="f64")), c, 0)
+    got = R.render_rays(rays, bg, e2, n2, **kw2)
+    assert B.psnr_equiv(got["rgb_coarse"], want["rgb_coarse"]) >= 115.0
+    x = (torch.rand(2000, 3) - 0.5) * 12
+    for nf in (10, 5, 4):
+        ref = R.Embedding(3, nf)(x)
+        for mode, tol in (("hw", 7.5e-8 * 2 ** (nf - 1) * 6 + 2e-7), ("chain", 5e-6)):
+            e = B.Embedding(3, nf)
+            e.mode = mode
+            assert float((e(x) - ref).abs().max()) <= tol, (nf, mode, float((e(x) - ref).abs().max()))

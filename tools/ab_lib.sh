@@ -13,9 +13,8 @@ if [ "$mode" = build ]; then
   unit=$1; shift
   make -C $REPO/moco_flow_amd/csrc -j8 > /dev/null || exit 1
   others=$(ls $REPO/moco_flow_amd/csrc/*.o | grep -v "/${unit%.hip}.o")
-  # (csrc/Makefile builds the bf16 unit without SLP vectorisation -- packed-fp32 ops were not bit-stable there; the A/B
-  #  variants of that unit must carry the same flag or they measure it too)
-  unitflags=""; [ "$unit" = mf_render_bf16.hip -o "$unit" = mf_backward_bf16.hip ] && unitflags="-fno-slp-vectorize -mllvm -pragma-unroll-threshold=1000000"
+  # (the variant carries the unit's own flags of the shipped build -- csrc/Makefile, `unitflags` -- or it measures them too)
+  unitflags=$(make -s -C $REPO/moco_flow_amd/csrc unitflags UNIT=$unit)
   for spec in "$@"; do
     name=${spec%%=*}; flags="${spec#*=} $unitflags"
     ( cd $REPO/moco_flow_amd/csrc && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -Wno-unused-function $flags -c $unit -o $AB/${unit%.hip}_$name.o \

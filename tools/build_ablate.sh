@@ -11,7 +11,7 @@ for variant in flags ablate; do
   DEFS="-DMF_TIMING_FLAGS=1"; [ $variant = ablate ] && DEFS="$DEFS -DMF_ABLATE_NOLDS=1"
   mkdir -p /tmp/abl_$variant
   for f in *.hip; do
-    X=""; [ $f = mf_render_bf16.hip ] && X="-fno-slp-vectorize -mllvm -pragma-unroll-threshold=1000000"
+    X=$(make -s unitflags UNIT=$f)       # per-unit flags of the shipped build (csrc/Makefile)
     /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $DEFS $X -c $f -o /tmp/abl_$variant/${f%.hip}.o &
   done
   wait

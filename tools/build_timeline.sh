@@ -6,7 +6,7 @@ REPO=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p /tmp/tlobj $REPO/build/ab
 cd $REPO/moco_flow_amd/csrc
 for f in mf_abi mf_pack mf_forward mf_render mf_render_bf16 mf_backward mf_backward_bf16 mf_wgrad mf_nofgrad mf_composite mf_sample mf_aux mf_loss mf_smpl; do
-  X=""; [ $f = mf_render_bf16 -o $f = mf_backward_bf16 ] && X="-fno-slp-vectorize -mllvm -pragma-unroll-threshold=1000000"
+  X=$(make -s unitflags UNIT=$f)         # per-unit flags of the shipped build (csrc/Makefile)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off ${MF_VARIANT_FLAGS:--DMF_TIMELINE} $X "$@" -c $f.hip -o /tmp/tlobj/$f.o &
 done
 wait
