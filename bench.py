@@ -46,13 +46,23 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FLOPS = {"nerf_dir": 1186816, "nerf_ind": 1181184, "nof_quat": 134400}   # per sample, SURVEY.md §8d
-# TFLOP/s, MI355X_MICROARCH.md: fp32-input MFMA / dense bf16 MFMA.  bf16x3 issues THREE bf16 matrix instructions per
-# algorithmic product (hi*hi + hi*lo + lo*hi): its ceiling in algorithmic FLOP/s is a third of the bf16 peak.
-PEAK = {"f32": 157.3, "bf16": 2516.0, "bf16x3": 2516.0 / 3}
+# TFLOP/s, MI355X_MICROARCH.md: fp32-input MFMA / dense bf16 MFMA.  bf16x3 issues SEVERAL bf16 matrix instructions per
+# algorithmic product -- three for the NeRF (hi*hi + hi*lo + lo*hi of (hi, lo) operand pairs), six for the NoF ((hi, mid, lo)
+# triples, every product down to 2^-16: its output point feeds sin(512 x)) -- so its ceiling in ALGORITHMIC FLOP/s is the bf16
+# peak x (algorithmic FLOP / issued FLOP) of the configuration: peak_of().
+PEAK = {"f32": 157.3, "bf16": 2516.0}
+X3_PRODUCTS = {"nerf": 3, "nof": 6}
 PEAK_NOTE = {"f32": "dense fp32-input MFMA peak", "bf16": "dense bf16 MFMA peak",
-             "bf16x3": "dense bf16 MFMA peak / 3 (three bf16 matrix instructions per algorithmic product; `achieved` counts "
-                       "algorithmic FLOP)"}
-# (bf16x3 is priced on ALGORITHMIC flops against the bf16 peak like bf16: its extra products are its own overhead)
+             "bf16x3": "dense bf16 MFMA peak x algorithmic / issued FLOP (three bf16 matrix instructions per NeRF product, six per "
+                       "NoF product; `achieved` counts algorithmic FLOP)"}
+
+
+def peak_of(cfg):
+    if cfg["precision"] != "bf16x3":
+        return PEAK[cfg["precision"]]
+    nerf, nof = FLOPS["nerf_" + cfg["net"]], n_nof(cfg) * FLOPS["nof_quat"]
+    return PEAK["bf16"] * (nerf + nof) / (X3_PRODUCTS["nerf"] * nerf + X3_PRODUCTS["nof"] * nof)
+
 
 CONFIGS = {
     "C2": dict(net="dir", precision="f32", rays=4096, S=64, M=0, nof=None,
@@ -64,13 +74,13 @@ CONFIGS = {
     "C3": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="local",
                what="C3: bw NoF -> NeRF(ind) -> fw NoF local consensus chain, bf16 hidden GEMMs"),
     "C2x": dict(net="dir", precision="bf16x3", rays=4096, S=64, M=0, nof=None,
-                what="C2 in the accuracy mode of the bf16 pipe (bf16x3: every matrix product as three bf16 products of (hi, lo) "
+                what="C2 in the contract mode of the bf16 pipe (bf16x3: every matrix product as three bf16 products of (hi, lo) "
                      "operand pairs, fp32 accumulation and heads)"),
     "C3x": dict(net="ind", precision="bf16x3", rays=4096, S=64, M=0, nof="local",
-                what="C3 in the accuracy mode of the bf16 pipe (bf16x3: every matrix product of both networks as three bf16 "
-                     "products of (hi, lo) operand pairs, fp32 accumulation, heads and per-ray image-index bias)"),
+                what="C3 in the contract mode of the bf16 pipe (bf16x3: the NeRF's products as three bf16 products of (hi, lo) pairs, "
+                     "the NoFs' as six of (hi, mid, lo) triples, fp32 accumulation, heads and per-ray image-index bias: 1e-4 max-rel)"),
     "C5x": dict(net="ind", precision="bf16x3", rays=1024, S=64, M=128, nof="global", loss=True,
-                what="C5 in the accuracy mode of the bf16 pipe (bf16x3)"),
+                what="C5 in the contract mode of the bf16 pipe (bf16x3)"),
     "C3g": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="global",
                 what="C3 + global chain (5 NoF evaluations per sample), bf16 hidden GEMMs"),
     "C4": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="local", loss=True,
@@ -520,7 +530,7 @@ def run_config(name, a, ctx, steps, warmup, main):
     kernel_ms, launch_samples, probe_how = kernel_probe(M, rendering, torch, cfg, models, rays, bg, kw)
     flops_launch = launch_samples * flops_per_sample(cfg)
     achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
-    peak = PEAK[cfg["precision"]]
+    peak = peak_of(cfg)
     traffic, traffic_src = traffic_of(name)
     res = {
         "value": value, "ms_per_step": elapsed / steps * 1e3, "dtype": cfg["precision"],

@@ -161,11 +161,12 @@ struct Net {
   uint32_t emb_mask;       // trunk layers that consume the embedded input (layer 0 + skips)
   int aux;                 // NeRF: k-steps of the extra block (0, 1, 2); NoF: head rows (3 | 9)
 };
-// HS (MF_PREC_BF16X3): the layers' HIDDEN k-steps are (hi, lo) group pairs -- 0: none, 1: every layer
-template <int KH, int EKS, bool SPLIT, int HS = 0>
+// HS (MF_PREC_BF16X3): the layers' HIDDEN k-steps are split too -- 0: none, 1: every layer.  T: bf16 terms (= groups per
+// k-step) of a split range: 2 = (hi, lo), 3 = (hi, mid, lo) -- NetLayout::terms.
+template <int KH, int EKS, bool SPLIT, int HS = 0, int T = 2>
 MF_D int tgroups(const Net& n, int layer) {
   const bool hs = HS == 1;
-  return (((n.emb_mask >> layer) & 1) ? (SPLIT ? 2 : 1) * EKS : 0) + (layer > 0 ? (hs ? 2 : 1) * KH : 0);
+  return (((n.emb_mask >> layer) & 1) ? (SPLIT ? T : 1) * EKS : 0) + (layer > 0 ? (hs ? T : 1) * KH : 0);
 }
 
 // What follows the layer being computed in the panel program: its first panel (`groups`, at `jump` if the program
@@ -177,9 +178,9 @@ struct Next {
 };
 // PAIR (the fast mode's NoF, 128 wide: four tiles of 6-14 groups per layer): TWO tiles stream as one panel -- half the
 // barriers of a NoF evaluation, whose tiles are 8-14 MFMAs long.
-template <int KH, int EKS, bool SPLIT, int TPP = 1>
+template <int KH, int EKS, bool SPLIT, int TPP = 1, int T = 2>
 MF_D Next first_of(const Net& n) {       // layer 0: embedded input only, TPP tiles per panel
-  return Next{TPP * (SPLIT ? 2 : 1) * EKS, n.packed + n.res_bytes, TPP * (SPLIT ? 2 : 1) * EKS, nullptr};
+  return Next{TPP * (SPLIT ? T : 1) * EKS, n.packed + n.res_bytes, TPP * (SPLIT ? T : 1) * EKS, nullptr};
 }
 template <int KH, int EKS, bool SPLIT, int HS = 0, bool PAIR = false>
 MF_D Next next_trunk_bf(const Net& n, int layer) {
@@ -633,6 +634,25 @@ MF_D void split_operands(const float* emb, int n_slots, u32x4 (&xhi)[KS], u32x4 
   }
 }
 
+// fp32 slots -> three-term operands: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)   (24 mantissa bits)
+template <int KS>
+MF_D void split_operands3(const float* emb, int n_slots, u32x4 (&xhi)[KS], u32x4 (&xmid)[KS], u32x4 (&xlo)[KS]) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int e0 = 8 * ks + 2 * w, e1 = e0 + 1;
+      const float a = e0 < n_slots ? emb[e0] : 0.f, b = e1 < n_slots ? emb[e1] : 0.f;
+      const unsigned hi = pack_bf16x2(a, b);
+      const float ra = a - bflo(hi), rb = b - bfhi(hi);
+      const unsigned mid = pack_bf16x2(ra, rb);
+      xhi[ks][w] = hi;
+      xmid[ks][w] = mid;
+      xlo[ks][w] = pack_bf16x2(ra - bflo(mid), rb - bfhi(mid));
+    }
+  }
+}
+
 // fp32 slots -> plain bf16 operands (the NeRF's encodings)
 template <int KS>
 MF_D void pack_operands(const float* emb, int n_slots, u32x4 (&x)[KS]) {
@@ -646,9 +666,9 @@ MF_D void pack_operands(const float* emb, int n_slots, u32x4 (&x)[KS]) {
 }
 
 // ------------------------------------------------------------------ the two networks
-template <int KH, int EKS, bool SPLIT, int TPP = 1, class ST, class CR>
+template <int KH, int EKS, bool SPLIT, int TPP = 1, int T = 2, class ST, class CR>
 MF_D void start_program(const Net& n, ST& st, CR& carry, uint32_t ring, uint32_t buf_bytes, const Lane& id) {
-  st.start(n.packed + n.res_bytes, TPP * (SPLIT ? 2 : 1) * EKS, ring, buf_bytes, id);
+  st.start(n.packed + n.res_bytes, TPP * (SPLIT ? T : 1) * EKS, ring, buf_bytes, id);
   carry.load(st.slot_off(0) + id.lane * 16);
 }
 
@@ -790,6 +810,15 @@ MF_D void nof_embed(u32x4 (&xhi)[kKsNofXyz], u32x4 (&xlo)[kKsNofXyz], const floa
   emb_eval<3, 5, HW>(emb, xyz, par_xyz, h, pow2_xyz);
   split_operands<kKsNofXyz>(emb, B2Xyz5::SLOTS, xhi, xlo);
 }
+// the same as T-term operands (T = 2: xmid untouched)
+template <bool HW, int T>
+MF_D void nof_embed_t(u32x4 (&xhi)[kKsNofXyz], u32x4 (&xmid)[kKsNofXyz], u32x4 (&xlo)[kKsNofXyz], const float (&xyz)[3], uint32_t par_xyz,
+                      int h, bool pow2_xyz) {
+  float emb[B2Xyz5::SLOTS];
+  emb_eval<3, 5, HW>(emb, xyz, par_xyz, h, pow2_xyz);
+  if constexpr (T == 3) split_operands3<kKsNofXyz>(emb, B2Xyz5::SLOTS, xhi, xmid, xlo);
+  else split_operands<kKsNofXyz>(emb, B2Xyz5::SLOTS, xhi, xlo);
+}
 
 
 // ================================================================== MF_PREC_BF16X3 (the accuracy mode of the bf16 pipe)
@@ -846,11 +875,15 @@ MF_D f32x2 lds_f2(uint32_t byte_off) { return *(const f32x2*)(smem + byte_off); 
 // -> out1[u-4]  (C/D order: register 4q + i = row 8q + 4h + i of the tile).
 template <bool RELU, int OUTS, int NHEAD, int HSTRIDE>
 MF_D void epi_step(const f32x16& acc, int step, int h, u32x4& out0, u32x4& out1, u32x4& lo0, u32x4& lo1, uint32_t headw_off,
-                   float (&head)[NHEAD ? NHEAD : 1]) {
-  const int u = step >> 1, w = u & 3, r = u < 4 ? 2 * u : 8 + 2 * (u - 4);
+                   float (&head)[NHEAD ? NHEAD : 1], u32x4& mid0, u32x4& mid1) {
+  // OUTS == 3 (three-term operands, the NoF under MF_PREC_BF16X3): three steps per pair -- hi, mid = bf16(v - hi),
+  // lo = bf16(v - hi - mid) -- 24 in all; else two (hi, lo), 16 in all
+  constexpr int SPP = OUTS == 3 ? 3 : 2;
+  const int u = step / SPP, ph = step % SPP, w = u & 3, r = u < 4 ? 2 * u : 8 + 2 * (u - 4);
 #ifdef MF_BF_ABL_NOEPI                                        // (timing ablation, tools/ab_lib.sh: results are garbage)
-  if (OUTS > 0 && !(step & 1)) { if (u < 4) out0[w] = __builtin_bit_cast(unsigned, acc[r]); else out1[w] = __builtin_bit_cast(unsigned, acc[r]); }
-  if (OUTS == 2 && (step & 1)) { if (u < 4) lo0[w] = __builtin_bit_cast(unsigned, acc[r + 1]); else lo1[w] = __builtin_bit_cast(unsigned, acc[r + 1]); }
+  if (OUTS > 0 && ph == 0) { if (u < 4) out0[w] = __builtin_bit_cast(unsigned, acc[r]); else out1[w] = __builtin_bit_cast(unsigned, acc[r]); }
+  if (OUTS >= 2 && ph == 1) { if (u < 4) lo0[w] = __builtin_bit_cast(unsigned, acc[r + 1]); else lo1[w] = __builtin_bit_cast(unsigned, acc[r + 1]); }
+  if (OUTS == 3 && ph == 2) { if (u < 4) mid0[w] = __builtin_bit_cast(unsigned, acc[r + 1]); else mid1[w] = __builtin_bit_cast(unsigned, acc[r + 1]); }
   if (NHEAD > 0 && step == 0) for (int o = 0; o < NHEAD; ++o) head[o] += acc[o];
   return;
 #endif
@@ -859,7 +892,7 @@ MF_D void epi_step(const f32x16& acc, int step, int h, u32x4& out0, u32x4& out1,
   auto relu = [](float x) { const int b = __builtin_bit_cast(int, x); return __builtin_bit_cast(float, b > 0 ? b : 0); };
   const float v0 = RELU ? relu(acc[r]) : acc[r], v1 = RELU ? relu(acc[r + 1]) : acc[r + 1];
   u32x4& hv = u < 4 ? out0 : out1;
-  if (!(step & 1)) {
+  if (ph == 0) {
     if constexpr (NHEAD > 0) {                               // rows 8q + 4h + i: q = r / 4, i = r % 4
       const uint32_t so = headw_off + 16 * h + 32 * (r >> 2) + 4 * (r & 3);
 #pragma unroll
@@ -881,18 +914,49 @@ MF_D void epi_step(const f32x16& acc, int step, int h, u32x4& out0, u32x4& out1,
     unsigned lo = pack_bf16x2(v0 - bflo(hi), v1 - bfhi(hi));
     asm volatile("" : "+v"(lo));
     (u < 4 ? lo0 : lo1)[w] = lo;
+  } else if constexpr (OUTS == 3) {
+    const unsigned hi = hv[w];
+    const float r0 = v0 - bflo(hi), r1 = v1 - bfhi(hi);          // exact
+    if (ph == 1) {
+      unsigned mid = pack_bf16x2(r0, r1);
+      asm volatile("" : "+v"(mid));
+      (u < 4 ? mid0 : mid1)[w] = mid;
+    } else {
+      const unsigned mid = (u < 4 ? mid0 : mid1)[w];
+      unsigned lo = pack_bf16x2(r0 - bflo(mid), r1 - bfhi(mid));
+      asm volatile("" : "+v"(lo));
+      (u < 4 ? lo0 : lo1)[w] = lo;
+    }
   }
+}
+
+// extra MFMAs of group gi of a tile beyond its first one: a k-step of T terms is the groups W_0 .. W_{T-1} (hi, [mid,] lo), and
+// group W_t multiplies the operand terms x_0 .. x_{T-1-t} -- every product down to 2^(-8 (T-1)): T (T + 1) / 2 per k-step
+template <int T, int NEG, int NHG, int HMODE, bool EMB_FIRST>
+MF_D constexpr int x_extras(int gi) {
+  const int ge = EMB_FIRST ? gi : gi - NHG, gh = EMB_FIRST ? gi - NEG : gi;
+  if (ge >= 0 && ge < NEG) return T - 1 - ge % T;
+  if (HMODE == 2 && gh >= 0 && gh < NHG) return T - 1 - gh % T;
+  return 0;
+}
+template <int T, int NEG, int NHG, int HMODE, bool EMB_FIRST>
+MF_D constexpr int x_slots(int lo, int hi) {                 // groups of [lo, hi) with at least one extra MFMA
+  int n = 0;
+  for (int g = lo; g < hi; ++g) n += x_extras<T, NEG, NHG, HMODE, EMB_FIRST>(g) >= 1 ? 1 : 0;
+  return n;
 }
 
 // The matrix part of one output tile: acc = bias + W_tile [emb ; (hid, hidlo)] in three products per k-step.  `gap(m)`
 // runs behind the m-th MFMA (m = 0 .. NM-1): the caller's deferred work (the previous tile's epilogue steps).
 // KEEP: see StreamT::sync (the tile's FIRST panel barrier only).  LATE_FREE: no LDS-DMA pieces behind the last two (hi, lo)
 // group pairs of the tile's last panel -- the caller's dump stores go there, behind every piece of the panel.
-template <int NGE, int KHID, int HMODE, bool EMB_FIRST, int KEEP = 0, bool LATE_FREE = false, class ST, class Gap>
+template <int NGE, int KHID, int HMODE, bool EMB_FIRST, int KEEP = 0, bool LATE_FREE = false, int T = 2, class ST, class Gap>
 MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, const u32x4* hidlo, const u32x4* xhi, const u32x4* xlo,
-                     uint32_t bias_off, const Ahead& two, f32x16& acc, Gap&& gap, bool keep_ok = true) {
-  constexpr int NEG = 2 * NGE;
-  constexpr int NHG = (HMODE ? 2 : 1) * KHID;
+                     uint32_t bias_off, const Ahead& two, f32x16& acc, Gap&& gap, bool keep_ok = true,
+                     const u32x4* hidmid = nullptr, const u32x4* xmid = nullptr) {
+  static_assert(T == 2 || T == 3, "operand terms");
+  constexpr int NEG = T * NGE;
+  constexpr int NHG = (HMODE ? T : 1) * KHID;
   constexpr int NG = NEG + NHG;
   constexpr int NSEG = NG > 32 ? 2 : 1;
   constexpr int NG1 = NSEG == 2 ? (NG + 1) / 2 : NG;         // groups of the first panel (panel_cap)
@@ -923,9 +987,11 @@ MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, co
     const int s = gi % (PDX + 1);
     const int ge = EMB_FIRST ? gi : gi - NHG, gh = EMB_FIRST ? gi - NEG : gi;
     const bool emb = ge >= 0 && ge < NEG;
+    const bool split = emb || HMODE == 2;
+    const int ks = emb ? ge / T : (HMODE ? gh / T : gh);     // k-step of the group within its block
+    const int nx = x_extras<T, NEG, NHG, HMODE, EMB_FIRST>(gi);
     if (gi == NG1) st.advance();                             // second panel of the tile
-    if (emb) acc = MF_MFMA32(r[s], xhi[ge >> 1], acc);                      // even: Whi xhi ; odd: Wlo xhi
-    else acc = MF_MFMA32(r[s], hid[HMODE ? gh >> 1 : gh], acc);             // even: Whi ahi ; odd: Wlo ahi
+    acc = MF_MFMA32(r[s], (emb ? xhi : hid)[ks], acc);       // W_t x_0
     __builtin_amdgcn_sched_barrier(0);
     const int sp = (gi + PDX) % (PDX + 1), nb = gi + PDX;
     if (nb < NG) r[sp] = frag(nb);
@@ -939,21 +1005,27 @@ MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, co
     if (nb >= NG) r[sp] = frag(nb);
     gap(m++);
     __builtin_amdgcn_sched_barrier(0);
-    if ((emb && !(ge & 1)) || (!emb && HMODE == 2 && !(gh & 1))) {         // (the even groups: both blocks start at an even gi)
-      acc = MF_MFMA32(r[s], emb ? xlo[ge >> 1] : hidlo[gh >> 1], acc);       // Whi xlo / Whi alo
-      __builtin_amdgcn_sched_barrier(0);
-      // the pieces of the panel two ahead go behind these second MFMAs -- gaps that carry no fragment read (an LDS-DMA
-      // issued next to a ds_read_b128 costs the wave ~50 cycles, alone ~10) -- spread evenly over the panel
-      const int e0 = base + (base & 1), nall = (base + len - e0 + 1) / 2, j = (gi - e0) / 2;
-      const bool last_panel = base + len == NG;
-      const int nslots = (LATE_FREE && last_panel && nall > 2) ? nall - 2 : nall;
-      if (j < nslots) {
 #pragma unroll
-        for (int k = j * ST::kPieces / nslots; k < (j + 1) * ST::kPieces / nslots; ++k) st.piece(k, id);
+    for (int e = 1; e <= nx; ++e) {                          // W_t x_e: the lower-order products of this group
+      const u32x4* op = T == 3 ? (e == 1 ? (emb ? xmid : hidmid) : (emb ? xlo : hidlo)) : (emb ? xlo : hidlo);
+      acc = MF_MFMA32(r[s], op[ks], acc);
+      __builtin_amdgcn_sched_barrier(0);
+      if (e == 1) {
+        // the pieces of the panel two ahead go behind these second MFMAs -- gaps that carry no fragment read (an LDS-DMA
+        // issued next to a ds_read_b128 costs the wave ~50 cycles, alone ~10) -- spread evenly over the panel
+        const int nall = x_slots<T, NEG, NHG, HMODE, EMB_FIRST>(base, base + len);
+        const int j = x_slots<T, NEG, NHG, HMODE, EMB_FIRST>(base, gi);
+        const bool last_panel = base + len == NG;
+        const int nslots = (LATE_FREE && last_panel && nall > 2) ? nall - 2 : nall;
+        if (j < nslots) {
+#pragma unroll
+          for (int k = j * ST::kPieces / nslots; k < (j + 1) * ST::kPieces / nslots; ++k) st.piece(k, id);
+        }
       }
       gap(m++);
       __builtin_amdgcn_sched_barrier(0);
     }
+    (void)split;
   }
 #pragma unroll
   for (int i = 0; i < PDX; ++i) carry.w[i] = r[(NG + i) % (PDX + 1)];
@@ -961,22 +1033,26 @@ MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, co
 
 // the first two panels of a layer whose tiles are `g` groups long
 MF_D Next next_of_groups(int g) { return g > 32 ? Next{(g + 1) / 2, nullptr, g / 2, nullptr} : Next{g, nullptr, g, nullptr}; }
-template <int KH, int EKS>
-MF_D Next next_x(const Net& n, int layer) { return next_of_groups(tgroups<KH, EKS, true, 1>(n, layer)); }
+template <int KH, int EKS, int T = 2>
+MF_D Next next_x(const Net& n, int layer) { return next_of_groups(tgroups<KH, EKS, true, 1, T>(n, layer)); }
 
 // One layer of NT tiles with split operands: (out, outlo) <- act(W [emb ; (in, inlo)] + b), `nxt` = what follows it.
 // The epilogue of tile t runs in the MFMA gaps of tile t + 1 (a wave alone on its SIMD has nobody to cover it); only the
 // last tile's stands alone.
-template <int NT, int NGE, int KHID, int HMODE, bool EMB_FIRST, bool RELU, int OUTS, int NHEAD, int HSTRIDE, class DT, class ST, int KI, int KO>
+// T = 3 (OUTS = 3): three-term operands -- `inmid` / `outmid` / `xmid` are the middle terms (unused with T = 2).
+template <int NT, int NGE, int KHID, int HMODE, bool EMB_FIRST, bool RELU, int OUTS, int NHEAD, int HSTRIDE, int T = 2, class DT, class ST, int KI, int KO>
 MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], const u32x4 (&inlo)[KI], u32x4 (&out)[KO],
                   u32x4 (&outlo)[KO], const u32x4* xhi, const u32x4* xlo, uint32_t bias_off, const Next& nxt, uint32_t headw_off,
-                  float (&head)[NHEAD ? NHEAD : 1], const DT& dump) {
+                  float (&head)[NHEAD ? NHEAD : 1], const DT& dump, const u32x4* inmid = nullptr, u32x4* outmid = nullptr,
+                  const u32x4* xmid = nullptr) {
   constexpr bool DUMP = __is_same(DT, RowDump);
-  constexpr int NG = 2 * NGE + (HMODE ? 2 : 1) * KHID;
+  static_assert(OUTS != 3 || T == 3, "three-term outputs feed three-term layers");
+  constexpr int NG = T * NGE + (HMODE ? T : 1) * KHID;
   constexpr int NSEG = NG > 32 ? 2 : 1;
   constexpr int NG1 = NSEG == 2 ? (NG + 1) / 2 : NG;
-  constexpr int NM = 3 * NGE + (HMODE == 2 ? 3 : 2) * KHID / (HMODE ? 1 : 2);      // MFMAs of a tile
-  constexpr int kSteps = 16;
+  constexpr int PK = T * (T + 1) / 2;                        // products per split k-step
+  constexpr int NM = PK * NGE + (HMODE == 2 ? PK * KHID : KHID);      // MFMAs of a tile
+  constexpr int kSteps = OUTS == 3 ? 24 : 16;
   static_assert(!DUMP || NM >= 8, "dump stores need four piece-free MFMA gaps");
   f32x16 pend = {};
   // DUMP: the pending tile's four row stores go into the LAST four MFMA gaps of the next tile, behind that tile's last
@@ -984,6 +1060,12 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
   // barriers: the first of tile t >= 2 (tile t - 1 carried tile t - 2's stores) and the first of tile 0 (the layer in
   // front ended with its last tile's stores; a lower bound where other VM traffic sits in between).  Tile 1's waits for
   // everything: tile 0 carries no stores.
+  auto epi = [&](const f32x16& a, int sidx, int tile) __attribute__((always_inline)) {
+    u32x4* om = OUTS == 3 ? outmid : &outlo[0];              // (placeholders where a term does not exist)
+    epi_step<RELU, OUTS, NHEAD, HSTRIDE>(a, sidx, id.h, out[OUTS ? 2 * tile : 0], out[OUTS ? 2 * tile + 1 : 1], outlo[OUTS >= 2 ? 2 * tile : 0],
+                                         outlo[OUTS >= 2 ? 2 * tile + 1 : 1], headw_off + 32 * tile * 4, head,
+                                         om[OUTS == 3 ? 2 * tile : 0], om[OUTS == 3 ? 2 * tile + 1 : 1]);
+  };
   auto run = [&](auto tc) __attribute__((always_inline)) {
     constexpr int t = decltype(tc)::value;
     Ahead two;
@@ -998,21 +1080,18 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
 #ifndef MF_BF_X3_NODEFER
       if (t == 0) return;
 #pragma unroll
-      for (int sidx = kSteps * m / NM; sidx < kSteps * (m + 1) / NM; ++sidx)
-        epi_step<RELU, OUTS, NHEAD, HSTRIDE>(pend, sidx, id.h, out[OUTS ? 2 * tp : 0], out[OUTS ? 2 * tp + 1 : 1], outlo[OUTS == 2 ? 2 * tp : 0],
-                                             outlo[OUTS == 2 ? 2 * tp + 1 : 1], headw_off + 32 * tp * 4, head);
+      for (int sidx = kSteps * m / NM; sidx < kSteps * (m + 1) / NM; ++sidx) epi(pend, sidx, tp);
       if (DUMP && m >= NM - 4) dump_store<RELU>(dump, pend, tp, m - (NM - 4));
 #endif
     };
     f32x16 acc;
     constexpr int KEEP = (DUMP && t != 1) ? 4 : 0;
-    mma_tile_x<NGE, KHID, HMODE, EMB_FIRST, KEEP, DUMP>(st, id, carry, in, inlo, xhi, xlo, bias_off + 32 * t * 4, two, acc, gap, dump_wave_on(dump));
+    mma_tile_x<NGE, KHID, HMODE, EMB_FIRST, KEEP, DUMP, T>(st, id, carry, in, inlo, xhi, xlo, bias_off + 32 * t * 4, two, acc, gap,
+                                                          dump_wave_on(dump), inmid, xmid);
     st.advance();
 #ifdef MF_BF_X3_NODEFER
 #pragma unroll
-    for (int sidx = 0; sidx < kSteps; ++sidx)
-      epi_step<RELU, OUTS, NHEAD, HSTRIDE>(acc, sidx, id.h, out[OUTS ? 2 * t : 0], out[OUTS ? 2 * t + 1 : 1], outlo[OUTS == 2 ? 2 * t : 0],
-                                           outlo[OUTS == 2 ? 2 * t + 1 : 1], headw_off + 32 * t * 4, head);
+    for (int sidx = 0; sidx < kSteps; ++sidx) epi(acc, sidx, t);
     __builtin_amdgcn_sched_barrier(0);
 #endif
     pend = acc;
@@ -1026,10 +1105,7 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
   }
 #ifndef MF_BF_X3_NODEFER
 #pragma unroll
-  for (int sidx = 0; sidx < kSteps; ++sidx)
-    epi_step<RELU, OUTS, NHEAD, HSTRIDE>(pend, sidx, id.h, out[OUTS ? 2 * (NT - 1) : 0], out[OUTS ? 2 * (NT - 1) + 1 : 1],
-                                         outlo[OUTS == 2 ? 2 * (NT - 1) : 0], outlo[OUTS == 2 ? 2 * (NT - 1) + 1 : 1],
-                                         headw_off + 32 * (NT - 1) * 4, head);
+  for (int sidx = 0; sidx < kSteps; ++sidx) epi(pend, sidx, NT - 1);
   if constexpr (DUMP) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) dump_store<RELU>(dump, pend, NT - 1, q);
@@ -1039,23 +1115,23 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
 }
 
 // One trunk layer: MODE as trunk_layer_m (1 embedded input only, 2 hidden only, 3 both, embedded input first).
-template <int KH, int NGE, int MODE, bool RELU, int NHEAD, class RBT, class ST, class DT = NoDump>
+template <int KH, int NGE, int MODE, bool RELU, int NHEAD, int T = 2, class RBT, class ST, class DT = NoDump>
 MF_D void trunk_layer_x(const Net& net, int layer, const u32x4 (&in)[KH], const u32x4 (&inlo)[KH], u32x4 (&out)[KH],
                         u32x4 (&outlo)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE], ST& st, CarryX& carry,
                         const Lane& id, const Next& nxt, const RBT& rb, uint32_t headw_off, float (&head)[NHEAD ? NHEAD : 1],
-                        const DT& dump = DT{}) {
+                        const DT& dump = DT{}, const u32x4* inmid = nullptr, u32x4* outmid = nullptr, const u32x4* xmid = nullptr) {
   uint32_t bias_off = net.res_lds + layer * (16 * KH) * 4;
   if constexpr (__is_same(RBT, LdsRayBias) && (MODE & 1))
     bias_off = rb.lane_off + (uint32_t)__builtin_popcount(net.emb_mask & ((1u << layer) - 1u)) * (16 * KH) * 4;
-  layer_x<KH / 2, (MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, 2, true, RELU, 2, NHEAD, 0>(
-      st, id, carry, in, inlo, out, outlo, xhi, xlo, bias_off, nxt, headw_off, head, dump);
+  layer_x<KH / 2, (MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, 2, true, RELU, T, NHEAD, 0, T>(
+      st, id, carry, in, inlo, out, outlo, xhi, xlo, bias_off, nxt, headw_off, head, dump, inmid, outmid, xmid);
 }
 
-// NoF head with split activations and weights: groups (Whi, Wlo) per k-step, three products.
-template <int KHID, class ST>
+// NoF head with split activations and weights: T groups per k-step (Whi, [Wmid,] Wlo), T (T + 1) / 2 products.
+template <int KHID, int T = 2, class ST>
 MF_D f32x16 head_tile_x3(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, const u32x4* hidlo, uint32_t bias_off, int g2,
-                         const char* j2) {
-  constexpr int NG = 2 * KHID;
+                         const char* j2, const u32x4* hidmid = nullptr) {
+  constexpr int NG = T * KHID;
   const int h = id.h;
   const uint32_t p = st.off0 + id.lane * 16, pn = st.off1 + id.lane * 16;
   f32x16 acc;
@@ -1071,7 +1147,7 @@ MF_D f32x16 head_tile_x3(ST& st, const Lane& id, CarryX& carry, const u32x4* hid
 #pragma unroll
   for (int gi = 0; gi < NG; ++gi) {
     const int s = gi % (PDX + 1);
-    acc = MF_MFMA32(r[s], hid[gi >> 1], acc);
+    acc = MF_MFMA32(r[s], hid[gi / T], acc);
     __builtin_amdgcn_sched_barrier(0);
     const int sp = (gi + PDX) % (PDX + 1), nb = gi + PDX;
     if (nb < NG) r[sp] = lds_u4(p + nb * kGroupBytes);
@@ -1079,8 +1155,9 @@ MF_D f32x16 head_tile_x3(ST& st, const Lane& id, CarryX& carry, const u32x4* hid
     if (gi >= 1 && gi <= ST::kPieces) st.piece(gi - 1, id);
     if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
     __builtin_amdgcn_sched_barrier(0);
-    if (!(gi & 1)) {
-      acc = MF_MFMA32(r[s], hidlo[gi >> 1], acc);
+#pragma unroll
+    for (int e = 1; e <= T - 1 - gi % T; ++e) {
+      acc = MF_MFMA32(r[s], (T == 3 && e == 1 ? hidmid : hidlo)[gi / T], acc);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -1089,49 +1166,53 @@ MF_D f32x16 head_tile_x3(ST& st, const Lane& id, CarryX& carry, const u32x4* hid
   return acc;
 }
 
-template <class RBT, class AfterFirst, class ST>
-MF_D void nof_eval_x3(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&xlo)[kKsNofXyz], const float (&xyz)[3],
-                      ST& st, CarryX& carry, const Lane& id, const Next& follow, float (&out)[3], const RBT& rb,
+// T = kNofTermsX3 terms per operand: with T = 3 every product of the NoF carries 24 mantissa bits -- its output point feeds
+// sin(512 x) of the canonical encoding, where the 2^-17 of a two-term split is ~1e-4 of the rendered ray (oracle/bf16_ref.py,
+// tools/bf16_explore.py: C3 on the dense draw 1.5e-4 max-rel with two terms, 1.4e-5 with three = the exact-fp32 NoF's)
+template <int T = 2, class RBT, class AfterFirst, class ST>
+MF_D void nof_eval_x3(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&xmid)[kKsNofXyz], const u32x4 (&xlo)[kKsNofXyz],
+                      const float (&xyz)[3], ST& st, CarryX& carry, const Lane& id, const Next& follow, float (&out)[3], const RBT& rb,
                       AfterFirst&& after_first) {
-  u32x4 ah[8], al[8], bh[8], bl[8];
+  u32x4 ah[8], am[T == 3 ? 8 : 1], al[8], bh[8], bm[T == 3 ? 8 : 1], bl[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t)
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { ah[t][i] = 0; al[t][i] = 0; }
+    for (int i = 0; i < 4; ++i) { ah[t][i] = 0; al[t][i] = 0; if (T == 3) am[T == 3 ? t : 0][i] = 0; }
   const int D = net.D;
-  const Next hd{16, nullptr, follow.groups, follow.jump};
+  const Next hd{T * 8, nullptr, follow.groups, follow.jump};
   float nohead[1] = {0.f};
-  auto one = [&](int layer, const u32x4 (&ih)[8], const u32x4 (&il)[8], u32x4 (&oh)[8], u32x4 (&ol)[8]) __attribute__((always_inline)) {
-    const Next nxt = layer == D - 1 ? hd : next_x<8, kKsNofXyz>(net, layer + 1);
+  auto one = [&](int layer, const u32x4 (&ih)[8], const u32x4* im, const u32x4 (&il)[8], u32x4 (&oh)[8], u32x4* om, u32x4 (&ol)[8]) __attribute__((always_inline)) {
+    const Next nxt = layer == D - 1 ? hd : next_x<8, kKsNofXyz, T>(net, layer + 1);
     const int has_emb = (net.emb_mask >> layer) & 1;
-    if (layer == 0) trunk_layer_x<8, kKsNofXyz, 1, true, 0>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead);
-    else if (has_emb) trunk_layer_x<8, kKsNofXyz, 3, true, 0>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead);
-    else trunk_layer_x<8, kKsNofXyz, 2, true, 0>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead);
+    const NoDump nd{};
+    if (layer == 0) trunk_layer_x<8, kKsNofXyz, 1, true, 0, T>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead, nd, im, om, xmid);
+    else if (has_emb) trunk_layer_x<8, kKsNofXyz, 3, true, 0, T>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead, nd, im, om, xmid);
+    else trunk_layer_x<8, kKsNofXyz, 2, true, 0, T>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead, nd, im, om, xmid);
   };
   int l = 0;
   for (; l + 1 < D; l += 2) {
-    one(l, ah, al, bh, bl);
+    one(l, ah, am, al, bh, bm, bl);
     if (l == 0) after_first();
-    one(l + 1, bh, bl, ah, al);
+    one(l + 1, bh, bm, bl, ah, am, al);
   }
   if (l < D) {
-    one(l, ah, al, bh, bl);
+    one(l, ah, am, al, bh, bm, bl);
     if (l == 0) after_first();
 #pragma unroll
-    for (int t = 0; t < 8; ++t) { ah[t] = bh[t]; al[t] = bl[t]; }
+    for (int t = 0; t < 8; ++t) { ah[t] = bh[t]; al[t] = bl[t]; if (T == 3) am[T == 3 ? t : 0] = bm[T == 3 ? t : 0]; }
   }
   // the head panel; the panel two ahead of it = the SECOND panel of whatever follows
-  f32x16 acc = head_tile_x3<8>(st, id, carry, ah, al, net.res_lds + (D + net.aux) * 128 * 4, follow.groups2, follow.jump2);
+  f32x16 acc = head_tile_x3<8, T>(st, id, carry, ah, al, net.res_lds + (D + net.aux) * 128 * 4, follow.groups2, follow.jump2, am);
   st.advance();
   float own[5], oth[5];
 #pragma unroll
   for (int i = 0; i < 5; ++i) { own[i] = acc[i]; oth[i] = __shfl_xor(acc[i], 32, 64); }
   if (net.aux == 9) {
-    float T[9];
+    float T9[9];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) { T[i] = id.h ? oth[i] : own[i]; T[4 + i] = id.h ? own[i] : oth[i]; }
-    T[8] = id.h ? oth[4] : own[4];
-    quat_transform(T, xyz, out);
+    for (int i = 0; i < 4; ++i) { T9[i] = id.h ? oth[i] : own[i]; T9[4 + i] = id.h ? own[i] : oth[i]; }
+    T9[8] = id.h ? oth[4] : own[4];
+    quat_transform(T9, xyz, out);
   } else {
 #pragma unroll
     for (int c = 0; c < 3; ++c) out[c] = (id.h ? oth[c] : own[c]) + xyz[c];

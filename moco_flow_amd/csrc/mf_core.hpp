@@ -95,7 +95,10 @@ MF_HD int emb_feature(int kind, int g, int e, int xyz_cols) {
     case kEmbNerfXyz:
       return e < BlkXyz10::SLOTS ? BlkXyz10::feature(g, e) : -1;
     case kEmbNofIn:
-      if (e < BlkXyz5::SLOTS) return BlkXyz5::feature(g, e);
+      if (e < BlkXyz5::SLOTS) {            // (a NoF narrower than 33 xyz columns: the block's upper features have no column --
+        const int f = BlkXyz5::feature(g, e);      // the index block starts at xyz_cols)
+        return f < xyz_cols ? f : -1;
+      }
       if (e < BlkXyz5::SLOTS + BlkInd16::SLOTS) {
         const int f = BlkInd16::feature(g, e - BlkXyz5::SLOTS);
         return f < 0 ? -1 : xyz_cols + f;
@@ -149,8 +152,10 @@ MF_HD int emb_feature2(int kind, int h, int e, int xyz_cols) {
   switch (kind) {
     case kEmbNerfXyz:
       return e < B2Xyz10::SLOTS ? B2Xyz10::feature(h, e) : -1;
-    case kEmbNofIn:      // xyz block only: the image-index block is a per-ray bias (kKsNofXyz)
-      return e < B2Xyz5::SLOTS ? B2Xyz5::feature(h, e) : -1;
+    case kEmbNofIn: {    // xyz block only: the image-index block is a per-ray bias (kKsNofXyz)
+      const int f = e < B2Xyz5::SLOTS ? B2Xyz5::feature(h, e) : -1;
+      return f < xyz_cols ? f : -1;
+    }
     case kEmbDir:
       return e < B2Dir4::SLOTS ? B2Dir4::feature(h, e) : -1;
     case kEmbInd:
@@ -192,6 +197,9 @@ struct NetLayout {
                            // activations and weights split) -- every layer of both networks; bit n_trunk = the NeRF's
                            // extra_encoding
   int max_groups;          // largest panel, in groups (x3: tiles of more than 32 groups stream as two panels, panel_cap)
+  int terms;               // bf16 terms of every SPLIT range of this network: 2 = (hi, lo), three products per k-step; 3 = (hi,
+                           // mid, lo), six products down to 2^-24 -- the NoF under MF_PREC_BF16X3 (kNofTermsX3): its output point
+                           // feeds sin(512 x) of the canonical encoding and needs fp32-class accuracy
   // resident block float offsets
   int off_bias_trunk;      // n_trunk * W
   int off_bias_extra;      // W/2
@@ -212,21 +220,27 @@ MF_HD int trunk_batches(const NetLayout& L, int layer) {
   return (((L.emb_mask >> layer) & 1) ? L.emb_steps / 4 : 0) + (layer > 0 ? hidden_batches(L) : 0);
 }
 MF_HD int trunk_groups(const NetLayout& L, int layer) {
-  if (L.bf16) return (((L.emb_mask >> layer) & 1) ? (L.emb_split ? 2 : 1) * L.emb_steps : 0) +
-                     (layer > 0 ? (((L.hsplit_mask >> layer) & 1) ? 2 : 1) * L.NK : 0);
+  if (L.bf16) return (((L.emb_mask >> layer) & 1) ? (L.emb_split ? L.terms : 1) * L.emb_steps : 0) +
+                     (layer > 0 ? (((L.hsplit_mask >> layer) & 1) ? L.terms : 1) * L.NK : 0);
   return 2 * trunk_batches(L, layer);
 }
 // bf16 NoF: the 3|9-row head (nof.py:75-82) as one more panel behind the trunk: a 32-row tile (rows >= n_head zero)
-// whose hidden k-steps are split (hi, lo) group pairs -- the head's weights keep 16 mantissa bits.
-MF_HD int head_groups(const NetLayout& L) { return 2 * L.NK; }
+// whose hidden k-steps are split (hi, lo) group pairs -- the head's weights keep 16 mantissa bits (x3: `terms` groups).
+MF_HD int head_groups(const NetLayout& L) { return L.terms * L.NK; }
 MF_HD int extra_groups(const NetLayout& L) {
-  if (L.bf16) return (((L.hsplit_mask >> L.n_trunk) & 1) ? 2 : 1) * L.NK + (L.emb_split ? 2 : 1) * L.extra_steps;
+  if (L.bf16) return (((L.hsplit_mask >> L.n_trunk) & 1) ? L.terms : 1) * L.NK + (L.emb_split ? L.terms : 1) * L.extra_steps;
   return 2 * (hidden_batches(L) + L.extra_steps / 4);
 }
 
 // MF_PREC_BF16X3: a tile's groups stream as ONE panel up to 32 groups, as two halves beyond (the 3-slot LDS ring holds
 // 32 KiB slots; the groups of a tile are contiguous in the packed buffer, so a panel boundary is only a barrier position)
 MF_HD int panel_cap(int groups) { return groups > 32 ? (groups + 1) / 2 : groups; }
+
+// bf16 terms of the NoF's operands under MF_PREC_BF16X3 (NetLayout::terms; host layout, packer and kernels agree on it)
+#ifndef MF_X3_NOF_TERMS
+#define MF_X3_NOF_TERMS 3            // (A/B: 2 = round 3's two-term NoF, three products)
+#endif
+constexpr int kNofTermsX3 = MF_X3_NOF_TERMS;
 
 // ------------------------------------------------------------------ device helpers
 extern __shared__ __attribute__((aligned(16))) char smem[];

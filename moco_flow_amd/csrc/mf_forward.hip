@@ -80,7 +80,7 @@ __global__ __launch_bounds__(kThreads, 2) void nerf_forward_kernel(NerfFwdParams
     for (int e = 0; e < kStepsNerfXyz; ++e) {
       const int f = sel4(id.g, emb_feature(kEmbNerfXyz, 0, e, 0), emb_feature(kEmbNerfXyz, 1, e, 0),
                          emb_feature(kEmbNerfXyz, 2, e, 0), emb_feature(kEmbNerfXyz, 3, e, 0));
-      embx[e] = f >= 0 ? row[f] : 0.f;
+      embx[e] = (f >= 0 && f < p.xyz_cols) ? row[f] : 0.f;      // (features beyond in_channels_xyz have no input column)
     }
 #pragma unroll
     for (int e = 0; e < kStepsExtraMax; ++e) {
@@ -120,6 +120,7 @@ struct NofFwdParams {
   const float* xyz;
   float* out;
   uint32_t ring_off, buf_bytes;
+  int xyz_cols, in_cols;     // in_channels_xyz, in_channels_xyz + extra_feat_dim: the columns an input row has
 };
 
 __global__ __launch_bounds__(kThreads, 2) void nof_forward_kernel(NofFwdParams p) {
@@ -142,9 +143,9 @@ __global__ __launch_bounds__(kThreads, 2) void nof_forward_kernel(NofFwdParams p
     float emb[kStepsNofIn];
 #pragma unroll
     for (int e = 0; e < kStepsNofIn; ++e) {
-      const int f = sel4(id.g, emb_feature(kEmbNofIn, 0, e, 33), emb_feature(kEmbNofIn, 1, e, 33),
-                         emb_feature(kEmbNofIn, 2, e, 33), emb_feature(kEmbNofIn, 3, e, 33));
-      emb[e] = f >= 0 ? row[f] : 0.f;
+      const int f = sel4(id.g, emb_feature(kEmbNofIn, 0, e, p.xyz_cols), emb_feature(kEmbNofIn, 1, e, p.xyz_cols),
+                         emb_feature(kEmbNofIn, 2, e, p.xyz_cols), emb_feature(kEmbNofIn, 3, e, p.xyz_cols));
+      emb[e] = (f >= 0 && f < p.in_cols) ? row[f] : 0.f;
     }
     const float xyz[3] = {p.xyz[bb * 3 + 0], p.xyz[bb * 3 + 1], p.xyz[bb * 3 + 2]};
     float o[3];
@@ -309,6 +310,7 @@ extern "C" int32_t mf_nof_forward(const mf_nof_desc* d, const void* packed, cons
   p.net.packed = static_cast<const char*>(packed);
   p.net.res_lds = 0;
   p.in = inputs; p.in_stride = in_stride; p.B = B; p.xyz = xyz; p.out = out;
+  p.xyz_cols = d->in_channels_xyz; p.in_cols = d->in_channels_xyz + d->extra_feat_dim;
   p.ring_off = (uint32_t)p.net.L.res_bytes;
   p.buf_bytes = (uint32_t)p.net.L.max_groups * kGroupBytes;
   const size_t lds = p.ring_off + 3 * (size_t)p.buf_bytes;

@@ -15,7 +15,11 @@ inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L, int bf16 = 0) {
   L.bf16 = bf16 ? 1 : 0;
   if (d.W != 256 && d.W != 128) return false;
   if (d.D < 2 || d.D + 1 > MF_MAX_LAYERS) return false;
-  if (d.in_channels_xyz != 63) return false;          // 3*(2*10+1); see DESIGN.md "envelope"
+  // the embedded xyz block has slots for 3 channels x <= 10 frequencies = 63 features; a narrower in_channels_xyz (the
+  // reference's default is 33, models/nerf.py:6-12) leaves the upper features without a weight column (packed as zeros), a
+  // 64th column only ever sees the reference's zero padding (rendering.py:127-129)
+  if (d.in_channels_xyz < 3 || d.in_channels_xyz > 64) return false;
+  if (d.extra_feat_type != MF_EXTRA_NONE && (d.extra_feat_dim < 1 || d.extra_feat_dim > 32)) return false;
   if (d.skip_mask & 1u) return false;                 // layer 0 already takes the input
   if (d.skip_mask >> d.D) return false;
   L.W = d.W;
@@ -26,6 +30,7 @@ inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L, int bf16 = 0) {
   L.emb_steps = bf16 ? kKsNerfXyz : kStepsNerfXyz;     // bf16: 16-slot k-steps (mf_bf16.hpp); fp32: 4-k MFMA steps
   L.emb_split = x3 ? 1 : 0;                            // bf16: the NeRF's encodings are plain bf16 operands (mf_bf16.hpp); x3: split
   L.hsplit_mask = x3 ? ((1u << (d.D + 2)) - 1u) & ~1u : 0u;   // x3: every hidden range (trunk, final, extra_encoding) as (hi, lo) pairs
+  L.terms = 2;
   L.emb_mask = 1u | d.skip_mask;
   L.relu_mask = (1u << d.D) - 1u;
   switch (d.extra_feat_type) {
@@ -63,7 +68,9 @@ inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0) {
   L.bf16 = bf16 ? 1 : 0;
   if (d.W != 128) return false;
   if (d.D < 2 || d.D > MF_MAX_LAYERS) return false;
-  if (d.in_channels_xyz != 33 || d.extra_feat_dim != 33) return false;   // 3*(2*5+1), 1*(2*16+1)
+  // slots for 3 x <= 5 xyz frequencies (33 features) and 1 x <= 16 index frequencies (33); narrower blocks leave the upper
+  // features without a column (models/nof.py:7-15: in_channels_xyz = 33, extra_feat_dim = 0 by default)
+  if (d.in_channels_xyz < 3 || d.in_channels_xyz > 33 || d.extra_feat_dim < 0 || d.extra_feat_dim > 33) return false;
   if ((d.skip_mask & 1u) || (d.skip_mask >> d.D)) return false;
   L.W = d.W;
   L.NK = d.W / 16;
@@ -71,7 +78,8 @@ inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0) {
   L.n_trunk = d.D;
   L.emb_steps = bf16 ? kKsNofXyz : kStepsNofIn;         // bf16: xyz block only, the image-index block is a per-ray bias
   L.emb_split = bf16 ? 1 : 0;                          // bf16: the NoF's embedded input keeps 16 mantissa bits
-  L.hsplit_mask = x3 ? ((1u << d.D) - 1u) & ~1u : 0u;  // x3: every hidden range as (hi, lo) pairs, three products
+  L.hsplit_mask = x3 ? ((1u << d.D) - 1u) & ~1u : 0u;  // x3: every hidden range split too
+  L.terms = x3 ? kNofTermsX3 : 2;                      // x3: (hi, mid, lo) terms, six products per k-step (mf_bf16.hpp)
   L.emb_mask = 1u | d.skip_mask;
   L.relu_mask = (1u << d.D) - 1u;
   L.extra_steps = -1;
@@ -86,9 +94,9 @@ inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0) {
   for (int l = 0; l < L.n_trunk; ++l) {
     const int g = trunk_groups(L, l);
     groups += (int64_t)g * L.NP;
-    if (g > L.max_groups) L.max_groups = g;
+    if ((x3 ? panel_cap(g) : g) > L.max_groups) L.max_groups = x3 ? panel_cap(g) : g;
   }
-  if (bf16) {                                          // head panel: one 32-row tile, hidden k-steps as (hi, lo) group pairs
+  if (bf16) {                                          // head panel: one 32-row tile, hidden k-steps as (hi, lo[, ...]) groups
     groups += head_groups(L);
     if (head_groups(L) > L.max_groups) L.max_groups = head_groups(L);
   }

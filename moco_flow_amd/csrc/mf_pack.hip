@@ -27,8 +27,8 @@ struct PackRegion {          // one trunk/extra layer's panels
   int hid_col0;              // column of hidden feature 0 in W
   int xyz_cols;
   int n_rows;                // rows present in W (bf16 head panel: 3|9 of its 32; 0 = all)
-  int hid_split;             // bf16: hidden k-step ks is TWO groups (hi, lo) instead of one
-  int emb_split;             // bf16: embedded k-step ks is TWO groups (hi, lo) instead of one
+  int hid_split;             // bf16: groups per hidden k-step ks: 1 = plain, 2 = (hi, lo), 3 = (hi, mid, lo)
+  int emb_split;             // bf16: groups per embedded k-step, likewise
   long long dst_group0;      // first group index (in 1 KiB units) within the panel area
 };
 
@@ -60,32 +60,35 @@ __global__ void pack_panels_kernel(PackJob job) {
   if (R.bf16) {
     // bf16 layout (mf_bf16.hpp): panel = ONE 32-row tile, group = A fragment of v_mfma_f32_32x32x16_bf16:
     // lane (i = lane&31, h = lane>>5) holds 8 bf16 = W[32P + i][col(k-step, slot 8h + e)], e = 0..7.
-    // Embedded k-step ks is one group, or two with emb_split (hi = bf16(w), lo = bf16(w - hi)); hidden k-step ks covers features
-    // 16 ks + hid_perm2(h, e).
+    // Embedded k-step ks is emb_split groups (1: bf16(w); 2: + lo = bf16(w - hi); 3: hi, mid, lo); hidden k-step ks covers
+    // features 16 ks + hid_perm2(h, e), hid_split groups likewise.
     const int i = lane & 31, h = lane >> 5;
     const float* row = R.W + (long long)(32 * P + i) * R.n_in;
-    const int eg = (R.emb_split ? 2 : 1) * R.emb_steps;      // groups of the embedded block
-    const int hg = (R.hid_split ? 2 : 1) * R.hid_batches;    // groups of the hidden block
+    const int eg = R.emb_split * R.emb_steps;                // groups of the embedded block
+    const int hg = R.hid_split * R.hid_batches;              // groups of the hidden block
     const int ge = R.emb_first ? gi : gi - hg;
     const int gh = R.emb_first ? gi - eg : gi;
     unsigned short h8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    // term t of a weight: t = 0: bf16(w); 1: bf16(w - hi); 2: bf16(w - hi - mid)   (exact fp32 subtractions)
+    auto term = [](float w, int t) {
+      unsigned short b = bf16_rne(w);
+      for (int k = 0; k < t; ++k) {
+        w -= __uint_as_float((unsigned)b << 16);
+        b = bf16_rne(w);
+      }
+      return b;
+    };
     if (R.n_rows && 32 * P + i >= R.n_rows) {
       // zero row of a partial tile
     } else if (ge >= 0 && ge < eg) {
-      const int ks = R.emb_split ? ge >> 1 : ge, lo = R.emb_split ? ge & 1 : 0;
+      const int ks = ge / R.emb_split, t = ge % R.emb_split;
       for (int e = 0; e < 8; ++e) {
         const int f = emb_feature2(R.emb_kind, h, 8 * ks + e, R.xyz_cols);
-        const float w = (f >= 0 && f < R.emb_cols) ? row[R.emb_col0 + f] : 0.f;
-        const unsigned short hi = bf16_rne(w);
-        h8[e] = lo ? bf16_rne(w - __uint_as_float((unsigned)hi << 16)) : hi;
+        h8[e] = term((f >= 0 && f < R.emb_cols) ? row[R.emb_col0 + f] : 0.f, t);
       }
     } else if (gh >= 0 && gh < hg) {
-      const int ks = R.hid_split ? gh >> 1 : gh, lo = R.hid_split ? gh & 1 : 0;
-      for (int e = 0; e < 8; ++e) {
-        const float w = row[R.hid_col0 + 16 * ks + hid_perm2(h, e)];
-        const unsigned short hi = bf16_rne(w);
-        h8[e] = lo ? bf16_rne(w - __uint_as_float((unsigned)hi << 16)) : hi;
-      }
+      const int ks = gh / R.hid_split, t = gh % R.hid_split;
+      for (int e = 0; e < 8; ++e) h8[e] = term(row[R.hid_col0 + 16 * ks + hid_perm2(h, e)], t);
     }
     unsigned* pu = reinterpret_cast<unsigned*>(&v.x);
     for (int w = 0; w < 4; ++w) pu[w] = (unsigned)h8[2 * w] | ((unsigned)h8[2 * w + 1] << 16);
@@ -188,8 +191,8 @@ extern "C" int32_t mf_nerf_pack_p(const mf_nerf_desc* d, int32_t precision, void
     R.hid_steps = l > 0 ? L.NK * 4 : 0;
     R.hid_batches = l > 0 ? hidden_batches(L) : 0;
     R.bf16 = L.bf16;
-    R.emb_split = L.emb_split;
-    R.hid_split = (L.hsplit_mask >> l) & 1;
+    R.emb_split = L.emb_split ? L.terms : 1;
+    R.hid_split = ((L.hsplit_mask >> l) & 1) ? L.terms : 1;
     R.hid_col0 = has_emb ? d->in_channels_xyz : 0;
     R.xyz_cols = d->in_channels_xyz;
     R.dst_group0 = g0;
@@ -213,8 +216,8 @@ extern "C" int32_t mf_nerf_pack_p(const mf_nerf_desc* d, int32_t precision, void
     R.hid_steps = L.NK * 4;
     R.hid_batches = hidden_batches(L);
     R.bf16 = L.bf16;
-    R.emb_split = L.emb_split;
-    R.hid_split = (L.hsplit_mask >> L.n_trunk) & 1;
+    R.emb_split = L.emb_split ? L.terms : 1;
+    R.hid_split = ((L.hsplit_mask >> L.n_trunk) & 1) ? L.terms : 1;
     R.hid_col0 = 0;
     R.xyz_cols = 0;
     R.dst_group0 = g0;
@@ -264,8 +267,8 @@ extern "C" int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* 
     R.hid_steps = l > 0 ? L.NK * 4 : 0;
     R.hid_batches = l > 0 ? hidden_batches(L) : 0;
     R.bf16 = L.bf16;
-    R.emb_split = L.emb_split;
-    R.hid_split = (L.hsplit_mask >> l) & 1;
+    R.emb_split = L.emb_split ? L.terms : 1;
+    R.hid_split = ((L.hsplit_mask >> l) & 1) ? L.terms : 1;
     R.hid_col0 = has_emb ? cin : 0;
     R.xyz_cols = d->in_channels_xyz;
     R.dst_group0 = g0;
@@ -284,7 +287,8 @@ extern "C" int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* 
     R.hid_batches = L.NK;
     R.bf16 = 1;
     R.n_rows = L.n_head;
-    R.hid_split = 1;
+    R.hid_split = L.terms;
+    R.emb_split = 1;
     R.dst_group0 = g0;
     g0 += R.groups;
   }

@@ -183,7 +183,8 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
   typename std::conditional<X3, CarryX, Carry>::type carry;
   constexpr int NP2 = X3 ? 1 : kNofTpp;      // the fast mode's NoF layers stream two tiles per panel,
   constexpr int NF0 = X3 ? 1 : kNerfTpp0;    // its NeRF layer 0 four
-  const Next prog_first = MOCO ? first_of<8, kKsNofXyz, true, NP2>(p.bw) : first_of<16, kKsNerfXyz, X3, NF0>(p.nerf);
+  constexpr int TN = X3 ? kNofTermsX3 : 2;   // bf16 terms of the NoF's operands (x3: hi, mid, lo -- six products per k-step)
+  const Next prog_first = MOCO ? first_of<8, kKsNofXyz, true, NP2, TN>(p.bw) : first_of<16, kKsNerfXyz, X3, NF0>(p.nerf);
   int seq = 0;                       // NoF evaluations done by this workgroup: evaluation number `seq` reads buffer seq & 1
   if (MOCO) {                        // rows of the first evaluation (first group, tile 0, bw at index i)
     const long long g0 = blockIdx.x;
@@ -192,7 +193,7 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
     tile_rays<TILE>(0, nr0, p.S, f0, n0);
     stage_raybias<NW>(p, g0 * p.G + f0, n0, 0, p.rb_off, id);
   }
-  if (MOCO) start_program<8, kKsNofXyz, true, NP2>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);   // (its wait + barrier also publish the resident blocks / tables)
+  if (MOCO) start_program<8, kKsNofXyz, true, NP2, TN>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);   // (its wait + barrier also publish the resident blocks / tables)
   else start_program<16, kKsNerfXyz, X3, NF0>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
 
   const int S = p.S;
@@ -255,14 +256,15 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
           if (role == 1 || role == 2) { cur[0] = canon[0]; cur[1] = canon[1]; cur[2] = canon[2]; }
           const bool last = step == nsteps - 1;
           const bool next_fw = (role + 1 == 1 || role + 1 == 2 || role + 1 == 4);
-          const Next follow = last ? first_of<16, kKsNerfXyz, X3, NF0>(p.nerf) : first_of<8, kKsNofXyz, true, NP2>(next_fw ? p.fw : p.bw);
-          u32x4 nhi[kKsNofXyz], nlo[kKsNofXyz];
+          const Next follow = last ? first_of<16, kKsNerfXyz, X3, NF0>(p.nerf) : first_of<8, kKsNofXyz, true, NP2, TN>(next_fw ? p.fw : p.bw);
+          u32x4 nhi[kKsNofXyz], nmid[TN == 3 ? kKsNofXyz : 1], nlo[kKsNofXyz];
           float out[3];
-          nof_embed<!X3 || MF_NOF_HW_X3>(nhi, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
+          if constexpr (TN == 3) nof_embed_t<!X3 || MF_NOF_HW_X3, 3>(nhi, nmid, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
+          else nof_embed<!X3 || MF_NOF_HW_X3>(nhi, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
           auto stage_next = [&] {
             if (!last) stage_raybias<NW>(p, ray0 + tf, tn, role + 1 == 4 ? 1 : role + 1, p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes, id);
           };
-          if constexpr (X3) nof_eval_x3(net, nhi, nlo, cur, st, carry, id, follow, out, rb, stage_next);
+          if constexpr (X3) nof_eval_x3<TN>(net, nhi, reinterpret_cast<const u32x4(&)[kKsNofXyz]>(nmid), nlo, cur, st, carry, id, follow, out, rb, stage_next);
           else nof_eval(net, nhi, nlo, cur, st, carry, id, follow, out, rb, nullptr, stage_next);
           if (role == 0) { canon[0] = out[0]; canon[1] = out[1]; canon[2] = out[2]; }
           if (role == 1) dl = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
@@ -471,9 +473,10 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void points_kernel
   st.tl.start(nullptr, id);
   typename std::conditional<X3, CarryX, Carry>::type carry;
   constexpr int NP2 = X3 ? 1 : kNofTpp, NF0 = X3 ? 1 : kNerfTpp0;
+  constexpr int TN = X3 ? kNofTermsX3 : 2;
   const Next nerf_first = first_of<16, kKsNerfXyz, X3, NF0>(p.nerf);
-  const Next prog_first = NOF ? first_of<8, kKsNofXyz, true, NP2>(p.bw) : nerf_first;
-  if (NOF) start_program<8, kKsNofXyz, true, NP2>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);
+  const Next prog_first = NOF ? first_of<8, kKsNofXyz, true, NP2, TN>(p.bw) : nerf_first;
+  if (NOF) start_program<8, kKsNofXyz, true, NP2, TN>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);
   else start_program<16, kKsNerfXyz, X3, NF0>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
   const long long ntiles = (p.B + TILE - 1) / TILE;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -482,7 +485,7 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void points_kernel
     const long long bb = valid ? b : p.B - 1;
     float x[3] = {p.xyz[bb * 3 + 0], p.xyz[bb * 3 + 1], p.xyz[bb * 3 + 2]};
     if (NOF) {
-      u32x4 nhi[kKsNofXyz], nlo[kKsNofXyz];
+      u32x4 nhi[kKsNofXyz], nmid[TN == 3 ? kKsNofXyz : 1], nlo[kKsNofXyz];
       float out[3];
       if constexpr (PERPT) {
         const float* rbp = p.raybias + (size_t)bb * (size_t)(p.rb_layers * 128) + 4 * id.h;
@@ -492,8 +495,9 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void points_kernel
         nof_eval(p.bw, nhi, nlo, x, st, carry, id, nerf_first, out, rb, rbp, [] {});
       } else {
         LdsRayBias rb{p.rb_off};
-        nof_embed<!X3 || MF_NOF_HW_X3>(nhi, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
-        if constexpr (X3) nof_eval_x3(p.bw, nhi, nlo, x, st, carry, id, nerf_first, out, rb, [] {});
+        if constexpr (TN == 3) nof_embed_t<!X3 || MF_NOF_HW_X3, 3>(nhi, nmid, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
+        else nof_embed<!X3 || MF_NOF_HW_X3>(nhi, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
+        if constexpr (X3) nof_eval_x3<TN>(p.bw, nhi, reinterpret_cast<const u32x4(&)[kKsNofXyz]>(nmid), nlo, x, st, carry, id, nerf_first, out, rb, [] {});
         else nof_eval(p.bw, nhi, nlo, x, st, carry, id, nerf_first, out, rb, nullptr, [] {});
       }
       x[0] = out[0]; x[1] = out[1]; x[2] = out[2];

@@ -92,6 +92,18 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
     dev = rays.device
     N = rays.shape[0]
     S = z_vals.shape[1] if z_vals is not None else z_steps.shape[0]
+    # the reference zero-pads each embedding INTO the network's input width (rendering.py:70-72, 127-142) and fails with a
+    # shape error when the embedding is wider; the NoF's index block is concatenated unpadded (:73-75) and must fit exactly
+    extra_emb = nerf_embs[1] if nerf.extra_feat_type == "ind" else (nerf_embs[2] if nerf.extra_feat_type == "dir" else None)
+    if nerf_embs[0].out_channels > nerf.in_channels_xyz or \
+            (extra_emb is not None and not sigma_only and extra_emb.out_channels > nerf.extra_feat_dim):
+        raise RuntimeError(f"render_rays: embedding wider than the NeRF's input block (xyz {nerf_embs[0].out_channels} > "
+                           f"{nerf.in_channels_xyz} or {nerf.extra_feat_type} > {nerf.extra_feat_dim})")
+    if nof_models is not None:
+        for m in nof_models[:2 if (chain_local or chain_global) else 1]:
+            if nof_embs[0].out_channels > m.in_channels_xyz or nof_embs[1].out_channels != m.extra_feat_dim:
+                raise RuntimeError(f"render_rays: the NoF takes [xyz <= {m.in_channels_xyz} | ind = {m.extra_feat_dim}] input columns, "
+                                   f"the embeddings give {nof_embs[0].out_channels} | {nof_embs[1].out_channels}")
     a = L.mf_render_args()
     a.rays, a.ray_stride, a.n_rays = L.ptr(rays), rays.stride(0), N
     a.background = L.ptr(background)

@@ -135,10 +135,13 @@ BF16 = Arith(name="bf16", acc="f64", nof_xyz="split", nof_ind_bias=True, nof_hid
 BF16X3_R3 = Arith(name="bf16x3_r3", acc="f64", nof_xyz="split", nof_ind_bias=True, nof_hidden="split", nof_head="split",
                   nof_xyz_sincos="hw", nerf_emb="split", nerf_hidden="split", nerf_tail="split", nerf_heads="f32acc",
                   nerf_xyz_sincos="chain", nerf_extra_sincos="hw")
-# set_precision("bf16x3"), round 4 (see ARITH["bf16x3"] below; kept in step with the kernel)
-BF16X3 = replace(BF16X3_R3, name="bf16x3", nof_xyz_sincos="chain")
+# set_precision("bf16x3"), round 4: the NoF in THREE-term operands (hi, mid, lo; six products per k-step, 24 mantissa bits)
+# with its xyz block from exact seeds + doubling chains -- its output point feeds sin(512 x); the NeRF as before
+BF16X3 = replace(BF16X3_R3, name="bf16x3", nof_xyz="split3", nof_hidden="split3", nof_head="split3", nof_xyz_sincos="chain")
+# (the intermediate step: round 3's two-term NoF with the exact seeds)
+BF16X3_2T = replace(BF16X3_R3, name="bf16x3_2t", nof_xyz_sincos="chain")
 
-ARITH = {"f32": F32, "bf16": BF16, "bf16x3": BF16X3, "bf16x3_r3": BF16X3_R3}
+ARITH = {"f32": F32, "bf16": BF16, "bf16x3": BF16X3, "bf16x3_2t": BF16X3_2T, "bf16x3_r3": BF16X3_R3}
 
 
 # ------------------------------------------------------------------ E with the kernels' sin / cos

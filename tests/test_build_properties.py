@@ -15,6 +15,11 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=o
          "-Rpass-analysis=kernel-resource-usage", "-S", "-o"]
 
 
+def _unit_flags(unit):
+    """the unit's own flags of the shipped build (csrc/Makefile, `unitflags`)"""
+    return subprocess.run(["make", "-s", "unitflags", f"UNIT={unit}"], cwd=CSRC, capture_output=True, text=True, check=True).stdout.split()
+
+
 def _compile(unit, extra):
     out = f"/tmp/mf_props_{os.getpid()}_{unit}.s"
     r = subprocess.run([HIPCC] + FLAGS + [out] + extra + [unit + ".hip"], cwd=CSRC, capture_output=True, text=True, timeout=900)
@@ -39,8 +44,9 @@ def _compile(unit, extra):
 def test_inference_kernels_have_no_spills_and_stream_weights_by_buffer_dma():
     with ThreadPoolExecutor(3) as ex:
         f32 = ex.submit(_compile, "mf_render", [])
-        b16 = ex.submit(_compile, "mf_render_bf16", ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"])      # csrc/Makefile builds this unit so
-        bw3 = ex.submit(_compile, "mf_backward_bf16", ["-fno-slp-vectorize", "-mllvm", "-pragma-unroll-threshold=1000000"])
+        b16 = ex.submit(_compile, "mf_render_bf16", _unit_flags("mf_render_bf16"))      # csrc/Makefile builds this unit so
+        bw3 = ex.submit(_compile, "mf_backward_bf16", _unit_flags("mf_backward_bf16"))
+        assert "-fno-slp-vectorize" in _unit_flags("mf_render_bf16") and not _unit_flags("mf_render")
         (u32, a32), (u16, a16), (ub3, _) = f32.result(), b16.result(), bw3.result()
     u16 = {**u16, **{k: v for k, v in ub3.items() if "nerf_backward_kernel_x3" in k}}
     # render_kernel<MOCO, DUMP>: the two inference instantiations (DUMP = false) and every bf16 kernel

@@ -336,27 +336,71 @@ def test_full_size_properties(M):
     assert cap["z_fine"].shape == (n, 192)
 
 
-def _oracle_grads(R, c, seed, rays, bg, loss_fn):
+def _oracle_grads(R, c, seed, rays, bg, loss_fn, dtype=torch.float32):
+    """Oracle forward + autograd of `loss_fn` at `dtype` (float64: the arithmetic-noise-free truth of the same function)."""
     embs_o, nerfs_o, kw_o = build_case(R, c, seed)
     nets = list(nerfs_o) + (list(kw_o["nof_models"]) if kw_o["nof_models"] else [])
     for m in nets:
         for k in m.p:
-            m.p[k] = m.p[k].clone().requires_grad_(True)
-    res = R.render_rays(rays, bg, embs_o, nerfs_o, **kw_o)
-    loss = loss_fn(res)
+            m.p[k] = m.p[k].to(dtype).clone().requires_grad_(True)
+    for e in list(embs_o) + list(kw_o["nof_embeddings"] or []):
+        if e is not None:
+            e.freq_bands = e.freq_bands.to(dtype)
+    torch.set_default_dtype(dtype)              # the oracle allocates its pads / ones with the default dtype
+    try:
+        res = R.render_rays(rays.to(dtype), bg.to(dtype) if bg is not None else None, embs_o, nerfs_o, **kw_o)
+        loss = loss_fn(res)
+    finally:
+        torch.set_default_dtype(torch.float32)
     flat = [(i, k) for i, m in enumerate(nets) for k in m.p]
     grads = torch.autograd.grad(loss, [nets[i].p[k] for i, k in flat], allow_unused=True)
     return res, {f"{i}.{k}": g for (i, k), g in zip(flat, grads)}
 
 
-# end-to-end gradient bars (max-rel per parameter tensor).  NeRF-only passes are well conditioned: measured 1e-6 .. 2e-6.
-# r_moco_global (dense regime behind two NoFs) is not: the gradient runs through sin(512 x) of a canonical point, and
-# the ORACLE's own fp32 and fp64 autograd differ by 30-120 % on the NeRF / backward-NoF tensors of this very case
-# (measured in the build container, seed of the fixture) -- its 5e-2 (measured 2e-2 vs the fp32 oracle) is already far
-# inside the reference's own noise.  What pins the HIP backward is test_*_backward_vs_oracle* (same function at the same
-# points: 2e-6).  The default-init MoCo case is smoother but still carries the 512 x phase: oracle fp32 vs fp64 differ
-# by up to 5.9e-3 there; HIP vs the fp32 oracle measures 1.3e-3.
-GRAD_BARS = {"r_nerf_dir_dense": 1e-4, "r_nerf_ind_dense": 1e-4, "r_moco_global": 5e-2, "r_moco_global_default": 3e-3}
+# End-to-end gradient bars.  The truth is the ORACLE IN FLOAT64 (the same function without arithmetic noise); the yardstick
+# per parameter tensor is the reference arithmetic's own distance to it, noise = l2-rel(fp32 oracle autograd, float64 oracle
+# autograd): a HIP tensor must be within max(1e-4, 3 x noise) of the truth in l2-rel, with the max-rel distance to the fp32
+# oracle bounded the same way (guard against a wrong element).  NeRF-only passes: HIP and the fp32 oracle evaluate the same
+# ReLU masks and agree to 1e-6 .. 8e-6 although both sit up to 7e-3 from the float64 truth on the first layers (mask flips) --
+# there the fixed 1e-4 against the fp32 oracle stays as the tighter bar.  The MoCo cases carry sin(512 x) of a canonical point through dense NoFs: there the fp32 and
+# float64 oracles differ by percents on some tensors (r3 measured 30-120 % max-rel on r_moco_global's NeRF / backward-NoF
+# tensors, 0.6 % at default init), and a fixed bar either hides a regression on the well-conditioned tensors or fails on the
+# others -- rounds 1-3 used 5e-2 / 3e-3 against the fp32 oracle; per-tensor noise floors replace them.  What pins each backward
+# KERNEL at 1e-4 is test_*_backward_vs_oracle* (same function at the same points, masks included).
+GRAD_CASES = ["r_nerf_dir_dense", "r_nerf_ind_dense", "r_moco_global", "r_moco_global_default"]
+
+
+def _check_grads_vs_float64(nets, want32, want64, skip=lambda k: False, label="", fp32_bar=None):
+    """fp32_bar: fixed max-rel bar against the fp32 oracle (NeRF-only passes: HIP and the fp32 oracle evaluate the same ReLU
+    masks and agree to ~1e-6 where both sit 1e-3 from the float64 truth -- there the fixed 1e-4 is the tighter test).
+    The yardstick of a tensor is the larger of its own noise and the MEDIAN noise of its network's tensors: one fp32-vs-float64
+    pair is a single draw of a random distance, and on some tensor it comes out several times under the typical one
+    (r_moco_global_default, xyz_encoding_8.weight: 1.6e-5 where the network's median is 3e-4 and HIP sits at 2.1e-4)."""
+    checked, worst, floor = 0, (0.0, ""), (0.0, "")
+    for i, m in enumerate(nets):
+        live = [k for k, _ in m.named_parameters() if not skip(k) and want64[f"{i}.{k}"] is not None
+                and float(want64[f"{i}.{k}"].abs().max()) > 0.0]
+        net_l2 = float(np.median([_l2rel(want32[f"{i}.{k}"], want64[f"{i}.{k}"]) for k in live])) if live else 0.0
+        net_mr = float(np.median([relerr(want32[f"{i}.{k}"], want64[f"{i}.{k}"]) for k in live])) if live else 0.0
+        for k, p in m.named_parameters():
+            key = f"{i}.{k}"
+            if skip(k):
+                assert p.grad is None, key
+                continue
+            w64, w32 = want64[key], want32[key]
+            if w64 is None or float(w64.abs().max()) == 0.0:
+                assert p.grad is None or float(p.grad.abs().max()) == 0.0, key
+                continue
+            assert p.grad is not None, key
+            noise_l2, noise_mr = max(_l2rel(w32, w64), net_l2), max(relerr(w32, w64), net_mr)
+            e_l2, e_mr32 = _l2rel(p.grad, w64), relerr(p.grad, w32)
+            worst, floor = max(worst, (e_l2, key)), max(floor, (noise_l2, key))
+            assert e_l2 <= max(TOL, 3 * noise_l2), (key, e_l2, noise_l2)
+            assert e_mr32 <= (fp32_bar if fp32_bar is not None else max(TOL, 3 * noise_mr)), (key, e_mr32, noise_mr)
+            checked += 1
+    print(f"{label}: end-to-end gradients vs the float64 oracle, worst l2-rel {worst[0]:.2e} at {worst[1]} (the fp32 oracle's own worst "
+          f"{floor[0]:.2e} at {floor[1]}; {checked} tensors, each within max(1e-4, 3 x its noise floor))")
+    return checked
 
 
 @pytest.mark.parametrize("name", ["r_nerf_dir_dense", "r_nerf_ind_dense"])
@@ -435,11 +479,12 @@ def test_train_forward_bf16x3(M, R, name):
             assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k])
 
 
-@pytest.mark.parametrize("name", sorted(GRAD_BARS))
+@pytest.mark.parametrize("name", GRAD_CASES)
 def test_gradients_vs_oracle(M, R, name, wgrad):
     """Training contract (moco_flow_amd/autograd.py): forward values from the HIP kernels, gradients from
     the HIP backward nodes (composite, NeRF dX chain + weight gradients, NoF evaluations); against the CPU oracle's autograd
-    for the reference's loss shape (MSE on rgb + consensus means, trainer_moco_flow.py:317-328)."""
+    for the reference's loss shape (MSE on rgb + consensus means, trainer_moco_flow.py:317-328), float64 oracle as the truth
+    and the fp32 oracle's own distance to it as the per-tensor yardstick (see above)."""
     c = dict(RENDER_CASES[name])
     seed = int(load_golden(name)["meta_seed"])
     n = 48
@@ -447,13 +492,14 @@ def test_gradients_vs_oracle(M, R, name, wgrad):
     gt = torch.rand(n, 3, generator=torch.Generator().manual_seed(0))
 
     def loss_fn(res, gt=gt):
-        loss = ((res["rgb_coarse"] - gt.to(res["rgb_coarse"].device)) ** 2).mean() + 0.1 * res["depth_coarse"].mean()
+        loss = ((res["rgb_coarse"] - gt.to(res["rgb_coarse"])) ** 2).mean() + 0.1 * res["depth_coarse"].mean()
         for k in ("nof_local_disp_coarse", "nof_global_disp_coarse"):
             if k in res:
                 loss = loss + 0.2 * res[k].mean()
         return loss
 
-    _, want = _oracle_grads(R, c, seed, rays, bg, loss_fn)
+    _, want32 = _oracle_grads(R, c, seed, rays, bg, loss_fn)
+    _, want64 = _oracle_grads(R, c, seed, rays, bg, loss_fn, torch.float64)
     embs, nerfs, kw = build_case(M, c, seed, device="cuda")
     nets = list(nerfs) + (list(kw["nof_models"]) if kw["nof_models"] else [])
     # frozen sub-module (trainer_moco_flow.py:391-404): no grad must reach it
@@ -462,22 +508,8 @@ def test_gradients_vs_oracle(M, R, name, wgrad):
     res = M.render_rays(rays.cuda(), bg.cuda(), embs, nerfs, **kw)
     assert res["rgb_coarse"].requires_grad
     loss_fn(res).backward()
-    checked, worst = 0, (0.0, "")
-    for i, m in enumerate(nets):
-        for k, p in m.named_parameters():
-            w = want[f"{i}.{k}"]
-            if k.startswith("rgb."):
-                assert p.grad is None
-                continue
-            if w is None:
-                assert p.grad is None or float(p.grad.abs().max()) == 0.0, k
-                continue
-            assert p.grad is not None, k
-            tol = GRAD_BARS[name]
-            worst = max(worst, (relerr(p.grad, w), f"{i}.{k}"))
-            assert relerr(p.grad, w) <= tol, (k, relerr(p.grad, w))
-            checked += 1
-    print(f"{name}: end-to-end gradients vs oracle autograd, worst max-rel {worst[0]:.2e} at {worst[1]}")
+    checked = _check_grads_vs_float64(nets, want32, want64, skip=lambda k: k.startswith("rgb."), label=name,
+                                      fp32_bar=TOL if c.get("nof", "none") == "none" else None)
     assert checked >= 10
 
 
@@ -485,9 +517,8 @@ def test_gradients_vs_oracle(M, R, name, wgrad):
 def test_gradients_when_the_loss_skips_outputs(M, R, name):
     """A loss that does not touch rgb (depth + opacity only): the composite node gets NO seed for rgb (autograd hands None,
     the node does not materialise zeros -- mf_composite_backward takes a null pointer) and the gradients still match the
-    oracle's autograd; an output-free NoF evaluation chain leaves its parameters without gradient.  (Bar of the MoCo case:
-    the gradient runs through sin(512 x) of the canonical point -- see GRAD_BARS; with only 40 rays and no rgb term the
-    backward NoF's head bias measures 9e-3 against the fp32 oracle, inside the oracle's own fp32-vs-fp64 spread.)"""
+    oracle's autograd (float64 truth, per-tensor noise floor: GRAD_CASES above); an output-free NoF evaluation chain leaves
+    its parameters without gradient."""
     c = dict(RENDER_CASES[name])
     seed = int(load_golden(name)["meta_seed"])
     rays, bg = case_inputs(c, seed, n=40)
@@ -495,21 +526,13 @@ def test_gradients_when_the_loss_skips_outputs(M, R, name):
     def loss_fn(res):
         return 0.3 * res["depth_coarse"].mean() + 0.2 * res["opacity_coarse"].square().mean()
 
-    _, want = _oracle_grads(R, c, seed, rays, bg, loss_fn)
+    _, want32 = _oracle_grads(R, c, seed, rays, bg, loss_fn)
+    _, want64 = _oracle_grads(R, c, seed, rays, bg, loss_fn, torch.float64)
     embs, nerfs, kw = build_case(M, c, seed, device="cuda")
     nets = list(nerfs) + (list(kw["nof_models"]) if kw["nof_models"] else [])
     loss_fn(M.render_rays(rays.cuda(), bg.cuda(), embs, nerfs, **kw)).backward()
-    checked = 0
-    for i, m in enumerate(nets):
-        for k, p in m.named_parameters():
-            w = want[f"{i}.{k}"]
-            if w is None or float(w.abs().max()) == 0.0:
-                assert p.grad is None or float(p.grad.abs().max()) == 0.0, (i, k)
-                continue
-            bar = {"r_nerf_dir_dense": 1e-4, "r_moco_global_default": 2e-2}[name]
-            assert p.grad is not None and relerr(p.grad, w) <= bar, (i, k, None if p.grad is None else relerr(p.grad, w))
-            checked += 1
-    assert checked >= 8
+    assert _check_grads_vs_float64(nets, want32, want64, label=name + " (no rgb term)",
+                                   fp32_bar=TOL if c.get("nof", "none") == "none" else None) >= 8
 
 
 def test_module_gradients(M, R):
@@ -768,50 +791,50 @@ def test_c3_full_size_bf16_vs_oracle(M, R, name, draw):
             assert abs(res[k].shape[0] - want[k].shape[0]) <= 0.02 * want[k].shape[0], k
 
 
-# bf16x3 (MF_PREC_BF16X3): every matrix product of both networks as three bf16 products of (hi, lo) operand pairs, fp32
-# accumulation, heads and per-ray image-index bias.  tools/bf16_emulate.py ("x3full") predicts 98-108 dB; measured at 4096
-# rays: bench draw 104.4 dB, l2 1.1e-5 / 8.2e-6 / 1.7e-6 (the fp32 kernels: 123 dB, 1.3e-6); golden-case draw 88.6 dB, l2
-# 9.0e-5 / 2.4e-4 / 1.3e-4 (fp32 kernels: 118.7 dB -- that draw's dense NoF amplifies the 2^-17 of the split ~30x more).
-# Round 3's first bf16x3 (NoF and the NeRF's last layer only) gave 60.4 / 47.0 dB, the fast mode 51.4 / 38.1.
-#                 draw     tags         PSNR   l2 rgb   l2 depth  l2 opacity
-C3_X3_BARS = {"bench": (BENCH_TAGS, 100.0, 3e-5, 3e-5, 1e-5), "case": (None, 84.0, 2e-4, 5e-4, 3e-4)}
+# bf16x3 (MF_PREC_BF16X3): the fp32 CONTRACT on the bf16 matrix pipe -- the NeRF's products as three bf16 products of (hi, lo)
+# operand pairs, the NoF's as six products of (hi, mid, lo) triples (24 mantissa bits: its output point feeds sin(512 x)), fp32
+# accumulation, heads on the fp32 accumulators, exact per-ray image-index bias, exact seeds + doubling chains for the encodings.
+# Measured at 4096 rays (round 4): bench draw 114.1 dB, max-rel 1.0e-5 / 1.4e-5 / 1.0e-5 (rgb / depth / opacity; the fp32
+# kernels: 123 dB); golden-case draw 111.3 dB, 2.1e-5 / 2.3e-5 / 3.1e-5 (fp32 kernels 118.7 dB).  History: round 3's kernel (two-term
+# NoF, its xyz encoding from the transcendental unit) measured 104.4 dB on the bench draw but 88.6 dB / 7e-3 max-rel on the
+# golden-case draw -- oracle/bf16_ref.py located both causes: the unit's 6e-6 rad argument error flipped the sign of a
+# far-sample sigma (exact seeds: 99.1 dB, 1.4e-4 .. 2.0e-4), and the two-term split's 2^-17 is 1.5e-4 of the rendered ray (three
+# terms: the numbers above = an exact-fp32 NoF's).  The fast mode on the same batches: 51.4 / 38.1 dB.
+C3_X3_DRAWS = {"bench": BENCH_TAGS, "case": None}
 
 
-@pytest.mark.parametrize("draw", sorted(C3_X3_BARS))
+@pytest.mark.parametrize("draw", sorted(C3_X3_DRAWS))
 @pytest.mark.parametrize("name", ["r_moco_local", "r_moco_global"])
 def test_c3_full_size_bf16x3_vs_oracle(M, R, name, draw):
-    """BASELINE config C3 in the accuracy mode of the bf16 pipe (set_precision("bf16x3")): every matrix product as
-    three bf16 products, heads on fp32 accumulators -- against the fp32 oracle, and against the fast bf16 mode on the same
-    batch (must be >= 40 dB better)."""
-    tags, bar_db, bar_rgb, bar_depth, bar_op = C3_X3_BARS[draw]
-    c, res, want = _full_size_case(M, R, name, 4096, "bf16x3", tags=tags)
-    _, fast, _ = _full_size_case(M, R, name, 4096, "bf16", tags=tags)
+    """BASELINE config C3 in the contract mode of the bf16 pipe (set_precision("bf16x3")) against the fp32 oracle: north_star's
+    1e-4 max-rel on EVERY per-ray output, on both weight draws, local and local + global chains; >= 50 dB better than the fast
+    bf16 mode on the same batch; the consensus means to 1e-4."""
+    c, res, want = _full_size_case(M, R, name, 4096, "bf16x3", tags=C3_X3_DRAWS[draw])
+    _, fast, _ = _full_size_case(M, R, name, 4096, "bf16", tags=C3_X3_DRAWS[draw])
     ps, ps_fast = _psnr(res["rgb_coarse"], want["rgb_coarse"]), _psnr(fast["rgb_coarse"], want["rgb_coarse"])
-    l2 = {k: _l2rel(res[k], want[k]) for k in ("rgb_coarse", "depth_coarse", "opacity_coarse")}
-    print(f"C3 {name} bf16x3 [{draw} draw]: PSNR-equiv {ps:.1f} dB (fast bf16: {ps_fast:.1f}); l2-rel rgb {l2['rgb_coarse']:.2e} "
-          f"depth {l2['depth_coarse']:.2e} opacity {l2['opacity_coarse']:.2e}")
-    assert ps >= bar_db and ps >= ps_fast + 40.0
-    assert l2["rgb_coarse"] <= bar_rgb and l2["depth_coarse"] <= bar_depth and l2["opacity_coarse"] <= bar_op
+    mr = {k: relerr(res[k], want[k]) for k in ("rgb_coarse", "depth_coarse", "opacity_coarse")}
+    print(f"C3 {name} bf16x3 [{draw} draw]: PSNR-equiv {ps:.1f} dB (fast bf16: {ps_fast:.1f}); max-rel rgb {mr['rgb_coarse']:.2e} "
+          f"depth {mr['depth_coarse']:.2e} opacity {mr['opacity_coarse']:.2e}")
+    assert ps >= 106.0 and ps >= ps_fast + 50.0
+    for k, e in mr.items():
+        assert e <= TOL, (k, e)
     for k in want:
         if k.startswith("nof_"):
-            assert abs(float(res[k].mean()) - float(want[k].mean())) <= 5e-4 * abs(float(want[k].mean())), k
+            assert abs(float(res[k].mean()) - float(want[k].mean())) <= 1e-4 * abs(float(want[k].mean())), k
             assert abs(res[k].shape[0] - want[k].shape[0]) <= 0.002 * want[k].shape[0] + 2, k
 
 
 def test_c5_shard_shape_bf16x3_vs_oracle(M, R):
-    """BASELINE config C5's shard (1024 rays x (64 + 128), two NeRFs, local + global chains) in bf16x3, both passes
-    against the oracle on identical samples.  Measured: rgb_fine 108.5 dB / l2 5.3e-6 (fast mode 52.7 dB), rgb_coarse 82.9
-    dB / 1.8e-4 (39.9; the coarse NeRF of this fixture is the dense golden-case draw)."""
+    """BASELINE config C5's shard (1024 rays x (64 + 128), two NeRFs, local + global chains) in bf16x3, both passes against the
+    oracle on identical samples: 1e-4 max-rel on every per-ray output of BOTH passes.  Measured (round 4): coarse 111.2 dB,
+    max-rel <= 3.1e-5; fine 116.2 dB, <= 8.1e-6 (round 3: coarse 82.9 dB / 8e-3 -- the coarse NeRF of this fixture is the dense
+    golden-case draw, see C3_X3_DRAWS; the fast mode 39.9 / 52.7 dB)."""
     c, res, want = _full_size_case(M, R, "r_moco_global_fine", 1024, "bf16x3")
     for k in ("rgb_coarse", "rgb_fine", "depth_coarse", "depth_fine", "opacity_coarse", "opacity_fine"):
         print(f"C5 shard bf16x3 {k}: PSNR-equiv {_psnr(res[k], want[k]):.1f} dB, l2-rel {_l2rel(res[k], want[k]):.2e}, "
               f"max-rel {relerr(res[k], want[k]):.2e}")
-    assert _psnr(res["rgb_fine"], want["rgb_fine"]) >= 100.0 and _l2rel(res["rgb_fine"], want["rgb_fine"]) <= 2e-5
-    assert _psnr(res["rgb_coarse"], want["rgb_coarse"]) >= 78.0 and _l2rel(res["rgb_coarse"], want["rgb_coarse"]) <= 4e-4
-    for k in ("depth_coarse", "opacity_coarse"):
-        assert _l2rel(res[k], want[k]) <= 1e-3, k
-    for k in ("rgb_fine", "depth_fine", "opacity_fine"):
-        assert relerr(res[k], want[k]) <= TOL, k          # the fine pass: the fp32 contract
+        assert relerr(res[k], want[k]) <= TOL, k
+    assert _psnr(res["rgb_fine"], want["rgb_fine"]) >= 106.0 and _psnr(res["rgb_coarse"], want["rgb_coarse"]) >= 106.0
 
 
 @pytest.mark.parametrize("precision", ["f32", "bf16"])
@@ -1002,8 +1025,8 @@ def test_fused_point_query_bf16(M, R):
 
 def test_fused_point_query_bf16x3(M, R):
     """query_sigma(precision="bf16x3"): the lattice query on the three-product kernels (scalar image index or canonical
-    space): raw sigma in canonical space and the canonical point to 1e-4 max-rel against the oracle (the fp32 contract),
-    raw sigma behind the NoF to 3e-4, at every launch shape; a per-point index tensor runs the exact-fp32 kernel; repeat runs bit-identical."""
+    space): raw sigma in canonical space, behind the NoF, and the canonical point to 1e-4 max-rel against the oracle (the fp32
+    contract), at every launch shape; a per-point index tensor runs the exact-fp32 kernel; repeat runs bit-identical."""
     from moco_flow_amd import synth
     torch.manual_seed(1)
     sd_n = synth.nerf_state(41, extra_feat_type="ind", extra_feat_dim=5, regime="dense", tag="pts")
@@ -1035,9 +1058,9 @@ def test_fused_point_query_bf16x3(M, R):
         assert torch.equal(sig, sig_again)
         print(f"bf16x3 point query B={B}: max-rel canonical {relerr(sig0[:k], osig0):.2e}, through bw NoF {relerr(sig[:k], osig):.2e}, "
               f"canonical point {relerr(canon[:k], ocanon):.2e}; per-point index (fp32 kernel) {relerr(sig_t[:k], osig):.2e}")
-        # (raw sigma behind the NoF on these dense random weights: the fp32 kernel measures 2.6e-5, the three-product one
-        #  1.3e-4 -- the canonical point itself is at 8e-7 -- so that bar is 3e-4)
-        assert relerr(sig0[:k], osig0) <= TOL and relerr(canon[:k], ocanon) <= TOL and relerr(sig[:k], osig) <= 3e-4
+        # (raw sigma behind the NoF on these dense random weights: the fp32 kernel measures 2.6e-5; round 3's two-term NoF
+        #  1.3e-4 (bar 3e-4), the three-term NoF of round 4 holds the contract)
+        assert relerr(sig0[:k], osig0) <= TOL and relerr(canon[:k], ocanon) <= TOL and relerr(sig[:k], osig) <= TOL
         assert relerr(sig_t[:k], osig) <= TOL
 
 
@@ -1650,7 +1673,7 @@ def test_aux_point_losses_train(M, R):
     assert relerr(canon, canon_t) <= 1e-5 and relerr(loss, loss_t) <= 1e-4
     want_nof, want_nerf = O.grads(nof), O.grads(nerf)
     # The NoF's gradient runs through sin(512 x) of the canonical point into a dense-regime NeRF: ill-conditioned in the
-    # reference itself (see GRAD_BARS above: its own fp32 and fp64 autograd differ by tens of percent on such chains),
+    # reference itself (see GRAD_CASES above: its own fp32 and fp64 autograd differ by tens of percent on such chains),
     # so two fp32 evaluation orders agree to ~1e-2 here (measured 7e-3 on nof_encoding_1.0.weight); the NeRF's own
     # parameters are well conditioned.  Each node is pinned at 1e-4 on identical inputs by test_*_backward_vs_oracle*.
     for n, q in nof.named_parameters():

@@ -163,11 +163,29 @@ def test_packed_layout_sizes():
     d.extra_feat_type, d.extra_feat_dim = L.MF_EXTRA_DIR, 27
     groups = (4 + 3 * 16 + 20 + 3 * 16 + 16) * 8 + (16 + 2) * 4
     assert lib.mf_nerf_packed_bytes_p(ctypes.byref(d), L.MF_PREC_BF16) == 13 * 1024 + groups * 1024
-    # MF_PREC_BF16X3: every k-step as a (hi, lo) group pair -- twice the groups of the bf16 layout where the NeRF is
-    # concerned (its encodings split too), the NoF's hidden ranges doubled (its embedded input and head already were)
+    # MF_PREC_BF16X3: the NeRF's k-steps as (hi, lo) group pairs -- twice the groups of the bf16 layout (its encodings split
+    # too); the NoF's as (hi, mid, lo) TRIPLES (round 4: six products per k-step, 24 mantissa bits -- its output point feeds
+    # sin(512 x)): 3 embedded k-steps x 3, 8 hidden k-steps x 3, a 24-group head panel
     groups = (8 + 3 * 32 + 40 + 3 * 32 + 32) * 8 + (32 + 4) * 4
     assert lib.mf_nerf_packed_bytes_p(ctypes.byref(d), L.MF_PREC_BF16X3) == 13 * 1024 + groups * 1024
-    assert lib.mf_nof_packed_bytes_p(ctypes.byref(n), L.MF_PREC_BF16X3) == 7 * 1024 + ((6 + 16 + 22 + 16) * 4 + 16) * 1024 + 36 * 1024
+    assert lib.mf_nof_packed_bytes_p(ctypes.byref(n), L.MF_PREC_BF16X3) == 7 * 1024 + ((9 + 24 + 33 + 24) * 4 + 24) * 1024 + 36 * 1024
+    # the envelope is the reference's constructors, not only its YAMLs: NeRF() defaults to in_channels_xyz = 33 and no
+    # extra block (models/nerf.py:6-12), NoF() to extra_feat_dim = 0 (models/nof.py:7-15) -- narrower input blocks pack
+    # into the same slots (same sizes); wider ones are refused
+    d2 = L.mf_nerf_desc()
+    d2.D, d2.W, d2.in_channels_xyz, d2.skip_mask = 8, 256, 33, 1 << 4
+    d2.extra_feat_type, d2.extra_feat_dim = L.MF_EXTRA_NONE, 0
+    groups = (8 + 3 * 32 + 40 + 3 * 32 + 32) * 8 + 32 * 4
+    assert lib.mf_nerf_packed_bytes(ctypes.byref(d2)) == 13 * 1024 + groups * 1024
+    d2.in_channels_xyz = 65
+    assert lib.mf_nerf_packed_bytes(ctypes.byref(d2)) == 0
+    n2 = L.mf_nof_desc()
+    n2.D, n2.W, n2.in_channels_xyz, n2.extra_feat_dim, n2.skip_mask, n2.use_quat = 4, 128, 33, 0, 0, 0
+    assert lib.mf_nof_packed_bytes(ctypes.byref(n2)) == 4 * 1024 + (10 + 3 * 16) * 4 * 1024      # (flow head: 3 rows resident)
+    n2.in_channels_xyz, n2.extra_feat_dim = 21, 17
+    assert lib.mf_nof_packed_bytes_p(ctypes.byref(n2), L.MF_PREC_BF16) > 0
+    n2.extra_feat_dim = 34
+    assert lib.mf_nof_packed_bytes(ctypes.byref(n2)) == 0
     assert lib.mf_loss_partials_scratch_bytes() == 256 * 12 * 8
     assert lib.mf_loss_partials(None, None, None, 0, None, None, None, None) == -1
 
