@@ -150,7 +150,7 @@ MF_D void bwd_layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[1
   auto run = [&](auto tc) __attribute__((always_inline)) {
     constexpr int t = decltype(tc)::value;
     const Ahead two{t + 2 < NT ? NG : (t == NT - 2 ? nxt.groups : nxt.groups2),
-                    t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), 0, nullptr};
+                    t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), 0, nullptr, t + 2 < NT ? NG : -1, -1};
     if constexpr (MASK && BITS) {                             // this tile's mask word: in flight across its MFMAs
       hm[0][0] = __builtin_bit_cast(float, reinterpret_cast<const unsigned*>(mrow)[t] >> (8 * id.h));
     } else if constexpr (MASK) {

@@ -73,13 +73,19 @@ struct StreamT {
   // ahead are latched.  piece(k): this wave's k-th 1 KiB piece of that panel (k = 0..kPieces-1: a panel is at most 32
   // groups); the pieces are issued one per MFMA gap behind the barrier instead of as a burst.
   const char* dsrc; uint32_t ddst; uint32_t pmask;
+  // `sg` (sync's last argument): the groups of the panel two ahead when the CALLER knows them at compile time (the same
+  // layer's next-but-one tile), -1 otherwise.  With sg a multiple of NW every wave issues exactly sg / NW pieces: after
+  // inlining, `stat` / `nstat` are constants, piece(k) is either an unconditional LDS-DMA or nothing, and the per-piece
+  // mask test + scalar branch (s_and_b64 vcc / s_cbranch_vccnz in front of every buffer_load ... lds, dead pieces included)
+  // is gone -- what remains runtime are the two panels at a layer boundary.
+  bool stat; int nstat;
   // KEEP: VM operations this wave has issued behind its last piece of the panel that must have landed (dump stores of
   // the training forward: the VM counter retires in order, so "all but the KEEP youngest" still covers every piece
   // without waiting for those stores' round trip).  A LOWER bound is safe; 0 waits for everything.
   // `keep_ok` (wave-uniform): the KEEP operations were really issued by this wave (a wave whose lanes all sit past the last
   // sample issues no dump stores: its youngest operations ARE pieces).
   template <int KEEP = 0>
-  MF_D void sync(int groups, const char* jump, const Lane& id, bool keep_ok = true) {
+  MF_D void sync(int groups, const char* jump, const Lane& id, bool keep_ok = true, int sg = -1) {
     // (MF_BF_ABL_*: timing-ablation builds only, tools/ab_lib.sh; results are garbage there)
     jitter();
 #ifndef MF_BF_ABL_NOWAIT
@@ -104,13 +110,18 @@ struct StreamT {
     gnext += (size_t)groups * kGroupBytes;
     return;
 #endif
-    const int per = (groups + NW - 1) / NW;
+#ifdef MF_BF_DMA_MASKED                       // (A/B: round 3's runtime mask on every piece)
+    sg = -1;
+#endif
+    stat = sg >= 0 && sg % NW == 0;
+    nstat = stat ? sg / NW : 0;
+    const int per = stat ? nstat : (groups + NW - 1) / NW;
     const int first = id.wave * per;
     dsrc = gnext + first * kGroupBytes;
     ddst = off2 + first * kGroupBytes;
     const int mine = groups - first < per ? groups - first : per;
-    pmask = (1u << (mine < 0 ? 0 : mine)) - 1u;
-    gnext += (size_t)groups * kGroupBytes;
+    pmask = stat ? 0u : (1u << (mine < 0 ? 0 : mine)) - 1u;
+    gnext += (size_t)(stat ? sg : groups) * kGroupBytes;
   }
   MF_D void piece(int k, const Lane& id) {
 #ifdef MF_BF_DMA_RR
@@ -118,7 +129,7 @@ struct StreamT {
     return;
 #endif
 #ifndef MF_BF_ABL_NODMA
-    if ((pmask >> k) & 1u) {
+    if (stat ? k < nstat : (bool)((pmask >> k) & 1u)) {
       const uint32_t hi = (uint32_t)(k >> 2) * (4 * kGroupBytes);
       switch (k & 3) {
         case 0: blds16_imm<0>(dsrc, id.lane * 16, hi, ddst + hi); break;
@@ -378,7 +389,7 @@ MF_D void trunk_layer_m(const Net& net, int layer, bool relu, const u32x4 (&act)
     auto hook = [&]() {
       if (second) return;
       st.sync(pi + 2 < NP ? pgroups : (pi == NP - 2 ? nxt.groups : nxt.groups2),
-              pi == NP - 2 ? nxt.jump : (pi == NP - 1 ? nxt.jump2 : nullptr), id);
+              pi == NP - 2 ? nxt.jump : (pi == NP - 1 ? nxt.jump2 : nullptr), id, true, pi + 2 < NP ? pgroups : -1);
     };
     auto piece = [&](int k) { if (!second) st.piece(k, id); };
     if constexpr (RB && (MODE & 1)) {
@@ -691,7 +702,7 @@ MF_D void extra_layer(const Net& net, const u32x4 (&act)[16], const u32x4* ex, c
     const uint32_t pn = st.slot_off(1) + id.lane * 16;
     auto hook = [&]() {
       st.sync(t + 2 < NT ? groups : (t == NT - 2 ? nxt.groups : nxt.groups2),
-              t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id);
+              t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id, true, t + 2 < NT ? groups : -1);
     };
     auto piece = [&](int k) { st.piece(k, id); };
     const f32x16 none = {};
@@ -843,7 +854,7 @@ MF_D void nof_embed_t(u32x4 (&xhi)[kKsNofXyz], u32x4 (&xmid)[kKsNofXyz], u32x4 (
 // HSTRIDE bytes apart.  `two` = the panels two ahead of this tile's first / second panel.
 constexpr int PDX = MF_BF_PDX;
 
-struct Ahead { int g0; const char* j0; int g1; const char* j1; };
+struct Ahead { int g0; const char* j0; int g1; const char* j1; int s0 = -1, s1 = -1; };   // s0 / s1: g0 / g1 when static (StreamT::sync's sg)
 
 // Activation dump of the training forward (mf_render_args.dump_acts): `row` = this lane's sample row + the layer's first
 // column + 4 (lane >> 5); a tile's 16 accumulators are rows 8 q + 4 h + i, i.e. four 16-byte stores at row[32 t + 8 q].
@@ -999,8 +1010,8 @@ MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, co
     // gaps that follow (several per gap where the panel is short)
     const int base = gi >= NG1 ? NG1 : 0, len = gi >= NG1 ? NG - NG1 : NG1, q = gi - base;
     if (q == 0) {
-      if (base) st.sync(two.g1, two.j1, id);
-      else st.template sync<KEEP>(two.g0, two.j0, id, keep_ok);
+      if (base) st.sync(two.g1, two.j1, id, true, two.s1);
+      else st.template sync<KEEP>(two.g0, two.j0, id, keep_ok, two.s0);
     }
     if (nb >= NG) r[sp] = frag(nb);
     gap(m++);
@@ -1071,9 +1082,9 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
     Ahead two;
     if constexpr (NSEG == 1) {        // panel t + 2 of this layer, else panel t + 2 - NT of what follows
       two = Ahead{t + 2 < NT ? NG : (t == NT - 2 ? nxt.groups : nxt.groups2),
-                  t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), 0, nullptr};
+                  t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), 0, nullptr, t + 2 < NT ? NG : -1, -1};
     } else {                          // the same half of the next tile, else of the first tile of what follows
-      two = t + 1 < NT ? Ahead{NG1, nullptr, NG - NG1, nullptr} : Ahead{nxt.groups, nxt.jump, nxt.groups2, nxt.jump2};
+      two = t + 1 < NT ? Ahead{NG1, nullptr, NG - NG1, nullptr, NG1, NG - NG1} : Ahead{nxt.groups, nxt.jump, nxt.groups2, nxt.jump2, -1, -1};
     }
     constexpr int tp = t > 0 ? t - 1 : 0;                    // the tile whose epilogue is pending
     auto gap = [&](int m) __attribute__((always_inline)) {

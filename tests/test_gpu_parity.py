@@ -396,7 +396,12 @@ def _check_grads_vs_float64(nets, want32, want64, skip=lambda k: False, label=""
             e_l2, e_mr32 = _l2rel(p.grad, w64), relerr(p.grad, w32)
             worst, floor = max(worst, (e_l2, key)), max(floor, (noise_l2, key))
             assert e_l2 <= max(TOL, 3 * noise_l2), (key, e_l2, noise_l2)
-            assert e_mr32 <= (fp32_bar if fp32_bar is not None else max(TOL, 3 * noise_mr)), (key, e_mr32, noise_mr)
+            # max-rel guard against a wrong element.  Its floor is 2e-3, not 1e-4: ONE ReLU unit whose pre-activation rounds to the
+            # other side of zero between two fp32 evaluation orders moves a weight-gradient row of the layers in front of it by
+            # that sample's whole contribution -- a discrete event (measured 1.4e-4 .. 3.8e-4 of max|dW| at 6144 samples, layers
+            # 1-3 only, the layers behind the unit agreeing to 2e-7, with the fp32 backward kernels too: tools/debug_ctor.py) that
+            # the fp32-vs-float64 pair of the same batch need not contain
+            assert e_mr32 <= (fp32_bar if fp32_bar is not None else max(2e-3, 3 * noise_mr)), (key, e_mr32, noise_mr)
             checked += 1
     print(f"{label}: end-to-end gradients vs the float64 oracle, worst l2-rel {worst[0]:.2e} at {worst[1]} (the fp32 oracle's own worst "
           f"{floor[0]:.2e} at {floor[1]}; {checked} tensors, each within max(1e-4, 3 x its noise floor))")

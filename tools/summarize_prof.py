@@ -51,9 +51,18 @@ for sub in ("pmc_mfma", "pmc_fetch", "pmc_write", "pmc_wait"):
         if k == "WRITE_SIZE":
             kb = sum(v) / len(v)
             print(f"{'':10s} -> HBM write {kb*1024/1e6:.3f} MB per launch (uncalibrated)")
+        if k in ("FETCH_SIZE", "WRITE_SIZE"):
+            # per-dispatch distribution: a mean can hide a few dispatches of a different kind (planes requested, a graph replay)
+            sv = sorted(v)
+            hist = defaultdict(int)
+            for x in v:
+                hist[int(round(x / 64.0)) * 64] += 1
+            top = sorted(hist.items(), key=lambda kv: -kv[1])[:4]
+            print(f"{'':10s}    per dispatch (KiB): min {sv[0]:.0f}  median {sv[len(sv)//2]:.0f}  max {sv[-1]:.0f};  most frequent (64-KiB bins): "
+                  + ", ".join(f"{b} x{c}" for b, c in top))
 
 # traffic.json entry for bench.py's roofline.traffic (HBM bytes per launch of the dominant kernel: FETCH_SIZE x2 per
-# the gfx950 note + WRITE_SIZE, both in KiB units as rocprofv3 reports them)
+# the gfx950 note + WRITE_SIZE, both in KiB units as rocprofv3 reports them; median over the dispatches)
 import json
 vals = {}
 for sub in ("pmc_fetch", "pmc_write"):
@@ -63,7 +72,9 @@ for sub in ("pmc_fetch", "pmc_write"):
             continue
         acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
     for k, v in acc.items():
-        vals[k] = sum(v) / len(v)
+        # MEDIAN per dispatch: the first dispatch of a process can carry two thousand times the bytes of the others (r04_c2:
+        # 86 dispatches at 80 KiB of WRITE_SIZE, one at 168 625 KiB -- round 3's "2.07 MB per launch" was that one in the mean)
+        vals[k] = sorted(v)[len(v) // 2]
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     entry = {"bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
              "fetch_kib_raw": vals["FETCH_SIZE"], "write_kib": vals["WRITE_SIZE"], "kernel": dom}
