@@ -600,8 +600,11 @@ class NerfSamples(torch.autograd.Function):
     ``xin`` (under NoF) and every NeRF parameter."""
 
     @staticmethod
-    def forward(ctx, m, acts, rgbsig, emb_in, extra_in, emb_xyz, xin, *params):
+    def forward(ctx, m, acts, rgbsig, emb_in, extra_in, emb_xyz, xin, sigma_path_only, *params):
         ctx.m, ctx.acts, ctx.emb_in, ctx.extra_in, ctx.emb_xyz = m, acts, emb_in, extra_in, emb_xyz
+        # sigma_path_only: only sigma of this evaluation reaches the result (the coarse pass of a test_time render,
+        # rendering.py:290-294): xyz_encoding_final / extra_encoding / rgb get no gradient, as under torch autograd
+        ctx.sigma_path_only = bool(sigma_path_only)
         ctx.save_for_backward(rgbsig, xin)
         ctx.xin_grad = xin.requires_grad
         ctx.n_params = len(params)
@@ -619,11 +622,15 @@ class NerfSamples(torch.autograd.Function):
         need_in = ctx.xin_grad
 
         with torch.no_grad():
-            grads, gpre, g_emb_hip, emb64 = nerf_fused_grads(m, g_out, acts, rgbsig, emb, extra, need_in)
+            if ctx.sigma_path_only:
+                g_out = g_out.clone()
+                g_out[:, :3] = 0
+            grads, gpre, g_emb_hip, emb64 = nerf_fused_grads(m, g_out, acts, rgbsig, emb, extra, need_in,
+                                                             sigma_path_only=ctx.sigma_path_only)
             # the embedded input's gradient comes out of the chain launch itself; the sin / cos chain rule is one more
             # small launch (an embedding narrower than in_channels_xyz -- fewer frequencies -- reads its own columns only)
             g_xin = embed_backward_hip(ctx.emb_xyz, emb64, g_emb_hip) if need_in else None
-        return (None, None, None, None, None, None, g_xin) + tuple(grads[n] for n in names)
+        return (None, None, None, None, None, None, g_xin, None) + tuple(grads[n] for n in names)
 
 
 def require_nerf_hip(m, P, under_nof):

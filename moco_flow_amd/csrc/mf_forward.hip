@@ -362,8 +362,8 @@ extern "C" int32_t mf_points_sigma_p(int32_t precision, const mf_nerf_desc* nerf
       return fail(MF_E_UNSUPPORTED, "mf_points_sigma: xyz embedding must have 3 channels and <= 10 frequencies");
     if (nof) {
       if (!nof_packed || !nof_emb_xyz || !nof_emb_ind) return fail(MF_E_INVALID, "mf_points_sigma: NoF arguments missing");
-      if (nof_emb_xyz->in_channels != 3 || nof_emb_xyz->n_freqs > 5 || nof_emb_ind->in_channels != 1 || nof_emb_ind->n_freqs != 16)
-        return fail(MF_E_UNSUPPORTED, "mf_points_sigma: NoF embeddings must be xyz(3, <=5 freqs) and ind(1, 16 freqs)");
+      if (nof_emb_xyz->in_channels != 3 || nof_emb_xyz->n_freqs > 5 || nof_emb_ind->in_channels != 1 || nof_emb_ind->n_freqs > 16)
+        return fail(MF_E_UNSUPPORTED, "mf_points_sigma: NoF embeddings must be xyz(3, <=5 freqs) and ind(1, <=16 freqs)");
     }
     if (B == 0) return MF_OK;
     return points_sigma_bf16(precision, nerf, nerf_packed, emb_xyz, nof, nof_packed, nof_emb_xyz, nof_emb_ind, xyz, ind, ind_scalar, B, sigma, canon,
@@ -383,8 +383,8 @@ extern "C" int32_t mf_points_sigma_p(int32_t precision, const mf_nerf_desc* nerf
   if (nof) {
     if (!nof_packed || !nof_emb_xyz || !nof_emb_ind) return fail(MF_E_INVALID, "mf_points_sigma: NoF arguments missing");
     if (!nof_layout(*nof, p.nof.L)) return fail(MF_E_UNSUPPORTED, "mf_points_sigma: unsupported NoF configuration");
-    if (nof_emb_xyz->in_channels != 3 || nof_emb_xyz->n_freqs > 5 || nof_emb_ind->in_channels != 1 || nof_emb_ind->n_freqs != 16)
-      return fail(MF_E_UNSUPPORTED, "mf_points_sigma: NoF embeddings must be xyz(3, <=5 freqs) and ind(1, 16 freqs)");
+    if (nof_emb_xyz->in_channels != 3 || nof_emb_xyz->n_freqs > 5 || nof_emb_ind->in_channels != 1 || nof_emb_ind->n_freqs > 16)
+      return fail(MF_E_UNSUPPORTED, "mf_points_sigma: NoF embeddings must be xyz(3, <=5 freqs) and ind(1, <=16 freqs)");
     p.nof.packed = static_cast<const char*>(nof_packed);
     p.nof.res_lds = lds; lds += (uint32_t)p.nof.L.res_bytes;
     if (p.nof.L.max_groups > max_groups) max_groups = p.nof.L.max_groups;

@@ -416,8 +416,8 @@ static int32_t render_entry(const mf_render_args* a, void* stream, bool prepare_
       if (p.fw.L.max_groups > max_groups) max_groups = p.fw.L.max_groups;
     }
     if (a->nof_emb_xyz.in_channels != 3 || a->nof_emb_xyz.n_freqs > 5 || a->nof_emb_ind.in_channels != 1 ||
-        a->nof_emb_ind.n_freqs != 16)
-      return fail(MF_E_UNSUPPORTED, "mf_render_pass: NoF embeddings must be xyz(3, <=5 freqs) and ind(1, 16 freqs)");
+        a->nof_emb_ind.n_freqs > 16)
+      return fail(MF_E_UNSUPPORTED, "mf_render_pass: NoF embeddings must be xyz(3, <=5 freqs) and ind(1, <=16 freqs)");
     to_table(a->nof_emb_xyz, p.emb_par[2]);
     to_table(a->nof_emb_ind, p.emb_par[3]);
   }

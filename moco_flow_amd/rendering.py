@@ -410,16 +410,20 @@ def render_rays(rays,
             torch.randn(shape, device=dev)
         return None
 
-    coarse_sigma_only = bool(need_fine and test_time)                  # rendering.py:290-294
+    coarse_opacity_only = bool(need_fine and test_time)                # rendering.py:290-294: only opacity_coarse comes back
+    # ... from a sigma-only evaluation of the coarse NeRF -- unless the pass records gradients (the reference renders
+    # test_time passes under no_grad, but its signature allows it): then the full network runs, its dump is complete, and
+    # the backward treats it as the sigma path it is (autograd.NerfSamples, sigma_path_only: rgb-branch parameters get None)
+    coarse_sigma_only = coarse_opacity_only and not grad
     # a pass that records gradients runs the reference's fp32 arithmetic (or, NeRF-only passes, the three-product kernels:
     # set_train_forward_precision)
     pass_prec = (TRAIN_FORWARD_PRECISION if not use_nof else "f32") if grad else None
     want_planes = need_fine or loc or glob or grad or _capture is not None
     noise_c = draw_noise((N, S), "noise_coarse")
     if grad and N > 0:
-        if coarse_sigma_only:
-            raise NotImplementedError("render_rays(test_time=True, N_importance > 0) with gradients: the sigma-only coarse pass "
-                                      "has no HIP backward (the reference renders test_time passes under torch.no_grad())")
+        if coarse_opacity_only and _loss_target is not None:
+            raise NotImplementedError("render_rays(test_time=True, N_importance > 0, _loss_target=...) with gradients: the fused loss "
+                                      "partials need rgb_coarse, which a test_time pass does not return")
         for m in nerf_models[:2 if need_fine else 1]:
             A.require_nerf_hip(m, N * S, use_nof)
         if use_nof:
@@ -430,7 +434,7 @@ def render_rays(rays,
                      noise_c, act, nerf_models[0], nerf_embeddings,
                      nof_models if use_nof else None, nof_embeddings, loc, glob, coarse_sigma_only, want_planes,
                      dump=grad and not coarse_sigma_only, precision=pass_prec, workspace=ws)
-    if coarse_sigma_only:
+    if coarse_opacity_only:
         result = {'opacity_coarse': c["opacity"]}
     else:
         result = {'rgb_coarse': c["rgb"], 'depth_coarse': c["depth"], 'opacity_coarse': c["opacity"]}
@@ -469,12 +473,12 @@ def render_rays(rays,
         result = _attach_explicit(result, rays, background, nerf_embeddings, nerf_models, nof_embeddings,
                                   nof_models if use_nof else None, loc, glob, nerf_activate_type,
                                   (c, z_vals, noise_c), (f, z_all, noise_f) if need_fine else None,
-                                  loss_target=_loss_target)
+                                  loss_target=_loss_target, coarse_opacity_only=coarse_opacity_only)
     return result
 
 
 def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs, nof_models, loc, glob,
-                     activation, coarse, fine, loss_target=None):
+                     activation, coarse, fine, loss_target=None, coarse_opacity_only=False):
     """Training graph on top of the fused forward (fp32): values are the HIP
     kernels' outputs; gradients flow through
       * autograd.CompositeSamples -- mf_composite_backward on the dumped per-sample (rgb, sigma) planes,
@@ -485,7 +489,7 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
     rays_o, rays_d, ind = rays[:, 0:3], rays[:, 3:6], rays[:, 8:9]
     out, recons, kernel_vals = {}, {}, set()
 
-    def one(tag, nerf, pack):
+    def one(tag, nerf, pack, opacity_only=False):
         p, z, noise = pack
         N, S = z.shape
         xyz = rays_o.unsqueeze(1) + rays_d.unsqueeze(1) * z.unsqueeze(2)
@@ -557,16 +561,15 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
                 extra_in = nerf_embs[1].rows(ind, S, max(32, nerf.extra_feat_dim))
             elif nerf.extra_feat_type == "dir":
                 extra_in = nerf_embs[2].rows(rays_d, S, max(32, nerf.extra_feat_dim))
-        rgbsig = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, nerf_embs[0], xin,
+        rgbsig = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, nerf_embs[0], xin, opacity_only,
                                      *nerf.parameters())
         if S > 2048:
             raise NotImplementedError(f"render_rays with gradients: mf_composite_backward is built for <= 2048 samples per ray, got {S}")
         out[f"rgb_{tag}"], out[f"depth_{tag}"], out[f"opacity_{tag}"] = A.CompositeSamples.apply(
-            rgbsig, rays, z, noise, activation, background, result[f"rgb_{tag}"], result[f"depth_{tag}"],
-            result[f"opacity_{tag}"])
+            rgbsig, rays, z, noise, activation, background, p["rgb"], p["depth"], p["opacity"])
         kernel_vals.update((f"rgb_{tag}", f"depth_{tag}", f"opacity_{tag}"))
 
-    one("coarse", nerf_models[0], coarse)
+    one("coarse", nerf_models[0], coarse, opacity_only=coarse_opacity_only)
     if fine is not None:
         one("fine", nerf_models[1], fine)
     final = {}

@@ -61,12 +61,20 @@ def _hip(M, c, rays, bg, precision, tags, seed=0):
     return {k: v.cpu() for k, v in res.items() if not k.startswith("nof_")}, cap
 
 
-def _oracle(B, arith, c, rays, bg, tags, z_fine=None, seed=0):
+_CACHE = {}      # oracle passes shared by the two tests (single-pass cases: the fine depths of a two-pass case depend on the mode)
+
+
+def _oracle(B, arith, c, rays, bg, tags, z_fine=None, seed=0, key=None):
     from oracle import cpu_ref as R
+    if key is not None and z_fine is None and (key, arith.name) in _CACHE:
+        return _CACHE[key, arith.name]
     embs, nerfs, kw = build_case(B.Backend(arith), c, seed, tags=tags)
     extra = dict(_z_fine_override=z_fine) if z_fine is not None else {}
     with torch.no_grad():
-        return R.render_rays(rays, bg, embs, nerfs, **extra, **kw)
+        out = R.render_rays(rays, bg, embs, nerfs, **extra, **kw)
+    if key is not None and z_fine is None:
+        _CACHE[key, arith.name] = out
+    return out
 
 
 def _distances(B, got, want, tag):
@@ -84,8 +92,10 @@ def _inputs(name, n, draw):
     return c, torch.from_numpy(rays_np), torch.from_numpy(bg_np), (BENCH_TAGS if draw == "bench" else None), 0
 
 
+# (the C5 shape -- 64 + 128 samples, two NeRFs, local + global chains in both passes -- on 256 of the shard's 1024 rays: the
+#  float64 oracle of that shape costs a minute per pass at 1024)
 CASES = [("r_moco_local", 4096, "bench"), ("r_moco_local", 4096, "case"), ("r_moco_global", 32, "golden"),
-         ("r_moco_global_fine", 1024, "case")]
+         ("r_moco_global_fine", 256, "case")]
 
 
 @pytest.mark.parametrize("name,n,draw", CASES, ids=[f"{a}-{b}-{c}" for a, b, c in CASES])
@@ -96,7 +106,7 @@ def test_fast_bf16_kernel_vs_the_oracle_of_its_arithmetic(M, B, name, n, draw):
     got, cap = _hip(M, c, rays, bg, "bf16", tags, seed)
     z_fine = cap["z_fine"].cpu() if c["M"] > 0 else None
     own = _oracle(B, B.BF16, c, rays, bg, tags, z_fine, seed)
-    f32 = _oracle(B, B.F32, c, rays, bg, tags, z_fine, seed)
+    f32 = _oracle(B, B.F32, c, rays, bg, tags, z_fine, seed, key=(name, n, draw))
     wrong = _oracle(B, replace(B.BF16, nof_xyz="plain"), c, rays, bg, tags, z_fine, seed)
     for tag in (["coarse", "fine"] if c["M"] > 0 else ["coarse"]):
         ps_own, l2_own, mr_own = _distances(B, got, own, tag)
@@ -112,7 +122,7 @@ def test_fast_bf16_kernel_vs_the_oracle_of_its_arithmetic(M, B, name, n, draw):
         assert ps_wrong <= ps_own - 10.0, (tag, ps_wrong, ps_own)
 
 
-X3_CASES = [("r_moco_local", 4096, "bench"), ("r_moco_local", 4096, "case"), ("r_moco_global_fine", 1024, "case")]
+X3_CASES = [("r_moco_local", 4096, "bench"), ("r_moco_local", 2048, "case"), ("r_moco_global_fine", 256, "case")]
 
 
 @pytest.mark.parametrize("name,n,draw", X3_CASES, ids=[f"{a}-{b}-{c}" for a, b, c in X3_CASES])
@@ -124,12 +134,13 @@ def test_bf16x3_kernel_vs_the_oracle_of_its_arithmetic(M, B, name, n, draw):
     got, cap = _hip(M, c, rays, bg, "bf16x3", tags, seed)
     z_fine = cap["z_fine"].cpu() if c["M"] > 0 else None
     own = _oracle(B, B.BF16X3, c, rays, bg, tags, z_fine, seed)
-    f32 = _oracle(B, B.F32, c, rays, bg, tags, z_fine, seed)
-    wrong = _oracle(B, replace(B.BF16X3, nerf_hidden="wsplit"), c, rays, bg, tags, z_fine, seed)
+    f32 = _oracle(B, B.F32, c, rays, bg, tags, z_fine, seed, key=(name, n, draw))
+    # (the wrong oracle -- the NeRF's hidden activations unsplit -- on the first batch only: it is 50 dB off everywhere)
+    wrong = _oracle(B, replace(B.BF16X3, nerf_hidden="wsplit"), c, rays, bg, tags, z_fine, seed) if draw == "bench" else None
     for tag in (["coarse", "fine"] if c["M"] > 0 else ["coarse"]):
         ps_own, l2_own, mr_own = _distances(B, got, own, tag)
         ps_f32, l2_f32, mr_f32 = _distances(B, got, f32, tag)
-        ps_wrong, _, _ = _distances(B, got, wrong, tag)
+        ps_wrong = _distances(B, got, wrong, tag)[0] if wrong is not None else float("-inf")
         print(f"{name} [{draw}] bf16x3 {tag}: PSNR-equiv to its own oracle {ps_own:.1f} dB (fp32 oracle {ps_f32:.1f}, NeRF hidden "
               f"activations unsplit {ps_wrong:.1f}); l2-rel " + " / ".join(f"{x:.1e}" for x in l2_own) + " (fp32 oracle "
               + " / ".join(f"{x:.1e}" for x in l2_f32) + "); max-rel " + " / ".join(f"{x:.1e}" for x in mr_own)

@@ -540,6 +540,58 @@ def test_gradients_when_the_loss_skips_outputs(M, R, name):
                                    fp32_bar=TOL if c.get("nof", "none") == "none" else None) >= 8
 
 
+@pytest.mark.parametrize("name", ["r_nerf_dir_fine_test", "r_moco_global_fine_test"])
+def test_test_time_pass_with_gradients(M, R, name):
+    """render_rays(test_time=True, N_importance > 0) under grad (rendering.py:290-294: the coarse pass returns opacity_coarse
+    only, from a sigma-only evaluation; the reference renders such passes under no_grad, but its signature allows gradients
+    and rounds 1-3 raised here).  Same keys as the reference; values 1e-4; gradients of a loss on opacity_coarse + the fine
+    outputs against the oracle's autograd (float64 truth, per-tensor noise floors), the coarse network's rgb branch left
+    without gradient exactly as torch autograd leaves it."""
+    c = dict(RENDER_CASES[name])
+    seed = int(load_golden(name)["meta_seed"])
+    n = 40
+    rays, bg = case_inputs(c, seed, n=n)
+    gt = torch.rand(n, 3, generator=torch.Generator().manual_seed(0))
+    embs, nerfs, kw = build_case(M, c, seed, device="cuda")
+    nets = list(nerfs) + (list(kw["nof_models"]) if kw["nof_models"] else [])
+    cap = {}
+    res = M.render_rays(rays.cuda(), bg.cuda(), embs, nerfs, _capture=cap, **kw)
+    assert list(res) == ["opacity_coarse", "rgb_fine", "depth_fine", "opacity_fine"] and res["opacity_coarse"].requires_grad
+    z_fine = cap["z_fine"].cpu()
+
+    def loss_fn(r):
+        return ((r["rgb_fine"] - gt.to(r["rgb_fine"])) ** 2).mean() + 0.3 * r["opacity_coarse"].square().mean() + 0.1 * r["depth_fine"].mean()
+
+    loss_fn(res).backward()
+
+    def oracle(dtype):
+        embs_o, nerfs_o, kw_o = build_case(R, c, seed)
+        nets_o = list(nerfs_o) + (list(kw_o["nof_models"]) if kw_o["nof_models"] else [])
+        for m in nets_o:
+            for k in m.p:
+                m.p[k] = m.p[k].to(dtype).clone().requires_grad_(True)
+        for e in list(embs_o) + list(kw_o["nof_embeddings"] or []):
+            if e is not None:
+                e.freq_bands = e.freq_bands.to(dtype)
+        torch.set_default_dtype(dtype)
+        try:
+            r = R.render_rays(rays.to(dtype), bg.to(dtype), embs_o, nerfs_o, _z_fine_override=z_fine.to(dtype), **kw_o)
+            loss = loss_fn(r)
+        finally:
+            torch.set_default_dtype(torch.float32)
+        flat = [(i, k) for i, m in enumerate(nets_o) for k in m.p]
+        g = torch.autograd.grad(loss, [nets_o[i].p[k] for i, k in flat], allow_unused=True)
+        return r, {f"{i}.{k}": v for (i, k), v in zip(flat, g)}
+
+    want, g32 = oracle(torch.float32)
+    _, g64 = oracle(torch.float64)
+    for k, v in want.items():
+        assert relerr(res[k].detach(), v.detach()) <= TOL, (k, relerr(res[k].detach(), v.detach()))
+    for k in ("xyz_encoding_final.weight", "extra_encoding.0.weight", "rgb.0.weight"):      # the coarse NeRF's rgb branch: unused
+        assert g32[f"0.{k}"] is None and dict(nerfs[0].named_parameters())[k].grad is None, k
+    assert _check_grads_vs_float64(nets, g32, g64, label=name + " (test_time)") >= 30
+
+
 def test_module_gradients(M, R):
     """NoF / Embedding called directly with grad (trainer_nof.py:111, trainer_moco_flow.py:153,185) against the oracle's
     CPU autograd; gradients w.r.t. the points of a module-level NoF call are not built and say so."""
