@@ -36,8 +36,10 @@ extern "C" {
  *     mf_render_workspace_bytes, mf_render_prepare, mf_loss_partials_backward, perturb arguments of mf_z_vals, mf_points_sigma_workspace_bytes, workspace arguments of mf_points_sigma_p
  * 13: MF_PREC_BF16X3 is the full three-product mode (own packed layout); mf_weight_grads_p, mf_weight_grads_scratch_bytes_p,
  *     mf_nerf_backward3 (+ mf_nerf_bwd3_packed_bytes, mf_nerf_pack_bwd3), MF_PREC_BF16X3 in mf_points_sigma_p and with the NeRF dump
- * 14: mf_embedding_forward_rows */
-#define MF_ABI_VERSION 14
+ * 14: mf_embedding_forward_rows
+ * 15: MF_PREC_BF16X3 packs the NoF in three-term operands (six products per k-step); mf_nof_backward3 (+ mf_nof_bwd3_packed_bytes,
+ *     mf_nof_pack_bwd3) */
+#define MF_ABI_VERSION 15
 
 enum {
   MF_OK = 0,
@@ -255,6 +257,17 @@ int32_t mf_nof_pack_bwd(const mf_nof_desc* d, void* packed, void* stream);
 int32_t mf_nof_backward(const mf_nof_desc* d, const void* packed_bwd, const mf_embedding* emb_xyz, int64_t P,
                         const float* pts, const float* acts, int64_t stride, const float* g_out,
                         float* gpre, float* g_pts, void* stream);
+/* mf_nof_backward in three bf16 products (ABI v15; csrc/mf_nofgrad_bf16.hip): the hidden contractions and the embedded-input
+ * layers on gradients and transposed weights as (hi, lo) bf16 pairs with fp32 accumulation, ReLU masks from the dump as in
+ * the fp32 kernel (no unit changes side), the transform's backward / head product / sin-cos chain rule in fp32.  Own packed
+ * stream (mf_nof_bwd3_packed_bytes / mf_nof_pack_bwd3); same arguments and outputs as mf_nof_backward; dump rows 16-byte
+ * aligned.  Replaces the same autograd range: models/rendering.py:49-83 + models/nof.py:69-82 under loss.backward()
+ * (trainer/base.py:188-197). */
+int64_t mf_nof_bwd3_packed_bytes(const mf_nof_desc* d);
+int32_t mf_nof_pack_bwd3(const mf_nof_desc* d, void* packed, void* stream);
+int32_t mf_nof_backward3(const mf_nof_desc* d, const void* packed_bwd3, const mf_embedding* emb_xyz, int64_t P,
+                         const float* pts, const float* acts, int64_t stride, const float* g_out,
+                         float* gpre, float* g_pts, void* stream);
 
 /* Fused point query: xyz (B,3) -> [backward NoF at image index ind] -> positional encoding -> NeRF
  * trunk -> raw sigma (B,), one launch.  Replaces the per-chunk module sequence forward_nof /

@@ -17,7 +17,7 @@ MF_ACT_RELU, MF_ACT_SOFTPLUS = 0, 1
 MF_F_SIGMA_ONLY, MF_F_CHAIN_LOCAL, MF_F_CHAIN_GLOBAL = 1, 2, 4
 MF_PREC_F32, MF_PREC_BF16, MF_PREC_BF16X3 = 0, 1, 2
 PRECISIONS = {"f32": MF_PREC_F32, "bf16": MF_PREC_BF16, "bf16x3": MF_PREC_BF16X3}
-MF_ABI_VERSION = 14
+MF_ABI_VERSION = 15
 
 LIB_PATH = os.environ.get("MOCOFLOW_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmocoflow_hip.so")   # (override: A/B builds)
 
@@ -113,6 +113,10 @@ SYMBOLS = {
     "mf_nof_pack_bwd": (C.c_int32, [C.POINTER(mf_nof_desc), _fp, _fp]),
     "mf_nof_backward": (C.c_int32, [C.POINTER(mf_nof_desc), _fp, C.POINTER(mf_embedding), C.c_int64, _fp, _fp, C.c_int64,
                                     _fp, _fp, _fp, _fp]),
+    "mf_nof_backward3": (C.c_int32, [C.POINTER(mf_nof_desc), _fp, C.POINTER(mf_embedding), C.c_int64, _fp, _fp, C.c_int64,
+                                    _fp, _fp, _fp, _fp]),
+    "mf_nof_bwd3_packed_bytes": (C.c_int64, [C.POINTER(mf_nof_desc)]),
+    "mf_nof_pack_bwd3": (C.c_int32, [C.POINTER(mf_nof_desc), _fp, _fp]),
     "mf_composite_backward": (C.c_int32, [_fp, C.c_int64, C.c_int64, C.c_int32, _fp, _fp, _fp, C.c_int32, _fp, _fp, _fp, _fp,
                                           _fp, _fp]),
     "mf_image_compose": (C.c_int32, [_fp, _fp, C.c_int64, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),

@@ -52,6 +52,18 @@ def set_dx_precision(p: str):
     DX_PRECISION = p
 
 
+def nof_backward_hip(m, emb_desc, P, pts, acts, stride, g_out, gpre, g_pts):
+    """One NoF evaluation's backward launch: mf_nof_backward3 (three bf16 products, set_dx_precision("bf16x3"), the default)
+    or mf_nof_backward (exact-fp32 MFMA).  Same arguments, same outputs (gpre rows + the point gradient)."""
+    dev = pts.device
+    x3 = DX_PRECISION == "bf16x3" and stride % 4 == 0 and acts.data_ptr() % 16 == 0 and gpre.data_ptr() % 16 == 0
+    desc, buf = m.packed_bwd3() if x3 else m.packed_bwd()
+    fn, what = (L.lib().mf_nof_backward3, "mf_nof_backward3") if x3 else (L.lib().mf_nof_backward, "mf_nof_backward")
+    with torch.cuda.device(dev):
+        L.check(fn(C.byref(desc), buf.data_ptr(), C.byref(emb_desc), P, pts.data_ptr(), acts.data_ptr(), stride,
+                   g_out.data_ptr(), gpre.data_ptr(), L.ptr(g_pts), L.current_stream(dev)), what)
+
+
 def nerf_backward_hip(m, g_out, acts, rgbsig, want_emb=False):
     """mf_nerf_backward_x: (gpre (P,stride) in the dump's layout, ghead (P,4), g_emb (P,64) | None) from
     dL/d[rgb, sigma]; g_emb = the gradient of the embedded input, produced by the same launch."""
@@ -273,15 +285,11 @@ class NofModule(torch.autograd.Function):
         names = [n for n, _ in m.named_parameters()]
         req = {n: p.requires_grad for n, p in m.named_parameters()}
         with torch.no_grad():
-            desc, buf = m.packed_bwd()
             noemb = L.mf_embedding()
             noemb.in_channels, noemb.n_freqs = 3, 0               # no point gradient is requested
             g_out = g_out.contiguous().float()
             gpre = torch.empty(((B + 127) // 128 * 128, stride), device=dev, dtype=torch.float32)
-            with torch.cuda.device(dev):
-                L.check(L.lib().mf_nof_backward(C.byref(desc), buf.data_ptr(), C.byref(noemb), B, pts.data_ptr(),
-                                                acts.data_ptr(), stride, g_out.data_ptr(), gpre.data_ptr(), None,
-                                                L.current_stream(dev)), "mf_nof_backward")
+            nof_backward_hip(m, noemb, B, pts, acts, stride, g_out, gpre, None)
             grads = _nof_param_grads(m, gpre[:B], acts, F.pad(x, (0, 80 - x.shape[1])), req)
         return (None, None, None) + tuple(grads[n] for n in names)
 
@@ -323,15 +331,10 @@ class NofPoints(torch.autograd.Function):
         grads = {n: None for n in names}
         need_pts = ctx.needs_input_grad[4]
         with torch.no_grad():
-            desc, buf = m.packed_bwd()
             g_out = g_out.contiguous().float()
             gpre = torch.empty(((P + 127) // 128 * 128, stride), device=dev, dtype=torch.float32)
             g_pts = torch.empty((P, 3), device=dev, dtype=torch.float32) if need_pts else None
-            with torch.cuda.device(dev):
-                L.check(L.lib().mf_nof_backward(C.byref(desc), buf.data_ptr(), C.byref(ctx.ex), P, pts.data_ptr(),
-                                                acts.data_ptr(), stride, g_out.data_ptr(), gpre.data_ptr(),
-                                                g_pts.data_ptr() if need_pts else None, L.current_stream(dev)),
-                        "mf_nof_backward")
+            nof_backward_hip(m, ctx.ex, P, pts, acts, stride, g_out, gpre, g_pts)
             grads = _nof_param_grads(m, gpre[:P], acts, emb, req)
         return (None, None, None, None, g_pts) + tuple(grads[n] for n in names)
 
@@ -415,18 +418,13 @@ class NofPointsDumped(torch.autograd.Function):
         if g_out is None:
             return (None,) * (8 + len(names))
         with torch.no_grad():
-            desc, buf = m.packed_bwd()
             g_out = g_out.contiguous().float()
             if ctx.sink is not None:
                 gpre = ctx.sink.plane(ctx.sink_plane)                 # (P, stride), P % 128 == 0
             else:
                 gpre = torch.empty(((P + 127) // 128 * 128, stride), device=dev, dtype=torch.float32)
             g_pts = torch.empty((P, 3), device=dev, dtype=torch.float32) if need_pts else None
-            with torch.cuda.device(dev):
-                L.check(L.lib().mf_nof_backward(C.byref(desc), buf.data_ptr(), C.byref(ctx.ex), P, pts.data_ptr(),
-                                                acts.data_ptr(), stride, g_out.data_ptr(), gpre.data_ptr(),
-                                                g_pts.data_ptr() if need_pts else None, L.current_stream(dev)),
-                        "mf_nof_backward")
+            nof_backward_hip(m, ctx.ex, P, pts, acts, stride, g_out, gpre, g_pts)
             if ctx.sink is not None:
                 return (None,) * 7 + (g_pts,) + (None,) * len(names)
             grads = _nof_param_grads(m, gpre[:P], acts, emb, req, slot_order=True)

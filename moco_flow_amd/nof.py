@@ -38,6 +38,7 @@ class NoF(nn.Module):
         self._packed_bf16 = PackedWeights()
         self._packed_x3 = PackedWeights()
         self._packed_bwd = PackedWeights()
+        self._packed_bwd3 = PackedWeights()
 
     def _build_desc(self):
         if self.extra_feat_type == "latent_code":
@@ -67,7 +68,7 @@ class NoF(nn.Module):
 
     def invalidate_packed(self):
         """Drop the packed-weight caches (needed only after in-place edits through ``param.data``)."""
-        for c in (self._packed, self._packed_bf16, self._packed_x3, self._packed_bwd):
+        for c in (self._packed, self._packed_bf16, self._packed_x3, self._packed_bwd, self._packed_bwd3):
             c.invalidate()
 
     def packed_bwd(self):
@@ -75,6 +76,12 @@ class NoF(nn.Module):
         lib = L.lib()
         return self._packed_bwd.get(self, self._build_desc, lambda d, _p: lib.mf_nof_bwd_packed_bytes(d),
                                     lambda d, _p, buf, st: lib.mf_nof_pack_bwd(d, buf, st), "NoF backward", "bwd")
+
+    def packed_bwd3(self):
+        """(descriptor, transposed (hi, lo) bf16 fragment stream) for mf_nof_backward3."""
+        lib = L.lib()
+        return self._packed_bwd3.get(self, self._build_desc, lambda d, _p: lib.mf_nof_bwd3_packed_bytes(d),
+                                     lambda d, _p, buf, st: lib.mf_nof_pack_bwd3(d, buf, st), "NoF backward (bf16x3)", "bwd3")
 
     def packed(self, precision=L.MF_PREC_F32):
         lib = L.lib()

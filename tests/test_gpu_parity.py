@@ -1338,7 +1338,7 @@ def test_embedding_rows_is_embed_repeat_pad(M):
 
 
 @pytest.mark.parametrize("quat", [True, False])
-def test_nof_backward_vs_oracle(M, R, quat):
+def test_nof_backward_vs_oracle(M, R, quat, wgrad):
     """One NoF evaluation on points (rendering.py:49-83 + nof.py:69-82): HIP forward-with-dump / backward node
     (autograd.NofPoints) against the oracle's CPU autograd of nof_inference on the same points: output, every
     parameter gradient and d/d point to 1e-4 (quaternion head: kornia restated, like the forward)."""
@@ -1442,7 +1442,7 @@ def test_explicit_nerf_backward_unit(M, R, n_rays, wgrad):
 
 
 @pytest.mark.parametrize("quat,n_rays,S", [(True, 40, 64), (False, 40, 64), (True, 3, 37), (True, 1, 1)])
-def test_nof_points_backward_unit(M, R, quat, n_rays, S):
+def test_nof_points_backward_unit(M, R, quat, n_rays, S, wgrad):
     """autograd.NofPoints (mf_nof_points_dump + mf_nof_backward + mf_weight_grads) against the oracle's CPU autograd of
     the same evaluation (nof_inference: rendering.py:49-83 + nof.py:69-82) on the same points: output to 1e-5,
     parameter and point gradients to 1e-4; ragged sample counts."""
@@ -1615,7 +1615,7 @@ def test_nerf_backward_other_shapes(M, R, D, skips, extra, extra_dim):
 
 
 @pytest.mark.parametrize("D,skips,quat", [(3, [1], True), (5, [], False), (6, [5], True), (2, [], True)])
-def test_nof_backward_other_shapes(M, R, D, skips, quat):
+def test_nof_backward_other_shapes(M, R, D, skips, quat, wgrad):
     """NofPoints on depths / skip positions other than the configs' 4x128 / skip 2 (default nn.Linear init), against the
     oracle's CPU autograd."""
     from moco_flow_amd import autograd as A
@@ -1674,7 +1674,7 @@ def test_training_gradients_are_reproducible(M, name):
 
 
 @pytest.mark.parametrize("quat,B", [(True, 1000), (False, 333)])
-def test_nof_module_training_call(M, R, quat, B):
+def test_nof_module_training_call(M, R, quat, B, wgrad):
     """NoF(inputs, xyz) on data points with only the parameters requiring grad (trainer_nof.py:85-125, the
     stage-2 step; trainer_moco_flow.py:159-187): autograd.NofModule (mf_nof_forward_dump + mf_nof_backward
     + mf_weight_grads) against the oracle's CPU autograd of the same call, values 1e-5, gradients 1e-4."""
