@@ -1234,7 +1234,7 @@ def test_nerf_backward_vs_oracle_on_dumped_points(M, R):
         emb_in = pad_to(embs[0](p["xyz_in"]), 63)
         extra_in = pad_to(torch.repeat_interleave(embs[1](ind.contiguous()), S, dim=0), 5)
     gout = torch.randn(n_rays * S, 4, device="cuda")
-    out = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, embs[0], xin, *nerf.parameters())
+    out = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, embs[0], xin, False, *nerf.parameters())
     out.backward(gout)
     # oracle, CPU, on the kernel's dumped points
     x_o = p["xyz_in"].cpu().clone().requires_grad_(True)
@@ -1425,7 +1425,7 @@ def test_explicit_nerf_backward_unit(M, R, n_rays, wgrad):
     for q in nerf.rgb.parameters():
         q.requires_grad_(False)
     gout = torch.randn(n_rays * S, 4, device="cuda")
-    out = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, embs[0], xin, *nerf.parameters())
+    out = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, embs[0], xin, False, *nerf.parameters())
     out.backward(gout)
     x2 = p["xyz_in"].cpu().clone().requires_grad_(True)
     e_ind = O.pad_to(torch.repeat_interleave(O.embed(embs[1], rays[:, 8:9].cpu()), S, dim=0), 5)
@@ -1601,7 +1601,7 @@ def test_nerf_backward_other_shapes(M, R, D, skips, extra, extra_dim):
             extra_in = pad_to(torch.repeat_interleave(embs[2](rays[:, 3:6].contiguous()), S, dim=0), extra_dim)
             extra_o = O.pad_to(torch.repeat_interleave(O.embed(embs[2], rays[:, 3:6].cpu()), S, dim=0), extra_dim)
     gout = torch.randn(n_rays * S, 4, device="cuda")
-    out = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, embs[0], xin, *nerf.parameters())
+    out = A.NerfSamples.apply(nerf, p["acts"], p["rgbsig"], emb_in, extra_in, embs[0], xin, False, *nerf.parameters())
     out.backward(gout)
     x2 = p["xyz_in"].cpu().clone().requires_grad_(True)
     full = O.pad_to(O.embed(embs[0], x2), 63)
