@@ -832,14 +832,16 @@ MF_D void nof_embed_t(u32x4 (&xhi)[kKsNofXyz], u32x4 (&xmid)[kKsNofXyz], u32x4 (
 }
 
 
-// ================================================================== MF_PREC_BF16X3 (the accuracy mode of the bf16 pipe)
-// EVERY matrix product of both networks as a two-term bf16 split of activations AND weights, x = hi + lo, three products
-// hi*hi + hi*lo + lo*hi with fp32 accumulation (16 mantissa bits per operand: the dropped lo*lo term is 2^-16 relative),
-// the sigma / rgb heads as fp32 dot products on the fp32 accumulators inside the epilogue of the layer in front of them,
-// the NoF's image index as the exact fp32 per-ray bias.  tools/bf16_emulate.py ("x3full"): 98-108 dB and l2 <= 4e-5
-// against the fp32 oracle through the MoCo chains where the fast mode gives 38-51 dB -- fp32-class results at three
-// bf16 matrix instructions per fp32 one (the fp32 pipe costs sixteen).  Splitting only parts does not get there: the NoF
-// alone 47-60 dB, + the NeRF's trunk 63-72 dB (round 3's first bf16x3 was the former).
+// ================================================================== MF_PREC_BF16X3 (the contract mode of the bf16 pipe)
+// EVERY matrix product of the NeRF as a two-term bf16 split of activations AND weights, x = hi + lo, three products
+// hi*hi + hi*lo + lo*hi with fp32 accumulation (16 mantissa bits per operand: the dropped lo*lo term is 2^-16 relative);
+// every product of the NoFs as a THREE-term split (hi, mid, lo: 24 mantissa bits, six products per k-step, template
+// parameter T below) -- their output point feeds sin(512 x) of the canonical encoding, where the 2^-17 of two terms is 1.5e-4
+// of the rendered ray (oracle/bf16_ref.py); the sigma / rgb heads as fp32 dot products on the fp32 accumulators inside the
+// epilogue of the layer in front of them, the NoF's image index as the exact fp32 per-ray bias.  Measured through the MoCo
+// chains at 4096 rays: 111-114 dB, max-rel <= 3.1e-5 against the fp32 oracle on both weight draws (the fast mode: 38-51 dB) --
+// fp32-class results at three / six bf16 matrix instructions per fp32 one (the fp32 pipe costs sixteen).  Splitting only parts
+// does not get there: the NoF alone in two terms 47-60 dB, + the NeRF's trunk 63-72 dB (round 3's first bf16x3 was the former).
 //
 // Registers: the (hi, lo) activations of a 256-wide layer are 128 registers per lane, its output as many: more than the
 // 256 of a wave at two waves per SIMD.  The x3 kernels therefore run ONE wave per SIMD (workgroup = 4 waves = 128
