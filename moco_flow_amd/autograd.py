@@ -52,6 +52,12 @@ def set_dx_precision(p: str):
     DX_PRECISION = p
 
 
+def nof_dump_stride(m):
+    """Floats per row of a NoF evaluation's dump: [h_1 .. h_D | T padded to 16 | the layers' ReLU bit rows, 4 words each].  The
+    bit rows are what mf_nof_backward3 reads instead of the activations (the forward writes them when the row has room)."""
+    return m.D * m.W + 16 + 4 * m.D
+
+
 def nof_backward_hip(m, emb_desc, P, pts, acts, stride, g_out, gpre, g_pts):
     """One NoF evaluation's backward launch: mf_nof_backward3 (three bf16 products, set_dx_precision("bf16x3"), the default)
     or mf_nof_backward (exact-fp32 MFMA).  Same arguments, same outputs (gpre rows + the point gradient)."""
@@ -262,7 +268,7 @@ class NofModule(torch.autograd.Function):
     def forward(ctx, m, inputs, xyz, *params):
         B, dev = inputs.shape[0], inputs.device
         desc, buf = m.packed()
-        stride = m.D * m.W + 16
+        stride = nof_dump_stride(m)
         x = inputs.detach().float()
         if x.stride(1) != 1:
             x = x.contiguous()
@@ -306,7 +312,7 @@ class NofPoints(torch.autograd.Function):
         P, dev = pts.shape[0], pts.device
         pts = pts.detach().contiguous().float()
         desc, buf = m.packed()
-        stride = m.D * m.W + 16
+        stride = nof_dump_stride(m)
         out = torch.empty((P, 3), device=dev, dtype=torch.float32)
         acts = torch.empty((P, stride), device=dev, dtype=torch.float32)
         emb = torch.empty((P, 80), device=dev, dtype=torch.float32)

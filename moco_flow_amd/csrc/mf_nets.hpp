@@ -177,10 +177,13 @@ MF_D void quat_transform(const float (&T)[9], const float (&xyz)[3], float (&out
 // Neural motion flow on this wave's 16 samples; emb = [xyz block ; ind block] (kStepsNofIn).
 // DUMP (training forward): `drow` = this lane's sample row [h_1 .. h_D | T (9 | 3) zero-padded to 16] (nullptr: skip),
 // the layout mf_nof_backward / mf_weight_grads read (mf_nofgrad.hip).
+// `masks` (ABI v15, uniform): the row has room behind T for the layers' ReLU BIT rows -- 4 words per layer at float offset
+// D W + 16 (trunk_layer's mask_row: byte 4 t + g = this lane's eight outputs of panel t) -- what mf_nof_backward3 reads
+// instead of the 512 bytes of activations per layer.
 template <bool DUMP = false>
 MF_D void nof_eval(const NetDev& net, const float (&emb)[kStepsNofIn], const float (&xyz)[3], Stream& st,
                    CarryT<kPD>& carry, const LaneId& id, const NextLayer& follow, float (&out)[3],
-                   float* drow = nullptr) {
+                   float* drow = nullptr, bool masks = false) {
   constexpr int NK = 8;
   f32x4 act[NK];
 #pragma unroll
@@ -191,7 +194,8 @@ MF_D void nof_eval(const NetDev& net, const float (&emb)[kStepsNofIn], const flo
   for (int l = 0; l < D; ++l) {
     const bool last = l == D - 1;
     trunk_layer<NK, kStepsNofIn, DUMP>(net, l, act, emb, st, carry, id, last ? follow : next_trunk(net, l + 1),
-                                       drow ? drow + l * net.L.W : nullptr);
+                                       drow ? drow + l * net.L.W : nullptr,
+                                       (DUMP && drow && masks) ? reinterpret_cast<unsigned*>(drow + D * net.L.W + 16) + 4 * l : nullptr);
   }
   const uint32_t wo = net.res_lds + net.L.off_head_w * 4, bo = net.res_lds + net.L.off_head_b * 4;
   float T[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};

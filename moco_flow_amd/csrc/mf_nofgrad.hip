@@ -92,10 +92,13 @@ __global__ __launch_bounds__(kThreads, 2) void nof_points_dump_kernel(NofDumpPar
 #pragma unroll
     for (int t = 0; t < 8; ++t) act[t] = f32x4{0.f, 0.f, 0.f, 0.f};
     st.keep2 = 0;
+    // (rows with room behind T also get the layers' ReLU bit rows: nof_eval's `masks`, mf_nets.hpp)
+    const bool masks = p.stride >= (long long)D * kNofW + kNofHeadPad + 4 * D;
     for (int l = 0; l < D; ++l)
       trunk_layer<8, kStepsNofIn, true>(net, l, act, emb, st, carry, id,
                                                l == D - 1 ? follow_of(net) : next_trunk(net, l + 1),
-                                               drow ? drow + l * kNofW : nullptr);
+                                               drow ? drow + l * kNofW : nullptr,
+                                               (drow && masks) ? reinterpret_cast<unsigned*>(drow + D * kNofW + kNofHeadPad) + 4 * l : nullptr);
     const uint32_t wo = net.res_lds + net.L.off_head_w * 4, bo = net.res_lds + net.L.off_head_b * 4;
     float T[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, o[3];
     if (net.L.n_head == 9) {

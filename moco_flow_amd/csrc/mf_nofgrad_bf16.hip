@@ -88,12 +88,19 @@ struct Nof3Params {
   uint32_t par_off, ring_off, buf_bytes;
 };
 
-// value of accumulator register r, masked by the forward activation (m: the four float4 of this lane's activations of the tile)
-MF_D float n3_val(const f32x16& acc, const f32x4 (&m)[4], int r) { return m[r >> 2][r & 3] > 0.f ? acc[r] : 0.f; }
+// value of accumulator register r, masked by the forward activation (m: the four float4 of this lane's activations of the tile;
+// BITS: m[0][0] carries the tile's mask word shifted by 8 h -- row 8 q + 4 h + i = feature f of the tile sits at bit
+// relu_mask_bit(f) = 8 h + {0, 16, 4, 20}[q] + i, mf_core.hpp)
+template <bool BITS>
+MF_D float n3_val(const f32x16& acc, const f32x4 (&m)[4], int r) {
+  if (BITS) return ((__builtin_bit_cast(unsigned, m[0][0]) >> (((r >> 2) & 1) * 16 + ((r >> 2) >> 1) * 4 + (r & 3))) & 1u) ? acc[r] : 0.f;
+  return m[r >> 2][r & 3] > 0.f ? acc[r] : 0.f;
+}
 
 // One backward layer of the chain: (out, outlo) <- split(mask * (Wt (in, inlo))), the fp32 values to grow[32 t + ...].
 // mrow / grow: this lane's dump row / gradient row of the layer + 4 (lane >> 5).  OUT: the result is an operand again.
-template <bool OUT, class ST>
+// BITS: `mrow` points at the layer's 4 mask words of this lane's sample instead (one 4-byte load per tile).
+template <bool OUT, bool BITS, class ST>
 MF_D void nof3_layer(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[8], const u32x4 (&inlo)[8], u32x4 (&out)[8],
                      u32x4 (&outlo)[8], uint32_t zero_off, const Next& nxt, const float* mrow, float* grow) {
   constexpr int NT = 4, KHID = 8, NG = 2 * KHID, NM = 3 * KHID, kSteps = 16;
@@ -102,7 +109,7 @@ MF_D void nof3_layer(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[8]
   auto step = [&](const f32x16& acc, const f32x4 (&m)[4], int sidx, int t) __attribute__((always_inline)) {
     const int u = sidx >> 1, w = u & 3, r = u < 4 ? 2 * u : 8 + 2 * (u - 4);
     if (!OUT) return;
-    const float v0 = n3_val(acc, m, r), v1 = n3_val(acc, m, r + 1);
+    const float v0 = n3_val<BITS>(acc, m, r), v1 = n3_val<BITS>(acc, m, r + 1);
     u32x4& hv = u < 4 ? out[2 * t] : out[2 * t + 1];
     if (!(sidx & 1)) {
       unsigned hi = pack_bf16x2(v0, v1);
@@ -118,15 +125,19 @@ MF_D void nof3_layer(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[8]
   auto store = [&](const f32x16& acc, const f32x4 (&m)[4], int t, int q) __attribute__((always_inline)) {
     f32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = n3_val(acc, m, 4 * q + i);
+    for (int i = 0; i < 4; ++i) v[i] = n3_val<BITS>(acc, m, 4 * q + i);
     *reinterpret_cast<f32x4*>(grow + 32 * t + 8 * q) = v;
   };
   auto run = [&](auto tc) __attribute__((always_inline)) {
     constexpr int t = decltype(tc)::value;
     const Ahead two{t + 2 < NT ? NG : (t == NT - 2 ? nxt.groups : nxt.groups2),
                     t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), 0, nullptr, t + 2 < NT ? NG : -1, -1};
+    if constexpr (BITS) {                                      // this tile's mask word: in flight across its MFMAs
+      hm[0][0] = __builtin_bit_cast(float, reinterpret_cast<const unsigned*>(mrow)[t] >> (8 * id.h));
+    } else {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) hm[q] = *reinterpret_cast<const f32x4*>(mrow + 32 * t + 8 * q);   // in flight across the tile's MFMAs
+      for (int q = 0; q < 4; ++q) hm[q] = *reinterpret_cast<const f32x4*>(mrow + 32 * t + 8 * q);
+    }
     constexpr int tp = t > 0 ? t - 1 : 0;
     auto gap = [&](int m) __attribute__((always_inline)) {
       if (t == 0) return;
@@ -137,7 +148,7 @@ MF_D void nof3_layer(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[8]
     f32x16 acc;
     // VM operations younger than the previous panel's last piece at this tile's barrier: the four row stores that closed the
     // previous tile (tile 0: the layer in front; none behind tile 0) + this tile's four mask loads
-    constexpr int KEEP = (t == 1 ? 0 : 4) + 4;
+    constexpr int KEEP = (t == 1 ? 0 : 4) + (BITS ? 1 : 4);
     mma_tile_x<0, KHID, 2, true, KEEP, true>(st, id, carry, in, inlo, in, inlo, zero_off, two, acc, gap);
     st.advance();
     pend = acc;
@@ -176,6 +187,9 @@ MF_D void n3_split8(const f32x4& v0, const f32x4& v1, u32x4& hi4, u32x4& lo4) {
   }
 }
 
+// BITS: the dump rows carry the layers' ReLU bit rows behind T (4 words per layer at float offset D W + 16: written by the
+// forward when the row has room, nof_eval's `masks`) -- the chain then reads 16 bytes instead of 512 per layer and point.
+template <bool BITS>
 __global__ __launch_bounds__(256, 1) void nof_backward_kernel_x3(const Nof3Params p) {
   constexpr int NW = 4, TILE = NW * kWaveSamples;
   const Lane id;
@@ -201,7 +215,9 @@ __global__ __launch_bounds__(256, 1) void nof_backward_kernel_x3(const Nof3Param
     const long long ss = valid ? s : p.P - 1;
     const float x[3] = {p.pts[ss * 3 + 0], p.pts[ss * 3 + 1], p.pts[ss * 3 + 2]};
     const float go[3] = {p.g_out[ss * 3 + 0], p.g_out[ss * 3 + 1], p.g_out[ss * 3 + 2]};
-    const float* arow = p.acts + ss * p.stride + 4 * id.h;
+    // "activation rows": BITS: the sample's mask words (4 per layer); else the dump rows + 4 h
+    const float* arow = BITS ? p.acts + ss * p.stride + (long long)D * kNW + 16 : p.acts + ss * p.stride + 4 * id.h;
+    constexpr int LW = BITS ? 4 : kNW;                           // row elements per layer
     float* grow = p.gpre + s * p.stride + 4 * id.h;            // rows up to round_up(P, 128) exist
     float T[9], dT[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, dx[3];
     {
@@ -225,7 +241,7 @@ __global__ __launch_bounds__(256, 1) void nof_backward_kernel_x3(const Nof3Param
     // d z_{D-1} = (W_head^T d T) [h_D > 0] as the (hi, lo) operands of 8 k-steps: slot e of step ks = feature 16 ks + hid_perm2(h, e)
     u32x4 ah[8], al[8], bh[8], bl[8];
     {
-      const float* hrow = arow + (long long)(D - 1) * kNW;
+      const float* hrow = arow + (long long)(D - 1) * LW;
       float* ghrow = grow + (long long)(D - 1) * kNW;
 #pragma unroll
       for (int ks = 0; ks < 8; ++ks) {
@@ -242,7 +258,14 @@ __global__ __launch_bounds__(256, 1) void nof_backward_kernel_x3(const Nof3Param
               for (int r = 0; r < 4; ++r) acc[r] = __builtin_fmaf(w[r], dT[c], acc[r]);
             }
           }
-          const f32x4 h4 = *reinterpret_cast<const f32x4*>(hrow + f);
+          f32x4 h4;
+          if constexpr (BITS) {                                  // features (f & 31) + 4 h + r of word f / 32
+            const unsigned wv = reinterpret_cast<const unsigned*>(hrow)[f >> 5];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) h4[r] = ((wv >> relu_mask_bit((f & 31) + 4 * id.h + r)) & 1u) ? 1.f : 0.f;
+          } else {
+            h4 = *reinterpret_cast<const f32x4*>(hrow + f);
+          }
 #pragma unroll
           for (int r = 0; r < 4; ++r) g2[c2][r] = h4[r] > 0.f ? acc[r] : 0.f;
           *reinterpret_cast<f32x4*>(ghrow + f) = g2[c2];
@@ -252,7 +275,7 @@ __global__ __launch_bounds__(256, 1) void nof_backward_kernel_x3(const Nof3Param
     }
     // chain: d z_{l-1} = (W_l[:, hidden]^T d z_l) [h_l > 0],  l = D-1 .. 1   (a -> b, copied back)
     for (int l = D - 1; l >= 1; --l) {
-      nof3_layer<true>(st, id, carry, ah, al, bh, bl, zero_off, n16, arow + (long long)(l - 1) * kNW, grow + (long long)(l - 1) * kNW);
+      nof3_layer<true, BITS>(st, id, carry, ah, al, bh, bl, zero_off, n16, arow + (long long)(l - 1) * LW, grow + (long long)(l - 1) * kNW);
 #pragma unroll
       for (int t = 0; t < 8; ++t) { ah[t] = bh[t]; al[t] = bl[t]; }
     }
@@ -424,8 +447,11 @@ extern "C" int32_t mf_nof_backward3(const mf_nof_desc* d, const void* packed_bwd
   // during the VALU phases around the chain), so the persistent grid is two per CU
   const long long slots = 2LL * device_cus();
   const int grid = (int)(ntiles < slots ? ntiles : slots);
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(bf::nof_backward_kernel_x3), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  // the forward wrote the layers' ReLU bit rows when the row has room for them (nof_eval's `masks`)
+  const bool bits = stride >= (int64_t)d->D * bf::kNW + 16 + 4 * d->D;
+  void (*kern)(const bf::Nof3Params) = bits ? bf::nof_backward_kernel_x3<true> : bf::nof_backward_kernel_x3<false>;
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(MF_E_LAUNCH, "mf_nof_backward3: cannot reserve %u bytes of LDS", lds);
-  hipLaunchKernelGGL(bf::nof_backward_kernel_x3, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(256), lds, static_cast<hipStream_t>(stream), p);
   return check_launch("mf_nof_backward3");
 }

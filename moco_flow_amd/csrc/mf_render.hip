@@ -175,7 +175,8 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
             }
             st.keep2 = 0;
           }
-          nof_eval<DUMP>(net, emb, cur, st, carry, id, follow, out, nof_row);
+          nof_eval<DUMP>(net, emb, cur, st, carry, id, follow, out, nof_row,
+                         DUMP && p.dump_nof_stride >= (long long)net.L.n_trunk * net.L.W + 16 + 4 * net.L.n_trunk);
           if constexpr (DUMP) {
             const Where v = where();
             if (v.valid && p.dump_nof_acts && id.g == 0) {
@@ -221,8 +222,9 @@ __global__ __launch_bounds__(kThreads, 2) void render_kernel(RenderParams p) {
         }
         if constexpr (DUMP) {
           if (w.valid && p.dump_acts) dump_row = p.dump_acts + (w.ray * S + w.si) * p.dump_stride;
-          if constexpr (!MOCO)    // (the chain kernel is at its register limit: bit masks are written by NeRF-only passes)
-            if (p.dump_mask) mask_row = p.dump_mask + (w.ray * S + w.si) * p.dump_mask_stride;   // (uniformly non-null when asked for)
+          // (round 4: the chain kernel writes them too -- one more spilled dword in its prologue, two scratch reloads per tile;
+          //  the NeRF's dX chain under NoF then reads 32 bytes instead of 1 KiB per layer and sample)
+          if (p.dump_mask) mask_row = p.dump_mask + (w.ray * S + w.si) * p.dump_mask_stride;   // (uniformly non-null when asked for)
         }
       }
       st.tl.stamp(4, id);
@@ -468,7 +470,6 @@ static int32_t render_entry(const mf_render_args* a, void* stream, bool prepare_
     return fail(MF_E_INVALID, "mf_render_pass: dump_stride %lld too small", (long long)a->dump_stride);
   p.dump_acts = a->dump_acts; p.dump_stride = a->dump_stride; p.dump_rgbsigma = a->dump_rgbsigma; p.dump_xyz = a->dump_xyz;
   if (a->dump_mask) {
-    if (moco) return fail(MF_E_UNSUPPORTED, "mf_render_pass: dump_mask is written by passes without NoF");
     if (!a->dump_acts || a->dump_mask_stride < (int64_t)(p.nerf.L.n_trunk + 1) * 8)
       return fail(MF_E_INVALID, "mf_render_pass: dump_mask needs dump_acts and dump_mask_stride >= 8 (D + 2) words");
     p.dump_mask = a->dump_mask; p.dump_mask_stride = a->dump_mask_stride;

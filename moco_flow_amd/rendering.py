@@ -159,7 +159,7 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
         a.dump_stride = stride
         a.dump_rgbsigma = alloc("rgbsig", (N * S, 4))
         a.dump_xyz = alloc("xyz_in", (N * S, 3))
-        if not sigma_only and prec == L.MF_PREC_F32 and A.DX_PRECISION == "bf16x3" and nof_models is None:
+        if not sigma_only and prec == L.MF_PREC_F32 and A.DX_PRECISION == "bf16x3":
             # the ReLU bit mask of the dumped activations: all the three-product dX chain needs of them (32 bytes instead
             # of 1 KiB per layer and sample); travels with the dump tensor
             mw = (nerf.D + 2) * 8
@@ -173,7 +173,7 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
             out["nof_plane"] = [order.index(k) for k in range(steps)]
             for k in range(steps):
                 a.dump_nof_plane[k] = out["nof_plane"][k]
-            nstride = nof_models[0].D * nof_models[0].W + 16
+            nstride = A.nof_dump_stride(nof_models[0])
             a.dump_nof_acts = alloc("nof_acts", (steps, N * S, nstride))
             a.dump_nof_stride = nstride
             a.dump_nof_emb = alloc("nof_emb", (steps, N * S, 80))
