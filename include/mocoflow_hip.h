@@ -363,9 +363,10 @@ typedef struct mf_render_args {
    * is constant along a ray).  mf_render_prepare fills it (one small launch); mf_render_pass reads it as those layers'
    * initial accumulator values.  Ignored (may be NULL) otherwise. */
   void* workspace; int64_t workspace_bytes;
-  /* ReLU bit mask of the NeRF's dumped activations (ABI v13; with dump_acts, passes without NoF; NULL = none): dump_mask (N*S, dump_mask_stride
-   * >= 8 (D + 2) words): word 8 l + t covers outputs 32 t .. 32 t + 31 of layer l, output 32 t + f at bit
-   * (f < 16 ? 8 (f / 4) + f % 4 : 8 ((f - 16) / 4) + 4 + f % 4) -- the forward kernels' lane order -- for the trunk layers
+  /* ReLU bit mask of the NeRF's dumped activations (ABI v13; with dump_acts; ABI v15: passes with NoF too; NULL = none): dump_mask (N*S, dump_mask_stride
+   * >= 8 (D + 2) words): layer l owns words 8 l .. 8 l + 7; output 32 t + f (f < 32) of the layer sits in word
+   * 8 l + 4 (t / 4) + (f % 16) / 4 at bit 8 (t % 4) + 4 (f / 16) + f % 4 (ABI v15: the forward kernels' lane order, one 4-byte store per lane
+   * and four 32-row panels; v13 / v14 stored a byte per panel) -- for the trunk layers
    * l = 0 .. D-1 and extra_encoding (l = D + 1, 4 words; l = D, xyz_encoding_final, is not written: no activation) -- what
    * mf_nerf_backward3 needs of the activations: 32 bytes instead of 1 KiB per layer and sample. */
   uint32_t* dump_mask; int64_t dump_mask_stride;

@@ -99,14 +99,15 @@ struct Bwd3Params {
 };
 
 // value of accumulator register r of tile t: + the sigma term, masked by the forward activation
-// (BITS: m[0][0] carries the tile's mask word shifted by 8 h: row 8 q + 4 h + i = feature f of the tile sits at bit
-//  relu_mask_bit(f) = 8 h + {0, 16, 4, 20}[q] + i, mf_core.hpp)
+// (BITS: m[0][0] carries the two mask bytes of this lane half for the tile -- lane groups g = h (low byte) and g = 2 + h of the
+//  forward's panel t, relu_mask_word / relu_mask_shift in mf_core.hpp: row 8 q + 4 h + i of the tile sits at bit
+//  8 (q & 1) + 4 (q >> 1) + i)
 template <bool MASK, bool SIG, bool BITS>
 MF_D float b3_val(const f32x16& acc, const f32x4 (&m)[4], int r, uint32_t sigw_off, int t, int h, float dsig) {
   float v = acc[r];
   if (SIG) v = __builtin_fmaf(lds_f(sigw_off + (32 * t + 8 * (r >> 2) + 4 * h + (r & 3)) * 4), dsig, v);
   if (MASK) {
-    if (BITS) v = ((__builtin_bit_cast(unsigned, m[0][0]) >> (((r >> 2) & 1) * 16 + ((r >> 2) >> 1) * 4 + (r & 3))) & 1u) ? v : 0.f;
+    if (BITS) v = ((__builtin_bit_cast(unsigned, m[0][0]) >> (((r >> 2) & 1) * 8 + ((r >> 2) >> 1) * 4 + (r & 3))) & 1u) ? v : 0.f;
     else v = m[r >> 2][r & 3] > 0.f ? v : 0.f;
   }
   return v;
@@ -151,8 +152,8 @@ MF_D void bwd_layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[1
     constexpr int t = decltype(tc)::value;
     const Ahead two{t + 2 < NT ? NG : (t == NT - 2 ? nxt.groups : nxt.groups2),
                     t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), 0, nullptr, t + 2 < NT ? NG : -1, -1};
-    if constexpr (MASK && BITS) {                             // this tile's mask word: in flight across its MFMAs
-      hm[0][0] = __builtin_bit_cast(float, reinterpret_cast<const unsigned*>(mrow)[t] >> (8 * id.h));
+    if constexpr (MASK && BITS) {                             // this tile's two mask bytes: in flight across its MFMAs
+      hm[0][0] = __builtin_bit_cast(float, relu_mask_pair(reinterpret_cast<const unsigned*>(mrow), t, id.h));
     } else if constexpr (MASK) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) hm[q] = *reinterpret_cast<const f32x4*>(mrow + 32 * t + 8 * q);
@@ -167,7 +168,7 @@ MF_D void bwd_layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[1
     f32x16 acc;
     // VM operations younger than the previous panel's last piece at this tile's first barrier: the four row stores that
     // closed the previous tile (tile 0: the layer in front; none behind tile 0) + this tile's four mask loads
-    constexpr int KEEP = (t == 1 ? 0 : 4) + (MASK ? (BITS ? 1 : 4) : 0);
+    constexpr int KEEP = (t == 1 ? 0 : 4) + (MASK ? (BITS ? 2 : 4) : 0);
     mma_tile_x<0, KHID, 2, true, KEEP, true>(st, id, carry, in, inlo, in, inlo, zero_off, two, acc, gap);
     st.advance();
     pend = acc;
@@ -238,10 +239,11 @@ __global__ __launch_bounds__(256, 1) void nerf_backward_kernel_x3(const Bwd3Para
           const f32x4 w0 = lds_f4(rgbw + (0 * 128 + f + 4 * id.h) * 4), w1 = lds_f4(rgbw + (1 * 128 + f + 4 * id.h) * 4);
           const f32x4 w2 = lds_f4(rgbw + (2 * 128 + f + 4 * id.h) * 4);
           f32x4 e4;
-          if constexpr (BITS) {                                  // features (f & 31) + 4 h + r of word f / 32
-            const unsigned wv = reinterpret_cast<const unsigned*>(erow)[f >> 5];
+          if constexpr (BITS) {                                  // outputs (f & 31) + 4 h + r of the forward's panel f / 32
+            const int fp = (f & 31) + 4 * id.h;
+            const unsigned wv = reinterpret_cast<const unsigned*>(erow)[relu_mask_word(f >> 5, fp)] >> relu_mask_shift(f >> 5, fp);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) e4[r] = ((wv >> relu_mask_bit((f & 31) + 4 * id.h + r)) & 1u) ? 1.f : 0.f;
+            for (int r = 0; r < 4; ++r) e4[r] = ((wv >> r) & 1u) ? 1.f : 0.f;
           } else {
             e4 = *reinterpret_cast<const f32x4*>(erow + f);
           }

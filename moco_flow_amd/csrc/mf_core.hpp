@@ -563,17 +563,33 @@ struct NextLayer {
 // `dump_row` (training forward only, DUMP instantiations): this lane's sample row of the activation
 // dump, already offset to this layer; the layer's post-activation outputs are stored there in
 // natural feature order (the dW GEMMs of the backward read them).  nullptr: nothing stored.
-// `mask_row` (ABI v13): this lane's sample row of the ReLU bit mask, offset to this layer (8 words = 32 bytes): byte
-// 4 t + g of the row = this lane's eight outputs of panel t -- bit r = [output 32 t + 4 g + r > 0], bit 4 + r = [output
-// 32 t + 16 + 4 g + r > 0] -- one byte store per lane and panel (no cross-lane traffic in the forward); what the
-// three-product dX chain reads instead of the 1 KiB of activations.  relu_mask_bit(f): bit of feature f (0..31) in word t.
+// `mask_row` (ABI v13; layout of ABI v15): this lane's sample row of the ReLU bit mask, offset to this layer (8 words for a 256-wide
+// layer, 4 for a 128-wide one).  A lane's eight outputs of panel t make one byte -- bit r = [output 32 t + 4 g + r > 0], bit
+// 4 + r = [output 32 t + 16 + 4 g + r > 0] -- and the bytes of FOUR consecutive panels make one word: word 4 (t / 4) + g, byte
+// t % 4.  One 4-byte store per lane and four panels (round 3 stored a byte per panel at byte 4 t + g: four times the store
+// instructions, +0.44 ms per stage-1 forward launch); no cross-lane traffic in the forward; what the three-product backward
+// chains read instead of the activations.  relu_mask_word / relu_mask_shift: where output f (0..31) of panel t sits.
 MF_D unsigned relu_mask_byte(const f32x4& E, const f32x4& O) {
   unsigned w = 0;
 #pragma unroll
   for (int r = 0; r < 4; ++r) w |= (E[r] > 0.f ? 1u : 0u) << r | (O[r] > 0.f ? 0x10u : 0u) << r;
   return w;
 }
-MF_HD int relu_mask_bit(int f) { return f < 16 ? 8 * (f >> 2) + (f & 3) : 8 * ((f - 16) >> 2) + 4 + (f & 3); }
+MF_HD int relu_mask_word(int t, int f) { return 4 * (t >> 2) + (f < 16 ? f >> 2 : (f - 16) >> 2); }      // word of the layer's row
+MF_HD int relu_mask_shift(int t, int f) { return 8 * (t & 3) + (f < 16 ? 0 : 4) + (f & 3); }               // bit within that word
+// the x3 backward chains' side: tile t (the forward's panel t) as seen by lane half h of a 32-row tile -- rows 8 q + 4 h + i are
+// outputs of lane groups g = h (q = 0, 2) and g = 2 + h (q = 1, 3): their two bytes as (byte of g = h) | (byte of g = 2 + h) << 8
+MF_D unsigned relu_mask_pair(const unsigned* row, int t, int h) {
+  const unsigned a = row[4 * (t >> 2) + h], b = row[4 * (t >> 2) + 2 + h];
+  return ((a >> (8 * (t & 3))) & 0xffu) | (((b >> (8 * (t & 3))) & 0xffu) << 8);
+}
+// the writer's side: accumulate panel t's byte, store the word behind every fourth panel.  Returns: a store was issued.
+MF_D bool relu_mask_put(unsigned& macc, unsigned* mask_row, bool ok, int t, int g, const f32x4& E, const f32x4& O) {
+  macc = ((t & 3) == 0 ? 0u : macc) | relu_mask_byte(E, O) << (8 * (t & 3));
+  if ((t & 3) != 3) return false;
+  if (ok) mask_row[4 * (t >> 2) + g] = macc;
+  return true;
+}
 template <int NK, int EMB, bool DUMP = false>
 MF_D void trunk_layer(const NetDev& net, int layer, f32x4 (&act)[NK],
                       const float (&emb)[EMB], Stream& st, CarryT<kPD>& carry, const LaneId& id,
@@ -585,6 +601,8 @@ MF_D void trunk_layer(const NetDev& net, int layer, f32x4 (&act)[NK],
   const float lo = ((net.L.relu_mask >> layer) & 1) ? 0.f : -__builtin_inff();
   const uint32_t bias_off = net.res_lds + (net.L.off_bias_trunk + layer * net.L.W) * 4;
   f32x4 out[NK];
+  static_assert(NP % 4 == 0, "mask words collect four panels");
+  unsigned macc = 0;
 #pragma unroll
   for (int t = 0; t < NP; ++t) {
     const uint32_t p = st.slot_off(0) + id.lane * 16;
@@ -606,8 +624,8 @@ MF_D void trunk_layer(const NetDev& net, int layer, f32x4 (&act)[NK],
         *reinterpret_cast<f32x4*>(dump_row + 32 * t + 16 + 4 * id.g) = O;
       }
       const bool wm = __ballot(mask_row != nullptr) != 0ull;
-      if (wm && dump_row && mask_row) reinterpret_cast<unsigned char*>(mask_row)[4 * t + id.g] = (unsigned char)relu_mask_byte(E, O);
-      st.keep2 = __ballot(dump_row != nullptr) != 0ull ? (wm ? 3 : 2) : 0;   // the wave issued the stores
+      const bool put = wm && relu_mask_put(macc, mask_row, dump_row && mask_row, t, id.g, E, O);
+      st.keep2 = __ballot(dump_row != nullptr) != 0ull ? (put ? 3 : 2) : 0;   // the wave issued the stores
     }
     st.advance();
   }

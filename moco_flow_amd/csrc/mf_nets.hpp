@@ -50,6 +50,8 @@ MF_D void extra_layer(const NetDev& net, const f32x4 (&act)[NK],
   const int qe = net.L.extra_steps / 4;
   const uint32_t bias_off = net.res_lds + net.L.off_bias_extra * 4;
   const float dummy[4] = {0.f, 0.f, 0.f, 0.f};
+  static_assert(NPO % 4 == 0, "mask words collect four panels");
+  unsigned macc = 0;
 #pragma unroll
   for (int t = 0; t < NPO; ++t) {
     const uint32_t p = st.slot_off(0) + id.lane * 16;
@@ -85,8 +87,8 @@ MF_D void extra_layer(const NetDev& net, const f32x4 (&act)[NK],
         *reinterpret_cast<f32x4*>(dump_row + 32 * t + 16 + 4 * id.g) = O;
       }
       const bool wm = __ballot(mask_row != nullptr) != 0ull;
-      if (wm && dump_row && mask_row) reinterpret_cast<unsigned char*>(mask_row)[4 * t + id.g] = (unsigned char)relu_mask_byte(E, O);
-      st.keep2 = __ballot(dump_row != nullptr) != 0ull ? (wm ? 3 : 2) : 0;   // the wave issued the stores
+      const bool put = wm && relu_mask_put(macc, mask_row, dump_row && mask_row, t, id.g, E, O);
+      st.keep2 = __ballot(dump_row != nullptr) != 0ull ? (put ? 3 : 2) : 0;   // the wave issued the stores
     }
     st.advance();
   }
