@@ -38,7 +38,7 @@ extern "C" {
  *     mf_nerf_backward3 (+ mf_nerf_bwd3_packed_bytes, mf_nerf_pack_bwd3), MF_PREC_BF16X3 in mf_points_sigma_p and with the NeRF dump
  * 14: mf_embedding_forward_rows
  * 15: MF_PREC_BF16X3 packs the NoF in three-term operands (six products per k-step); mf_nof_backward3 (+ mf_nof_bwd3_packed_bytes,
- *     mf_nof_pack_bwd3) */
+ *     mf_nof_pack_bwd3); ReLU bit rows: four panels per word, written for NoF evaluations (behind T) and under NoF; mf_sample_pdf_eps */
 #define MF_ABI_VERSION 15
 
 enum {
@@ -396,6 +396,12 @@ int32_t mf_sample_pdf(const float* bins, const float* z_coarse, const float* wei
                       int64_t n_rays, int32_t n_bins, int32_t M, const float* u, int64_t u_stride,
                       const float* cdf_in, float* z_new_out, int32_t* inds_out, float* z_sorted_out,
                       void* stream);
+/* The same with sample_pdf's `eps` argument (rendering.py:5, :20, :41-42; ABI v15): mf_sample_pdf is eps = 1e-5, the value of
+ * every call the reference makes. */
+int32_t mf_sample_pdf_eps(const float* bins, const float* z_coarse, const float* weights, int64_t w_stride,
+                          int64_t n_rays, int32_t n_bins, int32_t M, const float* u, int64_t u_stride,
+                          const float* cdf_in, float* z_new_out, int32_t* inds_out, float* z_sorted_out,
+                          float eps, void* stream);
 /* render_rays' use of it: z_coarse (N,S), weights (N,S) of the coarse pass (the kernel takes
  * weights[:,1:-1]); u (N,M) draws; writes the sorted union z_out (N,S+M). */
 int32_t mf_sample_pdf_merge(const float* z_coarse, const float* weights, int64_t n_rays,

@@ -141,6 +141,8 @@ SYMBOLS = {
     "mf_sample_pdf_merge": (C.c_int32, [_fp, _fp, C.c_int64, C.c_int32, C.c_int32, _fp, _fp, _fp, _fp, _fp]),
     "mf_sample_pdf": (C.c_int32, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_int64,
                                   _fp, _fp, _fp, _fp, _fp]),
+    "mf_sample_pdf_eps": (C.c_int32, [_fp, _fp, _fp, C.c_int64, C.c_int64, C.c_int32, C.c_int32, _fp, C.c_int64,
+                                      _fp, _fp, _fp, _fp, C.c_float, _fp]),
     "mf_z_vals": (C.c_int32, [_fp, C.c_int64, C.c_int64, _fp, C.c_int32, C.c_int32, _fp, C.c_float, _fp, _fp]),
     "mf_make_rays": (C.c_int32, [C.c_int32, C.c_int32, C.c_float, C.c_float, C.c_float, C.POINTER(C.c_float),
                                  C.c_float, C.c_float, C.c_float, _fp, _fp]),

@@ -19,6 +19,7 @@ struct PdfParams {
   const float* cdf_in;                     // optional (N, nb): skip pdf/cdf (index-parity tests)
   float* z_out; int* inds_out; float* z_new_out;
   uint32_t per_wave_floats;
+  float eps;                               // rendering.py:5 `eps` (1e-5 in every call the reference makes)
 };
 
 __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(PdfParams p) {
@@ -43,7 +44,7 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(PdfParams p) {
     for (int i = lane; i < nb; i += 64) cdf[i] = p.cdf_in[ray * nb + i];
   } else {
     const float* wr = p.w + ray * p.w_stride;                                                // weights[:, 1:-1]
-    for (int i = lane; i < nw; i += 64) pdf[i] = wr[i] + 1e-5f;                              // :20
+    for (int i = lane; i < nw; i += 64) pdf[i] = wr[i] + p.eps;                              // :20
     __builtin_amdgcn_wave_barrier();
     // :21 torch.sum -- its association order is backend/ISA specific even inside the reference;
     // here: plain left-to-right fp32 (every lane recomputes it, LDS broadcast reads)
@@ -74,7 +75,7 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(PdfParams p) {
     const float c0 = cdf[below], c1 = cdf[above];
     const float b0 = bins[below], b1 = bins[above];
     float denom = c1 - c0;
-    if (denom < 1e-5f) denom = 1.f;                                                          // :41-42
+    if (denom < p.eps) denom = 1.f;                                                          // :41-42
     const float s = b0 + (u - c0) / denom * (b1 - b0);                                       // :45
     zall[S + m] = s;
     if (p.inds_out) p.inds_out[ray * M + m] = inds;
@@ -172,16 +173,29 @@ __global__ __launch_bounds__(256) void compact_scatter_kernel(CompactParams p) {
 
 using namespace mf;
 
+extern "C" int32_t mf_sample_pdf_eps(const float* bins, const float* z_coarse, const float* weights, int64_t w_stride,
+                                     int64_t n_rays, int32_t n_bins, int32_t M, const float* u, int64_t u_stride,
+                                     const float* cdf_in, float* z_new_out, int32_t* inds_out, float* z_sorted_out,
+                                     float eps, void* stream);
+
 extern "C" int32_t mf_sample_pdf(const float* bins, const float* z_coarse, const float* weights, int64_t w_stride,
                                  int64_t n_rays, int32_t n_bins, int32_t M, const float* u, int64_t u_stride,
                                  const float* cdf_in, float* z_new_out, int32_t* inds_out, float* z_sorted_out,
                                  void* stream) {
+  return mf_sample_pdf_eps(bins, z_coarse, weights, w_stride, n_rays, n_bins, M, u, u_stride, cdf_in, z_new_out, inds_out,
+                           z_sorted_out, 1e-5f, stream);
+}
+
+extern "C" int32_t mf_sample_pdf_eps(const float* bins, const float* z_coarse, const float* weights, int64_t w_stride,
+                                     int64_t n_rays, int32_t n_bins, int32_t M, const float* u, int64_t u_stride,
+                                     const float* cdf_in, float* z_new_out, int32_t* inds_out, float* z_sorted_out,
+                                     float eps, void* stream) {
   if (n_rays < 0 || n_bins < 2 || M < 1) return fail(MF_E_INVALID, "mf_sample_pdf: n_rays=%lld n_bins=%d M=%d", (long long)n_rays, n_bins, M);
   if (n_rays == 0) return MF_OK;
   if ((!bins && !z_coarse) || (!weights && !cdf_in) || !u) return fail(MF_E_INVALID, "mf_sample_pdf: null argument");
   if (z_sorted_out && !z_coarse) return fail(MF_E_INVALID, "mf_sample_pdf: the sorted merge needs z_coarse");
   PdfParams p{bins ? nullptr : z_coarse, bins, weights, w_stride, n_rays, n_bins, M, u, u_stride, cdf_in,
-              z_sorted_out, inds_out, z_new_out, 0};
+              z_sorted_out, inds_out, z_new_out, 0, eps};
   if (bins && z_sorted_out) return fail(MF_E_INVALID, "mf_sample_pdf: give either explicit bins or z_coarse (+merge)");
   const int S = n_bins + 1;
   p.per_wave_floats = (uint32_t)((S + M) + 2 * n_bins + (n_bins - 1) + 3) & ~3u;

@@ -274,8 +274,6 @@ def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
     """Reference signature (rendering.py:5-46): bins (N, nb), weights (N, nb-1) -> (N, N_importance).
     (render_rays itself uses the fused form, ``resample_merge``.)"""
     L.require_gpu(bins, "sample_pdf")
-    if eps != 1e-5:
-        raise NotImplementedError("sample_pdf: only eps=1e-5 (the reference's only call value) is built")
     dev = bins.device
     N, nb = bins.shape
     if weights.shape != (N, nb - 1):
@@ -289,8 +287,8 @@ def sample_pdf(bins, weights, N_importance, det=False, eps=1e-5):
     w = weights.detach().contiguous().float()
     out = torch.empty((N, M), device=dev, dtype=torch.float32)
     with torch.cuda.device(dev):
-        L.check(L.lib().mf_sample_pdf(L.ptr(b), None, L.ptr(w), nb - 1, N, nb, M, L.ptr(u), u_stride, None,
-                                      L.ptr(out), None, None, L.current_stream(dev)), "mf_sample_pdf")
+        L.check(L.lib().mf_sample_pdf_eps(L.ptr(b), None, L.ptr(w), nb - 1, N, nb, M, L.ptr(u), u_stride, None,
+                                          L.ptr(out), None, None, float(eps), L.current_stream(dev)), "mf_sample_pdf")
     return out
 
 
