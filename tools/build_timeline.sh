@@ -5,7 +5,8 @@ set -e
 REPO=$(cd "$(dirname "$0")/.." && pwd)
 mkdir -p /tmp/tlobj $REPO/build/ab
 cd $REPO/moco_flow_amd/csrc
-for f in mf_abi mf_pack mf_forward mf_render mf_render_bf16 mf_backward mf_backward_bf16 mf_wgrad mf_nofgrad mf_composite mf_sample mf_aux mf_loss mf_smpl; do
+rm -f /tmp/tlobj/*.o
+for f in $(make -s units); do        # the library's translation units (csrc/Makefile)
   X=$(make -s unitflags UNIT=$f)         # per-unit flags of the shipped build (csrc/Makefile)
   /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off ${MF_VARIANT_FLAGS:--DMF_TIMELINE} $X "$@" -c $f.hip -o /tmp/tlobj/$f.o &
 done
