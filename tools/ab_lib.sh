@@ -26,7 +26,8 @@ else
   BARGS=$1; shift
   for rep in 1 2 3; do
     for name in "$@"; do
-      MOCOFLOW_HIP_LIB=$AB/lib_$name.so python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-train-leg --no-extra-legs $BARGS 2>/dev/null | python3 -c "
+      L=$AB/lib_$name.so; [ $name = default ] && L=""       # "default": the in-tree library
+      MOCOFLOW_HIP_LIB=$L python3 $REPO/bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-train-leg --no-extra-legs $BARGS 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); r=d['roofline']
 print('$name rep$rep kernel_ms %.4f frac %.3f step %.3f' % (r['kernel_ms'], r['frac'], d['ms_per_step']))"
