@@ -454,6 +454,11 @@ def test_train_forward_bf16x3(M, R, name):
         worst_mr, worst_l2 = max(worst_mr, mr), max(worst_l2, l2)
     print(f"{name}: bf16x3 training forward: gradients vs oracle autograd worst max-rel {worst_mr:.2e}, l2-rel {worst_l2:.2e}")
     assert worst_mr <= 1e-2 and worst_l2 <= 2e-3
+    # the same gradients against the FLOAT64 oracle (the truth of the function), with the fp32 oracle's own distance to it as the
+    # yardstick (GRAD_CASES above): the three-product forward's mask flips are of the size of the reference arithmetic's own --
+    # every tensor within max(1e-4, 3 x noise) -- which is the case for making this mode a default some day, and why it is safe for SGD
+    _, want64 = _oracle_grads(R, c, seed, rays, bg, loss_fn, torch.float64)
+    assert _check_grads_vs_float64([nerfs[0]], want, want64, label=name + " (bf16x3 training forward)") >= 20
     # bit-identical between runs at a size that keeps every workgroup busy for several tiles (the dump stores stay in flight
     # across the panel barriers: a piece of the weight stream that had not landed would show up here)
     rays2, bg2 = case_inputs(c, seed, n=1500)
