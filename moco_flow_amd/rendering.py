@@ -22,9 +22,10 @@ from . import autograd as A
 # reference's arithmetic, BASELINE configs C1-C2; default); "bf16" = bf16 operands with fp32
 # accumulate (BASELINE configs C3-C5), the NoF's xyz block as a two-term bf16 split (16 mantissa
 # bits), its image-index block as an exact fp32 per-ray bias, heads and composite in fp32;
-# "bf16x3" = fp32-class results on the bf16 pipe (include/mocoflow_hip.h, MF_PREC_BF16X3: every matrix product of both
-# networks as three bf16 products of (hi, lo) operand pairs, fp32 accumulation, heads on the fp32 accumulators: <= 5e-5
-# max-rel on the golden vectors at about a third of the fp32 kernels' time).
+# "bf16x3" = the fp32 contract on the bf16 pipe (include/mocoflow_hip.h, MF_PREC_BF16X3: the NeRF's matrix products as three
+# bf16 products of (hi, lo) operand pairs, the NoFs' as six of (hi, mid, lo) triples, fp32 accumulation, heads on the fp32
+# accumulators: 1e-4 max-rel on every per-ray output -- <= 5e-5 on the golden vectors, <= 3.1e-5 through the MoCo chains at
+# 4096 rays -- at 0.35-0.4 of the fp32 kernels' time).
 # The reference's render_rays signature has no such knob, so it is a module setting.
 PRECISION = "f32"
 # Arithmetic of the TRAINING forward (a pass that records gradients) when no NoF is involved (stage 1: the canonical
