@@ -491,7 +491,7 @@ def run_config(name, a, ctx, steps, warmup, main):
         if i is not None:
             ev[i][1].record()
         if reducer is not None:
-            reducer.push(out["loss_partials"])
+            reducer.push(out["loss_partials"], donate=True)      # (nothing reads the local partials afterwards)
         return out
 
     with torch.no_grad():
@@ -517,6 +517,16 @@ def run_config(name, a, ctx, steps, warmup, main):
         if reducer is not None:
             reducer.finish()
         torch.cuda.synchronize()
+        if os.environ.get("MF_BENCH_TRACE_OPS") == "1" and rank == 0:
+            # which torch ops (copies, fills, allocations' memsets) ride along with the HIP launches of one step: stderr
+            from torch.profiler import ProfilerActivity, profile
+            with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof:
+                step()
+                if reducer is not None:
+                    reducer.finish()
+                torch.cuda.synchronize()
+            print(prof.key_averages(group_by_stack_n=6).table(sort_by="cuda_time_total", row_limit=25, max_name_column_width=60),
+                  file=sys.stderr)
     if dist is not None:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -22,16 +22,59 @@ struct PdfParams {
   float eps;                               // rendering.py:5 `eps` (1e-5 in every call the reference makes)
 };
 
+// Ascending bitonic sort of 64*E floats held E per lane (element lane*E + q) and the store of the first T of them.
+// A compare-exchange evaluates ONE predicate on both sides of a pair ("the upper element is smaller"), so the two lanes of
+// a pair always agree and no value is duplicated or lost, whatever the inputs (NaNs included).
+template <int E>
+MF_D void sort_store(const float* zall, float* zo, int T, int lane) {
+  constexpr int P = 64 * E;
+  float v[E];
+#pragma unroll
+  for (int q = 0; q < E; ++q) v[q] = lane * E + q < T ? zall[lane * E + q] : __builtin_inff();
+#pragma unroll
+  for (int k = 2; k <= P; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j >= 1; j >>= 1) {
+      if (j >= E) {                                        // partner: the same slot of lane ^ (j / E)
+        const bool lower = (lane & (j / E)) == 0;
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+          const float o = __shfl_xor(v[q], j / E);
+          const bool up = ((lane * E + q) & k) == 0;
+          const float a = lower ? v[q] : o, b = lower ? o : v[q];   // a: the pair's lower index
+          const bool swap = up ? b < a : a < b;
+          v[q] = swap ? o : v[q];
+        }
+      } else {                                             // partner: slot q ^ j of this lane
+#pragma unroll
+        for (int q = 0; q < E; ++q) {
+          if (q & j) continue;
+          const bool up = ((lane * E + q) & k) == 0;
+          const float a = v[q], b = v[q ^ j];
+          const bool swap = up ? b < a : a < b;
+          v[q] = swap ? b : a;
+          v[q ^ j] = swap ? a : b;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < E; ++q)
+    if (lane * E + q < T) zo[lane * E + q] = v[q];
+}
+
 __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(PdfParams p) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const long long ray = (long long)blockIdx.x * 4 + wave;
   if (ray >= p.n_rays) return;
   const int nb = p.nb, M = p.M, S = nb + 1, nw = nb - 1, T = S + M;
+  // every array starts on a 16-byte boundary: the sums below read them four floats at a time
+  const int T4 = (T + 3) & ~3, nb4 = (nb + 3) & ~3;
   float* zall = sm + (size_t)wave * p.per_wave_floats;   // [T] : coarse z then new samples
-  float* bins = zall + T;                                 // [nb]
-  float* cdf = bins + nb;                                 // [nb]
-  float* pdf = cdf + nb;                                  // [nw]
+  float* bins = zall + T4;                                // [nb]
+  float* cdf = bins + nb4;                                // [nb]
+  float* pdf = cdf + nb4;                                 // [nw]
   if (p.z) {
     const float* zr = p.z + ray * S;
     for (int i = lane; i < S; i += 64) zall[i] = zr[i];
@@ -49,15 +92,25 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(PdfParams p) {
     // :21 torch.sum -- its association order is backend/ISA specific even inside the reference;
     // here: plain left-to-right fp32 (every lane recomputes it, LDS broadcast reads)
     float tot = 0.f;
-    for (int i = 0; i < nw; ++i) tot += pdf[i];
+    for (int i = 0; i < nw; i += 4) {                      // (same left-to-right order, four elements per LDS read)
+      const f32x4 v = *reinterpret_cast<const f32x4*>(pdf + i);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tot = i + j < nw ? tot + v[j] : tot;
+    }
     __builtin_amdgcn_wave_barrier();
     for (int i = lane; i < nw; i += 64) pdf[i] = pdf[i] / tot;
     __builtin_amdgcn_wave_barrier();
     // cdf[k] = pdf[0] + ... + pdf[k-1], summed left to right (:22-23)
-    for (int k = lane; k < nb; k += 64) {
+    for (int k0 = 0; k0 < nb; k0 += 64) {
+      const int k = k0 + lane;
+      const int kmax = k0 + 63 < nb ? k0 + 63 : nb - 1;    // the block's longest sum (uniform trip count)
       float c = 0.f;
-      for (int i = 0; i < k; ++i) c += pdf[i];
-      cdf[k] = c;
+      for (int i = 0; i < kmax; i += 4) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(pdf + i);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) c = i + j < k ? c + v[j] : c;
+      }
+      if (k < nb) cdf[k] = c;
     }
   }
   __builtin_amdgcn_wave_barrier();
@@ -83,8 +136,15 @@ __global__ __launch_bounds__(256) void sample_pdf_merge_kernel(PdfParams p) {
   }
   if (!p.z_out) return;
   __builtin_amdgcn_wave_barrier();
-  // stable rank sort of the S+M depths (torch.sort, :326): rank = #{x < v} + #{x == v, earlier}
+  // torch.sort of the S+M depths (:326).  Only the values leave, so equal depths are interchangeable and any comparison
+  // sort gives torch's output bit for bit: a bitonic network over the wave's registers (E depths per lane, padded with
+  // +inf), 64E >= T.  (The rank sort this replaces -- rank = #{x < v} + #{x == v, earlier}, T compares per depth -- was
+  // 35 of the launch's 41 us at T = 192; it stays as the path for T > 1024.)
   float* zo = p.z_out + ray * T;
+  if (T <= 128) return sort_store<2>(zall, zo, T, lane);
+  if (T <= 256) return sort_store<4>(zall, zo, T, lane);
+  if (T <= 512) return sort_store<8>(zall, zo, T, lane);
+  if (T <= 1024) return sort_store<16>(zall, zo, T, lane);
   for (int k = lane; k < T; k += 64) {
     const float v = zall[k];
     int rank = 0;
@@ -198,7 +258,8 @@ extern "C" int32_t mf_sample_pdf_eps(const float* bins, const float* z_coarse, c
               z_sorted_out, inds_out, z_new_out, 0, eps};
   if (bins && z_sorted_out) return fail(MF_E_INVALID, "mf_sample_pdf: give either explicit bins or z_coarse (+merge)");
   const int S = n_bins + 1;
-  p.per_wave_floats = (uint32_t)((S + M) + 2 * n_bins + (n_bins - 1) + 3) & ~3u;
+  const int r4 = 3;
+  p.per_wave_floats = (uint32_t)(((S + M + r4) & ~r4) + 2 * ((n_bins + r4) & ~r4) + ((n_bins - 1 + r4) & ~r4));   // 16-byte aligned arrays
   const size_t lds = (size_t)p.per_wave_floats * 4 * 4;
   if (lds > 64 * 1024) return fail(MF_E_UNSUPPORTED, "mf_sample_pdf: n_bins+M=%d too large", S + M);
   hipLaunchKernelGGL(sample_pdf_merge_kernel, dim3((unsigned)((n_rays + 3) / 4)), dim3(256), lds,

@@ -89,7 +89,9 @@ class OverlappedLossReducer:
         # RCCL: tests/rccl_child.py runs exactly that on one GPU); without a group the pushes are plain copies
         self.active = dist.is_available() and dist.is_initialized()
 
-    def push(self, partials: torch.Tensor, collect: bool = False) -> Optional[torch.Tensor]:
+    def push(self, partials: torch.Tensor, collect: bool = False, donate: bool = False) -> Optional[torch.Tensor]:
+        """``donate``: the caller gives ``partials`` up (render_rays returns a fresh tensor every step) -- it becomes the ring
+        slot and is reduced in place, without the staging copy (a 4 us launch on the step's stream)."""
         k = self.i % len(self.bufs)
         self.i += 1
         done = None
@@ -97,7 +99,10 @@ class OverlappedLossReducer:
             self.work[k].wait()                      # stream-ordered for NCCL/RCCL (no host block); blocking for gloo
             if collect:
                 done = self.bufs[k].clone()
-        self.bufs[k].copy_(partials)
+        if donate and partials.dtype == self.bufs[k].dtype and partials.shape == self.bufs[k].shape and partials.is_contiguous():
+            self.bufs[k] = partials
+        else:
+            self.bufs[k].copy_(partials)
         if self.active:
             self.work[k] = dist.all_reduce(self.bufs[k], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:

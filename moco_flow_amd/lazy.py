@@ -32,12 +32,20 @@ class ConsensusPass:
         self._stats_fn, self._compact_fn = stats_fn, compact_fn
         self.differentiable = differentiable
         self._stats, self._vectors, self._mask = None, None, None
+        self._mean_taken = set()
 
     def stats(self):
         """{"local": (sum, count), "global": (sum, count)} as device scalars (float64), no host sync."""
         if self._stats is None:
             self._stats = self._stats_fn()
         return self._stats
+
+    def take_mean(self, key):
+        """True the first time: the caller may have the kernel's fp32 mean of plane ``key`` itself (see MaskedVector.mean)."""
+        if key in self._mean_taken:
+            return False
+        self._mean_taken.add(key)
+        return True
 
     def mask(self):
         """alpha >= 0.01, all-true when empty (rendering.py:306-308), without the host round trip."""
@@ -77,10 +85,12 @@ class MaskedVector:
     def mean(self, *args, **kwargs):
         if args or kwargs:
             return self.materialize().mean(*args, **kwargs)
-        if len(self._parts) == 1 and not self._g.differentiable:
-            # the kernel's own fp32 mean -- a COPY: the reference adds in place into what torch.mean returned
-            # (`nof_local = torch.mean(coarse); nof_local += torch.mean(fine)`, trainer_moco_flow.py:318-321)
-            return self._g.stats()[self._k][2].clone()
+        if len(self._parts) == 1 and not self._g.differentiable and self._g.take_mean(self._k):
+            # the kernel's own fp32 mean, (float)(sum / count) in float64 -- handed out ONCE: the reference adds in place into
+            # what torch.mean returned (`nof_local = torch.mean(coarse); nof_local += torch.mean(fine)`,
+            # trainer_moco_flow.py:318-321), so the caller owns that scalar; a second request recomputes the same float from
+            # the float64 (sum, count) below (two tiny launches, not on the trainer's path)
+            return self._g.stats()[self._k][2]
         s, c = self._sum_count()
         return (s / c).to(torch.float32)
 

@@ -252,6 +252,26 @@ def test_sample_pdf_indices_bit_exact(M):
     assert relerr(M.sample_pdf(bins, w, M_, det=True, eps=1e-3)[:, :-1], s[:, :-1]) > 1e-4        # (the argument matters)
 
 
+@pytest.mark.parametrize("S,Mi", [(8, 5), (64, 64), (64, 128), (40, 100), (128, 256), (192, 400), (256, 768), (300, 800)])
+def test_resample_merge_is_torch_sort_of_the_union(M, S, Mi):
+    """rendering.py:326 `torch.sort(torch.cat([z_vals, z_vals_], -1), -1)`: the merged depths of the one-launch resample are
+    bit for bit torch.sort of [coarse depths, the launch's own new samples], for every width class of the in-register
+    bitonic network (T = S + M <= 128 / 256 / 512 / 1024) and the rank-sort path behind it (T > 1024), with sorted
+    (linspace) and unsorted (random) draws, duplicates included (zero-weight bins collapse samples onto bin edges)."""
+    N = 77
+    g = torch.Generator(device="cuda").manual_seed(S * 1000 + Mi)
+    z = torch.sort(2.0 + 4.0 * torch.rand(N, S, device="cuda", generator=g), -1)[0]
+    w = torch.rand(N, S, device="cuda", generator=g)
+    w[:, S // 3: S // 2] = 0.0
+    w[::5] = 0.0                                                                 # eps-only pdf: uniform
+    for u in (None, torch.rand(N, Mi, device="cuda", generator=g)):
+        with torch.no_grad():
+            z_out, _, z_new = M.resample_merge(z, w, Mi, det=True, u=u, return_aux=True)
+        want = torch.sort(torch.cat([z, z_new], -1), -1)[0]
+        assert z_out.shape == (N, S + Mi)
+        assert torch.equal(z_out, want), (S, Mi, u is None, int((z_out != want).sum()))
+
+
 def test_compaction_order_bit_exact(M):
     torch.manual_seed(0)
     N, S = 37, 64

@@ -409,7 +409,10 @@ def _reducer_worker(rank, world, port, q):
     got = []
     for step in range(5):
         part = torch.tensor([float(step * 10 + rank + 1), 1.0], dtype=torch.float64)
-        r = red.push(part, collect=True)
+        r = red.push(part, collect=True, donate=step % 2 == 1)      # (odd steps: reduced in place, no staging copy)
+        if step % 2 == 1:
+            red.work[(red.i - 1) % 2].wait()
+            assert part.tolist() == [float(2 * step * 10 + 3), 2.0]   # the donated tensor IS the ring slot
         if r is not None:
             got.append(r.tolist())
     got += [r.tolist() for r in red.finish()]
@@ -547,8 +550,8 @@ def test_lazy_vectors_host_logic():
     "local" before the "global" plane exists -- the keyed cache must serve both (KeyError 'global' with
     LAZY_CONSENSUS off and chain_global); (ii) torch.cat of vectors along dim 0 -- the reference trainer's per-chunk
     concatenation, trainer/trainer_moco_flow.py:199-223 -- stays lazy, and its mean / sum are those of the concatenated
-    tensors; (iii) the mean of a gradient-free vector is a copy: the trainer's in-place `+=` (trainer_moco_flow.py:318-321)
-    must not reach the cached kernel output."""
+    tensors; (iii) the mean of a gradient-free vector is the caller's own scalar: the trainer's in-place `+=`
+    (trainer_moco_flow.py:318-321) must not reach what a later torch.mean of the same vector returns."""
     from moco_flow_amd.lazy import ConsensusPass, MaskedVector
     torch.manual_seed(0)
 
@@ -592,8 +595,12 @@ def test_lazy_vectors_host_logic():
     cache = {"local": (torch.tensor(6.0, dtype=torch.float64), torch.tensor(3.0, dtype=torch.float64), torch.tensor(2.0))}
     gf = ConsensusPass(torch.rand(2, 2), {"local": torch.rand(2, 2)}, lambda: cache, lambda: {}, False)
     v = MaskedVector(gf, "local")
-    m = torch.mean(v)
+    m = torch.mean(v)                                                # the kernel's scalar itself, handed out once (no copy)
+    assert m is cache["local"][2]
     m += 10.0
-    assert float(torch.mean(v)) == 2.0 and float(cache["local"][2]) == 2.0
+    m2 = torch.mean(v)                                               # later requests: the same float from (sum, count)
+    assert float(m2) == 2.0 and m2.dtype == torch.float32 and m2 is not m
+    m2 += 1.0
+    assert float(torch.mean(v)) == 2.0 and float(cache["local"][0]) == 6.0
     two = torch.cat([v, v], 0)                                       # chunks: sum of sums / sum of counts
     assert float(torch.mean(two)) == pytest.approx(2.0)
