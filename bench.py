@@ -24,7 +24,10 @@ matrix pipe -- every product as three bf16 products of (hi, lo) operand pairs; N
 roofline fraction and error against the CPU oracle, so every BASELINE config is driver-measured without changing what
 `value` means.  The legs are sub-millisecond passes: each gets 100 warm-up and 200 timed steps of its own (a handful of
 warm-up steps leaves the clocks ramping); the main line uses exactly the --steps / --warmup it was given.  The timed region
-of every config holds the calls alone: the per-call event pairs behind "step_span_ms" are recorded in a second, untimed loop.
+of every config holds the calls alone: the per-call event pairs behind "step_span_ms" are recorded in a second, untimed loop,
+and the interpreter's cyclic garbage collector is collected + frozen in front of it and off inside it (as `timeit` does): one
+full collection of the heap torch's import leaves behind stalls the host 40-50 ms at a call of its own choosing, which a
+20-step region of a 0.34 ms pass reports as 2.3 ms per step (MF_BENCH_STEP_TIMES=2 prints each call's host time).
 
 Extra JSON objects: "roofline" (MFMA bound: algorithmic Linear-layer FLOPs of the dominant kernel's launch / its
 average duration, HIP events on the launch stream around the launch alone, vs the dense matrix peak of the dtype;
@@ -34,6 +37,7 @@ best thread count of a sweep; rank 0, N = 1 only).  The line ENDS with "legs": o
 (ms per step, kernel ms, roofline fraction, PSNR-equivalent dB, worst max-rel) + the training-step times.
 """
 import argparse
+import gc
 import json
 import os
 import socket
@@ -494,22 +498,50 @@ def run_config(name, a, ctx, steps, warmup, main):
             reducer.push(out["loss_partials"], donate=True)      # (nothing reads the local partials afterwards)
         return out
 
+    # everything built so far (torch's import, the models) leaves the collector's generations: the later collections of
+    # every leg scan the few objects of a step, not the whole heap
+    gc.collect()
+    gc.freeze()
     with torch.no_grad():
+        if os.environ.get("MF_BENCH_STEP_TIMES") == "1" and rank == 0:
+            # diagnosis: host time of each of the first calls, synchronised one by one (stderr)
+            ts = []
+            for _ in range(12):
+                t1 = time.perf_counter()
+                out = step()
+                torch.cuda.synchronize()
+                ts.append(round((time.perf_counter() - t1) * 1e3, 3))
+            print("first calls, ms each (synchronised):", ts, file=sys.stderr)
         for _ in range(warmup):
             out = step()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+        # the interpreter's cyclic collector stays out of the timed region (as `timeit` does): a full collection of the heap
+        # torch's import leaves behind blocks the host for 40-50 ms once, at a call of its own choosing -- in a 20-step
+        # region of a 0.34 ms pass that is the difference between 0.37 and 2.3 ms per step (MF_BENCH_STEP_TIMES=2 shows it)
+        gc_was = gc.isenabled()
+        if os.environ.get("MF_BENCH_GC") != "1":
+            gc.collect()
+            gc.disable()
         t0 = time.perf_counter()
+        host_ts = [] if os.environ.get("MF_BENCH_STEP_TIMES") == "2" else None
         for _ in range(steps):                  # the timed region: exactly `steps` calls, nothing else on the stream
             out = step()
+            if host_ts is not None:
+                host_ts.append(time.perf_counter())
         if reducer is not None:
             reducer.finish()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
         elapsed = time.perf_counter() - t0
+        if gc_was:
+            gc.enable()
+        if host_ts and rank == 0:
+            print("host time of each timed call's enqueue, ms:", [round((b - a) * 1e3, 3) for a, b in zip([t0] + host_ts, host_ts)],
+                  "then the final synchronize: %.3f" % ((t0 + elapsed - host_ts[-1]) * 1e3), file=sys.stderr)
         # per-call device span (step_span_ms), outside the timed region: the event pairs cost ~10 us of stream time each on
         # this runtime, which is 3 % of a 0.33 ms step
         for i in range(steps):

@@ -131,6 +131,9 @@ __global__ __launch_bounds__(256) void nof_raybias_kernel(const RayBiasParams p)
 template <int NW = kWaves>
 MF_D void stage_raybias(const float* table, int combos, int layers, long long ray_first, int n, int combo, uint32_t dst,
                         const Lane& id) {
+#ifdef MF_AB_NO_RAYBIAS      // (A/B pricing build only, wrong results: what the per-ray table costs the pass)
+  return;
+#endif
   const uint32_t entry = (uint32_t)layers * 512u, chunk = (uint32_t)n * entry;
   const char* base = reinterpret_cast<const char*>(table) + ((size_t)ray_first * combos + combo) * entry;
   for (uint32_t q = id.wave; q * 1024u < chunk; q += NW) {
@@ -649,7 +652,9 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
       }
       for (int k = 0; k < 16; ++k) { r.freq[k] = p.emb_par[3][k]; r.weight[k] = p.emb_par[3][16 + k]; }
       r.out = static_cast<float*>(a->workspace);
+#ifndef MF_AB_NO_RAYBIAS
       hipLaunchKernelGGL(nof_raybias_kernel, dim3((unsigned)((a->n_rays + kRbEntries - 1) / kRbEntries), combos), dim3(256), 0, st, r);
+#endif
     }
   }
   if (prepare_only) return moco ? check_launch("mf_render_prepare") : MF_OK;
