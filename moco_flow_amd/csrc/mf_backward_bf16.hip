@@ -146,7 +146,11 @@ MF_D void bwd_layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[1
 #ifdef MF_B3_ABL_NOSTORE                                        // (timing ablation, tools/ab_lib.sh: results are garbage)
     if (v[0] == 1.2345e-30f)
 #endif
+#ifdef MF_B3_ABL_COALESCED     // (timing ablation: the same bytes into the same rows, but one contiguous KiB per instruction)
+    *reinterpret_cast<f32x4*>(grow - 4 * id.h + ((long long)(4 * t + q) - (id.lane & 31)) * 2432LL /* D = 8 stride */ + 4 * id.lane) = v;
+#else
     *reinterpret_cast<f32x4*>(grow + 32 * t + 8 * q) = v;
+#endif
   };
   auto run = [&](auto tc) __attribute__((always_inline)) {
     constexpr int t = decltype(tc)::value;

@@ -59,7 +59,9 @@ struct WgShapeX {
 };
 using ShapeAX = WgShapeX<256, 256, 4, 2, 4>;      // hidden x hidden
 using ShapeCX = WgShapeX<128, 256, 2, 2, 4>;      // extra_encoding x final
-// (a 128 x 128 variant for the NoF's hidden blocks measured no gain: those items already run against HBM in fp32)
+// (a 128 x 128 variant, WgShapeX<128, 128, 2, 1, 4>, for the NoF's hidden blocks: three such items at 1.97 M evaluations 2.02 ->
+//  1.86 ms, the NoF's six items 3.51 -> 3.40 ms as two launches (round 4, same box) -- those items already run against HBM
+//  in fp32 (3.0 of the ~4 TB/s this chip streams to a reader); not kept)
 constexpr int kWgShapeX0 = 8;                     // first x3 shape id
 
 // cost of one stage of each block shape in CU cycles, MEASURED (tools/bench_wgrad.py: each shape alone at 1.3 M samples,

@@ -35,6 +35,12 @@ sets = {
     "D x1 (128x32)": [(sl(gpre, 9, 128), ext32, 128, 32, False)],
     "E x1 (4x640)": [(ghead, acts[:, 7 * W:7 * W + 640], 4, 640, True)],
 }
+# the same nine blocks with every layer's rows contiguous ((layer, P, 256) planes instead of (P, layers x 256) rows): what a
+# plane-major dump would give the reader
+if os.environ.get("MF_WGRAD_PLANES") == "1":
+    gpl = torch.randn(9, P, W, device=dev)
+    apl = torch.randn(9, P, W, device=dev)
+    sets["A x9 planes"] = [(gpl[l], apl[l - 1], 256, 256, True) for l in range(1, 9)] + [(gpl[8], apl[7], 256, 256, True)]
 # NoF shapes (one evaluation: D = 4, W = 128, skip at 2; dump stride 4*128 + 16, embedded input 80 columns)
 nacts = torch.randn(P, 4 * 128 + 16, device=dev)
 ngpre = torch.randn((P + 127) // 128 * 128, 4 * 128 + 16, device=dev)[:P]
@@ -45,6 +51,7 @@ sets["F x1"] = sets["F x3 (128x128)"][:1]
 sets["G x2 (128x80)"] = [(nsl(ngpre, 0), emb80, 128, 80, True), (nsl(ngpre, 2), emb80, 128, 80, False)]
 sets["H x1 (12x128)"] = [(ngpre[:, 512:524], nsl(nacts, 3), 12, 128, True)]
 sets["NoF all 6"] = sets["F x3 (128x128)"] + sets["G x2 (128x80)"] + sets["H x1 (12x128)"]
+sets_check = None
 sets["all 13"] = sum((sets[k] for k in ("A x9 (256x256)", "B x2 (256x64)", "C x1 (128x256)", "D x1 (128x32)", "E x1 (4x640)")), [])
 flops = lambda jobs: sum(2.0 * P * a[2] * a[3] for a in jobs)
 byts = lambda jobs: sum(4.0 * P * (a[2] + a[3]) for a in jobs)
