@@ -696,6 +696,58 @@ class LossPartials(torch.autograd.Function):
         return (None, None, None, None) + tuple(grads)
 
 
+class ConsensusMean(torch.autograd.Function):
+    """``torch.mean`` of ONE consensus vector of a training pass -- what the unchanged trainer takes of every
+    ``nof_*_disp_*`` entry right away (trainer/trainer_moco_flow.py:317-328) -- as one node instead of ~15 torch launches each
+    way (|x - recon|, the mean over the three coordinates, the mask, two masked sums, their quotient, and the backward of all
+    of them over (N, S, 3) tensors).  Forward: the mean mf_loss_partials takes over the per-sample distances the fused pass
+    itself wrote (models/rendering.py:306-314; the two launches are shared by the vectors of the pass, lazy.ConsensusPass.stats).
+    Backward: mf_loss_partials_backward with the one seed g / count -- ``-g mask sign(x - recon) / (3 count)`` straight into
+    the buffer the NoF chain's last node consumes.  ``key``: "local" | "global"; ``planes``: the pass's output dict (alphas)."""
+
+    @staticmethod
+    def forward(ctx, group, key, planes, rays, z, recon):
+        st = group.stats()
+        ctx.key, ctx.alphas, ctx.rays, ctx.z, ctx.out12 = key, planes["alphas"], rays, z, st["out12"]
+        ctx.save_for_backward(recon.detach())
+        return st[key][2].clone()            # (the kernel's fp32 mean; a copy: the trainer adds into it in place)
+
+    @staticmethod
+    def backward(ctx, g):
+        recon, = ctx.saved_tensors
+        if g is None or not ctx.needs_input_grad[5]:
+            return (None,) * 6
+        rays, z, out12 = ctx.rays, ctx.z, ctx.out12
+        dev, N = rays.device, rays.shape[0]
+        slot = 4 if ctx.key == "local" else 8
+        g12 = _onehot12(slot, dev) * (g.detach().double() / out12[slot + 1])
+        recon = recon.contiguous()
+        g_recon = torch.empty_like(recon)
+        d = L.mf_loss_grad_pass()
+        d.alphas, d.n_samples = L.ptr(ctx.alphas), z.shape[1]
+        d.rays, d.ray_stride, d.z_vals = L.ptr(rays), rays.stride(0), L.ptr(z)
+        if ctx.key == "local":
+            d.recon_local, d.g_recon_local = L.ptr(recon), L.ptr(g_recon)
+        else:
+            d.recon_global, d.g_recon_global = L.ptr(recon), L.ptr(g_recon)
+        with torch.cuda.device(dev):
+            L.check(L.lib().mf_loss_partials_backward(C.byref(d), None, None, N, out12.data_ptr(), g12.data_ptr(),
+                                                      L.current_stream(dev)), "mf_loss_partials_backward")
+        return None, None, None, None, None, g_recon
+
+
+_ONEHOT12 = {}
+
+
+def _onehot12(slot, dev):
+    key = (slot, str(dev))
+    if key not in _ONEHOT12:
+        v = torch.zeros(12, dtype=torch.float64, device=dev)
+        v[slot] = 1.0
+        _ONEHOT12[key] = v
+    return _ONEHOT12[key]
+
+
 class CompositeSamples(torch.autograd.Function):
     """(rgb, depth, opacity) of a pass as a function of the per-sample (rgb, sigma) plane.  Forward: the
     values the fused HIP pass already produced; backward: mf_composite_backward (rendering.py:157-192

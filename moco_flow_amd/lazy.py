@@ -7,7 +7,8 @@ reference's only caller takes ``torch.mean`` of each right away (trainer/trainer
 
 ``MaskedVector`` stands for such a vector.  ``v.mean()`` / ``torch.mean(v)`` / ``v.sum()`` / ``torch.sum(v)`` come from
 masked sums on the device -- no compaction, no ``.item()``, so consecutive steps pipeline (gradient-free passes: the two
-launches of mf_loss_partials, shared by the pass's vectors; with gradients: differentiable device reductions on the
+launches of mf_loss_partials, shared by the pass's vectors; with gradients: ONE autograd node per mean, autograd.ConsensusMean, on those same sums -- or, for anything but the mean of a
+single pass's vector, differentiable device reductions on the
 per-sample distances).  Anything else -- ``.shape``, ``len()``, indexing, arithmetic, any other torch function --
 materialises the real tensor first (mf_compact_mask: count -> scan -> scatter in row-major (ray, sample) order, one host
 sync; ``torch.masked_select`` under autograd), after which the object simply forwards to it.  It is not a
@@ -27,10 +28,11 @@ class ConsensusPass:
     """What the vectors of one pass share: the (N,S) alphas, the per-sample distance planes, the cached masked sums and
     the cached compacted tensors (one compaction serves both vectors)."""
 
-    def __init__(self, alphas, planes, stats_fn, compact_fn, differentiable):
-        self.alphas, self.planes = alphas, planes            # planes: {"local": (N,S), "global": (N,S)}
+    def __init__(self, alphas, planes, stats_fn, compact_fn, differentiable, mean_fn=None):
+        self.alphas, self.planes = alphas, planes            # planes: {"local": (N,S), "global": (N,S)} (or callables making them)
         self._stats_fn, self._compact_fn = stats_fn, compact_fn
         self.differentiable = differentiable
+        self._mean_fn = mean_fn                              # training passes: key -> the mean as ONE autograd node
         self._stats, self._vectors, self._mask = None, None, None
         self._mean_taken = set()
 
@@ -39,6 +41,13 @@ class ConsensusPass:
         if self._stats is None:
             self._stats = self._stats_fn()
         return self._stats
+
+    def plane(self, key):
+        """The (N, S) per-sample distances of ``key`` (training passes build them on first use)."""
+        v = self.planes[key]
+        if callable(v):
+            v = self.planes[key] = v()
+        return v
 
     def take_mean(self, key):
         """True the first time: the caller may have the kernel's fp32 mean of plane ``key`` itself (see MaskedVector.mean)."""
@@ -71,8 +80,9 @@ class MaskedVector:
     @staticmethod
     def _part_sum_count(g, k):
         if g.differentiable:
-            m = g.mask().to(g.planes[k].dtype)
-            return (g.planes[k] * m).sum(), m.sum()
+            pl = g.plane(k)
+            m = g.mask().to(pl.dtype)
+            return (pl * m).sum(), m.sum()
         return g.stats()[k][:2]
 
     def _sum_count(self):
@@ -91,6 +101,8 @@ class MaskedVector:
             # trainer_moco_flow.py:318-321), so the caller owns that scalar; a second request recomputes the same float from
             # the float64 (sum, count) below (two tiny launches, not on the trainer's path)
             return self._g.stats()[self._k][2]
+        if len(self._parts) == 1 and self._g.differentiable and self._g._mean_fn is not None:
+            return self._g._mean_fn(self._k)                  # one autograd node (autograd.ConsensusMean)
         s, c = self._sum_count()
         return (s / c).to(torch.float32)
 

@@ -60,6 +60,9 @@ def set_precision(p: str):
 # The consensus vectors nof_*_disp_* as lazy.MaskedVector (default): .mean() / .sum() from masked sums on the device, the
 # data-dependent-length tensor only when something asks for it.  False: eager tensors (compaction + host sync per pass).
 LAZY_CONSENSUS = True
+# torch.mean of a training pass's consensus vector as one autograd node on the distances the fused pass wrote
+# (autograd.ConsensusMean); False: torch ops on the per-sample planes (|x - recon|, mask, masked sums), as in rounds 2-3
+FUSED_CONSENSUS_MEAN = True
 
 
 # Draw torch.randn(N,S) in every pass even when noise_std == 0, as the reference does
@@ -252,7 +255,7 @@ def _pass_stats(p, N):
         L.check(lib.mf_loss_partials(C.byref(d), None, None, N, out.data_ptr(), means.data_ptr(), scratch.data_ptr(),
                                      L.current_stream(dev)), "mf_loss_partials")
     # (sum, count, mean): the mean is a view of the kernel's own fp32 output -- torch.mean(vector) launches nothing
-    return {"local": (out[4], out[5], means[2]), "global": (out[8], out[9], means[4])}
+    return {"local": (out[4], out[5], means[2]), "global": (out[8], out[9], means[4]), "out12": out}
 
 
 def _consensus_vectors(p, N, loc, glob):
@@ -495,14 +498,18 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
         group = None
         if (loc or glob) and loss_target is None:
             from .lazy import ConsensusPass, MaskedVector
-            planes = {}
-            group = ConsensusPass(p["alphas"], planes, None,
-                                  lambda: {k: torch.masked_select(v, _mask_of(p["alphas"])) for k, v in planes.items()}, True)
+            planes, recon_of = {}, {}
+            # torch.mean(vector) -- all the trainer asks of these entries -- is ONE autograd node on the distances the fused
+            # pass wrote (autograd.ConsensusMean); the per-sample planes are only built (torch ops) when something else is asked
+            group = ConsensusPass(p["alphas"], planes, lambda: _pass_stats(p, N),
+                                  lambda: {k: torch.masked_select(group.plane(k), _mask_of(p["alphas"])) for k in planes}, True,
+                                  mean_fn=(lambda k: A.ConsensusMean.apply(group, k, p, rays, z, recon_of[k])) if FUSED_CONSENSUS_MEAN else None)
 
-            def vector(key, dist3):
-                # torch.mean(dist3[mask], dim=1) of rendering.py:310-314 as mean-then-select (same numbers; the backward is a
-                # masked scatter instead of the sort + accumulate of boolean-index backward), lazily (lazy.MaskedVector)
-                planes[key] = dist3.mean(-1)
+            def vector(key, recon):
+                # torch.mean(|xyz - recon|[mask], dim=1) of rendering.py:310-314 as mean-then-select (same numbers; the backward
+                # is a masked scatter instead of the sort + accumulate of boolean-index backward), lazily (lazy.MaskedVector)
+                recon_of[key] = recon
+                planes[key] = lambda: torch.abs(xyz - recon).mean(-1)
                 v = MaskedVector(group, key)
                 return v if LAZY_CONSENSUS else v.materialize()
         xin = p["xyz_in"]
@@ -538,7 +545,7 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
                 fw = nof_models[1]
                 recon = nof_points(canon, ind, nof_embs, fw)
                 if loss_target is None:
-                    out[f"nof_local_disp_{tag}"] = vector("local", torch.abs(xyz - recon))
+                    out[f"nof_local_disp_{tag}"] = vector("local", recon)
                 else:
                     recons[f"local_{tag}"] = recon           # the loss node differentiates |x - recon| itself
             if glob:
@@ -547,7 +554,7 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
                 b_ = nof_points(a_, cind, nof_embs, bw)
                 chained = nof_points(b_, ind, nof_embs, fw)
                 if loss_target is None:
-                    out[f"nof_global_disp_{tag}"] = vector("global", torch.abs(xyz - chained))
+                    out[f"nof_global_disp_{tag}"] = vector("global", chained)
                 else:
                     recons[f"global_{tag}"] = chained
             xin = canon.reshape(-1, 3)

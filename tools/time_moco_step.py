@@ -11,6 +11,9 @@ import moco_flow_amd as M
 import eager_ref as E      # tools/eager_ref.py
 from moco_flow_amd import synth, rendering
 from moco_flow_amd import autograd as _A
+if os.environ.get("MF_NO_FUSED_MEAN") == "1":      # A/B: the consensus means through torch ops on the per-sample planes (rounds 2-3)
+    from moco_flow_amd import rendering as _R
+    _R.FUSED_CONSENSUS_MEAN = False
 if os.environ.get("MF_WGRAD"):
     _A.set_wgrad_precision(os.environ["MF_WGRAD"])      # f32 | bf16x3
 rendering.STRICT_RNG = False
