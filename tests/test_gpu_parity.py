@@ -552,6 +552,52 @@ def test_gradients_vs_oracle(M, R, name, wgrad):
     assert checked >= 10
 
 
+def test_consensus_mean_node_equals_the_torch_reductions(M):
+    """torch.mean of a training pass's consensus vector is ONE autograd node (autograd.ConsensusMean: mf_loss_partials forward on
+    the distances the fused pass wrote, mf_loss_partials_backward with the seed g / count).  Against the same step with
+    rendering.FUSED_CONSENSUS_MEAN off -- torch ops on |x - recon|, the mask and the masked sums, rounds 2-3: the means agree to fp32
+    rounding, every parameter gradient to 1e-5 l2-rel (both seed -g mask sign(x - recon) / (3 count)); the trainer's in-place
+    accumulation of the coarse and fine means (trainer_moco_flow.py:318-321) works on the node's output, and the other
+    reductions (.sum(), the vector itself) still come from the per-sample planes."""
+    from moco_flow_amd import rendering
+    c = dict(RENDER_CASES["r_moco_global"])
+    c["M"] = 16                                                # (a fine pass: two vectors per chain)
+    seed = int(load_golden("r_moco_global")["meta_seed"])
+    n = 40
+    rays, bg = case_inputs(c, seed, n=n)
+    gt = torch.rand(n, 3, generator=torch.Generator().manual_seed(1)).cuda()
+
+    def step(fused):
+        embs, nerfs, kw = build_case(M, c, seed, device="cuda")
+        nets = list(nerfs) + list(kw["nof_models"])
+        rendering.FUSED_CONSENSUS_MEAN = fused
+        try:
+            res = M.render_rays(rays.cuda(), bg.cuda(), embs, nerfs, **kw)
+            local = torch.mean(res["nof_local_disp_coarse"])
+            local += torch.mean(res["nof_local_disp_fine"])
+            glob = torch.mean(res["nof_global_disp_coarse"])
+            glob += torch.mean(res["nof_global_disp_fine"])
+            assert local.requires_grad and local.dtype == torch.float32 and local.dim() == 0
+            extra = res["nof_local_disp_fine"].sum() / res["nof_local_disp_fine"].shape[0]      # the plane path, both settings
+            loss = ((res["rgb_coarse"] - gt) ** 2).mean() + ((res["rgb_fine"] - gt) ** 2).mean() + 0.3 * local + 0.2 * glob
+            (loss + 0.1 * extra).backward()
+        finally:
+            rendering.FUSED_CONSENSUS_MEAN = True
+        return float(local.detach()), float(glob.detach()), float(extra.detach()), {f"{i}.{k}": p.grad for i, m in enumerate(nets) for k, p in m.named_parameters()}
+
+    l1, g1, e1, grads1 = step(True)
+    l0, g0, e0, grads0 = step(False)
+    assert abs(l1 - l0) <= 2e-6 * abs(l0) and abs(g1 - g0) <= 2e-6 * abs(g0), (l1, l0, g1, g0)
+    assert abs(e1 - e0) <= 2e-6 * abs(e0)
+    worst = 0.0
+    for k, g in grads0.items():
+        assert (g is None) == (grads1[k] is None), k
+        if g is not None and float(g.abs().max()) > 0:
+            worst = max(worst, _l2rel(grads1[k], g))
+    print(f"ConsensusMean node vs torch reductions: means {l1:.6g} / {l0:.6g}, worst parameter-gradient l2-rel {worst:.2e}")
+    assert worst <= 1e-5
+
+
 @pytest.mark.parametrize("name", ["r_nerf_dir_dense", "r_moco_global_default"])
 def test_gradients_when_the_loss_skips_outputs(M, R, name):
     """A loss that does not touch rgb (depth + opacity only): the composite node gets NO seed for rgb (autograd hands None,
