@@ -294,10 +294,12 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
     if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
 #endif
     __builtin_amdgcn_sched_barrier(0);
+#ifndef MF_BF_BREAK_LO      // (-DMF_BF_BREAK_LO: the deliberately broken build the oracle-of-the-arithmetic tests must reject)
     if (SPLIT && ge >= 0 && ge < NEG && !(ge & 1)) {
       acc = MF_MFMA32(r[s], xlo[ge >> 1], acc);           // Whi * xlo
       __builtin_amdgcn_sched_barrier(0);
     }
+#endif
   }
 #pragma unroll
   for (int i = 0; i < PD; ++i) carry.w[i] = r[(NG + i) % (PD + 1)];
