@@ -1023,6 +1023,9 @@ MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, co
 #pragma unroll
     for (int e = 1; e <= nx; ++e) {                          // W_t x_e: the lower-order products of this group
       const u32x4* op = T == 3 ? (e == 1 ? (emb ? xmid : hidmid) : (emb ? xlo : hidlo)) : (emb ? xlo : hidlo);
+#ifdef MF_X3_BREAK_LO       // (the deliberately broken build the oracle-of-the-arithmetic tests must reject: W_0 x_last of the embedded blocks dropped)
+      if (!(emb && e == nx && ge % T == 0))
+#endif
       acc = MF_MFMA32(r[s], op[ks], acc);
       __builtin_amdgcn_sched_barrier(0);
       if (e == 1) {
