@@ -258,7 +258,7 @@ def test_resample_merge_is_torch_sort_of_the_union(M, S, Mi):
     bit for bit torch.sort of [coarse depths, the launch's own new samples], for every width class of the in-register
     bitonic network (T = S + M <= 128 / 256 / 512 / 1024) and the rank-sort path behind it (T > 1024), with sorted
     (linspace) and unsorted (random) draws, duplicates included (zero-weight bins collapse samples onto bin edges)."""
-    N = 77
+    N = 8192 if (S, Mi) == (64, 128) else 77                   # (BASELINE config C5's full ray count at its own widths)
     g = torch.Generator(device="cuda").manual_seed(S * 1000 + Mi)
     z = torch.sort(2.0 + 4.0 * torch.rand(N, S, device="cuda", generator=g), -1)[0]
     w = torch.rand(N, S, device="cuda", generator=g)
