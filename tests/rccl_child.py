@@ -57,7 +57,8 @@ def main():
     def step(i):
         res = M.render_rays(rays, bg, embs, nerfs, _loss_target=gts[i], **kw)
         local.append(res["loss_partials"].clone())
-        done = red.push(res["loss_partials"], collect=True)
+        # odd steps donate the kernel's own tensor: it becomes the ring slot and ncclAllReduce runs in place on it (what bench.py does)
+        done = red.push(res["loss_partials"], collect=True, donate=i % 2 == 1)
         if done is not None:
             reduced.append(done)
 
