@@ -252,11 +252,13 @@ def test_sample_pdf_indices_bit_exact(M):
     assert relerr(M.sample_pdf(bins, w, M_, det=True, eps=1e-3)[:, :-1], s[:, :-1]) > 1e-4        # (the argument matters)
 
 
-@pytest.mark.parametrize("S,Mi", [(8, 5), (64, 64), (64, 128), (40, 100), (128, 256), (192, 400), (256, 768), (300, 800)])
+@pytest.mark.parametrize("S,Mi", [(8, 5), (64, 64), (64, 128), (64, 192), (40, 100), (128, 256), (200, 312), (192, 400), (256, 768),
+                                  (300, 800)])
 def test_resample_merge_is_torch_sort_of_the_union(M, S, Mi):
     """rendering.py:326 `torch.sort(torch.cat([z_vals, z_vals_], -1), -1)`: the merged depths of the one-launch resample are
     bit for bit torch.sort of [coarse depths, the launch's own new samples], for every width class of the in-register
-    bitonic network (T = S + M <= 128 / 256 / 512 / 1024) and the rank-sort path behind it (T > 1024), with sorted
+    bitonic network (T = S + M <= 128 / 256 / 512 / 1024, the exactly full networks T = 128 / 256 / 512 / 1024 included) and the
+    rank-sort path behind it (T > 1024), with sorted
     (linspace) and unsorted (random) draws, duplicates included (zero-weight bins collapse samples onto bin edges)."""
     N = 8192 if (S, Mi) == (64, 128) else 77                   # (BASELINE config C5's full ray count at its own widths)
     g = torch.Generator(device="cuda").manual_seed(S * 1000 + Mi)
