@@ -27,10 +27,26 @@ struct LossParams {
   float* means;       // (6) sum / count of each pair as fp32 (0 / 0 = nan, like torch.mean of an empty vector), or null
 };
 
+// Sum over the 64 lanes, returned wave-uniform, on the DPP path (row shifts + row broadcasts, both halves of the double moved
+// together: ~20 instructions).  The six __shfl_xor steps it replaces are twelve ds_bpermute round trips per value, and both
+// kernels reduce TWELVE values (round 4, under rocprofv3: partials kernel 9.9 -> 8.3 us, finish kernel 4.9 -> 4.5 at C5's shard).
+template <int CTRL, int ROW_MASK>
+__device__ inline double dpp_f64(double v) {
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)b, CTRL, ROW_MASK, 0xf, false);
+  const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
+  return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
+}
 __device__ inline double wave_sum_d(double v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
+  v += dpp_f64<0x111, 0xf>(v);                   // row_shr:1, 2, 4, 8 -- lane 15 of every row holds the row's sum
+  v += dpp_f64<0x112, 0xf>(v);
+  v += dpp_f64<0x114, 0xf>(v);
+  v += dpp_f64<0x118, 0xf>(v);
+  v += dpp_f64<0x142, 0xa>(v);                   // row_bcast:15 -> rows 1, 3
+  v += dpp_f64<0x143, 0xc>(v);                   // row_bcast:31 -> rows 2, 3: lane 63 holds the wave's sum
+  const unsigned long long b = __builtin_bit_cast(unsigned long long, v);
+  const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)b, 63), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(b >> 32), 63);
+  return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
 }
 
 __global__ __launch_bounds__(kLossThreads) void loss_partials_kernel(LossParams p) {
