@@ -91,7 +91,8 @@ class OverlappedLossReducer:
 
     def push(self, partials: torch.Tensor, collect: bool = False, donate: bool = False) -> Optional[torch.Tensor]:
         """``donate``: the caller gives ``partials`` up (render_rays returns a fresh tensor every step) -- it becomes the ring
-        slot and is reduced in place, without the staging copy (a 4 us launch on the step's stream)."""
+        slot and is reduced in place, without the staging copy (a 4 us launch on the step's stream).  Honoured only for
+        gradient-free partials on the reducer's device (see below); otherwise the call takes the copy."""
         k = self.i % len(self.bufs)
         self.i += 1
         done = None
@@ -99,10 +100,15 @@ class OverlappedLossReducer:
             self.work[k].wait()                      # stream-ordered for NCCL/RCCL (no host block); blocking for gloo
             if collect:
                 done = self.bufs[k].clone()
-        if donate and partials.dtype == self.bufs[k].dtype and partials.shape == self.bufs[k].shape and partials.is_contiguous():
+        # Donation is for GRADIENT-FREE partials only: under grad, `partials` is the output of autograd.LossPartials, which
+        # saves it for its backward (the counts decide the all-true mask and the scaling) -- reducing it in place would
+        # hand that backward the cross-rank sums (or trip autograd's version check).  A tensor on another device must not
+        # replace the ring slot either.  Anything else takes the staging copy.
+        if (donate and not partials.requires_grad and partials.grad_fn is None and partials.device == self.bufs[k].device
+                and partials.dtype == self.bufs[k].dtype and partials.shape == self.bufs[k].shape and partials.is_contiguous()):
             self.bufs[k] = partials
         else:
-            self.bufs[k].copy_(partials)
+            self.bufs[k].copy_(partials.detach())
         if self.active:
             self.work[k] = dist.all_reduce(self.bufs[k], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         else:
@@ -152,3 +158,156 @@ def gather_pixels(local: torch.Tensor, n_total: int, group=None) -> torch.Tensor
     parts = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(parts, pad, group=group)
     return torch.cat([parts[r][: sizes[r][1] - sizes[r][0]] for r in range(world)], 0)
+
+
+# ------------------------------------------------------------------ data-parallel TRAINING (training half)
+class _GlobalSum(torch.autograd.Function):
+    """y = all_reduce(SUM)(x) as a differentiable node.  Every rank then forms the SAME global loss L(y), and
+    dL / dx_r = dL / dy on every rank (y = sum_r x_r), so the backward is the identity -- no collective in it.  With the
+    loss formed from the globally reduced (sum, count) partials each rank's parameter gradients are its rays' share of
+    the gradient of the GLOBAL loss: their SUM over the ranks (GradReducer, average=False) is exactly the single-process
+    gradient on the concatenated batch, masked consensus means with data-dependent counts included."""
+
+    @staticmethod
+    def forward(ctx, x, group):
+        y = x.detach().clone()
+        if dist.is_available() and dist.is_initialized():
+            dist.all_reduce(y, op=dist.ReduceOp.SUM, group=group)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, None
+
+
+def global_partials(partials: torch.Tensor, group=None) -> torch.Tensor:
+    """The 12 loss partials of ``render_rays(..., _loss_target=gt)`` summed over the ranks (96 bytes through RCCL),
+    differentiable: feed the result to ``losses.from_partials`` and call ``backward()``; pair with
+    ``GradReducer(average=False)``."""
+    return _GlobalSum.apply(partials, group)
+
+
+class GradReducer:
+    """Bucketed gradient all-reduce for ray-sharded data-parallel training, overlapped with the backward launches.
+
+    The reference wraps its networks in DistributedDataParallel (trainer/base.py:251-256) but hands the BARE modules to
+    render_rays (trainer_moco_flow.py:80-117, 203-206), so its reducer never fires and its "8-GPU training" is eight
+    unsynchronised replicas.  This is what a drop-in that is meant to use eight GPUs for ONE model
+    needs instead, sized for this path: 1.32 M fp32 gradients = 5.3 MB in total, four networks.
+
+    * ONE flat fp32 buffer holds every gradient; bucket = one network (``buckets``: a list of modules, parameter lists or
+      (name, module | parameters) pairs).  A parameter's ``.grad`` IS a view of its slot (DDP's gradient_as_bucket_view):
+      autograd accumulates into it in place; after ``zero_grad(set_to_none=True)`` the first gradient of the step is
+      copied in and ``.grad`` re-pointed at the slot.
+    * ``register_post_accumulate_grad_hook`` on every trainable parameter: when the last parameter of a bucket that takes
+      part in this step has its gradient, the bucket's slice goes out as ONE ``all_reduce(async_op=True)`` -- in the joint
+      step the two NoFs' ``mf_weight_grads`` launches are enqueued before the NeRFs' dX chains finish, so their collectives
+      run under the remaining backward launches.  xGMI is point to point (7 links x ~153 GB/s): a 2.4 MB NeRF bucket is
+      ~16 us of link time per ring step, the 0.27 MB NoF buckets are latency; four collectives per step, never one per
+      parameter.
+    * ``wait()`` before ``optimizer.step()``: issues the buckets whose hooks did not complete (frozen sub-modules,
+      parameters that got no gradient: every rank must issue the same collectives, and requires_grad is the same on
+      every rank), waits for the work handles (stream-ordered for RCCL: no host block), and -- ``average=True`` (DDP's
+      convention: per-rank mean losses) -- scales the whole flat buffer by 1 / world in ONE launch; ``average=False``
+      with ``global_partials`` (the exact formulation, see there) needs no scaling at all.
+    Parameters that got no gradient in a step keep ``.grad = None`` (the optimiser skips them, as in the reference's
+    frozen-trunk phase, trainer_moco_flow.py:391-404); their slots travel as zeros."""
+
+    def __init__(self, buckets, group=None, average: bool = True, device=None):
+        self.group, self.average = group, average
+        self.buckets = []
+        params = []
+        for i, b in enumerate(buckets):
+            name = f"bucket{i}"
+            if isinstance(b, tuple) and len(b) == 2 and isinstance(b[0], str):
+                name, b = b
+            ps = list(b.parameters()) if hasattr(b, "parameters") else list(b)
+            if not ps:
+                continue
+            self.buckets.append({"name": name, "params": ps, "lo": 0, "hi": 0, "pending": None, "work": None})
+            params += ps
+        if not params:
+            raise ValueError("GradReducer: no parameters")
+        if any(p.dtype != torch.float32 for p in params):
+            raise TypeError("GradReducer: fp32 parameters only (the path trains in fp32)")
+        dev = device if device is not None else params[0].device
+        off = 0
+        self.slot = {}
+        for b in self.buckets:
+            b["lo"] = off
+            for p in b["params"]:
+                self.slot[id(p)] = (off, p.numel(), b)
+                off += (p.numel() + 3) // 4 * 4                 # 16-byte aligned slots
+            b["hi"] = off
+        self.flat = torch.zeros(off, dtype=torch.float32, device=dev)
+        self.active = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.active else 1
+        self.issued = 0                                         # collectives issued so far (tests)
+        self._handles = {}
+        self._register()
+
+    def _register(self):
+        # torch refuses hooks on tensors that do not require grad: a parameter frozen now gets its hook once it is unfrozen
+        # (checked at every wait(); until then _issue() picks its gradient up, so a missing hook only costs overlap)
+        for b in self.buckets:
+            for p in b["params"]:
+                if p.requires_grad and id(p) not in self._handles:
+                    self._handles[id(p)] = p.register_post_accumulate_grad_hook(self._hook)
+
+    def view_of(self, p):
+        """A parameter's slot of the flat buffer, in the parameter's shape."""
+        off, n, _ = self.slot[id(p)]
+        return self.flat[off:off + n].view(p.shape)
+
+    def _adopt(self, p):
+        """p.grad -> the flat slot (first gradient of a step after zero_grad(set_to_none=True)); .grad becomes the view."""
+        view = self.view_of(p)
+        if p.grad.data_ptr() != view.data_ptr():
+            view.copy_(p.grad)
+            p.grad = view
+
+    def _hook(self, p):
+        b = self.slot[id(p)][2]
+        if b["work"] is not None:
+            raise RuntimeError(f"GradReducer: gradient for bucket {b['name']} after its all-reduce was issued "
+                               f"(call wait() once per backward; gradient accumulation over several backwards: wait() after the last)")
+        if b["pending"] is None:
+            b["pending"] = {id(q) for q in b["params"] if q.requires_grad and id(q) in self._handles}
+        if p.grad is not None:
+            self._adopt(p)
+        b["pending"].discard(id(p))
+        if not b["pending"]:
+            self._issue(b)
+
+    def _issue(self, b):
+        # slots of parameters without a gradient this step travel as zeros (their .grad stays None: the optimiser skips them)
+        for p in b["params"]:
+            if p.grad is None:
+                self.view_of(p).zero_()
+            else:
+                self._adopt(p)
+        seg = self.flat[b["lo"]:b["hi"]]
+        if self.active:
+            b["work"] = dist.all_reduce(seg, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            b["work"] = _Done()
+        self.issued += 1
+
+    def wait(self):
+        """Before optimizer.step(): every bucket reduced, gradients averaged (average=True).  Returns the flat buffer."""
+        for b in self.buckets:
+            if b["work"] is None:
+                self._issue(b)
+        for b in self.buckets:
+            b["work"].wait()
+        if self.average and self.world > 1:
+            self.flat.mul_(1.0 / self.world)
+        for b in self.buckets:
+            b["work"], b["pending"] = None, None
+        self._register()
+        return self.flat
+
+    def remove(self):
+        for h in self._handles.values():
+            h.remove()
+        self._handles = {}

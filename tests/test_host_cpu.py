@@ -444,6 +444,157 @@ def test_overlapped_loss_reducer_two_rank_gloo():
     assert [r.tolist() for r in solo.finish()] == [[1.0, 1.0], [2.0, 1.0], [3.0, 1.0]]
 
 
+def _dp_case(n, lo=0, hi=None):
+    """The oracle's networks + one MoCo coarse + fine pass over rays [lo, hi) WITH gradients (the oracle stands in for the
+    HIP modules: this is about the reduction logic, and HIP modules do not run on the CPU)."""
+    from helpers import build_case, case_inputs
+    from oracle import cpu_ref as R
+    case = dict(extra="ind", regime="dense", nof="global", S=12, M=8, n=n)
+    embs, nerfs, kw = build_case(R, case, 5)
+    rays, bg = case_inputs(case, 5)
+    hi = n if hi is None else hi
+    nets = list(nerfs) + list(kw["nof_models"])
+    plists = []
+    for i, m in enumerate(nets):                                # the oracle's networks are tensor containers (.p)
+        plists.append([m.p[k].requires_grad_(not (i == 1 and k.startswith("rgb."))) for k in sorted(m.p)])
+    return plists, (lambda: R.render_rays(rays[lo:hi], bg[lo:hi], embs, nerfs, **kw))
+
+
+def _dp_total(parts):
+    from moco_flow_amd import losses
+    t = losses.from_partials(parts)
+    return t["img_loss"] + 0.1 * t["nof_local"] + 0.1 * t["nof_global"]
+
+
+def _grad_worker(rank, world, port, n, q):
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.set_num_threads(2)
+    from moco_flow_amd import dist as D, synth
+    lo, hi = D.shard_bounds(n, rank, world)
+    gt = torch.from_numpy(synth.uniform01(11, n * 3).reshape(n, 3).astype(np.float32))
+    # (the fine NeRF's rgb head is frozen -- the reference's frozen-sub-module phases, trainer_moco_flow.py:391-404: no
+    #  gradient, no hook, and the bucket still goes out, at wait())
+    nets, render = _dp_case(n, lo, hi)
+    red = D.GradReducer([(f"net{i}", m) for i, m in enumerate(nets)], average=False)
+    opt = torch.optim.SGD([p for m in nets for p in m if p.requires_grad], lr=0.05)
+    snap = []
+    for step in range(2):
+        opt.zero_grad(set_to_none=(step == 0))
+        res = render()
+        total = _dp_total(D.global_partials(D.loss_partials(res, gt[lo:hi])))
+        total.backward()
+        issued_in_backward = red.issued
+        red.wait()
+        if step == 0:
+            snap = [None if p.grad is None else p.grad.clone() for m in nets for p in m]
+            first = float(total.detach())
+        opt.step()
+        if step == 0:
+            w_first = [p.detach().clone().numpy() for m in nets for p in m]
+    w = [p.detach().clone() for m in nets for p in m]
+    q.put((rank, (first, float(total.detach()), w_first), issued_in_backward, [None if g is None else g.numpy() for g in snap], [t.numpy() for t in w]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_grad_reducer_two_rank_gloo_equals_single_process_step():
+    """SURVEY 8(e), training half: two ranks, different rays (a ragged 11 / 10 split), the global loss from the all-reduced
+    partials (dist.global_partials), per-network gradient buckets all-reduced from the post-accumulate hooks
+    (dist.GradReducer, SUM) -> after two SGD steps both ranks hold IDENTICAL weights, equal to the single-process steps on
+    the concatenated batch within fp32 reduction order; masked consensus means with data-dependent counts included."""
+    import torch.multiprocessing as mp
+    from moco_flow_amd import dist as D, synth
+    n = 21
+    gt = torch.from_numpy(synth.uniform01(11, n * 3).reshape(n, 3).astype(np.float32))
+    nets, render = _dp_case(n)
+    opt = torch.optim.SGD([p for m in nets for p in m if p.requires_grad], lr=0.05)
+    for step in range(2):
+        opt.zero_grad()
+        total = _dp_total(D.loss_partials(render(), gt))
+        total.backward()
+        if step == 0:
+            want_g = [None if p.grad is None else p.grad.clone() for m in nets for p in m]
+            first = float(total.detach())
+        opt.step()
+        if step == 0:
+            want_w = [p.detach().clone() for m in nets for p in m]
+    world, port = 2, 35500 + os.getpid() % 2000
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_grad_worker, args=(r, world, port, n, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    outs = sorted([q.get(timeout=240) for _ in range(world)], key=lambda t: t[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, l0, i0, g0, w0), (_, l1, i1, g1, w1) = outs
+    # every rank forms the same global loss; step 0: float64 sums of the same fp32 terms; step 1: behind one update (the MoCo
+    # chain carries sin(512 x) of a NoF output: a 1e-6 difference in a gradient moves the next loss by ~1e-5)
+    assert l0[:2] == l1[:2]
+    assert l0[0] == pytest.approx(first, rel=1e-9) and l0[1] == pytest.approx(float(total.detach()), rel=1e-3)
+    # all four buckets go out INSIDE backward(), from the hooks (a frozen parameter is not waited for), in both steps
+    assert i0 == i1 == 8
+    for a, b in zip(w0, w1):
+        assert np.array_equal(a, b)                                     # identical weights on both ranks
+    for a, b, w in zip(g0, g1, want_g):
+        assert (a is None) == (w is None) == (b is None)
+        if w is not None:
+            assert np.array_equal(a, b)
+            denom = max(float(w.abs().max()), 1e-12)
+            assert float(np.abs(a - w.numpy()).max()) / denom < 2e-5
+    # the weights after the FIRST update against the single-process step (the second gradient is taken at weights 1e-6
+    # apart, on a loss with ReLU kinks and sin(512 x): compared between the ranks only, above)
+    for a, b, w in zip(l0[2], l1[2], want_w):
+        assert np.array_equal(a, b)
+        assert float(np.abs(a - w.numpy()).max()) / max(float(w.abs().max()), 1e-12) < 2e-5
+
+
+def test_grad_reducer_single_process_semantics():
+    """No process group: the reducer is a flat-buffer view manager.  .grad aliases the flat slots; zero_grad(set_to_none)
+    is survived; average=True at world 1 is the identity; a second backward without wait() raises (a bucket is reduced
+    once per step); the donate path of the loss reducer refuses tensors that autograd saved."""
+    from moco_flow_amd.dist import GradReducer, OverlappedLossReducer
+    torch.manual_seed(0)
+    m = torch.nn.Sequential(torch.nn.Linear(4, 5), torch.nn.ReLU(), torch.nn.Linear(5, 2))
+    red = GradReducer([m[0], m[2]])
+    x = torch.randn(7, 4)
+    m(x).square().sum().backward()
+    assert red.issued == 2
+    flat = red.wait().clone()
+    for p in m.parameters():
+        assert p.grad.data_ptr() == red.view_of(p).data_ptr()
+    ref = torch.autograd.grad(m(x).square().sum(), list(m.parameters()))
+    for p, g in zip(m.parameters(), ref):
+        assert torch.allclose(p.grad, g)
+    m.zero_grad(set_to_none=True)
+    m(x).square().sum().backward()
+    assert torch.equal(red.wait(), flat)
+    m.zero_grad(set_to_none=True)
+    m(x).square().sum().backward()
+    with pytest.raises(RuntimeError, match="after its all-reduce was issued"):
+        m(x).square().sum().backward()
+    red.wait()
+    red.remove()
+    with pytest.raises(ValueError):
+        GradReducer([])
+    # donation only for gradient-free partials
+    lr = OverlappedLossReducer(3, "cpu", depth=2)
+    w = torch.ones(3, dtype=torch.float64, requires_grad=True)
+    part = w * 2.0
+    lr.push(part, donate=True)
+    assert lr.bufs[0] is not part and lr.bufs[0].tolist() == [2.0, 2.0, 2.0]
+    part.sum().backward()                                               # autograd's saved tensors are untouched
+    free = torch.full((3,), 5.0, dtype=torch.float64)
+    lr.push(free, donate=True)
+    assert lr.bufs[1] is free
+
+
 def test_packed_cache_does_not_travel():
     """the packed-weights cache holds ctypes structures with device pointers; deepcopy / pickle of a
     module that has rendered must work (the copy re-packs) and invalidate_packed() must drop every cache."""
