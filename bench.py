@@ -91,6 +91,12 @@ CONFIGS = {
                what="C4: C3 ray-sharded (4096 rays per rank) + all-reduce of the per-batch loss partials"),
     "C5": dict(net="ind", precision="bf16", rays=1024, S=64, M=128, nof="global", loss=True,
                what="C5: coarse 64 + fine 128 (inverse-CDF resample), MoCo local+global chains, bf16, 1024 rays per rank"),
+    # BASELINE config 5 at its FULL size on one GPU (the largest single-GPU configuration of `configs`): 8192 rays, not the
+    # 1024-ray per-rank shard -- 32 coarse / 96 fine 256-sample tiles per CU instead of one / three
+    "C5full": dict(net="ind", precision="bf16", rays=8192, S=64, M=128, nof="global", loss=True, steps=(40, 10),
+                   what="C5 at full size on ONE GPU: 8192 rays, coarse 64 + fine 128 (inverse-CDF resample), MoCo local+global chains, bf16"),
+    "C5xfull": dict(net="ind", precision="bf16x3", rays=8192, S=64, M=128, nof="global", loss=True, steps=(20, 5),
+                    what="C5 at full size on ONE GPU in the contract mode of the bf16 pipe (bf16x3)"),
 }
 
 
@@ -215,7 +221,7 @@ def cpu_baseline(cfg, states, rays_np, bg_np, budget_s=30.0):
     rays, bg = torch.from_numpy(rays_np), torch.from_numpy(bg_np)
     n = rays.shape[0]
     ncpu = os.cpu_count() or 8
-    sweep = sorted({t for t in (8, 16, 32, 64, 128) if t <= ncpu} | {min(ncpu, 128)})
+    sweep = sorted({t for t in (16, 32, 64) if t <= ncpu} or {min(ncpu, 64)})      # (round 5: 8 / 128 never won on the 64-core box)
     t_start = time.perf_counter()
     oracle_render(cfg, states, rays[:128], bg[:128])                  # warm-up
     per_thread, out = {}, None
@@ -264,10 +270,28 @@ def traffic_of(name):
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             t = json.load(fh).get(name)
         if t:
-            return t["bytes_per_launch"], t["source"]
+            return t["bytes_per_launch"], t["source"], t
     except (OSError, ValueError, KeyError):
         pass
-    return None, None
+    return None, None, {}
+
+
+def algorithmic_bytes(cfg, launch_samples):
+    """HBM bytes ONE launch of the dominant kernel must move (SURVEY.md 8d: 48 B in + 20 B out per ray; + the weights once;
+    + 4 B per sample and (N, S) plane the caller asked for: a consensus pass hands back alphas and one distance plane per
+    chain; + the bf16 modes' per-ray NoF bias rows, 512 B per (ray, network-index combination, embedded layer), written by
+    mf_render_prepare and read once).  Weights in the element size of the packed stream (f32 4 B, bf16 2 B, bf16x3 2 x 2 B
+    for the NeRF / 3 x 2 B for the NoFs)."""
+    S = cfg["S"] + cfg["M"] if cfg["M"] else cfg["S"]
+    rays = launch_samples // S
+    n_nerf = {"dir": 595844, "ind": 593028}[cfg["net"]]
+    wbytes = {"f32": (4, 4), "bf16": (2, 2), "bf16x3": (4, 6)}[cfg["precision"]]
+    w = n_nerf * wbytes[0] + (2 if cfg["nof"] in ("local", "global") else (1 if cfg["nof"] else 0)) * 67721 * wbytes[1]
+    planes = {None: 0, "bw": 0, "local": 2, "global": 3}[cfg["nof"]]
+    bias = 0
+    if cfg["nof"] and cfg["precision"] != "f32":
+        bias = rays * {"bw": 1, "local": 2, "global": 4}[cfg["nof"]] * 2 * 512
+    return rays * 68 + w + planes * 4 * launch_samples + bias
 
 
 def train_leg(M, torch, models, rays, bg, gt, kw, cfg, steps=10):
@@ -366,15 +390,7 @@ def train_shape_legs(M, synth, torch, dev, steps=6):
     torch.cuda.empty_cache()
     # joint MoCo stage
     N = 1024
-    nerfs = [load(M.NeRF(8, 256, 63, [4], "ind", 5), synth.nerf_state(0, extra_feat_type="ind", extra_feat_dim=5, regime="dense", tag=t))
-             for t in ("coarse", "fine")]
-    nofs = [load(M.NoF(4, 128, 33, [2], "ind", 33, True), synth.nof_state(0, use_quat=True, tag=t, head_scale=0.25)) for t in ("bw", "fw")]
-    embs = [M.Embedding(3, 10), M.Embedding(1, 2), None]
-    r, b = synth.rays(0, N, chained=True)
-    rays, bg = torch.from_numpy(r).to(dev), torch.from_numpy(b).to(dev)
-    gt = torch.rand(N, 3, device=dev)
-    kw = dict(nof_embeddings=[M.Embedding(3, 5), M.Embedding(1, 16)], nof_models=nofs, chain_local=True, chain_global=True,
-              N_samples=128, N_importance=128, noise_std=0, perturb=1.0)
+    nerfs, nofs, rays, bg, gt, embs, kw = joint_stage_setup(M, synth, torch, dev, N)
 
     def joint():
         for m in nerfs + nofs:
@@ -387,6 +403,139 @@ def train_shape_legs(M, synth, torch, dev, steps=6):
 
     out["joint"] = {"ms_per_step": med(joint), "rays": N, "samples_per_ray": 384}
     del nerfs, nofs, rays, bg, gt
+    torch.cuda.empty_cache()
+    return out
+
+
+def joint_stage_setup(M, synth, torch, dev, N=1024, seed=0):
+    """The joint MoCo stage's step shape (c2f.yaml: N rays x (128 + 128 + 128), NeRF(ind / 5) x 2 behind the backward NoF,
+    local + global consensus chains, perturb = 1) -> (networks, rays, bg, gt, embeddings, render kwargs)."""
+    def load(m, sd):
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        return m.to(dev)
+    nerfs = [load(M.NeRF(8, 256, 63, [4], "ind", 5), synth.nerf_state(0, extra_feat_type="ind", extra_feat_dim=5, regime="dense", tag=t))
+             for t in ("coarse", "fine")]
+    nofs = [load(M.NoF(4, 128, 33, [2], "ind", 33, True), synth.nof_state(0, use_quat=True, tag=t, head_scale=0.25)) for t in ("bw", "fw")]
+    embs = [M.Embedding(3, 10), M.Embedding(1, 2), None]
+    r, b = synth.rays(seed, N, chained=True)
+    rays, bg = torch.from_numpy(r).to(dev), torch.from_numpy(b).to(dev)
+    gt = torch.rand(N, 3, device=dev)
+    kw = dict(nof_embeddings=[M.Embedding(3, 5), M.Embedding(1, 16)], nof_models=nofs, chain_local=True, chain_global=True,
+              N_samples=128, N_importance=128, noise_std=0, perturb=1.0)
+    return nerfs, nofs, rays, bg, gt, embs, kw
+
+
+def train_dp_leg(M, synth, torch, dev, dist, rank, world, steps=6):
+    """Data-parallel TRAINING across the ranks (training half): the joint stage's step, 1024 rays per rank
+    (weak scaling), global loss from the all-reduced 12 partials (dist.global_partials: 96 B), the four networks' flat
+    gradient (5.3 MB) all-reduced per network from the post-accumulate hooks while the remaining backward launches run
+    (dist.GradReducer) -- median ms per step with and without the reduce (MAX over ranks)."""
+    from moco_flow_amd import dist as D, losses
+    nerfs, nofs, rays, bg, gt, embs, kw = joint_stage_setup(M, synth, torch, dev, 1024, seed=rank)
+    nets = nerfs + nofs
+
+    def total_of(parts):
+        t = losses.from_partials(parts)
+        return t["img_loss"] + 0.1 * t["nof_local"] + 0.1 * t["nof_global"]
+
+    def step(red):
+        for m in nets:
+            m.zero_grad(set_to_none=True)
+        res = M.render_rays(rays, bg, embs, nerfs, _loss_target=gt, **kw)
+        total_of(res["loss_partials"] if red is None else D.global_partials(res["loss_partials"])).backward()
+        if red is not None:
+            red.wait()
+
+    def med(red):
+        step(red)
+        step(red)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(steps):
+            if dist is not None:
+                dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            step(red)
+            torch.cuda.synchronize()
+            ts.append((time.perf_counter() - t0) * 1e3)
+        t = torch.tensor([sorted(ts)[len(ts) // 2]], device=dev, dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
+
+    local = med(None)
+    red = D.GradReducer([(n, m) for n, m in zip(("nerf_coarse", "nerf_fine", "nof_bw", "nof_fw"), nets)], average=False)
+    with_reduce = med(red)
+    red.remove()
+    return {"ms_per_step_local": local, "ms_per_step_allreduce": with_reduce, "rays_per_gpu": 1024, "samples_per_ray": 384,
+            "flat_gradient_bytes": int(red.flat.numel() * 4), "buckets": len(red.buckets), "world": world,
+            "what": "joint MoCo training step per rank: without any collective / with the global loss from the all-reduced "
+                    "partials + the per-network gradient all-reduce overlapped with backward (dist.GradReducer), median ms, MAX over ranks"}
+
+
+def aux_legs(M, synth, torch, dev):
+    """The paths either side of render_rays that SURVEY.md 8(f) rows 2-3 name, driver-visible:
+      lattice: the mesh-extraction sigma query (test.py:55-56,96 -> visualize_mesh, trainer_moco_flow.py:485-548) on a 256^3
+               lattice as ONE fused launch (mf_points_sigma_p): canonical space in f32 / bf16x3, observation space (bw NoF
+               first) in bf16x3; points/s and the fraction of the matrix peak (NeRF sigma path 982 528 FLOP per point,
+               + 134 400 through the NoF; bf16x3: peak / 3 resp. the NeRF-3 / NoF-6 mix);
+      image:   one 512 x 512 image.render_image call (MoCoFlowTrainer.render, trainer_moco_flow.py:226-268): rays made on the
+               device, 1/7 of the pixels masked out, MoCo path (bw NoF -> NeRF), 64 + 128 samples, test_time, bf16."""
+    import functools
+    import numpy as np
+    from moco_flow_amd import camera, image, rendering
+
+    def load(m, sd):
+        m.load_state_dict({k: torch.from_numpy(v) for k, v in sd.items()})
+        return m.to(dev)
+
+    def timeit(f, n=3):
+        f()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            f()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n
+
+    sig = lambda x, n=3: float(f"{x:.{n}g}")
+    out = {}
+    with torch.no_grad():
+        nerf = load(M.NeRF(8, 256, 63, [4], "ind", 5), synth.nerf_state(0, extra_feat_type="ind", extra_feat_dim=5, regime="dense"))
+        nof = load(M.NoF(4, 128, 33, [2], "ind", 33, True), synth.nof_state(0, use_quat=True, tag="bw", head_scale=0.25))
+        G = 256
+        ax = torch.linspace(-1.2, 1.2, G, device=dev)
+        xyz = torch.stack(torch.meshgrid(ax, ax, ax, indexing="ij"), -1).reshape(-1, 3).contiguous()
+        emb, nof_embs = M.Embedding(3, 10), [M.Embedding(3, 5), M.Embedding(1, 16)]
+        P = xyz.shape[0]
+        f_nerf, f_nof = 982528, FLOPS["nof_quat"]
+        x3_nof_peak = PEAK["bf16"] * (f_nerf + f_nof) / (3 * f_nerf + 6 * f_nof)
+        for tag, fn, flops, peak in (
+                ("f32", lambda: M.query_sigma(xyz, nerf, emb, precision="f32"), f_nerf, PEAK["f32"]),
+                ("x3", lambda: M.query_sigma(xyz, nerf, emb, precision="bf16x3"), f_nerf, PEAK["bf16"] / 3),
+                ("x3_nof", lambda: M.query_sigma(xyz, nerf, emb, nof, nof_embs, 0.25, precision="bf16x3"), f_nerf + f_nof, x3_nof_peak)):
+            t = timeit(fn)
+            out["lattice_" + tag] = {"pts_s": sig(P / t, 4), "frac": sig(P * flops / t / 1e12 / peak)}
+        del xyz
+        H = W = 512
+        c2w = np.array([[1, 0, 0, 0.0], [0, 1, 0, 0.0], [0, 0, 1, 4.0]], dtype=np.float64)
+        rays = camera.make_rays(H, W, 1.2 * W, (W / 2, H / 2), c2w, 2.0, 6.0, -0.25)
+        bg = torch.ones(H * W, 3, device=dev)
+        msk = np.ones(H * W, dtype=bool)
+        msk[::7] = False
+        nerfs = [nerf, load(M.NeRF(8, 256, 63, [4], "ind", 5), synth.nerf_state(0, extra_feat_type="ind", extra_feat_dim=5, regime="dense", tag="fine"))]
+        fn = functools.partial(M.render_rays, nerf_embeddings=[M.Embedding(3, 10), M.Embedding(1, 2), None], nerf_models=nerfs,
+                               nof_embeddings=nof_embs, nof_models=[nof], N_samples=64, N_importance=128, perturb=0, noise_std=0, test_time=True)
+        prev = rendering.PRECISION
+        rendering.set_precision("bf16")
+        try:
+            t = timeit(lambda: image.render_image(rays, bg, lambda r, b: fn(r, b), 65536, msk))
+        finally:
+            rendering.set_precision(prev)
+        nv = int(msk.sum())
+        flops = nv * (64 * (f_nerf + f_nof) + 192 * (FLOPS["nerf_ind"] + f_nof))
+        out["image_512_bf16"] = {"ms": sig(t * 1e3, 4), "rs_s": sig(nv * 256 / t, 4), "frac": sig(flops / t / 1e12 / PEAK["bf16"])}
     torch.cuda.empty_cache()
     return out
 
@@ -573,7 +722,18 @@ def run_config(name, a, ctx, steps, warmup, main):
     flops_launch = launch_samples * flops_per_sample(cfg)
     achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
     peak = peak_of(cfg)
-    traffic, traffic_src = traffic_of(name)
+    traffic, traffic_src, prof = traffic_of(name)
+    alg_bytes = algorithmic_bytes(cfg, launch_samples)
+    launches = 2 if cfg["M"] else 1
+    # three readings of the same fraction, so that they are never confused:
+    #   frac             HIP-graph replay of back-to-back launches of the dominant kernel, median (warm box: the best case)
+    #   frac_step        the whole step's algorithmic FLOP / ms_per_step of the timed region (everything a step does)
+    #   frac_rocprof_avg the rocprofv3 --kernel-trace average of the same command in profiles/ (+ MFMA busy and the effective
+    #                    clock of that run: busy x GHz / 2.4 / (issued / algorithmic MFMAs) = the fraction)
+    rp = {}
+    if prof.get("rocprof_avg_us"):
+        rp = {"frac_rocprof_avg": flops_launch / (prof["rocprof_avg_us"] * 1e-6) / 1e12 / peak, "rocprof_avg_us": prof["rocprof_avg_us"],
+              "mfma_busy": prof.get("mfma_busy"), "ghz": prof.get("ghz"), "rocprof_source": prof.get("profile")}
     res = {
         "value": value, "ms_per_step": elapsed / steps * 1e3, "dtype": cfg["precision"],
         "config": {"workload": cfg["what"] + f" [{cfg['precision']}]", "rays_per_gpu": n,
@@ -581,14 +741,17 @@ def run_config(name, a, ctx, steps, warmup, main):
                    "sharding": f"rays{world}" if world > 1 else "none",
                    "loss_allreduce": bool(reducer is not None and world > 1)},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "peak_note": PEAK_NOTE[cfg["precision"]],
-                     "unit": "TFLOP/s", "frac": achieved / peak, "traffic": traffic, "traffic_unit": "B/launch",
+                     "unit": "TFLOP/s", "frac": achieved / peak,
+                     "frac_step": flops_step / (elapsed / steps) / 1e12 / peak, **rp,
+                     "traffic": traffic, "traffic_unit": "B/launch", "traffic_algorithmic": alg_bytes,
+                     "traffic_ratio": (traffic / alg_bytes) if traffic else None,
                      "traffic_source": traffic_src,
                      "traffic_note": "HBM bytes per launch: the weight stream is read once per XCD L2 (8 x the packed weights) + "
                                      "rays / requested (N,S) planes" + (" + the per-ray NoF bias table" if cfg["nof"] and cfg["precision"] != "f32" else "")
                                      + "; algorithmic I/O is 68 B/ray (+ 8 B/sample per requested plane): MFMA-bound, not HBM-bound",
                      "kernel": "mf_render_pass" + (" (fine pass)" if cfg["M"] else ""),
                      "kernel_ms": kernel_ms, "kernel_ms_how": probe_how, "flops_per_launch": flops_launch, "samples_per_launch": launch_samples,
-                     "step_span_ms": step_span_ms, "launches_per_step": 2 if cfg["M"] else 1,
+                     "step_span_ms": step_span_ms, "launches_per_step": launches,
                      "flops_per_step": flops_step},
     }
     if cfg["nof"] and reducer is None and world == 1:
@@ -709,12 +872,12 @@ def worker(a):
         if k in res:
             line[k] = res[k]
     if not a.no_extra_legs and a.config == "C2":
-        legs = ["C2x", "C3", "C3x", "C3g", "C5", "C5x"] if world == 1 else ["C4", "C5"]
+        legs = ["C2x", "C3", "C3x", "C3g", "C5", "C5x", "C5full", "C5xfull"] if world == 1 else ["C4", "C5"]
         line["configs"] = {}
         for name in legs:
             # sub-millisecond passes: 100 warm-up steps (a handful leaves the clocks ramping -- C3 measured 0.372 ms/step
             # after 5 warm-up steps, 0.345 after 100, kernel 0.346 -- profiles/README.md) and 200 timed ones
-            k_leg, w_leg = (200, 100) if a.steps >= 10 else (a.steps, a.warmup)
+            k_leg, w_leg = CONFIGS[name].get("steps", (200, 100)) if a.steps >= 10 else (a.steps, a.warmup)
             r = run_config(name, a, ctx, k_leg, w_leg, main=False)
             line["configs"][name] = {k: r[k] for k in ("value", "ms_per_step", "dtype", "config", "roofline", "error_vs_cpu", "loss_path",
                                                        "cpu_baseline", "speedup_vs_cpu") if k in r}
@@ -727,12 +890,20 @@ def worker(a):
         worst = max(e["max_rel"].values()) if e.get("max_rel") else None
         sig = lambda x, n=4: None if x is None else float(f"{x:.{n}g}")
         return {"ms": sig(r["ms_per_step"]), "kernel_ms": sig(r["roofline"]["kernel_ms"]), "frac": sig(r["roofline"]["frac"], 3),
-                "db": sig(e.get("psnr_equiv_db"), 4), "max_rel": sig(worst, 2)}
+                "frac_step": sig(r["roofline"]["frac_step"], 3), "db": sig(e.get("psnr_equiv_db"), 4), "max_rel": sig(worst, 2)}
     legs = {main_cfg: compact(res)}
     for name, r in line.get("configs", {}).items():
         legs[name] = compact(r)
     if "train_steps" in res:
         legs["train_ms"] = {k: float(f"{v['ms_per_step']:.4g}") for k, v in res["train_steps"].items() if isinstance(v, dict)}
+    if not a.no_extra_legs and not a.no_train_leg and a.config == "C2":
+        if world > 1:
+            line["train_joint_dp"] = train_dp_leg(M, synth, torch, dev, dist, rank, world)
+            legs["train_dp_ms"] = {"local": float(f"{line['train_joint_dp']['ms_per_step_local']:.4g}"),
+                                   "allreduce": float(f"{line['train_joint_dp']['ms_per_step_allreduce']:.4g}")}
+        else:
+            line["aux"] = aux_legs(M, synth, torch, dev)
+            legs["aux"] = line["aux"]
     if "fwd_bwd" in res:
         legs["fwd_bwd_ms"] = float(f"{res['fwd_bwd']['ms_per_step']:.4g}")
     line["legs"] = legs

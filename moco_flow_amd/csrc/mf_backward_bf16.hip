@@ -143,14 +143,7 @@ MF_D void bwd_layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[1
     f32x4 v;
 #pragma unroll
     for (int i = 0; i < 4; ++i) v[i] = b3_val<MASK, SIG, BITS>(acc, m, 4 * q + i, sigw_off, t, id.h, dsig);
-#ifdef MF_B3_ABL_NOSTORE                                        // (timing ablation, tools/ab_lib.sh: results are garbage)
-    if (v[0] == 1.2345e-30f)
-#endif
-#ifdef MF_B3_ABL_COALESCED     // (timing ablation: the same bytes into the same rows, but one contiguous KiB per instruction)
-    *reinterpret_cast<f32x4*>(grow - 4 * id.h + ((long long)(4 * t + q) - (id.lane & 31)) * 2432LL /* D = 8 stride */ + 4 * id.lane) = v;
-#else       // (plain stores: a line's eight 16-byte pieces meet in L2; `nt` stores of the same pieces: 5.19 -> 11.5 ms)
     *reinterpret_cast<f32x4*>(grow + 32 * t + 8 * q) = v;
-#endif
   };
   auto run = [&](auto tc) __attribute__((always_inline)) {
     constexpr int t = decltype(tc)::value;

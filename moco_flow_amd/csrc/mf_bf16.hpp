@@ -36,10 +36,7 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int kWaveSamples = 32;     // samples per wave
 constexpr int kTile = 256;           // samples per workgroup tile (8 waves)
-#ifndef MF_BF_PD
-#define MF_BF_PD 3                   // A-fragment prefetch distance in groups
-#endif
-constexpr int PD = MF_BF_PD;
+constexpr int PD = 3;                // A-fragment prefetch distance in groups (2 / 4 / 5 measured: +-1 %)
 
 #define MF_MFMA32(a, b, c) \
   __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, (a)), __builtin_bit_cast(bf16x8, (b)), (c), 0, 0, 0)
@@ -88,31 +85,16 @@ struct StreamT {
   MF_D void sync(int groups, const char* jump, const Lane& id, bool keep_ok = true, int sg = -1) {
     // (MF_BF_ABL_*: timing-ablation builds only, tools/ab_lib.sh; results are garbage there)
     jitter();
-#ifndef MF_BF_ABL_NOWAIT
     if constexpr (KEEP == 0) wait_vm0();     // this wave's pieces of the NEXT panel have landed
     else {
       if (keep_ok) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(KEEP) : "memory");
       else wait_vm0();
     }
-#endif
-#ifndef MF_BF_ABL_NOBAR
     __builtin_amdgcn_s_barrier();            // RAW: everybody's have; WAR: everybody left the previous panel
-#endif
     asm volatile("" ::: "memory");
     if (jump) gnext = jump;
     // this wave's pieces: a BLOCK of consecutive groups (wave w: groups w per .. w per + per - 1), so that they share one
     // base / M0 and differ in the instruction offset only
-#ifdef MF_BF_DMA_RR                           // (A/B: round 2's round-robin assignment, groups wave, wave + NW, ...)
-    dsrc = gnext + id.wave * kGroupBytes;
-    ddst = off2 + id.wave * kGroupBytes;
-    const int mine_rr = (groups - id.wave + NW - 1) / NW;
-    pmask = (1u << (mine_rr < 0 ? 0 : mine_rr)) - 1u;
-    gnext += (size_t)groups * kGroupBytes;
-    return;
-#endif
-#ifdef MF_BF_DMA_MASKED                       // (A/B: round 3's runtime mask on every piece)
-    sg = -1;
-#endif
     stat = sg >= 0 && sg % NW == 0;
     nstat = stat ? sg / NW : 0;
     const int per = stat ? nstat : (groups + NW - 1) / NW;
@@ -124,11 +106,6 @@ struct StreamT {
     gnext += (size_t)(stat ? sg : groups) * kGroupBytes;
   }
   MF_D void piece(int k, const Lane& id) {
-#ifdef MF_BF_DMA_RR
-    if ((pmask >> k) & 1u) blds16(dsrc, id.lane * 16, k * (NW * kGroupBytes), ddst + k * (NW * kGroupBytes));
-    return;
-#endif
-#ifndef MF_BF_ABL_NODMA
     if (stat ? k < nstat : (bool)((pmask >> k) & 1u)) {
       const uint32_t hi = (uint32_t)(k >> 2) * (4 * kGroupBytes);
       switch (k & 3) {
@@ -138,7 +115,6 @@ struct StreamT {
         default: blds16_imm<3072>(dsrc, id.lane * 16, hi, ddst + hi); break;
       }
     }
-#endif
   }
   MF_D void advance() {
     const uint32_t t = off0;
@@ -209,10 +185,8 @@ struct CarryT {           // the first N fragments of the panel that follows, pr
   }
 };
 using Carry = CarryT<PD>;
-#ifndef MF_BF_PDX
-#define MF_BF_PDX 3                  // the same distance in the MF_PREC_BF16X3 kernels (one wave per SIMD)
-#endif
-using CarryX = CarryT<MF_BF_PDX>;
+constexpr int PDX = 3;               // the same distance in the MF_PREC_BF16X3 kernels (one wave per SIMD; 5 measured: 0 %)
+using CarryX = CarryT<PDX>;
 
 MF_D float bflo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
 MF_D float bfhi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
@@ -257,9 +231,6 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
   static_assert(NG > PD, "panel shorter than the fragment pipeline");
   static_assert(NG >= 4, "panel too short for the DMA pieces");
   f32x16 acc;
-#ifdef MF_BF_ABL_NOBIAS
-  for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-#else
   if constexpr (RB) {
     acc = rb;
   } else {                                                // C/D order: reg 4q + i <- bias[8q + 4h + i]
@@ -268,7 +239,6 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
 #pragma unroll
     for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; acc[8 + i] = b2[i]; acc[12 + i] = b3[i]; }
   }
-#endif
   u32x4 r[PD + 1];
 #pragma unroll
   for (int i = 0; i < PD; ++i) r[i] = carry.w[i];
@@ -283,16 +253,10 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
     }
     __builtin_amdgcn_sched_barrier(0);
     const int sp = (gi + PD) % (PD + 1), nb = gi + PD;
-#ifndef MF_BF_ABL_NOFRAG
     if (nb < NG) r[sp] = lds_u4(p + nb * kGroupBytes);
-#else
-    r[sp] = r[s];
-#endif
     if (gi == 0) hook();
     if (gi >= 1 && gi <= 4) piece(gi - 1);     // (the 4th piece: only the 32-group panels of MF_PREC_BF16X3 have one)
-#ifndef MF_BF_ABL_NOFRAG
     if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
-#endif
     __builtin_amdgcn_sched_barrier(0);
 #ifndef MF_BF_BREAK_LO      // (-DMF_BF_BREAK_LO: the deliberately broken build the oracle-of-the-arithmetic tests must reject)
     if (SPLIT && ge >= 0 && ge < NEG && !(ge & 1)) {
@@ -305,9 +269,6 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
   for (int i = 0; i < PD; ++i) carry.w[i] = r[(NG + i) % (PD + 1)];
 #pragma unroll
   for (int w = 0; w < 4; ++w) {
-#ifdef MF_BF_ABL_NOEPI
-    out0[w] = __builtin_bit_cast(unsigned, acc[2 * w]); out1[w] = __builtin_bit_cast(unsigned, acc[8 + 2 * w]); continue;
-#endif
     out0[w] = pk_floor_bf16(pack_bf16x2(acc[2 * w], acc[2 * w + 1]), floor);
     out1[w] = pk_floor_bf16(pack_bf16x2(acc[8 + 2 * w], acc[8 + 2 * w + 1]), floor);
   }
@@ -338,9 +299,6 @@ MF_D f32x16 head_tile(Carry& carry, const u32x4* hid, uint32_t p, uint32_t pn, u
 #pragma unroll
   for (int gi = 0; gi < NG; ++gi) {
     const int s = gi % (PD + 1);
-#ifdef MF_BF_HEAD_HI                                         // (experiment: head weights hi-only -- the lo groups are skipped)
-    if (!(gi & 1))
-#endif
     acc = MF_MFMA32(r[s], hid[gi >> 1], acc);
     __builtin_amdgcn_sched_barrier(0);
     const int sp = (gi + PD) % (PD + 1), nb = gi + PD;
@@ -422,11 +380,6 @@ MF_D void trunk_layer(const Net& net, int layer, bool relu, const u32x4 (&act)[K
 MF_D void load_raybias(RayBias& rb, const float* rbp, int el) {
   const float* src = rbp + el * 128;
   typedef float f32x8 __attribute__((ext_vector_type(8)));
-#ifdef MF_BF_ABL_NORB                                       // (timing ablation, tools/ab_lib.sh: no table loads)
-  for (int t = 0; t < 4; ++t)
-    for (int i = 0; i < 16; ++i) rb.t[t][i] = 0.f;
-  return;
-#endif
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const f32x4 a = *reinterpret_cast<const f32x4*>(src + 32 * t), b = *reinterpret_cast<const f32x4*>(src + 32 * t + 8);
@@ -487,10 +440,6 @@ template <int KH, int NOUT>
 MF_D void valu_head(const u32x4 (&act)[KH], uint32_t w_byte_off, uint32_t b_byte_off, int h, float (&out)[NOUT]) {
   constexpr int row_floats = 16 * KH;
   const uint32_t wl = w_byte_off + 16 * h;
-#ifdef MF_BF_ABL_NOHEAD
-  for (int o = 0; o < NOUT; ++o) out[o] = bflo(act[o % KH][0]);
-  return;
-#endif
 #pragma unroll
   for (int o = 0; o < NOUT; ++o) {
     float s0 = 0.f, s1 = 0.f;
@@ -555,14 +504,10 @@ MF_D void emb_eval_direct(float* dst, const float (&v)[C], uint32_t par_off, int
     // skipped when both halves' frequencies are muted (coarse-to-fine start, trainer_moco_flow.py:113-114)
     const bool live = lds_f(par_off + 64 + 4 * f0) != 0.f || (real1 && lds_f(par_off + 64 + 4 * f1) != 0.f);
     float sn = 0.f, cs = 0.f;
-#ifndef MF_BF_ABL_NOSINCOS
     if (__builtin_amdgcn_readfirstlane((int)live)) {
       if (HW) sincos_rev(fr * x, sn, cs);
       else sincosf(fr * x, &sn, &cs);
     }
-#else
-    sn = fr * x; cs = fr - x;
-#endif
     dst[2 * pi] = real ? w * sn : (h ? ra1 : ra0);
     dst[2 * pi + 1] = real ? w * cs : (h ? rb1 : rb0);
   }
@@ -581,12 +526,7 @@ MF_D void emb_eval_direct(float* dst, const float (&v)[C], uint32_t par_off, int
 template <int C, int F, bool HW = false>
 MF_D void emb_eval(float* dst, const float (&v)[C], uint32_t par_off, int h, bool pow2) {
   using B = EmbBlock2<C, F>;
-#ifdef MF_BF_ABL_NODOUBLING
-  pow2 = false;
-#endif
-#ifndef MF_BF_NO_HWSIN
   if (HW) { emb_eval_direct<C, F, true>(dst, v, par_off, h); return; }
-#endif
   if (!pow2) { emb_eval_direct<C, F>(dst, v, par_off, h); return; }
   float cs_[C], sn_[C];                                    // the chains' current (cos, sin)
 #pragma unroll
@@ -610,11 +550,7 @@ MF_D void emb_eval(float* dst, const float (&v)[C], uint32_t par_off, int h, boo
     if (m % 3 == 0) {                                      // seed: exact
       const float x = h ? v[c1] : v[c0];
       const float fr = lds_f(par_off + 4 * f);
-#ifndef MF_BF_ABL_NOSINCOS
       sincosf(fr * x, &sn_[j], &cs_[j]);
-#else
-      sn_[j] = fr * x; cs_[j] = fr - x;
-#endif
     } else {                                               // two doublings: f -> f + 2
 #pragma unroll
       for (int d = 0; d < 2; ++d) {
@@ -716,10 +652,7 @@ MF_D void extra_layer(const Net& net, const u32x4 (&act)[16], const u32x4* ex, c
 // Canonical NeRF (W = 256) on this wave's 32 samples.  xe: bf16 operands of the xyz embedding (4 k-steps).
 // `make_extra(ex)` builds the extra block's operands; it is called right before extra_encoding so that those
 // registers are not held through the trunk.
-#ifndef MF_BF_NERF_TPP0
-#define MF_BF_NERF_TPP0 1            // the fast mode's NeRF layer 0 (eight tiles of 4 groups): tiles per panel (2 and 4 measured 0 %)
-#endif
-constexpr int kNerfTpp0 = MF_BF_NERF_TPP0;
+constexpr int kNerfTpp0 = 1;         // the fast mode's NeRF layer 0 (eight tiles of 4 groups): tiles per panel (2 and 4 measured 0 %)
 template <class MakeExtra>
 MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
                     MakeExtra&& make_extra, bool sigma_only, Stream& st,
@@ -762,10 +695,7 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
 // Neural motion flow (W = 128) on this wave's 32 samples; xhi/xlo = split operands of the xyz block; `rb` = the per-ray
 // bias (image-index block + layer bias) of layer 0, already in flight, `rbp` = where the later embedded layers' sets are.
 // (RBT = RayBias: register sets fetched from the global table, the per-point query; LdsRayBias: staged in LDS, the render pass)
-#ifndef MF_BF_NOF_PAIR
-#define MF_BF_NOF_PAIR 1             // the fast mode's NoF layers as two-tile panels (A/B: 0)
-#endif
-constexpr bool kNofPair = MF_BF_NOF_PAIR != 0;
+constexpr bool kNofPair = true;      // the fast mode's NoF layers as two-tile panels (one tile per panel: C3g +1.9 %, C5 +2.4 %)
 constexpr int kNofTpp = kNofPair ? 2 : 1;
 template <class RBT, class AfterFirst>
 MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&xlo)[kKsNofXyz], const float (&xyz)[3],
@@ -812,11 +742,6 @@ MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&
 // HW: sin / cos from the transcendental unit (the fast mode: the angle's fp32 rounding in revolutions, <= 6e-6 rad at
 // 16 x, is far under the hidden layers' bf16 rounding); the three-product mode takes exact seeds + doubling chains -- the
 // canonical point this network produces feeds sin(512 x), and 6e-6 rad is the size of the split operands' own 2^-17.
-#ifdef MF_X3_NOF_HW                  // (A/B: round 3's x3 kernels took the unit's values here too)
-#define MF_NOF_HW_X3 true
-#else
-#define MF_NOF_HW_X3 false
-#endif
 template <bool HW = true>
 MF_D void nof_embed(u32x4 (&xhi)[kKsNofXyz], u32x4 (&xlo)[kKsNofXyz], const float (&xyz)[3], uint32_t par_xyz, int h, bool pow2_xyz) {
   float emb[B2Xyz5::SLOTS];
@@ -856,7 +781,6 @@ MF_D void nof_embed_t(u32x4 (&xhi)[kKsNofXyz], u32x4 (&xmid)[kKsNofXyz], u32x4 (
 // HMODE 0: hidden plain (one group, one MFMA per k-step), 2: hidden split (groups hi, lo; hi: two MFMAs, lo: one).
 // OUTS: 0 no operand output, 1 hi, 2 (hi, lo).  NHEAD: head[o] += w_o[rows of this tile] . act(acc) in fp32, rows
 // HSTRIDE bytes apart.  `two` = the panels two ahead of this tile's first / second panel.
-constexpr int PDX = MF_BF_PDX;
 
 struct Ahead { int g0; const char* j0; int g1; const char* j1; int s0 = -1, s1 = -1; };   // s0 / s1: g0 / g1 when static (StreamT::sync's sg)
 
@@ -895,13 +819,6 @@ MF_D void epi_step(const f32x16& acc, int step, int h, u32x4& out0, u32x4& out1,
   // lo = bf16(v - hi - mid) -- 24 in all; else two (hi, lo), 16 in all
   constexpr int SPP = OUTS == 3 ? 3 : 2;
   const int u = step / SPP, ph = step % SPP, w = u & 3, r = u < 4 ? 2 * u : 8 + 2 * (u - 4);
-#ifdef MF_BF_ABL_NOEPI                                        // (timing ablation, tools/ab_lib.sh: results are garbage)
-  if (OUTS > 0 && ph == 0) { if (u < 4) out0[w] = __builtin_bit_cast(unsigned, acc[r]); else out1[w] = __builtin_bit_cast(unsigned, acc[r]); }
-  if (OUTS >= 2 && ph == 1) { if (u < 4) lo0[w] = __builtin_bit_cast(unsigned, acc[r + 1]); else lo1[w] = __builtin_bit_cast(unsigned, acc[r + 1]); }
-  if (OUTS == 3 && ph == 2) { if (u < 4) mid0[w] = __builtin_bit_cast(unsigned, acc[r + 1]); else mid1[w] = __builtin_bit_cast(unsigned, acc[r + 1]); }
-  if (NHEAD > 0 && step == 0) for (int o = 0; o < NHEAD; ++o) head[o] += acc[o];
-  return;
-#endif
   // ReLU as a signed-integer max: every negative float (and -0) is a negative int32 -- one v_max_i32 where fmaxf's IEEE
   // canonicalisation costs two v_max_f32
   auto relu = [](float x) { const int b = __builtin_bit_cast(int, x); return __builtin_bit_cast(float, b > 0 ? b : 0); };
@@ -980,9 +897,6 @@ MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, co
   const int h = id.h;
   const uint32_t b0 = st.off0 + id.lane * 16, b1 = st.off1 + id.lane * 16, b2 = st.off2 + id.lane * 16;
   auto frag = [&](int g) {                                   // group g of this tile; g >= NG: of the tile behind it
-#ifdef MF_BF_ABL_NOFRAG
-    return carry.w[0];
-#endif
     if (g < NG1) return lds_u4(b0 + g * kGroupBytes);
     if (g < NG) return lds_u4(b1 + (g - NG1) * kGroupBytes);
     return lds_u4((NSEG == 2 ? b2 : b1) + (g - NG) * kGroupBytes);
@@ -1095,23 +1009,16 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
     }
     constexpr int tp = t > 0 ? t - 1 : 0;                    // the tile whose epilogue is pending
     auto gap = [&](int m) __attribute__((always_inline)) {
-#ifndef MF_BF_X3_NODEFER
       if (t == 0) return;
 #pragma unroll
       for (int sidx = kSteps * m / NM; sidx < kSteps * (m + 1) / NM; ++sidx) epi(pend, sidx, tp);
       if (DUMP && m >= NM - 4) dump_store<RELU>(dump, pend, tp, m - (NM - 4));
-#endif
     };
     f32x16 acc;
     constexpr int KEEP = (DUMP && t != 1) ? 4 : 0;
     mma_tile_x<NGE, KHID, HMODE, EMB_FIRST, KEEP, DUMP, T>(st, id, carry, in, inlo, xhi, xlo, bias_off + 32 * t * 4, two, acc, gap,
                                                           dump_wave_on(dump), inmid, xmid);
     st.advance();
-#ifdef MF_BF_X3_NODEFER
-#pragma unroll
-    for (int sidx = 0; sidx < kSteps; ++sidx) epi(acc, sidx, t);
-    __builtin_amdgcn_sched_barrier(0);
-#endif
     pend = acc;
   };
   static_assert(NT == 4 || NT == 8, "tiles per layer");
@@ -1121,7 +1028,6 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
     run(std::integral_constant<int, 4>{}); run(std::integral_constant<int, 5>{});
     run(std::integral_constant<int, 6>{}); run(std::integral_constant<int, 7>{});
   }
-#ifndef MF_BF_X3_NODEFER
 #pragma unroll
   for (int sidx = 0; sidx < kSteps; ++sidx) epi(pend, sidx, NT - 1);
   if constexpr (DUMP) {
@@ -1129,7 +1035,6 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
     for (int q = 0; q < 4; ++q) dump_store<RELU>(dump, pend, NT - 1, q);
   }
   __builtin_amdgcn_sched_barrier(0);
-#endif
 }
 
 // One trunk layer: MODE as trunk_layer_m (1 embedded input only, 2 hidden only, 3 both, embedded input first).

@@ -21,13 +21,9 @@
 // two panels ahead of the MFMAs in a 3-slot ring.
 #pragma once
 #include <hip/hip_runtime.h>
-#ifndef MF_F32_PD
-#define MF_F32_PD 1   // fp32 fragment prefetch distance in batches (1 or 2; 2 measured 1.3 % slower: more spills)
-#endif
+constexpr int kF32PD = 1;         // fp32 fragment prefetch distance in batches (2 measured 0.9-1.3 % slower)
 #include <stdint.h>
-#ifndef MF_F32_DMA_DELAY
-#define MF_F32_DMA_DELAY 8   // batches (8 MFMAs each) between the late half's panel barrier and its LDS-DMA pieces
-#endif
+constexpr int kF32DmaDelay = 8;   // batches (8 MFMAs each) between the late half's panel barrier and its LDS-DMA pieces
 #ifndef MF_TIMING_FLAGS
 #define MF_TIMING_FLAGS 0   // 1 (tools/build_ablate.sh): the kernels honour MF_DEBUG_FLAGS (timing ablations).
 #endif                      // Production compiles the switches out: the tests on them cost 1.5 % of the C2 kernel.
@@ -237,10 +233,7 @@ MF_HD int extra_groups(const NetLayout& L) {
 MF_HD int panel_cap(int groups) { return groups > 32 ? (groups + 1) / 2 : groups; }
 
 // bf16 terms of the NoF's operands under MF_PREC_BF16X3 (NetLayout::terms; host layout, packer and kernels agree on it)
-#ifndef MF_X3_NOF_TERMS
-#define MF_X3_NOF_TERMS 3            // (A/B: 2 = round 3's two-term NoF, three products)
-#endif
-constexpr int kNofTermsX3 = MF_X3_NOF_TERMS;
+constexpr int kNofTermsX3 = 3;       // (2 = round 3's two-term NoF, three products: C3x -12.6 % time, 1.5e-4 max-rel on the dense draw)
 
 // ------------------------------------------------------------------ device helpers
 extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -399,7 +392,7 @@ struct Stream {
   // retires in issue order, so vmcnt(2) already guarantees the panel DMA issued before them has landed
   // and the stores stay in flight across the barrier instead of being drained at it.
   // `ph`: 0 = the barrier half only, 1 = the DMA half only, 2 = both.  The late half of the workgroup (waves 0-3, barrier
-  // in the middle of their panel) issues its pieces MF_F32_DMA_DELAY batches behind the barrier: straight behind it the
+  // in the middle of their panel) issues its pieces kF32DmaDelay batches behind the barrier: straight behind it the
   // SIMD's other wave is issuing ITS pieces, and with both waves of a SIMD inside their 4-5 buffer_load ... lds at the
   // same time (60-100+ cycles of issue each) nobody feeds the matrix pipe.
   template <bool KEEP2 = false>
@@ -438,7 +431,7 @@ MF_D float lds_f(uint32_t byte_off) { return *(const float*)(smem + byte_off); }
 
 // Activation storage of one wave (16 samples): one f32x4 per 16-feature k-tile.
 // Fragment prefetch distance in batches: a batch is 8 MFMAs (256 matrix cycles), one of them covers the LDS latency.
-constexpr int kPD = MF_F32_PD;
+constexpr int kPD = kF32PD;
 
 // What a panel needs before its first MFMAs, pre-read during the previous panel's tail: the
 // fragment groups of its first PD batches (two tiles each) and the two tiles' bias in C/D order
@@ -499,14 +492,12 @@ MF_D void out_pair(CarryT<kPD>& carry, const f32x4 (&hid)[NK],
     O = MF_MFMA(wO[0], bop(q, 0), O);
     __builtin_amdgcn_sched_barrier(0);
     const int nq = q + PDF;
-#ifndef MF_ABLATE_NOLDS      // (timing ablation builds only: keep re-using the fragments in registers)
     if (nq < Q) {
       nE = lds_f4(panel_lane_off + (2 * nq) * kGroupBytes);
       nO = lds_f4(panel_lane_off + (2 * nq + 1) * kGroupBytes);
     }
-#endif
     {
-      constexpr int QD = (Q / 2 + MF_F32_DMA_DELAY < Q) ? Q / 2 + MF_F32_DMA_DELAY : Q - 1;   // the late half's DMA batch
+      constexpr int QD = (Q / 2 + kF32DmaDelay < Q) ? Q / 2 + kF32DmaDelay : Q - 1;   // the late half's DMA batch
       if (q == 0 && !late) hook(2);
       if (QD == Q / 2) { if (q == Q / 2 && late) hook(2); }
       else {
@@ -514,12 +505,10 @@ MF_D void out_pair(CarryT<kPD>& carry, const f32x4 (&hid)[NK],
         if (q == QD && late) hook(1);
       }
     }
-#ifndef MF_ABLATE_NOLDS
     if (nq >= Q) {                                     // runs on into the next panel (after the barrier)
       nE = lds_f4(next_panel_lane_off + (2 * (nq - Q)) * kGroupBytes);
       nO = lds_f4(next_panel_lane_off + (2 * (nq - Q) + 1) * kGroupBytes);
     }
-#endif
     if (q + 1 >= Q) carry.load_bias(next_bias_off, g);
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll

@@ -131,9 +131,6 @@ __global__ __launch_bounds__(256) void nof_raybias_kernel(const RayBiasParams p)
 template <int NW = kWaves>
 MF_D void stage_raybias(const float* table, int combos, int layers, long long ray_first, int n, int combo, uint32_t dst,
                         const Lane& id) {
-#ifdef MF_AB_NO_RAYBIAS      // (A/B pricing build only, wrong results: what the per-ray table costs the pass)
-  return;
-#endif
   const uint32_t entry = (uint32_t)layers * 512u, chunk = (uint32_t)n * entry;
   const char* base = reinterpret_cast<const char*>(table) + ((size_t)ray_first * combos + combo) * entry;
   for (uint32_t q = id.wave; q * 1024u < chunk; q += NW) {
@@ -262,8 +259,8 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
           const Next follow = last ? first_of<16, kKsNerfXyz, X3, NF0>(p.nerf) : first_of<8, kKsNofXyz, true, NP2, TN>(next_fw ? p.fw : p.bw);
           u32x4 nhi[kKsNofXyz], nmid[TN == 3 ? kKsNofXyz : 1], nlo[kKsNofXyz];
           float out[3];
-          if constexpr (TN == 3) nof_embed_t<!X3 || MF_NOF_HW_X3, 3>(nhi, nmid, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
-          else nof_embed<!X3 || MF_NOF_HW_X3>(nhi, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
+          if constexpr (TN == 3) nof_embed_t<!X3, 3>(nhi, nmid, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
+          else nof_embed<!X3>(nhi, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
           auto stage_next = [&] {
             if (!last) stage_raybias<NW>(p, ray0 + tf, tn, role + 1 == 4 ? 1 : role + 1, p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes, id);
           };
@@ -498,8 +495,8 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void points_kernel
         nof_eval(p.bw, nhi, nlo, x, st, carry, id, nerf_first, out, rb, rbp, [] {});
       } else {
         LdsRayBias rb{p.rb_off};
-        if constexpr (TN == 3) nof_embed_t<!X3 || MF_NOF_HW_X3, 3>(nhi, nmid, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
-        else nof_embed<!X3 || MF_NOF_HW_X3>(nhi, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
+        if constexpr (TN == 3) nof_embed_t<!X3, 3>(nhi, nmid, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
+        else nof_embed<!X3>(nhi, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
         if constexpr (X3) nof_eval_x3<TN>(p.bw, nhi, reinterpret_cast<const u32x4(&)[kKsNofXyz]>(nmid), nlo, x, st, carry, id, nerf_first, out, rb, [] {});
         else nof_eval(p.bw, nhi, nlo, x, st, carry, id, nerf_first, out, rb, nullptr, [] {});
       }
@@ -652,9 +649,7 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
       }
       for (int k = 0; k < 16; ++k) { r.freq[k] = p.emb_par[3][k]; r.weight[k] = p.emb_par[3][16 + k]; }
       r.out = static_cast<float*>(a->workspace);
-#ifndef MF_AB_NO_RAYBIAS
       hipLaunchKernelGGL(nof_raybias_kernel, dim3((unsigned)((a->n_rays + kRbEntries - 1) / kRbEntries), combos), dim3(256), 0, st, r);
-#endif
     }
   }
   if (prepare_only) return moco ? check_launch("mf_render_prepare") : MF_OK;

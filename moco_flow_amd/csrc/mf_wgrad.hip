@@ -230,16 +230,11 @@ MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, 
     const uint32_t base = cur * S::SLOT_BYTES;
     auto hook = [&]() {      // (MF_WG_ABL_*: timing-ablation builds only, tools/ab_lib.sh; results are garbage there)
       asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-#ifndef MF_WG_ABL_NOBAR
       __builtin_amdgcn_s_barrier();
-#endif
       asm volatile("" ::: "memory");
-#ifndef MF_WG_ABL_NODMA
       if (st + 2 < se) wg_load_stage<S>(src, P, (cur >= 1 ? cur - 1 : 2) * S::SLOT_BYTES, id);
-#endif
     };
     if (!late || st == sb) hook();      // (a segment's first stage has no earlier barrier to rely on)
-#ifndef MF_WG_ABL_NOBIAS
     if (want_bias) {
 #pragma unroll
       for (int s = 0; s < BR; ++s) {
@@ -252,7 +247,6 @@ MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, 
         }
       }
     }
-#endif
     float a[2][WR], b[2][WC];
 #pragma unroll
     for (int t = 0; t < WR; ++t) a[0][t] = lds_f(base + aoff + (16 * t) * 4);
@@ -262,17 +256,12 @@ MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, 
     for (int m = 0; m < 4; ++m) {
       const int c = m & 1, n = c ^ 1;
       if (m == 2 && late && st != sb) hook();
-#ifndef MF_WG_ABL_NOFRAG
       if (m + 1 < 4) {
 #pragma unroll
         for (int t = 0; t < WR; ++t) a[n][t] = lds_f(base + aoff + ((m + 1) * S::PG + 16 * t) * 4);
 #pragma unroll
         for (int t = 0; t < WC; ++t) b[n][t] = lds_f(base + boff + ((m + 1) * S::PX + 16 * t) * 4);
       }
-#else
-      for (int t = 0; t < WR; ++t) a[n][t] = a[c][t];
-      for (int t = 0; t < WC; ++t) b[n][t] = b[c][t];
-#endif
 #pragma unroll
       for (int ti = 0; ti < WR; ++ti)
 #pragma unroll

@@ -7,7 +7,9 @@ steps of the MoCo bf16 pass whose 12 loss partials (mf_loss_partials) go through
 later.  Checks: (i) every step's reduced totals equal its un-reduced partials bit for bit (SUM over one rank);
 (ii) the pushes raise nothing under `torch.cuda.set_sync_debug_mode("error")` (no host synchronisation: the
 step stays launch-only); (iii) `reduce_loss` on the reduced vector gives the reference's loss terms of the
-un-reduced one.  Prints one JSON line; exit code 0 = pass.
+un-reduced one; (iv) round 5: ten joint training steps whose real flat gradient goes through `dist.GradReducer`
+(four buckets, ncclAllReduce from the post-accumulate hooks, global loss from `dist.global_partials`) under the same
+sync-debug mode, bit-identical to the un-reduced gradients.  Prints one JSON line; exit code 0 = pass.
 
 Started by tests/conftest.py at session start -- BEFORE the pytest process touches the GPU -- because a process
 that has initialised the GPU must not exec another program on this pool; `test_rccl_one_rank_child` asserts on
@@ -89,6 +91,57 @@ def main():
     for k in ("img_loss", "nof_local", "nof_global"):
         assert abs(t_red[k] - float(t_loc[k])) <= 1e-12 * max(1.0, abs(t_red[k])), (k, t_red[k], float(t_loc[k]))
     out["img_loss"] = t_red["img_loss"]
+
+    # ---- the gradient leg (training half): 10 joint MoCo training steps whose REAL flat gradient (two NeRF-sized
+    # and two NoF buckets) goes through dist.GradReducer's ncclAllReduce Work objects, issued from the post-accumulate
+    # hooks inside backward(), with the global loss formed from the all-reduced partials (dist.global_partials) -- under
+    # sync-debug "error": the data-parallel step stays launch-only.  World 1: SUM is the identity, so the reduced flat
+    # buffer must equal the gradients of the same step without a reducer bit for bit (the kernels are deterministic).
+    from moco_flow_amd.dist import GradReducer, global_partials
+    rendering.set_precision("f32")
+    nets = list(nerfs) + list(kw["nof_models"])
+    gsteps = 10
+
+    def total_of(parts):
+        t = losses.from_partials(parts)
+        return t["img_loss"] + 0.1 * t["nof_local"] + 0.1 * t["nof_global"]
+
+    def train_step(i, red):
+        for m in nets:
+            m.zero_grad(set_to_none=True)
+        res = M.render_rays(rays[:256], bg[:256], embs, nerfs, _loss_target=gts[i][:256], **kw)
+        parts = res["loss_partials"] if red is None else global_partials(res["loss_partials"])
+        total_of(parts).backward()
+        if red is not None:
+            red.wait()
+
+    want = []
+    for i in range(gsteps):
+        train_step(i, None)
+        want.append([None if q.grad is None else q.grad.clone() for m in nets for q in m.parameters()])
+    red = GradReducer([(f"net{k}", m) for k, m in enumerate(nets)], average=False)
+    assert red.active and red.world == 1
+    train_step(0, red)                           # communicator warm-up for the new message sizes
+    torch.cuda.synchronize()
+    got = []
+    torch.cuda.set_sync_debug_mode("error")
+    try:
+        for i in range(gsteps):
+            train_step(i, red)
+            got.append([None if q.grad is None else q.grad.clone() for m in nets for q in m.parameters()])
+            assert all(q.grad is None or q.grad.data_ptr() == red.view_of(q).data_ptr() for m in nets for q in m.parameters())
+    finally:
+        torch.cuda.set_sync_debug_mode("default")
+    torch.cuda.synchronize()
+    bad = sum(0 if ((a is None and b is None) or torch.equal(a, b)) else 1 for ws, gs in zip(want, got) for a, b in zip(ws, gs))
+    out["grad_steps"] = gsteps
+    out["grad_buckets"] = len(red.buckets)
+    out["grad_collectives"] = red.issued
+    out["grad_flat_bytes"] = int(red.flat.numel() * 4)
+    out["grad_mismatching_tensors"] = bad
+    assert bad == 0
+    assert red.issued == (gsteps + 1) * len(red.buckets)
+    assert float(sum(float(g.abs().sum()) for g in got[-1] if g is not None)) > 0
     dist.barrier()
     dist.destroy_process_group()
     out["ok"] = True

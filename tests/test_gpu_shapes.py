@@ -226,6 +226,10 @@ def test_rccl_one_rank_child(preflight):
     assert out["ok"] and out["backend"] == "nccl" and out["world"] == 1
     assert out["steps"] == 50 and out["mismatching_steps"] == 0
     assert all("Done" not in t for t in out["work_types"]), out["work_types"]
+    # round 5, the training half of SURVEY 8(e): ten joint steps' flat gradient (four buckets, 5.3 MB) through
+    # dist.GradReducer's ncclAllReduce from the post-accumulate hooks, bit-identical to the un-reduced gradients
+    assert out["grad_steps"] == 10 and out["grad_buckets"] == 4 and out["grad_mismatching_tensors"] == 0
+    assert out["grad_collectives"] == 11 * 4 and out["grad_flat_bytes"] > 5_000_000
 
 
 def test_bench_two_ranks_real_worker_path(preflight):
@@ -246,7 +250,12 @@ def test_bench_two_ranks_real_worker_path(preflight):
         leg = d["configs"][name]
         assert leg["config"]["loss_allreduce"] is True and leg["config"]["sharding"] == "rays2", name
         assert np.isfinite(leg["value"]) and leg["value"] > 0 and 0 < leg["roofline"]["frac"] < 1, name
-    assert list(d)[-1] == "legs" and set(d["legs"]) >= {"C2", "C4", "C5"}
+    assert list(d)[-1] == "legs" and set(d["legs"]) >= {"C2", "C4", "C5", "train_dp_ms"}
+    # round 5: the data-parallel TRAINING leg -- the joint step per rank with the global loss (dist.global_partials) and the
+    # four per-network gradient buckets all-reduced from the backward's hooks (dist.GradReducer); both ranks ran it
+    dp = d["train_joint_dp"]
+    assert dp["world"] == 2 and dp["buckets"] == 4 and dp["flat_gradient_bytes"] > 5_000_000
+    assert np.isfinite(dp["ms_per_step_local"]) and np.isfinite(dp["ms_per_step_allreduce"]) and dp["ms_per_step_allreduce"] > 0
     assert all(np.isfinite(v["ms"]) and v["ms"] > 0 for k, v in d["legs"].items() if isinstance(v, dict) and "ms" in v)
 
 

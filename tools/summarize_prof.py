@@ -33,8 +33,22 @@ if dur:
     d = dur[dom]
     print(f"\ndominant kernel: {dom[:90]}\n  dispatches {len(d)}  avg {sum(d)/len(d)/1e3:.1f} us  min {min(d)/1e3:.1f}  max {max(d)/1e3:.1f}")
     r0 = next(r for r in rows("trace/**/*kernel_trace.csv") if r["Kernel_Name"] == dom)
-    print("  VGPR", r0.get("VGPR_Count"), "AccVGPR", r0.get("Accum_VGPR_Count"), "SGPR", r0.get("SGPR_Count"),
-          "LDS", r0.get("LDS_Block_Size"), "scratch", r0.get("Scratch_Size"), "grid", r0.get("Grid_Size"),
+    # registers / occupancy as the COMPILER reports them (profiles/kernel_resources.json, tools/kernel_resources.py); the
+    # trace's VGPR_Count / Accum_VGPR_Count columns are the dispatch packet's allocation fields, not these numbers
+    res = {}
+    try:
+        import json as _json
+        allres = _json.load(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles", "kernel_resources.json")))
+        norm = lambda s: s.replace("void ", "").replace(" ", "")
+        res = next((v for k, v in allres.items() if norm(k) == norm(dom)), {})
+    except (OSError, ValueError):
+        pass
+    if res:
+        print(f"  hipcc resource usage: VGPRs {res.get('VGPRs')}  AGPRs {res.get('AGPRs')}  SGPRs {res.get('SGPRs')}  occupancy {res.get('Occupancy')} "
+              f"waves/SIMD  scratch {res.get('ScratchSize')} B/lane  LDS {res.get('LDS Size')} B static  (VGPR spills {res.get('VGPRs Spill')})")
+    else:
+        print("  hipcc resource usage: not found in profiles/kernel_resources.json (run tools/kernel_resources.py)")
+    print("  dispatch packet: LDS", r0.get("LDS_Block_Size"), "scratch", r0.get("Scratch_Size"), "grid", r0.get("Grid_Size"),
           "wg", r0.get("Workgroup_Size"))
 print("\n== PMC (per dispatch of the dominant kernel, mean) ==")
 for sub in ("pmc_mfma", "pmc_fetch", "pmc_write", "pmc_wait"):
