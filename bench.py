@@ -51,14 +51,14 @@ if ROOT not in sys.path:
 
 FLOPS = {"nerf_dir": 1186816, "nerf_ind": 1181184, "nof_quat": 134400}   # per sample, SURVEY.md §8d
 # TFLOP/s, MI355X_MICROARCH.md: fp32-input MFMA / dense bf16 MFMA.  bf16x3 issues SEVERAL bf16 matrix instructions per
-# algorithmic product -- three for the NeRF (hi*hi + hi*lo + lo*hi of (hi, lo) operand pairs), six for the NoF ((hi, mid, lo)
-# triples, every product down to 2^-16: its output point feeds sin(512 x)) -- so its ceiling in ALGORITHMIC FLOP/s is the bf16
-# peak x (algorithmic FLOP / issued FLOP) of the configuration: peak_of().
+# algorithmic product -- three for the NeRF (hi*hi + hi*lo + lo*hi of bf16 (hi, lo) operand pairs) and, since round 5, three for
+# the NoF (IEEE-half (hi, lo) pairs on the f16 instruction of the same rate; rounds 3-4: six, bf16 triples) -- so its ceiling in
+# ALGORITHMIC FLOP/s is the bf16 peak / 3: peak_of().
 PEAK = {"f32": 157.3, "bf16": 2516.0}
-X3_PRODUCTS = {"nerf": 3, "nof": 6}
+X3_PRODUCTS = {"nerf": 3, "nof": 3}
 PEAK_NOTE = {"f32": "dense fp32-input MFMA peak", "bf16": "dense bf16 MFMA peak",
-             "bf16x3": "dense bf16 MFMA peak x algorithmic / issued FLOP (three bf16 matrix instructions per NeRF product, six per "
-                       "NoF product; `achieved` counts algorithmic FLOP)"}
+             "bf16x3": "dense bf16 MFMA peak x algorithmic / issued FLOP = peak / 3 (three matrix instructions per product: bf16 (hi, lo) "
+                       "pairs in the NeRF, IEEE-half (hi, lo) pairs in the NoF; `achieved` counts algorithmic FLOP)"}
 
 
 def peak_of(cfg):
@@ -82,7 +82,7 @@ CONFIGS = {
                      "operand pairs, fp32 accumulation and heads)"),
     "C3x": dict(net="ind", precision="bf16x3", rays=4096, S=64, M=0, nof="local",
                 what="C3 in the contract mode of the bf16 pipe (bf16x3: the NeRF's products as three bf16 products of (hi, lo) pairs, "
-                     "the NoFs' as six of (hi, mid, lo) triples, fp32 accumulation, heads and per-ray image-index bias: 1e-4 max-rel)"),
+                     "the NoFs' as three of IEEE-half (hi, lo) pairs, fp32 accumulation, heads and per-ray image-index bias: 1e-4 max-rel)"),
     "C5x": dict(net="ind", precision="bf16x3", rays=1024, S=64, M=128, nof="global", loss=True,
                 what="C5 in the contract mode of the bf16 pipe (bf16x3)"),
     "C3g": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="global",
@@ -402,6 +402,15 @@ def train_shape_legs(M, synth, torch, dev, steps=6):
         loss.backward()
 
     out["joint"] = {"ms_per_step": med(joint), "rays": N, "samples_per_ray": 384}
+    # round 5: the same step with the opt-in three-product training forward, now for passes WITH NoF too
+    # (render_kernel_bf16<true, true, true>; forward values to 1e-4, gradients inside the fp32 oracle's own noise floor against
+    # the float64 truth, tests/test_gpu_parity.py::test_train_forward_bf16x3_moco) -- reported beside the default, never instead
+    rendering.set_train_forward_precision("bf16x3")
+    try:
+        out["joint_optin_bf16x3_forward"] = {"ms_per_step": med(joint), "rays": N, "samples_per_ray": 384,
+                                            "note": "not the default: ReLU mask flips put gradient parity at the noise-floor yardstick instead of 1e-4"}
+    finally:
+        rendering.set_train_forward_precision(prev)
     del nerfs, nofs, rays, bg, gt
     torch.cuda.empty_cache()
     return out

@@ -38,8 +38,11 @@ extern "C" {
  *     mf_nerf_backward3 (+ mf_nerf_bwd3_packed_bytes, mf_nerf_pack_bwd3), MF_PREC_BF16X3 in mf_points_sigma_p and with the NeRF dump
  * 14: mf_embedding_forward_rows
  * 15: MF_PREC_BF16X3 packs the NoF in three-term operands (six products per k-step); mf_nof_backward3 (+ mf_nof_bwd3_packed_bytes,
- *     mf_nof_pack_bwd3); ReLU bit rows: four panels per word, written for NoF evaluations (behind T) and under NoF; mf_sample_pdf_eps */
-#define MF_ABI_VERSION 15
+ *     mf_nof_pack_bwd3); ReLU bit rows: four panels per word, written for NoF evaluations (behind T) and under NoF; mf_sample_pdf_eps
+ * 16: MF_PREC_BF16X3 packs the NoF as IEEE-half (hi, lo) pairs at 2^5 x (three products per k-step on the f16 matrix
+ *     instruction, biases at 2^10 x); MF_PREC_BF16X3 training forward under NoF (mf_render_args.dump_nof_acts / dump_nof_out without
+ *     dump_nof_emb) + mf_nof_embed_rows */
+#define MF_ABI_VERSION 16
 
 enum {
   MF_OK = 0,
@@ -384,6 +387,14 @@ int64_t mf_render_workspace_bytes(const mf_render_args* a);
 /* Column map of mf_render_args.dump_nof_emb: features80[c] = column of the NoF's embedded input ([xyz 33 | ind 33])
  * stored at dump column c, or -1 (zero).  Host-side, no stream. */
 int32_t mf_nof_emb_slot_features(int32_t* features80);
+
+/* The embedded input of a NoF evaluation as rows, NATURAL column order (ABI v16): out (P, 80) = [emb_xyz(pts) zero-padded to 33 |
+ * emb_ind(ind of the point's ray) | 0 x 14], row r belongs to ray r / S (ind + (r / S) * ind_stride).  Reference:
+ * models/rendering.py:70-75, models/embedding.py:42-47.  The X operand of the NoF's 128 x 80 weight-gradient blocks for training
+ * forwards that do not write mf_render_args.dump_nof_emb themselves (MF_PREC_BF16X3).  xyz embedding: 3 channels, <= 5
+ * frequencies; index embedding: 1 channel, <= 16. */
+int32_t mf_nof_embed_rows(const mf_embedding* emb_xyz, const mf_embedding* emb_ind, const float* pts, const float* ind,
+                          int64_t ind_stride, int32_t S, int64_t P, float* out, void* stream);
 
 /* ---- hierarchical resampling: sample_pdf (rendering.py:5-46) [+ cat + sort, :321-326] ------
  * General form.  Per ray: n_bins bin positions -- either explicit `bins` (N, n_bins), the

@@ -17,7 +17,7 @@ MF_ACT_RELU, MF_ACT_SOFTPLUS = 0, 1
 MF_F_SIGMA_ONLY, MF_F_CHAIN_LOCAL, MF_F_CHAIN_GLOBAL = 1, 2, 4
 MF_PREC_F32, MF_PREC_BF16, MF_PREC_BF16X3 = 0, 1, 2
 PRECISIONS = {"f32": MF_PREC_F32, "bf16": MF_PREC_BF16, "bf16x3": MF_PREC_BF16X3}
-MF_ABI_VERSION = 15
+MF_ABI_VERSION = 16
 
 LIB_PATH = os.environ.get("MOCOFLOW_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "libmocoflow_hip.so")   # (override: A/B builds)
 
@@ -148,6 +148,7 @@ SYMBOLS = {
                                  C.c_float, C.c_float, C.c_float, _fp, _fp]),
     "mf_knn1": (C.c_int32, [_fp, C.c_int64, _fp, C.c_int64, _fp, _fp, _fp]),
     "mf_nof_emb_slot_features": (C.c_int32, [C.POINTER(C.c_int32)]),
+    "mf_nof_embed_rows": (C.c_int32, [C.POINTER(mf_embedding), C.POINTER(mf_embedding), _fp, _fp, C.c_int64, C.c_int32, C.c_int64, _fp, _fp]),
     "mf_smpl_scratch_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "mf_smpl_lbs": (C.c_int32, [C.POINTER(mf_smpl_model), _fp, C.c_int32, _fp, C.c_int64, _fp, _fp, _fp, _fp]),
     "mf_smpl_frame_transforms": (C.c_int32, [_fp, _fp, C.c_int64, _fp, _fp]),

@@ -352,8 +352,9 @@ class NofGradSink:
     the gated parameters -- turns all of them into dW / db with one mf_weight_grads launch (instead of one launch and
     one gradient accumulation per evaluation)."""
 
-    def __init__(self, m, acts, emb):
+    def __init__(self, m, acts, emb, slot_order=True):
         self.m, self.acts, self.emb = m, acts, emb           # (n, P, stride), (n, P, 80): this network's planes
+        self.slot_order = slot_order                         # columns of `emb`: the fp32 pass' register slots | natural (mf_nof_embed_rows)
         self.gpre, self.filled = None, set()
 
     def plane(self, k):
@@ -377,7 +378,7 @@ class NofGradSink:
             i = j + 1
         for lo, hi in runs:
             flat = lambda t: t[lo:hi].reshape(-1, t.shape[-1])
-            g = _nof_param_grads(m, flat(self.gpre), flat(self.acts), flat(self.emb), req, slot_order=True)
+            g = _nof_param_grads(m, flat(self.gpre), flat(self.acts), flat(self.emb), req, slot_order=self.slot_order)
             for n in names:
                 if g[n] is not None:
                     total[n] = g[n] if total[n] is None else total[n] + g[n]
@@ -409,6 +410,7 @@ class NofPointsDumped(torch.autograd.Function):
     def forward(ctx, m, nof_embs, acts, emb, out, sink, sink_plane, pts, *params):
         ctx.m, ctx.ex, ctx.stride = m, nof_embs[0].descriptor(), acts.shape[1]
         ctx.sink, ctx.sink_plane = sink, sink_plane
+        ctx.slot_order = not getattr(emb, "_mf_natural", False)
         ctx.save_for_backward(pts.detach().contiguous().float(), acts, emb)
         ctx.set_materialize_grads(False)
         return out.detach()                                   # the dump's own plane (nobody writes it after the pass)
@@ -433,7 +435,7 @@ class NofPointsDumped(torch.autograd.Function):
             nof_backward_hip(m, ctx.ex, P, pts, acts, stride, g_out, gpre, g_pts)
             if ctx.sink is not None:
                 return (None,) * 7 + (g_pts,) + (None,) * len(names)
-            grads = _nof_param_grads(m, gpre[:P], acts, emb, req, slot_order=True)
+            grads = _nof_param_grads(m, gpre[:P], acts, emb, req, slot_order=ctx.slot_order)
         return (None,) * 7 + (g_pts,) + tuple(grads[n] for n in names)
 
 

@@ -368,3 +368,50 @@ extern "C" int32_t mf_image_compose(const uint8_t* rays_msk, const int64_t* rank
   hipLaunchKernelGGL(image_compose_kernel, dim3((unsigned)((B + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   return check_launch("mf_image_compose");
 }
+
+// ---- mf_nof_embed_rows (ABI v16): the NoF's embedded input [emb_xyz(point) zero-padded to 33 | emb_ind(index of the point's ray) | 0]
+// as (P, 80) rows in NATURAL column order -- the X operand of the 128 x 80 weight-gradient blocks of the NoF's embedded-input
+// layers (models/rendering.py:70-75, models/embedding.py:42-47) -- for training forwards that do not write that plane themselves
+// (MF_PREC_BF16X3: the index block is a per-ray bias there and never exists per sample).  One thread per output column.
+namespace mf {
+struct NofEmbRowsParams { mf_embedding exyz, eind; const float* pts; const float* ind; long long ind_stride; int S; long long P; float* out; };
+
+__global__ void nof_embed_rows_kernel(const NofEmbRowsParams p) {
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= p.P * 80) return;
+  const long long row = idx / 80;
+  const int c = (int)(idx % 80);
+  float v = 0.f;
+  if (c < 33) {                                                           // xyz block: [x (3) | w_k sin(f_k x) (3) | w_k cos(f_k x) (3) | ...]
+    const int width = 3 * (2 * p.exyz.n_freqs + 1);
+    if (c < 3) v = p.pts[row * 3 + c];
+    else if (c < width) {
+      const int k = (c - 3) / 6, r = (c - 3) % 6;
+      const float arg = p.exyz.freq[k] * p.pts[row * 3 + r % 3];          // embedding.py:45: func(freq * x)
+      v = p.exyz.weight[k] * (r < 3 ? sinf(arg) : cosf(arg));
+    }
+  } else if (c < 66) {                                                    // index block: [ind | w_k sin(f_k ind) | w_k cos(f_k ind) | ...]
+    const int cc = c - 33, width = 2 * p.eind.n_freqs + 1;
+    const float iv = p.ind[(row / p.S) * p.ind_stride];
+    if (cc == 0) v = iv;
+    else if (cc < width) {
+      const int k = (cc - 1) / 2;
+      const float arg = p.eind.freq[k] * iv;
+      v = p.eind.weight[k] * (((cc - 1) & 1) ? cosf(arg) : sinf(arg));
+    }
+  }
+  p.out[idx] = v;
+}
+}  // namespace mf
+
+extern "C" int32_t mf_nof_embed_rows(const mf_embedding* emb_xyz, const mf_embedding* emb_ind, const float* pts, const float* ind,
+                                     int64_t ind_stride, int32_t S, int64_t P, float* out, void* stream) {
+  if (!emb_xyz || !emb_ind || P < 0 || S < 1 || (P > 0 && (!pts || !ind || !out))) return fail(MF_E_INVALID, "mf_nof_embed_rows: bad argument");
+  if (emb_xyz->in_channels != 3 || emb_xyz->n_freqs < 0 || emb_xyz->n_freqs > 5 || emb_ind->in_channels != 1 || emb_ind->n_freqs < 0 ||
+      emb_ind->n_freqs > 16)
+    return fail(MF_E_UNSUPPORTED, "mf_nof_embed_rows: xyz embedding 3 channels x <= 5 frequencies, index embedding 1 x <= 16");
+  if (P == 0) return MF_OK;
+  NofEmbRowsParams p{*emb_xyz, *emb_ind, pts, ind, ind_stride, S, P, out};
+  hipLaunchKernelGGL(nof_embed_rows_kernel, dim3((unsigned)((P * 80 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  return check_launch("mf_nof_embed_rows");
+}

@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256, 1) void nerf_backward_kernel_x3(const Bwd3Para
   CarryX carry;
   const int D = p.net.D;
   const char* first = p.net.packed + p.net.res_bytes;
-  st.start(first, 16, p.ring_off, p.buf_bytes, id);
+  st.start(first, 16, 16, p.ring_off, p.buf_bytes, id);
   carry.load(st.slot_off(0) + id.lane * 16);
   const uint32_t zero_off = p.net.res_lds + kB3Zero * 4, rgbw = p.net.res_lds + kB3Rgb * 4, sigw = p.net.res_lds + kB3Sig * 4;
   const Next n32{32, nullptr, 32, nullptr}, nfirst{16, first, 16, nullptr};

@@ -120,13 +120,11 @@ struct StreamT {
     const uint32_t t = off0;
     off0 = off1; off1 = off2; off2 = t;
   }
-  MF_D void start(const char* first, int groups, uint32_t ring, uint32_t buf_bytes, const Lane& id) {
+  MF_D void start(const char* first, int groups, int groups2, uint32_t ring, uint32_t buf_bytes, const Lane& id) {
     off0 = ring; off1 = ring + buf_bytes; off2 = ring + 2 * buf_bytes;
-    for (int grp = id.wave; grp < groups; grp += NW) {
-      blds16(first, id.lane * 16, grp * kGroupBytes, off0 + grp * kGroupBytes);
-      blds16(first, id.lane * 16, (groups + grp) * kGroupBytes, off1 + grp * kGroupBytes);
-    }
-    gnext = first + (size_t)2 * groups * kGroupBytes;
+    for (int grp = id.wave; grp < groups; grp += NW) blds16(first, id.lane * 16, grp * kGroupBytes, off0 + grp * kGroupBytes);
+    for (int grp = id.wave; grp < groups2; grp += NW) blds16(first, id.lane * 16, (groups + grp) * kGroupBytes, off1 + grp * kGroupBytes);
+    gnext = first + (size_t)(groups + groups2) * kGroupBytes;
     wait_vm0();
     __syncthreads();
   }
@@ -163,16 +161,32 @@ struct Next {
   int groups; const char* jump;
   int groups2; const char* jump2;
 };
-// PAIR (the fast mode's NoF, 128 wide: four tiles of 6-14 groups per layer): TWO tiles stream as one panel -- half the
-// barriers of a NoF evaluation, whose tiles are 8-14 MFMAs long.
-template <int KH, int EKS, bool SPLIT, int TPP = 1, int T = 2>
+// Tiles per panel (the fast mode): several 32-row tiles of a layer stream as ONE panel -- one barrier, one set of LDS-DMA pieces
+// per wave -- where the ring slot holds them: template triples <TPP0, TPPH, TPPS> = layer 0 (embedded input only: 4-6 groups per
+// tile), hidden-only layers, skip layers.
+// A `Next` names the first panel of what follows and THE PANEL BEHIND IT, wherever that lives: a layer whose tiles all stream
+// as one panel (KH / 2 == TPP) is followed, two panels on, by the first panel of the layer after it (`after` behind the last
+// trunk layer: the NoF's head panel).
+template <int KH, int EKS, bool SPLIT, int TPP = 1, int T = 2, int TPPH = 0, int TPPS = 0>
 MF_D Next first_of(const Net& n) {       // layer 0: embedded input only, TPP tiles per panel
-  return Next{TPP * (SPLIT ? T : 1) * EKS, n.packed + n.res_bytes, TPP * (SPLIT ? T : 1) * EKS, nullptr};
+  const int g = TPP * (SPLIT ? T : 1) * EKS;
+  if constexpr (TPPH > 0 && KH / 2 == TPP)      // (fast mode) a single-panel layer 0: behind it comes layer 1's first panel
+    return Next{g, n.packed + n.res_bytes, (((n.emb_mask >> 1) & 1) ? TPPS : TPPH) * tgroups<KH, EKS, SPLIT, 0, T>(n, 1), nullptr};
+  return Next{g, n.packed + n.res_bytes, g, nullptr};
 }
-template <int KH, int EKS, bool SPLIT, int HS = 0, bool PAIR = false>
+template <int KH, int EKS, bool SPLIT, int HS = 0, int TPPH = 1, int TPPS = 1>
 MF_D Next next_trunk_bf(const Net& n, int layer) {
-  const int g = (PAIR ? 2 : 1) * tgroups<KH, EKS, SPLIT, HS>(n, layer);
+  const int g = (((n.emb_mask >> layer) & 1) ? TPPS : TPPH) * tgroups<KH, EKS, SPLIT, HS>(n, layer);
   return Next{g, nullptr, g, nullptr};
+}
+// the same where layers may be single panels (the fast mode's NoF): trunk layer `layer` (>= 1) of D, `after` = what follows the trunk
+template <int KH, int EKS, bool SPLIT, int TPPH, int TPPS>
+MF_D Next next_trunk_np(const Net& n, int layer, int D, const Next& after) {
+  const int tpp = ((n.emb_mask >> layer) & 1) ? TPPS : TPPH;
+  const int g = tpp * tgroups<KH, EKS, SPLIT>(n, layer);
+  if ((KH / 2) / tpp >= 2) return Next{g, nullptr, g, nullptr};
+  if (layer + 1 < D) return Next{g, nullptr, (((n.emb_mask >> (layer + 1)) & 1) ? TPPS : TPPH) * tgroups<KH, EKS, SPLIT>(n, layer + 1), nullptr};
+  return Next{g, nullptr, after.groups, after.jump};
 }
 
 template <int N>
@@ -201,6 +215,26 @@ MF_D unsigned pack_bf16x2(float lo, float hi) {
   v[0] = lo; v[1] = hi;
   return __builtin_bit_cast(unsigned, __builtin_convertvector(v, bf16x2));
 }
+// IEEE half, the NoF's operands under MF_PREC_BF16X3 (kNofHalfX3, mf_core.hpp): two floats -> one dword of two halves (RNE;
+// |x| > 65504 -> inf), and back
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+MF_D unsigned pack_f16x2(float lo, float hi) {
+  f32x2 v;
+  v[0] = lo; v[1] = hi;
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(v, f16x2));
+}
+MF_D float hflo(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[0]; }
+MF_D float hfhi(unsigned u) { return (float)__builtin_bit_cast(f16x2, u)[1]; }
+// the matrix instruction of a tile: HF = v_mfma_f32_32x32x16_f16 (same shape, same rate, fp16 denormals honoured)
+template <bool HF>
+MF_D f32x16 mfma32(const u32x4& a, const u32x4& b, const f32x16& c) {
+  if constexpr (HF) return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+constexpr float kHalfActScale = (float)(1 << kNofHalfSA), kHalfInvW = 1.f / (float)(1 << kNofHalfSW),
+                kHalfInvAcc = 1.f / (float)(1 << (kNofHalfSA + kNofHalfSW));
+
 // max(x, floor) on both bf16 halves of a dword through their int16 order: v_pk_max_i16.  floor = 0 is ReLU (every
 // negative bf16, -0 included, has the sign bit set, i.e. is a negative int16); floor = 0x80008000 (int16 min) passes
 // the value through.
@@ -214,31 +248,54 @@ MF_D unsigned pk_floor_bf16(unsigned x, unsigned floor) {
 // NGE = embedded 16-slot k-steps (SPLIT: each is the groups hi, lo and the MFMAs Whi*xhi, Whi*xlo, Wlo*xhi; else one
 // group, one MFMA), KHID = hidden k-steps.
 // The A fragments are fetched PD groups ahead through a register ring that runs on into the NEXT panel's slot.
-// `hook` = the panel's barrier + DMA of the panel two ahead, behind the first group; its pieces go into the three MFMA
-// gaps that follow.  (No half-panel stagger of the SIMD partners here, unlike the fp32 core: this pass does not gain from
-// hidden stalls -- DESIGN.md -- and the second barrier position cost 4 % in scalar bookkeeping and branches.)
-// The accumulators start as the bias (four ds_reads straight into the C operand: no
-// VALU, no extra registers; the SIMD's other wave covers their latency) and the epilogue is 8 packed converts + 8
-// packed integer max per tile.
-// RB (the NoF's embedded-input layers): the accumulators start from `rb` = this lane's 16 rows of the per-ray vector
-// b + W[:, ind columns] emb(ind) (nof_raybias_kernel; C/D order: rb[4q + i] = row 8q + 4h + i) instead of the LDS bias.
-template <int NGE, int KHID, bool EMB_FIRST, bool SPLIT, bool RB, class Hook, class Piece>
-MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4* xlo, uint32_t p, uint32_t pn,
-                   uint32_t bias_off, const f32x16& rb, int h, Hook&& hook, Piece&& piece, unsigned floor, u32x4& out0,
-                   u32x4& out1) {
+// `hook` = the panel's barrier + DMA of the panel two ahead, behind the first group; its pieces go into the MFMA
+// gaps that follow.
+//
+// Round 5 -- the tile as a PIPELINE STAGE.  Measured with the phase timeline (profiles/README.md, round 5): a 256-wide layer
+// took 10.4 k cycles for 8 x 1 024 of matrix work, ~280 cycles per tile in which neither wave of a SIMD fed the pipe, and the
+// ISA says what they were -- at every tile boundary a wave (i) waited for its last MFMA to retire (`s_nop 10`), (ii) ran the 16
+// VALU of the epilogue (8 packed converts + 8 packed max), (iii) issued the four ds_reads that start the next tile's
+// accumulators as its bias and waited `lgkmcnt(0)` for them, all in a row, and its SIMD partner, released by the same
+// barrier, did the same at the same time.  Now:
+//   * `acc` arrives INITIALISED (the bias, read into a second accumulator set during the previous tile -- `gap(NG - 2, NG)` --
+//     while that tile's MFMAs still run), so the first MFMA of a tile waits for nothing;
+//   * the epilogue of the PREVIOUS tile (`pend`) runs in this tile's MFMA gaps, one convert + max pair per gap (`gap(gi, NG)`,
+//     gi >= 1: the caller's schedule), its accumulators retired long before;
+// a tile boundary is then the panel barrier alone.  Costs 16 more live registers (two accumulator sets in flight).
+// RB (the NoF's embedded-input layers, point queries): the accumulators start from `rb` = this lane's 16 rows of the per-ray
+// vector b + W[:, ind columns] emb(ind) (nof_raybias_kernel; C/D order: rb[4q + i] = row 8q + 4h + i) instead of the LDS bias.
+MF_D f32x16 bias_acc(uint32_t bias_off, int h) {            // C/D order: reg 4q + i <- bias[8q + 4h + i]
+  const f32x4 b0 = lds_f4(bias_off + (0 + 4 * h) * 4), b1 = lds_f4(bias_off + (8 + 4 * h) * 4);
+  const f32x4 b2 = lds_f4(bias_off + (16 + 4 * h) * 4), b3 = lds_f4(bias_off + (24 + 4 * h) * 4);
+  f32x16 acc;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; acc[8 + i] = b2[i]; acc[12 + i] = b3[i]; }
+  return acc;
+}
+
+// Epilogue step u (0..7) of a finished tile: accumulator pair -> one packed bf16 dword, floored (ReLU / pass-through).
+// u < 4: registers 2u, 2u+1 -> out0[u]; u >= 4: registers 8 + 2(u-4), +1 -> out1[u-4].
+// The register file is full: each packed dword must exist HERE.  Left alone, hipcc sinks the pure convert / max chain down
+// to the outputs' first use (the next layer), keeps every tile's 16 accumulators alive until then and spills ~200
+// registers.  The empty asm makes the dword a value that exists at this point.
+MF_D void epi_pair(const f32x16& a, int u, unsigned floor, u32x4& out0, u32x4& out1) {
+  const int w = u & 3, r = (u < 4 ? 0 : 8) + 2 * w;
+  unsigned v = pk_floor_bf16(pack_bf16x2(a[r], a[r + 1]), floor);
+  asm volatile("" : "+v"(v));
+  (u < 4 ? out0 : out1)[w] = v;
+}
+// the steps of gap gi of an NG-group tile: the 8 steps spread over gaps 1 .. min(8, NG - 3) (gap 0 carries the panel barrier,
+// gap NG - 2 the next tile's bias reads)
+MF_D constexpr int epi_lo(int gi, int ng) { const int e = ng - 3 < 8 ? ng - 3 : 8; return gi < 1 ? 0 : (gi - 1 >= e ? 8 : 8 * (gi - 1) / e); }
+MF_D constexpr int epi_hi(int gi, int ng) { const int e = ng - 3 < 8 ? ng - 3 : 8; return gi < 1 ? 0 : (gi >= e ? 8 : 8 * gi / e); }
+
+template <int NGE, int KHID, bool EMB_FIRST, bool SPLIT, class Hook, class Piece, class Gap>
+MF_D void mma_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4* xlo, uint32_t p, uint32_t pn,
+                   f32x16& acc, Hook&& hook, Piece&& piece, Gap&& gap) {
   constexpr int NEG = (SPLIT ? 2 : 1) * NGE;            // groups of the embedded block
   constexpr int NG = NEG + KHID;
   static_assert(NG > PD, "panel shorter than the fragment pipeline");
   static_assert(NG >= 4, "panel too short for the DMA pieces");
-  f32x16 acc;
-  if constexpr (RB) {
-    acc = rb;
-  } else {                                                // C/D order: reg 4q + i <- bias[8q + 4h + i]
-    const f32x4 b0 = lds_f4(bias_off + (0 + 4 * h) * 4), b1 = lds_f4(bias_off + (8 + 4 * h) * 4);
-    const f32x4 b2 = lds_f4(bias_off + (16 + 4 * h) * 4), b3 = lds_f4(bias_off + (24 + 4 * h) * 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { acc[i] = b0[i]; acc[4 + i] = b1[i]; acc[8 + i] = b2[i]; acc[12 + i] = b3[i]; }
-  }
   u32x4 r[PD + 1];
 #pragma unroll
   for (int i = 0; i < PD; ++i) r[i] = carry.w[i];
@@ -257,6 +314,7 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
     if (gi == 0) hook();
     if (gi >= 1 && gi <= 4) piece(gi - 1);     // (the 4th piece: only the 32-group panels of MF_PREC_BF16X3 have one)
     if (nb >= NG) r[sp] = lds_u4(pn + (nb - NG) * kGroupBytes);
+    gap(gi, NG);
     __builtin_amdgcn_sched_barrier(0);
 #ifndef MF_BF_BREAK_LO      // (-DMF_BF_BREAK_LO: the deliberately broken build the oracle-of-the-arithmetic tests must reject)
     if (SPLIT && ge >= 0 && ge < NEG && !(ge & 1)) {
@@ -267,18 +325,6 @@ MF_D void out_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
   }
 #pragma unroll
   for (int i = 0; i < PD; ++i) carry.w[i] = r[(NG + i) % (PD + 1)];
-#pragma unroll
-  for (int w = 0; w < 4; ++w) {
-    out0[w] = pk_floor_bf16(pack_bf16x2(acc[2 * w], acc[2 * w + 1]), floor);
-    out1[w] = pk_floor_bf16(pack_bf16x2(acc[8 + 2 * w], acc[8 + 2 * w + 1]), floor);
-  }
-  // The register file is full: the epilogue must retire this tile's accumulators HERE.  Left alone, hipcc sinks the
-  // pure convert / max chain down to the outputs' first use (the next layer), keeps every tile's 16 accumulators
-  // alive until then and spills ~200 registers.  The empty asm makes each packed dword a value that exists at this
-  // point.
-#pragma unroll
-  for (int w = 0; w < 4; ++w) asm volatile("" : "+v"(out0[w]), "+v"(out1[w]));
-  __builtin_amdgcn_sched_barrier(0);
 }
 
 // Head tile (NoF 3|9-row head): acc = bias + (Whi + Wlo) * hidden, raw fp32 accumulators (rows (r&3)+8(r>>2)+4h).
@@ -317,7 +363,7 @@ MF_D f32x16 head_tile(Carry& carry, const u32x4* hid, uint32_t p, uint32_t pn, u
 // MODE: 1 = embedded input only (layer 0), 2 = hidden only, 3 = both (skip layers, embedded input first).  A template
 // parameter, not a switch inside the tile loop: the register file is full here and every control-flow merge inside
 // the unrolled tile sequence costs copies.
-// RB: the layer's accumulators start from the per-ray bias `rb` (one f32x4[4] per tile, see out_tile).
+// RB: the layer's accumulators start from the per-ray bias `rb` (one f32x16 per tile, see mma_tile).
 struct RayBias { f32x16 t[4]; };    // per tile of a 128-wide layer: the accumulators' initial value (whole vectors: a
                                     // f32x4[16] read back as f32x16 defeats SROA and lands in scratch)
 struct NoRayBias {};
@@ -339,6 +385,11 @@ MF_D void trunk_layer_m(const Net& net, int layer, bool relu, const u32x4 (&act)
   uint32_t bias_off = net.res_lds + layer * (16 * KH) * 4;
   if constexpr (__is_same(RBT, LdsRayBias) && (MODE & 1))      // embedded layer number popcount(mask below `layer`)
     bias_off = rb.lane_off + (uint32_t)__builtin_popcount(net.emb_mask & ((1u << layer) - 1u)) * (16 * KH) * 4;
+  auto init = [&](int t) __attribute__((always_inline)) -> f32x16 {       // tile t's accumulators before its first MFMA
+    if constexpr (RB && (MODE & 1)) return rb.t[t < 4 ? t : 0];
+    else return bias_acc(bias_off + 32 * t * 4, id.h);
+  };
+  f32x16 acc = init(0), pend = {}, nacc = {};
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int pi = t / TPP, sub = t % TPP;             // panel of this tile, position inside it
@@ -351,27 +402,37 @@ MF_D void trunk_layer_m(const Net& net, int layer, bool relu, const u32x4 (&act)
       st.sync(pi + 2 < NP ? pgroups : (pi == NP - 2 ? nxt.groups : nxt.groups2),
               pi == NP - 2 ? nxt.jump : (pi == NP - 1 ? nxt.jump2 : nullptr), id, true, pi + 2 < NP ? pgroups : -1);
     };
-    auto piece = [&](int k) { if (!second) st.piece(k, id); };
-    if constexpr (RB && (MODE & 1)) {
-      out_tile<NGE, (MODE & 2) ? KH : 0, true, SPLIT, true>(carry, act, xhi, xlo, p, pn, 0u, rb.t[t < 4 ? t : 0], id.h, hook, piece, lo,
-                                                            out[2 * t], out[2 * t + 1]);
-    } else {
-      const f32x16 none = {};
-      out_tile<(MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, true, SPLIT, false>(carry, act, xhi, xlo, p, pn, bias_off + 32 * t * 4, none,
-                                                                             id.h, hook, piece, lo, out[2 * t], out[2 * t + 1]);
-    }
+    // this wave's pieces of the panel two ahead: up to four per tile (gaps 1-4), the panel's later tiles carry on where a
+    // short first tile stops (layer 0 of the NeRF: eight 4-group tiles in one panel, 3 + 1 pieces)
+    const int ppt = groups - 1 < 4 ? groups - 1 : 4;
+    auto piece = [&](int k) { if (k < ppt) st.piece(sub * ppt + k, id); };
+    const int tp = t > 0 ? t - 1 : 0;                  // the tile whose epilogue is pending
+    auto gap = [&](int gi, int ng) __attribute__((always_inline)) {
+      if (t > 0) {
+#pragma unroll
+        for (int u = epi_lo(gi, ng); u < epi_hi(gi, ng); ++u) epi_pair(pend, u, lo, out[2 * tp], out[2 * tp + 1]);
+      }
+      if (gi == ng - 2 && t + 1 < NT) nacc = init(t + 1);
+    };
+    mma_tile<(MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, true, SPLIT>(carry, act, xhi, xlo, p, pn, acc, hook, piece, gap);
+    pend = acc;
+    acc = nacc;
     if (sub == TPP - 1) st.advance();
   }
+  // the layer's last tile: nobody's gaps to run in (the next layer's first tile reads every input)
+#pragma unroll
+  for (int u = 0; u < 8; ++u) epi_pair(pend, u, lo, out[2 * (NT - 1)], out[2 * (NT - 1) + 1]);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // in -> out (two register sets: the callers alternate them from layer to layer, so no layer ends in a 64-register copy)
-template <int KH, int NGE, bool SPLIT, class RBT = NoRayBias, bool PAIR = false, int TPP0 = (PAIR ? 2 : 1)>
+template <int KH, int NGE, bool SPLIT, class RBT = NoRayBias, int TPP0 = 1, int TPPH = 1, int TPPS = 1>
 MF_D void trunk_layer(const Net& net, int layer, bool relu, const u32x4 (&act)[KH], u32x4 (&out)[KH], const u32x4 (&xhi)[NGE],
                       const u32x4 (&xlo)[NGE], Stream& st, Carry& carry, const Lane& id, const Next& nxt, const RBT& rb) {
   const int has_emb = (net.emb_mask >> layer) & 1;
   if (layer == 0) trunk_layer_m<KH, NGE, 1, SPLIT, RBT, TPP0>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt, rb);
-  else if (has_emb) trunk_layer_m<KH, NGE, 3, SPLIT, RBT, PAIR ? 2 : 1>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt, rb);
-  else trunk_layer_m<KH, NGE, 2, SPLIT, RBT, PAIR ? 2 : 1>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt, rb);
+  else if (has_emb) trunk_layer_m<KH, NGE, 3, SPLIT, RBT, TPPS>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt, rb);
+  else trunk_layer_m<KH, NGE, 2, SPLIT, RBT, TPPH>(net, layer, relu, act, out, xhi, xlo, st, carry, id, nxt, rb);
 }
 
 // This lane's rows of the per-ray bias of embedded layer number `el` (0 = layer 0, 1 = the first skip layer, ...):
@@ -397,7 +458,7 @@ MF_D void load_raybias(LdsRayBias&, const float*, int) {}
 // right behind it.  One set is live at a time.
 // `after_first()` runs once behind layer 0 (the render pass stages the NEXT chain step's per-ray bias rows there: this
 // wave is past the step's first panel barrier, and every later barrier of the step publishes them).
-template <int KH, int NGE, bool SPLIT, bool PAIR = false, int TPP0 = (PAIR ? 2 : 1), class NextOf, class RBT, class AfterFirst>
+template <int KH, int NGE, bool SPLIT, int TPP0 = 1, int TPPH = 1, int TPPS = 1, class NextOf, class RBT, class AfterFirst>
 MF_D void trunk(const Net& net, int D, u32x4 (&a)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE], Stream& st, Carry& carry,
                 const Lane& id, NextOf&& next_of, RBT& rb, const float* rbp, AfterFirst&& after_first) {
   constexpr bool RB = __is_same(RBT, RayBias);
@@ -408,11 +469,11 @@ MF_D void trunk(const Net& net, int D, u32x4 (&a)[KH], const u32x4 (&xhi)[NGE], 
     if constexpr (RB) {
       const bool emb_here = (net.emb_mask >> layer) & 1, emb_next = layer + 1 < D && ((net.emb_mask >> (layer + 1)) & 1);
       if (!emb_here && emb_next) load_raybias(rb, rbp, el);
-      trunk_layer<KH, NGE, SPLIT, RBT, PAIR, TPP0>(net, layer, true, in, out, xhi, xlo, st, carry, id, next_of(layer), rb);
+      trunk_layer<KH, NGE, SPLIT, RBT, TPP0, TPPH, TPPS>(net, layer, true, in, out, xhi, xlo, st, carry, id, next_of(layer), rb);
       if (emb_here && emb_next) load_raybias(rb, rbp, el);
       if (emb_next) ++el;
     } else {
-      trunk_layer<KH, NGE, SPLIT, RBT, PAIR, TPP0>(net, layer, true, in, out, xhi, xlo, st, carry, id, next_of(layer), rb);
+      trunk_layer<KH, NGE, SPLIT, RBT, TPP0, TPPH, TPPS>(net, layer, true, in, out, xhi, xlo, st, carry, id, next_of(layer), rb);
     }
   };
   for (; l + 1 < D; l += 2) {
@@ -583,6 +644,22 @@ MF_D void split_operands(const float* emb, int n_slots, u32x4 (&xhi)[KS], u32x4 
   }
 }
 
+// fp32 slots -> IEEE-half (hi, lo) pairs of kHalfActScale x: hi = half(s x), lo = half(s x - hi)   (22 significand bits)
+template <int KS>
+MF_D void split_operands_half(const float* emb, int n_slots, u32x4 (&xhi)[KS], u32x4 (&xlo)[KS]) {
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+      const int e0 = 8 * ks + 2 * w, e1 = e0 + 1;
+      const float a = e0 < n_slots ? emb[e0] * kHalfActScale : 0.f, b = e1 < n_slots ? emb[e1] * kHalfActScale : 0.f;
+      const unsigned hi = pack_f16x2(a, b);
+      xhi[ks][w] = hi;
+      xlo[ks][w] = pack_f16x2(a - hflo(hi), b - hfhi(hi));
+    }
+  }
+}
+
 // fp32 slots -> three-term operands: hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid)   (24 mantissa bits)
 template <int KS>
 MF_D void split_operands3(const float* emb, int n_slots, u32x4 (&xhi)[KS], u32x4 (&xmid)[KS], u32x4 (&xlo)[KS]) {
@@ -615,9 +692,10 @@ MF_D void pack_operands(const float* emb, int n_slots, u32x4 (&x)[KS]) {
 }
 
 // ------------------------------------------------------------------ the two networks
-template <int KH, int EKS, bool SPLIT, int TPP = 1, int T = 2, class ST, class CR>
+template <int KH, int EKS, bool SPLIT, int TPP = 1, int T = 2, int TPPH = 0, int TPPS = 0, class ST, class CR>
 MF_D void start_program(const Net& n, ST& st, CR& carry, uint32_t ring, uint32_t buf_bytes, const Lane& id) {
-  st.start(n.packed + n.res_bytes, TPP * (SPLIT ? T : 1) * EKS, ring, buf_bytes, id);
+  const Next f = first_of<KH, EKS, SPLIT, TPP, T, TPPH, TPPS>(n);        // the program's first two panels (contiguous)
+  st.start(f.jump, f.groups, f.groups2, ring, buf_bytes, id);
   carry.load(st.slot_off(0) + id.lane * 16);
 }
 
@@ -634,6 +712,7 @@ MF_D void extra_layer(const Net& net, const u32x4 (&act)[16], const u32x4* ex, c
   constexpr int NT = 4;
   const int groups = 16 + (SPLIT ? 2 : 1) * NGX;
   const uint32_t bias_off = net.res_lds + (net.D + 1) * 256 * 4;
+  f32x16 acc = bias_acc(bias_off, id.h), pend = {}, nacc = {};
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const uint32_t p = st.slot_off(0) + id.lane * 16;
@@ -643,16 +722,31 @@ MF_D void extra_layer(const Net& net, const u32x4 (&act)[16], const u32x4* ex, c
               t == NT - 2 ? nxt.jump : (t == NT - 1 ? nxt.jump2 : nullptr), id, true, t + 2 < NT ? groups : -1);
     };
     auto piece = [&](int k) { st.piece(k, id); };
-    const f32x16 none = {};
-    out_tile<NGX, 16, false, SPLIT, false>(carry, act, ex, exlo, p, pn, bias_off + 32 * t * 4, none, id.h, hook, piece, 0u, out[2 * t], out[2 * t + 1]);
+    const int tp = t > 0 ? t - 1 : 0;
+    auto gap = [&](int gi, int ng) __attribute__((always_inline)) {
+      if (t > 0) {
+#pragma unroll
+        for (int u = epi_lo(gi, ng); u < epi_hi(gi, ng); ++u) epi_pair(pend, u, 0u, out[2 * tp], out[2 * tp + 1]);
+      }
+      if (gi == ng - 2 && t + 1 < NT) nacc = bias_acc(bias_off + 32 * (t + 1) * 4, id.h);
+    };
+    mma_tile<NGX, 16, false, SPLIT>(carry, act, ex, exlo, p, pn, acc, hook, piece, gap);
+    pend = acc;
+    acc = nacc;
     st.advance();
   }
+#pragma unroll
+  for (int u = 0; u < 8; ++u) epi_pair(pend, u, 0u, out[2 * (NT - 1)], out[2 * (NT - 1) + 1]);
+  __builtin_amdgcn_sched_barrier(0);
 }
 
 // Canonical NeRF (W = 256) on this wave's 32 samples.  xe: bf16 operands of the xyz embedding (4 k-steps).
 // `make_extra(ex)` builds the extra block's operands; it is called right before extra_encoding so that those
 // registers are not held through the trunk.
-constexpr int kNerfTpp0 = 1;         // the fast mode's NeRF layer 0 (eight tiles of 4 groups): tiles per panel (2 and 4 measured 0 %)
+// tiles per panel of the fast mode's NeRF: layer 0 (eight tiles of 4 groups), hidden-only layers (16 groups), skip layers (20).
+// Re-priced on the pipelined tile loop in round 5 (profiles/r05_ab_nof_tpp_and_fp16_nof.txt, same-box A/Bs): layer 0 as ONE
+// panel and two hidden tiles per panel both measure +-1 % (rounds 2-4 measured the same on the serial tile loop).
+constexpr int kNerfTpp0 = 1, kNerfTppH = 1, kNerfTppS = 1;
 template <class MakeExtra>
 MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
                     MakeExtra&& make_extra, bool sigma_only, Stream& st,
@@ -664,8 +758,8 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
     for (int i = 0; i < 4; ++i) act[t][i] = 0;
   const int D = net.D;
   NoRayBias norb;
-  trunk<16, kKsNerfXyz, false, false, kNerfTpp0>(net, D, act, xe, xe, st, carry, id, [&](int l) {
-    return (sigma_only && l == D - 1) ? follow : next_trunk_bf<16, kKsNerfXyz, false>(net, l + 1);
+  trunk<16, kKsNerfXyz, false, kNerfTpp0, kNerfTppH, kNerfTppS>(net, D, act, xe, xe, st, carry, id, [&](int l) {
+    return (sigma_only && l == D - 1) ? follow : next_trunk_bf<16, kKsNerfXyz, false, 0, kNerfTppH, kNerfTppS>(net, l + 1);
   }, norb, nullptr, [] {});
   // resident block: [bias_trunk (D+1) 256 | bias_extra 128 | sigma_w 256 | sigma_b 4 | rgb_w 384 | rgb_b 4]
   const uint32_t r_sigma_w = net.res_lds + ((D + 1) * 256 + 128) * 4;
@@ -677,7 +771,7 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
   const int xg = 16 + net.aux;
   const Next ex{xg, nullptr, xg, nullptr};
   u32x4 fin[16];
-  trunk_layer_m<16, kKsNerfXyz, 2, false>(net, D, false, act, fin, xe, xe, st, carry, id, ex, norb);   // xyz_encoding_final (no ReLU, hidden input only)
+  trunk_layer_m<16, kKsNerfXyz, 2, false, NoRayBias, kNerfTppH>(net, D, false, act, fin, xe, xe, st, carry, id, ex, norb);   // xyz_encoding_final (no ReLU, hidden input only)
   st.tl.stamp(31, id);
   u32x4 e[8], eo[kKsExtraMax];
   make_extra(eo);
@@ -695,8 +789,11 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
 // Neural motion flow (W = 128) on this wave's 32 samples; xhi/xlo = split operands of the xyz block; `rb` = the per-ray
 // bias (image-index block + layer bias) of layer 0, already in flight, `rbp` = where the later embedded layers' sets are.
 // (RBT = RayBias: register sets fetched from the global table, the per-point query; LdsRayBias: staged in LDS, the render pass)
-constexpr bool kNofPair = true;      // the fast mode's NoF layers as two-tile panels (one tile per panel: C3g +1.9 %, C5 +2.4 %)
-constexpr int kNofTpp = kNofPair ? 2 : 1;
+// tiles per panel of the fast mode's NoF (128 wide: four tiles per layer of 6 / 8 / 14 groups): two everywhere since round 3
+// (one tile per panel: C3g +1.9 %, C5 +2.4 %).  Round 5, with whole layers as one panel where the ring slot holds them -- (4, 4, 2),
+// (4, 2, 2), (2, 4, 2); the stream's two-panel look-ahead handles single-panel layers since then (first_of / next_trunk_np) --:
+// C3 / C3g / C5 all within +-1 % of (2, 2, 2), every variant green against the oracle of the arithmetic.
+constexpr int kNofTpp0 = 2, kNofTppH = 2, kNofTppS = 2;
 template <class RBT, class AfterFirst>
 MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&xlo)[kKsNofXyz], const float (&xyz)[3],
                    Stream& st, Carry& carry, const Lane& id, const Next& follow, float (&out)[3], RBT& rb,
@@ -709,8 +806,8 @@ MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&
   const int D = net.D;
   // the head panel (16 groups) follows the last trunk layer contiguously; behind it comes `follow`'s first panel
   const Next hd{16, nullptr, follow.groups, follow.jump};
-  trunk<8, kKsNofXyz, true, kNofPair>(net, D, act, xhi, xlo, st, carry, id,
-                                      [&](int l) { return l == D - 1 ? hd : next_trunk_bf<8, kKsNofXyz, true, 0, kNofPair>(net, l + 1); }, rb, rbp, after_first);
+  trunk<8, kKsNofXyz, true, kNofTpp0, kNofTppH, kNofTppS>(net, D, act, xhi, xlo, st, carry, id,
+      [&](int l) { return l == D - 1 ? hd : next_trunk_np<8, kKsNofXyz, true, kNofTppH, kNofTppS>(net, l + 1, D, hd); }, rb, rbp, after_first);
   // head on the matrix pipe (16 MFMAs instead of 9 x 64 dependent FMAs + 144 LDS reads per lane); T[0..3] come
   // out in half 0's registers 0-3, T[4..7] in half 1's registers 0-3, T[8] in half 0's register 4
   f32x16 acc;
@@ -749,12 +846,13 @@ MF_D void nof_embed(u32x4 (&xhi)[kKsNofXyz], u32x4 (&xlo)[kKsNofXyz], const floa
   split_operands<kKsNofXyz>(emb, B2Xyz5::SLOTS, xhi, xlo);
 }
 // the same as T-term operands (T = 2: xmid untouched)
-template <bool HW, int T>
+template <bool HW, int T, bool HF = false>
 MF_D void nof_embed_t(u32x4 (&xhi)[kKsNofXyz], u32x4 (&xmid)[kKsNofXyz], u32x4 (&xlo)[kKsNofXyz], const float (&xyz)[3], uint32_t par_xyz,
                       int h, bool pow2_xyz) {
   float emb[B2Xyz5::SLOTS];
   emb_eval<3, 5, HW>(emb, xyz, par_xyz, h, pow2_xyz);
-  if constexpr (T == 3) split_operands3<kKsNofXyz>(emb, B2Xyz5::SLOTS, xhi, xmid, xlo);
+  if constexpr (HF) split_operands_half<kKsNofXyz>(emb, B2Xyz5::SLOTS, xhi, xlo);
+  else if constexpr (T == 3) split_operands3<kKsNofXyz>(emb, B2Xyz5::SLOTS, xhi, xmid, xlo);
   else split_operands<kKsNofXyz>(emb, B2Xyz5::SLOTS, xhi, xlo);
 }
 
@@ -790,7 +888,9 @@ struct RowDump { float* row; bool on; bool wave_on; };     // wave_on: some lane
 MF_D bool dump_wave_on(const RowDump& d) { return d.wave_on; }
 struct NoDump {};
 MF_D bool dump_wave_on(const NoDump&) { return true; }
-template <bool RELU>
+// HF: the accumulators of a half-operand layer are 2^(kNofHalfSA + kNofHalfSW) x the pre-activations (mf_core.hpp): the dump holds
+// the activations themselves
+template <bool RELU, bool HF = false>
 MF_D void dump_store(const RowDump& d, const f32x16& acc, int t, int q) {
   if (!d.on) return;
   auto act = [](float x) {
@@ -800,10 +900,10 @@ MF_D void dump_store(const RowDump& d, const f32x16& acc, int t, int q) {
   };
   f32x4 v;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) v[i] = act(acc[4 * q + i]);
+  for (int i = 0; i < 4; ++i) v[i] = act(acc[4 * q + i]) * (HF ? kHalfInvAcc : 1.f);
   *reinterpret_cast<f32x4*>(d.row + 32 * t + 8 * q) = v;
 }
-template <bool RELU>
+template <bool RELU, bool HF = false>
 MF_D void dump_store(const NoDump&, const f32x16&, int, int) {}
 
 MF_D f32x2 lds_f2(uint32_t byte_off) { return *(const f32x2*)(smem + byte_off); }
@@ -812,9 +912,10 @@ MF_D f32x2 lds_f2(uint32_t byte_off) { return *(const f32x2*)(smem + byte_off); 
 // MFMA, MI355X_MICROARCH.md): step 2u (u = 0..7) turns accumulator pair u into the hi dword (+ its share of the head dot
 // products), step 2u + 1 into the lo dword.  Pair u < 4: registers 2u, 2u+1 -> out0[u]; u >= 4: registers 8 + 2(u-4), +1
 // -> out1[u-4]  (C/D order: register 4q + i = row 8q + 4h + i of the tile).
-template <bool RELU, int OUTS, int NHEAD, int HSTRIDE>
+template <bool RELU, int OUTS, int NHEAD, int HSTRIDE, bool HF = false>
 MF_D void epi_step(const f32x16& acc, int step, int h, u32x4& out0, u32x4& out1, u32x4& lo0, u32x4& lo1, uint32_t headw_off,
                    float (&head)[NHEAD ? NHEAD : 1], u32x4& mid0, u32x4& mid1) {
+  static_assert(!HF || (OUTS == 2 && NHEAD == 0), "half operands: (hi, lo) outputs, no fused head");
   // OUTS == 3 (three-term operands, the NoF under MF_PREC_BF16X3): three steps per pair -- hi, mid = bf16(v - hi),
   // lo = bf16(v - hi - mid) -- 24 in all; else two (hi, lo), 16 in all
   constexpr int SPP = OUTS == 3 ? 3 : 2;
@@ -822,7 +923,8 @@ MF_D void epi_step(const f32x16& acc, int step, int h, u32x4& out0, u32x4& out1,
   // ReLU as a signed-integer max: every negative float (and -0) is a negative int32 -- one v_max_i32 where fmaxf's IEEE
   // canonicalisation costs two v_max_f32
   auto relu = [](float x) { const int b = __builtin_bit_cast(int, x); return __builtin_bit_cast(float, b > 0 ? b : 0); };
-  const float v0 = RELU ? relu(acc[r]) : acc[r], v1 = RELU ? relu(acc[r + 1]) : acc[r + 1];
+  // HF: the accumulators are 2^(SA + SW) x the pre-activation, the next operand 2^SA x the activation: un-scale by 2^-SW (exact)
+  const float v0 = (RELU ? relu(acc[r]) : acc[r]) * (HF ? kHalfInvW : 1.f), v1 = (RELU ? relu(acc[r + 1]) : acc[r + 1]) * (HF ? kHalfInvW : 1.f);
   u32x4& hv = u < 4 ? out0 : out1;
   if (ph == 0) {
     if constexpr (NHEAD > 0) {                               // rows 8q + 4h + i: q = r / 4, i = r % 4
@@ -835,7 +937,7 @@ MF_D void epi_step(const f32x16& acc, int step, int h, u32x4& out0, u32x4& out1,
       }
     }
     if constexpr (OUTS > 0) {
-      unsigned hi = pack_bf16x2(v0, v1);
+      unsigned hi = HF ? pack_f16x2(v0, v1) : pack_bf16x2(v0, v1);
       // (the register file is full: each packed dword must exist HERE -- left alone, hipcc sinks the pure convert chain to
       //  the outputs' first use in the next layer and keeps every tile's accumulators alive until then)
       asm volatile("" : "+v"(hi));
@@ -843,7 +945,7 @@ MF_D void epi_step(const f32x16& acc, int step, int h, u32x4& out0, u32x4& out1,
     }
   } else if constexpr (OUTS == 2) {
     const unsigned hi = hv[w];
-    unsigned lo = pack_bf16x2(v0 - bflo(hi), v1 - bfhi(hi));
+    unsigned lo = HF ? pack_f16x2(v0 - hflo(hi), v1 - hfhi(hi)) : pack_bf16x2(v0 - bflo(hi), v1 - bfhi(hi));
     asm volatile("" : "+v"(lo));
     (u < 4 ? lo0 : lo1)[w] = lo;
   } else if constexpr (OUTS == 3) {
@@ -882,7 +984,7 @@ MF_D constexpr int x_slots(int lo, int hi) {                 // groups of [lo, h
 // runs behind the m-th MFMA (m = 0 .. NM-1): the caller's deferred work (the previous tile's epilogue steps).
 // KEEP: see StreamT::sync (the tile's FIRST panel barrier only).  LATE_FREE: no LDS-DMA pieces behind the last two (hi, lo)
 // group pairs of the tile's last panel -- the caller's dump stores go there, behind every piece of the panel.
-template <int NGE, int KHID, int HMODE, bool EMB_FIRST, int KEEP = 0, bool LATE_FREE = false, int T = 2, class ST, class Gap>
+template <int NGE, int KHID, int HMODE, bool EMB_FIRST, int KEEP = 0, bool LATE_FREE = false, int T = 2, bool HF = false, class ST, class Gap>
 MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, const u32x4* hidlo, const u32x4* xhi, const u32x4* xlo,
                      uint32_t bias_off, const Ahead& two, f32x16& acc, Gap&& gap, bool keep_ok = true,
                      const u32x4* hidmid = nullptr, const u32x4* xmid = nullptr) {
@@ -901,12 +1003,10 @@ MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, co
     if (g < NG) return lds_u4(b1 + (g - NG1) * kGroupBytes);
     return lds_u4((NSEG == 2 ? b2 : b1) + (g - NG) * kGroupBytes);
   };
-  {
-    const f32x4 c0 = lds_f4(bias_off + (0 + 4 * h) * 4), c1 = lds_f4(bias_off + (8 + 4 * h) * 4);
-    const f32x4 c2 = lds_f4(bias_off + (16 + 4 * h) * 4), c3 = lds_f4(bias_off + (24 + 4 * h) * 4);
-#pragma unroll
-    for (int i = 0; i < 4; ++i) { acc[i] = c0[i]; acc[4 + i] = c1[i]; acc[8 + i] = c2[i]; acc[12 + i] = c3[i]; }
-  }
+  // (the bias read here stands in front of the tile's first MFMA; reading it into the freed accumulator set three MFMAs before
+  //  the previous tile ends -- what the fast mode's mma_tile does -- was built and measured in round 5: no change, C3x 1.0127
+  //  vs 1.0081 ms, 2.131e6 vs 2.135e6 cycles: this wave's previous MFMA and its fragment reads cover the round trip)
+  acc = bias_acc(bias_off, h);
   u32x4 r[PDX + 1];
 #pragma unroll
   for (int i = 0; i < PDX; ++i) r[i] = carry.w[i];
@@ -920,7 +1020,7 @@ MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, co
     const int ks = emb ? ge / T : (HMODE ? gh / T : gh);     // k-step of the group within its block
     const int nx = x_extras<T, NEG, NHG, HMODE, EMB_FIRST>(gi);
     if (gi == NG1) st.advance();                             // second panel of the tile
-    acc = MF_MFMA32(r[s], (emb ? xhi : hid)[ks], acc);       // W_t x_0
+    acc = mfma32<HF>(r[s], (emb ? xhi : hid)[ks], acc);      // W_t x_0
     __builtin_amdgcn_sched_barrier(0);
     const int sp = (gi + PDX) % (PDX + 1), nb = gi + PDX;
     if (nb < NG) r[sp] = frag(nb);
@@ -940,7 +1040,7 @@ MF_D void mma_tile_x(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, co
 #ifdef MF_X3_BREAK_LO       // (the deliberately broken build the oracle-of-the-arithmetic tests must reject: W_0 x_last of the embedded blocks dropped)
       if (!(emb && e == nx && ge % T == 0))
 #endif
-      acc = MF_MFMA32(r[s], op[ks], acc);
+      acc = mfma32<HF>(r[s], op[ks], acc);
       __builtin_amdgcn_sched_barrier(0);
       if (e == 1) {
         // the pieces of the panel two ahead go behind these second MFMAs -- gaps that carry no fragment read (an LDS-DMA
@@ -972,7 +1072,7 @@ MF_D Next next_x(const Net& n, int layer) { return next_of_groups(tgroups<KH, EK
 // The epilogue of tile t runs in the MFMA gaps of tile t + 1 (a wave alone on its SIMD has nobody to cover it); only the
 // last tile's stands alone.
 // T = 3 (OUTS = 3): three-term operands -- `inmid` / `outmid` / `xmid` are the middle terms (unused with T = 2).
-template <int NT, int NGE, int KHID, int HMODE, bool EMB_FIRST, bool RELU, int OUTS, int NHEAD, int HSTRIDE, int T = 2, class DT, class ST, int KI, int KO>
+template <int NT, int NGE, int KHID, int HMODE, bool EMB_FIRST, bool RELU, int OUTS, int NHEAD, int HSTRIDE, int T = 2, bool HF = false, class DT, class ST, int KI, int KO>
 MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], const u32x4 (&inlo)[KI], u32x4 (&out)[KO],
                   u32x4 (&outlo)[KO], const u32x4* xhi, const u32x4* xlo, uint32_t bias_off, const Next& nxt, uint32_t headw_off,
                   float (&head)[NHEAD ? NHEAD : 1], const DT& dump, const u32x4* inmid = nullptr, u32x4* outmid = nullptr,
@@ -994,7 +1094,7 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
   // everything: tile 0 carries no stores.
   auto epi = [&](const f32x16& a, int sidx, int tile) __attribute__((always_inline)) {
     u32x4* om = OUTS == 3 ? outmid : &outlo[0];              // (placeholders where a term does not exist)
-    epi_step<RELU, OUTS, NHEAD, HSTRIDE>(a, sidx, id.h, out[OUTS ? 2 * tile : 0], out[OUTS ? 2 * tile + 1 : 1], outlo[OUTS >= 2 ? 2 * tile : 0],
+    epi_step<RELU, OUTS, NHEAD, HSTRIDE, HF>(a, sidx, id.h, out[OUTS ? 2 * tile : 0], out[OUTS ? 2 * tile + 1 : 1], outlo[OUTS >= 2 ? 2 * tile : 0],
                                          outlo[OUTS >= 2 ? 2 * tile + 1 : 1], headw_off + 32 * tile * 4, head,
                                          om[OUTS == 3 ? 2 * tile : 0], om[OUTS == 3 ? 2 * tile + 1 : 1]);
   };
@@ -1012,11 +1112,11 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
       if (t == 0) return;
 #pragma unroll
       for (int sidx = kSteps * m / NM; sidx < kSteps * (m + 1) / NM; ++sidx) epi(pend, sidx, tp);
-      if (DUMP && m >= NM - 4) dump_store<RELU>(dump, pend, tp, m - (NM - 4));
+      if (DUMP && m >= NM - 4) dump_store<RELU, HF>(dump, pend, tp, m - (NM - 4));
     };
     f32x16 acc;
     constexpr int KEEP = (DUMP && t != 1) ? 4 : 0;
-    mma_tile_x<NGE, KHID, HMODE, EMB_FIRST, KEEP, DUMP, T>(st, id, carry, in, inlo, xhi, xlo, bias_off + 32 * t * 4, two, acc, gap,
+    mma_tile_x<NGE, KHID, HMODE, EMB_FIRST, KEEP, DUMP, T, HF>(st, id, carry, in, inlo, xhi, xlo, bias_off + 32 * t * 4, two, acc, gap,
                                                           dump_wave_on(dump), inmid, xmid);
     st.advance();
     pend = acc;
@@ -1032,13 +1132,13 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
   for (int sidx = 0; sidx < kSteps; ++sidx) epi(pend, sidx, NT - 1);
   if constexpr (DUMP) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) dump_store<RELU>(dump, pend, NT - 1, q);
+    for (int q = 0; q < 4; ++q) dump_store<RELU, HF>(dump, pend, NT - 1, q);
   }
   __builtin_amdgcn_sched_barrier(0);
 }
 
 // One trunk layer: MODE as trunk_layer_m (1 embedded input only, 2 hidden only, 3 both, embedded input first).
-template <int KH, int NGE, int MODE, bool RELU, int NHEAD, int T = 2, class RBT, class ST, class DT = NoDump>
+template <int KH, int NGE, int MODE, bool RELU, int NHEAD, int T = 2, bool HF = false, class RBT, class ST, class DT = NoDump>
 MF_D void trunk_layer_x(const Net& net, int layer, const u32x4 (&in)[KH], const u32x4 (&inlo)[KH], u32x4 (&out)[KH],
                         u32x4 (&outlo)[KH], const u32x4 (&xhi)[NGE], const u32x4 (&xlo)[NGE], ST& st, CarryX& carry,
                         const Lane& id, const Next& nxt, const RBT& rb, uint32_t headw_off, float (&head)[NHEAD ? NHEAD : 1],
@@ -1046,12 +1146,12 @@ MF_D void trunk_layer_x(const Net& net, int layer, const u32x4 (&in)[KH], const 
   uint32_t bias_off = net.res_lds + layer * (16 * KH) * 4;
   if constexpr (__is_same(RBT, LdsRayBias) && (MODE & 1))
     bias_off = rb.lane_off + (uint32_t)__builtin_popcount(net.emb_mask & ((1u << layer) - 1u)) * (16 * KH) * 4;
-  layer_x<KH / 2, (MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, 2, true, RELU, T, NHEAD, 0, T>(
+  layer_x<KH / 2, (MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, 2, true, RELU, T, NHEAD, 0, T, HF>(
       st, id, carry, in, inlo, out, outlo, xhi, xlo, bias_off, nxt, headw_off, head, dump, inmid, outmid, xmid);
 }
 
 // NoF head with split activations and weights: T groups per k-step (Whi, [Wmid,] Wlo), T (T + 1) / 2 products.
-template <int KHID, int T = 2, class ST>
+template <int KHID, int T = 2, bool HF = false, class ST>
 MF_D f32x16 head_tile_x3(ST& st, const Lane& id, CarryX& carry, const u32x4* hid, const u32x4* hidlo, uint32_t bias_off, int g2,
                          const char* j2, const u32x4* hidmid = nullptr) {
   constexpr int NG = T * KHID;
@@ -1070,7 +1170,7 @@ MF_D f32x16 head_tile_x3(ST& st, const Lane& id, CarryX& carry, const u32x4* hid
 #pragma unroll
   for (int gi = 0; gi < NG; ++gi) {
     const int s = gi % (PDX + 1);
-    acc = MF_MFMA32(r[s], hid[gi / T], acc);
+    acc = mfma32<HF>(r[s], hid[gi / T], acc);
     __builtin_amdgcn_sched_barrier(0);
     const int sp = (gi + PDX) % (PDX + 1), nb = gi + PDX;
     if (nb < NG) r[sp] = lds_u4(p + nb * kGroupBytes);
@@ -1080,7 +1180,7 @@ MF_D f32x16 head_tile_x3(ST& st, const Lane& id, CarryX& carry, const u32x4* hid
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int e = 1; e <= T - 1 - gi % T; ++e) {
-      acc = MF_MFMA32(r[s], (T == 3 && e == 1 ? hidmid : hidlo)[gi / T], acc);
+      acc = mfma32<HF>(r[s], (T == 3 && e == 1 ? hidmid : hidlo)[gi / T], acc);
       __builtin_amdgcn_sched_barrier(0);
     }
   }
@@ -1092,10 +1192,13 @@ MF_D f32x16 head_tile_x3(ST& st, const Lane& id, CarryX& carry, const u32x4* hid
 // T = kNofTermsX3 terms per operand: with T = 3 every product of the NoF carries 24 mantissa bits -- its output point feeds
 // sin(512 x) of the canonical encoding, where the 2^-17 of a two-term split is ~1e-4 of the rendered ray (oracle/bf16_ref.py,
 // tools/bf16_explore.py: C3 on the dense draw 1.5e-4 max-rel with two terms, 1.4e-5 with three = the exact-fp32 NoF's)
-template <int T = 2, class RBT, class AfterFirst, class ST>
+// DT = RowDump (the training forward under NoF, round 5): the evaluation's row [h_1 .. h_D | T (9 | 3) zero-padded to 16] -- what
+// mf_nof_backward3 / mf_weight_grads read (dump.row = row start + 4 (lane >> 5)); no ReLU bit rows (the caller's row has no room
+// for them: the backward then reads the activations)
+template <int T = 2, bool HF = false, class RBT, class AfterFirst, class ST, class DT = NoDump>
 MF_D void nof_eval_x3(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&xmid)[kKsNofXyz], const u32x4 (&xlo)[kKsNofXyz],
                       const float (&xyz)[3], ST& st, CarryX& carry, const Lane& id, const Next& follow, float (&out)[3], const RBT& rb,
-                      AfterFirst&& after_first) {
+                      AfterFirst&& after_first, const DT& dump = DT{}) {
   u32x4 ah[8], am[T == 3 ? 8 : 1], al[8], bh[8], bm[T == 3 ? 8 : 1], bl[8];
 #pragma unroll
   for (int t = 0; t < 8; ++t)
@@ -1107,10 +1210,14 @@ MF_D void nof_eval_x3(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4
   auto one = [&](int layer, const u32x4 (&ih)[8], const u32x4* im, const u32x4 (&il)[8], u32x4 (&oh)[8], u32x4* om, u32x4 (&ol)[8]) __attribute__((always_inline)) {
     const Next nxt = layer == D - 1 ? hd : next_x<8, kKsNofXyz, T>(net, layer + 1);
     const int has_emb = (net.emb_mask >> layer) & 1;
-    const NoDump nd{};
-    if (layer == 0) trunk_layer_x<8, kKsNofXyz, 1, true, 0, T>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead, nd, im, om, xmid);
-    else if (has_emb) trunk_layer_x<8, kKsNofXyz, 3, true, 0, T>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead, nd, im, om, xmid);
-    else trunk_layer_x<8, kKsNofXyz, 2, true, 0, T>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead, nd, im, om, xmid);
+    auto dump_at = [&](int col) {
+      if constexpr (__is_same(DT, RowDump)) return RowDump{dump.row + col, dump.on, dump.wave_on};
+      else return NoDump{};
+    };
+    const auto nd = dump_at(layer * 128);
+    if (layer == 0) trunk_layer_x<8, kKsNofXyz, 1, true, 0, T, HF>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead, nd, im, om, xmid);
+    else if (has_emb) trunk_layer_x<8, kKsNofXyz, 3, true, 0, T, HF>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead, nd, im, om, xmid);
+    else trunk_layer_x<8, kKsNofXyz, 2, true, 0, T, HF>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead, nd, im, om, xmid);
   };
   int l = 0;
   for (; l + 1 < D; l += 2) {
@@ -1125,20 +1232,29 @@ MF_D void nof_eval_x3(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4
     for (int t = 0; t < 8; ++t) { ah[t] = bh[t]; al[t] = bl[t]; if (T == 3) am[T == 3 ? t : 0] = bm[T == 3 ? t : 0]; }
   }
   // the head panel; the panel two ahead of it = the SECOND panel of whatever follows
-  f32x16 acc = head_tile_x3<8, T>(st, id, carry, ah, al, net.res_lds + (D + net.aux) * 128 * 4, follow.groups2, follow.jump2, am);
+  f32x16 acc = head_tile_x3<8, T, HF>(st, id, carry, ah, al, net.res_lds + (D + net.aux) * 128 * 4, follow.groups2, follow.jump2, am);
   st.advance();
   float own[5], oth[5];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) { own[i] = acc[i]; oth[i] = __shfl_xor(acc[i], 32, 64); }
+  for (int i = 0; i < 5; ++i) { own[i] = acc[i] * (HF ? kHalfInvAcc : 1.f); oth[i] = __shfl_xor(own[i], 32, 64); }
+  float T9[9] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
   if (net.aux == 9) {
-    float T9[9];
 #pragma unroll
     for (int i = 0; i < 4; ++i) { T9[i] = id.h ? oth[i] : own[i]; T9[4 + i] = id.h ? own[i] : oth[i]; }
     T9[8] = id.h ? oth[4] : own[4];
     quat_transform(T9, xyz, out);
   } else {
 #pragma unroll
-    for (int c = 0; c < 3; ++c) out[c] = (id.h ? oth[c] : own[c]) + xyz[c];
+    for (int c = 0; c < 3; ++c) { T9[c] = id.h ? oth[c] : own[c]; out[c] = T9[c] + xyz[c]; }
+  }
+  if constexpr (__is_same(DT, RowDump)) {
+    if (dump.on && id.h == 0) {                               // (h == 0: dump.row is the row's start)
+      f32x4* tr = reinterpret_cast<f32x4*>(dump.row + D * 128);
+      tr[0] = f32x4{T9[0], T9[1], T9[2], T9[3]};
+      tr[1] = f32x4{T9[4], T9[5], T9[6], T9[7]};
+      tr[2] = f32x4{T9[8], 0.f, 0.f, 0.f};
+      tr[3] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
 }
 

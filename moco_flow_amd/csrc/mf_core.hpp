@@ -193,6 +193,7 @@ struct NetLayout {
                            // activations and weights split) -- every layer of both networks; bit n_trunk = the NeRF's
                            // extra_encoding
   int max_groups;          // largest panel, in groups (x3: tiles of more than 32 groups stream as two panels, panel_cap)
+  int half;                // 1: the split ranges are IEEE-half (hi, lo) pairs, weights 2^kNofHalfSW x, biases 2^(kNofHalfSA + kNofHalfSW) x
   int terms;               // bf16 terms of every SPLIT range of this network: 2 = (hi, lo), three products per k-step; 3 = (hi,
                            // mid, lo), six products down to 2^-24 -- the NoF under MF_PREC_BF16X3 (kNofTermsX3): its output point
                            // feeds sin(512 x) of the canonical encoding and needs fp32-class accuracy
@@ -233,7 +234,17 @@ MF_HD int extra_groups(const NetLayout& L) {
 MF_HD int panel_cap(int groups) { return groups > 32 ? (groups + 1) / 2 : groups; }
 
 // bf16 terms of the NoF's operands under MF_PREC_BF16X3 (NetLayout::terms; host layout, packer and kernels agree on it)
-constexpr int kNofTermsX3 = 3;       // (2 = round 3's two-term NoF, three products: C3x -12.6 % time, 1.5e-4 max-rel on the dense draw)
+// The NoF under MF_PREC_BF16X3.  Its output point feeds sin(512 x) of the canonical encoding, so its products need fp32-class
+// operands.  Round 3: bf16 (hi, lo) pairs, three products: 16 significand bits, 1.5e-4 max-rel on the dense draw.  Round 4: bf16
+// (hi, mid, lo) triples, SIX products: 24 bits, 1.4e-5 .. 3.1e-5, +12.6 % time on C3x.  Round 5: IEEE-half (hi, lo) pairs on
+// v_mfma_f32_32x32x16_f16 (same rate as the bf16 instruction; the unit honours fp16 denormals, tools/proto/f16_denorm.hip):
+// 22 significand bits in THREE products.  Both operands are carried at 2^5 x their value (exact: the accumulators are 2^10 x,
+// biases packed 2^10 x, the epilogue un-scales) so that the lo terms of O(0.01 .. 1) values stay normal halves: priced in
+// oracle/bf16_ref.py ("hsplit_g") at 1.2e-5 / 2.0e-5 max-rel on the two draws = the three-term split's; |x| < 2047 or the
+// conversion overflows to inf (loudly: NaN rays).
+constexpr int kNofTermsX3 = 2;
+constexpr bool kNofHalfX3 = true;
+constexpr int kNofHalfSA = 5, kNofHalfSW = 5;   // log2 of the activation / weight scale
 
 // ------------------------------------------------------------------ device helpers
 extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -79,7 +79,8 @@ inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0) {
   L.emb_steps = bf16 ? kKsNofXyz : kStepsNofIn;         // bf16: xyz block only, the image-index block is a per-ray bias
   L.emb_split = bf16 ? 1 : 0;                          // bf16: the NoF's embedded input keeps 16 mantissa bits
   L.hsplit_mask = x3 ? ((1u << d.D) - 1u) & ~1u : 0u;  // x3: every hidden range split too
-  L.terms = x3 ? kNofTermsX3 : 2;                      // x3: (hi, mid, lo) terms, six products per k-step (mf_bf16.hpp)
+  L.terms = x3 ? kNofTermsX3 : 2;                      // x3: kNofTermsX3 terms per split operand (mf_core.hpp)
+  L.half = (x3 && kNofHalfX3) ? 1 : 0;                 // x3: IEEE-half (hi, lo) pairs, scaled (mf_core.hpp)
   L.emb_mask = 1u | d.skip_mask;
   L.relu_mask = (1u << d.D) - 1u;
   L.extra_steps = -1;

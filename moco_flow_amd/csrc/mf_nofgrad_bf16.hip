@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 1) void nof_backward_kernel_x3(const Nof3Param
   CarryX carry;
   const int D = p.net.D, NH = p.net.aux;
   const char* first = p.net.packed + p.net.res_bytes;
-  st.start(first, 16, p.ring_off, p.buf_bytes, id);          // (its wait + barrier also publish the resident block / table)
+  st.start(first, 16, 16, p.ring_off, p.buf_bytes, id);          // (its wait + barrier also publish the resident block / table)
   carry.load(st.slot_off(0) + id.lane * 16);
   const uint32_t zero_off = p.net.res_lds + kN3Zero * 4, headw = p.net.res_lds + kN3Head * 4;
   const Next n16{16, nullptr, 16, nullptr}, nfirst{16, first, 16, nullptr};

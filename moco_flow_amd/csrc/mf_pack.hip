@@ -6,6 +6,7 @@
 // weight or 0.  A panel is 32 output rows; its groups alternate between its two 16-row tiles.
 // Group (tile half, k-quad q) holds, for lane (i = lane&15, g = lane>>4) and r = 0..3,
 // W[32P + 16*half + i][col(step = 4q + r, g)]  -- see mf_core.hpp for the step -> column maps.
+#include <hip/hip_fp16.h>
 #include "mf_host.hpp"
 #include "mf_layout.hpp"
 
@@ -27,6 +28,8 @@ struct PackRegion {          // one trunk/extra layer's panels
   int hid_col0;              // column of hidden feature 0 in W
   int xyz_cols;
   int n_rows;                // rows present in W (bf16 head panel: 3|9 of its 32; 0 = all)
+  int half;                  // the split terms are IEEE halves of wscale * w (NetLayout::half) instead of bf16
+  float wscale;
   int hid_split;             // bf16: groups per hidden k-step ks: 1 = plain, 2 = (hi, lo), 3 = (hi, mid, lo)
   int emb_split;             // bf16: groups per embedded k-step, likewise
   long long dst_group0;      // first group index (in 1 KiB units) within the panel area
@@ -70,7 +73,15 @@ __global__ void pack_panels_kernel(PackJob job) {
     const int gh = R.emb_first ? gi - eg : gi;
     unsigned short h8[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     // term t of a weight: t = 0: bf16(w); 1: bf16(w - hi); 2: bf16(w - hi - mid)   (exact fp32 subtractions)
-    auto term = [](float w, int t) {
+    const bool half = R.half != 0;
+    const float ws = R.wscale;
+    auto term = [half, ws](float w, int t) {
+      if (half) {                                           // hi = half(ws w) (saturated: no inf in the stream), lo = half(ws w - hi)
+        w = fminf(fmaxf(w * ws, -65504.f), 65504.f);
+        __half hb = __float2half_rn(w);
+        if (t > 0) hb = __float2half_rn(w - __half2float(hb));
+        return __half_as_ushort(hb);
+      }
       unsigned short b = bf16_rne(w);
       for (int k = 0; k < t; ++k) {
         w -= __uint_as_float((unsigned)b << 16);
@@ -113,7 +124,7 @@ __global__ void pack_panels_kernel(PackJob job) {
   reinterpret_cast<float4*>(job.panels)[gidx] = v;
 }
 
-struct ResCopy { const float* src; int dst_off; int n; };
+struct ResCopy { const float* src; int dst_off; int n; float scale = 1.f; };
 struct ResJob { ResCopy c[2 * MF_MAX_LAYERS + 8]; int n; float* res; int total; };
 
 __global__ void pack_resident_kernel(ResJob job) {
@@ -122,7 +133,7 @@ __global__ void pack_resident_kernel(ResJob job) {
   float v = 0.f;
   for (int k = 0; k < job.n; ++k) {
     const int o = idx - job.c[k].dst_off;
-    if (o >= 0 && o < job.c[k].n) v = job.c[k].src[o];
+    if (o >= 0 && o < job.c[k].n) v = job.c[k].src[o] * job.c[k].scale;
   }
   job.res[idx] = v;
 }
@@ -130,14 +141,14 @@ __global__ void pack_resident_kernel(ResJob job) {
 // bf16 NoF: the fp32 image-index columns of the layers that consume the embedded input, TRANSPOSED:
 // [embedded layer][column (kNofIndCols)][row] -- what nof_raybias_kernel contracts with emb(ind) once per ray, one thread
 // per row reading its column entries coalesced
-struct IndJob { const float* W[MF_MAX_LAYERS]; int n_in[MF_MAX_LAYERS]; int n_layers, rows, col0, cols; float* dst; };
+struct IndJob { const float* W[MF_MAX_LAYERS]; int n_in[MF_MAX_LAYERS]; int n_layers, rows, col0, cols; float* dst; float scale; };
 
 __global__ void pack_ind_kernel(IndJob job) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   const int per_layer = job.rows * kNofIndCols;
   if (idx >= job.n_layers * per_layer) return;
   const int e = idx / per_layer, r = (idx % per_layer) / kNofIndCols, c = idx % kNofIndCols;
-  job.dst[(e * kNofIndCols + c) * job.rows + r] = c < job.cols ? job.W[e][(long long)r * job.n_in[e] + job.col0 + c] : 0.f;
+  job.dst[(e * kNofIndCols + c) * job.rows + r] = c < job.cols ? job.scale * job.W[e][(long long)r * job.n_in[e] + job.col0 + c] : 0.f;
 }
 
 static int launch_pack(const PackJob& job, const ResJob& rj, hipStream_t st) {
@@ -251,6 +262,8 @@ extern "C" int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* 
   long long g0 = 0;
   int nr = 0;
   const int cin = d->in_channels_xyz + d->extra_feat_dim;
+  // NetLayout::half (the NoF under MF_PREC_BF16X3): weights at 2^kNofHalfSW, biases at the accumulators' 2^(kNofHalfSA + kNofHalfSW)
+  const float wscale = L.half ? (float)(1 << kNofHalfSW) : 1.f, bscale = L.half ? (float)(1 << (kNofHalfSA + kNofHalfSW)) : 1.f;
   for (int l = 0; l < L.n_trunk; ++l) {
     PackRegion& R = job.reg[nr++];
     const bool has_emb = (L.emb_mask >> l) & 1;
@@ -269,11 +282,13 @@ extern "C" int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* 
     R.bf16 = L.bf16;
     R.emb_split = L.emb_split ? L.terms : 1;
     R.hid_split = ((L.hsplit_mask >> l) & 1) ? L.terms : 1;
+    R.half = L.half;
+    R.wscale = wscale;
     R.hid_col0 = has_emb ? cin : 0;
     R.xyz_cols = d->in_channels_xyz;
     R.dst_group0 = g0;
     g0 += (long long)R.groups * R.tiles;
-    rj.c[rj.n++] = ResCopy{d->trunk_b[l], L.off_bias_trunk + l * L.W, L.W};
+    rj.c[rj.n++] = ResCopy{d->trunk_b[l], L.off_bias_trunk + l * L.W, L.W, bscale};
   }
   if (!d->head_w || !d->head_b) return fail(MF_E_INVALID, "mf_nof_pack: missing head parameters");
   if (L.bf16) {
@@ -289,11 +304,13 @@ extern "C" int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* 
     R.n_rows = L.n_head;
     R.hid_split = L.terms;
     R.emb_split = 1;
+    R.half = L.half;
+    R.wscale = wscale;
     R.dst_group0 = g0;
     g0 += R.groups;
   }
   rj.c[rj.n++] = ResCopy{d->head_w, L.off_head_w, L.n_head * L.W};
-  rj.c[rj.n++] = ResCopy{d->head_b, L.off_head_b, L.n_head};
+  rj.c[rj.n++] = ResCopy{d->head_b, L.off_head_b, L.n_head, bscale};
   job.n_regions = nr;
   job.total_groups = g0;
   job.panels = reinterpret_cast<float*>(static_cast<char*>(packed) + L.res_bytes);
@@ -309,6 +326,7 @@ extern "C" int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* 
         ++ij.n_layers;
       }
     ij.rows = L.W; ij.col0 = d->in_channels_xyz; ij.cols = d->extra_feat_dim;
+    ij.scale = bscale;                    // (the per-ray index bias b + W_ind emb(ind) comes out at the accumulators' scale)
     ij.dst = reinterpret_cast<float*>(static_cast<char*>(packed) + L.res_bytes + L.panel_bytes);
     const int total = ij.n_layers * ij.rows * kNofIndCols;
     hipLaunchKernelGGL(pack_ind_kernel, dim3((total + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), ij);

@@ -369,8 +369,8 @@ static int32_t render_entry(const mf_render_args* a, void* stream, bool prepare_
   if (!nerf_layout(*a->nerf, p.nerf.L, 0)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported NeRF configuration");
   if (p.nerf.L.NK != 16) return fail(MF_E_UNSUPPORTED, "mf_render_pass: only W=256 NeRF is built");
   const bool dump = a->dump_acts || a->dump_rgbsigma || a->dump_xyz || a->dump_nof_acts;
-  if (dump && bf16 && !(a->precision == MF_PREC_BF16X3 && !a->nof_bw && !a->dump_nof_acts))
-    return fail(MF_E_UNSUPPORTED, "mf_render_pass: the activation dump (training forward) exists in fp32, and in bf16x3 for passes without NoF");
+  if (dump && bf16 && a->precision != MF_PREC_BF16X3)
+    return fail(MF_E_UNSUPPORTED, "mf_render_pass: the activation dump (training forward) exists in fp32 and in bf16x3");
   if (a->emb_xyz.in_channels != 3 || a->emb_xyz.n_freqs > 10)
     return fail(MF_E_UNSUPPORTED, "mf_render_pass: xyz embedding must have 3 channels and <= 10 frequencies");
   const bool sigma_only = a->flags & MF_F_SIGMA_ONLY;

@@ -33,7 +33,9 @@ struct Params {
   const float* raybias;            // MOCO: (n_rays, rb_combos, rb_layers, 128) per-ray NoF biases (nof_raybias_kernel)
   int rb_combos, rb_layers;
   uint32_t rb_off, rb_buf_bytes;   // LDS: two buffers of the current / next chain step's rows of the tile's rays
-  float* dump_acts; long long dump_stride; float* dump_rgbsigma; float* dump_xyz;   // training forward (X3, no NoF)
+  float* dump_acts; long long dump_stride; float* dump_rgbsigma; float* dump_xyz;   // training forward (X3)
+  float* dump_nof_acts; long long dump_nof_stride; float* dump_nof_out;             // ... under NoF: per chain step (round 5)
+  uint32_t nof_plane_pack;         // plane of step k = (pack >> 3k) & 7
 };
 
 // ---- per-ray bias of the NoF's embedded-input layers (models/rendering.py:73-75 + models/nof.py:69-73) ----
@@ -158,7 +160,7 @@ MF_D void tile_rays(int tile, int nr, int S, int& first, int& n) {
 // for the backward (mf_render_args.dump_*), as mf_render.hip's render_kernel<*, true> does in fp32.
 template <bool MOCO, bool X3 = false, bool DUMP = false>
 __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel_bf16(const Params p) {
-  static_assert(!DUMP || (X3 && !MOCO), "the dump variant exists for the three-product canonical pass");
+  static_assert(!DUMP || X3, "the dump variants exist for the three-product passes");
   constexpr int NW = X3 ? 4 : kWaves;
   constexpr int TILE = NW * kWaveSamples;
   const Lane id;
@@ -181,10 +183,11 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
   StreamT<NW> st;
   st.tl.start(p.alphas, id);
   typename std::conditional<X3, CarryX, Carry>::type carry;
-  constexpr int NP2 = X3 ? 1 : kNofTpp;      // the fast mode's NoF layers stream two tiles per panel,
+  constexpr int NP2 = X3 ? 1 : kNofTpp0;     // the fast mode's NoF layers stream several tiles per panel (mf_bf16.hpp),
+  constexpr int NPH = X3 ? 0 : kNofTppH, NPS = X3 ? 0 : kNofTppS;
   constexpr int NF0 = X3 ? 1 : kNerfTpp0;    // its NeRF layer 0 four
-  constexpr int TN = X3 ? kNofTermsX3 : 2;   // bf16 terms of the NoF's operands (x3: hi, mid, lo -- six products per k-step)
-  const Next prog_first = MOCO ? first_of<8, kKsNofXyz, true, NP2, TN>(p.bw) : first_of<16, kKsNerfXyz, X3, NF0>(p.nerf);
+  constexpr int TN = X3 ? kNofTermsX3 : 2;   // terms of the NoF's operands (x3: kNofTermsX3 terms, IEEE halves with kNofHalfX3: mf_core.hpp)
+  const Next prog_first = MOCO ? first_of<8, kKsNofXyz, true, NP2, TN, NPH, NPS>(p.bw) : first_of<16, kKsNerfXyz, X3, NF0>(p.nerf);
   int seq = 0;                       // NoF evaluations done by this workgroup: evaluation number `seq` reads buffer seq & 1
   if (MOCO) {                        // rows of the first evaluation (first group, tile 0, bw at index i)
     const long long g0 = blockIdx.x;
@@ -193,7 +196,7 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
     tile_rays<TILE>(0, nr0, p.S, f0, n0);
     stage_raybias<NW>(p, g0 * p.G + f0, n0, 0, p.rb_off, id);
   }
-  if (MOCO) start_program<8, kKsNofXyz, true, NP2, TN>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);   // (its wait + barrier also publish the resident blocks / tables)
+  if (MOCO) start_program<8, kKsNofXyz, true, NP2, TN, NPH, NPS>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);   // (its wait + barrier also publish the resident blocks / tables)
   else start_program<16, kKsNerfXyz, X3, NF0>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
 
   const int S = p.S;
@@ -256,16 +259,27 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
           if (role == 1 || role == 2) { cur[0] = canon[0]; cur[1] = canon[1]; cur[2] = canon[2]; }
           const bool last = step == nsteps - 1;
           const bool next_fw = (role + 1 == 1 || role + 1 == 2 || role + 1 == 4);
-          const Next follow = last ? first_of<16, kKsNerfXyz, X3, NF0>(p.nerf) : first_of<8, kKsNofXyz, true, NP2, TN>(next_fw ? p.fw : p.bw);
+          const Next follow = last ? first_of<16, kKsNerfXyz, X3, NF0>(p.nerf) : first_of<8, kKsNofXyz, true, NP2, TN, NPH, NPS>(next_fw ? p.fw : p.bw);
           u32x4 nhi[kKsNofXyz], nmid[TN == 3 ? kKsNofXyz : 1], nlo[kKsNofXyz];
           float out[3];
-          if constexpr (TN == 3) nof_embed_t<!X3, 3>(nhi, nmid, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
-          else nof_embed<!X3>(nhi, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
+          if constexpr (X3) nof_embed_t<false, TN, kNofHalfX3>(nhi, reinterpret_cast<u32x4(&)[kKsNofXyz]>(nmid), nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
+          else nof_embed<true>(nhi, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
           auto stage_next = [&] {
             if (!last) stage_raybias<NW>(p, ray0 + tf, tn, role + 1 == 4 ? 1 : role + 1, p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes, id);
           };
-          if constexpr (X3) nof_eval_x3<TN>(net, nhi, reinterpret_cast<const u32x4(&)[kKsNofXyz]>(nmid), nlo, cur, st, carry, id, follow, out, rb, stage_next);
-          else nof_eval(net, nhi, nlo, cur, st, carry, id, follow, out, rb, nullptr, stage_next);
+          if constexpr (X3 && DUMP) {
+            // training forward: what autograd.NofPointsDumped's backward reads, per chain step (step-major planes; the embedded
+            // input is made from the points by mf_nof_embed_rows, the rows carry no ReLU bit words)
+            const long long nof_idx = (long long)((p.nof_plane_pack >> (3 * step)) & 7u) * p.n_rays * S + (ray * S + si);
+            const bool don = valid && p.dump_nof_acts != nullptr;
+            const RowDump nd{p.dump_nof_acts + nof_idx * p.dump_nof_stride + 4 * id.h, don, __ballot(don) != 0ull};
+            nof_eval_x3<TN, kNofHalfX3>(net, nhi, reinterpret_cast<const u32x4(&)[kKsNofXyz]>(nmid), nlo, cur, st, carry, id, follow, out, rb, stage_next, nd);
+            if (don && id.h == 0) { float* q = p.dump_nof_out + nof_idx * 3; q[0] = out[0]; q[1] = out[1]; q[2] = out[2]; }
+          } else if constexpr (X3) {
+            nof_eval_x3<TN, kNofHalfX3>(net, nhi, reinterpret_cast<const u32x4(&)[kKsNofXyz]>(nmid), nlo, cur, st, carry, id, follow, out, rb, stage_next);
+          } else {
+            nof_eval(net, nhi, nlo, cur, st, carry, id, follow, out, rb, nullptr, stage_next);
+          }
           if (role == 0) { canon[0] = out[0]; canon[1] = out[1]; canon[2] = out[2]; }
           if (role == 1) dl = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
           if (role == 4) dg = (fabsf(x[0] - out[0]) + fabsf(x[1] - out[1]) + fabsf(x[2] - out[2])) / 3.f;
@@ -472,11 +486,11 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void points_kernel
   StreamT<NW> st;
   st.tl.start(nullptr, id);
   typename std::conditional<X3, CarryX, Carry>::type carry;
-  constexpr int NP2 = X3 ? 1 : kNofTpp, NF0 = X3 ? 1 : kNerfTpp0;
+  constexpr int NP2 = X3 ? 1 : kNofTpp0, NF0 = X3 ? 1 : kNerfTpp0, NPH = X3 ? 0 : kNofTppH, NPS = X3 ? 0 : kNofTppS;
   constexpr int TN = X3 ? kNofTermsX3 : 2;
   const Next nerf_first = first_of<16, kKsNerfXyz, X3, NF0>(p.nerf);
-  const Next prog_first = NOF ? first_of<8, kKsNofXyz, true, NP2, TN>(p.bw) : nerf_first;
-  if (NOF) start_program<8, kKsNofXyz, true, NP2, TN>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);
+  const Next prog_first = NOF ? first_of<8, kKsNofXyz, true, NP2, TN, NPH, NPS>(p.bw) : nerf_first;
+  if (NOF) start_program<8, kKsNofXyz, true, NP2, TN, NPH, NPS>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);
   else start_program<16, kKsNerfXyz, X3, NF0>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
   const long long ntiles = (p.B + TILE - 1) / TILE;
   for (long long tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
@@ -495,9 +509,9 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void points_kernel
         nof_eval(p.bw, nhi, nlo, x, st, carry, id, nerf_first, out, rb, rbp, [] {});
       } else {
         LdsRayBias rb{p.rb_off};
-        if constexpr (TN == 3) nof_embed_t<!X3, 3>(nhi, nmid, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
-        else nof_embed<!X3>(nhi, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
-        if constexpr (X3) nof_eval_x3<TN>(p.bw, nhi, reinterpret_cast<const u32x4(&)[kKsNofXyz]>(nmid), nlo, x, st, carry, id, nerf_first, out, rb, [] {});
+        if constexpr (X3) nof_embed_t<false, TN, kNofHalfX3>(nhi, reinterpret_cast<u32x4(&)[kKsNofXyz]>(nmid), nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
+        else nof_embed<true>(nhi, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
+        if constexpr (X3) nof_eval_x3<TN, kNofHalfX3>(p.bw, nhi, reinterpret_cast<const u32x4(&)[kKsNofXyz]>(nmid), nlo, x, st, carry, id, nerf_first, out, rb, [] {});
         else nof_eval(p.bw, nhi, nlo, x, st, carry, id, nerf_first, out, rb, nullptr, [] {});
       }
       x[0] = out[0]; x[1] = out[1]; x[2] = out[2];
@@ -547,12 +561,18 @@ static bool emb_table(const mf_embedding& e, float* dst) {      // returns: freq
 }
 
 // combination c of a ray-bias table: network (packed buffer + layout) and the index column it reads
-// largest panel of a NoF in groups: its trunk tiles stream `tpp` per panel (fast mode: two), its head is one panel
-static int nof_panel_groups(const NetLayout& L, int tpp) {
-  int g = head_groups(L);
-  for (int l = 0; l < L.n_trunk; ++l)
+// largest panel of a network in groups when its trunk tiles stream several per panel (the fast mode's <TPP0, TPPH, TPPS>:
+// layer 0, hidden-only layers, skip layers; the NoF's head / the NeRF's extra_encoding tiles are one panel each)
+static int fast_panel_groups(const NetLayout& L, bool is_nof, int tpp0, int tpph, int tpps) {
+  int g = is_nof ? head_groups(L) : extra_groups(L);
+  for (int l = 0; l < L.n_trunk; ++l) {
+    const int tpp = l == 0 ? tpp0 : (((L.emb_mask >> l) & 1) ? tpps : tpph);
     if (tpp * trunk_groups(L, l) > g) g = tpp * trunk_groups(L, l);
+  }
   return g;
+}
+static int nof_panel_groups(const NetLayout& L, bool x3) {
+  return x3 ? fast_panel_groups(L, true, 1, 1, 1) : fast_panel_groups(L, true, bf::kNofTpp0, bf::kNofTppH, bf::kNofTppS);
 }
 
 static void raybias_combo(RayBiasParams& r, int c, const void* packed, const NetLayout& L, int col) {
@@ -614,16 +634,15 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
     return n;
   };
   p.nerf = net_of(Ln, a->nerf_packed, Ln.n_trunk - 1, Ln.extra_steps);
-  int max_groups = Ln.max_groups;
+  int max_groups = x3 ? Ln.max_groups : fast_panel_groups(Ln, false, bf::kNerfTpp0, bf::kNerfTppH, bf::kNerfTppS);
   if (moco) {
     if (!nof_layout(*a->nof_bw, Lb, prec)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported backward NoF configuration");
     p.bw = net_of(Lb, a->nof_bw_packed, Lb.n_trunk, Lb.n_head);
-    const int nof_pair = (!x3 && bf::kNofPair) ? 2 : 1;        // fast mode: two NoF tiles per panel
-    if (bf::nof_panel_groups(Lb, nof_pair) > max_groups) max_groups = bf::nof_panel_groups(Lb, nof_pair);
+    if (bf::nof_panel_groups(Lb, x3) > max_groups) max_groups = bf::nof_panel_groups(Lb, x3);
     if (chains) {
       if (!nof_layout(*a->nof_fw, Lf, prec)) return fail(MF_E_UNSUPPORTED, "mf_render_pass: unsupported forward NoF configuration");
       p.fw = net_of(Lf, a->nof_fw_packed, Lf.n_trunk, Lf.n_head);
-      if (bf::nof_panel_groups(Lf, nof_pair) > max_groups) max_groups = bf::nof_panel_groups(Lf, nof_pair);
+      if (bf::nof_panel_groups(Lf, x3) > max_groups) max_groups = bf::nof_panel_groups(Lf, x3);
     }
     p.pow2 |= (emb_table(a->nof_emb_xyz, p.emb_par[2]) ? 4 : 0) | (emb_table(a->nof_emb_ind, p.emb_par[3]) ? 8 : 0);
     // the per-ray bias table (image-index block of the NoFs' embedded-input layers), one small launch in front
@@ -690,15 +709,32 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
   lds = (lds + 15u) & ~15u;
 
   const int grid = (int)(p.n_groups < device_cus() ? p.n_groups : device_cus());
-  const bool dump = a->dump_acts || a->dump_rgbsigma || a->dump_xyz;
-  if (dump) {      // (validated by the caller: bf16x3, no NoF)
+  const bool dump = a->dump_acts || a->dump_rgbsigma || a->dump_xyz || a->dump_nof_acts;
+  if (dump) {      // (validated by the caller: bf16x3)
     if (a->dump_acts && a->dump_stride < (int64_t)Ln.n_trunk * Ln.W + Ln.W / 2)
       return fail(MF_E_INVALID, "mf_render_pass: dump_stride %lld too small", (long long)a->dump_stride);
     if (a->dump_acts && ((a->dump_stride & 3) || (reinterpret_cast<uintptr_t>(a->dump_acts) & 15)))
       return fail(MF_E_INVALID, "mf_render_pass(bf16x3): dump_acts must be 16-byte aligned with a stride that is a multiple of 4 floats");
     p.dump_acts = a->dump_acts; p.dump_stride = a->dump_stride; p.dump_rgbsigma = a->dump_rgbsigma; p.dump_xyz = a->dump_xyz;
+    if (a->dump_nof_acts) {
+      // the chain's evaluations: rows [h_1 .. h_D | T padded to 16] (no ReLU bit words, no embedded-input plane: mf_nof_embed_rows)
+      if (!moco || !a->dump_nof_out) return fail(MF_E_INVALID, "mf_render_pass(bf16x3): dump_nof_acts needs NoF models and dump_nof_out");
+      if (a->dump_nof_stride < (int64_t)Lb.n_trunk * Lb.W + 16 || (a->dump_nof_stride & 3) || (reinterpret_cast<uintptr_t>(a->dump_nof_acts) & 15))
+        return fail(MF_E_INVALID, "mf_render_pass(bf16x3): dump_nof_acts must be 16-byte aligned with a stride >= D W + 16 that is a multiple of 4 floats");
+      if (chains && (Lf.n_trunk != Lb.n_trunk)) return fail(MF_E_UNSUPPORTED, "mf_render_pass(bf16x3): the NoF dump needs both flows of one depth");
+      const int nsteps = 1 + ((a->flags & MF_F_CHAIN_LOCAL) ? 1 : 0) + ((a->flags & MF_F_CHAIN_GLOBAL) ? 3 : 0);
+      uint32_t seen = 0;
+      for (int k = 0; k < nsteps; ++k) {
+        const int pl = a->dump_nof_plane[k];
+        if (pl < 0 || pl >= nsteps || ((seen >> pl) & 1u)) return fail(MF_E_INVALID, "mf_render_pass: dump_nof_plane must be a permutation of 0..%d", nsteps - 1);
+        seen |= 1u << pl;
+        p.nof_plane_pack |= (uint32_t)pl << (3 * k);
+      }
+      p.dump_nof_acts = a->dump_nof_acts; p.dump_nof_stride = a->dump_nof_stride; p.dump_nof_out = a->dump_nof_out;
+    }
   }
-  void (*kern)(const Params) = x3 ? (moco ? render_kernel_bf16<true, true> : (dump ? render_kernel_bf16<false, true, true> : render_kernel_bf16<false, true>))
+  void (*kern)(const Params) = x3 ? (moco ? (dump ? render_kernel_bf16<true, true, true> : render_kernel_bf16<true, true>)
+                                          : (dump ? render_kernel_bf16<false, true, true> : render_kernel_bf16<false, true>))
                                   : (moco ? render_kernel_bf16<true, false> : render_kernel_bf16<false, false>);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);
@@ -735,13 +771,12 @@ int points_sigma_bf16(int prec, const mf_nerf_desc* nerf, const void* nerf_packe
     return n;
   };
   p.nerf = net_of(Ln, nerf_packed, Ln.n_trunk - 1, Ln.extra_steps);
-  int max_groups = Ln.max_groups;
+  int max_groups = x3 ? Ln.max_groups : fast_panel_groups(Ln, false, bf::kNerfTpp0, bf::kNerfTppH, bf::kNerfTppS);
   p.pow2 = emb_table(*emb_xyz, p.emb_par[0]) ? 1 : 0;
   if (nof) {
     if (!nof_layout(*nof, Lb, prec)) return fail(MF_E_UNSUPPORTED, "mf_points_sigma: unsupported NoF configuration");
     p.bw = net_of(Lb, nof_packed, Lb.n_trunk, Lb.n_head);
-    const int nof_pair = (!x3 && bf::kNofPair) ? 2 : 1;
-    if (nof_panel_groups(Lb, nof_pair) > max_groups) max_groups = nof_panel_groups(Lb, nof_pair);
+    if (nof_panel_groups(Lb, x3) > max_groups) max_groups = nof_panel_groups(Lb, x3);
     p.pow2 |= (emb_table(*nof_emb_xyz, p.emb_par[2]) ? 4 : 0) | (emb_table(*nof_emb_ind, p.emb_par[3]) ? 8 : 0);
     // per-point (ind given) or single (ind_scalar) bias of the NoF's embedded-input layers, see nof_raybias_kernel
     const int64_t need = points_workspace_bytes_bf16(nof, ind != nullptr, B);

@@ -177,10 +177,16 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
             out["nof_plane"] = [order.index(k) for k in range(steps)]
             for k in range(steps):
                 a.dump_nof_plane[k] = out["nof_plane"][k]
-            nstride = A.nof_dump_stride(nof_models[0])
+            x3 = prec == L.MF_PREC_BF16X3
+            # (the three-product forward writes rows without ReLU bit words and no embedded-input plane: the image-index block is
+            #  a per-ray bias there; _attach_explicit makes the plane from the points, mf_nof_embed_rows)
+            nstride = nof_models[0].D * nof_models[0].W + 16 if x3 else A.nof_dump_stride(nof_models[0])
             a.dump_nof_acts = alloc("nof_acts", (steps, N * S, nstride))
             a.dump_nof_stride = nstride
-            a.dump_nof_emb = alloc("nof_emb", (steps, N * S, 80))
+            if x3:
+                out["nof_emb"] = None
+            else:
+                a.dump_nof_emb = alloc("nof_emb", (steps, N * S, 80))
             a.dump_nof_out = alloc("nof_out", (steps, N * S, 3))
     need = int(L.lib().mf_render_workspace_bytes(C.byref(a)))      # bf16 + NoF: the per-ray bias table (ABI v12)
     with torch.cuda.device(dev):
@@ -419,7 +425,7 @@ def render_rays(rays,
     coarse_sigma_only = coarse_opacity_only and not grad
     # a pass that records gradients runs the reference's fp32 arithmetic (or, NeRF-only passes, the three-product kernels:
     # set_train_forward_precision)
-    pass_prec = (TRAIN_FORWARD_PRECISION if not use_nof else "f32") if grad else None
+    pass_prec = TRAIN_FORWARD_PRECISION if grad else None
     want_planes = need_fine or loc or glob or grad or _capture is not None
     noise_c = draw_noise((N, S), "noise_coarse")
     if grad and N > 0:
@@ -518,6 +524,8 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
             if "nof_acts" in p:       # the fused pass dumped every evaluation of the chain: nodes without a forward launch
                 step = [0]
                 plane = p["nof_plane"]
+                if p.get("nof_emb") is None:
+                    p["nof_emb"] = _nof_embedded_inputs(p, plane, xyz.detach().reshape(-1, 3), rays, S, nof_embs)
                 n_bw = sum(1 for k in range(len(plane)) if k in (0, 3))
                 # per network: its planes are adjacent; with whole 128-row blocks per plane the nodes leave their
                 # pre-activation gradients in one buffer and ONE mf_weight_grads launch per network follows them
@@ -526,17 +534,20 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
                 batched = (N * S) % 128 == 0 and (len(nof_models) < 2 or nof_models[0] is not nof_models[1])
                 trains = lambda m: any(q.requires_grad for q in m.parameters())
                 sinks = {}
+                slots = not getattr(p["nof_emb"], "_mf_natural", False)
                 if batched and trains(bw):
-                    sinks[id(bw)] = (A.NofGradSink(bw, p["nof_acts"][:n_bw], p["nof_emb"][:n_bw]), 0)
+                    sinks[id(bw)] = (A.NofGradSink(bw, p["nof_acts"][:n_bw], p["nof_emb"][:n_bw], slots), 0)
                 if batched and len(plane) > n_bw and trains(nof_models[1]):
-                    sinks[id(nof_models[1])] = (A.NofGradSink(nof_models[1], p["nof_acts"][n_bw:], p["nof_emb"][n_bw:]), n_bw)
+                    sinks[id(nof_models[1])] = (A.NofGradSink(nof_models[1], p["nof_acts"][n_bw:], p["nof_emb"][n_bw:], slots), n_bw)
                 gated = {key: A.NofParamGate.apply(sk, *sk.m.parameters()) for key, (sk, _) in sinks.items()}
 
                 def nof_points(pts, ray_ind, embs_, m):
                     k = plane[step[0]]
                     step[0] += 1
                     sk, first = sinks.get(id(m), (None, 0))
-                    return A.nof_points_dumped(pts, nof_embs, m, p["nof_acts"][k], p["nof_emb"][k], p["nof_out"][k],
+                    emb_k = p["nof_emb"][k]
+                    emb_k._mf_natural = not slots
+                    return A.nof_points_dumped(pts, nof_embs, m, p["nof_acts"][k], emb_k, p["nof_out"][k],
                                                sink=sk, sink_plane=k - first, params=gated.get(id(m)))
             else:
                 nof_points = A.nof_points
@@ -595,6 +606,29 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
         final["loss_partials"] = A.LossPartials.apply(
             lambda: _loss_partials_hip(coarse[0], fine[0] if fine is not None else None, tgt, N), rays, tgt, passes, *tensors)
     return final
+
+
+def _nof_embedded_inputs(p, plane, x_obs, rays, S, nof_embs):
+    """(steps, N S, 80) embedded inputs of the chain's NoF evaluations in natural column order (mf_nof_embed_rows), from the
+    points each step saw: step 0 the observation-space samples, then the dumped outputs of the steps in front
+    (rendering.py:270-282: bw(x, i); fw(canon, i); fw(canon, j); bw(., j); fw(., i))."""
+    steps, P = len(plane), x_obs.shape[0]
+    out_of = lambda k: p["nof_out"][plane[k]]
+    src = {0: x_obs, 1: out_of(0), 2: out_of(0)}
+    if steps > 3:
+        src[3], src[4] = out_of(2), out_of(3)
+    if steps == 2:
+        src = {0: x_obs, 1: out_of(0)}
+    emb = torch.empty((steps, P, 80), device=x_obs.device, dtype=torch.float32)
+    ex, ei = nof_embs[0].descriptor(), nof_embs[1].descriptor()
+    with torch.cuda.device(x_obs.device):
+        for k in range(steps):
+            col = rays[:, 9:10] if k in (2, 3) else rays[:, 8:9]
+            pts = src[k].contiguous()
+            L.check(L.lib().mf_nof_embed_rows(ex, ei, L.ptr(pts), col.data_ptr(), rays.stride(0), S, P, emb[plane[k]].data_ptr(),
+                                              L.current_stream(x_obs.device)), "mf_nof_embed_rows")
+    emb._mf_natural = True
+    return emb
 
 
 def _mask_of(alphas):

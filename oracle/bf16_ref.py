@@ -16,7 +16,8 @@ choices, not anything in the reference (which has no reduced-precision path).
 
 What is modelled (``Arith`` fields; kernel site in brackets):
   * matrix operands: "plain" = RNE to bf16; "split" = x = hi + lo, hi = bf16(x), lo = bf16(x - hi), three products
-    hi*hi + lo*hi + hi*lo; "split3" = hi + mid + lo with the six products down to 2^-24; "f32" = untouched
+    hi*hi + lo*hi + hi*lo; "split3" = hi + mid + lo with the six products down to 2^-24; "hsplit*" = IEEE-half (hi, lo)
+    pairs, three products (the NoF under bf16x3 since round 5: "hsplit_g", both operands at 2^5 x); "f32" = untouched
     [out_tile / mma_tile_x, split_operands, pack_operands, mf_pack.hip]
   * the NoF's image-index block as a per-ray fp32 bias, b + W[:, 33:66] emb(ind) by 33 sequential fp32 FMAs
     [nof_raybias_kernel]
@@ -64,6 +65,23 @@ def split3(x):
     return hi, mid, bf(x - hi - mid)
 
 
+def hf(x: torch.Tensor, ftz: bool = False) -> torch.Tensor:
+    """RNE to IEEE half, back in fp32 (v_cvt_pk_f16_f32; |x| > 65504 -> inf).  ``ftz``: results below the normal range
+    (|y| < 2^-14) flushed to zero -- what the split would see if the matrix unit dropped fp16 denormals (it does not:
+    tools/proto/f16_denorm.hip; kept as a what-if)."""
+    y = x.to(torch.float16).to(torch.float32)
+    if ftz:
+        y = torch.where(y.abs() < 2.0 ** -14, torch.zeros_like(y), y)
+    return y
+
+
+def hsplit2(x, scale_lo: float = 1.0, ftz: bool = False):
+    """x = hi + lo in IEEE half: hi = half(x), lo = half((x - hi) * scale_lo) / scale_lo (22 significand bits; x - hi is
+    exact in fp32).  scale_lo = 2^11 moves the lo term into hi's binade (a separate accumulator on the device)."""
+    hi = hf(x, ftz)
+    return hi, hf((x - hi) * scale_lo, ftz) / scale_lo
+
+
 def operand_terms(x: torch.Tensor, W: torch.Tensor, how: str):
     """[(X_i, W_i)]: the products sum_i X_i W_i^T the matrix pipe evaluates for ``x W^T`` under arithmetic ``how``."""
     if how == "f32":
@@ -82,6 +100,16 @@ def operand_terms(x: torch.Tensor, W: torch.Tensor, how: str):
         xh, xm, xl = split3(x)
         Wh, Wm, Wl = split3(W)
         return [(xh, Wh), (xh, Wm), (xm, Wh), (xh, Wl), (xm, Wm), (xl, Wh)]
+    if how in ("hsplit", "hsplit_s", "hsplit_ftz", "hsplit_g", "hsplit_gftz"):
+        # fp16 (hi, lo) pairs, three products (v_mfma_f32_32x32x16_f16): 22 significand bits per operand.  _s: the lo terms scaled by
+        # 2^11 (their own accumulator); _g: BOTH operands carried at 2^5 x their value (exact: powers of two; the accumulators
+        # are 2^10 x, un-scaled in the epilogue), which keeps the lo terms of O(0.01 .. 1) values out of the denormal range;
+        # ftz: what a matrix unit that flushed fp16 denormals would compute
+        sc, ftz = (2.0 ** 11 if how == "hsplit_s" else 1.0), how.endswith("ftz")
+        g = 32.0 if how in ("hsplit_g", "hsplit_gftz") else 1.0
+        xh, xl = hsplit2(x * g, sc, ftz)
+        Wh, Wl = hsplit2(W * g, sc, ftz)
+        return [(xh / g, Wh / g), (xh / g, Wl / g), (xl / g, Wh / g)]
     raise ValueError(how)
 
 
@@ -135,13 +163,21 @@ BF16 = Arith(name="bf16", acc="f64", nof_xyz="split", nof_ind_bias=True, nof_hid
 BF16X3_R3 = Arith(name="bf16x3_r3", acc="f64", nof_xyz="split", nof_ind_bias=True, nof_hidden="split", nof_head="split",
                   nof_xyz_sincos="hw", nerf_emb="split", nerf_hidden="split", nerf_tail="split", nerf_heads="f32acc",
                   nerf_xyz_sincos="chain", nerf_extra_sincos="hw")
-# set_precision("bf16x3"), round 4: the NoF in THREE-term operands (hi, mid, lo; six products per k-step, 24 mantissa bits)
+# round 4's set_precision("bf16x3"): the NoF in THREE-term bf16 operands (hi, mid, lo; six products per k-step, 24 mantissa bits)
 # with its xyz block from exact seeds + doubling chains -- its output point feeds sin(512 x); the NeRF as before
-BF16X3 = replace(BF16X3_R3, name="bf16x3", nof_xyz="split3", nof_hidden="split3", nof_head="split3", nof_xyz_sincos="chain")
+BF16X3_R4 = replace(BF16X3_R3, name="bf16x3_r4", nof_xyz="split3", nof_hidden="split3", nof_head="split3", nof_xyz_sincos="chain")
+# set_precision("bf16x3") as shipped (round 5): the NoF in IEEE-half (hi, lo) pairs at 2^5 x -- THREE products per k-step on
+# v_mfma_f32_32x32x16_f16, 22 significand bits (csrc/mf_core.hpp kNofHalfX3): the same distance to the fp32 oracle as the
+# three-term bf16 split at half the matrix instructions
+BF16X3 = replace(BF16X3_R4, name="bf16x3", nof_xyz="hsplit_g", nof_hidden="hsplit_g", nof_head="hsplit_g")
 # (the intermediate step: round 3's two-term NoF with the exact seeds)
 BF16X3_2T = replace(BF16X3_R3, name="bf16x3_2t", nof_xyz_sincos="chain")
 
-ARITH = {"f32": F32, "bf16": BF16, "bf16x3": BF16X3, "bf16x3_2t": BF16X3_2T, "bf16x3_r3": BF16X3_R3}
+# (priced on the way: the same pairs without the 2^5 scale -- the lo terms of O(0.1) values are denormal halves: 109 dB / 3.9e-5)
+BF16X3_H = replace(BF16X3, name="bf16x3_h", nof_xyz="hsplit", nof_hidden="hsplit", nof_head="hsplit")
+
+ARITH = {"f32": F32, "bf16": BF16, "bf16x3": BF16X3, "bf16x3_2t": BF16X3_2T, "bf16x3_r3": BF16X3_R3, "bf16x3_r4": BF16X3_R4,
+         "bf16x3_h": BF16X3_H}
 
 
 # ------------------------------------------------------------------ E with the kernels' sin / cos

@@ -99,6 +99,7 @@ def main():
     # buffer must equal the gradients of the same step without a reducer bit for bit (the kernels are deterministic).
     from moco_flow_amd.dist import GradReducer, global_partials
     rendering.set_precision("f32")
+    embs, nerfs, kw = build_case(M, dict(RENDER_CASES["r_moco_global_fine"]), 0, device="cuda")     # coarse + fine NeRF, bw + fw NoF
     nets = list(nerfs) + list(kw["nof_models"])
     gsteps = 10
 

@@ -40,6 +40,24 @@ def _compile(unit, extra):
     return usage, asm
 
 
+def _scratch_distance_to_mfma(asm, mangled):
+    """Smallest distance, in INSTRUCTIONS, between a scratch access and a matrix instruction inside kernel `mangled` (a large
+    number when the kernel has no scratch access)."""
+    body, on = [], False
+    for line in asm.splitlines():
+        if line.startswith(mangled + ":"):
+            on = True
+        if on:
+            t = line.strip()
+            if t and not t.startswith((";", ".", "//")) and not t.endswith(":"):
+                body.append(t)
+            if "s_endpgm" in line:
+                break
+    sc = [i for i, t in enumerate(body) if t.startswith("scratch_")]
+    mf = [i for i, t in enumerate(body) if t.startswith("v_mfma")]
+    return min((abs(i - j) for i in sc for j in mf), default=10 ** 9)
+
+
 @pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not available")
 def test_inference_kernels_have_no_spills_and_stream_weights_by_buffer_dma():
     with ThreadPoolExecutor(4) as ex:
@@ -62,11 +80,19 @@ def test_inference_kernels_have_no_spills_and_stream_weights_by_buffer_dma():
           "nerf_backward_kernel_x3" in k]                                                 # the three-product dX chain
     want = [k for k in u32 if re.search(r"render_kernelILb[01]ELb0EE", k)] + \
            [k for k in u16 if ("render_kernel_bf16" in k or "points_kernel_bf16" in k) and k not in x3]
-    assert len(want) == 2 + 5 and len(x3) == 7, sorted(list(u32) + list(u16))   # fp32 NeRF / MoCo; bf16 render x 2, point query x 3; x3: NeRF, MoCo, NeRF + dump, point query x 2, dX chain x 2
+    assert len(want) == 2 + 5 and len(x3) == 8, sorted(list(u32) + list(u16))   # fp32 NeRF / MoCo; bf16 render x 2, point query x 3; x3: NeRF, MoCo, NeRF + dump, MoCo + dump (round 5), point query x 2, dX chain x 2
     for k in want:
         u = {**u32, **u16}[k]
-        assert u["VGPRs Spill"] == 0 and u["ScratchSize"] == 0, (k, u)
         assert u["VGPRs"] <= 256, (k, u)
+        if k in u16:
+            # round 5: the fast bf16 tiles are pipeline stages -- the previous tile's epilogue in this tile's MFMA gaps, the next
+            # tile's bias in a second accumulator set (csrc/mf_bf16.hpp, mma_tile) -- 16 more live registers in a full file:
+            # hipcc parks <= 20 dwords of per-tile bookkeeping (ray pointers, output addresses) in scratch at the tile's start
+            # and reloads them in the VALU phases between the networks.  None of it may sit inside the MFMA-dense tile loops.
+            assert u["VGPRs Spill"] <= 20 and u["ScratchSize"] <= 80, (k, u)
+            assert _scratch_distance_to_mfma(a16, k) >= 8, (k, _scratch_distance_to_mfma(a16, k))
+        else:
+            assert u["VGPRs Spill"] == 0 and u["ScratchSize"] == 0, (k, u)
     # the bf16x3 kernels hold (hi, lo) pairs of a 256-wide layer's input AND output: one wave per SIMD with the whole register
     # file -- 256 VGPRs + AGPRs (hipcc parks finished output tiles there), nothing in scratch
     for k in x3:

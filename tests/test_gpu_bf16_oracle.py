@@ -127,8 +127,8 @@ X3_CASES = [("r_moco_local", 4096, "bench"), ("r_moco_local", 2048, "case"), ("r
 
 @pytest.mark.parametrize("name,n,draw", X3_CASES, ids=[f"{a}-{b}-{c}" for a, b, c in X3_CASES])
 def test_bf16x3_kernel_vs_the_oracle_of_its_arithmetic(M, B, name, n, draw):
-    """The same in bf16x3 against oracle/bf16_ref.BF16X3 (NeRF in two-term operands / three products, the NoF in three-term
-    operands / six products, heads on the fp32 accumulators, exact seeds + doubling chains): the kernel is within the
+    """The same in bf16x3 against oracle/bf16_ref.BF16X3 (NeRF in two-term bf16 operands / three products, the NoF in IEEE-half
+    (hi, lo) pairs at 2^5 x / three products, heads on the fp32 accumulators, exact seeds + doubling chains): the kernel is within the
     fp32 accumulation noise of its own oracle, and no farther from it than from the fp32 oracle."""
     c, rays, bg, tags, seed = _inputs(name, n, draw)
     got, cap = _hip(M, c, rays, bg, "bf16x3", tags, seed)

@@ -520,6 +520,56 @@ def test_train_forward_bf16x3(M, R, name):
             assert torch.equal(outs[0][k], outs[1][k]) and torch.equal(outs[0][k], outs[2][k])
 
 
+@pytest.mark.parametrize("name", ["r_moco_global", "r_moco_global_default", "r_moco_local"])
+def test_train_forward_bf16x3_moco(M, R, name):
+    """Round 5: rendering.set_train_forward_precision("bf16x3") for passes WITH NoF -- render_kernel_bf16<true, true, true>: the
+    MoCo chain (NoFs in IEEE-half pairs) + canonical NeRF in three products, dumping the NeRF's activations and, per chain
+    step, the NoF rows [h_1 .. h_D | T] + output points; the embedded-input plane comes from mf_nof_embed_rows (natural column
+    order).  Forward values hold the fp32 contract (1e-4 max-rel on rgb / depth / opacity; consensus means 1e-4); gradients
+    are judged like the fp32 default's (test_gradients_vs_oracle): float64 oracle as the truth, per tensor within
+    max(1e-4, 3 x the fp32 oracle's own distance to it) -- the three-product forward moves ReLU units across zero as fp32 rounding
+    does, only more of them (opt-in for that reason).  Same values and gradients between runs, bit for bit."""
+    from moco_flow_amd import rendering
+    c = dict(RENDER_CASES[name])
+    seed = int(load_golden(name)["meta_seed"])
+    n = 48
+    rays, bg = case_inputs(c, seed, n=n)
+    gt = torch.rand(n, 3, generator=torch.Generator().manual_seed(0))
+
+    def loss_fn(res, gt=gt):
+        loss = ((res["rgb_coarse"] - gt.to(res["rgb_coarse"])) ** 2).mean() + 0.1 * res["depth_coarse"].mean()
+        for k in ("nof_local_disp_coarse", "nof_global_disp_coarse"):
+            if k in res:
+                loss = loss + 0.2 * res[k].mean()
+        return loss
+
+    want_res, want32 = _oracle_grads(R, c, seed, rays, bg, loss_fn)
+    _, want64 = _oracle_grads(R, c, seed, rays, bg, loss_fn, torch.float64)
+    embs, nerfs, kw = build_case(M, c, seed, device="cuda")
+    nets = list(nerfs) + list(kw["nof_models"])
+    runs = []
+    try:
+        rendering.set_train_forward_precision("bf16x3")
+        for _ in range(2):
+            for m in nets:
+                m.zero_grad(set_to_none=True)
+            res = M.render_rays(rays.cuda(), bg.cuda(), embs, nerfs, **kw)
+            assert res["rgb_coarse"].requires_grad
+            loss_fn(res).backward()
+            runs.append([res["rgb_coarse"].detach().clone()] + [q.grad.clone() for m in nets for q in m.parameters() if q.grad is not None])
+    finally:
+        rendering.set_train_forward_precision("f32")
+    assert len(runs[0]) == len(runs[1]) and all(torch.equal(a, b) for a, b in zip(*runs))
+    for k in ("rgb_coarse", "depth_coarse", "opacity_coarse"):
+        assert relerr(res[k], want_res[k]) <= TOL, (k, relerr(res[k], want_res[k]))
+    for k in ("nof_local_disp_coarse", "nof_global_disp_coarse"):
+        if k in want_res:
+            a, b = float(res[k].mean()), float(want_res[k].mean())
+            assert abs(a - b) <= 1e-4 * abs(b), (k, a, b)
+    checked = _check_grads_vs_float64(nets, want32, want64, label=name + " (bf16x3 training forward, MoCo)")
+    assert checked >= 20
+
+
 @pytest.mark.parametrize("name", GRAD_CASES)
 def test_gradients_vs_oracle(M, R, name, wgrad):
     """Training contract (moco_flow_amd/autograd.py): forward values from the HIP kernels, gradients from

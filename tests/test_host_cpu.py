@@ -164,11 +164,12 @@ def test_packed_layout_sizes():
     groups = (4 + 3 * 16 + 20 + 3 * 16 + 16) * 8 + (16 + 2) * 4
     assert lib.mf_nerf_packed_bytes_p(ctypes.byref(d), L.MF_PREC_BF16) == 13 * 1024 + groups * 1024
     # MF_PREC_BF16X3: the NeRF's k-steps as (hi, lo) group pairs -- twice the groups of the bf16 layout (its encodings split
-    # too); the NoF's as (hi, mid, lo) TRIPLES (round 4: six products per k-step, 24 mantissa bits -- its output point feeds
-    # sin(512 x)): 3 embedded k-steps x 3, 8 hidden k-steps x 3, a 24-group head panel
+    # too); the NoF's as IEEE-half (hi, lo) pairs (round 5: three products per k-step on the f16 matrix instruction, 22
+    # significand bits -- its output point feeds sin(512 x); round 4 packed bf16 triples): 3 embedded k-steps x 2, 8 hidden
+    # k-steps x 2, a 16-group head panel
     groups = (8 + 3 * 32 + 40 + 3 * 32 + 32) * 8 + (32 + 4) * 4
     assert lib.mf_nerf_packed_bytes_p(ctypes.byref(d), L.MF_PREC_BF16X3) == 13 * 1024 + groups * 1024
-    assert lib.mf_nof_packed_bytes_p(ctypes.byref(n), L.MF_PREC_BF16X3) == 7 * 1024 + ((9 + 24 + 33 + 24) * 4 + 24) * 1024 + 36 * 1024
+    assert lib.mf_nof_packed_bytes_p(ctypes.byref(n), L.MF_PREC_BF16X3) == 7 * 1024 + ((6 + 16 + 22 + 16) * 4 + 16) * 1024 + 36 * 1024
     # the envelope is the reference's constructors, not only its YAMLs: NeRF() defaults to in_channels_xyz = 33 and no
     # extra block (models/nerf.py:6-12), NoF() to extra_feat_dim = 0 (models/nof.py:7-15) -- narrower input blocks pack
     # into the same slots (same sizes); wider ones are refused
