@@ -405,6 +405,7 @@ def train_shape_legs(M, synth, torch, dev, steps=6):
     # round 5: the same step with the opt-in three-product training forward, now for passes WITH NoF too
     # (render_kernel_bf16<true, true, true>; forward values to 1e-4, gradients inside the fp32 oracle's own noise floor against
     # the float64 truth, tests/test_gpu_parity.py::test_train_forward_bf16x3_moco) -- reported beside the default, never instead
+    torch.cuda.empty_cache()          # (a step holds ~20 GB of dumps: differently shaped blocks on top of the cached ones made the allocator go to the driver every step)
     rendering.set_train_forward_precision("bf16x3")
     try:
         out["joint_optin_bf16x3_forward"] = {"ms_per_step": med(joint), "rays": N, "samples_per_ray": 384,

@@ -389,12 +389,12 @@ int64_t mf_render_workspace_bytes(const mf_render_args* a);
 int32_t mf_nof_emb_slot_features(int32_t* features80);
 
 /* The embedded input of a NoF evaluation as rows, NATURAL column order (ABI v16): out (P, 80) = [emb_xyz(pts) zero-padded to 33 |
- * emb_ind(ind of the point's ray) | 0 x 14], row r belongs to ray r / S (ind + (r / S) * ind_stride).  Reference:
- * models/rendering.py:70-75, models/embedding.py:42-47.  The X operand of the NoF's 128 x 80 weight-gradient blocks for training
- * forwards that do not write mf_render_args.dump_nof_emb themselves (MF_PREC_BF16X3).  xyz embedding: 3 channels, <= 5
- * frequencies; index embedding: 1 channel, <= 16. */
-int32_t mf_nof_embed_rows(const mf_embedding* emb_xyz, const mf_embedding* emb_ind, const float* pts, const float* ind,
-                          int64_t ind_stride, int32_t S, int64_t P, float* out, void* stream);
+ * ind_emb[r / S] (ind_width <= 33 columns: the index embedding of the point's ray, embedded ONCE per ray by the caller,
+ * mf_embedding_forward) | 0], row r belongs to ray r / S.  Reference: models/rendering.py:70-75, models/embedding.py:42-47.
+ * The X operand of the NoF's 128 x 80 weight-gradient blocks for training forwards that do not write
+ * mf_render_args.dump_nof_emb themselves (MF_PREC_BF16X3).  xyz embedding: 3 channels, <= 5 frequencies. */
+int32_t mf_nof_embed_rows(const mf_embedding* emb_xyz, const float* pts, const float* ind_emb, int32_t ind_width, int32_t S,
+                          int64_t P, float* out, void* stream);
 
 /* ---- hierarchical resampling: sample_pdf (rendering.py:5-46) [+ cat + sort, :321-326] ------
  * General form.  Per ray: n_bins bin positions -- either explicit `bins` (N, n_bins), the

@@ -148,7 +148,7 @@ SYMBOLS = {
                                  C.c_float, C.c_float, C.c_float, _fp, _fp]),
     "mf_knn1": (C.c_int32, [_fp, C.c_int64, _fp, C.c_int64, _fp, _fp, _fp]),
     "mf_nof_emb_slot_features": (C.c_int32, [C.POINTER(C.c_int32)]),
-    "mf_nof_embed_rows": (C.c_int32, [C.POINTER(mf_embedding), C.POINTER(mf_embedding), _fp, _fp, C.c_int64, C.c_int32, C.c_int64, _fp, _fp]),
+    "mf_nof_embed_rows": (C.c_int32, [C.POINTER(mf_embedding), _fp, _fp, C.c_int32, C.c_int32, C.c_int64, _fp, _fp]),
     "mf_smpl_scratch_bytes": (C.c_int64, [C.c_int64, C.c_int64]),
     "mf_smpl_lbs": (C.c_int32, [C.POINTER(mf_smpl_model), _fp, C.c_int32, _fp, C.c_int64, _fp, _fp, _fp, _fp]),
     "mf_smpl_frame_transforms": (C.c_int32, [_fp, _fp, C.c_int64, _fp, _fp]),

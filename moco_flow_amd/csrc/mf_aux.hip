@@ -372,46 +372,46 @@ extern "C" int32_t mf_image_compose(const uint8_t* rays_msk, const int64_t* rank
 // ---- mf_nof_embed_rows (ABI v16): the NoF's embedded input [emb_xyz(point) zero-padded to 33 | emb_ind(index of the point's ray) | 0]
 // as (P, 80) rows in NATURAL column order -- the X operand of the 128 x 80 weight-gradient blocks of the NoF's embedded-input
 // layers (models/rendering.py:70-75, models/embedding.py:42-47) -- for training forwards that do not write that plane themselves
-// (MF_PREC_BF16X3: the index block is a per-ray bias there and never exists per sample).  One thread per output column.
+// (MF_PREC_BF16X3: the index block is a per-ray bias there and never exists per sample).  64 threads per row: 15 evaluate one
+// (frequency, component) pair each -- ONE sincosf, two columns --, 3 copy the raw point, 33 copy the ray's index block from the
+// per-ray table `ind_emb` (the caller embeds the N indices once: the block is constant along a ray), 13 write the padding.
 namespace mf {
-struct NofEmbRowsParams { mf_embedding exyz, eind; const float* pts; const float* ind; long long ind_stride; int S; long long P; float* out; };
+struct NofEmbRowsParams { mf_embedding exyz; const float* pts; const float* ind_emb; int ind_width; int S; long long P; float* out; };
 
-__global__ void nof_embed_rows_kernel(const NofEmbRowsParams p) {
-  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= p.P * 80) return;
-  const long long row = idx / 80;
-  const int c = (int)(idx % 80);
-  float v = 0.f;
-  if (c < 33) {                                                           // xyz block: [x (3) | w_k sin(f_k x) (3) | w_k cos(f_k x) (3) | ...]
-    const int width = 3 * (2 * p.exyz.n_freqs + 1);
-    if (c < 3) v = p.pts[row * 3 + c];
-    else if (c < width) {
-      const int k = (c - 3) / 6, r = (c - 3) % 6;
-      const float arg = p.exyz.freq[k] * p.pts[row * 3 + r % 3];          // embedding.py:45: func(freq * x)
-      v = p.exyz.weight[k] * (r < 3 ? sinf(arg) : cosf(arg));
+__global__ __launch_bounds__(256) void nof_embed_rows_kernel(const NofEmbRowsParams p) {
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= p.P) return;
+  const int s = threadIdx.x & 63;
+  float* o = p.out + row * 80;
+  if (s < 15) {                                                           // [w_k sin(f_k x_c) | w_k cos(f_k x_c)], embedding.py:45: func(freq * x)
+    const int k = s / 3, c = s % 3;
+    float sn = 0.f, cs = 0.f;
+    if (k < p.exyz.n_freqs) {
+      sincosf(p.exyz.freq[k] * p.pts[row * 3 + c], &sn, &cs);
+      sn *= p.exyz.weight[k]; cs *= p.exyz.weight[k];
     }
-  } else if (c < 66) {                                                    // index block: [ind | w_k sin(f_k ind) | w_k cos(f_k ind) | ...]
-    const int cc = c - 33, width = 2 * p.eind.n_freqs + 1;
-    const float iv = p.ind[(row / p.S) * p.ind_stride];
-    if (cc == 0) v = iv;
-    else if (cc < width) {
-      const int k = (cc - 1) / 2;
-      const float arg = p.eind.freq[k] * iv;
-      v = p.eind.weight[k] * (((cc - 1) & 1) ? cosf(arg) : sinf(arg));
-    }
+    o[3 + 6 * k + c] = sn;
+    o[3 + 6 * k + 3 + c] = cs;
+  } else if (s < 18) {
+    o[s - 15] = p.pts[row * 3 + (s - 15)];
+  } else if (s < 51) {
+    const int c = s - 18;
+    o[33 + c] = c < p.ind_width ? p.ind_emb[(row / p.S) * p.ind_width + c] : 0.f;
+  } else {
+    o[66 + (s - 51)] = 0.f;                                               // columns 66 .. 78
+    if (s == 51) o[79] = 0.f;
   }
-  p.out[idx] = v;
 }
 }  // namespace mf
 
-extern "C" int32_t mf_nof_embed_rows(const mf_embedding* emb_xyz, const mf_embedding* emb_ind, const float* pts, const float* ind,
-                                     int64_t ind_stride, int32_t S, int64_t P, float* out, void* stream) {
-  if (!emb_xyz || !emb_ind || P < 0 || S < 1 || (P > 0 && (!pts || !ind || !out))) return fail(MF_E_INVALID, "mf_nof_embed_rows: bad argument");
-  if (emb_xyz->in_channels != 3 || emb_xyz->n_freqs < 0 || emb_xyz->n_freqs > 5 || emb_ind->in_channels != 1 || emb_ind->n_freqs < 0 ||
-      emb_ind->n_freqs > 16)
-    return fail(MF_E_UNSUPPORTED, "mf_nof_embed_rows: xyz embedding 3 channels x <= 5 frequencies, index embedding 1 x <= 16");
+extern "C" int32_t mf_nof_embed_rows(const mf_embedding* emb_xyz, const float* pts, const float* ind_emb, int32_t ind_width, int32_t S,
+                                     int64_t P, float* out, void* stream) {
+  if (!emb_xyz || P < 0 || S < 1 || ind_width < 0 || ind_width > 33 || (P > 0 && (!pts || !out || (ind_width > 0 && !ind_emb))))
+    return fail(MF_E_INVALID, "mf_nof_embed_rows: bad argument");
+  if (emb_xyz->in_channels != 3 || emb_xyz->n_freqs < 0 || emb_xyz->n_freqs > 5)
+    return fail(MF_E_UNSUPPORTED, "mf_nof_embed_rows: xyz embedding 3 channels x <= 5 frequencies");
   if (P == 0) return MF_OK;
-  NofEmbRowsParams p{*emb_xyz, *emb_ind, pts, ind, ind_stride, S, P, out};
-  hipLaunchKernelGGL(nof_embed_rows_kernel, dim3((unsigned)((P * 80 + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
+  NofEmbRowsParams p{*emb_xyz, pts, ind_emb, ind_width, S, P, out};
+  hipLaunchKernelGGL(nof_embed_rows_kernel, dim3((unsigned)((P + 3) / 4)), dim3(256), 0, static_cast<hipStream_t>(stream), p);
   return check_launch("mf_nof_embed_rows");
 }

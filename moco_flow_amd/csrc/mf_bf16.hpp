@@ -884,10 +884,29 @@ struct Ahead { int g0; const char* j0; int g1; const char* j1; int s0 = -1, s1 =
 
 // Activation dump of the training forward (mf_render_args.dump_acts): `row` = this lane's sample row + the layer's first
 // column + 4 (lane >> 5); a tile's 16 accumulators are rows 8 q + 4 h + i, i.e. four 16-byte stores at row[32 t + 8 q].
-struct RowDump { float* row; bool on; bool wave_on; };     // wave_on: some lane of the wave stores (uniform)
+// `mask` (round 5; with `masks`, uniform): this lane's ReLU BIT ROW of the layer -- the words the fp32 forward writes
+// (relu_mask_word / relu_mask_shift, mf_core.hpp: word 4 (t >> 2) + g, byte t & 3, bit = feature of lane group g) and the x3
+// backward chains read (relu_mask_pair): lane half h of this 32 x 32 tiling owns the bytes of groups g = h and g = 2 + h.
+struct RowDump { float* row; bool on; bool wave_on; unsigned* mask = nullptr; bool masks = false; };     // wave_on: some lane of the wave stores (uniform)
 MF_D bool dump_wave_on(const RowDump& d) { return d.wave_on; }
 struct NoDump {};
 MF_D bool dump_wave_on(const NoDump&) { return true; }
+// Tile t's two mask bytes from its accumulators (register 4 q + i = feature 8 q + 4 h + i: q = 0 / 2 -> low / high nibble of
+// group h's byte, q = 1 / 3 -> of group 2 + h's), collected four tiles to a word and stored behind every fourth tile.
+MF_D void mask_put(const RowDump& d, const f32x16& acc, int t, int h, unsigned& ma, unsigned& mb) {
+  if (!d.masks) return;
+  auto pos = [](float x) { return __builtin_bit_cast(int, x) > 0 ? 1u : 0u; };
+  unsigned a = 0, b = 0;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    a |= pos(acc[i]) << i | pos(acc[8 + i]) << (4 + i);
+    b |= pos(acc[4 + i]) << i | pos(acc[12 + i]) << (4 + i);
+  }
+  ma = ((t & 3) == 0 ? 0u : ma) | a << (8 * (t & 3));
+  mb = ((t & 3) == 0 ? 0u : mb) | b << (8 * (t & 3));
+  if ((t & 3) == 3 && d.on) { d.mask[4 * (t >> 2) + h] = ma; d.mask[4 * (t >> 2) + 2 + h] = mb; }
+}
+MF_D void mask_put(const NoDump&, const f32x16&, int, int, unsigned&, unsigned&) {}
 // HF: the accumulators of a half-operand layer are 2^(kNofHalfSA + kNofHalfSW) x the pre-activations (mf_core.hpp): the dump holds
 // the activations themselves
 template <bool RELU, bool HF = false>
@@ -1087,6 +1106,7 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
   constexpr int kSteps = OUTS == 3 ? 24 : 16;
   static_assert(!DUMP || NM >= 8, "dump stores need four piece-free MFMA gaps");
   f32x16 pend = {};
+  unsigned mask_a = 0, mask_b = 0;                           // the layer's ReLU bit words being collected (RowDump::mask)
   // DUMP: the pending tile's four row stores go into the LAST four MFMA gaps of the next tile, behind that tile's last
   // LDS-DMA piece (LATE_FREE), so the panel barrier that follows may leave exactly them in flight (KEEP = 4).  Which
   // barriers: the first of tile t >= 2 (tile t - 1 carried tile t - 2's stores) and the first of tile 0 (the layer in
@@ -1112,6 +1132,7 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
       if (t == 0) return;
 #pragma unroll
       for (int sidx = kSteps * m / NM; sidx < kSteps * (m + 1) / NM; ++sidx) epi(pend, sidx, tp);
+      if (DUMP && RELU && m == NM - 5) mask_put(dump, pend, tp, id.h, mask_a, mask_b);    // (older than the four row stores: KEEP = 4 still leaves exactly those in flight)
       if (DUMP && m >= NM - 4) dump_store<RELU, HF>(dump, pend, tp, m - (NM - 4));
     };
     f32x16 acc;
@@ -1131,6 +1152,7 @@ MF_D void layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[KI], 
 #pragma unroll
   for (int sidx = 0; sidx < kSteps; ++sidx) epi(pend, sidx, NT - 1);
   if constexpr (DUMP) {
+    if (RELU) mask_put(dump, pend, NT - 1, id.h, mask_a, mask_b);
 #pragma unroll
     for (int q = 0; q < 4; ++q) dump_store<RELU, HF>(dump, pend, NT - 1, q);
   }
@@ -1210,11 +1232,11 @@ MF_D void nof_eval_x3(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4
   auto one = [&](int layer, const u32x4 (&ih)[8], const u32x4* im, const u32x4 (&il)[8], u32x4 (&oh)[8], u32x4* om, u32x4 (&ol)[8]) __attribute__((always_inline)) {
     const Next nxt = layer == D - 1 ? hd : next_x<8, kKsNofXyz, T>(net, layer + 1);
     const int has_emb = (net.emb_mask >> layer) & 1;
-    auto dump_at = [&](int col) {
-      if constexpr (__is_same(DT, RowDump)) return RowDump{dump.row + col, dump.on, dump.wave_on};
+    auto dump_at = [&](int col, int lyr) {                    // (the NoF's bit rows: 4 words per layer)
+      if constexpr (__is_same(DT, RowDump)) return RowDump{dump.row + col, dump.on, dump.wave_on, dump.mask + 4 * lyr, dump.masks};
       else return NoDump{};
     };
-    const auto nd = dump_at(layer * 128);
+    const auto nd = dump_at(layer * 128, layer);
     if (layer == 0) trunk_layer_x<8, kKsNofXyz, 1, true, 0, T, HF>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead, nd, im, om, xmid);
     else if (has_emb) trunk_layer_x<8, kKsNofXyz, 3, true, 0, T, HF>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead, nd, im, om, xmid);
     else trunk_layer_x<8, kKsNofXyz, 2, true, 0, T, HF>(net, layer, ih, il, oh, ol, xhi, xlo, st, carry, id, nxt, rb, 0u, nohead, nd, im, om, xmid);
@@ -1267,8 +1289,8 @@ template <class MakeExtra, class ST, class DT = NoDump>
 MF_D void nerf_eval_x3(const Net& net, const u32x4 (&xh)[kKsNerfXyz], const u32x4 (&xl)[kKsNerfXyz], MakeExtra&& make_extra,
                        bool sigma_only, ST& st, CarryX& carry, const Lane& id, const Next& follow, float& sigma,
                        float (&rgb)[3], const DT& dump = DT{}) {
-  auto dump_at = [&](int col) {                               // the dump of a layer whose first column is `col`
-    if constexpr (__is_same(DT, RowDump)) return RowDump{dump.row + col, dump.on, dump.wave_on};
+  auto dump_at = [&](int col) {                               // the dump of a layer whose first column is `col` (layer col / 256: 8 mask words each)
+    if constexpr (__is_same(DT, RowDump)) return RowDump{dump.row + col, dump.on, dump.wave_on, dump.mask + 8 * (col / 256), dump.masks};
     else return NoDump{};
   };
   u32x4 ah[16], al[16], bh[16], bl[16];

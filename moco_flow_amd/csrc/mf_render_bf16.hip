@@ -34,6 +34,7 @@ struct Params {
   int rb_combos, rb_layers;
   uint32_t rb_off, rb_buf_bytes;   // LDS: two buffers of the current / next chain step's rows of the tile's rays
   float* dump_acts; long long dump_stride; float* dump_rgbsigma; float* dump_xyz;   // training forward (X3)
+  unsigned* dump_mask; long long dump_mask_stride;                                  // ReLU bit rows of the NeRF's dump (optional)
   float* dump_nof_acts; long long dump_nof_stride; float* dump_nof_out;             // ... under NoF: per chain step (round 5)
   uint32_t nof_plane_pack;         // plane of step k = (pack >> 3k) & 7
 };
@@ -272,7 +273,10 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
             // input is made from the points by mf_nof_embed_rows, the rows carry no ReLU bit words)
             const long long nof_idx = (long long)((p.nof_plane_pack >> (3 * step)) & 7u) * p.n_rays * S + (ray * S + si);
             const bool don = valid && p.dump_nof_acts != nullptr;
-            const RowDump nd{p.dump_nof_acts + nof_idx * p.dump_nof_stride + 4 * id.h, don, __ballot(don) != 0ull};
+            // (a row with room behind T carries the layers' ReLU bit words, 4 per layer: what mf_nof_backward3 reads instead of the activations)
+            float* nrow = p.dump_nof_acts + nof_idx * p.dump_nof_stride;
+            const bool nmasks = p.dump_nof_stride >= (long long)net.D * 128 + 16 + 4 * net.D;
+            const RowDump nd{nrow + 4 * id.h, don, __ballot(don) != 0ull, reinterpret_cast<unsigned*>(nrow + net.D * 128 + 16), nmasks};
             nof_eval_x3<TN, kNofHalfX3>(net, nhi, reinterpret_cast<const u32x4(&)[kKsNofXyz]>(nmid), nlo, cur, st, carry, id, follow, out, rb, stage_next, nd);
             if (don && id.h == 0) { float* q = p.dump_nof_out + nof_idx * 3; q[0] = out[0]; q[1] = out[1]; q[2] = out[2]; }
           } else if constexpr (X3) {
@@ -337,7 +341,8 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
         if constexpr (DUMP) {
           const long long row = ray * S + si;
           const bool don = valid && p.dump_acts != nullptr;
-          const RowDump dump{p.dump_acts + row * p.dump_stride + 4 * id.h, don, __ballot(don) != 0ull};
+          const RowDump dump{p.dump_acts + row * p.dump_stride + 4 * id.h, don, __ballot(don) != 0ull,
+                             p.dump_mask ? p.dump_mask + row * p.dump_mask_stride : nullptr, p.dump_mask != nullptr};
           nerf_eval_x3(p.nerf, xh, xl, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb, dump);
           if (valid && id.h == 0) {
             if (p.dump_rgbsigma) *reinterpret_cast<float4*>(p.dump_rgbsigma + row * 4) = make_float4(rgb[0], rgb[1], rgb[2], sigma);
@@ -716,6 +721,11 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
     if (a->dump_acts && ((a->dump_stride & 3) || (reinterpret_cast<uintptr_t>(a->dump_acts) & 15)))
       return fail(MF_E_INVALID, "mf_render_pass(bf16x3): dump_acts must be 16-byte aligned with a stride that is a multiple of 4 floats");
     p.dump_acts = a->dump_acts; p.dump_stride = a->dump_stride; p.dump_rgbsigma = a->dump_rgbsigma; p.dump_xyz = a->dump_xyz;
+    if (a->dump_mask) {
+      if (!a->dump_acts || a->dump_mask_stride < (int64_t)(Ln.n_trunk + 1) * 8)
+        return fail(MF_E_INVALID, "mf_render_pass: dump_mask needs dump_acts and dump_mask_stride >= 8 (D + 2) words");
+      p.dump_mask = a->dump_mask; p.dump_mask_stride = a->dump_mask_stride;
+    }
     if (a->dump_nof_acts) {
       // the chain's evaluations: rows [h_1 .. h_D | T padded to 16] (no ReLU bit words, no embedded-input plane: mf_nof_embed_rows)
       if (!moco || !a->dump_nof_out) return fail(MF_E_INVALID, "mf_render_pass(bf16x3): dump_nof_acts needs NoF models and dump_nof_out");

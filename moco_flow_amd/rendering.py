@@ -163,7 +163,7 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
         a.dump_stride = stride
         a.dump_rgbsigma = alloc("rgbsig", (N * S, 4))
         a.dump_xyz = alloc("xyz_in", (N * S, 3))
-        if not sigma_only and prec == L.MF_PREC_F32 and A.DX_PRECISION == "bf16x3":
+        if not sigma_only and prec in (L.MF_PREC_F32, L.MF_PREC_BF16X3) and A.DX_PRECISION == "bf16x3":
             # the ReLU bit mask of the dumped activations: all the three-product dX chain needs of them (32 bytes instead
             # of 1 KiB per layer and sample); travels with the dump tensor
             mw = (nerf.D + 2) * 8
@@ -178,9 +178,9 @@ def _render_pass(rays, background, z_vals, z_steps, use_disp, noise, activation,
             for k in range(steps):
                 a.dump_nof_plane[k] = out["nof_plane"][k]
             x3 = prec == L.MF_PREC_BF16X3
-            # (the three-product forward writes rows without ReLU bit words and no embedded-input plane: the image-index block is
-            #  a per-ray bias there; _attach_explicit makes the plane from the points, mf_nof_embed_rows)
-            nstride = nof_models[0].D * nof_models[0].W + 16 if x3 else A.nof_dump_stride(nof_models[0])
+            # (the three-product forward writes no embedded-input plane: the image-index block is a per-ray bias there;
+            #  _attach_explicit makes the plane from the points, mf_nof_embed_rows)
+            nstride = A.nof_dump_stride(nof_models[0])
             a.dump_nof_acts = alloc("nof_acts", (steps, N * S, nstride))
             a.dump_nof_stride = nstride
             if x3:
@@ -620,12 +620,15 @@ def _nof_embedded_inputs(p, plane, x_obs, rays, S, nof_embs):
     if steps == 2:
         src = {0: x_obs, 1: out_of(0)}
     emb = torch.empty((steps, P, 80), device=x_obs.device, dtype=torch.float32)
-    ex, ei = nof_embs[0].descriptor(), nof_embs[1].descriptor()
+    ex = nof_embs[0].descriptor()
+    with torch.no_grad():                                   # the index block is constant along a ray: embedded once per ray
+        ind_i = nof_embs[1](rays[:, 8:9].contiguous())
+        ind_j = nof_embs[1](rays[:, 9:10].contiguous()) if steps > 2 else None
     with torch.cuda.device(x_obs.device):
         for k in range(steps):
-            col = rays[:, 9:10] if k in (2, 3) else rays[:, 8:9]
+            tab = ind_j if k in (2, 3) else ind_i
             pts = src[k].contiguous()
-            L.check(L.lib().mf_nof_embed_rows(ex, ei, L.ptr(pts), col.data_ptr(), rays.stride(0), S, P, emb[plane[k]].data_ptr(),
+            L.check(L.lib().mf_nof_embed_rows(ex, L.ptr(pts), L.ptr(tab), tab.shape[1], S, P, emb[plane[k]].data_ptr(),
                                               L.current_stream(x_obs.device)), "mf_nof_embed_rows")
     emb._mf_natural = True
     return emb

@@ -78,6 +78,9 @@ def fwd_bwd_fast():
     (t["img_loss"] + 0.1 * (t["nof_local"] + t["nof_global"])).backward()
 
 
+if os.environ.get("MF_TRAIN_FWD"):              # e.g. MF_TRAIN_FWD=bf16x3: the opt-in three-product training forward
+    from moco_flow_amd import rendering as _r
+    _r.set_train_forward_precision(os.environ["MF_TRAIN_FWD"])
 if os.environ.get("MF_ONLY") == "fast":       # profiling: only the trainer's fast path (loss from the fused partials)
     print(f"  HIP forward + backward, loss from the fused partials : {timeit(fwd_bwd_fast):8.2f} ms")
     sys.exit(0)

@@ -44,6 +44,9 @@ def eager_fwd():
         c = E.render_pass(rays, bg, z, None, "relu", nerfs[0], embs, None, None, False, False, False, None)
         z2 = rendering.resample_merge(z, c["weights"], Mi)
         E.render_pass(rays, bg, z2, None, "relu", nerfs[1], embs, None, None, False, False, False, None)
+if os.environ.get("MF_TRAIN_FWD"):              # e.g. MF_TRAIN_FWD=bf16x3: the opt-in three-product training forward
+    from moco_flow_amd import rendering as _r
+    _r.set_train_forward_precision(os.environ["MF_TRAIN_FWD"])
 if os.environ.get("MF_ONLY") in ("hipbwd", "step"):      # profiling: only the shipped training path
     print(f"  HIP forward + HIP dX chain + dW GEMMs : {timeit(fwd_bwd):8.2f} ms")
     sys.exit(0)
