@@ -742,7 +742,9 @@ def run_config(name, a, ctx, steps, warmup, main):
     #                    clock of that run: busy x GHz / 2.4 / (issued / algorithmic MFMAs) = the fraction)
     rp = {}
     if prof.get("rocprof_avg_us"):
-        rp = {"frac_rocprof_avg": flops_launch / (prof["rocprof_avg_us"] * 1e-6) / 1e12 / peak, "rocprof_avg_us": prof["rocprof_avg_us"],
+        # (with a fine pass the trace's average runs over coarse AND fine dispatches of the same kernel, one of each per step:
+        #  the step's algorithmic FLOP over launches x average)
+        rp = {"frac_rocprof_avg": flops_step / (launches * prof["rocprof_avg_us"] * 1e-6) / 1e12 / peak, "rocprof_avg_us": prof["rocprof_avg_us"],
               "mfma_busy": prof.get("mfma_busy"), "ghz": prof.get("ghz"), "rocprof_source": prof.get("profile")}
     res = {
         "value": value, "ms_per_step": elapsed / steps * 1e3, "dtype": cfg["precision"],

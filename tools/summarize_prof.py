@@ -92,6 +92,41 @@ for sub in ("pmc_fetch", "pmc_write"):
 if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
     entry = {"bytes_per_launch": (2 * vals["FETCH_SIZE"] + vals["WRITE_SIZE"]) * 1024,
              "fetch_kib_raw": vals["FETCH_SIZE"], "write_kib": vals["WRITE_SIZE"], "kernel": dom}
+    # round 5: what bench.py needs for roofline.frac_rocprof_avg / mfma_busy / ghz -- the kernel-trace average of the dominant
+    # kernel and, from the pmc_mfma pass, MFMA busy (SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8)) and the
+    # effective clock of THAT pass (cycles per XCD / its own average duration)
+    if dom and dur.get(dom):
+        d = dur[dom]
+        entry["rocprof_avg_us"] = sum(d) / len(d) / 1e3
+        entry["rocprof_min_us"] = min(d) / 1e3
+        entry["dispatches"] = len(d)
+    acc, pdur = defaultdict(list), []
+    for r in rows("pmc_mfma/**/*counter_collection.csv"):
+        if r["Kernel_Name"] == dom:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    for r in rows("pmc_mfma/**/*kernel_trace.csv"):
+        if r["Kernel_Name"] == dom:
+            pdur.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    if acc.get("GRBM_GUI_ACTIVE") and acc.get("SQ_VALU_MFMA_BUSY_CYCLES"):
+        cyc = sum(acc["GRBM_GUI_ACTIVE"]) / len(acc["GRBM_GUI_ACTIVE"]) / 8
+        entry["mfma_busy"] = sum(acc["SQ_VALU_MFMA_BUSY_CYCLES"]) / len(acc["SQ_VALU_MFMA_BUSY_CYCLES"]) / (1024 * cyc)
+        entry["cycles_per_xcd"] = cyc
+        if pdur:
+            entry["ghz"] = cyc / (sum(pdur) / len(pdur))
     with open(os.path.join(out, "traffic_entry.json"), "w") as fh:
         json.dump(entry, fh)
     print("\ntraffic entry:", json.dumps(entry))
+    # --merge KEY TAG: profiles/traffic.json[KEY] <- this entry (+ its source), profiles/<TAG>_summary.txt is this output's name
+    if "--merge" in sys.argv:
+        key, tag = sys.argv[sys.argv.index("--merge") + 1], sys.argv[sys.argv.index("--merge") + 2]
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        path = os.path.join(root, "profiles", "traffic.json")
+        try:
+            allt = json.load(open(path))
+        except (OSError, ValueError):
+            allt = {}
+        entry["profile"] = f"profiles/{tag}_summary.txt"
+        entry["source"] = (f"profiles/{tag}_summary.txt (rocprofv3 --kernel-trace --stats + --pmc passes of `bench.py --config {key}`; FETCH x2 per "
+                           f"MI355X_MICROARCH.md; median over the dispatches)")
+        allt[key] = entry
+        json.dump(allt, open(path, "w"), indent=1)
