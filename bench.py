@@ -751,7 +751,10 @@ def run_config(name, a, ctx, steps, warmup, main):
         "config": {"workload": cfg["what"] + f" [{cfg['precision']}]", "rays_per_gpu": n,
                    "samples_per_ray": spr, "global_rays": n * world,
                    "sharding": f"rays{world}" if world > 1 else "none",
-                   "loss_allreduce": bool(reducer is not None and world > 1)},
+                   "loss_allreduce": bool(reducer is not None and world > 1),
+                   #  the C2 main line carries no loss path and no collective at any N -- its 1 -> N curve is N
+                   # independent launches by design; the configs that name a collective (C4, C5) are the legs
+                   "main_has_collective": bool(reducer is not None and world > 1)},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "peak_note": PEAK_NOTE[cfg["precision"]],
                      "unit": "TFLOP/s", "frac": achieved / peak,
                      "frac_step": flops_step / (elapsed / steps) / 1e12 / peak, **rp,

@@ -62,7 +62,10 @@ def nof_backward_hip(m, emb_desc, P, pts, acts, stride, g_out, gpre, g_pts):
     """One NoF evaluation's backward launch: mf_nof_backward3 (three bf16 products, set_dx_precision("bf16x3"), the default)
     or mf_nof_backward (exact-fp32 MFMA).  Same arguments, same outputs (gpre rows + the point gradient)."""
     dev = pts.device
-    x3 = DX_PRECISION == "bf16x3" and stride % 4 == 0 and acts.data_ptr() % 16 == 0 and gpre.data_ptr() % 16 == 0
+    # (the three-product chain is built for the full 33 + 33 input block, mf_nofgrad_bf16.hip nof_bwd3_shape; anything else, and
+    #  misaligned dumps, take the exact-fp32 kernel)
+    x3 = (DX_PRECISION == "bf16x3" and stride % 4 == 0 and acts.data_ptr() % 16 == 0 and gpre.data_ptr() % 16 == 0
+          and m.in_channels_xyz + m.extra_feat_dim >= 64)
     desc, buf = m.packed_bwd3() if x3 else m.packed_bwd()
     fn, what = (L.lib().mf_nof_backward3, "mf_nof_backward3") if x3 else (L.lib().mf_nof_backward, "mf_nof_backward")
     with torch.cuda.device(dev):

@@ -37,7 +37,13 @@ __device__ inline double dpp_f64(double v) {
   const unsigned hi = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(unsigned)(b >> 32), CTRL, ROW_MASK, 0xf, false);
   return __builtin_bit_cast(double, (unsigned long long)lo | ((unsigned long long)hi << 32));
 }
+// (row_bcast:15 / :31 exist on the GFX9 family only -- gfx90a / gfx942 / gfx950; this library is built for gfx950 alone, but the
+//  Makefile's ARCH is overridable, so any other target takes the xor-shuffle tree: the sums are float64, the order is free)
 __device__ inline double wave_sum_d(double v) {
+#if !(defined(__gfx950__) || defined(__gfx942__) || defined(__gfx90a__)) && defined(__HIP_DEVICE_COMPILE__)
+  for (int m = 1; m < 64; m <<= 1) v += __shfl_xor(v, m, 64);
+  return v;
+#endif
   v += dpp_f64<0x111, 0xf>(v);                   // row_shr:1, 2, 4, 8 -- lane 15 of every row holds the row's sum
   v += dpp_f64<0x112, 0xf>(v);
   v += dpp_f64<0x114, 0xf>(v);
@@ -88,7 +94,7 @@ __global__ __launch_bounds__(kLossThreads) void loss_partials_kernel(LossParams 
 }
 
 // One workgroup of kLossBlocks threads: thread b holds block b's 12 partials (independent loads), then a fixed tree --
-// xor-shuffles inside a wave, the waves' sums in wave order -- so the result is the same in every run.  (Twelve
+// wave_sum_d (DPP row shifts / broadcasts) inside a wave, the waves' sums in wave order -- so the result is the same in every run.  (Twelve
 // threads walking the blocks one dependent load at a time took 24 us, longer than the partials kernel itself.)
 __global__ __launch_bounds__(kLossBlocks) void loss_finish_kernel(LossParams p, int n_blocks) {
   __shared__ double tot[kLossSlots];

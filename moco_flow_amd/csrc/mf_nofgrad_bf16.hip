@@ -362,6 +362,9 @@ using namespace mf;
 static bool nof_bwd3_shape(const mf_nof_desc* d, int& skip) {
   NetLayout F;
   if (!d || !nof_layout(*d, F, 0) || d->D < 2) return false;
+  // ONE condition for the size query, the packer and the launch: the transposed embedded-input tiles are built for the
+  // full 33 + 33 input block (64 packed columns); narrower blocks take the fp32 kernel (autograd.nof_backward_hip falls back)
+  if (d->in_channels_xyz + d->extra_feat_dim < 64) return false;
   skip = -1;
   for (int l = 1; l < d->D; ++l)
     if ((d->skip_mask >> l) & 1u) {

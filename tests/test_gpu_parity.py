@@ -426,7 +426,9 @@ def _check_grads_vs_float64(nets, want32, want64, skip=lambda k: False, label=""
             noise_l2, noise_mr = max(_l2rel(w32, w64), net_l2), max(relerr(w32, w64), net_mr)
             e_l2, e_mr32 = _l2rel(p.grad, w64), relerr(p.grad, w32)
             worst, floor = max(worst, (e_l2, key)), max(floor, (noise_l2, key))
-            assert e_l2 <= max(TOL, 3 * noise_l2), (key, e_l2, noise_l2)
+            # (NeRF-only passes, fp32_bar given: the multiplier is capped -- ADVICE r4 -- 3 x a 7.6e-3 first-layer floor would let
+            #  a 2e-2 error through; the MoCo cases' floors reach 100 % on some tensors and cannot be capped)
+            assert e_l2 <= max(TOL, 3 * noise_l2 if fp32_bar is None else min(3 * noise_l2, 5e-3)), (key, e_l2, noise_l2)
             # max-rel guard against a wrong element.  Its floor is 2e-3, not 1e-4: ONE ReLU unit whose pre-activation rounds to the
             # other side of zero between two fp32 evaluation orders moves a weight-gradient row of the layers in front of it by
             # that sample's whole contribution -- a discrete event (measured 1.4e-4 .. 3.8e-4 of max|dW| at 6144 samples, layers
