@@ -123,6 +123,7 @@ struct NofFwdParams {
   int xyz_cols, in_cols;     // in_channels_xyz, in_channels_xyz + extra_feat_dim: the columns an input row has
 };
 
+template <int NK>
 __global__ __launch_bounds__(kThreads, 2) void nof_forward_kernel(NofFwdParams p) {
   const LaneId id;
   NetDev net = p.net;
@@ -149,7 +150,7 @@ __global__ __launch_bounds__(kThreads, 2) void nof_forward_kernel(NofFwdParams p
     }
     const float xyz[3] = {p.xyz[bb * 3 + 0], p.xyz[bb * 3 + 1], p.xyz[bb * 3 + 2]};
     float o[3];
-    nof_eval<>(net, emb, xyz, st, carry, id, follow_of(net), o);
+    nof_eval<false, NK>(net, emb, xyz, st, carry, id, follow_of(net), o);
     if (valid && id.g == 0) {
       p.out[b * 3 + 0] = o[0];
       p.out[b * 3 + 1] = o[1];
@@ -305,7 +306,7 @@ extern "C" int32_t mf_nof_forward(const mf_nof_desc* d, const void* packed, cons
                                   const float* xyz, int64_t B, float* out, void* stream) {
   if (!d || !packed || (B > 0 && (!inputs || !xyz || !out))) return fail(MF_E_INVALID, "mf_nof_forward: null argument");
   NofFwdParams p{};
-  if (!nof_layout(*d, p.net.L)) return fail(MF_E_UNSUPPORTED, "mf_nof_forward: unsupported NoF configuration");
+  if (!nof_layout(*d, p.net.L, 0, true)) return fail(MF_E_UNSUPPORTED, "mf_nof_forward: unsupported NoF configuration");
   if (B == 0) return MF_OK;
   p.net.packed = static_cast<const char*>(packed);
   p.net.res_lds = 0;
@@ -314,11 +315,12 @@ extern "C" int32_t mf_nof_forward(const mf_nof_desc* d, const void* packed, cons
   p.ring_off = (uint32_t)p.net.L.res_bytes;
   p.buf_bytes = (uint32_t)p.net.L.max_groups * kGroupBytes;
   const size_t lds = p.ring_off + 3 * (size_t)p.buf_bytes;
-  if (hipFuncSetAttribute(reinterpret_cast<const void*>(nof_forward_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+  void (*kern)(NofFwdParams) = p.net.L.NK == 16 ? nof_forward_kernel<16> : nof_forward_kernel<8>;     // W = 256: the bare NoF() default
+  if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(MF_E_LAUNCH, "mf_nof_forward: cannot reserve %zu bytes of LDS", lds);
   const long long ntiles = (B + kTile - 1) / kTile;
   const int grid = (int)(ntiles < device_cus() ? ntiles : device_cus());
-  hipLaunchKernelGGL(nof_forward_kernel, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(kThreads), lds, static_cast<hipStream_t>(stream), p);
   return check_launch("mf_nof_forward");
 }
 

@@ -62,11 +62,14 @@ inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L, int bf16 = 0) {
   return true;
 }
 
-inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0) {
+// wide_ok: W = 256 too (fp32 only) -- the reference's bare `NoF()` (models/nof.py:7-15: D = 8, W = 256, skips = [4]); built for the
+// module-level forward alone (mf_nof_forward and its packer): the fused passes keep three networks' resident blocks beside the ring
+// and have no room for 256-wide NoFs, every other entry point keeps rejecting them
+inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0, bool wide_ok = false) {
   L = NetLayout{};
   const bool x3 = bf16 == MF_PREC_BF16X3;
   L.bf16 = bf16 ? 1 : 0;
-  if (d.W != 128) return false;
+  if (d.W != 128 && !(wide_ok && !bf16 && d.W == 256)) return false;
   if (d.D < 2 || d.D > MF_MAX_LAYERS) return false;
   // slots for 3 x <= 5 xyz frequencies (33 features) and 1 x <= 16 index frequencies (33); narrower blocks leave the upper
   // features without a column (models/nof.py:7-15: in_channels_xyz = 33, extra_feat_dim = 0 by default)

@@ -182,11 +182,12 @@ MF_D void quat_transform(const float (&T)[9], const float (&xyz)[3], float (&out
 // `masks` (ABI v15, uniform): the row has room behind T for the layers' ReLU BIT rows -- 4 words per layer at float offset
 // D W + 16 (trunk_layer's mask_row: byte 4 t + g = this lane's eight outputs of panel t) -- what mf_nof_backward3 reads
 // instead of the 512 bytes of activations per layer.
-template <bool DUMP = false>
+// NK = W / 16: 8 everywhere but the module-level forward of the reference's bare NoF() (W = 256: NK = 16, no dump).
+template <bool DUMP = false, int NK = 8>
 MF_D void nof_eval(const NetDev& net, const float (&emb)[kStepsNofIn], const float (&xyz)[3], Stream& st,
                    CarryT<kPD>& carry, const LaneId& id, const NextLayer& follow, float (&out)[3],
                    float* drow = nullptr, bool masks = false) {
-  constexpr int NK = 8;
+  static_assert(!DUMP || NK == 8, "the dump layout (bit rows: four words per layer) is the 128-wide one");
   f32x4 act[NK];
 #pragma unroll
   for (int t = 0; t < NK; ++t)

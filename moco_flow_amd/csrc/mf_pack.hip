@@ -172,7 +172,7 @@ extern "C" int64_t mf_nerf_packed_bytes_p(const mf_nerf_desc* d, int32_t precisi
 
 extern "C" int64_t mf_nof_packed_bytes_p(const mf_nof_desc* d, int32_t precision) {
   NetLayout L;
-  if (!d || (precision < MF_PREC_F32 || precision > MF_PREC_BF16X3) || !nof_layout(*d, L, precision)) { fail(MF_E_UNSUPPORTED, "mf_nof_packed_bytes: unsupported NoF configuration"); return 0; }
+  if (!d || (precision < MF_PREC_F32 || precision > MF_PREC_BF16X3) || !nof_layout(*d, L, precision, precision == MF_PREC_F32)) { fail(MF_E_UNSUPPORTED, "mf_nof_packed_bytes: unsupported NoF configuration"); return 0; }
   return L.res_bytes + L.panel_bytes + L.ind_bytes;
 }
 
@@ -254,7 +254,7 @@ extern "C" int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* 
   NetLayout L;
   if (!d || !packed) return fail(MF_E_INVALID, "mf_nof_pack: null argument");
   if (precision < MF_PREC_F32 || precision > MF_PREC_BF16X3) return fail(MF_E_INVALID, "mf_nof_pack: precision %d", precision);
-  if (!nof_layout(*d, L, precision)) return fail(MF_E_UNSUPPORTED, "mf_nof_pack: unsupported NoF configuration "
+  if (!nof_layout(*d, L, precision, precision == MF_PREC_F32)) return fail(MF_E_UNSUPPORTED, "mf_nof_pack: unsupported NoF configuration "
                                       "(W=%d D=%d in_channels_xyz=%d extra_feat_dim=%d)", d->W, d->D,
                                       d->in_channels_xyz, d->extra_feat_dim);
   PackJob job{};

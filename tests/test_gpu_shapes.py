@@ -436,6 +436,21 @@ def test_reference_constructor_defaults(M, R):
     print(f"NoF(D=4, W=128) defaults, module call: max-rel {e:.2e}")
     assert e <= TOL
 
+    # the reference's BARE constructor default (models/nof.py:7-15): D = 8, W = 256, skips = [4], 33 input columns, flow head -- the
+    # module-level forward (nof_forward_kernel<16>, round 5); the fused passes and the HIP backward stay at W = 128 and say so
+    nof0 = M.NoF()
+    assert (nof0.D, nof0.W, nof0.in_channels_xyz, nof0.skips, nof0.extra_feat_type, nof0.extra_feat_dim, nof0.use_quat) == (8, 256, 33, [4], "ind", 0, False)
+    nof0 = nof0.cuda()
+    onof0 = R.NoF(state=_twin_state(nof0))
+    with torch.no_grad():
+        e = relerr(nof0(inp.cuda(), pts.cuda()), onof0(inp, pts))
+    print(f"NoF() bare defaults (D=8, W=256), module call: max-rel {e:.2e}")
+    assert e <= TOL
+    with pytest.raises((NotImplementedError, RuntimeError)):                    # a render pass with it: refused loudly
+        M.render_rays(rays.cuda(), bg.cuda(), embs, [nerf], nof_embeddings=[M.Embedding(3, 5), M.Embedding(1, 16)], nof_models=[nof0], **kw)
+    with pytest.raises(NotImplementedError):                                    # gradients of the module call: not built at this width
+        nof0(inp.cuda(), pts.cuda())
+
     # narrower NoF input blocks through the consensus chains, every arithmetic
     nofs = [M.NoF(4, 128, 21, [2], "ind", 17, True).cuda() for _ in range(2)]
     with torch.no_grad():
