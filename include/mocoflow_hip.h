@@ -58,14 +58,14 @@ enum { MF_MAX_FREQS = 16, MF_MAX_LAYERS = 16 };
  * activations rounded to bf16 (RNE), fp32 accumulate (v_mfma_f32_32x32x16_bf16, 32 samples per wave); the
  * embedded-input k-ranges and the NoF head use a two-term bf16 split (16 mantissa bits); biases, the NeRF
  * heads and the composite stay fp32 (BASELINE configs C3-C5).
- * BF16X3 (ABI v12; NoF in three-term operands since v15): the fp32 CONTRACT on the bf16 pipe (1e-4 max-rel on every per-ray
+ * BF16X3 (ABI v12; NoF in three-term bf16 operands in v15, in IEEE-half pairs since v16): the fp32 CONTRACT on the bf16 pipe (1e-4 max-rel on every per-ray
  * output, measured <= 4.6e-5 on the reference-generated golden vectors and <= 3.1e-5 through the MoCo chains at 4096 rays on two
  * weight draws).  The NeRF's matrix products as a two-term bf16 split of activations AND weights (hi + lo, 16 mantissa bits
- * each), three products hi*hi + hi*lo + lo*hi; the NoFs' -- whose output point feeds sin(512 x) -- as a three-term split (hi +
- * mid + lo, 24 bits), six products; fp32 accumulation; sigma / rgb heads as fp32 dot products on the fp32 accumulators; the
- * NoF's image index an exact fp32 per-ray bias.  Three / six bf16 matrix instructions per product where F32 costs sixteen:
- * 0.35-0.4 of F32's time.  Own packed layout (every k-step a (hi, lo) group pair, the NoF's a (hi, mid, lo) triple).  Render passes
- * (with the NeRF activation dump of the training forward when no NoF is involved) and mf_points_sigma_p (scalar
+ * each), three products hi*hi + hi*lo + lo*hi; the NoFs' -- whose output point feeds sin(512 x) -- as IEEE-half (hi, lo) pairs of
+ * 2^5 x the value (22 significand bits), the same three products on v_mfma_f32_32x32x16_f16; fp32 accumulation; sigma / rgb heads as fp32 dot products on the fp32 accumulators; the
+ * NoF's image index an exact fp32 per-ray bias.  Three matrix instructions per product where F32 costs sixteen:
+ * 0.33-0.4 of F32's time.  Own packed layout (every k-step a (hi, lo) group pair: bf16 in the NeRF, halves in the NoF).  Render passes
+ * (with the activation dumps of the training forward, v16: under NoF too) and mf_points_sigma_p (scalar
  * image index or no NoF). */
 enum { MF_PREC_F32 = 0, MF_PREC_BF16 = 1, MF_PREC_BF16X3 = 2 };
 

@@ -23,13 +23,13 @@ from . import autograd as A
 # accumulate (BASELINE configs C3-C5), the NoF's xyz block as a two-term bf16 split (16 mantissa
 # bits), its image-index block as an exact fp32 per-ray bias, heads and composite in fp32;
 # "bf16x3" = the fp32 contract on the bf16 pipe (include/mocoflow_hip.h, MF_PREC_BF16X3: the NeRF's matrix products as three
-# bf16 products of (hi, lo) operand pairs, the NoFs' as six of (hi, mid, lo) triples, fp32 accumulation, heads on the fp32
+# bf16 products of (hi, lo) operand pairs, the NoFs' as three of IEEE-half (hi, lo) pairs, fp32 accumulation, heads on the fp32
 # accumulators: 1e-4 max-rel on every per-ray output -- <= 5e-5 on the golden vectors, <= 3.1e-5 through the MoCo chains at
 # 4096 rays -- at 0.35-0.4 of the fp32 kernels' time).
 # The reference's render_rays signature has no such knob, so it is a module setting.
 PRECISION = "f32"
-# Arithmetic of the TRAINING forward (a pass that records gradients) when no NoF is involved (stage 1: the canonical
-# NeRF alone): "f32" = the reference's; "bf16x3" = the three-product kernels writing the same activation dump (forward
+# Arithmetic of the TRAINING forward (a pass that records gradients; round 5: passes with NoF too):
+# "f32" = the reference's; "bf16x3" = the three-product kernels writing the same activation dump (forward
 # values and dumped activations to ~1e-5; the dX chain on them stays fp32, the weight gradients follow set_wgrad_precision).
 TRAIN_FORWARD_PRECISION = "f32"
 
