@@ -428,7 +428,9 @@ def _check_grads_vs_float64(nets, want32, want64, skip=lambda k: False, label=""
             worst, floor = max(worst, (e_l2, key)), max(floor, (noise_l2, key))
             # (NeRF-only passes, fp32_bar given: the multiplier is capped -- ADVICE r4 -- 3 x a 7.6e-3 first-layer floor would let
             #  a 2e-2 error through; the MoCo cases' floors reach 100 % on some tensors and cannot be capped)
-            assert e_l2 <= max(TOL, 3 * noise_l2 if fp32_bar is None else min(3 * noise_l2, 5e-3)), (key, e_l2, noise_l2)
+            # (HIP shares the fp32 oracle's ReLU masks there and so sits AT the fp32 oracle's own distance from the truth: the cap
+            #  cannot go under 1.5 x that distance; the fixed fp32_bar below is what catches a mis-scaled gradient)
+            assert e_l2 <= max(TOL, 3 * noise_l2 if fp32_bar is None else min(3 * noise_l2, max(1.5 * noise_l2, 5e-3))), (key, e_l2, noise_l2)
             # max-rel guard against a wrong element.  Its floor is 2e-3, not 1e-4: ONE ReLU unit whose pre-activation rounds to the
             # other side of zero between two fp32 evaluation orders moves a weight-gradient row of the layers in front of it by
             # that sample's whole contribution -- a discrete event (measured 1.4e-4 .. 3.8e-4 of max|dW| at 6144 samples, layers
@@ -570,6 +572,26 @@ def test_train_forward_bf16x3_moco(M, R, name):
             assert abs(a - b) <= 1e-4 * abs(b), (k, a, b)
     checked = _check_grads_vs_float64(nets, want32, want64, label=name + " (bf16x3 training forward, MoCo)")
     assert checked >= 20
+    # ragged ends: 7 rays x 64 samples = 3.5 tiles of 128 -- whole waves of the last tile without a sample issue no dump stores
+    # (StreamT::sync's keep_ok), the NoF planes are not whole 128-row blocks (per-node weight gradients instead of the sinks)
+    rays7, bg7 = case_inputs(c, seed, n=7)
+    with torch.no_grad():
+        embs_o, nerfs_o, kw_o = build_case(R, c, seed)
+        want7 = R.render_rays(rays7, bg7, embs_o, nerfs_o, **kw_o)
+    outs = []
+    try:
+        rendering.set_train_forward_precision("bf16x3")
+        for _ in range(2):
+            for m in nets:
+                m.zero_grad(set_to_none=True)
+            r7 = M.render_rays(rays7.cuda(), bg7.cuda(), embs, nerfs, **kw)
+            loss_fn(r7, gt[:7]).backward()
+            outs.append([r7["rgb_coarse"].detach().clone()] + [q.grad.clone() for m in nets for q in m.parameters() if q.grad is not None])
+    finally:
+        rendering.set_train_forward_precision("f32")
+    assert all(torch.equal(a, b) for a, b in zip(*outs)) and all(bool(torch.isfinite(t).all()) for t in outs[0])
+    for k in ("rgb_coarse", "depth_coarse", "opacity_coarse"):
+        assert relerr(r7[k], want7[k]) <= TOL, (k, relerr(r7[k], want7[k]))
 
 
 @pytest.mark.parametrize("name", GRAD_CASES)

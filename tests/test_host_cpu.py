@@ -23,7 +23,7 @@ def test_library_exports_every_declared_symbol():
     for n in names:
         assert hasattr(lib, n), f"{n} declared in the header but not exported"
         assert n in L.SYMBOLS, f"{n} has no ctypes prototype"
-    assert lib.mf_version() == L.MF_ABI_VERSION == 15
+    assert lib.mf_version() == L.MF_ABI_VERSION == 16
     # argument validation is host-side and must not need a GPU
     d = L.mf_nerf_desc()
     d.D, d.W, d.in_channels_xyz, d.skip_mask = 8, 256, 63, 1 << 4
