@@ -16,6 +16,7 @@
 //   * db falls out of the G tile already in LDS (one column per thread).
 #include "mf_host.hpp"
 #include "mf_core.hpp"
+#include <type_traits>
 #include <cstddef>
 #include <cstdlib>
 
@@ -48,21 +49,27 @@ using ShapeH = WgShape<16, 128, 1, 1, 8, 12>;     // NoF head: d T (9 | 3, padde
 // MF_PREC_BF16X3 variants of the large blocks (shape ids 8..): the contraction on v_mfma_f32_32x32x16_bf16 with G and X as
 // (hi, lo) bf16 pairs, three products per 16-sample k-step (wg_segment_x3).  8 waves as (8 / WAVES_C) x WAVES_C, each wave
 // WR x WC tiles of 32 x 32.
-template <int NOUT_, int NIN_, int WR_, int WC_, int WAVES_C_>
+template <int NOUT_, int NIN_, int WR_, int WC_, int WAVES_C_, int KS_ = 1, int SETS_ = 3>
 struct WgShapeX {
-  static constexpr int NOUT = NOUT_, NIN = NIN_, WR = WR_, WC = WC_, WAVES_C = WAVES_C_;
-  static constexpr int PART_BYTES = (NOUT + NIN) * 2 * 16;          // one of (hi | lo): both sample octets of every feature
-  static constexpr int BUF_BYTES = 2 * PART_BYTES;                  // a stage's fragments: hi + lo
+  static constexpr int NOUT = NOUT_, NIN = NIN_, WR = WR_, WC = WC_, WAVES_C = WAVES_C_, KS = KS_, SETS = SETS_;   // KS: k-steps (of 16 samples) per step
+  static constexpr int KSTEP_BYTES = (NOUT + NIN) * 2 * 16;         // one k-step of one of (hi | lo): both sample octets of every feature
+  static constexpr int PART_BYTES = KS * KSTEP_BYTES;
+  static constexpr int BUF_BYTES = 2 * PART_BYTES;                  // a step's fragments: hi + lo
   static constexpr int OUT_FLOATS = NOUT * NIN + NOUT;
   static_assert((8 / WAVES_C) * WR * 32 == NOUT && WAVES_C * WC * 32 == NIN, "wave tiling must cover the block");
-  static_assert(NOUT + NIN <= kThreads && NOUT % 64 == 0 && NIN % 64 == 0, "one conversion unit per thread");
+  static_assert((NOUT + NIN) * KS <= kThreads && NOUT % 128 == 0 && NIN % 128 == 0, "one conversion unit per thread, a wave inside one octet");
+  static_assert((KS * WR) % 2 == 0 && 4 % (KS * WR - KS * WR / 2) == 0, "the conversion pieces are dealt to the groups of the second half");
 };
 using ShapeAX = WgShapeX<256, 256, 4, 2, 4>;      // hidden x hidden
 using ShapeCX = WgShapeX<128, 256, 2, 2, 4>;      // extra_encoding x final
-// (a 128 x 128 variant, WgShapeX<128, 128, 2, 1, 4>, for the NoF's hidden blocks: three such items at 1.97 M evaluations 2.02 ->
-//  1.86 ms, the NoF's six items 3.51 -> 3.40 ms as two launches (round 4, same box) -- those items already run against HBM
-//  in fp32 (3.0 of the ~4 TB/s this chip streams to a reader); not kept)
+// The NoF's blocks (128 x 128, 128 x 80, 12 x 128) as ONE 128 x 128 shape with the operands' valid widths in the item (the
+// columns beyond them are zero: their lanes load nothing), two k-steps per step so that all 512 threads own a conversion unit
+// (with one, half of the waves load nothing and 32 KiB per CU in flight do not cover the HBM's latency: round 4's +3 %).
+using ShapeFX = WgShapeX<128, 128, 2, 1, 4, 2>;
+using ShapeBX = WgShapeX<256, 128, 4, 1, 4>;      // hidden x embedded xyz (64 of the 128 columns valid; two waves without a unit)
 constexpr int kWgShapeX0 = 8;                     // first x3 shape id
+constexpr uint32_t kWgX3Dump = 3 * ShapeAX::BUF_BYTES;   // LDS: 4 KiB behind the three fragment buffers, written by waves without a conversion unit
+static_assert(ShapeCX::BUF_BYTES <= ShapeAX::BUF_BYTES && ShapeFX::BUF_BYTES <= ShapeAX::BUF_BYTES && ShapeBX::BUF_BYTES <= ShapeAX::BUF_BYTES, "the dump area lies behind the largest shape's buffers");
 
 // cost of one stage of each block shape in CU cycles, MEASURED (tools/bench_wgrad.py: each shape alone at 1.3 M samples,
 // launch overhead subtracted).  Only the ratios matter: they decide where the linearised (item, stage) space is cut, and
@@ -79,8 +86,10 @@ MF_HD int wg_stage_cost(int shape) {
     case 5: return 3440;
     case 6: return 2690;
     case 7: return 2560;
-    case 8: return 5660;      // x3 variants (MF_WGRAD=bf16x3 tools/bench_wgrad.py; planned apart from the fp32 shapes)
-    default: return 4300;
+    case 8: return 4420;      // x3 variants (MF_WGRAD=bf16x3 tools/bench_wgrad.py, round 5; planned apart from the fp32 shapes)
+    case 9: return 3260;
+    case 10: return 1750;     // 128 x 128 at full width (wg_item_dims prices the narrower items)
+    default: return 2870;     // 256 x 128 with 64 valid X columns, priced BESIDE 256 x 256 workgroups (alone: 2 350 -- the chip's clock follows the others' matrix load)
   }
 }
 MF_HD int wg_out_floats(int shape) {
@@ -94,7 +103,9 @@ MF_HD int wg_out_floats(int shape) {
     case 6: return ShapeG::OUT_FLOATS;
     case 7: return ShapeH::OUT_FLOATS;
     case 8: return ShapeAX::OUT_FLOATS;
-    default: return ShapeCX::OUT_FLOATS;
+    case 9: return ShapeCX::OUT_FLOATS;
+    case 10: return ShapeFX::OUT_FLOATS;
+    default: return ShapeBX::OUT_FLOATS;
   }
 }
 
@@ -102,6 +113,9 @@ struct WgItem {
   const float* G; long long g_stride;
   const float* X; long long x_stride;
   int shape, want_bias;
+  int cost;               // cycles per 16-sample stage (wg_stage_cost of the shape; the x3 128 x 128 shape: by the operands' widths)
+  int gw, xw;             // x3 shapes: valid columns of G / X (even; = the shape's NOUT / NIN unless the item is narrower)
+  int out_rows, out_cols; // layout of dW: (out_rows, out_cols), the top-left corner of the shape's (NOUT, NIN) block
   long long cost0;        // start of this item in the linearised cost space
   long long part_off;     // float offset of its first partial in the scratch buffer
   int slot0, n_slots;     // first workgroup touching it, number of partials
@@ -297,12 +311,23 @@ MF_D void wg_segment(const WgItem& it, long long sb, long long se, long long P, 
 // The fp32 matrix pipe does 16 samples x 256 x 256 in 9 640 cycles per CU; three bf16 products of (hi, lo) pairs carry 16
 // mantissa bits per operand (the dropped lo*lo term is 2^-16 relative, the sum over samples accumulates in fp32 like the
 // fp32 MFMA's) at a fifth of the matrix time -- the launch then runs against the HBM reads of its two operands.
-// Stage = 16 samples = one k-step.  Thread t owns one conversion unit per stage -- two adjacent features x one sample
-// octet of G (t < NOUT) or of X (t - NOUT < NIN): eight 8-byte loads straight from HBM, issued two stages ahead into a
-// register pair set, (hi, lo) split in registers, four 16-byte LDS writes in the MFMA operand layout
-// [hi | lo][octet][feature][8 bf16] (A = G^T: 32 out-features x 16 samples, B = X: 16 samples x 32 in-features -- both
-// "one feature, eight consecutive samples" per lane).  No raw staging in LDS, no LDS-DMA; two fragment buffers, one
-// barrier per stage.  db: the G units' column sums (fp32) as a by-product of the conversion.
+// Step = KS k-steps of 16 samples.  Thread t owns one conversion unit per step -- two adjacent features x one sample octet of G
+// or of X: eight 8-byte loads straight from HBM into a register set, (hi, lo) split in registers, four 16-byte LDS writes in
+// the MFMA operand layout [hi | lo][k-step][operand][octet][feature][8 bf16] (A = G^T: 32 out-features x 16 samples, B = X:
+// 16 samples x 32 in-features -- both "one feature, eight consecutive samples" per lane).  No raw staging in LDS, no LDS-DMA.
+// db: the G units' column sums (fp32) as a by-product of the conversion.
+//
+// Round 5 -- the pipeline (profiles/r05_wgrad_x3.txt; before: 3.7 TB/s of operand reads, the stage's three phases in a row):
+//   * two register sets: during step s a thread converts the set that holds step s + 2 and re-loads it with step s + 4, two
+//     rows at a time behind the arithmetic that frees them (16 loads in flight per thread at every moment);
+//   * THREE fragment buffers, ONE barrier per step: step s reads buffer s % 3 and writes the fragments of step s + 2 into the
+//     buffer step s - 1 read.  After barrier s every wave has left step s - 1 (its buffer may be overwritten) and has written
+//     step s + 1 (complete one whole step ahead) -- so the barrier may sit anywhere in step s before the wave's own fragment
+//     writes: waves 4-7 take it at the start, waves 0-3 (their SIMD partners) in the middle, and the two waves of a SIMD run
+//     half a step out of phase: one multiplies while the other crosses the barrier, reads its first fragments, writes its
+//     own (with one buffer less and the barrier at the start for all, both waves of every SIMD stalled together: the matrix
+//     pipe idle for 40 % of a step);
+//   * the conversion in four pieces between the MFMA groups of the second half of the step.
 typedef float wg_f2 __attribute__((ext_vector_type(2)));
 typedef __bf16 wg_bf2 __attribute__((ext_vector_type(2)));
 MF_D unsigned wg_pack(float a, float b) {
@@ -313,19 +338,31 @@ typedef float f32x16w __attribute__((ext_vector_type(16)));
 
 template <class S>
 MF_D void wg_segment_x3(const WgItem& it, long long sb, long long se, long long P, float* part, const LaneId& id) {
-  constexpr int WR = S::WR, WC = S::WC;
+  constexpr int WR = S::WR, WC = S::WC, KS = S::KS;
+  constexpr int NG = KS * WR;                        // MFMA groups of a step: (k-step, row tile), WC tiles x 3 products each
   const int tid = threadIdx.x;
   const int lane = id.lane, li = lane & 31, lh = lane >> 5;
   const int wr = id.wave / S::WAVES_C, wc = id.wave % S::WAVES_C;
   const int row0 = wr * WR * 32, col0 = wc * WC * 32;
-  // conversion role of this thread
-  const bool is_g = tid < S::NOUT, is_x = !is_g && tid - S::NOUT < S::NIN;
-  const int ut = is_g ? tid : tid - S::NOUT, nf = is_g ? S::NOUT : S::NIN;
-  const int up = ut % (nf / 2), uh = ut / (nf / 2);                  // feature pair, sample octet
+  // conversion role of this thread.  Everything but the feature pair is derived from the WAVE index (a scalar register):
+  // operand, sample octet, source pointer and stride are wave-uniform (NOUT / 2 and NIN / 2 are multiples of 64), and the
+  // compiler has to SEE that -- derived from threadIdx they were per-lane values to it, every buffer load sat in a
+  // readfirstlane waterfall loop, and behind those loops its counter bookkeeping gave up: `s_waitcnt vmcnt(0)` at the head of
+  // the stage loop, i.e. no load was ever in flight across a stage.
+  const int w64 = id.wave * 64;
+  const bool is_g = w64 < S::NOUT * KS, is_x = !is_g && w64 - S::NOUT * KS < S::NIN * KS;
+  const bool unit = is_g || is_x;
+  const int ub = is_g ? w64 : w64 - S::NOUT * KS, nf = is_g ? S::NOUT : S::NIN;
+  const int uh = ub / (nf / 2), up = ub % (nf / 2) + lane;           // sample octet of the step (uniform), feature pair
   const float* src = is_g ? it.G : it.X;
   const long long stride = is_g ? it.g_stride : it.x_stride;
-  const uint32_t reg0 = is_g ? 0u : (uint32_t)(2 * S::NOUT * 16);    // byte offset of this operand's region inside a part
-  const uint32_t wdst = reg0 + (uint32_t)((uh * nf + 2 * up) * 16);  // [octet][feature] x 16 bytes
+  const int width = is_g ? it.gw : it.xw;                            // valid columns of the operand (even; the rest of the block is zero)
+  const uint32_t reg0 = is_g ? 0u : (uint32_t)(2 * S::NOUT * 16);    // byte offset of this operand's region inside a k-step
+  const uint32_t wdst = (uint32_t)((uh >> 1) * S::KSTEP_BYTES) + reg0 + (uint32_t)(((uh & 1) * nf + 2 * up) * 16);
+  // (no branch around the fragment writes: a wave without a unit -- 128 x 256 has two -- converts the zeros its loads return and
+  //  writes them to a dump area behind the buffers; under a branch the compiler sinks the pieces' arithmetic into it, i.e. behind
+  //  the step's MFMAs, and re-loads into fresh registers it then has to copy -- with a wait for the newest loads)
+  const uint32_t wbase = unit ? wdst : kWgX3Dump + (uint32_t)lane * 32u, wlo = unit ? (uint32_t)S::PART_BYTES : 2048u;
   __syncthreads();                                   // previous segment's readers are done with the buffers
   f32x16w acc[WR][WC];
 #pragma unroll
@@ -335,80 +372,146 @@ MF_D void wg_segment_x3(const WgItem& it, long long sb, long long se, long long 
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   float bs0 = 0.f, bs1 = 0.f;
-  wg_f2 raw[2][8];
-  // Loads through a buffer descriptor: wave-uniform 64-bit base (this wave's octet of the stage: `uh` is the same for a
-  // whole wave, NOUT / 2 and NIN / 2 being multiples of 64) + ONE per-lane 32-bit offset + a scalar row offset -- no
-  // 64-bit address per lane and row -- and `num_records` = the bytes up to sample P, so rows past the last sample read 0.
-  const int voff = up * 8;
+  constexpr int NS = S::SETS;                        // register sets: 8 NS loads of 8 bytes in flight per thread
+  wg_f2 raw[NS][8];
+  // Loads through a buffer descriptor: wave-uniform 64-bit base (this wave's octet of the step) + ONE per-lane 32-bit offset
+  // + a scalar row offset -- no 64-bit address per lane and row -- and `num_records` = the bytes up to sample P (0 past the
+  // segment's last stage), so rows past the end read 0; a lane whose feature pair lies beyond the operand's width carries an
+  // offset no record reaches.
+  const int voff = 2 * up < width ? up * 8 : 0x7ffffff0;
   const long long row_bytes = stride * 4;
-  auto load = [&](wg_f2 (&r)[8], long long st) {
-    const long long s0 = st * kWgStage + 8 * uh;
-    const long long left = (st < se && (is_g || is_x)) ? (P - s0) * row_bytes : 0;
-    const unsigned recs = left <= 0 ? 0u : (left > 0xffffffffLL ? 0xffffffffu : (unsigned)left);
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)(src + s0 * stride), 0, (int)recs, 0x00020000);
+  typedef unsigned wg_u2 __attribute__((ext_vector_type(2)));
+  auto desc = [&](long long step) {                  // step = index of the KS-stage step inside the segment's stage numbering
+    const long long st = sb + step * KS + (uh >> 1);
+    const long long s0 = st * kWgStage + 8 * (uh & 1);
+    const long long left = (st < se && unit) ? (P - s0) * row_bytes : 0;
+    const unsigned recs = left <= 0 ? 0u : (left > 0x7fffffe0LL ? 0x7fffffe0u : (unsigned)left);
+    return __builtin_amdgcn_make_buffer_rsrc((void*)(src + s0 * stride), 0, (int)recs, 0x00020000);
+  };
+  auto load1 = [&](wg_f2& r, const __amdgpu_buffer_rsrc_t& rs, int e) {
+    r = __builtin_bit_cast(wg_f2, (wg_u2)__builtin_amdgcn_raw_buffer_load_b64(rs, voff, (int)(e * row_bytes), 0));
+  };
+  auto load = [&](wg_f2 (&r)[8], long long step) {
+    const __amdgpu_buffer_rsrc_t rs = desc(step);
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      typedef unsigned wg_u2 __attribute__((ext_vector_type(2)));
-      const wg_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, voff, (int)(e * row_bytes), 0);
-      r[e] = __builtin_bit_cast(wg_f2, v);
+    for (int e = 0; e < 8; ++e) load1(r[e], rs, e);
+  };
+  // Conversion in four PIECES (w = sample pair 2w, 2w + 1 of the octet, both features of the unit): ~16 VALU each.
+  auto piece = [&](wg_f2 (&r)[8], int w, u32x4 (&hv)[2], u32x4 (&lv)[2]) {
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      const float a0 = r[2 * w][c], a1 = r[2 * w + 1][c];
+      const unsigned ha = wg_pack(a0, a1);
+      hv[c][w] = ha;
+      lv[c][w] = wg_pack(a0 - __builtin_bit_cast(float, ha << 16), a1 - __builtin_bit_cast(float, ha & 0xffff0000u));
+      if (c == 0) bs0 += a0 + a1; else bs1 += a0 + a1;
+    }
+    // pinned HERE: free-floating arithmetic is placed next to its users (the fragment writes at the end of the step) when the
+    // block is linearised, the re-loads of the rows it reads would then be issued before it -- into other registers, copied back
+    // at the end of the trip behind a wait for the newest loads
+    asm volatile("" : "+v"(hv[0][w]), "+v"(hv[1][w]), "+v"(lv[0][w]), "+v"(lv[1][w]), "+v"(bs0), "+v"(bs1) :: "memory");
+  };
+  auto put = [&](const u32x4 (&hv)[2], const u32x4 (&lv)[2], uint32_t buf) {
+    const uint32_t o = wbase + (unit ? buf : 0u);
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      *reinterpret_cast<u32x4*>(smem + o + 16 * c) = hv[c];
+      *reinterpret_cast<u32x4*>(smem + o + wlo + 16 * c) = lv[c];
     }
   };
-  auto convert = [&](const wg_f2 (&r)[8], uint32_t buf) {
-    if (!(is_g || is_x)) return;
+  // prologue: steps 0 and 1 into buffers 0 and 1, steps 2 .. 1 + NS on their way (set q holds step 2 + q)
+  // (issued in the ORDER the loop keeps them in -- set 0 oldest: the compiler merges the counter state of this block with the
+  //  loop's own at the loop head, and where the two orders differ it waits for the later position of every register)
+  load(raw[0], 0);
+  load(raw[1], 1);
 #pragma unroll
-    for (int c = 0; c < 2; ++c) {                    // the unit's two features, one after the other (8 live registers)
-      u32x4 hv, lv;
+  for (int q = 0; q < 2; ++q) {
+    u32x4 hv[2], lv[2];
 #pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        const float a0 = r[2 * w][c], a1 = r[2 * w + 1][c];
-        const unsigned ha = wg_pack(a0, a1);
-        hv[w] = ha;
-        lv[w] = wg_pack(a0 - __builtin_bit_cast(float, ha << 16), a1 - __builtin_bit_cast(float, ha & 0xffff0000u));
-        if (c == 0) bs0 += a0 + a1; else bs1 += a0 + a1;
-      }
-      *reinterpret_cast<u32x4*>(smem + buf + wdst + 16 * c) = hv;
-      *reinterpret_cast<u32x4*>(smem + buf + S::PART_BYTES + wdst + 16 * c) = lv;
-    }
-  };
-  load(raw[0], sb);
-  load(raw[1], sb + 1);
-  convert(raw[0], 0);
-  load(raw[0], sb + 2);
+    for (int w = 0; w < 4; ++w) piece(raw[q], w, hv, lv);
+    put(hv, lv, q * S::BUF_BYTES);
+    load(raw[q], 2 + q);
+  }
+#pragma unroll
+  for (int q = 2; q < NS; ++q) load(raw[q], 2 + q);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
   // fragment addresses of this lane: A rows row0 + 32 ti + li, B columns col0 + 32 tj + li, octet lh
   const uint32_t aoff = (uint32_t)((lh * S::NOUT + row0 + li) * 16);
   const uint32_t boff = (uint32_t)(2 * S::NOUT * 16 + (lh * S::NIN + col0 + li) * 16);
-  int par = 0;
-  for (long long st = sb; st < se; ++st) {
-    const uint32_t buf = par ? S::BUF_BYTES : 0u, nbuf = par ? 0u : S::BUF_BYTES;
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");         // this thread's fragment writes of stage st
-    __builtin_amdgcn_s_barrier();                               // everybody's; and everybody left buffer nbuf (stage st - 1)
-    asm volatile("" ::: "memory");
-    u32x4 bh[WC], bl[WC];
-#pragma unroll
-    for (int t = 0; t < WC; ++t) {
-      bh[t] = *reinterpret_cast<const u32x4*>(smem + buf + boff + t * 512);
-      bl[t] = *reinterpret_cast<const u32x4*>(smem + buf + S::PART_BYTES + boff + t * 512);
+  const bool late = id.wave < kWaves / 2;
+  uint32_t cur = 0, nxt = 2 * S::BUF_BYTES;          // byte offsets of the buffer this step reads / writes
+  // The step loop, two steps per trip in straight-line code (PAR = the register set of the step): with the parity a run-time
+  // variable the two sets met in one loop body through branches, and the compiler's load counter -- exact in straight-line
+  // code: a piece waits for vmcnt(14), the other fourteen loads stay in flight -- degraded to vmcnt(0) at the merges.
+  auto stage = [&](long long step, auto parc) {
+    constexpr int PAR = decltype(parc)::value;
+    if (!late) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this thread's fragment writes of the step before
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
-    u32x4 ah = *reinterpret_cast<const u32x4*>(smem + buf + aoff), al = *reinterpret_cast<const u32x4*>(smem + buf + S::PART_BYTES + aoff);
-    // the next stage's fragments, then the loads two stages further into the registers just freed
-    if (par) { convert(raw[0], nbuf); load(raw[0], st + 3); }
-    else { convert(raw[1], nbuf); load(raw[1], st + 3); }
+    const uint32_t ab = cur + aoff, bb = cur + boff;
+    u32x4 bh[KS][WC], bl[KS][WC];
 #pragma unroll
-    for (int ti = 0; ti < WR; ++ti) {
-      u32x4 nh = ah, nl = al;
-      if (ti + 1 < WR) {                                        // the next row tile's fragments while this one multiplies
-        nh = *reinterpret_cast<const u32x4*>(smem + buf + aoff + (ti + 1) * 512);
-        nl = *reinterpret_cast<const u32x4*>(smem + buf + S::PART_BYTES + aoff + (ti + 1) * 512);
+    for (int k = 0; k < KS; ++k)
+#pragma unroll
+      for (int t = 0; t < WC; ++t) {
+        bh[k][t] = *reinterpret_cast<const u32x4*>(smem + bb + k * S::KSTEP_BYTES + t * 512);
+        bl[k][t] = *reinterpret_cast<const u32x4*>(smem + bb + S::PART_BYTES + k * S::KSTEP_BYTES + t * 512);
       }
+    u32x4 ah = *reinterpret_cast<const u32x4*>(smem + ab), al = *reinterpret_cast<const u32x4*>(smem + ab + S::PART_BYTES);
+    const __amdgpu_buffer_rsrc_t rs = desc(step + 2 + NS);
+    u32x4 hv[2], lv[2];
+    constexpr int PPG = 4 / (NG - NG / 2);                      // pieces behind each group of the step's second half
 #pragma unroll
-      for (int tj = 0; tj < WC; ++tj) {
-        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[tj]), acc[ti][tj], 0, 0, 0);
-        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl[tj]), acc[ti][tj], 0, 0, 0);
-        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh[tj]), acc[ti][tj], 0, 0, 0);
+    for (int g = 0; g < NG; ++g) {
+      const int k = g / WR, ti = g % WR;
+      if (g == NG / 2 && late) {
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      u32x4 nh = ah, nl = al;
+      if (g + 1 < NG) {                                         // the next group's A fragments while this one multiplies
+        const int kn = (g + 1) / WR, tn = (g + 1) % WR;
+        nh = *reinterpret_cast<const u32x4*>(smem + ab + kn * S::KSTEP_BYTES + tn * 512);
+        nl = *reinterpret_cast<const u32x4*>(smem + ab + S::PART_BYTES + kn * S::KSTEP_BYTES + tn * 512);
+      }
+      // product-major: the three products of one accumulator are a dependent chain, the tiles of the group take turns
+#pragma unroll
+      for (int tj = 0; tj < WC; ++tj)
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bh[k][tj]), acc[ti][tj], 0, 0, 0);
+#pragma unroll
+      for (int tj = 0; tj < WC; ++tj)
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ah), __builtin_bit_cast(bf16x8, bl[k][tj]), acc[ti][tj], 0, 0, 0);
+#pragma unroll
+      for (int tj = 0; tj < WC; ++tj)
+        acc[ti][tj] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, al), __builtin_bit_cast(bf16x8, bh[k][tj]), acc[ti][tj], 0, 0, 0);
+      if (g >= NG / 2) {
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int w = (g - NG / 2) * PPG; w < (g - NG / 2 + 1) * PPG; ++w) {
+          piece(raw[PAR], w, hv, lv);
+          __builtin_amdgcn_sched_barrier(0);                    // (the loads stay BEHIND the arithmetic that frees their registers)
+          load1(raw[PAR][2 * w], rs, 2 * w);
+          load1(raw[PAR][2 * w + 1], rs, 2 * w + 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
       ah = nh; al = nl;
     }
-    par ^= 1;
+    put(hv, lv, nxt);
+    nxt = cur;                                                  // ring of three: the next step writes into the buffer this one read
+    cur = cur == 2 * S::BUF_BYTES ? 0u : cur + S::BUF_BYTES;
+  };
+  // (a segment whose step count is no multiple of NS runs up to NS - 1 steps past its end: `desc` hands out zeros there, the step adds nothing -- and
+  //  the loop stays one basic block)
+  const long long steps = (se - sb + KS - 1) / KS;
+  for (long long q = 0; q < steps; q += NS) {
+    stage(q, std::integral_constant<int, 0>{});
+    stage(q + 1, std::integral_constant<int, 1>{});
+    if constexpr (NS > 2) stage(q + 2, std::integral_constant<int, 2>{});
   }
   // partial result: C/D layout row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31
   // (the lane index is made opaque: hipcc otherwise computes the store addresses in front of the stage loop and carries
@@ -423,14 +526,19 @@ MF_D void wg_segment_x3(const WgItem& it, long long sb, long long se, long long 
 #pragma unroll
       for (int r = 0; r < 16; ++r)
         pl[(32 * ti + (r & 3) + 8 * (r >> 2)) * S::NIN + 32 * tj] = acc[ti][tj][r];
-  // db: the two octets' column sums meet in LDS (the fragment buffers are idle now)
+  // db: the octets' column sums meet in LDS (the fragment buffers are idle now)
   __syncthreads();
   if (is_g) {
     *reinterpret_cast<float*>(smem + (uh * S::NOUT + 2 * up) * 4) = bs0;
     *reinterpret_cast<float*>(smem + (uh * S::NOUT + 2 * up + 1) * 4) = bs1;
   }
   __syncthreads();
-  if (tid < S::NOUT) part[(long long)S::NOUT * S::NIN + tid] = lds_f(tid * 4) + lds_f((S::NOUT + tid) * 4);
+  if (tid < S::NOUT) {
+    float b = 0.f;
+#pragma unroll
+    for (int o = 0; o < 2 * KS; ++o) b += lds_f((o * S::NOUT + tid) * 4);
+    part[(long long)S::NOUT * S::NIN + tid] = b;
+  }
 }
 
 // The item table is read through the kernarg segment pointer (scalar loads of one item at a time): indexing the by-value
@@ -455,7 +563,7 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WgParams p) {
   for (int i = 0; i < p.n_items; ++i) {
     const WgItem it = wg_item(i);
     long long b, e;
-    wg_range(p.total_cost, p.grid, w, it.cost0, wg_stage_cost(it.shape), p.stages, b, e);
+    wg_range(p.total_cost, p.grid, w, it.cost0, it.cost, p.stages, b, e);
     if (b >= e) continue;
     float* part = p.scratch + it.part_off + (long long)(w - it.slot0) * wg_out_floats(it.shape);
     // The lane / wave indices are made opaque per item: everything the shape bodies derive from them (fragment
@@ -478,7 +586,9 @@ __global__ __launch_bounds__(kThreads, 2) void wgrad_kernel(WgParams p) {
     } else {
       switch (it.shape) {
         case kWgShapeX0: wg_segment_x3<ShapeAX>(it, b, e, p.P, part, id); break;
-        default: wg_segment_x3<ShapeCX>(it, b, e, p.P, part, id); break;
+        case kWgShapeX0 + 1: wg_segment_x3<ShapeCX>(it, b, e, p.P, part, id); break;
+        case kWgShapeX0 + 2: wg_segment_x3<ShapeFX>(it, b, e, p.P, part, id); break;
+        default: wg_segment_x3<ShapeBX>(it, b, e, p.P, part, id); break;
       }
     }
   }
@@ -502,7 +612,7 @@ __global__ void wgrad_reduce_kernel(WgParams p) {
   } else {
     for (int k = 0; k < it.n_slots; ++k) {
       long long b, en;    // workgroups whose range of this item is empty (tiny P) wrote nothing
-      wg_range(p.total_cost, p.grid, it.slot0 + k, it.cost0, wg_stage_cost(it.shape), p.stages, b, en);
+      wg_range(p.total_cost, p.grid, it.slot0 + k, it.cost0, it.cost, p.stages, b, en);
       if (b < en) s += src[(long long)k * nf];
     }
   }
@@ -517,16 +627,25 @@ __global__ void wgrad_reduce_kernel(WgParams p) {
     case 6: nout = ShapeG::NOUT; nin = ShapeG::NIN; break;
     case 7: nout = ShapeH::NOUT; nin = ShapeH::NIN; break;
     case 8: nout = ShapeAX::NOUT; nin = ShapeAX::NIN; break;
-    default: nout = ShapeCX::NOUT; nin = ShapeCX::NIN; break;
+    case 9: nout = ShapeCX::NOUT; nin = ShapeCX::NIN; break;
+    case 10: nout = ShapeFX::NOUT; nin = ShapeFX::NIN; break;
+    default: nout = ShapeBX::NOUT; nin = ShapeBX::NIN; break;
   }
-  if (e < nout * nin) it.dW[e] = (float)s;
-  else if (it.db) it.db[e - nout * nin] = (float)s;
+  if (e < nout * nin) {
+    const int r = e / nin, c = e % nin;
+    if (r < it.out_rows && c < it.out_cols) it.dW[r * it.out_cols + c] = (float)s;
+  } else if (it.db && e - nout * nin < it.out_rows) {
+    it.db[e - nout * nin] = (float)s;
+  }
 }
 
 static int shape_of(const mf_wgrad_item& a, int precision) {
   if (precision == MF_PREC_BF16X3) {                 // the large blocks have a three-product variant
     if (a.n_out == 256 && a.n_in == 256) return kWgShapeX0;
     if (a.n_out == 128 && a.n_in == 256) return kWgShapeX0 + 1;
+    if ((a.n_out == 128 && (a.n_in == 128 || a.n_in == 80)) || (a.n_out == 12 && a.n_in == 128)) return kWgShapeX0 + 2;   // the NoF's
+    if (a.n_out == 128 && a.n_in == 32) return kWgShapeX0 + 2;
+    if (a.n_out == 256 && a.n_in == 64) return kWgShapeX0 + 3;
   }
   if (a.n_out == 256 && a.n_in == 256) return 0;
   if (a.n_out == 256 && a.n_in == 64) return 1;
@@ -537,6 +656,34 @@ static int shape_of(const mf_wgrad_item& a, int precision) {
   if (a.n_out == 128 && a.n_in == 80) return 6;
   if (a.n_out == 12 && a.n_in == 128) return 7;
   return -1;
+}
+
+// widths, output layout and stage cost of an item: the fp32 shapes and the two large x3 shapes are their block; the x3 128 x 128
+// shape takes the NoF's narrower blocks too (output layout = the fp32 shape's of the same block: 128 x 80, 16 x 128)
+static void wg_item_dims(const mf_wgrad_item& a, int sh, WgItem& it) {
+  int nout = 0, nin = 0;
+  switch (sh) {
+    case 0: nout = ShapeA::NOUT; nin = ShapeA::NIN; break;
+    case 1: nout = ShapeB::NOUT; nin = ShapeB::NIN; break;
+    case 2: nout = ShapeC::NOUT; nin = ShapeC::NIN; break;
+    case 3: nout = ShapeD::NOUT; nin = ShapeD::NIN; break;
+    case 4: nout = ShapeE::NOUT; nin = ShapeE::NIN; break;
+    case 5: nout = ShapeF::NOUT; nin = ShapeF::NIN; break;
+    case 6: nout = ShapeG::NOUT; nin = ShapeG::NIN; break;
+    case 7: nout = ShapeH::NOUT; nin = ShapeH::NIN; break;
+    case 8: nout = ShapeAX::NOUT; nin = ShapeAX::NIN; break;
+    case 9: nout = ShapeCX::NOUT; nin = ShapeCX::NIN; break;
+    case 10: nout = a.n_out == 12 ? ShapeH::NOUT : ShapeFX::NOUT; nin = a.n_in; break;
+    default: nout = ShapeBX::NOUT; nin = a.n_in; break;
+  }
+  it.out_rows = nout; it.out_cols = nin;
+  it.gw = sh == kWgShapeX0 + 2 && a.n_out == 12 ? ShapeH::GW : nout;
+  it.xw = nin;
+  it.cost = wg_stage_cost(sh);
+  // the narrower items of the 128 x 128 shape run against their operand reads (measured, tools/bench_wgrad.py: 128 x 80 0.67 x the
+  // full block, 12 x 128 0.83 x -- its 48-byte G rows cost whole bursts; 128 x 32 0.87 x (beside 256 x 256 workgroups; alone 0.76 x).  An item priced 40 % low makes its
+  // workgroups -- and the launch -- 60 % late: the 13 NeRF items took 11.2 ms instead of 7.0 with 128 x 32 at 812)
+  if (sh == kWgShapeX0 + 2) it.cost = it.gw < 128 ? 1450 : it.xw >= 128 ? it.cost : it.xw > 32 ? 1250 : 1530;
 }
 
 static int wg_plan(const mf_wgrad_item* items, int n, long long P, int precision, WgParams& p, long long& scratch_floats) {
@@ -558,8 +705,9 @@ static int wg_plan(const mf_wgrad_item* items, int n, long long P, int precision
     WgItem& it = p.it[i];
     it.G = a.G; it.g_stride = a.g_stride; it.X = a.X; it.x_stride = a.x_stride;
     it.shape = sh; it.want_bias = a.db ? 1 : 0; it.dW = a.dW; it.db = a.db;
+    wg_item_dims(a, sh, it);
     it.cost0 = cost;
-    cost += p.stages * wg_stage_cost(sh);
+    cost += p.stages * it.cost;
   }
   p.total_cost = cost;
   scratch_floats = 0;
@@ -568,7 +716,7 @@ static int wg_plan(const mf_wgrad_item* items, int n, long long P, int precision
     int first = -1, last = -1, count = 0;
     for (int w = 0; w < p.grid; ++w) {
       long long b, e;
-      wg_range(p.total_cost, p.grid, w, it.cost0, wg_stage_cost(it.shape), p.stages, b, e);
+      wg_range(p.total_cost, p.grid, w, it.cost0, it.cost, p.stages, b, e);
       if (b < e) { if (first < 0) first = w; last = w; ++count; }
     }
     it.dense = first >= 0 && count == last - first + 1;
@@ -638,7 +786,7 @@ extern "C" int32_t mf_weight_grads_p(int32_t precision, const mf_wgrad_item* ite
   if (ShapeG::SLOT_BYTES > lds) lds = ShapeG::SLOT_BYTES;
   if (ShapeH::SLOT_BYTES > lds) lds = ShapeH::SLOT_BYTES;
   lds *= 3;
-  const int lds_k[2] = {lds, 2 * ShapeAX::BUF_BYTES};
+  const int lds_k[2] = {lds, (int)kWgX3Dump + 4096};
   for (int k = 0; k < 2; ++k) {
     if (sp.n[k] == 0) continue;
     WgParams& p = sp.p[k];

@@ -2137,10 +2137,13 @@ def test_pass_and_training_step_replay_in_a_hip_graph(M, mode):
 
 @pytest.mark.parametrize("P", [1, 37, 5000, 70001])
 def test_weight_grads_three_products_vs_float64(M, P):
-    """mf_weight_grads_p(MF_PREC_BF16X3) alone: the NeRF's block shapes on column slices of strided dumps, ragged sample
-    counts (not a multiple of the 16-sample stage, fewer samples than workgroups), against a float64 GEMM: the
-    three-product blocks (256x256, 128x256) to 3e-5 l2-rel / 1e-4 max-rel (measured 7e-6; the fp32 MFMA 4e-6), the
-    blocks that stay fp32 (256x64, 128x32, 4x640) to 2e-5; db = column sums to 1e-5; bit-identical between runs."""
+    """mf_weight_grads_p(MF_PREC_BF16X3) alone: the NeRF's and the NoF's block shapes on column slices of strided dumps,
+    ragged sample counts (not a multiple of the 16- / 32-sample step, fewer samples than workgroups), against a float64
+    GEMM: the three-product blocks (round 5: every block but the heads' 4x640 -- 256x256, 128x256, 256x64 and 128x32 of the
+    NeRF, 128x128, 128x80 and 12x128 of the NoF, the narrow ones as zero-padded 256x128 / 128x128 blocks) to 3e-5 l2-rel /
+    1e-4 max-rel (measured 6e-6 .. 1.6e-5; the fp32 MFMA 4e-6), the heads block (fp32 either way) to 2e-5 and equal to the
+    fp32 launch's; db = column sums to 1e-5; bit-identical between runs; nothing written outside a block's (rows, n_in)
+    layout (the padded columns / rows of the wider three-product block are dropped by the reduction)."""
     from moco_flow_amd import autograd as A
     dev = torch.device("cuda")
     g = torch.Generator(device="cpu").manual_seed(7 + P)
@@ -2150,10 +2153,17 @@ def test_weight_grads_three_products_vs_float64(M, P):
     emb = torch.randn(P, 64, generator=g).to(dev)
     ext = torch.randn(P, 32, generator=g).to(dev)
     ghead = torch.randn(P, 4, generator=g).to(dev)
+    nstride = 4 * 128 + 16
+    nacts = torch.randn(P, nstride, generator=g).to(dev)
+    ngpre = torch.randn(P, nstride, generator=g).to(dev)
+    emb80 = torch.randn(P, 80, generator=g).to(dev)
     sl = lambda t, l, w=W: t[:, l * W:l * W + w]
+    nsl = lambda t, l, w=128: t[:, l * 128:l * 128 + w]
     jobs = [(sl(gpre, 1), sl(acts, 0), 256, 256, True), (sl(gpre, 5), sl(acts, 4), 256, 256, False),
             (sl(gpre, 9, 128), sl(acts, 8), 128, 256, True), (sl(gpre, 0), emb, 256, 64, True),
-            (sl(gpre, 9, 128), ext, 128, 32, False), (ghead, acts[:, 7 * W:7 * W + 640], 4, 640, True)]
+            (sl(gpre, 9, 128), ext, 128, 32, False), (ghead, acts[:, 7 * W:7 * W + 640], 4, 640, True),
+            (nsl(ngpre, 1), nsl(nacts, 0), 128, 128, True), (nsl(ngpre, 0), emb80, 128, 80, True),
+            (nsl(ngpre, 2), emb80, 128, 80, False), (ngpre[:, 512:524], nsl(nacts, 3), 12, 128, True)]
     old = A.WGRAD_PRECISION
     try:
         A.set_wgrad_precision("bf16x3")
@@ -2165,11 +2175,12 @@ def test_weight_grads_three_products_vs_float64(M, P):
         A.set_wgrad_precision(old)
     for (G, X, no, ni, b), (dW, db), (dW2, db2), (dWf, dbf) in zip(jobs, res, res2, ref32):
         assert torch.equal(dW, dW2)                                   # deterministic (fixed-order partial sums)
+        assert dW.shape == dWf.shape and dW.shape[1] == ni            # the fp32 shape's layout under either arithmetic
         want = G.double().t() @ X.double()
         if ni == 640:        # the heads block: no head reads the `final` columns -- not fetched, dW there is 0 by contract
             want[:, 256:512] = 0
             assert not dW[:, 256:512].any()
-        x3 = (no, ni) in ((256, 256), (128, 256))
+        x3 = ni != 640
         l2 = float((dW[:no].double() - want).norm() / want.norm().clamp_min(1e-30))
         mr = float((dW[:no].double() - want).abs().max() / want.abs().max().clamp_min(1e-30))
         print(f"P={P} {no}x{ni} {'x3' if x3 else 'f32'}: l2-rel {l2:.2e} max-rel {mr:.2e}")

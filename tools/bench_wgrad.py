@@ -9,6 +9,14 @@ import moco_flow_amd as M
 from moco_flow_amd import autograd as A
 
 P = int(sys.argv[1]) if len(sys.argv) > 1 else 5120 * 256
+# MF_WGRAD_DATA: "randn" (default) | "zero" | "relu" (activations max(randn, 0), gradients randn masked likewise): what the operands'
+# bit patterns cost -- the chip answers switching activity with its clock (profiles/r05_duty_power.txt)
+_kind = os.environ.get("MF_WGRAD_DATA", "randn")
+_randn = torch.randn
+if _kind == "zero":
+    torch.randn = lambda *a, **k: torch.zeros(*a, **k)
+elif _kind == "relu":
+    torch.randn = lambda *a, **k: _randn(*a, **k).clamp_(min=0)
 dev = torch.device("cuda")
 D, W = 8, 256
 stride = (D + 1) * W + W // 2
@@ -52,16 +60,28 @@ sets["G x2 (128x80)"] = [(nsl(ngpre, 0), emb80, 128, 80, True), (nsl(ngpre, 2), 
 sets["H x1 (12x128)"] = [(ngpre[:, 512:524], nsl(nacts, 3), 12, 128, True)]
 sets["NoF all 6"] = sets["F x3 (128x128)"] + sets["G x2 (128x80)"] + sets["H x1 (12x128)"]
 sets_check = None
+A9, B2, C1, D1 = (sets[k] for k in ("A x9 (256x256)", "B x2 (256x64)", "C x1 (128x256)", "D x1 (128x32)"))
+if os.environ.get("MF_WGRAD_MIX") == "1":          # how the cost model balances mixed launches (the sum of the parts is the target)
+    sets["mix A9+C"] = A9 + C1
+    sets["mix A9+B2"] = A9 + B2
+    sets["mix A9+D"] = A9 + D1
+    sets["mix A9+B2+C+D"] = A9 + B2 + C1 + D1
+    sets["mix B2+C+D"] = B2 + C1 + D1
 sets["all 13"] = sum((sets[k] for k in ("A x9 (256x256)", "B x2 (256x64)", "C x1 (128x256)", "D x1 (128x32)", "E x1 (4x640)")), [])
 flops = lambda jobs: sum(2.0 * P * a[2] * a[3] for a in jobs)
 byts = lambda jobs: sum(4.0 * P * (a[2] + a[3]) for a in jobs)
 prec = os.environ.get("MF_WGRAD", "f32")          # MF_WGRAD=bf16x3: the three-product variants of the large blocks
 A.set_wgrad_precision(prec)
 print(f"P = {P} samples, wgrad precision {prec}")
+only = os.environ.get("MF_WGRAD_SETS")            # comma-separated prefixes of the set names to time (timing-ablation runs); no check then
 for k, jobs in sets.items():
+    if only and not any(k.startswith(o) for o in only.split(",")):
+        continue
     ms = timeit(lambda: A.weight_grads(jobs, P, dev))
     print(f"  {k:18s}: {ms:7.3f} ms  {flops(jobs)/ms/1e9:7.1f} TFLOP/s  {byts(jobs)/ms/1e9:6.2f} TB/s"
           f"  ({ms/len(jobs)*1e6/((P+15)//16)*256*2.4/1e3:7.0f} CU-cycles/stage/item @2.4GHz)")
+if only:
+    sys.exit(0)
 # correctness spot check against library GEMMs
 jobs = sets["all 13"] + sets["NoF all 6"]
 res = A.weight_grads(jobs[:13], P, dev) + A.weight_grads(jobs[13:], P, dev)
