@@ -235,10 +235,12 @@ typedef struct mf_wgrad_item {
 int64_t mf_weight_grads_scratch_bytes(const mf_wgrad_item* items, int32_t n_items, int64_t P);
 int32_t mf_weight_grads(const mf_wgrad_item* items, int32_t n_items, int64_t P, void* scratch, void* stream);
 /* The same with the arithmetic of the contraction chosen (ABI v13).  MF_PREC_F32: exact-fp32 MFMA (the two calls above).
- * MF_PREC_BF16X3: the large NeRF blocks (256x256, 128x256) contract G and X as two-term bf16 splits, three bf16
- * products per 16-sample step with fp32 accumulation (16 mantissa bits per operand; a fifth of the fp32 pipe's matrix
- * time, the launch then runs against the HBM reads of its operands); the other blocks stay fp32.  The scratch size
- * depends on the precision. */
+ * MF_PREC_BF16X3: every block but the heads' 4x640 (round 5; before: 256x256 and 128x256 only) contracts G and X as two-term
+ * bf16 splits, three bf16 products per 16-sample step with fp32 accumulation (16 mantissa bits per operand; a fifth of the
+ * fp32 pipe's matrix time, the launch then runs against the HBM reads of its operands) -- 256x64 on a 256x128 block, the NoF's
+ * 128x128 / 128x80 / 12x128 and 128x32 on a 128x128 block, columns beyond the operands' widths zero; dW keeps the (rows, n_in)
+ * layout of the fp32 call, the operand strides must be even.  The heads block stays fp32.  The scratch size depends on the
+ * precision. */
 int64_t mf_weight_grads_scratch_bytes_p(int32_t precision, const mf_wgrad_item* items, int32_t n_items, int64_t P);
 int32_t mf_weight_grads_p(int32_t precision, const mf_wgrad_item* items, int32_t n_items, int64_t P, void* scratch, void* stream);
 

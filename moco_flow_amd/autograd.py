@@ -143,12 +143,13 @@ _WG_BLOCK = {(256, 256): (256, 256), (256, 64): (256, 64), (128, 256): (128, 256
              (128, 128): (128, 128), (128, 80): (128, 80), (12, 128): (16, 128)}
 
 
-# Arithmetic of the weight-gradient contractions dW = G^T X (mf_weight_grads_p): "f32" = exact-fp32 MFMA; "bf16x3" = the
-# NeRF's large blocks (256x256, 128x256) as three bf16 products of (hi, lo) operand pairs with fp32 accumulation
-# (include/mocoflow_hip.h): 16 mantissa bits per operand, a sum over ~1e6 samples -- 7e-6 l2-rel against a float64 GEMM
-# where the fp32 MFMA measures 4e-6 (tools/bench_wgrad.py), every gradient test holds its bar in both (tests/conftest.py
-# `wgrad`) -- at 0.70x the time of the launch (it then runs against the HBM reads of its operands).  The default;
-# set_wgrad_precision("f32") restores the exact-fp32 contraction.
+# Arithmetic of the weight-gradient contractions dW = G^T X (mf_weight_grads_p): "f32" = exact-fp32 MFMA; "bf16x3" = every
+# block but the heads' 4 x 640 (round 5: the NeRF's 256x256, 128x256, 256x64, 128x32 and the NoF's 128x128, 128x80, 12x128) as
+# three bf16 products of (hi, lo) operand pairs with fp32 accumulation (include/mocoflow_hip.h): 16 mantissa bits per operand,
+# a sum over ~1e6 samples -- 6e-6 .. 1.6e-5 l2-rel against a float64 GEMM where the fp32 MFMA measures 4e-6
+# (tools/bench_wgrad.py), every gradient test holds its bar in both (tests/conftest.py `wgrad`) -- at 0.56x (NeRF) / 0.61x (NoF)
+# the time of the fp32 launch: it runs against the HBM reads of its operands.  The default; set_wgrad_precision("f32")
+# restores the exact-fp32 contraction.
 WGRAD_PRECISION = "bf16x3"
 
 

@@ -887,7 +887,24 @@ struct Ahead { int g0; const char* j0; int g1; const char* j1; int s0 = -1, s1 =
 // `mask` (round 5; with `masks`, uniform): this lane's ReLU BIT ROW of the layer -- the words the fp32 forward writes
 // (relu_mask_word / relu_mask_shift, mf_core.hpp: word 4 (t >> 2) + g, byte t & 3, bit = feature of lane group g) and the x3
 // backward chains read (relu_mask_pair): lane half h of this 32 x 32 tiling owns the bytes of groups g = h and g = 2 + h.
-struct RowDump { float* row; bool on; bool wave_on; unsigned* mask = nullptr; bool masks = false; };     // wave_on: some lane of the wave stores (uniform)
+// Round 5: the ROW stores go through a buffer descriptor -- `rs` = the wave's first row of the plane (uniform), `voff` = this
+// lane's byte offset from it (+ 16 (lane >> 5)), `soff` = the layer's first column in bytes (uniform); a lane without a row
+// carries an offset no record reaches and the hardware drops its store.  As `if (on) *row = v` every one of the ~530 row stores of
+// the sample-tile program sat in its own s_and_saveexec / s_cbranch_execz / s_or exec bracket: 1 600 scalar instructions and as
+// many basic-block ends inside the MFMA schedule.
+struct RowDump {
+  float* row; bool on; bool wave_on; unsigned* mask = nullptr; bool masks = false;     // wave_on: some lane of the wave stores (uniform)
+  float* rs = nullptr; uint32_t voff = 0; int soff = 0;      // (rs: the descriptor's base; the descriptor itself is made at the store -- four scalar moves the compiler keeps)
+};
+constexpr uint32_t kDumpNoRow = 0x7fffff00u;           // voff of a lane without a row = the descriptors' num_records
+// the descriptor + lane offset of a dump plane: `row` = this lane's row index (ascending over the wave: lane 0 holds the first), `on` its predicate
+MF_D void dump_rows(RowDump& d, float* plane, long long row, long long stride, bool on, int h) {
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)row), hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)row >> 32));
+  const long long row0 = (long long)(((unsigned long long)hi << 32) | lo);
+  d.rs = plane + row0 * stride;
+  d.voff = on ? (uint32_t)((row - row0) * stride * 4) + 16u * (uint32_t)h : kDumpNoRow;
+  d.soff = 0;
+}
 MF_D bool dump_wave_on(const RowDump& d) { return d.wave_on; }
 struct NoDump {};
 MF_D bool dump_wave_on(const NoDump&) { return true; }
@@ -913,7 +930,6 @@ MF_D void mask_put(const NoDump&, const f32x16&, int, int, unsigned&, unsigned&)
 // the activations themselves
 template <bool RELU, bool HF = false>
 MF_D void dump_store(const RowDump& d, const f32x16& acc, int t, int q) {
-  if (!d.on) return;
   auto act = [](float x) {
     if (!RELU) return x;
     const int b = __builtin_bit_cast(int, x);
@@ -922,7 +938,8 @@ MF_D void dump_store(const RowDump& d, const f32x16& acc, int t, int q) {
   f32x4 v;
 #pragma unroll
   for (int i = 0; i < 4; ++i) v[i] = act(acc[4 * q + i]) * (HF ? kHalfInvAcc : 1.f);
-  *reinterpret_cast<f32x4*>(d.row + 32 * t + 8 * q) = v;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)d.rs, 0, (int)kDumpNoRow, 0x00020000);
+  __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs, (int)(d.voff + (uint32_t)((32 * t + 8 * q) * 4)), d.soff, 0);
 }
 template <bool RELU, bool HF = false>
 MF_D void dump_store(const NoDump&, const f32x16&, int, int) {}
@@ -1235,7 +1252,7 @@ MF_D void nof_eval_x3(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4
     const Next nxt = layer == D - 1 ? hd : next_x<8, kKsNofXyz, T>(net, layer + 1);
     const int has_emb = (net.emb_mask >> layer) & 1;
     auto dump_at = [&](int col, int lyr) {                    // (the NoF's bit rows: 4 words per layer)
-      if constexpr (__is_same(DT, RowDump)) return RowDump{dump.row + col, dump.on, dump.wave_on, dump.mask + 4 * lyr, dump.masks};
+      if constexpr (__is_same(DT, RowDump)) return RowDump{dump.row + col, dump.on, dump.wave_on, dump.mask + 4 * lyr, dump.masks, dump.rs, dump.voff, col * 4};
       else return NoDump{};
     };
     const auto nd = dump_at(layer * 128, layer);
@@ -1292,7 +1309,7 @@ MF_D void nerf_eval_x3(const Net& net, const u32x4 (&xh)[kKsNerfXyz], const u32x
                        bool sigma_only, ST& st, CarryX& carry, const Lane& id, const Next& follow, float& sigma,
                        float (&rgb)[3], const DT& dump = DT{}) {
   auto dump_at = [&](int col) {                               // the dump of a layer whose first column is `col` (layer col / 256: 8 mask words each)
-    if constexpr (__is_same(DT, RowDump)) return RowDump{dump.row + col, dump.on, dump.wave_on, dump.mask + 8 * (col / 256), dump.masks};
+    if constexpr (__is_same(DT, RowDump)) return RowDump{dump.row + col, dump.on, dump.wave_on, dump.mask + 8 * (col / 256), dump.masks, dump.rs, dump.voff, col * 4};
     else return NoDump{};
   };
   u32x4 ah[16], al[16], bh[16], bl[16];

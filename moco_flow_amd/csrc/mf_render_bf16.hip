@@ -276,7 +276,8 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
             // (a row with room behind T carries the layers' ReLU bit words, 4 per layer: what mf_nof_backward3 reads instead of the activations)
             float* nrow = p.dump_nof_acts + nof_idx * p.dump_nof_stride;
             const bool nmasks = p.dump_nof_stride >= (long long)net.D * 128 + 16 + 4 * net.D;
-            const RowDump nd{nrow + 4 * id.h, don, __ballot(don) != 0ull, reinterpret_cast<unsigned*>(nrow + net.D * 128 + 16), nmasks};
+            RowDump nd{nrow + 4 * id.h, don, __ballot(don) != 0ull, reinterpret_cast<unsigned*>(nrow + net.D * 128 + 16), nmasks};
+            dump_rows(nd, p.dump_nof_acts, nof_idx, p.dump_nof_stride, don, id.h);
             nof_eval_x3<TN, kNofHalfX3>(net, nhi, reinterpret_cast<const u32x4(&)[kKsNofXyz]>(nmid), nlo, cur, st, carry, id, follow, out, rb, stage_next, nd);
             if (don && id.h == 0) { float* q = p.dump_nof_out + nof_idx * 3; q[0] = out[0]; q[1] = out[1]; q[2] = out[2]; }
           } else if constexpr (X3) {
@@ -341,8 +342,9 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
         if constexpr (DUMP) {
           const long long row = ray * S + si;
           const bool don = valid && p.dump_acts != nullptr;
-          const RowDump dump{p.dump_acts + row * p.dump_stride + 4 * id.h, don, __ballot(don) != 0ull,
-                             p.dump_mask ? p.dump_mask + row * p.dump_mask_stride : nullptr, p.dump_mask != nullptr};
+          RowDump dump{p.dump_acts + row * p.dump_stride + 4 * id.h, don, __ballot(don) != 0ull,
+                       p.dump_mask ? p.dump_mask + row * p.dump_mask_stride : nullptr, p.dump_mask != nullptr};
+          dump_rows(dump, p.dump_acts, row, p.dump_stride, don, id.h);
           nerf_eval_x3(p.nerf, xh, xl, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb, dump);
           if (valid && id.h == 0) {
             if (p.dump_rgbsigma) *reinterpret_cast<float4*>(p.dump_rgbsigma + row * 4) = make_float4(rgb[0], rgb[1], rgb[2], sigma);

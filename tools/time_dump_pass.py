@@ -17,14 +17,18 @@ r, b = synth.rays(0, N, chained=True)
 rays, bg = torch.from_numpy(r).to(dev), torch.from_numpy(b).to(dev)
 t = torch.linspace(0, 1, S, device=dev)
 z = (rays[:, 6:7] * (1 - t) + rays[:, 7:8] * t).contiguous()
-for dump in (False, True):
-    args = (rays, bg, z, None, False, None, L.MF_ACT_RELU, nerf, embs, nofs, nof_embs, True, True, False, True)
-    with torch.no_grad():
-        for _ in range(3):
-            rendering._render_pass(*args, dump=dump)
-        ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
-        for s, e in ev:
-            s.record(); rendering._render_pass(*args, dump=dump); e.record()
-        torch.cuda.synchronize()
-    ms = sorted(s.elapsed_time(e) for s, e in ev)
-    print(f"dump={dump}: median {ms[len(ms)//2]:.3f} ms (min {ms[0]:.3f})")
+# round 5: both arithmetics of the training forward (MF_PREC_F32 | MF_PREC_BF16X3), with and without the dump planes, and the
+# chain-free pass (bw NoF -> NeRF only) beside the local + global one
+for chains in (True, False):
+    for prec in ("f32", "bf16x3"):
+        for dump in (False, True):
+            args = (rays, bg, z, None, False, None, L.MF_ACT_RELU, nerf, embs, nofs, nof_embs, chains, chains, False, True)
+            with torch.no_grad():
+                for _ in range(3):
+                    rendering._render_pass(*args, dump=dump, precision=prec)
+                ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+                for s, e in ev:
+                    s.record(); rendering._render_pass(*args, dump=dump, precision=prec); e.record()
+                torch.cuda.synchronize()
+            ms = sorted(s.elapsed_time(e) for s, e in ev)
+            print(f"chains={chains} prec={prec} dump={dump}: median {ms[len(ms)//2]:.3f} ms (min {ms[0]:.3f})", flush=True)
