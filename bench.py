@@ -55,6 +55,7 @@ FLOPS = {"nerf_dir": 1186816, "nerf_ind": 1181184, "nof_quat": 134400}   # per s
 # the NoF (IEEE-half (hi, lo) pairs on the f16 instruction of the same rate; rounds 3-4: six, bf16 triples) -- so its ceiling in
 # ALGORITHMIC FLOP/s is the bf16 peak / 3: peak_of().
 PEAK = {"f32": 157.3, "bf16": 2516.0}
+HBM_PEAK_TBS = 8.0          # MI355X_MICROARCH.md: HBM3E, the roofline of the training step's streaming kernels (legs.aux.wgrad)
 X3_PRODUCTS = {"nerf": 3, "nof": 3}
 PEAK_NOTE = {"f32": "dense fp32-input MFMA peak", "bf16": "dense bf16 MFMA peak",
              "bf16x3": "dense bf16 MFMA peak x algorithmic / issued FLOP = peak / 3 (three matrix instructions per product: bf16 (hi, lo) "
@@ -547,6 +548,43 @@ def aux_legs(M, synth, torch, dev):
         flops = nv * (64 * (f_nerf + f_nof) + 192 * (FLOPS["nerf_ind"] + f_nof))
         out["image_512_bf16"] = {"ms": sig(t * 1e3, 4), "rs_s": sig(nv * 256 / t, 4), "frac": sig(flops / t / 1e12 / PEAK["bf16"])}
     torch.cuda.empty_cache()
+    out["wgrad"] = wgrad_leg(torch, dev, timeit, sig)
+    torch.cuda.empty_cache()
+    return out
+
+
+def wgrad_leg(torch, dev, timeit, sig):
+    """The training step's HBM-bound kernel against the HBM roofline (round 5): mf_weight_grads_p (three bf16 products, the
+    default of the explicit backward) on the joint stage's fine-pass shapes -- the NeRF's 13 blocks over 262 144 samples
+    (strided dump / gradient rows, 24.1 KB of operand rows per sample) and one NoF's 6 blocks over its 3 x 262 144
+    evaluations (5.3 KB each).  ALGORITHMIC bytes = every operand row read once (4 (n_out + n_in) P per block; the heads'
+    unfetched 256 columns excluded) / the launches' time, as a fraction of 8 TB/s.  Operands: ReLU-like activations
+    (max(randn, 0)), gradients masked the same way -- the chip's clock answers the operands' switching activity in this kernel
+    (zeros: 6.0 TB/s, randn: 4.6; profiles/r05_wgrad_x3.txt)."""
+    from moco_flow_amd import autograd as A
+    P, W = 262144, 256
+    stride = 9 * W + W // 2
+    g = torch.Generator(device=dev).manual_seed(0)
+    rn = lambda *shape: torch.randn(*shape, device=dev, generator=g)
+    acts = rn(P, stride).clamp_(min=0)
+    gpre = rn(P, stride) * (rn(P, stride) > 0)
+    ghead, emb64, ext32 = rn(P, 4), rn(P, 64), rn(P, 32)
+    sl = lambda t, l, w=W: t[:, l * W:l * W + w]
+    nerf = [(sl(gpre, l), sl(acts, l - 1), 256, 256, True) for l in range(1, 9)] + [(sl(gpre, 8), sl(acts, 7), 256, 256, True)]
+    nerf += [(sl(gpre, 0), emb64, 256, 64, True), (sl(gpre, 4), emb64, 256, 64, False), (sl(gpre, 9, 128), sl(acts, 8), 128, 256, True),
+             (sl(gpre, 9, 128), ext32, 128, 32, False), (ghead, acts[:, 7 * W:7 * W + 640], 4, 640, True)]
+    Pn, ns = 3 * P, 4 * 128 + 16 + 16
+    nacts = rn(Pn, ns).clamp_(min=0)
+    ngpre = rn(Pn, ns) * (rn(Pn, ns) > 0)
+    emb80 = rn(Pn, 80)
+    nsl = lambda t, l, w=128: t[:, l * 128:l * 128 + w]
+    nof = [(nsl(ngpre, l), nsl(nacts, l - 1), 128, 128, True) for l in (1, 2, 3)]
+    nof += [(nsl(ngpre, 0), emb80, 128, 80, True), (nsl(ngpre, 2), emb80, 128, 80, False), (ngpre[:, 512:524], nsl(nacts, 3), 12, 128, True)]
+    byts = lambda jobs, n: sum(4.0 * n * (a[2] + (384 if a[3] == 640 else a[3])) for a in jobs)
+    out = {"precision": A.WGRAD_PRECISION, "data": "relu-like"}
+    for tag, jobs, n in (("nerf13", nerf, P), ("nof6", nof, Pn)):
+        t = timeit(lambda: A.weight_grads(jobs, n, dev), 5)
+        out[tag] = {"ms": sig(t * 1e3, 4), "tb_s": sig(byts(jobs, n) / t / 1e12), "frac_hbm": sig(byts(jobs, n) / t / 1e12 / HBM_PEAK_TBS)}
     return out
 
 
