@@ -112,6 +112,21 @@ def test_three_product_entry_points_validate_on_the_host():
     assert lib.mf_weight_grads_scratch_bytes_p(L.MF_PREC_F32, items, 3, P) == lib.mf_weight_grads_scratch_bytes(items, 3, P)
     assert lib.mf_weight_grads_scratch_bytes_p(L.MF_PREC_BF16, items, 3, P) == -1          # not an arithmetic of this call
     assert lib.mf_weight_grads_p(L.MF_PREC_BF16, items, 3, P, None, None) < 0
+    # round 5: under MF_PREC_BF16X3 the NoF's blocks and the NeRF's narrow ones are planned on the three-product shapes too -- the
+    # 128 x 128 block for 128x128 / 128x80 / 12x128 / 128x32, the 256 x 128 block for 256x64: every partial has the padded block's
+    # size (the fp32 plan: the narrow shapes' own), one partial per workgroup range that touches the item
+    blk128, blk256 = (128 * 128 + 128) * 4, (256 * 128 + 256) * 4
+    for (no, ni), xs, blk, f32blk in (((128, 128), 544, blk128, blk128), ((128, 80), 80, blk128, (128 * 80 + 128) * 4),
+                                      ((12, 128), 544, blk128, (16 * 128 + 16) * 4), ((128, 32), 32, blk128, (128 * 32 + 128) * 4),
+                                      ((256, 64), 64, blk256, (256 * 64 + 256) * 4)):
+        one = (L.mf_wgrad_item * 1)()
+        one[0].G, one[0].g_stride, one[0].n_out, one[0].X, one[0].x_stride, one[0].n_in, one[0].dW, one[0].db = base, 2432, no, base, xs, ni, base, None
+        n3 = lib.mf_weight_grads_scratch_bytes_p(L.MF_PREC_BF16X3, one, 1, P)
+        n32 = lib.mf_weight_grads_scratch_bytes_p(L.MF_PREC_F32, one, 1, P)
+        assert n3 > 16 and (n3 - 16) % blk == 0 and (n32 - 16) % f32blk == 0, (no, ni, n3, n32)
+        assert (n3 - 16) // blk == (n32 - 16) // f32blk                      # the same workgroup ranges: one item, one cost
+        one[0].x_stride = xs + 1                                             # the three-product loads are 8 bytes wide
+        assert lib.mf_weight_grads_scratch_bytes_p(L.MF_PREC_BF16X3, one, 1, P) == -1 and b"even" in lib.mf_last_error()
     # point query: the workspace (per-point / single NoF bias) exists for both bf16 arithmetics
     n = L.mf_nof_desc()
     n.D, n.W, n.in_channels_xyz, n.extra_feat_dim, n.skip_mask, n.use_quat = 4, 128, 33, 33, 1 << 2, 1
