@@ -446,6 +446,7 @@ MF_D void wg_segment_x3(const WgItem& it, long long sb, long long se, long long 
   // code: a piece waits for vmcnt(14), the other fourteen loads stay in flight -- degraded to vmcnt(0) at the merges.
   auto stage = [&](long long step, auto parc) {
     constexpr int PAR = decltype(parc)::value;
+    jitter();                                                   // (race screen builds only, -DMF_DBG_JITTER)
     if (!late) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // this thread's fragment writes of the step before
       __builtin_amdgcn_s_barrier();
@@ -467,6 +468,7 @@ MF_D void wg_segment_x3(const WgItem& it, long long sb, long long se, long long 
 #pragma unroll
     for (int g = 0; g < NG; ++g) {
       const int k = g / WR, ti = g % WR;
+      if (g == NG / 2) jitter();
       if (g == NG / 2 && late) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
