@@ -123,10 +123,17 @@ MF_D void bwd_layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[1
   constexpr int NT = 8, NG = 2 * KHID, NM = 3 * KHID, kSteps = 16;
   f32x16 pend = {};
   f32x4 pm[4] = {}, hm[4] = {};
-  auto step = [&](const f32x16& acc, const f32x4 (&m)[4], int sidx, int t) __attribute__((always_inline)) {
+  // The sigma term and the mask are applied ONCE per element -- in the hi step of its pair, written back into the pending
+  // accumulators -- and the lo step and the row store read the finished value (round 5; before, each of the three re-did them).
+  // Every hi step (sidx <= 14) lies in front of the first store gap.
+  auto step = [&](f32x16& acc, const f32x4 (&m)[4], int sidx, int t) __attribute__((always_inline)) {
     const int u = sidx >> 1, w = u & 3, r = u < 4 ? 2 * u : 8 + 2 * (u - 4);
     if (!OUT) return;
-    const float v0 = b3_val<MASK, SIG, BITS>(acc, m, r, sigw_off, t, id.h, dsig), v1 = b3_val<MASK, SIG, BITS>(acc, m, r + 1, sigw_off, t, id.h, dsig);
+    if (!(sidx & 1)) {
+      acc[r] = b3_val<MASK, SIG, BITS>(acc, m, r, sigw_off, t, id.h, dsig);
+      acc[r + 1] = b3_val<MASK, SIG, BITS>(acc, m, r + 1, sigw_off, t, id.h, dsig);
+    }
+    const float v0 = acc[r], v1 = acc[r + 1];
     u32x4& hv = u < 4 ? out[2 * t] : out[2 * t + 1];
     if (!(sidx & 1)) {
       unsigned hi = pack_bf16x2(v0, v1);
@@ -142,7 +149,7 @@ MF_D void bwd_layer_x(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[1
   auto store = [&](const f32x16& acc, const f32x4 (&m)[4], int t, int q) __attribute__((always_inline)) {
     f32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = b3_val<MASK, SIG, BITS>(acc, m, 4 * q + i, sigw_off, t, id.h, dsig);
+    for (int i = 0; i < 4; ++i) v[i] = OUT ? acc[4 * q + i] : b3_val<MASK, SIG, BITS>(acc, m, 4 * q + i, sigw_off, t, id.h, dsig);   // (OUT: finished by the hi steps)
     *reinterpret_cast<f32x4*>(grow + 32 * t + 8 * q) = v;
   };
   auto run = [&](auto tc) __attribute__((always_inline)) {

@@ -106,10 +106,14 @@ MF_D void nof3_layer(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[8]
   constexpr int NT = 4, KHID = 8, NG = 2 * KHID, NM = 3 * KHID, kSteps = 16;
   f32x16 pend = {};
   f32x4 pm[4] = {}, hm[4] = {};
-  auto step = [&](const f32x16& acc, const f32x4 (&m)[4], int sidx, int t) __attribute__((always_inline)) {
+  // The mask is applied ONCE per element -- in the hi step of its pair, written back into the pending accumulators -- and the lo
+  // step and the row store read the masked value (round 5; before, each of the three re-did the bit test: 144 instead of 48
+  // VALU per tile in a kernel that runs against the VALU).  Every hi step (sidx <= 14) lies in front of the first store gap.
+  auto step = [&](f32x16& acc, const f32x4 (&m)[4], int sidx, int t) __attribute__((always_inline)) {
     const int u = sidx >> 1, w = u & 3, r = u < 4 ? 2 * u : 8 + 2 * (u - 4);
     if (!OUT) return;
-    const float v0 = n3_val<BITS>(acc, m, r), v1 = n3_val<BITS>(acc, m, r + 1);
+    if (!(sidx & 1)) { acc[r] = n3_val<BITS>(acc, m, r); acc[r + 1] = n3_val<BITS>(acc, m, r + 1); }
+    const float v0 = acc[r], v1 = acc[r + 1];
     u32x4& hv = u < 4 ? out[2 * t] : out[2 * t + 1];
     if (!(sidx & 1)) {
       unsigned hi = pack_bf16x2(v0, v1);
@@ -125,7 +129,7 @@ MF_D void nof3_layer(ST& st, const Lane& id, CarryX& carry, const u32x4 (&in)[8]
   auto store = [&](const f32x16& acc, const f32x4 (&m)[4], int t, int q) __attribute__((always_inline)) {
     f32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = n3_val<BITS>(acc, m, 4 * q + i);
+    for (int i = 0; i < 4; ++i) v[i] = OUT ? acc[4 * q + i] : n3_val<BITS>(acc, m, 4 * q + i);      // (OUT: masked by the hi steps)
     *reinterpret_cast<f32x4*>(grow + 32 * t + 8 * q) = v;
   };
   auto run = [&](auto tc) __attribute__((always_inline)) {
