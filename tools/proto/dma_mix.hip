@@ -82,6 +82,66 @@ __global__ __launch_bounds__(512, 2) void k(const u32x4* in, const char* w, floa
   out[blockIdx.x * blockDim.x + threadIdx.x] = s;
 }
 
+// round 5, "what comes next": FOUR waves (one per SIMD), each 64 samples = two 32-sample column blocks: every 1 KiB fragment feeds two
+// MFMAs (two accumulator chains), half the LDS fragment traffic per MFMA; 4 pieces per wave and panel, same ring, same barrier.
+__global__ __launch_bounds__(256, 1) void k2(const u32x4* in, const char* w, float* out, int panels, int wbytes) {
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  u32x4 b0[16], b1[16];
+  for (int i = 0; i < 16; ++i) { b0[i] = in[(lane + 64 * i + 17 * wave) & 1023]; b1[i] = in[(lane + 64 * i + 31 * wave + 300) & 1023]; }
+  for (int g = wave; g < NG; g += 4) { blds(w, lane * 16, g * 1024, g * 1024); blds(w, lane * 16, SLOT + g * 1024, SLOT + g * 1024); }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  uint32_t off0 = 0, off1 = SLOT, off2 = 2 * SLOT, gsrc = 2 * SLOT;
+  f32x16 a0, a1;
+  for (int i = 0; i < 16; ++i) { a0[i] = 0.f; a1[i] = 0.f; }
+  u32x4 r[PD + 1];
+#pragma unroll
+  for (int i = 0; i < PD; ++i) r[i] = lds4(off0 + lane * 16 + i * 1024);
+  for (int pnl = 0; pnl < panels; ++pnl) {
+    const uint32_t p = off0 + lane * 16, pn = off1 + lane * 16;
+    const char* src = w + gsrc;
+    const uint32_t dst = off2;
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      const int s = gi % (PD + 1);
+      a0 = MFMA(r[s], b0[gi], a0);
+      __builtin_amdgcn_sched_barrier(0);
+      const int sp = (gi + PD) % (PD + 1), nb = gi + PD;
+      if (nb < NG) r[sp] = lds4(p + nb * 1024);
+      if (gi == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+      }
+      if (nb >= NG) r[sp] = lds4(pn + (nb - NG) * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+      a1 = MFMA(r[s], b1[gi], a1);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gi >= 1 && gi <= 4) blds(src, lane * 16, (4 * wave + gi - 1) * 1024, dst + (4 * wave + gi - 1) * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    const uint32_t t = off0; off0 = off1; off1 = off2; off2 = t;
+    gsrc += SLOT; if (gsrc + SLOT > (uint32_t)wbytes) gsrc = 0;
+  }
+  float s = 0.f;
+  for (int i = 0; i < 16; ++i) s += a0[i] + a1[i];
+  out[blockIdx.x * blockDim.x + threadIdx.x] = s;
+}
+void run2(const u32x4* in, const char* w, float* out, int wbytes) {
+  const int panels = 20000, launches = 12;
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  (void)hipFuncSetAttribute((const void*)k2, hipFuncAttributeMaxDynamicSharedMemorySize, 3 * SLOT);
+  for (int i = 0; i < 4; ++i) hipLaunchKernelGGL(k2, dim3(256), dim3(256), 3 * SLOT, 0, in, w, out, panels, wbytes);
+  (void)hipEventRecord(e0);
+  for (int i = 0; i < launches; ++i) hipLaunchKernelGGL(k2, dim3(256), dim3(256), 3 * SLOT, 0, in, w, out, panels, wbytes);
+  (void)hipEventRecord(e1); (void)hipEventSynchronize(e1);
+  float ms; (void)hipEventElapsedTime(&ms, e0, e1); ms /= launches;
+  const double tf = (double)panels * NG * 8 * 256 * 2 * 32 * 32 * 16 / (ms * 1e-3) / 1e12;     // same tile: 4 waves x 2 blocks = 8 column blocks
+  printf("four waves x two column blocks per fragment (4 pieces per wave, gaps 1-4)          %8.3f ms  %6.0f TFLOP/s (%4.1f %% of 2516)  ns/panel %.1f\n", ms, tf, tf / 25.16,
+         ms * 1e6 / panels);
+  fflush(stdout);
+}
+
 template <int MODE>
 void run(const char* what, const u32x4* in, const char* w, float* out, int wbytes) {
   const int panels = 20000, launches = 12;
@@ -124,6 +184,7 @@ int main() {
     run<5>("every wave 2 pieces, gaps 12-13", in, w, out, wbytes);
     run<6>("waves 4-7 six gaps behind waves 0-3", in, w, out, wbytes);
     run<8>("no DMA, no barrier", in, w, out, wbytes);
+    run2(in, w, out, wbytes);
   }
   return 0;
 }
