@@ -358,11 +358,15 @@ MF_D void wg_segment_x3(const WgItem& it, long long sb, long long se, long long 
   const long long stride = is_g ? it.g_stride : it.x_stride;
   const int width = is_g ? it.gw : it.xw;                            // valid columns of the operand (even; the rest of the block is zero)
   const uint32_t reg0 = is_g ? 0u : (uint32_t)(2 * S::NOUT * 16);    // byte offset of this operand's region inside a k-step
-  const uint32_t wdst = (uint32_t)((uh >> 1) * S::KSTEP_BYTES) + reg0 + (uint32_t)(((uh & 1) * nf + 2 * up) * 16);
+  // Fragment slots: within a 32-feature tile the EVEN features take slots 0..15, the odd ones 16..31 (feature f of the tile: slot
+  // 16 (f & 1) + (f >> 1)).  A unit's two features then lie 256 bytes apart and the 64 lanes of one write instruction cover
+  // contiguous 256-byte runs -- with the natural order (slot = feature) they were 32 bytes apart: a two-way bank conflict on every
+  // fragment write.  The MFMA rows / columns are the slots; the partial store at the end of the segment maps them back.
+  const uint32_t wdst = (uint32_t)((uh >> 1) * S::KSTEP_BYTES) + reg0 + (uint32_t)(((uh & 1) * nf + 32 * (up >> 4) + (up & 15)) * 16);
   // (no branch around the fragment writes: a wave without a unit -- 128 x 256 has two -- converts the zeros its loads return and
   //  writes them to a dump area behind the buffers; under a branch the compiler sinks the pieces' arithmetic into it, i.e. behind
   //  the step's MFMAs, and re-loads into fresh registers it then has to copy -- with a wait for the newest loads)
-  const uint32_t wbase = unit ? wdst : kWgX3Dump + (uint32_t)lane * 32u, wlo = unit ? (uint32_t)S::PART_BYTES : 2048u;
+  const uint32_t wbase = unit ? wdst : kWgX3Dump + (uint32_t)lane * 16u, wlo = unit ? (uint32_t)S::PART_BYTES : 2048u;
   __syncthreads();                                   // previous segment's readers are done with the buffers
   f32x16w acc[WR][WC];
 #pragma unroll
@@ -415,8 +419,8 @@ MF_D void wg_segment_x3(const WgItem& it, long long sb, long long se, long long 
     const uint32_t o = wbase + (unit ? buf : 0u);
 #pragma unroll
     for (int c = 0; c < 2; ++c) {
-      *reinterpret_cast<u32x4*>(smem + o + 16 * c) = hv[c];
-      *reinterpret_cast<u32x4*>(smem + o + wlo + 16 * c) = lv[c];
+      *reinterpret_cast<u32x4*>(smem + o + 256 * c) = hv[c];
+      *reinterpret_cast<u32x4*>(smem + o + wlo + 256 * c) = lv[c];
     }
   };
   // prologue: steps 0 and 1 into buffers 0 and 1, steps 2 .. 1 + NS on their way (set q holds step 2 + q)
@@ -515,19 +519,21 @@ MF_D void wg_segment_x3(const WgItem& it, long long sb, long long se, long long 
     stage(q + 1, std::integral_constant<int, 1>{});
     if constexpr (NS > 2) stage(q + 2, std::integral_constant<int, 2>{});
   }
-  // partial result: C/D layout row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), col = lane & 31
+  // partial result: C/D layout slot row = (r & 3) + 8 (r >> 2) + 4 (lane >> 5), slot column = lane & 31; slot s of a tile is
+  // feature 2 s (s < 16) or 2 (s - 16) + 1: row feature = 2 (r & 3) + 16 ((r >> 2) & 1) + 8 (lane >> 5) + (r >> 3)
   // (the lane index is made opaque: hipcc otherwise computes the store addresses in front of the stage loop and carries
   //  them through it next to the 128 accumulators)
   int lo_ = lane;
   asm volatile("" : "+v"(lo_));
-  float* pl = part + (long long)(row0 + 4 * (lo_ >> 5)) * S::NIN + col0 + (lo_ & 31);
+  const int lc = lo_ & 31;
+  float* pl = part + (long long)(row0 + 8 * (lo_ >> 5)) * S::NIN + col0 + (lc < 16 ? 2 * lc : 2 * (lc - 16) + 1);
 #pragma unroll
   for (int ti = 0; ti < WR; ++ti)
 #pragma unroll
     for (int tj = 0; tj < WC; ++tj)
 #pragma unroll
       for (int r = 0; r < 16; ++r)
-        pl[(32 * ti + (r & 3) + 8 * (r >> 2)) * S::NIN + 32 * tj] = acc[ti][tj][r];
+        pl[(32 * ti + 2 * (r & 3) + 16 * ((r >> 2) & 1) + (r >> 3)) * S::NIN + 32 * tj] = acc[ti][tj][r];
   // db: the octets' column sums meet in LDS (the fragment buffers are idle now)
   __syncthreads();
   if (is_g) {
