@@ -349,14 +349,21 @@ def train_shape_legs(M, synth, torch, dev, steps=6):
         return m.to(dev)
 
     def med(f):
+        import gc
         f()
+        f()                                  # (two warm-up steps: the first one after empty_cache() goes to the driver for every dump)
         torch.cuda.synchronize()
-        ts = []
-        for _ in range(steps):
-            t0 = time.perf_counter()
-            f()
-            torch.cuda.synchronize()
-            ts.append((time.perf_counter() - t0) * 1e3)
+        gc.collect()
+        gc.disable()                         # (a collection inside a 15 ms step is a visible fraction of it)
+        try:
+            ts = []
+            for _ in range(steps + 2):
+                t0 = time.perf_counter()
+                f()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) * 1e3)
+        finally:
+            gc.enable()
         return float(sorted(ts)[len(ts) // 2])
 
     crit = M.get_loss(dict(type="MSE"))
