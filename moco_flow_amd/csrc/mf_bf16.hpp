@@ -914,7 +914,7 @@ MF_D void mask_put(const RowDump& d, const f32x16& acc, int t, int h, unsigned& 
   if (!d.masks) return;
   // (x > 0 as a bit costs a compare + select + shift-or per element, 48 VALU per tile: +0.33 ms per launch of the joint step's
   //  dumping forward against -0.7 ms in the two backward chains that read 64 bytes instead of 2 KiB per row)
-  auto pos = [](float x) { return __builtin_bit_cast(int, x) > 0 ? 1u : 0u; };
+  auto pos = [](float x) { return relu_bit(x); };                     // (v_med3_i32: mf_core.hpp)
   unsigned a = 0, b = 0;
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
