@@ -2236,3 +2236,66 @@ def test_nerf_backward_three_products_vs_fp32_chain(M, P):
             assert torch.equal(a == 0, b == 0) or l == 8            # same ReLU masks (xyz_encoding_final has none)
         print(f"P={P} extra={ext_type}: three-product dX chain vs the fp32 chain, worst max-rel per layer block {worst:.2e}")
         assert worst <= TOL
+
+
+class _GuardedTorch:
+    """`torch` as rendering.py sees it, with every device allocation of `empty` carved out of an arena that carries a sentinel
+    band on either side (test_training_forward_dumps_stay_inside_their_tensors)."""
+    GUARD = 2048                                            # elements on either side
+
+    def __init__(self, real):
+        self._real, self.arenas = real, []
+
+    def __getattr__(self, k):
+        return getattr(self._real, k)
+
+    def empty(self, *shape, device=None, dtype=None, **kw):
+        real = self._real
+        if len(shape) == 1 and isinstance(shape[0], (tuple, list, real.Size)):
+            shape = tuple(shape[0])
+        dt = dtype or real.float32
+        n = int(np.prod(shape)) if len(shape) else 1
+        if device is None or real.device(device).type != "cuda" or dt not in (real.float32, real.int32) or n == 0:
+            return real.empty(shape, device=device, dtype=dtype, **kw)
+        fill = 1234567.0 if dt == real.float32 else 0x5A5A5A5A
+        arena = real.full((n + 2 * self.GUARD,), fill, device=device, dtype=dt)
+        self.arenas.append((arena, n, fill))
+        return arena[self.GUARD:self.GUARD + n].view(shape)
+
+    def check(self):
+        for arena, n, fill in self.arenas:
+            lo, hi = arena[:self.GUARD], arena[self.GUARD + n:]
+            assert bool((lo == fill).all()) and bool((hi == fill).all()), (tuple(arena.shape), n)
+        return len(self.arenas)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+def test_training_forward_dumps_stay_inside_their_tensors(M, prec):
+    """The training forward writes its dump planes (activations, ReLU bit rows, per-step NoF rows, rgb / sigma, points) and its
+    per-ray outputs INSIDE their tensors also where a tile is ragged: 7 rays x 64 samples (448 samples: three and a half 128-sample
+    tiles, the last waves without a single row) with local + global chains, every output carved out of an arena with 8 KiB
+    sentinel bands on both sides (round 5: the three-product kernel's row stores are buffer stores whose row-less lanes carry an
+    out-of-range offset instead of an exec mask).  The valid part is fully written: no sentinel left inside the activations."""
+    from moco_flow_amd import rendering, _lib as L
+    c = dict(RENDER_CASES["r_moco_global"])
+    seed = int(load_golden("r_moco_global")["meta_seed"])
+    n, S = 7, c["S"]
+    rays, bg = case_inputs(c, seed, n=n)
+    rays, bg = rays.cuda(), bg.cuda()
+    embs, nerfs, kw = build_case(M, c, seed, device="cuda")
+    t = torch.linspace(0, 1, S, device="cuda")
+    z = (rays[:, 6:7] * (1 - t) + rays[:, 7:8] * t).contiguous()
+    g = _GuardedTorch(torch)
+    rendering.torch = g
+    try:
+        with torch.no_grad():
+            out = rendering._render_pass(rays, bg, z, None, False, None, L.MF_ACT_RELU, nerfs[0], embs, kw["nof_models"],
+                                         kw["nof_embeddings"], True, True, False, True, dump=True, precision=prec)
+            torch.cuda.synchronize()
+    finally:
+        rendering.torch = torch
+    assert g.check() >= 8                                    # outputs + dump planes all went through the guarded allocator
+    acts = out["acts"]
+    assert acts.shape[0] == n * S and not bool((acts == 1234567.0).any())     # every row of the valid part written
+    assert bool(torch.isfinite(out["rgb"]).all())
