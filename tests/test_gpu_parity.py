@@ -2255,9 +2255,9 @@ class _GuardedTorch:
             shape = tuple(shape[0])
         dt = dtype or real.float32
         n = int(np.prod(shape)) if len(shape) else 1
-        if device is None or real.device(device).type != "cuda" or dt not in (real.float32, real.int32) or n == 0:
+        if device is None or real.device(device).type != "cuda" or dt not in (real.float32, real.int32, real.uint8) or n == 0:
             return real.empty(shape, device=device, dtype=dtype, **kw)
-        fill = 1234567.0 if dt == real.float32 else 0x5A5A5A5A
+        fill = 1234567.0 if dt == real.float32 else (0x5A5A5A5A if dt == real.int32 else 0x5A)
         arena = real.full((n + 2 * self.GUARD,), fill, device=device, dtype=dt)
         self.arenas.append((arena, n, fill))
         return arena[self.GUARD:self.GUARD + n].view(shape)
@@ -2299,3 +2299,39 @@ def test_training_forward_dumps_stay_inside_their_tensors(M, prec):
     acts = out["acts"]
     assert acts.shape[0] == n * S and not bool((acts == 1234567.0).any())     # every row of the valid part written
     assert bool(torch.isfinite(out["rgb"]).all())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P", [37, 4099])
+def test_weight_grads_outputs_and_scratch_stay_inside(M, P):
+    """mf_weight_grads_p(MF_PREC_BF16X3): the narrow blocks run on zero-padded 128 x 128 / 256 x 128 three-product blocks whose
+    partials are wider than the results -- the reduction must write the (rows, n_in) layout of the fp32 shapes only, the partials
+    must fit the planned scratch: every dW / db / scratch allocation of autograd.weight_grads inside sentinel bands."""
+    from moco_flow_amd import autograd as A
+    dev = torch.device("cuda")
+    gen = torch.Generator(device="cpu").manual_seed(5 + P)
+    rn = lambda *s: torch.randn(*s, generator=gen).to(dev)
+    W, stride, ns = 256, 9 * 256 + 128, 4 * 128 + 16
+    acts, gpre, emb, ext, ghead = rn(P, stride), rn(P, stride), rn(P, 64), rn(P, 32), rn(P, 4)
+    nacts, ngpre, emb80 = rn(P, ns), rn(P, ns), rn(P, 80)
+    sl = lambda t, l, w=W: t[:, l * W:l * W + w]
+    nsl = lambda t, l, w=128: t[:, l * 128:l * 128 + w]
+    jobs = [(sl(gpre, 1), sl(acts, 0), 256, 256, True), (sl(gpre, 9, 128), sl(acts, 8), 128, 256, True), (sl(gpre, 0), emb, 256, 64, True),
+            (sl(gpre, 9, 128), ext, 128, 32, True), (ghead, acts[:, 7 * W:7 * W + 640], 4, 640, True),
+            (nsl(ngpre, 1), nsl(nacts, 0), 128, 128, True), (nsl(ngpre, 0), emb80, 128, 80, True), (ngpre[:, 512:524], nsl(nacts, 3), 12, 128, True)]
+    g = _GuardedTorch(torch)
+    old = A.WGRAD_PRECISION
+    A.torch = g
+    try:
+        A.set_wgrad_precision("bf16x3")
+        res = A.weight_grads(jobs, P, dev)
+        torch.cuda.synchronize()
+    finally:
+        A.torch = torch
+        A.set_wgrad_precision(old)
+    assert g.check() >= 2 * len(jobs) + 1 and any(a.dtype == torch.uint8 for a, _, _ in g.arenas)      # (+ the scratch buffer of the partials)
+    for (G, X, no, ni, b), (dW, db) in zip(jobs, res):
+        want = G.double().t() @ X.double()
+        if ni == 640:
+            want[:, 256:512] = 0
+        assert float((dW[:no].double() - want).norm() / want.norm()) <= 3e-5 and not bool((dW == 1234567.0).any())
