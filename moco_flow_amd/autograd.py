@@ -160,6 +160,18 @@ def set_wgrad_precision(p: str):
     WGRAD_PRECISION = p
 
 
+_WGRAD_ARRAY_TYPES = {}
+
+
+def _wgrad_items(n):
+    """The ctypes array type of n items, made once per n (every `mf_wgrad_item * n` is a NEW type object, and type objects are
+    cyclic garbage: a few per training step for the collector)."""
+    t = _WGRAD_ARRAY_TYPES.get(n)
+    if t is None:
+        t = _WGRAD_ARRAY_TYPES[n] = L.mf_wgrad_item * n
+    return t
+
+
 def weight_grads(jobs, P, dev):
     """mf_weight_grads_p: jobs = [(G, X, n_out, n_in, want_bias)] with G / X fp32 device matrices (column
     slices allowed) -> [(dW (rows, n_in), db (rows,) | None)] in ONE persistent HIP launch (two when WGRAD_PRECISION is
@@ -169,7 +181,7 @@ def weight_grads(jobs, P, dev):
         return []
     if n > L.MF_WG_MAX_ITEMS:
         raise RuntimeError(f"weight_grads: {n} items (max {L.MF_WG_MAX_ITEMS})")
-    items = (L.mf_wgrad_item * n)()
+    items = _wgrad_items(n)()
     outs = []
     for it, (G, X, n_out, n_in, bias) in zip(items, jobs):
         rows, cols = _WG_BLOCK[(n_out, n_in)]

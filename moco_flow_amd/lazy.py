@@ -28,11 +28,16 @@ class ConsensusPass:
     """What the vectors of one pass share: the (N,S) alphas, the per-sample distance planes, the cached masked sums and
     the cached compacted tensors (one compaction serves both vectors)."""
 
-    def __init__(self, alphas, planes, stats_fn, compact_fn, differentiable, mean_fn=None):
+    def __init__(self, alphas, planes, stats_fn, compact_fn, differentiable, mean_fn=None, pass_self=False):
         self.alphas, self.planes = alphas, planes            # planes: {"local": (N,S), "global": (N,S)} (or callables making them)
         self._stats_fn, self._compact_fn = stats_fn, compact_fn
         self.differentiable = differentiable
         self._mean_fn = mean_fn                              # training passes: key -> the mean as ONE autograd node
+        # pass_self: compact_fn(self) / mean_fn(self, key) -- callbacks that need the pass get it as an argument.  Closing over
+        # the variable that holds the pass made pass -> callback -> cell -> pass a reference CYCLE that kept the whole training
+        # pass (its 9 GB of dump planes in the joint stage's step) alive until Python's cyclic collector happened to run
+        # (round 5: tools/r05_gc_check.py -- the allocator then went to the driver for every step's dumps: 80-240 ms steps).
+        self._pass_self = pass_self
         self._stats, self._vectors, self._mask = None, None, None
         self._mean_taken = set()
 
@@ -67,7 +72,8 @@ class ConsensusPass:
         """The compacted tensor of plane ``key``.  (Keyed: under autograd the planes of a pass are registered one by one, and
         an eager caller -- LAZY_CONSENSUS off -- asks for "local" before "global" exists.)"""
         if self._vectors is None or key not in self._vectors:
-            self._vectors = {**self._compact_fn(), **(self._vectors or {})}      # (tensors already handed out stay)
+            made = self._compact_fn(self) if self._pass_self else self._compact_fn()
+            self._vectors = {**made, **(self._vectors or {})}                    # (tensors already handed out stay)
         return self._vectors[key]
 
 
@@ -102,7 +108,8 @@ class MaskedVector:
             # the float64 (sum, count) below (two tiny launches, not on the trainer's path)
             return self._g.stats()[self._k][2]
         if len(self._parts) == 1 and self._g.differentiable and self._g._mean_fn is not None:
-            return self._g._mean_fn(self._k)                  # one autograd node (autograd.ConsensusMean)
+            g = self._g                                       # one autograd node (autograd.ConsensusMean)
+            return g._mean_fn(g, self._k) if g._pass_self else g._mean_fn(self._k)
         s, c = self._sum_count()
         return (s / c).to(torch.float32)
 

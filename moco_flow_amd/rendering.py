@@ -507,9 +507,12 @@ def _attach_explicit(result, rays, background, nerf_embs, nerf_models, nof_embs,
             planes, recon_of = {}, {}
             # torch.mean(vector) -- all the trainer asks of these entries -- is ONE autograd node on the distances the fused
             # pass wrote (autograd.ConsensusMean); the per-sample planes are only built (torch ops) when something else is asked
+            # (the callbacks take the pass as an argument: closing over `group` would tie it into a reference cycle with them,
+            #  and the pass -- every dump plane of it -- would live until the cyclic collector runs, lazy.ConsensusPass)
             group = ConsensusPass(p["alphas"], planes, lambda: _pass_stats(p, N),
-                                  lambda: {k: torch.masked_select(group.plane(k), _mask_of(p["alphas"])) for k in planes}, True,
-                                  mean_fn=(lambda k: A.ConsensusMean.apply(group, k, p, rays, z, recon_of[k])) if FUSED_CONSENSUS_MEAN else None)
+                                  lambda g: {k: torch.masked_select(g.plane(k), _mask_of(p["alphas"])) for k in planes}, True,
+                                  mean_fn=(lambda g, k: A.ConsensusMean.apply(g, k, p, rays, z, recon_of[k])) if FUSED_CONSENSUS_MEAN else None,
+                                  pass_self=True)
 
             def vector(key, recon):
                 # torch.mean(|xyz - recon|[mask], dim=1) of rendering.py:310-314 as mean-then-select (same numbers; the backward
