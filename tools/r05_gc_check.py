@@ -49,3 +49,37 @@ for i in range(4):
     t0 = time.perf_counter(); stage1(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
     print("stage1 step", i, f"{dt:7.2f} ms  allocated {torch.cuda.memory_allocated()/1e9:6.2f} GB (base {base/1e9:.2f})  reserved {torch.cuda.memory_reserved()/1e9:6.2f} GB", flush=True)
 gc.enable()
+
+# stage 2 (the NoFs as modules on correspondence points) and the joint step through the fused loss partials (_loss_target)
+del nerfs1, rays1, bg1, gt1
+torch.cuda.empty_cache()
+from moco_flow_amd import losses
+B = 200000
+nofs2 = [load(M.NoF(4, 128, 33, [2], "ind", 33, True), synth.nof_state(0, use_quat=True, tag=t, head_scale=0.25)) for t in ("bw", "fw")]
+exyz, eind = M.Embedding(3, 5), M.Embedding(1, 16)
+q, c2 = torch.randn(B, 3, device=dev) * 0.5, torch.randn(B, 3, device=dev) * 0.5
+ind = torch.full((B, 1), -0.4, device=dev)
+def stage2():
+    for m in nofs2:
+        m.zero_grad(set_to_none=True)
+    loss = 0
+    for m, src, dst in ((nofs2[0], q, c2), (nofs2[1], c2, q)):
+        with torch.no_grad():
+            inp = torch.cat([exyz(src), eind(ind)], -1)
+        loss = loss + torch.nn.functional.mse_loss(m(inp, src), dst)
+    loss.backward()
+nerfs, nofs, rays, bg, gt, embs, kw = bench.joint_stage_setup(M, synth, torch, dev, 1024)
+def joint_fused():
+    for m in nerfs + nofs:
+        m.zero_grad(set_to_none=True)
+    res = M.render_rays(rays, bg, embs, nerfs, _loss_target=gt, **kw)
+    t = losses.from_partials(res["loss_partials"])
+    (t["img_loss"] + 0.1 * t["nof_local"] + 0.1 * t["nof_global"]).backward()
+for name, f in (("stage2", stage2), ("joint, fused loss", joint_fused)):
+    f(); f(); torch.cuda.synchronize(); gc.collect()
+    base = torch.cuda.memory_allocated()
+    gc.disable()
+    for i in range(3):
+        t0 = time.perf_counter(); f(); torch.cuda.synchronize(); dt = (time.perf_counter() - t0) * 1e3
+        print(name, "step", i, f"{dt:7.2f} ms  allocated {torch.cuda.memory_allocated()/1e9:6.2f} GB (base {base/1e9:.2f})", flush=True)
+    gc.enable()
