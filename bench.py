@@ -410,6 +410,16 @@ def train_shape_legs(M, synth, torch, dev, steps=6):
         loss.backward()
 
     out["joint"] = {"ms_per_step": med(joint), "rays": N, "samples_per_ray": 384}
+    # the whole training ITERATION as a trainer runs it: + the optimizer step (Adam over the four networks), after which every
+    # network re-packs its weight streams at the next forward (round 5: +0.26 ms)
+    opt = torch.optim.Adam([q for m in nerfs + nofs for q in m.parameters()], lr=1e-7)
+
+    def joint_iteration():
+        joint()
+        opt.step()
+
+    out["joint_with_optimizer"] = {"ms_per_step": med(joint_iteration), "rays": N, "samples_per_ray": 384, "optimizer": "Adam"}
+    del opt
     # round 5: the same step with the opt-in three-product training forward, now for passes WITH NoF too
     # (render_kernel_bf16<true, true, true>; forward values to 1e-4, gradients inside the fp32 oracle's own noise floor against
     # the float64 truth, tests/test_gpu_parity.py::test_train_forward_bf16x3_moco) -- reported beside the default, never instead
