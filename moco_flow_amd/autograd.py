@@ -399,6 +399,7 @@ class NofGradSink:
                 if g[n] is not None:
                     total[n] = g[n] if total[n] is None else total[n] + g[n]
         self.gpre, self.filled = None, set()
+        self.acts = self.emb = None                       # (this network's dump planes of the pass: dead now, see NerfSamples.backward)
         return [total[n] for n in names]
 
 
@@ -635,6 +636,12 @@ class NerfSamples(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out):
         m, acts, emb, extra = ctx.m, ctx.acts, ctx.emb_in, ctx.extra_in
+        if acts is None:
+            raise RuntimeError("NerfSamples: backward ran twice through one forward (its activation dump is released after the first; "
+                               "retain_graph is not supported by the explicit backward)")
+        # the dump (9.7 KB per sample) is dead after this call: released HERE, not when the caller drops the result dict whose graph
+        # holds this node -- a loop that keeps `results` until the next iteration overwrites it would otherwise hold two steps' dumps
+        ctx.acts = ctx.emb_in = ctx.extra_in = None
         rgbsig, xin = ctx.saved_tensors
         D, W = m.D, m.W
         names = [n for n, _ in m.named_parameters()]

@@ -29,5 +29,6 @@ for i in range(n_it):
     if i == 5:
         res0 = torch.cuda.memory_reserved()
 s = sorted(ts[5:])
+print("iterations above 2 x the median:", [(i, round(t, 1)) for i, t in enumerate(ts) if i >= 5 and t > 2 * s[len(s) // 2]])
 print(f"{n_it} iterations: median {s[len(s)//2]:.2f} ms, p99 {s[int(len(s)*0.99)]:.2f}, max {s[-1]:.2f}; reserved {res0/1e9:.2f} GB after 5, {torch.cuda.memory_reserved()/1e9:.2f} GB at the end; "
       f"peak allocated {torch.cuda.max_memory_allocated()/1e9:.2f} GB; loss {(lv if os.environ.get('MF_SOAK_DEL') == '1' else float(loss)):.5f}")
