@@ -70,33 +70,38 @@ def peak_of(cfg):
 
 
 CONFIGS = {
-    "C2": dict(net="dir", precision="f32", rays=4096, S=64, M=0, nof=None,
+    "C2": dict(short="C2 NeRF 8x256 fp32 4096x64", net="dir", precision="f32", rays=4096, S=64, M=0, nof=None,
                what="C2: canonical NeRF 8x256 (xyz F=10, dir F=4), fused HIP encode+MLP+composite, fp32 MFMA"),
-    "C2b": dict(net="dir", precision="bf16", rays=4096, S=64, M=0, nof=None,
+    # the main line at N > 1 (north_star: "partition batches across the 8 GPUs ... with an RCCL all-reduce of the pixel/loss
+    # tensor"): the SAME kernel, dtype and per-rank batch as C2, + the MSE partials of the rank's pixels (mf_loss_partials) and
+    # their 96-byte all-reduce inside the step -- so the driver's 1 -> N curve compares like with like AND carries the collective
+    "C2dp": dict(short="C2 NeRF 8x256 fp32 4096x64/rank + loss all-reduce", net="dir", precision="f32", rays=4096, S=64, M=0, nof=None, loss=True, profile="C2",
+                 what="C2 ray-sharded: canonical NeRF 8x256 fp32, 4096 rays x 64 per rank + RCCL all-reduce of the per-batch loss partials"),
+    "C2b": dict(short="C2 shape bf16", net="dir", precision="bf16", rays=4096, S=64, M=0, nof=None,
                 what="C2 shape in bf16 (canonical NeRF, bf16 hidden GEMMs; a kernel-tuning leg, not a BASELINE config)"),
-    "C3f": dict(net="ind", precision="f32", rays=4096, S=64, M=0, nof="local",
+    "C3f": dict(short="C3 chain fp32", net="ind", precision="f32", rays=4096, S=64, M=0, nof="local",
                 what="C3 chain in fp32 (bw NoF -> NeRF(ind) -> fw NoF, exact-fp32 MFMA; a kernel-tuning leg, not a BASELINE config)"),
-    "C3": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="local",
+    "C3": dict(short="C3 MoCo local bf16 4096x64", net="ind", precision="bf16", rays=4096, S=64, M=0, nof="local",
                what="C3: bw NoF -> NeRF(ind) -> fw NoF local consensus chain, bf16 hidden GEMMs"),
-    "C2x": dict(net="dir", precision="bf16x3", rays=4096, S=64, M=0, nof=None,
+    "C2x": dict(short="C2 bf16x3", net="dir", precision="bf16x3", rays=4096, S=64, M=0, nof=None,
                 what="C2 in the contract mode of the bf16 pipe (bf16x3: every matrix product as three bf16 products of (hi, lo) "
                      "operand pairs, fp32 accumulation and heads)"),
-    "C3x": dict(net="ind", precision="bf16x3", rays=4096, S=64, M=0, nof="local",
+    "C3x": dict(short="C3 bf16x3", net="ind", precision="bf16x3", rays=4096, S=64, M=0, nof="local",
                 what="C3 in the contract mode of the bf16 pipe (bf16x3: the NeRF's products as three bf16 products of (hi, lo) pairs, "
                      "the NoFs' as three of IEEE-half (hi, lo) pairs, fp32 accumulation, heads and per-ray image-index bias: 1e-4 max-rel)"),
-    "C5x": dict(net="ind", precision="bf16x3", rays=1024, S=64, M=128, nof="global", loss=True,
+    "C5x": dict(short="C5 shard bf16x3", net="ind", precision="bf16x3", rays=1024, S=64, M=128, nof="global", loss=True,
                 what="C5 in the contract mode of the bf16 pipe (bf16x3)"),
-    "C3g": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="global",
+    "C3g": dict(short="C3 + global chain bf16", net="ind", precision="bf16", rays=4096, S=64, M=0, nof="global",
                 what="C3 + global chain (5 NoF evaluations per sample), bf16 hidden GEMMs"),
-    "C4": dict(net="ind", precision="bf16", rays=4096, S=64, M=0, nof="local", loss=True,
+    "C4": dict(short="C4 = C3/rank + loss all-reduce", net="ind", precision="bf16", rays=4096, S=64, M=0, nof="local", loss=True,
                what="C4: C3 ray-sharded (4096 rays per rank) + all-reduce of the per-batch loss partials"),
-    "C5": dict(net="ind", precision="bf16", rays=1024, S=64, M=128, nof="global", loss=True,
+    "C5": dict(short="C5 shard 1024x(64+192) bf16", net="ind", precision="bf16", rays=1024, S=64, M=128, nof="global", loss=True,
                what="C5: coarse 64 + fine 128 (inverse-CDF resample), MoCo local+global chains, bf16, 1024 rays per rank"),
     # BASELINE config 5 at its FULL size on one GPU (the largest single-GPU configuration of `configs`): 8192 rays, not the
     # 1024-ray per-rank shard -- 32 coarse / 96 fine 256-sample tiles per CU instead of one / three
-    "C5full": dict(net="ind", precision="bf16", rays=8192, S=64, M=128, nof="global", loss=True, steps=(40, 10),
+    "C5full": dict(short="C5 8192x(64+192) bf16", net="ind", precision="bf16", rays=8192, S=64, M=128, nof="global", loss=True, steps=(40, 10),
                    what="C5 at full size on ONE GPU: 8192 rays, coarse 64 + fine 128 (inverse-CDF resample), MoCo local+global chains, bf16"),
-    "C5xfull": dict(net="ind", precision="bf16x3", rays=8192, S=64, M=128, nof="global", loss=True, steps=(20, 5),
+    "C5xfull": dict(short="C5 8192x(64+192) bf16x3", net="ind", precision="bf16x3", rays=8192, S=64, M=128, nof="global", loss=True, steps=(20, 5),
                     what="C5 at full size on ONE GPU in the contract mode of the bf16 pipe (bf16x3)"),
 }
 
@@ -242,7 +247,8 @@ def cpu_baseline(cfg, states, rays_np, bg_np, budget_s=30.0):
         times.append(time.perf_counter() - t0)
     med = float(np.median(times))
     sweep_s = ", ".join(f"{t}t {s:.2f}s" for t, s in per_thread.items())
-    return dict(value=n * samples_per_ray(cfg) / med, unit="ray-samples/s", cores=best, kind="port",
+    return dict(value=n * samples_per_ray(cfg) / med, unit="ray-samples/s", cores=best, kind="port", cpu=cpu_model(),
+                sample_short=f"{len(times)} full batches, {'/'.join(map(str, per_thread))}t sweep",
                 sample=f"{len(times)} full {n}x{samples_per_ray(cfg)} batches at the fastest of a thread sweep "
                        f"({sweep_s}), median {med:.3f} s/batch, torch {torch.__version__} CPU fp32, "
                        f"{best} threads on {cpu_model()} ({ncpu} logical CPUs)"), out
@@ -326,12 +332,8 @@ def train_leg(M, torch, models, rays, bg, gt, kw, cfg, steps=10):
         out["flops_per_sample"] = flops
         out["wgrad_precision"] = A.WGRAD_PRECISION
         out["dx_precision"] = A.DX_PRECISION
-        # against the fp32 matrix peak: the forward runs there; with "bf16x3" the dX chain and the large weight-gradient
-        # blocks run on the bf16 pipe (three products) and against HBM, so this is a throughput in units of the fp32 peak,
-        # not a utilisation of one pipe
-        out["mfma_frac"] = n * flops / (ms * 1e-3) / 1e12 / PEAK["f32"]
-        out["mfma_frac_note"] = ("algorithmic FLOP/s of fwd + dX + dW over the fp32 matrix peak (dX chain in " + A.DX_PRECISION +
-                                 ", dW blocks in " + A.WGRAD_PRECISION + ")")
+        # (no single roofline fraction here: the forward runs on the fp32 matrix pipe, the dX chain and the large weight-gradient
+        #  blocks on the bf16 pipe (three products) and against HBM -- a sum over one pipe's peak is not a utilisation)
     return out
 
 
@@ -790,7 +792,7 @@ def run_config(name, a, ctx, steps, warmup, main):
     flops_launch = launch_samples * flops_per_sample(cfg)
     achieved = flops_launch / (kernel_ms * 1e-3) / 1e12
     peak = peak_of(cfg)
-    traffic, traffic_src, prof = traffic_of(name)
+    traffic, traffic_src, prof = traffic_of(cfg.get("profile", name))
     alg_bytes = algorithmic_bytes(cfg, launch_samples)
     launches = 2 if cfg["M"] else 1
     # three readings of the same fraction, so that they are never confused:
@@ -798,12 +800,14 @@ def run_config(name, a, ctx, steps, warmup, main):
     #   frac_step        the whole step's algorithmic FLOP / ms_per_step of the timed region (everything a step does)
     #   frac_rocprof_avg the rocprofv3 --kernel-trace average of the same command in profiles/ (+ MFMA busy and the effective
     #                    clock of that run: busy x GHz / 2.4 / (issued / algorithmic MFMAs) = the fraction)
-    rp = {}
+    # everything below comes from the COMMITTED profiles of this same command (profiles/traffic.json, written by
+    # tools/summarize_prof.py) and does not move with this run: kept apart under "from_profiles" 
+    rp = {"source": traffic_src, "traffic": traffic, "traffic_ratio": (traffic / alg_bytes) if traffic else None}
     if prof.get("rocprof_avg_us"):
         # (with a fine pass the trace's average runs over coarse AND fine dispatches of the same kernel, one of each per step:
         #  the step's algorithmic FLOP over launches x average)
-        rp = {"frac_rocprof_avg": flops_step / (launches * prof["rocprof_avg_us"] * 1e-6) / 1e12 / peak, "rocprof_avg_us": prof["rocprof_avg_us"],
-              "mfma_busy": prof.get("mfma_busy"), "ghz": prof.get("ghz"), "rocprof_source": prof.get("profile")}
+        rp.update({"frac_rocprof_avg": flops_step / (launches * prof["rocprof_avg_us"] * 1e-6) / 1e12 / peak, "rocprof_avg_us": prof["rocprof_avg_us"],
+                   "mfma_busy": prof.get("mfma_busy"), "ghz": prof.get("ghz"), "profile": prof.get("profile")})
     res = {
         "value": value, "ms_per_step": elapsed / steps * 1e3, "dtype": cfg["precision"],
         "config": {"workload": cfg["what"] + f" [{cfg['precision']}]", "rays_per_gpu": n,
@@ -815,10 +819,9 @@ def run_config(name, a, ctx, steps, warmup, main):
                    "main_has_collective": bool(reducer is not None and world > 1)},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": peak, "peak_note": PEAK_NOTE[cfg["precision"]],
                      "unit": "TFLOP/s", "frac": achieved / peak,
-                     "frac_step": flops_step / (elapsed / steps) / 1e12 / peak, **rp,
+                     "frac_step": flops_step / (elapsed / steps) / 1e12 / peak,
                      "traffic": traffic, "traffic_unit": "B/launch", "traffic_algorithmic": alg_bytes,
-                     "traffic_ratio": (traffic / alg_bytes) if traffic else None,
-                     "traffic_source": traffic_src,
+                     "from_profiles": rp,
                      "traffic_note": "HBM bytes per launch: the weight stream is read once per XCD L2 (8 x the packed weights) + "
                                      "rays / requested (N,S) planes" + (" + the per-ray NoF bias table" if cfg["nof"] and cfg["precision"] != "f32" else "")
                                      + "; algorithmic I/O is 68 B/ray (+ 8 B/sample per requested plane): MFMA-bound, not HBM-bound",
@@ -882,14 +885,170 @@ def run_config(name, a, ctx, steps, warmup, main):
     return res
 
 
+COMPACT_LIMIT = 1800        # bytes: the driver's record keeps the final 2000 characters of stdout
+LEG_FIELDS = ["ms", "frac", "frac_step", "db", "max_rel"]
+
+
+def sig(x, n=4):
+    """x to n significant digits (None / non-finite -> None: the compact line must always json.loads strictly)."""
+    if x is None:
+        return None
+    x = float(x)
+    return float(f"{x:.{n}g}") if x == x and abs(x) != float("inf") else None
+
+
+def compact_leg(r):
+    """One measured configuration as LEG_FIELDS: ms per step, roofline fraction of the dominant kernel (graph replay), roofline
+    fraction of the whole step, PSNR-equivalent dB and worst max-rel of the per-ray outputs against the CPU oracle."""
+    e = r.get("error_vs_cpu") or {}
+    worst = max(e["max_rel"].values()) if e.get("max_rel") else None
+    rf = r["roofline"]
+    return [sig(r["ms_per_step"]), sig(rf["frac"], 3), sig(rf["frac_step"], 3), sig(e.get("psnr_equiv_db")), sig(worst, 2)]
+
+
+def assemble(a, world, main_cfg, res, leg_results, extras):
+    """-> (detail, compact).  `detail` is everything measured (tens of KB: written to gpurun_out/bench_detail_n<N>.json and to
+    stderr); `compact` is the ONE stdout line the driver parses: the contract keys + roofline + cpu_baseline + one array per
+    leg, numbers to 4 significant digits, no prose -- at most COMPACT_LIMIT bytes (tests/test_host_cpu.py holds it to that)."""
+    head = {"metric": "ray-samples/sec (4096 rays x 64 samples)", "value": res["value"], "unit": "ray-samples/s",
+            "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic"}
+    detail = dict(head, config=res["config"], roofline=res["roofline"])
+    for k in ("fwd_bwd", "train_steps", "cpu_baseline", "c1_cpu", "error_vs_cpu", "speedup_vs_cpu", "loss_path", "rccl_ranks_seen"):
+        if k in res:
+            detail[k] = res[k]
+    if leg_results:
+        detail["configs"] = leg_results
+    detail.update(extras)
+
+    rf, cfg = res["roofline"], res["config"]
+    fp = rf.get("from_profiles") or {}
+    compact = dict(head, value=sig(res["value"], 6), ms_per_step=sig(res["ms_per_step"], 5))
+    compact["config"] = {"workload": CONFIGS[main_cfg].get("short", main_cfg),
+                         **{k: cfg[k] for k in ("rays_per_gpu", "samples_per_ray", "global_rays", "sharding", "loss_allreduce", "main_has_collective")}}
+    compact["roofline"] = {"bound": rf["bound"], "achieved": sig(rf["achieved"]), "peak": rf["peak"], "unit": rf["unit"],
+                           "frac": sig(rf["frac"]), "frac_step": sig(rf["frac_step"]), "traffic": None if rf["traffic"] is None else int(sig(rf["traffic"])),
+                           "traffic_algorithmic": rf["traffic_algorithmic"], "kernel": rf["kernel"], "kernel_ms": sig(rf["kernel_ms"]),
+                           "from_profiles": {"frac_rocprof_avg": sig(fp.get("frac_rocprof_avg")), "mfma_busy": sig(fp.get("mfma_busy")),
+                                             "ghz": sig(fp.get("ghz")),
+                                             "profile": (fp.get("profile") or "").replace("profiles/", "").replace("_summary.txt", "") or None}}
+    if "cpu_baseline" in res:
+        cb = res["cpu_baseline"]
+        compact["cpu_baseline"] = {"value": sig(cb["value"]), "unit": cb["unit"], "cores": cb["cores"], "kind": cb["kind"],
+                                   "sample": cb.get("sample_short", cb["sample"])[:60], "cpu": cb.get("cpu", cpu_model())[:40]}
+        compact["speedup_vs_cpu"] = sig(res.get("speedup_vs_cpu"))
+    if "rccl_ranks_seen" in res:
+        compact["rccl_ranks_seen"] = res["rccl_ranks_seen"]
+    e = res.get("error_vs_cpu") or {}
+    if e.get("max_rel"):
+        worst = max(e["max_rel"], key=e["max_rel"].get)
+        compact["error_vs_cpu"] = {"max_rel": sig(e["max_rel"][worst], 3), "key": worst, "db": sig(e.get("psnr_equiv_db"))}
+    compact["leg_fields"] = LEG_FIELDS
+    legs = {} if leg_results else {main_cfg: compact_leg(res)}     # (the main line's own numbers are the top-level keys)
+    for name, r in leg_results.items():
+        legs[name] = compact_leg(r)
+    compact["legs"] = legs
+    if "train_steps" in res:
+        short = {"stage1": "s1", "joint": "joint", "joint_with_optimizer": "joint_adam"}        # (the opt-in forwards: detail only)
+        ts = {short[k]: v for k, v in res["train_steps"].items() if k in short}
+        compact["train_ms"] = {k: sig(v["ms_per_step"]) for k, v in ts.items()}
+        gb = {k: sig(v["hbm_gb_per_step"], 3) for k, v in ts.items() if v.get("hbm_gb_per_step") and k in ("s1", "joint")}
+        if gb:
+            compact["train_hbm_gb"] = gb
+    if "fwd_bwd" in res:
+        compact["fwd_bwd_ms"] = sig(res["fwd_bwd"]["ms_per_step"])
+    if "train_joint_dp" in extras:
+        dp = extras["train_joint_dp"]
+        compact["train_dp_ms"] = {"local": sig(dp["ms_per_step_local"]), "allreduce": sig(dp["ms_per_step_allreduce"])}
+    if "aux" in extras:
+        # roofline fraction per auxiliary path (lattice sigma query, 512^2 image: of the matrix peak; wgrad: of the HBM peak)
+        ax, c = extras["aux"], {}
+        for k, v in ax.items():
+            if k.startswith("lattice_"):
+                c[k.replace("lattice", "lat")] = v["frac"]
+            elif k.startswith("image_"):
+                c["img512"] = v["frac"]
+            elif k == "wgrad" and "nerf13" in v:
+                c["wg_nerf"], c["wg_nof"] = v["nerf13"]["frac_hbm"], v["nof6"]["frac_hbm"]
+        compact["aux_frac"] = c
+    return detail, compact
+
+
+def emit(detail, compact, world):
+    """Detail first (side file + ONE stderr line that does not start with '{'), then the compact line LAST on stdout."""
+    blob = json.dumps(detail)
+    try:
+        if compact.get("dryrun"):
+            raise OSError("dry run: no side file")
+        out = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, "bench_detail_n%d.json" % world), "w") as fh:
+            fh.write(blob + "\n")
+    except OSError as exc:
+        print(f"bench_detail: could not write the side file ({exc})", file=sys.stderr)
+    print("bench_detail " + blob, file=sys.stderr, flush=True)
+    # never out-grow the reporting channel again: shed the optional tails (never the contract keys) until the line fits
+    for k in ("aux_frac", "train_hbm_gb", "train_dp_ms", "fwd_bwd_ms", "train_ms", "error_vs_cpu"):
+        if len(json.dumps(compact)) <= COMPACT_LIMIT:
+            break
+        compact.pop(k, None)
+    while len(json.dumps(compact)) > COMPACT_LIMIT and len(compact.get("legs", {})) > 1:
+        compact["legs"].popitem()
+    line = json.dumps(compact, allow_nan=False)
+    assert len(line) <= COMPACT_LIMIT, len(line)
+    sys.stdout.flush()
+    print(line, flush=True)
+
+
+def leg_names(world):
+    """The short extra legs of a default run: every other BASELINE config at N = 1; at N > 1 the headline WITHOUT its
+    collective (C2: what the C2dp main line adds the loss all-reduce to) + the configs that name a collective (C4, C5)."""
+    return ["C2x", "C3", "C3x", "C3g", "C5", "C5x", "C5full", "C5xfull"] if world == 1 else ["C2", "C4", "C5"]
+
+
+def main_config(a, world):
+    return "C2dp" if (a.config == "C2" and world > 1) else a.config
+
+
+def fake_result(name, world, seed):
+    """MF_BENCH_DRYRUN: a result shaped exactly like run_config()'s, with full-length floats (worst case for the line length)."""
+    cfg = CONFIGS[name]
+    x = 0.123456789012345 + 0.01 * seed
+    with_loss = bool(cfg.get("loss"))
+    prof = traffic_of(cfg.get("profile", name))[2]
+    res = {"value": 118962552.06278363 * world * (1 + x), "ms_per_step": 2.2035841990145855 * (1 + x), "dtype": cfg["precision"],
+           "config": {"workload": cfg["what"] + f" [{cfg['precision']}]", "rays_per_gpu": cfg["rays"], "samples_per_ray": samples_per_ray(cfg),
+                      "global_rays": cfg["rays"] * world, "sharding": f"rays{world}" if world > 1 else "none",
+                      "loss_allreduce": with_loss and world > 1, "main_has_collective": with_loss and world > 1},
+           "roofline": {"bound": "mfma", "achieved": 139.76543219876 * (1 + x), "peak": peak_of(cfg), "peak_note": PEAK_NOTE[cfg["precision"]],
+                        "unit": "TFLOP/s", "frac": 0.88912345678 + 0.001 * seed, "frac_step": 0.8991234567 + 0.001 * seed,
+                        "traffic": 20912345.678, "traffic_unit": "B/launch", "traffic_algorithmic": algorithmic_bytes(cfg, cfg["rays"] * cfg["S"]),
+                        "from_profiles": {"source": "profiles/traffic.json", "traffic": 20912345.678, "traffic_ratio": 7.87654321,
+                                          "frac_rocprof_avg": 0.8887654321, "rocprof_avg_us": 2225.8123, "mfma_busy": 0.9112345,
+                                          "ghz": 2.3512345, "profile": prof.get("profile", "profiles/r06_c5xfull_summary.txt")},
+                        "kernel": "mf_render_pass" + (" (fine pass)" if cfg["M"] else ""), "kernel_ms": 2.15312345678 * (1 + x),
+                        "kernel_ms_how": "dryrun", "flops_per_launch": 311117381632, "samples_per_launch": 262144,
+                        "step_span_ms": 2.21234567, "launches_per_step": 2 if cfg["M"] else 1, "flops_per_step": 311117381632},
+           "error_vs_cpu": {"max_rel": {"rgb_coarse": 4.412345678e-07 * (1 + seed), "depth_coarse": 3.912345678e-07, "opacity_coarse": 2.1e-07},
+                            "l2_rel": {"rgb_coarse": 1.2e-07}, "psnr_equiv_db": 140.12345678, "psnr_key": "rgb_coarse", "sample": "dryrun"},
+           "cpu_baseline": {"value": 125842.77898723527, "unit": "ray-samples/s", "cores": 32, "kind": "port", "cpu": cpu_model(),
+                            "sample": "4 full 4096x64 batches at the fastest of a thread sweep (16t 2.51s, 32t 2.08s, 64t 2.31s), median 2.083 s/batch",
+                            "sample_short": "4 full batches, 16/32/64t sweep"},
+           "speedup_vs_cpu": 945.3123456789}
+    return res
+
+
 def dryrun_worker(a, rank, world):
-    """MF_BENCH_DRYRUN=1 (CPU control-flow test of the self-spawn / rendezvous / reduction path, no GPU):
-    gloo process group, the overlapped loss reducer on CPU tensors, MAX-over-ranks timing, one JSON line."""
+    """MF_BENCH_DRYRUN=1 (CPU control-flow test of the self-spawn / rendezvous / reduction / REPORTING path, no GPU):
+    gloo process group, the ranks-seen all-reduce, the overlapped loss reducer on CPU tensors, MAX-over-ranks timing, then the
+    same assemble() / emit() as a real run over results shaped like run_config()'s with full-length floats -- so the CPU
+    suite holds the compact stdout line to its byte limit and its required keys for every leg set."""
     import torch
     import torch.distributed as dist
     from moco_flow_amd.dist import N_PARTIALS, OverlappedLossReducer
     if world > 1:
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    seen = ranks_seen(torch, dist if world > 1 else None, "cpu")
     red = OverlappedLossReducer(N_PARTIALS, "cpu")
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -900,10 +1059,42 @@ def dryrun_worker(a, rank, world):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dist.barrier()
     if rank == 0:
-        print(json.dumps({"metric": "dryrun", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-                          "reduced": tot[-1].tolist()[0], "elapsed": float(t.item()), "dryrun": True}), flush=True)
+        main_cfg = main_config(a, world)
+        res = fake_result(main_cfg, world, 0)
+        res["rccl_ranks_seen"] = seen
+        legs, extras = {}, {}
+        if not a.no_extra_legs and a.config == "C2":
+            legs = {n: fake_result(n, world, i + 1) for i, n in enumerate(leg_names(world))}
+            if world == 1:
+                ts = lambda ms: {"ms_per_step": ms * 1.0123456789, "rays": 1024, "samples_per_ray": 384, "hbm_gb_per_step": 41.0123456}
+                res["train_steps"] = {"what": "dryrun", "stage1": ts(36.09), "stage1_optin_bf16x3_forward": ts(27.75), "joint": ts(15.56),
+                                      "joint_with_optimizer": ts(15.82), "joint_optin_bf16x3_forward": ts(13.42)}
+                res["fwd_bwd"] = {"ms_per_step": 10.123456789}
+                extras["aux"] = {"lattice_f32": {"pts_s": 140100000.0, "frac": 0.875}, "lattice_x3": {"pts_s": 491100000.0, "frac": 0.575},
+                                 "lattice_x3_nof": {"pts_s": 413300000.0, "frac": 0.617}, "image_512_bf16": {"ms": 56.96, "rs_s": 1010000000.0, "frac": 0.508},
+                                 "wgrad": {"precision": "bf16x3", "data": "relu-like", "nerf13": {"ms": 1.49, "tb_s": 4.35, "frac_hbm": 0.544},
+                                           "nof6": {"ms": 1.012, "tb_s": 4.12, "frac_hbm": 0.515}}}
+            else:
+                extras["train_joint_dp"] = {"ms_per_step_local": 15.5612345, "ms_per_step_allreduce": 15.9812345, "world": world, "buckets": 4,
+                                            "flat_gradient_bytes": 5300000}
+        detail, compact = assemble(a, world, main_cfg, res, legs, extras)
+        compact["dryrun"] = [tot[-1].tolist()[0], sig(float(t.item()), 2)]            # [reduced partial, elapsed s]
+        emit(detail, compact, world)
     if world > 1:
         dist.destroy_process_group()
+
+
+def ranks_seen(torch, dist, dev):
+    """How many ranks the process group's all-reduce actually reached: a ones-vector summed through the backend the run uses
+    ("nccl" = RCCL on the GPU box) BEFORE the timed region -- on the compact line as `rccl_ranks_seen`, so a scaling record
+    proves the collective saw N ranks.  1 without a process group."""
+    if dist is None:
+        return 1
+    ones = torch.ones(8, device=dev, dtype=torch.float32)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    v = ones.cpu().tolist()
+    assert all(x == v[0] for x in v), v
+    return int(v[0])
 
 
 def worker(a):
@@ -932,56 +1123,29 @@ def worker(a):
     rendering.STRICT_RNG = False        # noise_std = 0: do not launch the reference's dead randn (rendering.py:166)
     M._lib.lib()                        # fail loudly if the HIP library is missing
     ctx = dict(M=M, synth=synth, rendering=rendering, dist=dist, dev=dev, rank=rank, world=world)
+    seen = ranks_seen(torch, dist, dev)
 
-    main_cfg = a.config
+    main_cfg = main_config(a, world)
     res = run_config(main_cfg, a, ctx, a.steps, a.warmup, main=True)
-    line = {
-        "metric": "ray-samples/sec (4096 rays x 64 samples)", "value": res["value"], "unit": "ray-samples/s",
-        "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": res["ms_per_step"],
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": res["dtype"], "data": "synthetic",
-        "config": res["config"], "roofline": res["roofline"],
-    }
-    for k in ("fwd_bwd", "train_steps", "cpu_baseline", "c1_cpu", "error_vs_cpu", "speedup_vs_cpu", "loss_path"):
-        if k in res:
-            line[k] = res[k]
+    res["rccl_ranks_seen"] = seen
+    leg_results, extras = {}, {}
     if not a.no_extra_legs and a.config == "C2":
-        legs = ["C2x", "C3", "C3x", "C3g", "C5", "C5x", "C5full", "C5xfull"] if world == 1 else ["C4", "C5"]
-        line["configs"] = {}
-        for name in legs:
+        for name in leg_names(world):
             # sub-millisecond passes: 100 warm-up steps (a handful leaves the clocks ramping -- C3 measured 0.372 ms/step
             # after 5 warm-up steps, 0.345 after 100, kernel 0.346 -- profiles/README.md) and 200 timed ones
             k_leg, w_leg = CONFIGS[name].get("steps", (200, 100)) if a.steps >= 10 else (a.steps, a.warmup)
             r = run_config(name, a, ctx, k_leg, w_leg, main=False)
-            line["configs"][name] = {k: r[k] for k in ("value", "ms_per_step", "dtype", "config", "roofline", "error_vs_cpu", "loss_path",
-                                                       "cpu_baseline", "speedup_vs_cpu") if k in r}
-            line["configs"][name].update(steps=k_leg, warmup=w_leg)
-    # LAST key: a compact summary of every measured configuration (the driver's record keeps the final 2000 characters of
-    # the line; the full objects above may fall off it).  Per config: ms per step, dominant kernel ms, roofline fraction,
-    # PSNR-equivalent (dB) and the worst max-rel of the per-ray outputs against the CPU oracle.
-    def compact(r):
-        e = r.get("error_vs_cpu") or {}
-        worst = max(e["max_rel"].values()) if e.get("max_rel") else None
-        sig = lambda x, n=4: None if x is None else float(f"{x:.{n}g}")
-        return {"ms": sig(r["ms_per_step"]), "kernel_ms": sig(r["roofline"]["kernel_ms"]), "frac": sig(r["roofline"]["frac"], 3),
-                "frac_step": sig(r["roofline"]["frac_step"], 3), "db": sig(e.get("psnr_equiv_db"), 4), "max_rel": sig(worst, 2)}
-    legs = {main_cfg: compact(res)}
-    for name, r in line.get("configs", {}).items():
-        legs[name] = compact(r)
-    if "train_steps" in res:
-        legs["train_ms"] = {k: float(f"{v['ms_per_step']:.4g}") for k, v in res["train_steps"].items() if isinstance(v, dict)}
+            leg_results[name] = {k: r[k] for k in ("value", "ms_per_step", "dtype", "config", "roofline", "error_vs_cpu", "loss_path",
+                                                   "cpu_baseline", "speedup_vs_cpu") if k in r}
+            leg_results[name].update(steps=k_leg, warmup=w_leg)
     if not a.no_extra_legs and not a.no_train_leg and a.config == "C2":
         if world > 1:
-            line["train_joint_dp"] = train_dp_leg(M, synth, torch, dev, dist, rank, world)
-            legs["train_dp_ms"] = {"local": float(f"{line['train_joint_dp']['ms_per_step_local']:.4g}"),
-                                   "allreduce": float(f"{line['train_joint_dp']['ms_per_step_allreduce']:.4g}")}
+            extras["train_joint_dp"] = train_dp_leg(M, synth, torch, dev, dist, rank, world)
         else:
-            line["aux"] = aux_legs(M, synth, torch, dev)
-            legs["aux"] = line["aux"]
-    if "fwd_bwd" in res:
-        legs["fwd_bwd_ms"] = float(f"{res['fwd_bwd']['ms_per_step']:.4g}")
-    line["legs"] = legs
+            extras["aux"] = aux_legs(M, synth, torch, dev)
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        detail, compact = assemble(a, world, main_cfg, res, leg_results, extras)
+        emit(detail, compact, world)
     if dist is not None:
         dist.destroy_process_group()
 

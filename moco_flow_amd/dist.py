@@ -9,6 +9,7 @@ outputs reproduces the single-GPU result row for row.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Callable, Dict, Optional, Tuple
 
 import torch
@@ -128,6 +129,9 @@ class OverlappedLossReducer:
         return out
 
 
+_NEVER = object()           # member of a bucket's pending set that no hook ever removes
+
+
 class _Done:
     def wait(self):
         return True
@@ -224,7 +228,8 @@ class GradReducer:
             ps = list(b.parameters()) if hasattr(b, "parameters") else list(b)
             if not ps:
                 continue
-            self.buckets.append({"name": name, "params": ps, "lo": 0, "hi": 0, "pending": None, "work": None})
+            self.buckets.append({"name": name, "params": ps, "lo": 0, "hi": 0, "pending": None, "work": None, "ready": False,
+                                 "index": len(self.buckets)})
             params += ps
         if not params:
             raise ValueError("GradReducer: no parameters")
@@ -243,12 +248,21 @@ class GradReducer:
         self.active = dist.is_available() and dist.is_initialized()
         self.world = dist.get_world_size(group) if self.active else 1
         self.issued = 0                                         # collectives issued so far (tests)
+        self.issue_log = []                                     # bucket index of every collective, in issue order (tests)
         self._handles = {}
+        self._defer = 0
+        # issue order: reverse registration (the backward reaches the last network first) until the first wait() has agreed
+        # on the order observed in the first backward
+        self._order = list(range(len(self.buckets)))[::-1]
+        self._order_agreed, self._observed = False, []
         self._register()
 
     def _register(self):
         # torch refuses hooks on tensors that do not require grad: a parameter frozen now gets its hook once it is unfrozen
-        # (checked at every wait(); until then _issue() picks its gradient up, so a missing hook only costs overlap)
+        # (checked at every wait()).  Until it has one, its bucket is NOT issued from the hooks (see _hook: a gradient that
+        # lands after the bucket went out would never be reduced) -- the whole bucket waits for wait(): costs overlap for one
+        # step, never correctness (the coarse2fine transition unfreezes the NeRF trunk while rgb /
+        # xyz_encoding_final / extra_encoding of the same bucket already train, trainer_moco_flow.py:391-404)
         for b in self.buckets:
             for p in b["params"]:
                 if p.requires_grad and id(p) not in self._handles:
@@ -266,17 +280,48 @@ class GradReducer:
             view.copy_(p.grad)
             p.grad = view
 
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation over several backwards: inside this context the hooks only adopt the gradients into the
+        flat buffer (autograd then accumulates in place), nothing is issued; run the LAST backward outside it (its hooks
+        issue the buckets as usual) or call wait() right after the context (wait() issues what is left)."""
+        self._defer += 1
+        try:
+            yield self
+        finally:
+            self._defer -= 1
+            for b in self.buckets:
+                b["pending"] = None
+
     def _hook(self, p):
         b = self.slot[id(p)][2]
         if b["work"] is not None:
-            raise RuntimeError(f"GradReducer: gradient for bucket {b['name']} after its all-reduce was issued "
-                               f"(call wait() once per backward; gradient accumulation over several backwards: wait() after the last)")
-        if b["pending"] is None:
-            b["pending"] = {id(q) for q in b["params"] if q.requires_grad and id(q) in self._handles}
+            raise RuntimeError(f"GradReducer: gradient for bucket {b['name']} after its all-reduce was issued -- one backward per "
+                               f"wait(); for gradient accumulation run all but the last backward under `with reducer.no_sync():`")
         if p.grad is not None:
             self._adopt(p)
+        if self._defer:
+            return
+        if b["pending"] is None:
+            b["pending"] = {id(q) for q in b["params"] if q.requires_grad and id(q) in self._handles}
+            if any(q.requires_grad and id(q) not in self._handles for q in b["params"]):
+                b["pending"].add(_NEVER)       # a trainable parameter without a hook (unfrozen since the last wait()): leave the bucket to wait()
         b["pending"].discard(id(p))
         if not b["pending"]:
+            b["ready"] = True
+            self._observed.append(b["index"])
+            self._launch_ready()
+
+    def _launch_ready(self):
+        """Issue, IN self._order, every bucket that is ready and whose predecessors in that order have gone out: all ranks
+        issue the same collectives in the same order on the communicator whatever order their hooks complete in (a rank
+        with no rays, a pass whose NoF got no gradient there: ADVICE r5) -- what DDP does with its bucket indices."""
+        for i in self._order:
+            b = self.buckets[i]
+            if b["work"] is not None:
+                continue
+            if not b["ready"]:
+                return
             self._issue(b)
 
     def _issue(self, b):
@@ -292,18 +337,30 @@ class GradReducer:
         else:
             b["work"] = _Done()
         self.issued += 1
+        self.issue_log.append(b["index"])
 
     def wait(self):
         """Before optimizer.step(): every bucket reduced, gradients averaged (average=True).  Returns the flat buffer."""
-        for b in self.buckets:
-            if b["work"] is None:
-                self._issue(b)
+        for i in self._order:                                    # what the hooks did not complete: same fixed order
+            if self.buckets[i]["work"] is None:
+                self._issue(self.buckets[i])
         for b in self.buckets:
             b["work"].wait()
         if self.average and self.world > 1:
             self.flat.mul_(1.0 / self.world)
+        if not self._order_agreed:
+            # the order the buckets became ready in during the FIRST backward (rank 0's; the rest appended) becomes the issue
+            # order of every later step on every rank: a fixed order that also matches the backward, so a bucket seldom waits
+            # for a later one.  One 8-byte-per-bucket broadcast, once.
+            seen = self._observed + [i for i in self._order if i not in self._observed]
+            if self.active:
+                t = torch.tensor(seen, dtype=torch.int64, device=self.flat.device)
+                dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+                seen = [int(x) for x in t.cpu().tolist()]
+            self._order, self._order_agreed = seen, True
+        self._observed = []
         for b in self.buckets:
-            b["work"], b["pending"] = None, None
+            b["work"], b["pending"], b["ready"] = None, None, False
         self._register()
         return self.flat
 

@@ -234,29 +234,38 @@ def test_rccl_one_rank_child(preflight):
 
 def test_bench_two_ranks_real_worker_path(preflight):
     """`python bench.py --gpus 2 --steps 3 --warmup 1` -- bench.py's REAL world > 1 worker path (self-spawned ranks, 127.0.0.1
-    rendezvous, C2 main line, C4 / C5 legs with the loss-partials all-reduce, MAX-over-ranks timing, one JSON line from rank
-    0) -- with both ranks on GPU 0 and gloo as the backend (MF_BENCH_SHARE_GPU / MF_BENCH_BACKEND: what one GPU can
-    execute; RCCL itself is the other child's subject).  The N > 1 main line carries no loss path (same work as N = 1)."""
+    rendezvous, the sharded main line WITH its loss all-reduce, C2 / C4 / C5 legs, MAX-over-ranks timing, one compact JSON
+    line from rank 0 + the detail on stderr) -- with both ranks on GPU 0 and gloo as the backend (MF_BENCH_SHARE_GPU /
+    MF_BENCH_BACKEND: what one GPU can execute; RCCL itself is the other child's subject)."""
     log = _preflight_log(preflight, "bench2")
     lines = [ln for ln in log.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, lines
+    assert len(lines[0].encode()) <= 1800
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
     assert d["config"]["global_rays"] == 8192 and d["config"]["rays_per_gpu"] == 4096 and d["config"]["sharding"] == "rays2"
-    assert d["config"]["loss_allreduce"] is False and d["dtype"] == "f32"
+    # round 6: the N > 1 main line is the workload north_star describes -- the rank's 4096 x 64 fp32 batch + the all-reduce of
+    # its loss partials inside the step -- and the ranks the all-reduce reached are on the line
+    assert d["config"]["loss_allreduce"] is True and d["config"]["main_has_collective"] is True and d["dtype"] == "f32"
+    assert d["rccl_ranks_seen"] == 2
     assert np.isfinite(d["value"]) and d["value"] > 0 and np.isfinite(d["ms_per_step"])
-    assert set(d["configs"]) >= {"C4", "C5"}
+    assert 0 < d["roofline"]["frac"] < 1 and d["roofline"]["bound"] == "mfma"
+    assert set(d["legs"]) == {"C2", "C4", "C5"} and d["leg_fields"][0] == "ms"
+    assert all(np.isfinite(v[0]) and v[0] > 0 for v in d["legs"].values())
+    assert np.isfinite(d["train_dp_ms"]["local"]) and d["train_dp_ms"]["allreduce"] > 0
+    det = [ln for ln in log.splitlines() if ln.startswith("bench_detail {")]
+    assert len(det) == 1
+    full = json.loads(det[0][len("bench_detail "):])
+    assert full["configs"]["C2"]["config"]["loss_allreduce"] is False           # the headline without its collective: a leg
     for name in ("C4", "C5"):
-        leg = d["configs"][name]
+        leg = full["configs"][name]
         assert leg["config"]["loss_allreduce"] is True and leg["config"]["sharding"] == "rays2", name
         assert np.isfinite(leg["value"]) and leg["value"] > 0 and 0 < leg["roofline"]["frac"] < 1, name
-    assert list(d)[-1] == "legs" and set(d["legs"]) >= {"C2", "C4", "C5", "train_dp_ms"}
     # round 5: the data-parallel TRAINING leg -- the joint step per rank with the global loss (dist.global_partials) and the
     # four per-network gradient buckets all-reduced from the backward's hooks (dist.GradReducer); both ranks ran it
-    dp = d["train_joint_dp"]
+    dp = full["train_joint_dp"]
     assert dp["world"] == 2 and dp["buckets"] == 4 and dp["flat_gradient_bytes"] > 5_000_000
     assert np.isfinite(dp["ms_per_step_local"]) and np.isfinite(dp["ms_per_step_allreduce"]) and dp["ms_per_step_allreduce"] > 0
-    assert all(np.isfinite(v["ms"]) and v["ms"] > 0 for k, v in d["legs"].items() if isinstance(v, dict) and "ms" in v)
 
 
 def test_lazy_consensus_vectors(M):

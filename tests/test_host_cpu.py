@@ -599,6 +599,66 @@ def test_grad_reducer_single_process_semantics():
     red.remove()
     with pytest.raises(ValueError):
         GradReducer([])
+    # a parameter UNFROZEN after construction has no hook for one step -- its bucket must then be left to
+    # wait() as a whole (issued from the other parameters' hooks it would go out before that gradient exists and the
+    # gradient would land in a fresh .grad outside the flat buffer, never reduced): the reference's coarse2fine transition
+    # (trainer_moco_flow.py:391-404) unfreezes the trunk beside already-trainable heads of the same network
+    m = torch.nn.Sequential(torch.nn.Linear(4, 5), torch.nn.ReLU(), torch.nn.Linear(5, 2))
+    m[0].weight.requires_grad_(False)
+    red = GradReducer([("net", m)])
+    m(x).square().sum().backward()
+    assert red.issued == 1 and m[0].weight.grad is None
+    red.wait()
+    m[0].weight.requires_grad_(True)                                   # unfrozen between two steps: no hook yet
+    m.zero_grad(set_to_none=True)
+    m(x).square().sum().backward()
+    assert red.issued == 1                                             # NOT issued from the hooks this step
+    red.wait()
+    assert red.issued == 2
+    want = torch.autograd.grad(m(x).square().sum(), list(m.parameters()))
+    for q, g in zip(m.parameters(), want):
+        assert q.grad.data_ptr() == red.view_of(q).data_ptr() and torch.allclose(red.view_of(q), g)
+    m.zero_grad(set_to_none=True)
+    m(x).square().sum().backward()
+    assert red.issued == 3                                             # from the hooks again (registered by wait())
+    red.wait()
+    red.remove()
+    # the collectives go out in ONE order whatever order the hooks complete in.  Three independent
+    # networks, backward through them in different orders: before the first wait() reverse registration; afterwards the
+    # order observed in the first backward -- also when a later step's backward runs the other way round
+    nets = [torch.nn.Linear(3, 3) for _ in range(3)]
+    red = GradReducer([(f"n{i}", n) for i, n in enumerate(nets)])
+    y = torch.randn(2, 3)
+    loss_of = lambda order: sum((k + 1.0) * nets[i](y).square().sum() for k, i in enumerate(order))
+    for i in (1, 0, 2):                                                # hooks complete in the order 1, 0, 2
+        nets[i](y).square().sum().backward()
+    assert red.issue_log == [2, 1, 0]                                  # nothing went out before bucket 2 was ready
+    red.wait()
+    assert red._order == [1, 0, 2]                                     # adopted from the first backward
+    for n in nets:
+        n.zero_grad(set_to_none=True)
+    for i in (2, 0, 1):                                                # a step whose hooks complete the other way round
+        nets[i](y).square().sum().backward()
+    red.wait()
+    assert red.issue_log[3:] == [1, 0, 2]
+    # gradient accumulation: all but the last backward under no_sync() (the old message recommended a
+    # sequence that raised)
+    for n in nets:
+        n.zero_grad(set_to_none=True)
+    before = red.issued
+    with red.no_sync():
+        for n in nets:
+            n(y).square().sum().backward()
+    assert red.issued == before
+    for n in nets:
+        n(y).square().sum().backward()
+    flat2 = red.wait().clone()
+    for n in nets:
+        g = torch.autograd.grad(n(y).square().sum(), list(n.parameters()))
+        for q, gg in zip(n.parameters(), g):
+            assert torch.allclose(red.view_of(q), 2 * gg)
+    assert red.issued == before + 3 and flat2.abs().sum() > 0
+    red.remove()
     # donation only for gradient-free partials
     lr = OverlappedLossReducer(3, "cpu", depth=2)
     w = torch.ones(3, dtype=torch.float64, requires_grad=True)
@@ -690,16 +750,75 @@ def test_bench_self_spawns_its_ranks():
     lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
-    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["reduced"] == 3.0      # ranks contribute 1 + 2
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["dryrun"][0] == 3.0      # ranks contribute 1 + 2
     # the driver's largest world: 8 ranks (1 + 2 + ... + 8 = 36)
     r8 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "2", "--warmup", "1"],
                         env=env, capture_output=True, text=True, timeout=400)
     assert r8.returncode == 0, r8.stderr[-2000:]
     d8 = json.loads([l for l in r8.stdout.splitlines() if l.startswith("{")][-1])
-    assert d8["n_gpus"] == 8 and d8["reduced"] == 36.0
+    assert d8["n_gpus"] == 8 and d8["dryrun"][0] == 36.0
+    # round 6: at N > 1 the MAIN line is the sharded workload with its collective, and the ranks the
+    # process group's all-reduce reached are on the line
+    for dd, n in ((d, 2), (d8, 8)):
+        assert dd["rccl_ranks_seen"] == n
+        assert dd["config"]["main_has_collective"] is True and dd["config"]["loss_allreduce"] is True
+        assert dd["config"]["sharding"] == f"rays{n}" and dd["config"]["global_rays"] == 4096 * n and dd["dtype"] == "f32"
+        assert set(dd["legs"]) == {"C2", "C4", "C5"}
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--config", "nope"],
                          env=env, capture_output=True, text=True, timeout=120)
     assert bad.returncode != 0
+
+
+REQUIRED_LINE_KEYS = {"metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                      "dtype", "data", "config", "roofline", "legs"}
+
+
+@pytest.mark.parametrize("gpus", [1, 2])
+def test_bench_last_stdout_line_is_compact(gpus):
+    """round 5's 27.9 KB line left the driver's record with parsed = null.  The LAST stdout line of bench.py
+    must be ONE strict-JSON object of at most 1800 bytes (it then fits whole in the driver's 2000-character tail) that
+    carries the contract keys + roofline + cpu_baseline + legs; the tens of KB of detail go to stderr / a side file.  Run
+    through MF_BENCH_DRYRUN: the same assemble() / emit() as a real run, fed results shaped like run_config()'s with
+    full-length floats for the complete leg set of that world size."""
+    import json
+    import subprocess
+    env = dict(os.environ, MF_BENCH_DRYRUN="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(gpus), "--steps", "20", "--warmup", "5"],
+                       env=env, capture_output=True, text=True, timeout=240)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = r.stdout.rstrip("\n").splitlines()[-1]
+    assert len(last.encode()) <= 1800, len(last.encode())
+
+    def no_constants(name):
+        raise AssertionError("non-strict JSON constant " + name)
+    d = json.loads(last, parse_constant=no_constants)
+    assert REQUIRED_LINE_KEYS <= set(d), REQUIRED_LINE_KEYS - set(d)
+    assert d["n_gpus"] == gpus and d["steps"] == 20 and d["warmup"] == 5 and d["unit"] == "ray-samples/s"
+    assert {"workload", "rays_per_gpu", "samples_per_ray", "global_rays", "sharding", "loss_allreduce", "main_has_collective"} <= set(d["config"])
+    assert {"bound", "achieved", "peak", "unit", "frac", "frac_step", "traffic", "traffic_algorithmic", "kernel", "kernel_ms",
+            "from_profiles"} <= set(d["roofline"])
+    assert {"value", "unit", "cores", "kind", "sample", "cpu"} <= set(d["cpu_baseline"])
+    assert d["roofline"]["bound"] == "mfma" and 0 < d["roofline"]["frac"] <= 1
+    want = {"C2x", "C3", "C3x", "C3g", "C5", "C5x", "C5full", "C5xfull"} if gpus == 1 else {"C2", "C4", "C5"}
+    assert set(d["legs"]) == want and all(len(v) == len(d["leg_fields"]) for v in d["legs"].values())
+    if gpus == 1:
+        assert {"s1", "joint"} <= set(d["train_ms"])
+    # no prose: every string on the line is short
+    def strings(o):
+        if isinstance(o, str):
+            yield o
+        elif isinstance(o, dict):
+            for v in o.values():
+                yield from strings(v)
+        elif isinstance(o, list):
+            for v in o:
+                yield from strings(v)
+    assert max(len(x) for x in strings(d)) <= 64
+    # the detail went to stderr as one line that no '{'-line parser picks up
+    det = [l for l in r.stderr.splitlines() if l.startswith("bench_detail {")]
+    assert len(det) == 1 and json.loads(det[0][len("bench_detail "):])["roofline"]["from_profiles"] is not None
 
 
 def test_scripts_compile():
