@@ -36,7 +36,7 @@ class ConsensusPass:
         # pass_self: compact_fn(self) / mean_fn(self, key) -- callbacks that need the pass get it as an argument.  Closing over
         # the variable that holds the pass made pass -> callback -> cell -> pass a reference CYCLE that kept the whole training
         # pass (its 9 GB of dump planes in the joint stage's step) alive until Python's cyclic collector happened to run
-        # (round 5: tools/r05_gc_check.py -- the allocator then went to the driver for every step's dumps: 80-240 ms steps).
+        # (round 5: tools/rounds/r05/r05_gc_check.py -- the allocator then went to the driver for every step's dumps: 80-240 ms steps).
         self._pass_self = pass_self
         self._stats, self._vectors, self._mask = None, None, None
         self._mean_taken = set()

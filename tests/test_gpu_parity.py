@@ -434,7 +434,7 @@ def _check_grads_vs_float64(nets, want32, want64, skip=lambda k: False, label=""
             # max-rel guard against a wrong element.  Its floor is 2e-3, not 1e-4: ONE ReLU unit whose pre-activation rounds to the
             # other side of zero between two fp32 evaluation orders moves a weight-gradient row of the layers in front of it by
             # that sample's whole contribution -- a discrete event (measured 1.4e-4 .. 3.8e-4 of max|dW| at 6144 samples, layers
-            # 1-3 only, the layers behind the unit agreeing to 2e-7, with the fp32 backward kernels too: tools/debug_ctor.py) that
+            # 1-3 only, the layers behind the unit agreeing to 2e-7, with the fp32 backward kernels too: a one-off script, since removed) that
             # the fp32-vs-float64 pair of the same batch need not contain
             assert e_mr32 <= (fp32_bar if fp32_bar is not None else max(2e-3, 3 * noise_mr)), (key, e_mr32, noise_mr)
             checked += 1
@@ -1005,7 +1005,8 @@ def test_c3_full_size_bf16_vs_oracle(M, R, name, draw):
 
 
 # bf16x3 (MF_PREC_BF16X3): the fp32 CONTRACT on the bf16 matrix pipe -- the NeRF's products as three bf16 products of (hi, lo)
-# operand pairs, the NoF's as six products of (hi, mid, lo) triples (24 mantissa bits: its output point feeds sin(512 x)), fp32
+# operand pairs, the NoF's (its output point feeds sin(512 x)) as three products of IEEE-half (hi, lo) pairs at 2^5 x their value
+# (22 significand bits on v_mfma_f32_32x32x16_f16; rounds 3-4: six products of bf16 (hi, mid, lo) triples), fp32
 # accumulation, heads on the fp32 accumulators, exact per-ray image-index bias, exact seeds + doubling chains for the encodings.
 # Measured at 4096 rays (round 4): bench draw 114.1 dB, max-rel 1.0e-5 / 1.4e-5 / 1.0e-5 (rgb / depth / opacity; the fp32
 # kernels: 123 dB); golden-case draw 111.3 dB, 2.1e-5 / 2.3e-5 / 3.1e-5 (fp32 kernels 118.7 dB).  History: round 3's kernel (two-term

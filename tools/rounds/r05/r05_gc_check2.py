@@ -1,4 +1,4 @@
-"""Which reference cycle keeps a training step's dump tensors alive until the cyclic collector runs (tools/r05_gc_check.py showed
+"""Which reference cycle keeps a training step's dump tensors alive until the cyclic collector runs (tools/rounds/r05/r05_gc_check.py showed
 8.9 GB per joint step)?  One step with the collector off, then DEBUG_SAVEALL: the garbage by type and who refers to the big tensors."""
 import os, sys, gc, collections
 sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "."))

@@ -25,13 +25,21 @@ for f in glob.glob(os.path.join(out, "trace/**/*kernel_stats.csv"), recursive=Tr
             if i < 12:
                 print(line.rstrip())
 dur = defaultdict(list)
+by_grid = defaultdict(lambda: defaultdict(list))        # kernel -> grid size -> durations
 for r in rows("trace/**/*kernel_trace.csv"):
     dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    by_grid[r["Kernel_Name"]][(r.get("Grid_Size"), r.get("LDS_Block_Size"))].append(dur[r["Kernel_Name"]][-1])
 dom = None
 if dur:
     dom = max(dur, key=lambda k: sum(dur[k]))
     d = dur[dom]
     print(f"\ndominant kernel: {dom[:90]}\n  dispatches {len(d)}  avg {sum(d)/len(d)/1e3:.1f} us  min {min(d)/1e3:.1f}  max {max(d)/1e3:.1f}")
+    # the same kernel at DIFFERENT launch shapes is different work (a coarse and a fine pass of one render_rays call, the
+    # coarse / fine launches of a training step): one line per (grid, LDS) shape, so that an average never mixes them
+    if len(by_grid[dom]) > 1:
+        for (grid, lds), dd in sorted(by_grid[dom].items(), key=lambda kv: -sum(kv[1])):
+            print(f"    grid {grid} lds {lds}: dispatches {len(dd)}  avg {sum(dd)/len(dd)/1e3:.1f} us  min {min(dd)/1e3:.1f}  max {max(dd)/1e3:.1f}"
+                  f"  ({100.0*sum(dd)/sum(d):.0f} % of the kernel's time)")
     r0 = next(r for r in rows("trace/**/*kernel_trace.csv") if r["Kernel_Name"] == dom)
     # registers / occupancy as the COMPILER reports them (profiles/kernel_resources.json, tools/kernel_resources.py); the
     # trace's VGPR_Count / Accum_VGPR_Count columns are the dispatch packet's allocation fields, not these numbers
@@ -100,6 +108,9 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         entry["rocprof_avg_us"] = sum(d) / len(d) / 1e3
         entry["rocprof_min_us"] = min(d) / 1e3
         entry["dispatches"] = len(d)
+        if len(by_grid[dom]) > 1:
+            entry["by_grid"] = {str(g[0]): {"n": len(dd), "avg_us": sum(dd) / len(dd) / 1e3, "min_us": min(dd) / 1e3}
+                                for g, dd in by_grid[dom].items()}
     acc, pdur = defaultdict(list), []
     for r in rows("pmc_mfma/**/*counter_collection.csv"):
         if r["Kernel_Name"] == dom:
