@@ -538,9 +538,18 @@ MF_D void sincos_rev(float rad, float& sn, float& cs) {
   cs = __builtin_amdgcn_cosf(f);
 }
 
+// (`h` is made opaque at the top of each evaluation: everything derived from it here -- the half's component index, its table
+//  address -- is loop-invariant per lane, and hipcc hoisted those ~15 values out of the whole group loop into registers the MFMA
+//  section has no room for: the 17 spilled VGPRs / 72 B of scratch per lane of round 5's fast kernels.  Re-derived per evaluation
+//  they are a v_cndmask each, inside a VALU phase.)
+MF_D int opaque_lane_half(int h) {
+  asm volatile("" : "+v"(h));
+  return h;
+}
 template <int C, int F, bool HW = false>
-MF_D void emb_eval_direct(float* dst, const float (&v)[C], uint32_t par_off, int h) {
+MF_D void emb_eval_direct(float* dst, const float (&v)[C], uint32_t par_off, int h_in) {
   using B = EmbBlock2<C, F>;
+  const int h = opaque_lane_half(h_in);
 #pragma unroll
   for (int pi = 0; pi < B::NPI; ++pi) {
     const int p0 = 2 * pi, p1 = 2 * pi + 1;                // the two halves' pairs
@@ -585,10 +594,11 @@ MF_D void emb_eval_direct(float* dst, const float (&v)[C], uint32_t par_off, int
 // or whose arguments stay small (NeRF xyz / dir / ind, NoF xyz); the NoF's image-index block (arguments up to 2^15, split
 // operands) keeps the exact seeds + doubling chains.
 template <int C, int F, bool HW = false>
-MF_D void emb_eval(float* dst, const float (&v)[C], uint32_t par_off, int h, bool pow2) {
+MF_D void emb_eval(float* dst, const float (&v)[C], uint32_t par_off, int h_in, bool pow2) {
   using B = EmbBlock2<C, F>;
-  if (HW) { emb_eval_direct<C, F, true>(dst, v, par_off, h); return; }
-  if (!pow2) { emb_eval_direct<C, F>(dst, v, par_off, h); return; }
+  if (HW) { emb_eval_direct<C, F, true>(dst, v, par_off, h_in); return; }
+  if (!pow2) { emb_eval_direct<C, F>(dst, v, par_off, h_in); return; }
+  const int h = opaque_lane_half(h_in);
   float cs_[C], sn_[C];                                    // the chains' current (cos, sin)
 #pragma unroll
   for (int pi = 0; pi < B::NPI; ++pi) {

@@ -76,8 +76,13 @@ __global__ void pack_panels_kernel(PackJob job) {
     const bool half = R.half != 0;
     const float ws = R.wscale;
     auto term = [half, ws](float w, int t) {
-      if (half) {                                           // hi = half(ws w) (saturated: no inf in the stream), lo = half(ws w - hi)
-        w = fminf(fmaxf(w * ws, -65504.f), 65504.f);
+      if (half) {                                           // hi = half(ws w), lo = half(ws w - hi)
+        // |ws w| beyond the half range (|w| >= 2047 at ws = 2^5: no trained NoF is near it): the weight goes into the stream as a
+        // quiet NaN, so every ray that touches it comes out NaN -- the same loud failure as an activation beyond the range
+        // (mf_core.hpp, kNofHalfX3).  Rounds 5's saturation to +-65504 gave finite WRONG results with no diagnostic;
+        // a host-side check would cost a device sync at every re-pack, i.e. at every optimizer step.
+        w = w * ws;
+        if (!(fabsf(w) <= 65504.f)) return (unsigned short)0x7e00;
         __half hb = __float2half_rn(w);
         if (t > 0) hb = __float2half_rn(w - __half2float(hb));
         return __half_as_ushort(hb);

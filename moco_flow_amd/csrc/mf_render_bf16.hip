@@ -148,6 +148,11 @@ MF_D void stage_raybias(const P& p, long long ray_first, int n, int combo, uint3
   stage_raybias<NW>(p.raybias, p.rb_combos, p.rb_layers, ray_first, n, combo, dst, id);
 }
 // rays [first, first + n) touched by tile `tile` (TILE samples) of a group of `nr` rays
+// rays of group `g` (G per group, the last one shorter): 32-bit scalar arithmetic (a 64-bit `<` is a VALU compare here)
+MF_D int group_rays(long long n_rays, long long g, int G) {
+  const long long rem = n_rays - g * G;
+  return (rem >> 31) != 0 ? G : ((int)rem < G ? (int)rem : G);
+}
 template <int TILE>
 MF_D void tile_rays(int tile, int nr, int S, int& first, int& n) {
   const int s0 = tile * TILE, s1 = (s0 + TILE < nr * S ? s0 + TILE : nr * S) - 1;
@@ -192,7 +197,7 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
   int seq = 0;                       // NoF evaluations done by this workgroup: evaluation number `seq` reads buffer seq & 1
   if (MOCO) {                        // rows of the first evaluation (first group, tile 0, bw at index i)
     const long long g0 = blockIdx.x;
-    const int nr0 = (int)((p.n_rays - g0 * p.G) < p.G ? (p.n_rays - g0 * p.G) : p.G);
+    const int nr0 = group_rays(p.n_rays, g0, p.G);
     int f0, n0;
     tile_rays<TILE>(0, nr0, p.S, f0, n0);
     stage_raybias<NW>(p, g0 * p.G + f0, n0, 0, p.rb_off, id);
@@ -207,13 +212,19 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
 
   for (long long group = blockIdx.x; group < p.n_groups; group += gridDim.x) {
     const long long ray0 = group * p.G;
-    const int nr = (int)((p.n_rays - ray0) < p.G ? (p.n_rays - ray0) : p.G);
+    // (the rays left as a 32-bit scalar minimum: the 64-bit `rem < G` has no scalar compare on this target and became a
+    //  v_cmp_lt_i64 against a VGPR copy of G that hipcc kept -- spilled -- across the whole group loop)
+    const int nr = group_rays(p.n_rays, group, p.G);
     const int nsamp = nr * S;
     const int ntiles = (nsamp + TILE - 1) / TILE;
 
     for (int tile = 0; tile < ntiles; ++tile) {
       st.tl.stamp(1, id);
-      const int srel = tile * TILE + id.wave * kWaveSamples + id.j;
+      // (the lane's sample slot re-derived per tile from the hardware lane count + the scalar wave index: as a loop invariant
+      //  it -- and then the thread index it was rebuilt from -- was one more register held, i.e. spilled, through the MFMA section)
+      int ln;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      const int srel = tile * TILE + id.wave * kWaveSamples + (ln & 31);
       const bool valid = srel < nsamp;
       const int sl = valid ? srel : nsamp - 1;
       const int rr = sl / S;
@@ -304,7 +315,7 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
         const bool more = tile + 1 < ntiles;
         const long long ng = more ? group : group + gridDim.x;
         if (ng < p.n_groups) {
-          const int nnr = (int)((p.n_rays - ng * p.G) < p.G ? (p.n_rays - ng * p.G) : p.G);
+          const int nnr = group_rays(p.n_rays, ng, p.G);
           int nf, nn;
           tile_rays<TILE>(more ? tile + 1 : 0, nnr, S, nf, nn);
           stage_raybias<NW>(p, ng * p.G + nf, nn, 0, p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes, id);

@@ -84,15 +84,12 @@ def test_inference_kernels_have_no_spills_and_stream_weights_by_buffer_dma():
     for k in want:
         u = {**u32, **u16}[k]
         assert u["VGPRs"] <= 256, (k, u)
-        if k in u16:
-            # round 5: the fast bf16 tiles are pipeline stages -- the previous tile's epilogue in this tile's MFMA gaps, the next
-            # tile's bias in a second accumulator set (csrc/mf_bf16.hpp, mma_tile) -- 16 more live registers in a full file:
-            # hipcc parks <= 20 dwords of per-tile bookkeeping (ray pointers, output addresses) in scratch at the tile's start
-            # and reloads them in the VALU phases between the networks.  None of it may sit inside the MFMA-dense tile loops.
-            assert u["VGPRs Spill"] <= 20 and u["ScratchSize"] <= 80, (k, u)
-            assert _scratch_distance_to_mfma(a16, k) >= 8, (k, _scratch_distance_to_mfma(a16, k))
-        else:
-            assert u["VGPRs Spill"] == 0 and u["ScratchSize"] == 0, (k, u)
+        # round 6: the fast bf16 kernels are back at zero too.  Round 5's pipelined tile (two accumulator sets in flight) had pushed
+        # 17 / 11 dwords into scratch -- not per-tile bookkeeping of the tile loop but loop-INVARIANT per-lane values hipcc had
+        # hoisted out of the whole group loop: the embedding evaluations' half-dependent component indices and table addresses,
+        # a VGPR copy of G for a 64-bit compare, the lane's sample slot (csrc/mf_bf16.hpp opaque_lane_half, mf_render_bf16.hip
+        # group_rays / the per-tile v_mbcnt).  Re-derived where they are used they cost a v_cndmask each in a VALU phase.
+        assert u["VGPRs Spill"] == 0 and u["ScratchSize"] == 0, (k, u)
     # the bf16x3 kernels hold (hi, lo) pairs of a 256-wide layer's input AND output: one wave per SIMD with the whole register
     # file -- 256 VGPRs + AGPRs (hipcc parks finished output tiles there), nothing in scratch
     for k in x3:
