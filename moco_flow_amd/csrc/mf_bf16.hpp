@@ -328,12 +328,20 @@ MF_D void mma_tile(Carry& carry, const u32x4* hid, const u32x4* xhi, const u32x4
 }
 
 // Head tile (NoF 3|9-row head): acc = bias + (Whi + Wlo) * hidden, raw fp32 accumulators (rows (r&3)+8(r>>2)+4h).
-template <int KHID, class Hook, class Piece>
+// TERMS = groups per hidden k-step: 2 = the NoF's (hi, lo) group pairs; 1 = ONE group whose rows carry the terms (the NeRF's
+// sigma / rgb heads, NetLayout::head_tiles: row c = bf16(w_c), row 8 + c = bf16(w_c - hi) -- registers c and 4 + c of lane half
+// 0 -- half the MFMAs and fragment reads of the group-pair form for heads of <= 4 rows).  ZERO: accumulators start at 0 (the
+// caller adds its scalar biases) instead of a 32-row bias vector in LDS.
+template <int KHID, int TERMS = 2, bool ZERO = false, class Hook, class Piece>
 MF_D f32x16 head_tile(Carry& carry, const u32x4* hid, uint32_t p, uint32_t pn, uint32_t bias_off, int h, Hook&& hook,
                       Piece&& piece) {
-  constexpr int NG = 2 * KHID;
+  constexpr int NG = TERMS * KHID;
+  static_assert(NG > PD && NG >= 4, "head panel too short");
   f32x16 acc;
-  {
+  if constexpr (ZERO) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+  } else {
     const f32x4 b0 = lds_f4(bias_off + (0 + 4 * h) * 4), b1 = lds_f4(bias_off + (8 + 4 * h) * 4);
     const f32x4 b2 = lds_f4(bias_off + (16 + 4 * h) * 4), b3 = lds_f4(bias_off + (24 + 4 * h) * 4);
 #pragma unroll
@@ -345,7 +353,7 @@ MF_D f32x16 head_tile(Carry& carry, const u32x4* hid, uint32_t p, uint32_t pn, u
 #pragma unroll
   for (int gi = 0; gi < NG; ++gi) {
     const int s = gi % (PD + 1);
-    acc = MF_MFMA32(r[s], hid[gi >> 1], acc);
+    acc = MF_MFMA32(r[s], hid[TERMS == 2 ? gi >> 1 : gi], acc);
     __builtin_amdgcn_sched_barrier(0);
     const int sp = (gi + PD) % (PD + 1), nb = gi + PD;
     if (nb < NG) r[sp] = lds_u4(p + nb * kGroupBytes);
@@ -768,14 +776,29 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
     for (int i = 0; i < 4; ++i) act[t][i] = 0;
   const int D = net.D;
   NoRayBias norb;
+  // Round 6: the sigma and rgb heads are PANELS of the weight stream (NetLayout::head_tiles) -- 16 + 8 MFMAs and fragment reads per
+  // wave where the VALU dot products cost 192 + 192 FMAs, as many unpack operations and 32 + 48 ds_read_b128 of fp32 weight rows
+  // (80 KiB of LDS reads per wave and tile: what 80 MFMAs' fragments cost), with both waves of a SIMD in VALU code at the same time.
+  // Weights as bf16 (hi, lo) row pairs (16 significand bits; the activations they multiply are bf16), fp32 accumulation.
+  // The sigma panel follows the last trunk layer; behind it comes xyz_encoding_final's first panel -- or, sigma_only, `follow`'s.
+  const Next sg_next = sigma_only ? Next{16, nullptr, follow.groups, follow.jump} : Next{16, nullptr, 16, nullptr};
   trunk<16, kKsNerfXyz, false, kNerfTpp0, kNerfTppH, kNerfTppS>(net, D, act, xe, xe, st, carry, id, [&](int l) {
-    return (sigma_only && l == D - 1) ? follow : next_trunk_bf<16, kKsNerfXyz, false, 0, kNerfTppH, kNerfTppS>(net, l + 1);
+    return l == D - 1 ? sg_next : next_trunk_bf<16, kKsNerfXyz, false, 0, kNerfTppH, kNerfTppS>(net, l + 1);
   }, norb, nullptr, [] {});
   // resident block: [bias_trunk (D+1) 256 | bias_extra 128 | sigma_w 256 | sigma_b 4 | rgb_w 384 | rgb_b 4]
   const uint32_t r_sigma_w = net.res_lds + ((D + 1) * 256 + 128) * 4;
-  float sg[1];
-  valu_head(act, r_sigma_w, r_sigma_w + 256 * 4, id.h, sg);
-  sigma = sg[0];
+  {
+    const uint32_t p = st.slot_off(0) + id.lane * 16, pn = st.slot_off(1) + id.lane * 16;
+    // panel two ahead of the sigma panel: xyz_encoding_final's second tile (contiguous), or the SECOND panel of `follow`
+    auto hook = [&]() {
+      if (sigma_only) st.sync(follow.groups2, follow.jump2, id);
+      else st.sync(16, nullptr, id, true, 16);
+    };
+    auto piece = [&](int k) { st.piece(k, id); };
+    const f32x16 acc = head_tile<16, 1, true>(carry, act, p, pn, 0u, id.h, hook, piece);
+    st.advance();
+    sigma = acc[0] + acc[4] + lds_f(r_sigma_w + 256 * 4);      // rows 0 (hi) + 8 (lo): valid in lane half 0 (the half that stores it)
+  }
   st.tl.stamp(30, id);
   if (sigma_only) return;
   const int xg = 16 + net.aux;
@@ -786,14 +809,25 @@ MF_D void nerf_eval(const Net& net, const u32x4 (&xe)[kKsNerfXyz],
   u32x4 e[8], eo[kKsExtraMax];
   make_extra(eo);
   st.tl.stamp(32, id);
-  if (net.aux == 2) extra_layer<2>(net, fin, eo, eo, e, st, carry, id, follow);
-  else if (net.aux == 1) extra_layer<1>(net, fin, eo, eo, e, st, carry, id, follow);
-  else extra_layer<0>(net, fin, eo, eo, e, st, carry, id, follow);
+  // behind extra_encoding: the rgb panel (8 groups), then `follow`'s first panel
+  const Next rg_next{8, nullptr, follow.groups, follow.jump};
+  if (net.aux == 2) extra_layer<2>(net, fin, eo, eo, e, st, carry, id, rg_next);
+  else if (net.aux == 1) extra_layer<1>(net, fin, eo, eo, e, st, carry, id, rg_next);
+  else extra_layer<0>(net, fin, eo, eo, e, st, carry, id, rg_next);
   st.tl.stamp(33, id);
-  float o[3];
-  valu_head(e, r_sigma_w + (256 + 4) * 4, r_sigma_w + (256 + 4 + 384) * 4, id.h, o);
+  {
+    const uint32_t p = st.slot_off(0) + id.lane * 16, pn = st.slot_off(1) + id.lane * 16;
+    auto hook = [&]() { st.sync(follow.groups2, follow.jump2, id); };
+    auto piece = [&](int k) { st.piece(k, id); };
+    const f32x16 acc = head_tile<8, 1, true>(carry, e, p, pn, 0u, id.h, hook, piece);
+    st.advance();
+    const uint32_t r_rgb_b = r_sigma_w + (256 + 4 + 384) * 4;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) rgb[c] = 1.f / (1.f + expf(-o[c]));   // nn.Sigmoid, nerf.py:57-59
+    for (int c = 0; c < 3; ++c) {
+      const float o = acc[c] + acc[4 + c] + lds_f(r_rgb_b + 4 * c);      // rows c (hi) + 8 + c (lo), lane half 0
+      rgb[c] = 1.f / (1.f + expf(-o));                                  // nn.Sigmoid, nerf.py:57-59
+    }
+  }
 }
 
 // Neural motion flow (W = 128) on this wave's 32 samples; xhi/xlo = split operands of the xyz block; `rb` = the per-ray

@@ -47,10 +47,13 @@ inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L, int bf16 = 0) {
   L.off_rgb_w = off; off += 3 * (L.W / 2);
   L.off_rgb_b = off; off += 4;
   L.n_head = 1;
+  L.head_tiles = bf16 == MF_PREC_BF16 ? 1 : 0;        // fast bf16 mode: sigma / rgb heads on the matrix pipe (NetLayout::head_tiles)
   L.res_bytes = round_up((int64_t)off * 4, kGroupBytes);
   int64_t groups = 0;
   L.max_groups = 0;
+  // stream order: trunk layers 0 .. D-1, [sigma head panel], xyz_encoding_final, extra_encoding, [rgb head panel]
   for (int l = 0; l < L.n_trunk; ++l) {
+    if (l == L.n_trunk - 1) groups += nerf_sigma_groups(L);
     const int g = trunk_groups(L, l);
     groups += (int64_t)g * L.NP;
     if ((x3 ? panel_cap(g) : g) > L.max_groups) L.max_groups = x3 ? panel_cap(g) : g;
@@ -58,6 +61,7 @@ inline bool nerf_layout(const mf_nerf_desc& d, NetLayout& L, int bf16 = 0) {
   const int ge = extra_groups(L);
   groups += (int64_t)ge * (L.NP / 2);      // (W/2)-wide layer: NP/2 panels in either layout
   if ((x3 ? panel_cap(ge) : ge) > L.max_groups) L.max_groups = x3 ? panel_cap(ge) : ge;
+  groups += nerf_rgb_groups(L);
   L.panel_bytes = groups * kGroupBytes;
   return true;
 }

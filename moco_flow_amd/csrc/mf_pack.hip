@@ -28,6 +28,7 @@ struct PackRegion {          // one trunk/extra layer's panels
   int hid_col0;              // column of hidden feature 0 in W
   int xyz_cols;
   int n_rows;                // rows present in W (bf16 head panel: 3|9 of its 32; 0 = all)
+  int row_terms;             // bf16 head panel of the NeRF (NetLayout::head_tiles): tile row c < n_rows = bf16(W[c]), row 8 + c = bf16(W[c] - hi)
   int half;                  // the split terms are IEEE halves of wscale * w (NetLayout::half) instead of bf16
   float wscale;
   int hid_split;             // bf16: groups per hidden k-step ks: 1 = plain, 2 = (hi, lo), 3 = (hi, mid, lo)
@@ -36,7 +37,7 @@ struct PackRegion {          // one trunk/extra layer's panels
 };
 
 struct PackJob {
-  PackRegion reg[MF_MAX_LAYERS + 1];
+  PackRegion reg[MF_MAX_LAYERS + 3];
   int n_regions;
   long long total_groups;
   float* panels;             // packed + res_bytes
@@ -66,7 +67,13 @@ __global__ void pack_panels_kernel(PackJob job) {
     // Embedded k-step ks is emb_split groups (1: bf16(w); 2: + lo = bf16(w - hi); 3: hi, mid, lo); hidden k-step ks covers
     // features 16 ks + hid_perm2(h, e), hid_split groups likewise.
     const int i = lane & 31, h = lane >> 5;
-    const float* row = R.W + (long long)(32 * P + i) * R.n_in;
+    int srow = 32 * P + i, rterm = 0;
+    bool zero_row = R.n_rows && srow >= R.n_rows;
+    if (R.row_terms) {                                       // (hi rows at 0 .., lo rows at 8 ..: both in lane half 0's accumulators)
+      zero_row = !(srow < R.n_rows || (srow >= 8 && srow < 8 + R.n_rows));
+      if (srow >= 8) { rterm = 1; srow -= 8; }
+    }
+    const float* row = R.W + (long long)(zero_row ? 0 : srow) * R.n_in;
     const int eg = R.emb_split * R.emb_steps;                // groups of the embedded block
     const int hg = R.hid_split * R.hid_batches;              // groups of the hidden block
     const int ge = R.emb_first ? gi : gi - hg;
@@ -94,7 +101,7 @@ __global__ void pack_panels_kernel(PackJob job) {
       }
       return b;
     };
-    if (R.n_rows && 32 * P + i >= R.n_rows) {
+    if (zero_row) {
       // zero row of a partial tile
     } else if (ge >= 0 && ge < eg) {
       const int ks = ge / R.emb_split, t = ge % R.emb_split;
@@ -103,7 +110,7 @@ __global__ void pack_panels_kernel(PackJob job) {
         h8[e] = term((f >= 0 && f < R.emb_cols) ? row[R.emb_col0 + f] : 0.f, t);
       }
     } else if (gh >= 0 && gh < hg) {
-      const int ks = gh / R.hid_split, t = gh % R.hid_split;
+      const int ks = gh / R.hid_split, t = R.row_terms ? rterm : gh % R.hid_split;
       for (int e = 0; e < 8; ++e) h8[e] = term(row[R.hid_col0 + 16 * ks + hid_perm2(h, e)], t);
     }
     unsigned* pu = reinterpret_cast<unsigned*>(&v.x);
@@ -191,7 +198,28 @@ extern "C" int32_t mf_nerf_pack_p(const mf_nerf_desc* d, int32_t precision, void
   ResJob rj{};
   long long g0 = 0;
   int nr = 0;
+  auto head_region = [&](const float* W, int rows, int groups) {       // NetLayout::head_tiles: one 32-row tile, (hi, lo) ROW pairs
+    PackRegion& R = job.reg[nr++];
+    R.W = W;
+    R.n_in = groups * 16;
+    R.tiles = 1;
+    R.groups = groups;
+    R.emb_first = 1;
+    R.emb_kind = kEmbNone;
+    R.hid_batches = groups;
+    R.bf16 = 1;
+    R.n_rows = rows;
+    R.row_terms = 1;
+    R.hid_split = 1;
+    R.emb_split = 1;
+    R.dst_group0 = g0;
+    g0 += groups;
+  };
   for (int l = 0; l < L.n_trunk; ++l) {
+    if (l == L.n_trunk - 1 && L.head_tiles) {
+      if (!d->sigma_w) return fail(MF_E_INVALID, "mf_nerf_pack: missing sigma weight");
+      head_region(d->sigma_w, 1, nerf_sigma_groups(L));
+    }
     PackRegion& R = job.reg[nr++];
     const bool has_emb = (L.emb_mask >> l) & 1;
     R.W = l < d->D ? d->trunk_w[l] : d->final_w;
@@ -239,6 +267,10 @@ extern "C" int32_t mf_nerf_pack_p(const mf_nerf_desc* d, int32_t precision, void
     R.dst_group0 = g0;
     g0 += (long long)R.groups * R.tiles;
     rj.c[rj.n++] = ResCopy{d->extra_b, L.off_bias_extra, L.W / 2};
+  }
+  if (L.head_tiles) {
+    if (!d->rgb_w) return fail(MF_E_INVALID, "mf_nerf_pack: missing rgb weight");
+    head_region(d->rgb_w, 3, nerf_rgb_groups(L));
   }
   rj.c[rj.n++] = ResCopy{d->sigma_w, L.off_head_w, L.W};
   rj.c[rj.n++] = ResCopy{d->sigma_b, L.off_head_b, 1};

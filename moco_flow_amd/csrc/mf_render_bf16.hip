@@ -720,6 +720,20 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
     }
     G = best;
   }
+  // Several such ray sets per group (up to 8), as in the fp32 pass (mf_render.hip): the composite phase between two groups
+  // keeps at most one wave per ray busy and costs two workgroup barriers, so it comes once per several tiles -- as long as the
+  // CUs' shares stay what they were (same makespan in rays).
+#ifndef MF_AB_NO_GSETS
+  {
+    const long long cus = device_cus();
+    auto makespan = [&](long long g) { const long long groups = (a->n_rays + g - 1) / g; return (groups + cus - 1) / cus * g; };
+    const long long base = makespan(G);
+    int best = 1;
+    for (int c = 2; c <= 8; ++c)
+      if ((long long)G * c * S <= max_samples && (long long)G * c <= 64 && makespan((long long)G * c) <= base) best = c;
+    G *= best;
+  }
+#endif
   p.G = G;
   p.n_groups = (a->n_rays + G - 1) / G;
   p.sbuf_off = lds; lds += (uint32_t)(G * S) * 16;

@@ -22,7 +22,8 @@ What is modelled (``Arith`` fields; kernel site in brackets):
   * the NoF's image-index block as a per-ray fp32 bias, b + W[:, 33:66] emb(ind) by 33 sequential fp32 FMAs
     [nof_raybias_kernel]
   * activations: ReLU on the fp32 accumulator, then the operand rounding of the next layer [out_tile's epilogue, epi_step]
-  * heads: "bf16act" = fp32 weights x bf16-rounded activations [valu_head]; "f32acc" = fp32 weights x the fp32
+  * heads: "bf16act" = fp32 weights x bf16-rounded activations [valu_head, rounds 2-5]; "wsplit" on the NeRF = its sigma / rgb
+    heads as matrix-pipe panels of (hi, lo) bf16 weight rows x bf16 activations [head_tile<K, 1>, round 6]; "f32acc" = fp32 weights x the fp32
     accumulators [epi_step NHEAD]; the NoF head "wsplit" = (Whi + Wlo) x bf16 activations [head_tile] or "split"
     [head_tile_x3]
   * sin / cos of the encodings: "exact" = OCML-class [sincosf]; "hw" = the transcendental unit's argument path,
@@ -149,7 +150,7 @@ class Arith:
     nerf_emb: str = "f32"            # operands of the embedded input (layer 0, skip layers) and of the extra block
     nerf_hidden: str = "f32"
     nerf_tail: str = "f32"           # xyz_encoding_final and extra_encoding
-    nerf_heads: str = "f32"          # "f32" | "bf16act" | "f32acc"
+    nerf_heads: str = "f32"          # "f32" | "bf16act" (rounds 2-5's VALU heads) | "wsplit" (round 6: head panels) | "f32acc"
     nerf_xyz_sincos: str = "exact"
     nerf_extra_sincos: str = "exact"
 
@@ -157,7 +158,7 @@ class Arith:
 F32 = Arith()
 # set_precision("bf16") -- BASELINE configs C3-C5 as written ("MFMA bf16 hidden GEMMs")
 BF16 = Arith(name="bf16", acc="f64", nof_xyz="split", nof_ind_bias=True, nof_hidden="plain", nof_head="wsplit",
-             nof_xyz_sincos="hw", nerf_emb="plain", nerf_hidden="plain", nerf_tail="plain", nerf_heads="bf16act",
+             nof_xyz_sincos="hw", nerf_emb="plain", nerf_hidden="plain", nerf_tail="plain", nerf_heads="wsplit",
              nerf_xyz_sincos="hw", nerf_extra_sincos="hw")
 # set_precision("bf16x3") as shipped at the end of round 3 (NoF xyz block from the transcendental unit)
 BF16X3_R3 = Arith(name="bf16x3_r3", acc="f64", nof_xyz="split", nof_ind_bias=True, nof_hidden="split", nof_head="split",
@@ -259,8 +260,11 @@ class NeRF(R.NeRF):
                 terms = operand_terms(h, W, a.nerf_hidden)
             acc = mm(terms, b, None, a.acc)
             h = F.relu(acc)                               # fp32 accumulators; rounded where the next layer consumes them
-        head_in = bf(h) if a.nerf_heads == "bf16act" else h
-        sigma = mm([(head_in, p["sigma.weight"])], p["sigma.bias"], None, a.acc)
+        def head(x, W, b):
+            if a.nerf_heads == "wsplit":                   # matrix-pipe head panel: (Whi + Wlo) x bf16 activations [head_tile<.., 1>]
+                return mm(operand_terms(x, W, "wsplit"), b, None, a.acc)
+            return mm([(bf(x) if a.nerf_heads == "bf16act" else x, W)], b, None, a.acc)
+        sigma = head(h, p["sigma.weight"], p["sigma.bias"])
         if sigma_only:
             return sigma
         feat = mm(operand_terms(h, p["xyz_encoding_final.weight"], a.nerf_tail), p["xyz_encoding_final.bias"], None, a.acc)
@@ -273,7 +277,7 @@ class NeRF(R.NeRF):
             terms = operand_terms(feat, We[:, :self.W], a.nerf_tail) + \
                 (operand_terms(extra, We[:, self.W:], a.nerf_emb) if self.extra_feat_dim > 0 else [])
         e = F.relu(mm(terms, be, None, a.acc))
-        rgb = torch.sigmoid(mm([(bf(e) if a.nerf_heads == "bf16act" else e, p["rgb.0.weight"])], p["rgb.0.bias"], None, a.acc))
+        rgb = torch.sigmoid(head(e, p["rgb.0.weight"], p["rgb.0.bias"]))
         return torch.cat([rgb, sigma], -1)
 
 

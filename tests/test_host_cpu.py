@@ -176,7 +176,9 @@ def test_packed_layout_sizes():
     # 4 k-steps of the xyz block, 2 of the direction block)
     assert lib.mf_nof_packed_bytes_p(ctypes.byref(n), L.MF_PREC_BF16) == 7 * 1024 + ((6 + 8 + 14 + 8) * 4 + 16) * 1024 + 36 * 1024
     d.extra_feat_type, d.extra_feat_dim = L.MF_EXTRA_DIR, 27
-    groups = (4 + 3 * 16 + 20 + 3 * 16 + 16) * 8 + (16 + 2) * 4
+    # (round 6: + the sigma head panel, 16 groups in front of xyz_encoding_final, and the rgb head panel, 8 groups behind
+    #  extra_encoding -- NetLayout::head_tiles: the fast mode's heads run on the matrix pipe)
+    groups = (4 + 3 * 16 + 20 + 3 * 16 + 16) * 8 + (16 + 2) * 4 + 16 + 8
     assert lib.mf_nerf_packed_bytes_p(ctypes.byref(d), L.MF_PREC_BF16) == 13 * 1024 + groups * 1024
     # MF_PREC_BF16X3: the NeRF's k-steps as (hi, lo) group pairs -- twice the groups of the bf16 layout (its encodings split
     # too); the NoF's as IEEE-half (hi, lo) pairs (round 5: three products per k-step on the f16 matrix instruction, 22
