@@ -848,12 +848,14 @@ MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&
 #pragma unroll
     for (int i = 0; i < 4; ++i) act[t][i] = 0;
   const int D = net.D;
-  // the head panel (16 groups) follows the last trunk layer contiguously; behind it comes `follow`'s first panel
-  const Next hd{16, nullptr, follow.groups, follow.jump};
+  // the head panel (8 groups: rows c = bf16(w_c), rows 16 + c = bf16(w_c - hi), NetLayout::head_tiles) follows the last trunk
+  // layer contiguously; behind it comes `follow`'s first panel
+  const Next hd{8, nullptr, follow.groups, follow.jump};
   trunk<8, kKsNofXyz, true, kNofTpp0, kNofTppH, kNofTppS>(net, D, act, xhi, xlo, st, carry, id,
       [&](int l) { return l == D - 1 ? hd : next_trunk_np<8, kKsNofXyz, true, kNofTppH, kNofTppS>(net, l + 1, D, hd); }, rb, rbp, after_first);
-  // head on the matrix pipe (16 MFMAs instead of 9 x 64 dependent FMAs + 144 LDS reads per lane); T[0..3] come
-  // out in half 0's registers 0-3, T[4..7] in half 1's registers 0-3, T[8] in half 0's register 4
+  // head on the matrix pipe (8 MFMAs instead of 9 x 64 dependent FMAs + 144 LDS reads per lane; rounds 2-5: 16, the terms as
+  // group pairs); T[0..3] come out in half 0's registers 0-3 (+ their lo terms in 8-11), T[4..7] in half 1's registers 0-3
+  // (+ 8-11), T[8] in half 0's register 4 (+ 12)
   f32x16 acc;
   {
     const uint32_t p = st.slot_off(0) + id.lane * 16, pn = st.slot_off(1) + id.lane * 16;
@@ -861,12 +863,12 @@ MF_D void nof_eval(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4 (&
     auto hook = [&]() { st.sync(follow.groups2, follow.jump2, id); };
     auto piece = [&](int k) { st.piece(k, id); };
     // resident block: [bias_trunk D 128 | head_w n_head 128 | head_b 32]
-    acc = head_tile<8>(carry, act, p, pn, net.res_lds + (D + net.aux) * 128 * 4, id.h, hook, piece);
+    acc = head_tile<8, 1>(carry, act, p, pn, net.res_lds + (D + net.aux) * 128 * 4, id.h, hook, piece);
     st.advance();
   }
   float own[5], oth[5];
 #pragma unroll
-  for (int i = 0; i < 5; ++i) { own[i] = acc[i]; oth[i] = __shfl_xor(acc[i], 32, 64); }
+  for (int i = 0; i < 5; ++i) { own[i] = acc[i] + acc[8 + i]; oth[i] = __shfl_xor(own[i], 32, 64); }
   if (net.aux == 9) {
     float T[9];
 #pragma unroll

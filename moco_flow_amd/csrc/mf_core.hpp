@@ -205,7 +205,8 @@ struct NetLayout {
   int off_rgb_w;           // NeRF: 3 * W/2
   int off_rgb_b;
   int n_head;              // NoF: 9 | 3
-  int head_tiles;          // NeRF, fast bf16 mode (round 6): the sigma and rgb heads are matrix-pipe panels of the weight stream --
+  int head_tiles;          // fast bf16 mode (round 6).  NoF: the head panel's (hi, lo) terms are tile rows c and 16 + c of ONE group per
+                           // k-step instead of group pairs.  NeRF: the sigma and rgb heads are matrix-pipe panels of the weight stream --
                            // ONE 32-row tile each whose rows c < n are bf16(w_c) and rows 8 + c are bf16(w_c - hi) (both land in
                            // lane half 0's accumulators: registers c and 4 + c), plain hidden k-steps: NK groups behind trunk layer
                            // D - 1 (sigma, in front of xyz_encoding_final), NK / 2 groups behind extra_encoding (rgb)
@@ -227,7 +228,8 @@ MF_HD int trunk_groups(const NetLayout& L, int layer) {
 }
 // bf16 NoF: the 3|9-row head (nof.py:75-82) as one more panel behind the trunk: a 32-row tile (rows >= n_head zero)
 // whose hidden k-steps are split (hi, lo) group pairs -- the head's weights keep 16 mantissa bits (x3: `terms` groups).
-MF_HD int head_groups(const NetLayout& L) { return L.terms * L.NK; }
+// (fast mode, round 6 -- NetLayout::head_tiles: ONE group per k-step, the (hi, lo) terms as ROWS c and 16 + c of the tile)
+MF_HD int head_groups(const NetLayout& L) { return (L.head_tiles ? 1 : L.terms) * L.NK; }
 MF_HD int nerf_sigma_groups(const NetLayout& L) { return L.head_tiles ? L.NK : 0; }
 MF_HD int nerf_rgb_groups(const NetLayout& L) { return L.head_tiles ? L.NK / 2 : 0; }
 MF_HD int extra_groups(const NetLayout& L) {

@@ -88,6 +88,7 @@ inline bool nof_layout(const mf_nof_desc& d, NetLayout& L, int bf16 = 0, bool wi
   L.hsplit_mask = x3 ? ((1u << d.D) - 1u) & ~1u : 0u;  // x3: every hidden range split too
   L.terms = x3 ? kNofTermsX3 : 2;                      // x3: kNofTermsX3 terms per split operand (mf_core.hpp)
   L.half = (x3 && kNofHalfX3) ? 1 : 0;                 // x3: IEEE-half (hi, lo) pairs, scaled (mf_core.hpp)
+  L.head_tiles = bf16 == MF_PREC_BF16 ? 1 : 0;         // fast mode: the head panel's terms as tile rows (NetLayout::head_tiles)
   L.emb_mask = 1u | d.skip_mask;
   L.relu_mask = (1u << d.D) - 1u;
   L.extra_steps = -1;

@@ -28,7 +28,8 @@ struct PackRegion {          // one trunk/extra layer's panels
   int hid_col0;              // column of hidden feature 0 in W
   int xyz_cols;
   int n_rows;                // rows present in W (bf16 head panel: 3|9 of its 32; 0 = all)
-  int row_terms;             // bf16 head panel of the NeRF (NetLayout::head_tiles): tile row c < n_rows = bf16(W[c]), row 8 + c = bf16(W[c] - hi)
+  int row_terms;             // bf16 head panels of the fast mode (NetLayout::head_tiles): tile row c < n_rows = bf16(W[c]), row row_terms + c =
+                             // bf16(W[c] - hi); row_terms = 8 (NeRF sigma / rgb: <= 4 rows) or 16 (NoF head: 3 | 9 rows); 0 = off
   int half;                  // the split terms are IEEE halves of wscale * w (NetLayout::half) instead of bf16
   float wscale;
   int hid_split;             // bf16: groups per hidden k-step ks: 1 = plain, 2 = (hi, lo), 3 = (hi, mid, lo)
@@ -70,8 +71,8 @@ __global__ void pack_panels_kernel(PackJob job) {
     int srow = 32 * P + i, rterm = 0;
     bool zero_row = R.n_rows && srow >= R.n_rows;
     if (R.row_terms) {                                       // (hi rows at 0 .., lo rows at 8 ..: both in lane half 0's accumulators)
-      zero_row = !(srow < R.n_rows || (srow >= 8 && srow < 8 + R.n_rows));
-      if (srow >= 8) { rterm = 1; srow -= 8; }
+      zero_row = !(srow < R.n_rows || (srow >= R.row_terms && srow < R.row_terms + R.n_rows));
+      if (srow >= R.row_terms) { rterm = 1; srow -= R.row_terms; }
     }
     const float* row = R.W + (long long)(zero_row ? 0 : srow) * R.n_in;
     const int eg = R.emb_split * R.emb_steps;                // groups of the embedded block
@@ -209,7 +210,7 @@ extern "C" int32_t mf_nerf_pack_p(const mf_nerf_desc* d, int32_t precision, void
     R.hid_batches = groups;
     R.bf16 = 1;
     R.n_rows = rows;
-    R.row_terms = 1;
+    R.row_terms = 8;
     R.hid_split = 1;
     R.emb_split = 1;
     R.dst_group0 = g0;
@@ -339,7 +340,8 @@ extern "C" int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* 
     R.hid_batches = L.NK;
     R.bf16 = 1;
     R.n_rows = L.n_head;
-    R.hid_split = L.terms;
+    R.hid_split = L.head_tiles ? 1 : L.terms;
+    R.row_terms = L.head_tiles ? 16 : 0;
     R.emb_split = 1;
     R.half = L.half;
     R.wscale = wscale;

@@ -37,10 +37,10 @@ def main():
     for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
         env.pop(k, None)
     status = {}
-    status["rccl"] = run([sys.executable, os.path.join(ROOT, "tests", "rccl_child.py")], os.path.join(out, "rccl.log"), env, 600)
+    status["rccl"] = run([sys.executable, os.path.join(ROOT, "tests", "rccl_child.py")], os.path.join(out, "rccl.log"), env, 240)
     benv = dict(env, MF_BENCH_SHARE_GPU="1", MF_BENCH_BACKEND="gloo")
     status["bench2"] = run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
-                           os.path.join(out, "bench2.log"), benv, 900)
+                           os.path.join(out, "bench2.log"), benv, 420)
     with open(os.path.join(out, "status.json"), "w") as fh:
         json.dump(status, fh)
 

@@ -174,7 +174,7 @@ def test_packed_layout_sizes():
     # 16-group panel, and the fp32 image-index columns of its two embedded layers (2 x 128 rows x 36 floats = 36 KiB: the
     # per-ray bias is made from them) follow the panels; the NeRF's encodings are single groups (plain bf16 operands:
     # 4 k-steps of the xyz block, 2 of the direction block)
-    assert lib.mf_nof_packed_bytes_p(ctypes.byref(n), L.MF_PREC_BF16) == 7 * 1024 + ((6 + 8 + 14 + 8) * 4 + 16) * 1024 + 36 * 1024
+    assert lib.mf_nof_packed_bytes_p(ctypes.byref(n), L.MF_PREC_BF16) == 7 * 1024 + ((6 + 8 + 14 + 8) * 4 + 8) * 1024 + 36 * 1024      # (round 6: the head panel is 8 groups, its (hi, lo) terms are tile rows)
     d.extra_feat_type, d.extra_feat_dim = L.MF_EXTRA_DIR, 27
     # (round 6: + the sigma head panel, 16 groups in front of xyz_encoding_final, and the rgb head panel, 8 groups behind
     #  extra_encoding -- NetLayout::head_tiles: the fast mode's heads run on the matrix pipe)
