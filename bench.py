@@ -277,10 +277,15 @@ def traffic_of(name):
         with open(os.path.join(ROOT, "profiles", "traffic.json")) as fh:
             t = json.load(fh).get(name)
         if t:
-            return t["bytes_per_launch"], t["source"], t
+            return t.get("bytes_per_launch"), t.get("source"), t
     except (OSError, ValueError, KeyError):
         pass
     return None, None, {}
+
+
+def train_traffic(key):
+    t = traffic_of(key)[2]
+    return {"hbm_gb_per_step": t["hbm_gb_per_step"], "hbm_profile": t.get("profile")} if t.get("hbm_gb_per_step") else {}
 
 
 def algorithmic_bytes(cfg, launch_samples):
@@ -385,7 +390,9 @@ def train_shape_legs(M, synth, torch, dev, steps=6):
             m.zero_grad(set_to_none=True)
         crit(M.render_rays(rays, bg, embs, nerfs, **kw), gt).backward()
 
-    out["stage1"] = {"ms_per_step": med(stage1), "rays": N, "samples_per_ray": 384}
+    # hbm_gb_per_step: FETCH_SIZE x 2 + WRITE_SIZE summed over the step's kernels, from the committed rocprofv3 passes of the same step
+    # (profiles/traffic.json["train_stage1" | "train_joint"], tools/profile_train_all.sh): a profile-derived constant like roofline.from_profiles
+    out["stage1"] = {"ms_per_step": med(stage1), "rays": N, "samples_per_ray": 384, **train_traffic("train_stage1")}
     # the same step with the opt-in three-product training forward (set_train_forward_precision("bf16x3"): forward values to
     # 5e-6 max-rel, but gradients then differ from the fp32 oracle's by ~3e-3 max-rel through ReLU units that change side
     # -- outside the 1e-4 bars the default is held to; reported for information)
@@ -411,7 +418,7 @@ def train_shape_legs(M, synth, torch, dev, steps=6):
             loss = loss + 0.1 * res[k].mean()
         loss.backward()
 
-    out["joint"] = {"ms_per_step": med(joint), "rays": N, "samples_per_ray": 384}
+    out["joint"] = {"ms_per_step": med(joint), "rays": N, "samples_per_ray": 384, **train_traffic("train_joint")}
     # the whole training ITERATION as a trainer runs it: + the optimizer step (Adam over the four networks), after which every
     # network re-packs its weight streams at the next forward (round 5: +0.26 ms)
     opt = torch.optim.Adam([q for m in nerfs + nofs for q in m.parameters()], lr=1e-7)

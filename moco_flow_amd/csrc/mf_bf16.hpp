@@ -1334,6 +1334,13 @@ MF_D void nof_eval_x3(const Net& net, const u32x4 (&xhi)[kKsNofXyz], const u32x4
 #pragma unroll
     for (int c = 0; c < 3; ++c) { T9[c] = id.h ? oth[c] : own[c]; out[c] = T9[c] + xyz[c]; }
   }
+  if constexpr (HF) {
+    // the packer's poison slot (mf_pack.hip): rows 27 / 31 of the head tile have zero weights and a bias of 0 -- or NaN when one
+    // of this network's weights did not fit the half range; register 15 is that row in either lane half.  + 0 changes nothing.
+    const float poison = acc[15];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) out[c] += poison;
+  }
   if constexpr (__is_same(DT, RowDump)) {
     if (dump.on && id.h == 0) {                               // (h == 0: dump.row is the row's start)
       f32x4* tr = reinterpret_cast<f32x4*>(dump.row + D * 128);

@@ -42,6 +42,7 @@ struct PackJob {
   int n_regions;
   long long total_groups;
   float* panels;             // packed + res_bytes
+  float* poison;             // half-pair layouts: resident head-bias rows 27 (+ 4 = 31), set to NaN when a weight saturates; else null
 };
 
 __device__ inline unsigned short bf16_rne(float x) {        // round to nearest even (inf / nan pass through)
@@ -83,14 +84,16 @@ __global__ void pack_panels_kernel(PackJob job) {
     // term t of a weight: t = 0: bf16(w); 1: bf16(w - hi); 2: bf16(w - hi - mid)   (exact fp32 subtractions)
     const bool half = R.half != 0;
     const float ws = R.wscale;
-    auto term = [half, ws](float w, int t) {
-      if (half) {                                           // hi = half(ws w), lo = half(ws w - hi)
-        // |ws w| beyond the half range (|w| >= 2047 at ws = 2^5: no trained NoF is near it): the weight goes into the stream as a
-        // quiet NaN, so every ray that touches it comes out NaN -- the same loud failure as an activation beyond the range
-        // (mf_core.hpp, kNofHalfX3).  Rounds 5's saturation to +-65504 gave finite WRONG results with no diagnostic;
-        // a host-side check would cost a device sync at every re-pack, i.e. at every optimizer step.
+    bool sat = false;
+    auto term = [half, ws, &sat](float w, int t) {
+      if (half) {                                           // hi = half(ws w) (saturated: no inf in the stream), lo = half(ws w - hi)
+        // |ws w| beyond the half range (|w| >= 2047 at ws = 2^5: no trained NoF is near it) cannot be represented: the weight is
+        // saturated AND the network's poison slots are set (job.poison, below) -- every point the network evaluates then comes out
+        // NaN.  Round 5 saturated silently: finite WRONG results with no diagnostic; a host-side check would cost a
+        // device sync at every re-pack, i.e. at every optimizer step.
         w = w * ws;
-        if (!(fabsf(w) <= 65504.f)) return (unsigned short)0x7e00;
+        if (!(fabsf(w) <= 65504.f)) sat = true;
+        w = fminf(fmaxf(w, -65504.f), 65504.f);
         __half hb = __float2half_rn(w);
         if (t > 0) hb = __float2half_rn(w - __half2float(hb));
         return __half_as_ushort(hb);
@@ -117,6 +120,9 @@ __global__ void pack_panels_kernel(PackJob job) {
     unsigned* pu = reinterpret_cast<unsigned*>(&v.x);
     for (int w = 0; w < 4; ++w) pu[w] = (unsigned)h8[2 * w] | ((unsigned)h8[2 * w + 1] << 16);
     reinterpret_cast<float4*>(job.panels)[gidx] = v;
+    // poison: rows 27 / 31 of the head's 32-row bias vector (the two lane halves' last junk rows: zero weight rows, so their
+    // accumulators ARE this value) -- nof_eval_x3 adds that accumulator to every output point: + 0 or + NaN
+    if (sat && job.poison) { job.poison[0] = __int_as_float(0x7fc00000); job.poison[4] = __int_as_float(0x7fc00000); }
     return;
   }
   const int b = gi >> 1, half = gi & 1;                 // batch within the panel, tile half
@@ -353,6 +359,7 @@ extern "C" int32_t mf_nof_pack_p(const mf_nof_desc* d, int32_t precision, void* 
   job.n_regions = nr;
   job.total_groups = g0;
   job.panels = reinterpret_cast<float*>(static_cast<char*>(packed) + L.res_bytes);
+  job.poison = L.half ? static_cast<float*>(packed) + L.off_head_b + 27 : nullptr;       // (the resident kernel zero-fills them first)
   rj.res = static_cast<float*>(packed);
   rj.total = (int)(L.res_bytes / 4);
   if (g0 * kGroupBytes != L.panel_bytes) return fail(MF_E_INVALID, "mf_nof_pack: layout mismatch");

@@ -4,9 +4,11 @@
 // written to HBM -- on the 32x32x16 bf16 core of mf_bf16.hpp: a wave owns 32 samples, a workgroup tile is 256
 // samples, a weight panel is one 32-row tile of a layer.
 #include <cstddef>
+#include <cstdlib>
 #include <type_traits>
 
 #include "mf_bf16.hpp"
+#include "mf_bf16_2b.hpp"
 #include "mf_host.hpp"
 #include "mf_layout.hpp"
 
@@ -63,6 +65,7 @@ struct RayBiasParams {
 };
 
 constexpr int kRbEntries = 8;       // entries (rays) per workgroup of nof_raybias_kernel
+constexpr int kFastBlocksDefault = 1; // column blocks per wave of the fast mode's render kernels (see render_pass_bf16)
 
 // grid (ceil(n_entries / 8), n_combos), 256 threads.  Thread (embedded layer, row) first requests its 33 index-column
 // weights + bias (coalesced: the packed block is [layer][column][row]); while they travel, threads (entry e, frequency k)
@@ -158,6 +161,70 @@ MF_D void tile_rays(int tile, int nr, int S, int& first, int& n) {
   const int s0 = tile * TILE, s1 = (s0 + TILE < nr * S ? s0 + TILE : nr * S) - 1;
   first = s0 / S;
   n = s1 / S - first + 1;
+}
+
+// ---- composite (rendering.py:157-192) of a group's rays out of the LDS sample buffers: one wave per ray, lanes over samples
+template <int NW>
+MF_D void composite_group(const Params& p, const Lane& id, long long ray0, int nr, int S, bool sigma_only, const float4* sbuf, const float* zbuf) {
+    for (int rr = id.wave; rr < nr; rr += NW) {
+    const long long ray = ray0 + rr;
+    const float* rp = p.rays + ray * p.ray_stride;
+    const float dnorm = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);  // rendering.py:164
+    float carry_t = 1.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_w = 0.f;
+    for (int base = 0; base < S; base += 64) {
+      // (the lane index is made opaque here: hipcc otherwise hoists `plane + 4 lane` of every output plane out of the
+      //  whole group loop as 64-bit per-lane addresses and spills them across the MFMA section)
+      int ln = id.lane;
+      asm volatile("" : "+v"(ln));
+      const int i = base + ln;
+      const bool v = i < S;
+      const int ii = v ? i : S - 1;
+      const float4 s4 = sbuf[rr * S + ii];
+      const float z = zbuf[rr * S + ii];
+      const float znext = zbuf[rr * S + (ii + 1 < S ? ii + 1 : ii)];
+      float delta = (ii == S - 1) ? 1e10f : znext - z;                       // :158-160
+      delta = delta * dnorm;
+      float sg = s4.w;
+      if (p.noise) sg = sg + p.noise[ray * S + ii];                          // :166 (pre-scaled)
+      float a;
+      if (p.activation == MF_ACT_RELU) a = fmaxf(sg, 0.f);
+      else a = sg > 20.f ? sg : log1pf(expf(sg));                            // nn.Softplus(beta=1, threshold=20)
+      float alpha = 1.f - expf(-delta * a);                                  // :170/172
+      if (!v) alpha = 0.f;
+      const float pt = v ? (1.f - alpha) + 1e-10f : 1.f;                     // :176-177
+      const float incl = wave_scan_mul_dpp(pt);
+      const float excl = wave_shr1_dpp(1.f, incl);
+      const float w = alpha * (carry_t * excl);                              // :178-179
+      carry_t = carry_t * wave_last(incl);
+      if (v) {
+        if (p.weights) p.weights[ray * S + i] = w;
+#ifndef MF_TIMELINE
+        if (p.alphas) p.alphas[ray * S + i] = alpha;
+#endif
+        acc_w += w;
+        acc_r += w * s4.x; acc_g += w * s4.y; acc_b += w * s4.z;
+        acc_d += w * z;
+      }
+    }
+    acc_w = wave_sum_dpp(acc_w);                                                 // :180
+    if (!sigma_only) {
+      acc_r = wave_sum_dpp(acc_r); acc_g = wave_sum_dpp(acc_g); acc_b = wave_sum_dpp(acc_b);   // :186
+      acc_d = wave_sum_dpp(acc_d);                                               // :187
+    }
+    if (id.lane == 0) {
+      if (p.opacity) p.opacity[ray] = acc_w;
+      if (!sigma_only) {
+        if (p.bg) {                                                          // :189-190
+          const float k = 1.f - acc_w;
+          acc_r = acc_r + p.bg[ray * 3 + 0] * k;
+          acc_g = acc_g + p.bg[ray * 3 + 1] * k;
+          acc_b = acc_b + p.bg[ray * 3 + 2] * k;
+        }
+        if (p.rgb) { p.rgb[ray * 3 + 0] = acc_r; p.rgb[ray * 3 + 1] = acc_g; p.rgb[ray * 3 + 2] = acc_b; }
+        if (p.depth) p.depth[ray] = acc_d;
+      }
+    }
+  }
 }
 
 // X3: MF_PREC_BF16X3 (mf_bf16.hpp: every matrix product as a three-product split, heads on fp32 accumulators): 4 waves,
@@ -380,6 +447,14 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
         st.tl.stamp(4, id);
         nerf_eval(p.nerf, xe, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb);
       }
+      {
+        // NaN / inf in the point the NeRF sees (a NaN ray; a NoF whose weights left the half range: mf_pack.hip's poison slot) must
+        // come OUT as NaN: the integer-max ReLUs of these kernels turn a NaN with the sign bit set into 0, so a poisoned network
+        // would otherwise render finite garbage.  (x * 0 is not folded: no fast-math in this unit.)
+        const float nanprop = (xin[0] + xin[1] + xin[2]) * 0.f;
+        sigma += nanprop;
+        rgb[0] += nanprop; rgb[1] += nanprop; rgb[2] += nanprop;
+      }
       if (valid && id.h == 0) {
         sbuf[srel] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
         zbuf[srel] = z;
@@ -389,66 +464,7 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
     __syncthreads();
     st.tl.stamp(6, id);
 
-    // ---- composite (rendering.py:157-192): one wave per ray, lanes over samples
-    for (int rr = id.wave; rr < nr; rr += NW) {
-      const long long ray = ray0 + rr;
-      const float* rp = p.rays + ray * p.ray_stride;
-      const float dnorm = sqrtf(rp[3] * rp[3] + rp[4] * rp[4] + rp[5] * rp[5]);  // rendering.py:164
-      float carry_t = 1.f, acc_r = 0.f, acc_g = 0.f, acc_b = 0.f, acc_d = 0.f, acc_w = 0.f;
-      for (int base = 0; base < S; base += 64) {
-        // (the lane index is made opaque here: hipcc otherwise hoists `plane + 4 lane` of every output plane out of the
-        //  whole group loop as 64-bit per-lane addresses and spills them across the MFMA section)
-        int ln = id.lane;
-        asm volatile("" : "+v"(ln));
-        const int i = base + ln;
-        const bool v = i < S;
-        const int ii = v ? i : S - 1;
-        const float4 s4 = sbuf[rr * S + ii];
-        const float z = zbuf[rr * S + ii];
-        const float znext = zbuf[rr * S + (ii + 1 < S ? ii + 1 : ii)];
-        float delta = (ii == S - 1) ? 1e10f : znext - z;                       // :158-160
-        delta = delta * dnorm;
-        float sg = s4.w;
-        if (p.noise) sg = sg + p.noise[ray * S + ii];                          // :166 (pre-scaled)
-        float a;
-        if (p.activation == MF_ACT_RELU) a = fmaxf(sg, 0.f);
-        else a = sg > 20.f ? sg : log1pf(expf(sg));                            // nn.Softplus(beta=1, threshold=20)
-        float alpha = 1.f - expf(-delta * a);                                  // :170/172
-        if (!v) alpha = 0.f;
-        const float pt = v ? (1.f - alpha) + 1e-10f : 1.f;                     // :176-177
-        const float incl = wave_scan_mul_dpp(pt);
-        const float excl = wave_shr1_dpp(1.f, incl);
-        const float w = alpha * (carry_t * excl);                              // :178-179
-        carry_t = carry_t * wave_last(incl);
-        if (v) {
-          if (p.weights) p.weights[ray * S + i] = w;
-#ifndef MF_TIMELINE
-          if (p.alphas) p.alphas[ray * S + i] = alpha;
-#endif
-          acc_w += w;
-          acc_r += w * s4.x; acc_g += w * s4.y; acc_b += w * s4.z;
-          acc_d += w * z;
-        }
-      }
-      acc_w = wave_sum_dpp(acc_w);                                                 // :180
-      if (!sigma_only) {
-        acc_r = wave_sum_dpp(acc_r); acc_g = wave_sum_dpp(acc_g); acc_b = wave_sum_dpp(acc_b);   // :186
-        acc_d = wave_sum_dpp(acc_d);                                               // :187
-      }
-      if (id.lane == 0) {
-        if (p.opacity) p.opacity[ray] = acc_w;
-        if (!sigma_only) {
-          if (p.bg) {                                                          // :189-190
-            const float k = 1.f - acc_w;
-            acc_r = acc_r + p.bg[ray * 3 + 0] * k;
-            acc_g = acc_g + p.bg[ray * 3 + 1] * k;
-            acc_b = acc_b + p.bg[ray * 3 + 2] * k;
-          }
-          if (p.rgb) { p.rgb[ray * 3 + 0] = acc_r; p.rgb[ray * 3 + 1] = acc_g; p.rgb[ray * 3 + 2] = acc_b; }
-          if (p.depth) p.depth[ray] = acc_d;
-        }
-      }
-    }
+    composite_group<NW>(p, id, ray0, nr, S, sigma_only, sbuf, zbuf);
     st.tl.stamp(7, id);
     __syncthreads();
     st.tl.stamp(8, id);
@@ -462,6 +478,188 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
     o[3] = (float)(__builtin_amdgcn_s_memrealtime() & 0xFFFFFFull);
   }
 #endif
+}
+
+// The fast mode with two column blocks per wave (mf_bf16_2b.hpp): 4 waves, one per SIMD, 64 samples each -- 256-sample tiles as
+// render_kernel_bf16<*, false>, the same panel program, the same arithmetic (bit-identical outputs); every weight fragment read
+// from LDS feeds two MFMAs.  The per-sample code of a tile runs once per block b: sample slot wave * 64 + 32 b + (lane & 31).
+template <bool MOCO>
+__global__ __launch_bounds__(256, 1) void render_kernel_bf16_2b(const Params p) {
+  constexpr int NW = kWaves2;
+  constexpr int TILE = NW * kBlockSamples;
+  const Lane id;
+  load_resident<NW>(p.nerf, id);
+  if (MOCO) {
+    load_resident<NW>(p.bw, id);
+    if (p.flags & (MF_F_CHAIN_LOCAL | MF_F_CHAIN_GLOBAL)) load_resident<NW>(p.fw, id);
+  }
+  if (threadIdx.x < 128) {
+    typedef const __attribute__((address_space(4))) char* kptr;
+    const kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr() + offsetof(Params, emb_par);
+    *(float*)(smem + p.par_off + threadIdx.x * 4) = ((const __attribute__((address_space(4))) float*)ka)[threadIdx.x];
+  }
+  const uint32_t par_nerf_xyz = p.par_off, par_nerf_ext = p.par_off + 128, par_nof_xyz = p.par_off + 256;
+  Stream2 st;
+  st.tl.start(p.alphas, id);
+  Carry carry;
+  const Next prog_first = MOCO ? first_of<8, kKsNofXyz, true, kNofTpp0, 2, kNofTppH, kNofTppS>(p.bw) : first_of<16, kKsNerfXyz, false, kNerfTpp0>(p.nerf);
+  int seq = 0;
+  if (MOCO) {
+    const long long g0 = blockIdx.x;
+    const int nr0 = group_rays(p.n_rays, g0, p.G);
+    int f0, n0;
+    tile_rays<TILE>(0, nr0, p.S, f0, n0);
+    stage_raybias<NW>(p, g0 * p.G + f0, n0, 0, p.rb_off, id);
+  }
+  if (MOCO) start_program<8, kKsNofXyz, true, kNofTpp0, 2, kNofTppH, kNofTppS>(p.bw, st, carry, p.ring_off, p.buf_bytes, id);
+  else start_program<16, kKsNerfXyz, false, kNerfTpp0>(p.nerf, st, carry, p.ring_off, p.buf_bytes, id);
+
+  const int S = p.S;
+  const bool sigma_only = p.flags & MF_F_SIGMA_ONLY;
+  float4* sbuf = reinterpret_cast<float4*>(smem + p.sbuf_off);
+  float* zbuf = reinterpret_cast<float*>(smem + p.zbuf_off);
+
+  for (long long group = blockIdx.x; group < p.n_groups; group += gridDim.x) {
+    const long long ray0 = group * p.G;
+    const int nr = group_rays(p.n_rays, group, p.G);
+    const int nsamp = nr * S;
+    const int ntiles = (nsamp + TILE - 1) / TILE;
+
+    for (int tile = 0; tile < ntiles; ++tile) {
+      st.tl.stamp(1, id);
+      int ln;
+      asm volatile("v_mbcnt_lo_u32_b32 %0, -1, 0\n\tv_mbcnt_hi_u32_b32 %0, -1, %0" : "=v"(ln));
+      int srel[2], rr[2], si[2];
+      bool valid[2];
+      const float* rp[2];
+      float z[2], x[2][3], xin[2][3];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        srel[b] = tile * TILE + id.wave * kBlockSamples + b * kWaveSamples + (ln & 31);
+        valid[b] = srel[b] < nsamp;
+        const int sl = valid[b] ? srel[b] : nsamp - 1;
+        rr[b] = sl / S;
+        si[b] = sl - rr[b] * S;
+        const long long ray = ray0 + rr[b];
+        rp[b] = p.rays + ray * p.ray_stride;
+        const float o[3] = {rp[b][0], rp[b][1], rp[b][2]};
+        const float d[3] = {rp[b][3], rp[b][4], rp[b][5]};
+        if (p.z_vals) {
+          z[b] = p.z_vals[ray * S + si[b]];
+        } else {
+          const float nearv = rp[b][6], farv = rp[b][7], t = p.z_steps[si[b]];
+          if (!p.use_disp) z[b] = nearv * (1.f - t) + farv * t;                    // rendering.py:247
+          else z[b] = 1.f / (1.f / nearv * (1.f - t) + 1.f / farv * t);            // rendering.py:249
+        }
+#pragma unroll
+        for (int c = 0; c < 3; ++c) { x[b][c] = o[c] + d[c] * z[b]; xin[b][c] = x[b][c]; }      // rendering.py:262-263
+      }
+      st.tl.stamp(2, id);
+      if (MOCO) {
+        // chain program (rendering.py:270-282), as render_kernel_bf16
+        const bool loc = p.flags & MF_F_CHAIN_LOCAL, glob = p.flags & MF_F_CHAIN_GLOBAL;
+        const int nsteps = 1 + (loc ? 1 : 0) + (glob ? 3 : 0);
+        float canon[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}}, cur[2][3];
+        float dl[2] = {0.f, 0.f}, dg[2] = {0.f, 0.f};
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int c = 0; c < 3; ++c) cur[b][c] = x[b][c];
+        for (int step = 0; step < nsteps; ++step) {
+          const int role = step;
+          const bool use_fw = (role == 1 || role == 2 || role == 4);
+          const Net net = use_fw ? p.fw : p.bw;
+          int tf, tn;
+          tile_rays<TILE>(tile, nr, S, tf, tn);
+          const uint32_t rbase = p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes;
+          const LdsRayBias rb[2] = {LdsRayBias{rbase + (uint32_t)(rr[0] - tf) * (uint32_t)(p.rb_layers * 512)},
+                                    LdsRayBias{rbase + (uint32_t)(rr[1] - tf) * (uint32_t)(p.rb_layers * 512)}};
+          ++seq;
+          if (role == 1 || role == 2) {
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+              for (int c = 0; c < 3; ++c) cur[b][c] = canon[b][c];
+          }
+          const bool last = step == nsteps - 1;
+          const bool next_fw = (role + 1 == 1 || role + 1 == 2 || role + 1 == 4);
+          const Next follow = last ? first_of<16, kKsNerfXyz, false, kNerfTpp0>(p.nerf)
+                                   : first_of<8, kKsNofXyz, true, kNofTpp0, 2, kNofTppH, kNofTppS>(next_fw ? p.fw : p.bw);
+          u32x4 nhi[2][kKsNofXyz], nlo[2][kKsNofXyz];
+          float out[2][3];
+          nof_embed<true>(nhi[0], nlo[0], cur[0], par_nof_xyz, id.h, p.pow2 & 4);
+          nof_embed<true>(nhi[1], nlo[1], cur[1], par_nof_xyz, id.h, p.pow2 & 4);
+          auto stage_next = [&] {
+            if (!last) stage_raybias<NW>(p, ray0 + tf, tn, role + 1 == 4 ? 1 : role + 1, p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes, id);
+          };
+          nof_eval2(net, nhi, nlo, cur, st, carry, id, follow, out, rb, stage_next);
+#pragma unroll
+          for (int b = 0; b < 2; ++b) {
+            if (role == 0) { canon[b][0] = out[b][0]; canon[b][1] = out[b][1]; canon[b][2] = out[b][2]; }
+            if (role == 1) dl[b] = (fabsf(x[b][0] - out[b][0]) + fabsf(x[b][1] - out[b][1]) + fabsf(x[b][2] - out[b][2])) / 3.f;
+            if (role == 4) dg[b] = (fabsf(x[b][0] - out[b][0]) + fabsf(x[b][1] - out[b][1]) + fabsf(x[b][2] - out[b][2])) / 3.f;
+            cur[b][0] = out[b][0]; cur[b][1] = out[b][1]; cur[b][2] = out[b][2];
+          }
+        }
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          xin[b][0] = canon[b][0]; xin[b][1] = canon[b][1]; xin[b][2] = canon[b][2];
+          if (valid[b] && id.h == 0) {
+            const long long idx = (ray0 + rr[b]) * S + si[b];
+            if (loc && p.disp_local) p.disp_local[idx] = dl[b];
+            if (glob && p.disp_global) p.disp_global[idx] = dg[b];
+          }
+        }
+        // rows of the NEXT tile's first evaluation (see render_kernel_bf16)
+        const bool more = tile + 1 < ntiles;
+        const long long ng = more ? group : group + gridDim.x;
+        if (ng < p.n_groups) {
+          const int nnr = group_rays(p.n_rays, ng, p.G);
+          int nf, nn;
+          tile_rays<TILE>(more ? tile + 1 : 0, nnr, S, nf, nn);
+          stage_raybias<NW>(p, ng * p.G + nf, nn, 0, p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes, id);
+        }
+      }
+      st.tl.stamp(3, id);
+      float sigma[2], rgb[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
+      u32x4 xe[2][kKsNerfXyz];
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float embx[B2Xyz10::SLOTS];
+        emb_eval<3, 10, true>(embx, xin[b], par_nerf_xyz, id.h, p.pow2 & 1);
+        pack_operands<kKsNerfXyz>(embx, B2Xyz10::SLOTS, xe[b]);
+      }
+      auto make_extra = [&](int b, u32x4 (&eo)[kKsExtraMax]) {
+        float ext[8 * kKsExtraMax];
+#pragma unroll
+        for (int e = 0; e < 8 * kKsExtraMax; ++e) ext[e] = 0.f;
+        const float* q = b ? rp[1] : rp[0];
+        if (p.extra_type == MF_EXTRA_DIR) {
+          const float dd[3] = {q[3], q[4], q[5]};
+          emb_eval<3, 4, true>(ext, dd, par_nerf_ext, id.h, p.pow2 & 2);                         // rendering.py:138-142
+        } else if (p.extra_type == MF_EXTRA_IND) {
+          const float iv[1] = {q[8]};
+          emb_eval<1, 2, true>(ext, iv, par_nerf_ext, id.h, p.pow2 & 2);                         // rendering.py:133-137
+        }
+        pack_operands<kKsExtraMax>(ext, 8 * kKsExtraMax, eo);
+      };
+      st.tl.stamp(4, id);
+      nerf_eval2(p.nerf, xe, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float nanprop = (xin[b][0] + xin[b][1] + xin[b][2]) * 0.f;      // (NaN in -> NaN out: see render_kernel_bf16)
+        if (valid[b] && id.h == 0) {
+          sbuf[srel[b]] = make_float4(rgb[b][0] + nanprop, rgb[b][1] + nanprop, rgb[b][2] + nanprop, sigma[b] + nanprop);
+          zbuf[srel[b]] = z[b];
+        }
+      }
+      st.tl.stamp(5, id);
+    }
+    __syncthreads();
+    composite_group<NW>(p, id, ray0, nr, S, sigma_only, sbuf, zbuf);
+    __syncthreads();
+  }
+  wait_vm0();
 }
 
 // sigma (and the canonical position) of free points in bf16 mode: the lattice / SMPL-point query of mf_forward.hip's
@@ -563,7 +761,7 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void points_kernel
       };
       nerf_eval(p.nerf, xe, make_extra, true, st, carry, id, prog_first, sigma, rgb);
     }
-    if (valid && id.h == 0) p.sigma[b] = sigma;
+    if (valid && id.h == 0) p.sigma[b] = sigma + (x[0] + x[1] + x[2]) * 0.f;      // (NaN in -> NaN out: see render_kernel_bf16)
   }
   wait_vm0();
 }
@@ -770,12 +968,22 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
       p.dump_nof_acts = a->dump_nof_acts; p.dump_nof_stride = a->dump_nof_stride; p.dump_nof_out = a->dump_nof_out;
     }
   }
+  // the fast mode's kernels: one column block per wave (8 waves, two per SIMD: the default) or two (mf_bf16_2b.hpp: 4 waves, one
+  // per SIMD, every weight fragment read from LDS feeds two MFMAs); same tiles, same LDS layout, bit-identical results.
+  // MF_BF16_BLOCKS=1|2 selects the family.  Round 6 measured the two-block kernels at parity, not ahead (profiles/r06_two_blocks.txt:
+  // half the LDS instructions, 13 % more cycles with a lone wave per SIMD, a higher clock -- C2 shape -0.5 %, C3 +0.7 %), so
+  // they ship opt-in.
+  // (read per call: a getenv is ~100 ns beside a >= 300 us pass, and a test can switch families inside one process)
+  const char* be = getenv("MF_BF16_BLOCKS");
+  const int blocks = be && be[0] == '1' ? 1 : (be && be[0] == '2' ? 2 : kFastBlocksDefault);
+  const bool two = !x3 && blocks == 2;
   void (*kern)(const Params) = x3 ? (moco ? (dump ? render_kernel_bf16<true, true, true> : render_kernel_bf16<true, true>)
                                           : (dump ? render_kernel_bf16<false, true, true> : render_kernel_bf16<false, true>))
-                                  : (moco ? render_kernel_bf16<true, false> : render_kernel_bf16<false, false>);
+                                  : two ? (moco ? render_kernel_bf16_2b<true> : render_kernel_bf16_2b<false>)
+                                        : (moco ? render_kernel_bf16<true, false> : render_kernel_bf16<false, false>);
   if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
     return fail(MF_E_LAUNCH, "mf_render_pass: cannot reserve %u bytes of LDS", lds);
-  hipLaunchKernelGGL(kern, dim3(grid), dim3(x3 ? 256 : kThreads), lds, st, p);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3((x3 || two) ? 256 : kThreads), lds, st, p);
   return check_launch("mf_render_pass(bf16)");
 }
 

@@ -78,8 +78,13 @@ def test_inference_kernels_have_no_spills_and_stream_weights_by_buffer_dma():
     x3 = [k for k in u16 if re.search(r"render_kernel_bf16ILb[01]ELb1ELb[01]E", k) or      # <MOCO, X3 = true, DUMP>
           re.search(r"points_kernel_bf16ILb[01]ELb0ELb1E", k) or                           # <NOF, PERPT = false, X3 = true>
           "nerf_backward_kernel_x3" in k]                                                 # the three-product dX chain
+    # the opt-in two-block family of the fast mode (mf_bf16_2b.hpp, MF_BF16_BLOCKS=2): one wave per SIMD like the x3 kernels
+    two_block = [k for k in u16 if "render_kernel_bf16_2b" in k]
+    assert len(two_block) == 2, sorted(u16)
+    for k in two_block:
+        assert u16[k]["ScratchSize"] == 0 and u16[k]["VGPRs"] <= 256 and u16[k]["AGPRs"] <= 256 and u16[k]["Occupancy"] == 1, (k, u16[k])
     want = [k for k in u32 if re.search(r"render_kernelILb[01]ELb0EE", k)] + \
-           [k for k in u16 if ("render_kernel_bf16" in k or "points_kernel_bf16" in k) and k not in x3]
+           [k for k in u16 if ("render_kernel_bf16" in k or "points_kernel_bf16" in k) and k not in x3 and k not in two_block]
     assert len(want) == 2 + 5 and len(x3) == 8, sorted(list(u32) + list(u16))   # fp32 NeRF / MoCo; bf16 render x 2, point query x 3; x3: NeRF, MoCo, NeRF + dump, MoCo + dump (round 5), point query x 2, dX chain x 2
     for k in want:
         u = {**u32, **u16}[k]

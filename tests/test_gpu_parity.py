@@ -3,6 +3,8 @@ C ABI, against (a) the golden vectors produced by the reference itself and (b) t
 on the same seeded inputs. Tolerance: 1e-4 max-rel for fp32 values (north_star), bit-exact for
 index bookkeeping (searchsorted indices from a given cdf, mask-compaction order, ray order)."""
 import numpy as np
+import os
+
 import pytest
 import torch
 
@@ -1125,6 +1127,68 @@ def test_repeat_runs_bit_identical(M, name, precision):
                 for k in ref:
                     assert ref[k].shape == out[k].shape, (k, rep)
                     assert torch.equal(ref[k], out[k]), (k, rep, int((ref[k] != out[k]).sum()))
+    finally:
+        rendering.set_precision("f32")
+        rendering.STRICT_RNG = strict
+
+
+@pytest.mark.parametrize("name,n", [("r_nerf_dir_dense", 4096), ("r_moco_local", 4096), ("r_moco_global", 1000), ("r_moco_global_fine", 777)])
+def test_two_block_fast_kernels_bit_identical_to_the_default(M, name, n):
+    """Round 6: the fast bf16 mode's opt-in two-column-block kernels (csrc/mf_bf16_2b.hpp, MF_BF16_BLOCKS=2: 4 waves x 2 x 32
+    samples, every LDS weight fragment feeding two MFMAs) evaluate the SAME arithmetic in the same order as the default
+    8-wave kernels: every output plane bit-identical, ragged tails (n not a multiple of the 256-sample tile) included, and
+    repeatable.  (They ship opt-in: measured at parity, profiles/r06_two_blocks.txt.)"""
+    from moco_flow_amd import rendering, synth
+    c = dict(RENDER_CASES[name])
+    rays_np, bg_np = synth.rays(3, n, chained=(c.get("nof") == "global"))
+    rays, bg = torch.from_numpy(rays_np).cuda(), torch.from_numpy(bg_np).cuda()
+    embs, nerfs, kw = build_case(M, c, 0, device="cuda")
+    strict, lazy, prev = rendering.STRICT_RNG, rendering.LAZY_CONSENSUS, os.environ.get("MF_BF16_BLOCKS")
+    try:
+        rendering.STRICT_RNG, rendering.LAZY_CONSENSUS = False, False
+        rendering.set_precision("bf16")
+        with torch.no_grad():
+            os.environ["MF_BF16_BLOCKS"] = "1"
+            ref = M.render_rays(rays, bg, embs, nerfs, **kw)
+            os.environ["MF_BF16_BLOCKS"] = "2"
+            for rep in range(3):
+                out = M.render_rays(rays, bg, embs, nerfs, **kw)
+                assert set(out) == set(ref)
+                for k in ref:
+                    assert ref[k].shape == out[k].shape, (k, rep)
+                    assert torch.equal(ref[k], out[k]), (k, rep, int((ref[k] != out[k]).sum()))
+    finally:
+        if prev is None:
+            os.environ.pop("MF_BF16_BLOCKS", None)
+        else:
+            os.environ["MF_BF16_BLOCKS"] = prev
+        rendering.set_precision("f32")
+        rendering.STRICT_RNG, rendering.LAZY_CONSENSUS = strict, lazy
+
+
+def test_bf16x3_nof_weight_beyond_the_half_range_fails_loudly(M):
+    """under bf16x3 the NoF's weights travel as IEEE-half (hi, lo) pairs of 32 w; |w| >= 2047 does not fit.  The packer
+    used to saturate such a weight at +-65504 -- finite, WRONG results with no diagnostic.  Now it goes into the stream as a
+    NaN: every ray whose chain touches it renders NaN (the same loud failure as an activation beyond the range), while the
+    fp32 mode evaluates the same network normally."""
+    from moco_flow_amd import rendering, synth
+    c = dict(RENDER_CASES["r_moco_local"])
+    rays_np, bg_np = synth.rays(0, 256)
+    rays, bg = torch.from_numpy(rays_np).cuda(), torch.from_numpy(bg_np).cuda()
+    embs, nerfs, kw = build_case(M, c, 0, device="cuda")
+    bw = kw["nof_models"][0]
+    with torch.no_grad():
+        bw.nof_encoding_2[0].weight[5, 7] = 3000.0
+    strict = rendering.STRICT_RNG
+    try:
+        rendering.STRICT_RNG = False
+        with torch.no_grad():
+            rendering.set_precision("f32")
+            ok = M.render_rays(rays, bg, embs, nerfs, **kw)
+            assert bool(torch.isfinite(ok["rgb_coarse"]).all())
+            rendering.set_precision("bf16x3")
+            bad = M.render_rays(rays, bg, embs, nerfs, **kw)
+            assert bool(torch.isnan(bad["rgb_coarse"]).all())
     finally:
         rendering.set_precision("f32")
         rendering.STRICT_RNG = strict

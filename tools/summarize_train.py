@@ -52,3 +52,34 @@ for k, c in sorted(pmc.items(), key=lambda kv: -sum(dur.get(kv[0], [0]))):
     if "WRITE_SIZE" in m:
         line += f" write {m['WRITE_SIZE'] * 1024 / 1e9:.3f} GB"
     print(line)
+
+# HBM bytes per training step: every kernel's mean FETCH_SIZE (x2: the gfx950 correction of MI355X_MICROARCH.md) +
+# WRITE_SIZE per dispatch x its dispatches per step, all kernels of the trace -- and the time-weighted average rate.
+fetch, write = defaultdict(list), defaultdict(list)
+for r in rows("pmc_fetch/**/*counter_collection.csv"):
+    if r["Counter_Name"] == "FETCH_SIZE":
+        fetch[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+for r in rows("pmc_write/**/*counter_collection.csv"):
+    if r["Counter_Name"] == "WRITE_SIZE":
+        write[r["Kernel_Name"]].append(float(r["Counter_Value"]))
+if fetch and write:
+    rd = sum(2 * sum(v) * 1024 for v in fetch.values()) / STEPS
+    wr = sum(sum(v) * 1024 for v in write.values()) / STEPS
+    ms = tot / STEPS / 1e6
+    print(f"\n== HBM traffic per step: read {rd / 1e9:.1f} GB (FETCH_SIZE x2) + write {wr / 1e9:.1f} GB = {(rd + wr) / 1e9:.1f} GB over {ms:.2f} ms of kernels "
+          f"= {(rd + wr) / 1e9 / ms:.2f} TB/s average")
+    import json
+    with open(os.path.join(out, "traffic_entry.json"), "w") as fh:
+        json.dump({"hbm_gb_per_step": (rd + wr) / 1e9, "read_gb": rd / 1e9, "write_gb": wr / 1e9, "kernel_ms_per_step": ms}, fh)
+    if "--merge" in sys.argv:
+        key, tag = sys.argv[sys.argv.index("--merge") + 1], sys.argv[sys.argv.index("--merge") + 2]
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        path = os.path.join(root, "profiles", "traffic.json")
+        try:
+            allt = json.load(open(path))
+        except (OSError, ValueError):
+            allt = {}
+        allt[key] = {"hbm_gb_per_step": (rd + wr) / 1e9, "read_gb": rd / 1e9, "write_gb": wr / 1e9, "kernel_ms_per_step": ms,
+                     "profile": f"profiles/{tag}_summary.txt"}
+        json.dump(allt, open(path, "w"), indent=1)
+
