@@ -78,9 +78,9 @@ MF_D void mma_tile2(Carry& carry, const u32x4* hid0, const u32x4* hid1, const u3
 }
 
 // the pending tile's epilogue in slot m of an NM-slot tile: 16 steps (8 per block), none in slot 0 (the panel barrier) and none
-// in the last one
-MF_D constexpr int epi2_lo(int m, int nm) { const int e = nm - 2; return m < 1 ? 0 : (m - 1 >= e ? 16 : 16 * (m - 1) / e); }
-MF_D constexpr int epi2_hi(int m, int nm) { const int e = nm - 2; return m < 1 ? 0 : (m >= e ? 16 : 16 * m / e); }
+// in the last two (the next tile's bias reads)
+MF_D constexpr int epi2_lo(int m, int nm) { const int e = nm - 3; return m < 1 ? 0 : (m - 1 >= e ? 16 : 16 * (m - 1) / e); }
+MF_D constexpr int epi2_hi(int m, int nm) { const int e = nm - 3; return m < 1 ? 0 : (m >= e ? 16 : 16 * m / e); }
 
 // One trunk layer on both blocks: out[b] <- relu?(W_l [emb[b] ; act[b]] + bias).  MODE / TPP / RBT as trunk_layer_m; a per-ray
 // bias (LdsRayBias) is per block (the two blocks' samples sit on different rays).
@@ -95,7 +95,7 @@ MF_D void trunk_layer_m2(const Net& net, int layer, bool relu, const u32x4 (&act
   constexpr int groups = ((MODE & 1) ? (SPLIT ? 2 : 1) * NGE : 0) + ((MODE & 2) ? KH : 0);      // of one tile
   constexpr int pgroups = TPP * groups;
   constexpr int NM = tile2_slots<(MODE & 1) ? NGE : 0, (MODE & 2) ? KH : 0, SPLIT>();
-  constexpr int kInitSlot = NM / 2 >= 2 ? NM / 2 : 2;
+  constexpr int kInitSlot = NM - 2;                         // (earlier -- the middle of the tile -- holds 16-32 registers longer: 12-28 spilled, and measured nothing)
   const unsigned lo = relu ? 0u : 0x80008000u;
   uint32_t bias0 = net.res_lds + layer * (16 * KH) * 4, bias1 = bias0;
   if constexpr (RB) {
@@ -131,9 +131,7 @@ MF_D void trunk_layer_m2(const Net& net, int layer, bool relu, const u32x4 (&act
           else epi_pair(pend0, u >> 1, lo, out[0][2 * tp], out[0][2 * tp + 1]);
         }
       }
-      // the next tile's init vectors: read in the MIDDLE of this tile (the registers are free behind its first group) -- read two
-      // slots before the end, the four ds_reads' round trip stood in front of the next tile's first MFMA (timeline: +60-100
-      // cycles per tile with nobody else on the SIMD to fill them)
+      // the next tile's init vectors, into the registers the tile's first group freed
       if (t + 1 < NT) {
         if (m == kInitSlot) init0 = bias_acc(bias0 + 32 * (t + 1) * 4, id.h);
         if (RB && m == kInitSlot + 1) init1 = bias_acc(bias1 + 32 * (t + 1) * 4, id.h);
@@ -248,7 +246,7 @@ MF_D void extra_layer2(const Net& net, const u32x4 (&act)[2][16], const u32x4 (&
           else epi_pair(pend0, u >> 1, 0u, out[0][2 * tp], out[0][2 * tp + 1]);
         }
       }
-      if (m == NM / 2 && t + 1 < NT) init = bias_acc(bias_off + 32 * (t + 1) * 4, id.h);
+      if (m == NM - 2 && t + 1 < NT) init = bias_acc(bias_off + 32 * (t + 1) * 4, id.h);
     };
     mma_tile2<NGX, 16, false, false>(carry, act[0], act[1], ex[0], ex[1], ex[0], ex[1], p, pn, init, init, acc0, acc1, hook, piece, gap);
     pend0 = acc0; pend1 = acc1;

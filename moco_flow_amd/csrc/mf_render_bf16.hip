@@ -389,6 +389,12 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
         }
       }
       st.tl.stamp(3, id);
+      // The sample's depth goes to the group's LDS buffer NOW (nobody reads the slot before the group's barrier; one register less
+      // across the NeRF) -- and carries the poison: NaN / inf in the point the NeRF sees (a NaN ray; a NoF whose weights left the half
+      // range: mf_pack.hip's poison slot) must come OUT as NaN, but the integer-max ReLUs of these kernels turn a NaN with the sign
+      // bit set into 0 and a poisoned network would render finite garbage.  A NaN depth makes the composite's delta, alpha and
+      // every sum of the ray NaN.  (x * 0 is not folded: no fast-math in this unit.)
+      if (valid && id.h == 0) zbuf[srel] = z + (xin[0] + xin[1] + xin[2]) * 0.f;
       float sigma, rgb[3] = {0.f, 0.f, 0.f};
       auto extra_slots = [&](float (&ext)[8 * kKsExtraMax]) {
 #pragma unroll
@@ -447,18 +453,7 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
         st.tl.stamp(4, id);
         nerf_eval(p.nerf, xe, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb);
       }
-      {
-        // NaN / inf in the point the NeRF sees (a NaN ray; a NoF whose weights left the half range: mf_pack.hip's poison slot) must
-        // come OUT as NaN: the integer-max ReLUs of these kernels turn a NaN with the sign bit set into 0, so a poisoned network
-        // would otherwise render finite garbage.  (x * 0 is not folded: no fast-math in this unit.)
-        const float nanprop = (xin[0] + xin[1] + xin[2]) * 0.f;
-        sigma += nanprop;
-        rgb[0] += nanprop; rgb[1] += nanprop; rgb[2] += nanprop;
-      }
-      if (valid && id.h == 0) {
-        sbuf[srel] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
-        zbuf[srel] = z;
-      }
+      if (valid && id.h == 0) sbuf[srel] = make_float4(rgb[0], rgb[1], rgb[2], sigma);
       st.tl.stamp(5, id);
     }
     __syncthreads();
@@ -621,6 +616,9 @@ __global__ __launch_bounds__(256, 1) void render_kernel_bf16_2b(const Params p) 
         }
       }
       st.tl.stamp(3, id);
+#pragma unroll
+      for (int b = 0; b < 2; ++b)          // (depth to LDS now, carrying the NaN poison: see render_kernel_bf16)
+        if (valid[b] && id.h == 0) zbuf[srel[b]] = z[b] + (xin[b][0] + xin[b][1] + xin[b][2]) * 0.f;
       float sigma[2], rgb[2][3] = {{0.f, 0.f, 0.f}, {0.f, 0.f, 0.f}};
       u32x4 xe[2][kKsNerfXyz];
 #pragma unroll
@@ -646,13 +644,8 @@ __global__ __launch_bounds__(256, 1) void render_kernel_bf16_2b(const Params p) 
       st.tl.stamp(4, id);
       nerf_eval2(p.nerf, xe, make_extra, sigma_only, st, carry, id, prog_first, sigma, rgb);
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const float nanprop = (xin[b][0] + xin[b][1] + xin[b][2]) * 0.f;      // (NaN in -> NaN out: see render_kernel_bf16)
-        if (valid[b] && id.h == 0) {
-          sbuf[srel[b]] = make_float4(rgb[b][0] + nanprop, rgb[b][1] + nanprop, rgb[b][2] + nanprop, sigma[b] + nanprop);
-          zbuf[srel[b]] = z[b];
-        }
-      }
+      for (int b = 0; b < 2; ++b)
+        if (valid[b] && id.h == 0) sbuf[srel[b]] = make_float4(rgb[b][0], rgb[b][1], rgb[b][2], sigma[b]);
       st.tl.stamp(5, id);
     }
     __syncthreads();
@@ -736,6 +729,7 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void points_kernel
       }
     }
     float sigma, rgb[3] = {0.f, 0.f, 0.f};
+    const float nanprop = (x[0] + x[1] + x[2]) * 0.f;      // (NaN / inf in -> NaN out: see render_kernel_bf16)
     if constexpr (X3) {
       u32x4 xh[kKsNerfXyz], xl[kKsNerfXyz];
       {
@@ -761,7 +755,7 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void points_kernel
       };
       nerf_eval(p.nerf, xe, make_extra, true, st, carry, id, prog_first, sigma, rgb);
     }
-    if (valid && id.h == 0) p.sigma[b] = sigma + (x[0] + x[1] + x[2]) * 0.f;      // (NaN in -> NaN out: see render_kernel_bf16)
+    if (valid && id.h == 0) p.sigma[b] = sigma + nanprop;
   }
   wait_vm0();
 }
