@@ -28,7 +28,23 @@ dur = defaultdict(list)
 by_grid = defaultdict(lambda: defaultdict(list))        # kernel -> grid size -> durations
 for r in rows("trace/**/*kernel_trace.csv"):
     dur[r["Kernel_Name"]].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
-    by_grid[r["Kernel_Name"]][(r.get("Grid_Size"), r.get("LDS_Block_Size"))].append(dur[r["Kernel_Name"]][-1])
+    by_grid[r["Kernel_Name"]][(r.get("Grid_Size_X", r.get("Grid_Size")), r.get("LDS_Block_Size"))].append(dur[r["Kernel_Name"]][-1])
+
+
+def two_clusters(d):
+    """A kernel whose dispatches fall into two duration classes (coarse and fine pass of one call: same grid -- one workgroup per
+    CU -- and dynamic LDS the trace does not record): 2-means on log-duration; None when the spread is within a factor 1.6."""
+    import math
+    if len(d) < 4 or max(d) < 1.6 * min(d):
+        return None
+    lo, hi = math.log(min(d)), math.log(max(d))
+    for _ in range(20):
+        a = [x for x in d if abs(math.log(x) - lo) <= abs(math.log(x) - hi)]
+        b = [x for x in d if abs(math.log(x) - lo) > abs(math.log(x) - hi)]
+        if not a or not b:
+            return None
+        lo, hi = sum(math.log(x) for x in a) / len(a), sum(math.log(x) for x in b) / len(b)
+    return a, b
 dom = None
 if dur:
     dom = max(dur, key=lambda k: sum(dur[k]))
@@ -40,6 +56,12 @@ if dur:
         for (grid, lds), dd in sorted(by_grid[dom].items(), key=lambda kv: -sum(kv[1])):
             print(f"    grid {grid} lds {lds}: dispatches {len(dd)}  avg {sum(dd)/len(dd)/1e3:.1f} us  min {min(dd)/1e3:.1f}  max {max(dd)/1e3:.1f}"
                   f"  ({100.0*sum(dd)/sum(d):.0f} % of the kernel's time)")
+    else:
+        cl = two_clusters(d)
+        if cl:
+            for label, dd in (("short launches (coarse pass)", cl[0]), ("long launches (fine pass)", cl[1])):
+                print(f"    {label}: dispatches {len(dd)}  avg {sum(dd)/len(dd)/1e3:.1f} us  min {min(dd)/1e3:.1f}  max {max(dd)/1e3:.1f}"
+                      f"  ({100.0*sum(dd)/sum(d):.0f} % of the kernel's time)")
     r0 = next(r for r in rows("trace/**/*kernel_trace.csv") if r["Kernel_Name"] == dom)
     # registers / occupancy as the COMPILER reports them (profiles/kernel_resources.json, tools/kernel_resources.py); the
     # trace's VGPR_Count / Accum_VGPR_Count columns are the dispatch packet's allocation fields, not these numbers
@@ -56,8 +78,8 @@ if dur:
               f"waves/SIMD  scratch {res.get('ScratchSize')} B/lane  LDS {res.get('LDS Size')} B static  (VGPR spills {res.get('VGPRs Spill')})")
     else:
         print("  hipcc resource usage: not found in profiles/kernel_resources.json (run tools/kernel_resources.py)")
-    print("  dispatch packet: LDS", r0.get("LDS_Block_Size"), "scratch", r0.get("Scratch_Size"), "grid", r0.get("Grid_Size"),
-          "wg", r0.get("Workgroup_Size"))
+    print("  dispatch packet: LDS", r0.get("LDS_Block_Size"), "scratch", r0.get("Scratch_Size"), "grid", r0.get("Grid_Size_X", r0.get("Grid_Size")),
+          "wg", r0.get("Workgroup_Size_X", r0.get("Workgroup_Size")))
 print("\n== PMC (per dispatch of the dominant kernel, mean) ==")
 for sub in ("pmc_mfma", "pmc_fetch", "pmc_write", "pmc_wait"):
     acc = defaultdict(list)
@@ -111,6 +133,10 @@ if "FETCH_SIZE" in vals and "WRITE_SIZE" in vals:
         if len(by_grid[dom]) > 1:
             entry["by_grid"] = {str(g[0]): {"n": len(dd), "avg_us": sum(dd) / len(dd) / 1e3, "min_us": min(dd) / 1e3}
                                 for g, dd in by_grid[dom].items()}
+        elif two_clusters(d):
+            a, b = two_clusters(d)
+            entry["by_pass"] = {"coarse": {"n": len(a), "avg_us": sum(a) / len(a) / 1e3, "min_us": min(a) / 1e3},
+                                "fine": {"n": len(b), "avg_us": sum(b) / len(b) / 1e3, "min_us": min(b) / 1e3}}
     acc, pdur = defaultdict(list), []
     for r in rows("pmc_mfma/**/*counter_collection.csv"):
         if r["Kernel_Name"] == dom:
