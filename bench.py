@@ -813,7 +813,10 @@ def run_config(name, a, ctx, steps, warmup, main):
     if prof.get("rocprof_avg_us"):
         # (with a fine pass the trace's average runs over coarse AND fine dispatches of the same kernel, one of each per step:
         #  the step's algorithmic FLOP over launches x average)
-        rp.update({"frac_rocprof_avg": flops_step / (launches * prof["rocprof_avg_us"] * 1e-6) / 1e12 / peak, "rocprof_avg_us": prof["rocprof_avg_us"],
+        # (by_pass: tools/summarize_prof.py's split of the dominant kernel's dispatches into the coarse and the fine pass' launches)
+        bp = prof.get("by_pass")
+        step_us = (bp["coarse"]["avg_us"] + bp["fine"]["avg_us"]) if (bp and launches == 2) else launches * prof["rocprof_avg_us"]
+        rp.update({"frac_rocprof_avg": flops_step / (step_us * 1e-6) / 1e12 / peak, "rocprof_avg_us": prof["rocprof_avg_us"],
                    "mfma_busy": prof.get("mfma_busy"), "ghz": prof.get("ghz"), "profile": prof.get("profile")})
     res = {
         "value": value, "ms_per_step": elapsed / steps * 1e3, "dtype": cfg["precision"],
