@@ -30,6 +30,11 @@ def _gpu_run_selected(config):
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # A test that hangs (a rendezvous, a child process, a wedged launch) must fail, not hold the session until somebody's outer
+    # limit kills it with nothing reported: with pytest-timeout present (it is in this image) and no --timeout given, every test
+    # gets 900 s -- the slowest one takes ~3 min on a fresh box (hipcc builds of the deliberately broken kernels).
+    if config.pluginmanager.hasplugin("timeout") and not getattr(config.option, "timeout", None):
+        config.option.timeout = 900.0
     # MF_TEST_WGRAD=f32|bf16x3: run the whole session with that arithmetic of the weight-gradient contractions (the
     # gradient bars must hold in both; the package default is what a plain run tests)
     if os.environ.get("MF_TEST_TRAIN_FWD"):
