@@ -499,37 +499,6 @@ MF_D void trunk(const Net& net, int D, u32x4 (&a)[KH], const u32x4 (&xhi)[NGE], 
   }
 }
 
-// VALU head: NOUT dot products of the lane's half of the hidden vector (bf16, unpacked on the fly) with fp32
-// natural-order weight rows in LDS, summed across the two lane halves.  Element e of k-step s is feature
-// 16 s + (e&3) + 8 (e>>2) + 4 h: two 16-byte weight reads per step.
-// Rows are 16 KH floats long (compile time), so every read is ONE per-lane base register (w_byte_off + 16 h) plus an
-// immediate: runtime row lengths made hipcc hoist a separate address register per (row, step) to the kernel entry and
-// spill them all.
-template <int KH, int NOUT>
-MF_D void valu_head(const u32x4 (&act)[KH], uint32_t w_byte_off, uint32_t b_byte_off, int h, float (&out)[NOUT]) {
-  constexpr int row_floats = 16 * KH;
-  const uint32_t wl = w_byte_off + 16 * h;
-#pragma unroll
-  for (int o = 0; o < NOUT; ++o) {
-    float s0 = 0.f, s1 = 0.f;
-#pragma unroll
-    for (int s = 0; s < KH; ++s) {
-      const f32x4 wa = lds_f4(wl + (o * row_floats + 16 * s) * 4);
-      const f32x4 wb = lds_f4(wl + (o * row_floats + 16 * s + 8) * 4);
-      s0 = __builtin_fmaf(wa[0], bflo(act[s][0]), s0);
-      s1 = __builtin_fmaf(wa[1], bfhi(act[s][0]), s1);
-      s0 = __builtin_fmaf(wa[2], bflo(act[s][1]), s0);
-      s1 = __builtin_fmaf(wa[3], bfhi(act[s][1]), s1);
-      s0 = __builtin_fmaf(wb[0], bflo(act[s][2]), s0);
-      s1 = __builtin_fmaf(wb[1], bfhi(act[s][2]), s1);
-      s0 = __builtin_fmaf(wb[2], bflo(act[s][3]), s0);
-      s1 = __builtin_fmaf(wb[3], bfhi(act[s][3]), s1);
-    }
-    const float part = s0 + s1;
-    out[o] = part + __shfl_xor(part, 32, 64) + lds_f(b_byte_off + o * 4);
-  }
-}
-
 // ------------------------------------------------------------------ embedding in registers (two lane halves)
 // Embedding parameters live in LDS (par_off: freq[16] then weight[16], floats): this kernel keeps its SGPRs for
 // addresses.  dst[0..SLOTS) of block (C,F) for lane half h; arg = freq*x rounded to fp32 before sin/cos exactly as

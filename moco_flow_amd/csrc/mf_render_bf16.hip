@@ -65,11 +65,6 @@ struct RayBiasParams {
 };
 
 constexpr int kRbEntries = 8;       // entries (rays) per workgroup of nof_raybias_kernel
-#ifdef MF_AB_X3_HWSINCOS      // (timing-only A/B: the x3 passes' encodings from the transcendental unit -- WRONG results, prices the exact seeds)
-constexpr bool kX3ExactSincos = false;
-#else
-constexpr bool kX3ExactSincos = true;
-#endif
 constexpr int kFastBlocksDefault = 1; // column blocks per wave of the fast mode's render kernels (see render_pass_bf16)
 
 // grid (ceil(n_entries / 8), n_combos), 256 threads.  Thread (embedded layer, row) first requests its 33 index-column
@@ -346,7 +341,7 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
           const Next follow = last ? first_of<16, kKsNerfXyz, X3, NF0>(p.nerf) : first_of<8, kKsNofXyz, true, NP2, TN, NPH, NPS>(next_fw ? p.fw : p.bw);
           u32x4 nhi[kKsNofXyz], nmid[TN == 3 ? kKsNofXyz : 1], nlo[kKsNofXyz];
           float out[3];
-          if constexpr (X3) nof_embed_t<!kX3ExactSincos, TN, kNofHalfX3>(nhi, reinterpret_cast<u32x4(&)[kKsNofXyz]>(nmid), nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
+          if constexpr (X3) nof_embed_t<false, TN, kNofHalfX3>(nhi, reinterpret_cast<u32x4(&)[kKsNofXyz]>(nmid), nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
           else nof_embed<true>(nhi, nlo, cur, par_nof_xyz, id.h, p.pow2 & 4);
           auto stage_next = [&] {
             if (!last) stage_raybias<NW>(p, ray0 + tf, tn, role + 1 == 4 ? 1 : role + 1, p.rb_off + (uint32_t)(seq & 1) * p.rb_buf_bytes, id);
@@ -419,7 +414,7 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void render_kernel
           jitter();
           // exact seeds + doubling chains (<= 2e-6): the transcendental unit's 2e-4 rad at 512 x would sit above the
           // 2^-16 of the split operands
-          emb_eval<3, 10, !kX3ExactSincos>(embx, xin, par_nerf_xyz, id.h, p.pow2 & 1);
+          emb_eval<3, 10, false>(embx, xin, par_nerf_xyz, id.h, p.pow2 & 1);
           split_operands<kKsNerfXyz>(embx, B2Xyz10::SLOTS, xh, xl);
         }
         auto make_extra = [&](u32x4 (&eh)[kKsExtraMax], u32x4 (&el)[kKsExtraMax]) {
@@ -723,7 +718,7 @@ __global__ __launch_bounds__(X3 ? 256 : kThreads, X3 ? 1 : 2) void points_kernel
         nof_eval(p.bw, nhi, nlo, x, st, carry, id, nerf_first, out, rb, rbp, [] {});
       } else {
         LdsRayBias rb{p.rb_off};
-        if constexpr (X3) nof_embed_t<!kX3ExactSincos, TN, kNofHalfX3>(nhi, reinterpret_cast<u32x4(&)[kKsNofXyz]>(nmid), nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
+        if constexpr (X3) nof_embed_t<false, TN, kNofHalfX3>(nhi, reinterpret_cast<u32x4(&)[kKsNofXyz]>(nmid), nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
         else nof_embed<true>(nhi, nlo, x, par_nof_xyz, id.h, p.pow2 & 4);
         if constexpr (X3) nof_eval_x3<TN, kNofHalfX3>(p.bw, nhi, reinterpret_cast<const u32x4(&)[kKsNofXyz]>(nmid), nlo, x, st, carry, id, nerf_first, out, rb, [] {});
         else nof_eval(p.bw, nhi, nlo, x, st, carry, id, nerf_first, out, rb, nullptr, [] {});
@@ -920,7 +915,6 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
   // Several such ray sets per group (up to 8), as in the fp32 pass (mf_render.hip): the composite phase between two groups
   // keeps at most one wave per ray busy and costs two workgroup barriers, so it comes once per several tiles -- as long as the
   // CUs' shares stay what they were (same makespan in rays).
-#ifndef MF_AB_NO_GSETS
   {
     const long long cus = device_cus();
     auto makespan = [&](long long g) { const long long groups = (a->n_rays + g - 1) / g; return (groups + cus - 1) / cus * g; };
@@ -930,7 +924,6 @@ int render_pass_bf16(const mf_render_args* a, hipStream_t st, bool prepare_only)
       if ((long long)G * c * S <= max_samples && (long long)G * c <= 64 && makespan((long long)G * c) <= base) best = c;
     G *= best;
   }
-#endif
   p.G = G;
   p.n_groups = (a->n_rays + G - 1) / G;
   p.sbuf_off = lds; lds += (uint32_t)(G * S) * 16;
