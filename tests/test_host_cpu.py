@@ -823,6 +823,20 @@ def test_bench_last_stdout_line_is_compact(gpus):
     assert len(det) == 1 and json.loads(det[0][len("bench_detail "):])["roofline"]["from_profiles"] is not None
 
 
+def test_profile_summary_splits_coarse_and_fine_launches():
+    """tools/summarize_prof.py: the dispatches of ONE kernel that fall into two duration classes -- the coarse and
+    the fine pass of a render_rays call: same grid, dynamic LDS the trace does not record -- are reported per class, never as one
+    average; a kernel whose dispatches agree within a factor 1.6 is left alone."""
+    import re
+    src = open(os.path.join(ROOT, "tools", "summarize_prof.py")).read()
+    ns = {}
+    exec(re.search(r"def two_clusters\(d\):.*?return a, b\n", src, re.S).group(0), ns)
+    two = ns["two_clusters"]
+    a, b = two([850, 2520, 845, 2530, 2490, 860, 3500, 2510])
+    assert sorted(a) == [845, 850, 860] and len(b) == 5 and min(b) == 2490
+    assert two([318, 320, 330, 400, 298]) is None and two([100, 300]) is None
+
+
 def test_scripts_compile():
     """bench.py, __graft_entry__.py and every tools/*.py at least byte-compile (they only run on the GPU box)."""
     import glob
