@@ -1089,9 +1089,26 @@ def dryrun_worker(a, rank, world):
                                             "flat_gradient_bytes": 5300000}
         detail, compact = assemble(a, world, main_cfg, res, legs, extras)
         compact["dryrun"] = [tot[-1].tolist()[0], sig(float(t.item()), 2)]            # [reduced partial, elapsed s]
-        emit(detail, compact, world)
     if world > 1:
+        flush_c_stdio()
+        dist.barrier()
         dist.destroy_process_group()
+    flush_c_stdio()
+    if rank == 0:
+        emit(detail, compact, world)
+
+
+def flush_c_stdio():
+    """RCCL prints a version banner (five lines) through C stdio to STDOUT when its first communicator comes up; with stdout a pipe
+    that text sits in libc's buffer until the process exits -- i.e. it would land BEHIND the compact JSON line, and a driver that
+    parses the last stdout line would find "Librccl path : ..." there (seen in tests/rccl_child.py's log).  Flushing libc's
+    streams right after the communicator exists (every rank) and again before rank 0 prints keeps the JSON line last."""
+    try:
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+    except Exception:  # noqa: BLE001  (no libc handle: nothing buffered through it either)
+        pass
+    sys.stdout.flush()
 
 
 def ranks_seen(torch, dist, dev):
@@ -1104,6 +1121,7 @@ def ranks_seen(torch, dist, dev):
     dist.all_reduce(ones, op=dist.ReduceOp.SUM)
     v = ones.cpu().tolist()
     assert all(x == v[0] for x in v), v
+    flush_c_stdio()                         # (the communicator exists now: RCCL's banner leaves libc's buffer here, not at exit)
     return int(v[0])
 
 
@@ -1120,8 +1138,12 @@ def worker(a):
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
-    if world > 1:
+    # (MF_BENCH_FORCE_DIST=1: a process group at world size 1 too -- the GPU test of the reporting channel under a REAL RCCL communicator)
+    if world > 1 or os.environ.get("MF_BENCH_FORCE_DIST"):
         import torch.distributed as dist
+        os.environ.setdefault("MASTER_PORT", str(_free_port()))
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         backend = os.environ.get("MF_BENCH_BACKEND", "nccl")           # "nccl" IS RCCL on ROCm; "gloo": control-flow tests only
         if backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=dev)
@@ -1153,11 +1175,16 @@ def worker(a):
             extras["train_joint_dp"] = train_dp_leg(M, synth, torch, dev, dist, rank, world)
         else:
             extras["aux"] = aux_legs(M, synth, torch, dev)
+    # the compact line must be the LAST thing on stdout: every rank empties libc's buffers, all meet, the group goes down (whatever
+    # that prints comes first), and only then rank 0 prints
+    if dist is not None:
+        flush_c_stdio()
+        dist.barrier()
+        dist.destroy_process_group()
+    flush_c_stdio()
     if rank == 0:
         detail, compact = assemble(a, world, main_cfg, res, leg_results, extras)
         emit(detail, compact, world)
-    if dist is not None:
-        dist.destroy_process_group()
 
 
 def main():

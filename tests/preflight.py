@@ -11,7 +11,10 @@ for it before its first GPU test, so the children never share the device with a 
      loss-partials all-reduce, MAX-over-ranks timing), both ranks on GPU 0 (the first 8-GPU driver run must not be the
      first execution of that code).
 
-usage: preflight.py <outdir>   ->   <outdir>/{rccl.log, bench2.log, status.json}"""
+  3. `bench.py --steps 3 --warmup 1` (main line only) with MF_BENCH_FORCE_DIST=1: a 1-rank RCCL process group around the run, stdout kept
+     apart -- RCCL's version banner goes through C stdio to stdout and must not land behind the compact JSON line.
+
+usage: preflight.py <outdir>   ->   <outdir>/{rccl.log, bench2.log, bench1d.out, bench1d.log, status.json}"""
 import json
 import os
 import subprocess
@@ -41,6 +44,16 @@ def main():
     benv = dict(env, MF_BENCH_SHARE_GPU="1", MF_BENCH_BACKEND="gloo")
     status["bench2"] = run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1"],
                            os.path.join(out, "bench2.log"), benv, 420)
+    # 3. the reporting channel under a REAL RCCL communicator: bench.py with a 1-rank "nccl" group (MF_BENCH_FORCE_DIST), stdout alone
+    #    in its own file -- RCCL prints its version banner through C stdio to stdout, and the compact JSON line must still be last
+    denv = dict(env, MF_BENCH_FORCE_DIST="1")
+    with open(os.path.join(out, "bench1d.out"), "w") as fo, open(os.path.join(out, "bench1d.log"), "w") as fe:
+        try:
+            status["bench1d"] = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "3", "--warmup", "1", "--no-extra-legs",
+                                                "--no-cpu-baseline", "--no-train-leg"], stdout=fo, stderr=fe, env=denv, cwd=ROOT, timeout=240).returncode
+        except subprocess.TimeoutExpired:
+            fe.write("\nTIMEOUT after 240 s\n")
+            status["bench1d"] = -9
     with open(os.path.join(out, "status.json"), "w") as fh:
         json.dump(status, fh)
 

@@ -268,6 +268,22 @@ def test_bench_two_ranks_real_worker_path(preflight):
     assert np.isfinite(dp["ms_per_step_local"]) and np.isfinite(dp["ms_per_step_allreduce"]) and dp["ms_per_step_allreduce"] > 0
 
 
+def test_bench_json_line_is_last_on_stdout_under_rccl(preflight):
+    """Round 6: RCCL prints a five-line version banner through C stdio to STDOUT when its first communicator comes up; in a pipe that
+    text sits in libc's buffer until exit and used to land BEHIND the JSON line (visible in rccl_child's log) -- a driver parsing the
+    last stdout line of an N > 1 run would have read "Librccl path : ...".  bench.py now flushes libc's streams once the communicator
+    exists and prints only after the group is down.  Checked on the real thing: bench.py under a 1-rank "nccl" group
+    (MF_BENCH_FORCE_DIST), stdout alone in a file."""
+    assert preflight, "conftest.py did not start tests/preflight.py (MF_NO_PREFLIGHT set?)"
+    assert preflight["status"].get("bench1d") == 0, (preflight["status"], open(os.path.join(preflight["dir"], "bench1d.log")).read()[-3000:])
+    out = open(os.path.join(preflight["dir"], "bench1d.out")).read()
+    lines = [ln for ln in out.splitlines() if ln.strip()]
+    print(out[-2500:])
+    d = json.loads(lines[-1])                                  # the LAST non-empty stdout line is the compact object
+    assert len(lines[-1].encode()) <= 1800 and d["n_gpus"] == 1 and d["rccl_ranks_seen"] == 1 and d["value"] > 0
+    assert any("RCCL version" in ln for ln in lines[:-1]), "expected RCCL's banner in front of the JSON line (did the runtime stop printing it?)"
+
+
 def test_lazy_consensus_vectors(M):
     """The consensus vectors as lazy.MaskedVector (moco_flow_amd/lazy.py): what the unchanged trainer does with them --
     torch.mean(res["nof_local_disp_coarse"]) (trainer_moco_flow.py:317-328) -- involves no compaction and NO host
