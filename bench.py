@@ -988,12 +988,11 @@ def emit(detail, compact, world):
     """Detail first (side file + ONE stderr line that does not start with '{'), then the compact line LAST on stdout."""
     blob = json.dumps(detail)
     try:
-        if compact.get("dryrun"):
-            raise OSError("dry run: no side file")
-        out = os.path.join(ROOT, "gpurun_out")
-        os.makedirs(out, exist_ok=True)
-        with open(os.path.join(out, "bench_detail_n%d.json" % world), "w") as fh:
-            fh.write(blob + "\n")
+        if not compact.get("dryrun"):            # (a dry run leaves the real runs' side files alone)
+            out = os.path.join(ROOT, "gpurun_out")
+            os.makedirs(out, exist_ok=True)
+            with open(os.path.join(out, "bench_detail_n%d.json" % world), "w") as fh:
+                fh.write(blob + "\n")
     except OSError as exc:
         print(f"bench_detail: could not write the side file ({exc})", file=sys.stderr)
     print("bench_detail " + blob, file=sys.stderr, flush=True)

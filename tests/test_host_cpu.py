@@ -823,6 +823,30 @@ def test_bench_last_stdout_line_is_compact(gpus):
     assert len(det) == 1 and json.loads(det[0][len("bench_detail "):])["roofline"]["from_profiles"] is not None
 
 
+def test_bench_under_torch_distributed_run():
+    """The driver's N > 1 launch line -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ...` -- with MF_BENCH_DRYRUN (gloo, CPU): ranks from the launcher's environment (no
+    self-spawn), the compact object as the LAST stdout line."""
+    import json
+    import socket
+    import subprocess
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, MF_BENCH_DRYRUN="1")
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "2"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    last = [ln for ln in r.stdout.splitlines() if ln.strip()][-1]
+    d = json.loads(last)
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["warmup"] == 2 and d["rccl_ranks_seen"] == 2 and d["config"]["main_has_collective"] is True
+    assert d["dryrun"][0] == 3.0 and len(last.encode()) <= 1800
+
+
 def test_profile_summary_splits_coarse_and_fine_launches():
     """tools/summarize_prof.py: the dispatches of ONE kernel that fall into two duration classes -- the coarse and
     the fine pass of a render_rays call: same grid, dynamic LDS the trace does not record -- are reported per class, never as one
